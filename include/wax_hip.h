@@ -1,0 +1,215 @@
+/*
+ * wax_hip.h — C ABI of libwaxhip: the MI355X (gfx950 / CDNA4) brute-force vector
+ * scan + top-k backend for Wax's `VectorSearchEngine`.
+ *
+ * This is the drop-in boundary. Every entry point replaces one
+ * member of the reference's Swift surface; the reference file:line it stands in
+ * for is cited on each declaration (paths relative to the reference checkout).
+ * A Swift `actor HIPVectorEngine: VectorSearchEngine` binds these through a
+ * module map; Python binds them with ctypes
+ * (wax_amd/_abi.py); C++ callers can use include/wax_hip.hpp.
+ *
+ * Conventions
+ *   - plain C types only; no torch / HIP types in any signature
+ *     (`void* stream` is a hipStream_t passed opaquely, NULL = engine's own)
+ *   - return 0 (WAX_HIP_OK) or a negative wax_hip_status; the message is in
+ *     wax_hip_last_error() (thread-local)
+ *   - the caller owns every in/out array; buffers returned by
+ *     wax_hip_serialize() are released with wax_hip_free()
+ *   - search* calls are re-entrant (shared lock + per-call scratch slot),
+ *     mutations take the exclusive lock — the same reader/writer contract as
+ *     the reference's AsyncReadWriteLock (MetalVectorEngine.swift:56-81)
+ *   - there is NO CPU fallback in this library: without a gfx950 device every
+ *     engine call fails with WAX_HIP_ERR_NO_DEVICE.
+ */
+#ifndef WAX_HIP_H
+#define WAX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WAX_HIP_ABI_VERSION 1
+
+/* MetalVectorEngine.maxResults (MetalVectorEngine.swift:18) */
+#define WAX_HIP_MAX_RESULTS 10000
+/* Constants.maxEmbeddingDimensions (WaxCore/Constants.swift:51) */
+#define WAX_HIP_MAX_DIMENSIONS 1000000
+/* MetalVectorEngine.initialReserve (MetalVectorEngine.swift:19) */
+#define WAX_HIP_INITIAL_RESERVE 64
+
+typedef struct wax_hip_engine wax_hip_engine;
+
+/* Maps 1:1 onto the WaxError cases the Metal engine throws
+ * (MetalVectorEngine.swift:154-169, 830-840, 858-860; WaxError.swift:4-18). */
+typedef enum wax_hip_status {
+    WAX_HIP_OK = 0,
+    WAX_HIP_ERR_DIM_MISMATCH = -1,      /* WaxError.encodingError("vector dimension mismatch: expected X, got Y") */
+    WAX_HIP_ERR_CAPACITY = -2,          /* WaxError.capacityExceeded(limit:requested:) */
+    WAX_HIP_ERR_NO_DEVICE = -3,         /* WaxError.invalidToc("... device not available") */
+    WAX_HIP_ERR_ALLOC = -4,             /* WaxError.invalidToc("Failed to allocate ...") */
+    WAX_HIP_ERR_BAD_SEGMENT = -5,       /* WaxError.invalidToc(<segment decode reason>) */
+    WAX_HIP_ERR_METRIC_UNSUPPORTED = -6,
+    WAX_HIP_ERR_INVALID_ARGUMENT = -7,  /* WaxError.encodingError / invalidToc("dimensions must be > 0") */
+    WAX_HIP_ERR_INTERNAL = -8
+} wax_hip_status;
+
+/* VecSimilarity raw values (WaxCore/FileFormat/MV2SEnums.swift:34-38) ==
+ * VectorMetric cases (VectorMetric.swift:5-8). */
+typedef enum wax_hip_metric {
+    WAX_HIP_METRIC_COSINE = 0,
+    WAX_HIP_METRIC_DOT = 1,
+    WAX_HIP_METRIC_L2 = 2
+} wax_hip_metric;
+
+/* One ranked candidate as it lives in HBM and travels over RCCL between shards.
+ * key = (int64)ordered(distance_f32) << 32 | global_row_u32, where ordered()
+ * is the sign-magnitude -> two's-complement monotone map, so that a SIGNED
+ * 64-bit ascending sort is exactly "(distance asc, row asc)" — the tie rule
+ * SURVEY.md §8c adopts from MetalVectorEngine.topK's earlier-index-wins
+ * boundary (MetalVectorEngine.swift:671). Replaces the reference's
+ * TopKEntry{float distance; uint index} (TopKReduction.metal:15-18,
+ * MetalVectorEngine.swift:26-29) plus the frameIds[index] lookup (:601). */
+typedef struct wax_hip_hit {
+    int64_t key;
+    uint64_t frame_id;
+} wax_hip_hit;
+
+/* Counters; superset of MetalVectorEngine.BufferPoolStats
+ * (MetalVectorEngine.swift:43-46, 119-121). */
+typedef struct wax_hip_stats_t {
+    uint64_t searches;             /* single-query scans issued */
+    uint64_t rows_scanned;         /* sum of rows visited by those scans */
+    uint64_t bytes_scanned;        /* algorithmic bytes: rows * dims * 4 */
+    uint64_t transient_allocations;/* scratch slots created (BufferPoolStats.transientAllocations) */
+    uint64_t reuse_count;          /* scratch slot reuses (BufferPoolStats.reuseCount) */
+    uint64_t reserved_rows;        /* current capacity in rows (reservedCapacity) */
+    double   last_scan_kernel_ms;  /* HIP-event time of the most recent timed scan kernel (0 if timing off) */
+    double   scan_kernel_ms_total; /* sum of HIP-event scan-kernel times since "reset_stats" ("time_kernels"=1) */
+    uint64_t scan_kernels_timed;   /* number of scan-kernel launches in that sum */
+} wax_hip_stats_t;
+
+/* ---- availability ------------------------------------------------------- */
+
+/* MetalVectorEngine.isAvailable (MetalVectorEngine.swift:144-146): 1 iff a gfx950 device is visible. */
+int wax_hip_available(void);
+int wax_hip_device_count(void);
+uint32_t wax_hip_abi_version(void);
+/* thread-local, never NULL */
+const char* wax_hip_last_error(void);
+
+/* ---- lifecycle ---------------------------------------------------------- */
+
+/* MetalVectorEngine.init(metric:dimensions:) (MetalVectorEngine.swift:153-274).
+ * metric: wax_hip_metric (the Metal engine accepts only cosine, :163-165; this
+ * backend also implements dot and l2 with USearch's distance conventions,
+ * VectorMetric.swift:21-43). device_id: HIP ordinal, -1 = current device. */
+int wax_hip_engine_create(uint8_t metric, uint32_t dims, int device_id, wax_hip_engine** out);
+void wax_hip_engine_destroy(wax_hip_engine* e);
+
+/* VectorSearchEngine.dimensions (VectorSearchEngine.swift:11) */
+uint32_t wax_hip_dimensions(const wax_hip_engine* e);
+/* vectorCount (MetalVectorEngine.swift:51) */
+uint64_t wax_hip_count(const wax_hip_engine* e);
+uint8_t wax_hip_metric_of(const wax_hip_engine* e);
+int wax_hip_device_of(const wax_hip_engine* e);
+
+/* ---- store mutation (exclusive lock) ------------------------------------ */
+
+/* add(frameId:vector:) — upsert by frame id (MetalVectorEngine.swift:330-357). */
+int wax_hip_add(wax_hip_engine* e, uint64_t frame_id, const float* vector, uint32_t dims);
+/* addBatch(frameIds:vectors:) (MetalVectorEngine.swift:359-402); rows is row-major n x dims.
+ * addBatchStreaming (:404-421) is the same call made in chunks by the caller. */
+int wax_hip_add_batch(wax_hip_engine* e, const uint64_t* frame_ids, const float* rows, uint64_t n, uint32_t dims);
+/* Same, but `rows` is a DEVICE pointer on the engine's device (embeddings that
+ * were produced in HBM never bounce through the host). frame_ids stays a host
+ * pointer. All ids must be new (append-only fast path); WAX_HIP_ERR_INVALID_ARGUMENT otherwise. */
+int wax_hip_add_batch_device(wax_hip_engine* e, const uint64_t* frame_ids, const float* d_rows, uint64_t n, uint32_t dims);
+/* remove(frameId:) — order-preserving delete, absent id is a no-op (MetalVectorEngine.swift:423-444). */
+int wax_hip_remove(wax_hip_engine* e, uint64_t frame_id);
+/* reserveIfNeeded(for:) (MetalVectorEngine.swift:857-871): capacity doubling from 64, cap UInt32.max rows. */
+int wax_hip_reserve(wax_hip_engine* e, uint64_t rows);
+
+/* ---- search (shared lock, re-entrant) ----------------------------------- */
+
+/* VectorSearchEngine.search(vector:topK:) (VectorSearchEngine.swift:13;
+ * MetalVectorEngine.swift:446-627). Blocking. out_ids/out_scores must hold
+ * min(clamp(top_k,1,10000), count) entries; *out_count receives how many were
+ * written (best first: descending score == ascending distance, ties by
+ * ascending row). Empty engine => OK with *out_count = 0 (:448). */
+int wax_hip_search(wax_hip_engine* e, const float* query, uint32_t dims, int32_t top_k,
+                   uint64_t* out_ids, float* out_scores, uint32_t* out_count);
+
+/* Pipelined form of the same call: submit enqueues H2D + kernels + D2H on one
+ * of the engine's scratch slots and returns immediately with a ticket;
+ * collect blocks on that slot and fills the outputs exactly like
+ * wax_hip_search. Tickets must be collected exactly once, in any order. */
+int wax_hip_search_submit(wax_hip_engine* e, const float* query, uint32_t dims, int32_t top_k, uint64_t* out_ticket);
+int wax_hip_search_collect(wax_hip_engine* e, uint64_t ticket,
+                           uint64_t* out_ids, float* out_scores, uint32_t* out_count);
+
+/* nq queries, row-major nq x dims. out_ids/out_scores are nq x kcap where
+ * kcap = min(clamp(top_k), count); out_counts[nq]. */
+int wax_hip_search_batch(wax_hip_engine* e, const float* queries, uint32_t nq, uint32_t dims, int32_t top_k,
+                         uint64_t* out_ids, float* out_scores, uint32_t* out_counts);
+
+/* ---- sharded search: per-shard top-k left in HBM for the RCCL exchange ---- */
+
+/* Declares that this engine holds rows [row_base, row_base+count) of a corpus
+ * that is row-sharded over several engines/GPUs. row_base is
+ * folded into wax_hip_hit.key so ties break by GLOBAL row on every shard count. */
+int wax_hip_set_row_base(wax_hip_engine* e, uint64_t row_base);
+/* Scan this shard for one query and write exactly kpad = clamp(top_k) hits,
+ * sorted ascending by key, to the DEVICE buffer d_out_hits (entries past the
+ * shard's own count are padded with key = INT64_MAX, frame_id = UINT64_MAX).
+ * Work is enqueued on `stream` (a hipStream_t; NULL = the null stream) and NOT
+ * synchronised: the caller all-gathers d_out_hits over RCCL on the same stream
+ * order and then calls wax_hip_merge_hits_device. top_k must be <= 192 here. */
+int wax_hip_search_shard_device(wax_hip_engine* e, const float* query, uint32_t dims, int32_t top_k,
+                                wax_hip_hit* d_out_hits, void* stream);
+/* Stateless G*k -> k merge of gathered shard results on the current device:
+ * d_out receives the k smallest keys of d_in[0..n), ascending. n <= 16384. */
+int wax_hip_merge_hits_device(const wax_hip_hit* d_in, uint32_t n, uint32_t k, wax_hip_hit* d_out, void* stream);
+/* Host-side tail of search (MetalVectorEngine.swift:592-611 + VectorMetric.swift:32-43):
+ * drop padded / non-finite entries, distance -> score, emit (frameId, score). */
+int wax_hip_hits_to_results(uint8_t metric, const wax_hip_hit* hits, uint32_t n,
+                            uint64_t* out_ids, float* out_scores, uint32_t* out_count);
+
+/* ---- persistence: "MV2V" vec segment, encoding 2 ------------------------- */
+
+/* serialize() (MetalVectorEngine.swift:682-714): byte-identical layout
+ * "MV2V" u16 ver=1 u8 enc=2 u8 similarity u32 dim u64 count u64 vectorBytes 8x0
+ * | count*dim f32 LE | u64 idBytes | count u64 LE. */
+int wax_hip_serialize(wax_hip_engine* e, uint8_t** out_bytes, size_t* out_len);
+/* deserialize(_:) (MetalVectorEngine.swift:716-815), same validation order and reasons. */
+int wax_hip_deserialize(wax_hip_engine* e, const uint8_t* bytes, size_t len);
+void wax_hip_free(void* p);
+
+/* ---- observability / tuning --------------------------------------------- */
+
+int wax_hip_stats(wax_hip_engine* e, wax_hip_stats_t* out);
+/* Tunables (all optional): "grid_blocks" (0 = auto), "variant" (scan kernel
+ * variant index, -1 = auto), "time_kernels" (1 = bracket the scan kernel with
+ * HIP events on its own stream and report last_scan_kernel_ms),
+ * "slots" (scratch-slot pool size), "force_general" (1 = use the
+ * distance-buffer + radix-select path even for small k), "stream_nt",
+ * "reset_stats" (any value: zero the counters). get-only: "variant_count",
+ * "scan_grid", "fused_max_k". */
+int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value);
+int64_t wax_hip_get_tuning(wax_hip_engine* e, const char* key);
+/* Times `iters` back-to-back launches of ONLY the scan kernel for `query`
+ * with HIP events on the engine's stream; returns average ms per launch.
+ * This is what bench.py's roofline.achieved is computed from. */
+int wax_hip_time_scan_kernel(wax_hip_engine* e, const float* query, uint32_t dims, int32_t top_k,
+                             uint32_t iters, double* out_avg_ms);
+/* Pure streaming-read microbenchmark over the engine's own store (sum of all
+ * float4s, no top-k): the node's achievable read bandwidth for this layout. */
+int wax_hip_time_stream_read(wax_hip_engine* e, uint32_t iters, double* out_avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WAX_HIP_H */

@@ -1,0 +1,281 @@
+"""CPU oracle for the Wax vector scan + top-k path — TEST INFRASTRUCTURE ONLY.
+
+Thin ctypes binding over ``oracle/wax_oracle.c`` (the C restatement of the
+reference's arithmetic; every C function cites the reference file:line it
+follows) plus the seeded synthetic-input generators SURVEY.md §8d prescribes.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this package, and only as the checker / reported baseline. The
+product (``wax_amd``) never imports it and has no CPU fallback.
+
+Pinning: rank/membership/tolerance cases from the reference's own tests are
+pinned through ``tests/golden/reference_cases.json``; the numeric USearch
+boundary is *parity unpinned* (see the header of ``wax_oracle.c``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from typing import Optional, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libwaxoracle.so")
+
+METRIC_COSINE, METRIC_DOT, METRIC_L2 = 0, 1, 2
+MODE_TRUTH_F64, MODE_METAL_F32 = 0, 1
+
+# SURVEY.md §8d seeds
+CORPUS_SEED = 20260220
+QUERY_SEED = 7
+
+
+def build(force: bool = False) -> str:
+    """Compile the C oracle with gcc (recipe: oracle/Makefile)."""
+    src = os.path.join(_HERE, "wax_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", _HERE, "-s", "CC=gcc"], check=True)
+    return _LIB_PATH
+
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = ctypes.CDLL(_LIB_PATH)
+        f32p = ctypes.POINTER(ctypes.c_float)
+        u64p = ctypes.POINTER(ctypes.c_uint64)
+        i64p = ctypes.POINTER(ctypes.c_int64)
+        u8p = ctypes.POINTER(ctypes.c_uint8)
+        L.wax_oracle_clamp_topk.restype = ctypes.c_int32
+        L.wax_oracle_clamp_topk.argtypes = [ctypes.c_int64]
+        L.wax_oracle_score_from_distance.restype = ctypes.c_float
+        L.wax_oracle_score_from_distance.argtypes = [ctypes.c_int, ctypes.c_float]
+        L.wax_oracle_magnitude.restype = ctypes.c_float
+        L.wax_oracle_magnitude.argtypes = [f32p, ctypes.c_uint32]
+        L.wax_oracle_normalize_l2.restype = None
+        L.wax_oracle_normalize_l2.argtypes = [f32p, ctypes.c_uint32, f32p]
+        L.wax_oracle_is_normalized_l2.restype = ctypes.c_int
+        L.wax_oracle_is_normalized_l2.argtypes = [f32p, ctypes.c_uint32, ctypes.c_float]
+        L.wax_oracle_cosine_distances_metal.restype = None
+        L.wax_oracle_cosine_distances_metal.argtypes = [f32p, f32p, ctypes.c_uint64, ctypes.c_uint32, f32p]
+        L.wax_oracle_distances_f64.restype = None
+        L.wax_oracle_distances_f64.argtypes = [ctypes.c_int, f32p, f32p, ctypes.c_uint64, ctypes.c_uint32, f32p]
+        for name in ("wax_oracle_topk_heap", "wax_oracle_topk_sort", "wax_oracle_topk_total"):
+            fn = getattr(L, name)
+            fn.restype = ctypes.c_int64
+            fn.argtypes = [f32p, ctypes.c_int64, ctypes.c_int64, i64p, f32p]
+        L.wax_oracle_search.restype = ctypes.c_int64
+        L.wax_oracle_search.argtypes = [ctypes.c_int, ctypes.c_int, f32p, u64p, ctypes.c_uint64, ctypes.c_uint32,
+                                        f32p, ctypes.c_uint32, ctypes.c_int64, u64p, f32p, f32p, i64p]
+        L.wax_oracle_max_threads.restype = ctypes.c_int
+        L.wax_oracle_scan_topk_mt.restype = ctypes.c_int64
+        L.wax_oracle_scan_topk_mt.argtypes = [ctypes.c_int, f32p, ctypes.c_uint64, ctypes.c_uint32, f32p,
+                                              ctypes.c_int64, ctypes.c_int, i64p, f32p]
+        L.wax_oracle_mv2v_size.restype = ctypes.c_uint64
+        L.wax_oracle_mv2v_size.argtypes = [ctypes.c_uint64, ctypes.c_uint32]
+        L.wax_oracle_mv2v_serialize.restype = ctypes.c_uint64
+        L.wax_oracle_mv2v_serialize.argtypes = [ctypes.c_int, f32p, u64p, ctypes.c_uint64, ctypes.c_uint32, u8p]
+        L.wax_oracle_mv2v_parse.restype = ctypes.c_int
+        L.wax_oracle_mv2v_parse.argtypes = [u8p, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint32, u64p, u64p, u64p]
+        L.wax_oracle_deterministic_embed.restype = None
+        L.wax_oracle_deterministic_embed.argtypes = [u8p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int, f32p]
+        L.wax_oracle_tie_pattern.restype = None
+        L.wax_oracle_tie_pattern.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, f32p]
+        _lib = L
+    return _lib
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a: np.ndarray, t):
+    return a.ctypes.data_as(ctypes.POINTER(t))
+
+
+# --------------------------------------------------------------------------
+# reference-semantics helpers
+
+def clamp_topk(top_k: int) -> int:
+    return int(lib().wax_oracle_clamp_topk(int(top_k)))
+
+
+def score_from_distance(metric: int, d: float) -> float:
+    return float(lib().wax_oracle_score_from_distance(metric, ctypes.c_float(d)))
+
+
+def normalize_l2(v) -> np.ndarray:
+    v = _f32(v)
+    out = np.empty_like(v)
+    lib().wax_oracle_normalize_l2(_p(v, ctypes.c_float), v.size, _p(out, ctypes.c_float))
+    return out
+
+
+def is_normalized_l2(v, tolerance: float = 1e-3) -> bool:
+    v = _f32(v)
+    return bool(lib().wax_oracle_is_normalized_l2(_p(v, ctypes.c_float), v.size, ctypes.c_float(tolerance)))
+
+
+def distances(metric: int, vectors, query, mode: int = MODE_TRUTH_F64) -> np.ndarray:
+    vectors = _f32(vectors)
+    query = _f32(query)
+    n, d = vectors.shape
+    out = np.empty(n, dtype=np.float32)
+    if mode == MODE_METAL_F32:
+        assert metric == METRIC_COSINE
+        lib().wax_oracle_cosine_distances_metal(_p(vectors, ctypes.c_float), _p(query, ctypes.c_float), n, d,
+                                                _p(out, ctypes.c_float))
+    else:
+        lib().wax_oracle_distances_f64(metric, _p(vectors, ctypes.c_float), _p(query, ctypes.c_float), n, d,
+                                       _p(out, ctypes.c_float))
+    return out
+
+
+def topk_heap(dist, k: int, use_sort: bool = False, total: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+    """Reference heap (default), full (distance,index) sort (use_sort) or total-order heap (total)."""
+    dist = _f32(dist)
+    m = max(0, min(int(k), dist.size))
+    idx = np.empty(max(m, 1), dtype=np.int64)
+    dd = np.empty(max(m, 1), dtype=np.float32)
+    fn = lib().wax_oracle_topk_sort if use_sort else (lib().wax_oracle_topk_total if total else lib().wax_oracle_topk_heap)
+    got = fn(_p(dist, ctypes.c_float), dist.size, int(k), _p(idx, ctypes.c_int64), _p(dd, ctypes.c_float))
+    return idx[:got].copy(), dd[:got].copy()
+
+
+class DimensionMismatch(Exception):
+    pass
+
+
+def search(metric: int, vectors, frame_ids, query, top_k: int, mode: int = MODE_TRUTH_F64):
+    """Oracle for VectorSearchEngine.search(vector:topK:).
+
+    Returns (frame_ids u64[m], scores f32[m], distances f32[m], rows i64[m]),
+    best first under (distance asc, row asc).
+    """
+    vectors = _f32(vectors)
+    query = _f32(query)
+    if vectors.ndim != 2:
+        raise ValueError("vectors must be [n, d]")
+    n, d = vectors.shape
+    ids = None if frame_ids is None else np.ascontiguousarray(frame_ids, dtype=np.uint64)
+    cap = max(1, min(clamp_topk(top_k), max(n, 1)))
+    out_ids = np.empty(cap, dtype=np.uint64)
+    out_scores = np.empty(cap, dtype=np.float32)
+    out_d = np.empty(cap, dtype=np.float32)
+    out_rows = np.empty(cap, dtype=np.int64)
+    got = lib().wax_oracle_search(metric, mode, _p(vectors, ctypes.c_float),
+                                  None if ids is None else _p(ids, ctypes.c_uint64), n, d,
+                                  _p(query, ctypes.c_float), query.size, int(top_k),
+                                  _p(out_ids, ctypes.c_uint64), _p(out_scores, ctypes.c_float),
+                                  _p(out_d, ctypes.c_float), _p(out_rows, ctypes.c_int64))
+    if got < 0:
+        raise DimensionMismatch(f"vector dimension mismatch: expected {d}, got {query.size}")
+    return out_ids[:got].copy(), out_scores[:got].copy(), out_d[:got].copy(), out_rows[:got].copy()
+
+
+def max_threads() -> int:
+    return int(lib().wax_oracle_max_threads())
+
+
+def scan_topk_mt(metric: int, vectors, query, top_k: int, threads: int):
+    """The timed CPU baseline: f32 scan + per-thread heaps + merge."""
+    vectors = _f32(vectors)
+    query = _f32(query)
+    n, d = vectors.shape
+    cap = max(1, min(clamp_topk(top_k), max(n, 1)))
+    idx = np.empty(cap, dtype=np.int64)
+    dd = np.empty(cap, dtype=np.float32)
+    got = lib().wax_oracle_scan_topk_mt(metric, _p(vectors, ctypes.c_float), n, d, _p(query, ctypes.c_float),
+                                        int(top_k), int(threads), _p(idx, ctypes.c_int64), _p(dd, ctypes.c_float))
+    return idx[:got].copy(), dd[:got].copy()
+
+
+def mv2v_serialize(metric: int, vectors, frame_ids) -> bytes:
+    vectors = _f32(vectors)
+    ids = np.ascontiguousarray(frame_ids, dtype=np.uint64)
+    if vectors.ndim == 1:
+        raise ValueError("vectors must be [n, d]")
+    n, d = vectors.shape
+    size = int(lib().wax_oracle_mv2v_size(n, d))
+    buf = np.empty(size, dtype=np.uint8)
+    wrote = lib().wax_oracle_mv2v_serialize(metric, _p(vectors, ctypes.c_float), _p(ids, ctypes.c_uint64), n, d,
+                                            _p(buf, ctypes.c_uint8))
+    assert wrote == size
+    return buf.tobytes()
+
+
+def mv2v_parse(data: bytes, expect_metric: int = -1, expect_dims: int = 0):
+    """Returns (err_code, vectors or None, frame_ids or None). err_code 0 = ok."""
+    arr = np.frombuffer(data, dtype=np.uint8)
+    arr = np.ascontiguousarray(arr)
+    count = ctypes.c_uint64(0)
+    voff = ctypes.c_uint64(0)
+    ioff = ctypes.c_uint64(0)
+    if arr.size == 0:
+        return 1, None, None
+    rc = lib().wax_oracle_mv2v_parse(_p(arr, ctypes.c_uint8), arr.size, expect_metric, expect_dims,
+                                     ctypes.byref(count), ctypes.byref(voff), ctypes.byref(ioff))
+    if rc != 0:
+        return rc, None, None
+    dims = int(np.frombuffer(data[8:12], dtype="<u4")[0])
+    n = count.value
+    vec = np.frombuffer(data, dtype="<f4", count=n * dims, offset=voff.value).reshape(n, dims).copy()
+    ids = np.frombuffer(data, dtype="<u8", count=n, offset=ioff.value).copy()
+    return 0, vec, ids
+
+
+# --------------------------------------------------------------------------
+# seeded synthetic inputs
+
+def deterministic_embed(text: str, dims: int, normalize: bool = True) -> np.ndarray:
+    """Reference DeterministicEmbedder (RAGBenchmarkSupport.swift:114-157)."""
+    raw = np.frombuffer(text.encode("utf-8"), dtype=np.uint8)
+    raw = np.ascontiguousarray(raw) if raw.size else np.zeros(1, dtype=np.uint8)
+    out = np.empty(dims, dtype=np.float32)
+    lib().wax_oracle_deterministic_embed(_p(raw, ctypes.c_uint8), len(text.encode("utf-8")), dims, int(normalize),
+                                         _p(out, ctypes.c_float))
+    return out
+
+
+def tie_pattern(row0: int, n: int, dims: int) -> np.ndarray:
+    """MetalVectorEngineBenchmark.swift:33-38 pattern: ((i+d) % 256)/255."""
+    out = np.empty((n, dims), dtype=np.float32)
+    lib().wax_oracle_tie_pattern(row0, n, dims, _p(out, ctypes.c_float))
+    return out
+
+
+SHARD_ROWS = 65536  # generation granule: corpus is reproducible for any GPU count
+
+
+def gaussian_unit_rows(row0: int, n: int, dims: int, seed: int = CORPUS_SEED) -> np.ndarray:
+    """Unit-norm Gaussian rows [row0, row0+n): granule g = row // SHARD_ROWS is
+    drawn from PCG64(seed + g), L2-normalised in f64, cast to f32."""
+    out = np.empty((n, dims), dtype=np.float32)
+    r = row0
+    end = row0 + n
+    while r < end:
+        g = r // SHARD_ROWS
+        g0 = g * SHARD_ROWS
+        take_lo = r - g0
+        take_hi = min(end - g0, SHARD_ROWS)
+        rng = np.random.Generator(np.random.PCG64(seed + g))
+        block = rng.standard_normal((take_hi, dims))  # rows of a granule are drawn in order
+        block = block[take_lo:take_hi]
+        block /= np.linalg.norm(block, axis=1, keepdims=True)
+        out[r - row0:r - row0 + block.shape[0]] = block.astype(np.float32)
+        r = g0 + take_hi
+    return out
+
+
+def gaussian_unit_queries(nq: int, dims: int, seed: int = QUERY_SEED) -> np.ndarray:
+    rng = np.random.Generator(np.random.PCG64(seed))
+    q = rng.standard_normal((nq, dims))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    return q.astype(np.float32)

@@ -1,0 +1,1074 @@
+// engine.hip — host side of libwaxhip: the HBM-resident store, the scratch-slot pool,
+// the reader/writer lock and the C ABI declared in include/wax_hip.h.
+//
+// Behaviour follows MetalVectorEngine (Sources/WaxVectorSearch/MetalVectorEngine.swift),
+// re-designed for a discrete MI355X: the store is one hipMalloc slab [capacity x dims] f32
+// row-major (+ a u64 frame-id table beside it so id mapping also happens on device), queries
+// travel through pinned staging, every search runs on a pooled scratch slot with its own HIP
+// stream (the analogue of the transient buffer pool, :84-117), and there is no CPU fallback.
+#include <atomic>
+#include <condition_variable>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+using namespace wax;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr, code, what)                                                         \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess)                                                             \
+            return fail((code), std::string(what) + ": " + hipGetErrorString(_e));        \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) {
+            changed = (hipSetDevice(dev) == hipSuccess);
+        }
+    }
+    ~DeviceGuard() {
+        if (changed && prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+// Writer-preferring reader/writer lock with thread-agnostic unlock (a ticket may be
+// collected on another thread). Same contract as AsyncReadWriteLock
+// (WaxCore/Concurrency/ReadWriteLock.swift:79-156).
+class RWLock {
+  public:
+    void lock_shared() {
+        std::unique_lock<std::mutex> g(m_);
+        cv_.wait(g, [&] { return !writer_ && writers_waiting_ == 0; });
+        ++readers_;
+    }
+    void unlock_shared() {
+        std::unique_lock<std::mutex> g(m_);
+        if (--readers_ == 0) cv_.notify_all();
+    }
+    void lock() {
+        std::unique_lock<std::mutex> g(m_);
+        ++writers_waiting_;
+        cv_.wait(g, [&] { return !writer_ && readers_ == 0; });
+        --writers_waiting_;
+        writer_ = true;
+    }
+    void unlock() {
+        std::unique_lock<std::mutex> g(m_);
+        writer_ = false;
+        cv_.notify_all();
+    }
+
+  private:
+    std::mutex m_;
+    std::condition_variable cv_;
+    int readers_ = 0;
+    int writers_waiting_ = 0;
+    bool writer_ = false;
+};
+
+struct WriteGuard {
+    RWLock& l;
+    explicit WriteGuard(RWLock& l_) : l(l_) { l.lock(); }
+    ~WriteGuard() { l.unlock(); }
+};
+
+// frameId -> row. Open addressing, linear probing, backward-shift deletion. Replaces the
+// reference's O(N) `frameIds.firstIndex(of:)` (MetalVectorEngine.swift:334, 385, 426).
+class IdMap {
+  public:
+    IdMap() { resize_table(1024); }
+    int64_t find(uint64_t id) const {
+        size_t i = hash(id) & mask_;
+        while (used_[i]) {
+            if (keys_[i] == id) return (int64_t)vals_[i];
+            i = (i + 1) & mask_;
+        }
+        return -1;
+    }
+    void put(uint64_t id, uint32_t row) {
+        if ((size_ + 1) * 10 > (mask_ + 1) * 6) grow();
+        size_t i = hash(id) & mask_;
+        while (used_[i]) {
+            if (keys_[i] == id) { vals_[i] = row; return; }
+            i = (i + 1) & mask_;
+        }
+        used_[i] = 1; keys_[i] = id; vals_[i] = row; ++size_;
+    }
+    // remove `id` (stored at row `row`) and renumber every row above it down by one
+    void erase_row(uint64_t id, uint32_t row) {
+        erase_only(id);
+        for (size_t s = 0; s <= mask_; ++s)
+            if (used_[s] && vals_[s] > row) --vals_[s];
+    }
+    void erase_only(uint64_t id) {
+        size_t i = hash(id) & mask_;
+        while (used_[i] && keys_[i] != id) i = (i + 1) & mask_;
+        if (used_[i]) {
+            size_t hole = i, j = i;
+            for (;;) {
+                j = (j + 1) & mask_;
+                if (!used_[j]) break;
+                const size_t home = hash(keys_[j]) & mask_;
+                // can entry j move into the hole? yes iff hole lies cyclically in [home, j)
+                const bool movable = (hole <= j) ? (home <= hole || home > j) : (home <= hole && home > j);
+                if (movable) {
+                    keys_[hole] = keys_[j]; vals_[hole] = vals_[j];
+                    hole = j;
+                }
+            }
+            used_[hole] = 0;
+            --size_;
+        }
+    }
+    void clear() { resize_table(1024); }
+    void reserve(size_t n) {
+        size_t want = 1024;
+        while (want * 6 < n * 10 + 10) want <<= 1;
+        if (want > mask_ + 1) rehash(want);
+    }
+    size_t size() const { return size_; }
+
+  private:
+    static uint64_t hash(uint64_t x) {
+        x += 0x9e3779b97f4a7c15ull;
+        x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+        x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+        return x ^ (x >> 31);
+    }
+    void resize_table(size_t cap) {
+        keys_.assign(cap, 0); vals_.assign(cap, 0); used_.assign(cap, 0);
+        mask_ = cap - 1; size_ = 0;
+    }
+    void rehash(size_t cap) {
+        std::vector<uint64_t> ok; std::vector<uint32_t> ov; std::vector<uint8_t> ou;
+        ok.swap(keys_); ov.swap(vals_); ou.swap(used_);
+        resize_table(cap);
+        for (size_t s = 0; s < ou.size(); ++s)
+            if (ou[s]) put(ok[s], ov[s]);
+    }
+    void grow() { rehash((mask_ + 1) * 2); }
+    std::vector<uint64_t> keys_;
+    std::vector<uint32_t> vals_;
+    std::vector<uint8_t> used_;
+    size_t mask_ = 0, size_ = 0;
+};
+
+constexpr int kShardRing = 8;
+
+constexpr int kMaxStreams = 4;
+
+struct Slot {
+    int index = 0;
+    hipStream_t stream = nullptr;  // one of the engine's streams (not owned)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr;
+    float* d_query = nullptr;
+    float* h_query = nullptr;  // pinned
+    int64_t* d_partials = nullptr;
+    wax_hip_hit* d_hits = nullptr;
+    wax_hip_hit* h_hits = nullptr;  // pinned
+    // general path, allocated on first use
+    float* d_dist = nullptr;
+    uint64_t dist_cap = 0;
+    SelectWork sw{};
+    bool sw_ready = false;
+    // per-ticket state
+    int k_eff = 0;
+    bool timed = false;
+};
+
+}  // namespace
+
+struct wax_hip_engine {
+    int device = 0;
+    uint8_t metric = 0;
+    uint32_t dims = 0;
+    uint64_t count = 0;           // vectorCount
+    uint64_t capacity = 0;        // reservedCapacity, rows
+    float* d_store = nullptr;     // [capacity][dims]
+    uint64_t* d_ids = nullptr;    // [capacity]
+    std::vector<uint64_t> ids;    // frameIds (host mirror; row order)
+    IdMap idmap;
+    uint64_t row_base = 0;
+    RWLock lock;
+
+    hipStream_t streams[kMaxStreams] = {};
+    int n_streams = 2;            // slots are spread round-robin over this many in-order streams
+
+    std::mutex slot_mu;
+    std::condition_variable slot_cv;
+    std::vector<Slot*> all_slots;
+    std::vector<Slot*> free_slots;
+    int max_slots = 4;
+    std::map<uint64_t, Slot*> tickets;
+    uint64_t next_ticket = 1;
+
+    // shard-search scratch ring (caller-stream async work)
+    float* ring_d_query[kShardRing] = {};
+    float* ring_h_query[kShardRing] = {};
+    int64_t* ring_d_partials[kShardRing] = {};
+    std::atomic<uint32_t> ring_next{0};
+
+    float* d_sink = nullptr;
+    void* d_bounce = nullptr;
+
+    // tuning
+    std::atomic<int64_t> grid_blocks{0};
+    std::atomic<int64_t> variant{-1};
+    std::atomic<int64_t> time_kernels{0};
+    std::atomic<int64_t> force_general{0};
+    std::atomic<int64_t> stream_nt{1};
+
+    // stats
+    std::atomic<uint64_t> st_searches{0}, st_rows{0}, st_bytes{0}, st_alloc{0}, st_reuse{0};
+    std::mutex st_mu;
+    double st_last_ms = 0.0, st_total_ms = 0.0;
+    uint64_t st_timed = 0;
+};
+
+namespace {
+
+constexpr uint64_t kBounceBytes = 64ull << 20;
+
+int clamp_topk(int64_t top_k) {  // MetalVectorEngine.swift:842-846
+    if (top_k < 1) return 1;
+    if (top_k > WAX_HIP_MAX_RESULTS) return WAX_HIP_MAX_RESULTS;
+    return (int)top_k;
+}
+
+std::string dim_mismatch_msg(uint32_t expected, uint64_t got) {  // MetalVectorEngine.swift:832
+    return "vector dimension mismatch: expected " + std::to_string(expected) + ", got " + std::to_string(got);
+}
+
+int alloc_slot(wax_hip_engine* e, Slot** out) {
+    Slot* s = new Slot();
+    auto bail = [&](int code, const char* what, hipError_t err) {
+        std::string msg = std::string("Failed to allocate ") + what + ": " + hipGetErrorString(err);
+        if (s->ev0) (void)hipEventDestroy(s->ev0);
+        if (s->ev1) (void)hipEventDestroy(s->ev1);
+        if (s->ev_done) (void)hipEventDestroy(s->ev_done);
+        (void)hipFree(s->d_query); (void)hipHostFree(s->h_query); (void)hipFree(s->d_partials);
+        (void)hipFree(s->d_hits); (void)hipHostFree(s->h_hits);
+        delete s;
+        return fail(code, msg);
+    };
+    hipError_t err;
+    if ((err = hipEventCreate(&s->ev0)) != hipSuccess) return bail(WAX_HIP_ERR_ALLOC, "event", err);
+    if ((err = hipEventCreate(&s->ev1)) != hipSuccess) return bail(WAX_HIP_ERR_ALLOC, "event", err);
+    if ((err = hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming)) != hipSuccess) return bail(WAX_HIP_ERR_ALLOC, "event", err);
+    const size_t qbytes = (size_t)e->dims * sizeof(float);
+    if ((err = hipMalloc(&s->d_query, qbytes)) != hipSuccess) return bail(WAX_HIP_ERR_ALLOC, "transient query buffer", err);
+    if ((err = hipHostMalloc(&s->h_query, qbytes, hipHostMallocDefault)) != hipSuccess) return bail(WAX_HIP_ERR_ALLOC, "pinned query buffer", err);
+    if ((err = hipMalloc(&s->d_partials, (size_t)MAX_GRID_BLOCKS * FUSED_MAX_K * sizeof(int64_t))) != hipSuccess) return bail(WAX_HIP_ERR_ALLOC, "top-k stage buffer", err);
+    if ((err = hipMalloc(&s->d_hits, (size_t)WAX_HIP_MAX_RESULTS * sizeof(wax_hip_hit))) != hipSuccess) return bail(WAX_HIP_ERR_ALLOC, "top-k results buffer", err);
+    if ((err = hipHostMalloc(&s->h_hits, (size_t)WAX_HIP_MAX_RESULTS * sizeof(wax_hip_hit), hipHostMallocDefault)) != hipSuccess) return bail(WAX_HIP_ERR_ALLOC, "pinned results buffer", err);
+    *out = s;
+    return WAX_HIP_OK;
+}
+
+void free_slot(Slot* s) {
+    if (!s) return;
+    (void)hipFree(s->d_query); (void)hipHostFree(s->h_query); (void)hipFree(s->d_partials);
+    (void)hipFree(s->d_hits); (void)hipHostFree(s->h_hits); (void)hipFree(s->d_dist);
+    if (s->sw_ready) {
+        (void)hipFree(s->sw.hist); (void)hipFree(s->sw.state); (void)hipFree(s->sw.counter);
+        (void)hipFree(s->sw.keys_a); (void)hipFree(s->sw.keys_b);
+    }
+    (void)hipEventDestroy(s->ev0); (void)hipEventDestroy(s->ev1); (void)hipEventDestroy(s->ev_done);
+    delete s;
+}
+
+// acquireTransientBuffers (MetalVectorEngine.swift:84-113): reuse a pooled slot or create one.
+int acquire_slot(wax_hip_engine* e, Slot** out) {
+    std::unique_lock<std::mutex> g(e->slot_mu);
+    for (;;) {
+        if (!e->free_slots.empty()) {
+            Slot* s = e->free_slots.back();
+            e->free_slots.pop_back();
+            s->stream = e->streams[s->index % e->n_streams];  // idle slot: safe to re-home
+            e->st_reuse++;
+            *out = s;
+            return WAX_HIP_OK;
+        }
+        if ((int)e->all_slots.size() < e->max_slots) {
+            Slot* s = nullptr;
+            int rc = alloc_slot(e, &s);
+            if (rc != WAX_HIP_OK) return rc;
+            s->index = (int)e->all_slots.size();
+            s->stream = e->streams[s->index % e->n_streams];
+            e->all_slots.push_back(s);
+            e->st_alloc++;
+            *out = s;
+            return WAX_HIP_OK;
+        }
+        e->slot_cv.wait(g);
+    }
+}
+
+void release_slot(wax_hip_engine* e, Slot* s) {  // releaseTransientBuffers (:115-117)
+    std::unique_lock<std::mutex> g(e->slot_mu);
+    e->free_slots.push_back(s);
+    e->slot_cv.notify_one();
+}
+
+int ensure_general(wax_hip_engine* e, Slot* s) {
+    if (s->dist_cap < e->capacity) {
+        (void)hipStreamSynchronize(s->stream);
+        (void)hipFree(s->d_dist);
+        s->d_dist = nullptr; s->dist_cap = 0;
+        HIP_TRY(hipMalloc(&s->d_dist, (size_t)e->capacity * sizeof(float)), WAX_HIP_ERR_ALLOC,
+                "Failed to allocate transient distances buffer");
+        s->dist_cap = e->capacity;
+    }
+    if (!s->sw_ready) {
+        HIP_TRY(hipMalloc(&s->sw.hist, 256 * sizeof(uint32_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate select histogram");
+        HIP_TRY(hipMalloc(&s->sw.state, 2 * sizeof(uint64_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate select state");
+        HIP_TRY(hipMalloc(&s->sw.counter, sizeof(uint32_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate select counter");
+        HIP_TRY(hipMalloc(&s->sw.keys_a, (size_t)WAX_HIP_MAX_RESULTS * sizeof(int64_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate select keys");
+        HIP_TRY(hipMalloc(&s->sw.keys_b, (size_t)WAX_HIP_MAX_RESULTS * sizeof(int64_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate select keys");
+        s->sw_ready = true;
+    }
+    return WAX_HIP_OK;
+}
+
+float query_norm(const float* q, uint32_t dims) {
+    double s = 0.0;
+    for (uint32_t j = 0; j < dims; ++j) s += (double)q[j] * (double)q[j];
+    return (float)std::sqrt(s);
+}
+
+// resizeBuffersIfNeeded (MetalVectorEngine.swift:873-890): new slab + copy of the live rows.
+int resize_store(wax_hip_engine* e, uint64_t new_cap) {
+    if (new_cap <= e->capacity) return WAX_HIP_OK;
+    float* ns = nullptr;
+    uint64_t* ni = nullptr;
+    const size_t row_bytes = (size_t)e->dims * sizeof(float);
+    hipError_t err = hipMalloc(&ns, (size_t)new_cap * row_bytes);
+    if (err != hipSuccess) return fail(WAX_HIP_ERR_ALLOC, std::string("Failed to resize vectors buffer: ") + hipGetErrorString(err));
+    err = hipMalloc(&ni, (size_t)new_cap * sizeof(uint64_t));
+    if (err != hipSuccess) { (void)hipFree(ns); return fail(WAX_HIP_ERR_ALLOC, std::string("Failed to resize frame id buffer: ") + hipGetErrorString(err)); }
+    if (e->count > 0) {
+        err = hipMemcpy(ns, e->d_store, (size_t)e->count * row_bytes, hipMemcpyDeviceToDevice);
+        if (err == hipSuccess) err = hipMemcpy(ni, e->d_ids, (size_t)e->count * sizeof(uint64_t), hipMemcpyDeviceToDevice);
+        if (err != hipSuccess) { (void)hipFree(ns); (void)hipFree(ni); return fail(WAX_HIP_ERR_INTERNAL, std::string("store copy failed: ") + hipGetErrorString(err)); }
+    }
+    (void)hipFree(e->d_store); (void)hipFree(e->d_ids);
+    e->d_store = ns; e->d_ids = ni; e->capacity = new_cap;
+    return WAX_HIP_OK;
+}
+
+// reserveIfNeeded (MetalVectorEngine.swift:857-871)
+int reserve_rows(wax_hip_engine* e, uint64_t required) {
+    if (required > 0xffffffffull)
+        return fail(WAX_HIP_ERR_CAPACITY, "capacity exceeded: limit 4294967295, requested " + std::to_string(required));
+    if (required <= e->capacity) return WAX_HIP_OK;
+    uint64_t next = e->capacity == 0 ? WAX_HIP_INITIAL_RESERVE : e->capacity;
+    while (required > next) {
+        uint64_t doubled = next * 2;
+        next = doubled > 0xffffffffull ? 0xffffffffull : doubled;
+        if (next == 0xffffffffull) break;
+    }
+    return resize_store(e, next);
+}
+
+struct Enqueued { int k_eff; };
+
+// The scan + select chain for one query on `stream`; leaves kpad hits in d_hits.
+int enqueue_scan(wax_hip_engine* e, const float* d_query, float q_norm, int k_eff, int kpad, int64_t* d_partials,
+                 Slot* general_slot, wax_hip_hit* d_hits, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+    ScanArgs a{};
+    a.store = e->d_store;
+    a.query = d_query;
+    a.partials = d_partials;
+    a.dist_out = nullptr;
+    a.n_rows = (uint32_t)e->count;
+    a.row_base = (uint32_t)e->row_base;
+    a.dims = e->dims;
+    a.k = k_eff;
+    a.q_norm = q_norm;
+    const bool fused = k_eff <= FUSED_MAX_K && !(e->force_general.load() && general_slot != nullptr);
+    int grid = 0;
+    if (fused) {
+        const int cap = k_eff <= 64 ? 128 : 256;
+        if (ev0) HIP_TRY(hipEventRecord(ev0, stream), WAX_HIP_ERR_INTERNAL, "event record");
+        HIP_TRY(launch_scan(a, e->metric, (int)e->variant.load(), cap, false, (int)e->grid_blocks.load(), stream, &grid),
+                WAX_HIP_ERR_INTERNAL, "scan kernel launch");
+        if (ev1) HIP_TRY(hipEventRecord(ev1, stream), WAX_HIP_ERR_INTERNAL, "event record");
+        HIP_TRY(launch_merge_keys(d_partials, (uint32_t)grid * (uint32_t)k_eff, k_eff, kpad, e->d_ids, a.row_base,
+                                  a.n_rows, d_hits, cap, stream),
+                WAX_HIP_ERR_INTERNAL, "merge kernel launch");
+    } else {
+        if (!general_slot) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "top_k too large for the device-resident shard path (max 192)");
+        int rc = ensure_general(e, general_slot);
+        if (rc != WAX_HIP_OK) return rc;
+        a.dist_out = general_slot->d_dist;
+        if (ev0) HIP_TRY(hipEventRecord(ev0, stream), WAX_HIP_ERR_INTERNAL, "event record");
+        HIP_TRY(launch_scan(a, e->metric, 0, 128, true, (int)e->grid_blocks.load(), stream, &grid), WAX_HIP_ERR_INTERNAL,
+                "distance kernel launch");
+        if (ev1) HIP_TRY(hipEventRecord(ev1, stream), WAX_HIP_ERR_INTERNAL, "event record");
+        HIP_TRY(launch_select_general(general_slot->d_dist, a.n_rows, a.row_base, k_eff, kpad, e->d_ids,
+                                      general_slot->sw, d_hits, stream),
+                WAX_HIP_ERR_INTERNAL, "select kernel launch");
+    }
+    e->st_searches++;
+    e->st_rows += e->count;
+    e->st_bytes += e->count * (uint64_t)e->dims * 4ull;
+    return WAX_HIP_OK;
+}
+
+int hits_to_results(uint8_t metric, const wax_hip_hit* hits, uint32_t n, uint64_t* out_ids, float* out_scores,
+                    uint32_t* out_count) {
+    uint32_t m = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (hits[i].key == KEY_PAD) continue;                    // idx == UInt32.max (:597)
+        const float d = key_distance(hits[i].key);
+        if (!std::isfinite(d)) continue;                         // !distance.isFinite (:597)
+        if (hits[i].frame_id == ID_PAD) continue;                // index >= frameIds.count (:599)
+        out_ids[m] = hits[i].frame_id;
+        // VectorMetric.score(fromDistance:) (VectorMetric.swift:32-43)
+        out_scores[m] = (metric == WAX_HIP_METRIC_COSINE) ? (1.0f - d) : (-d);
+        ++m;
+    }
+    *out_count = m;
+    return WAX_HIP_OK;
+}
+
+bool device_is_gfx950(int dev) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, dev) != hipSuccess) return false;
+    return std::strncmp(p.gcnArchName, "gfx950", 6) == 0;
+}
+
+}  // namespace
+
+// ===========================================================================
+// C ABI
+extern "C" {
+
+int wax_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int wax_hip_available(void) {
+    const int n = wax_hip_device_count();
+    for (int d = 0; d < n; ++d)
+        if (device_is_gfx950(d)) return 1;
+    return 0;
+}
+
+uint32_t wax_hip_abi_version(void) { return WAX_HIP_ABI_VERSION; }
+
+const char* wax_hip_last_error(void) { return g_last_error.c_str(); }
+
+int wax_hip_engine_create(uint8_t metric, uint32_t dims, int device_id, wax_hip_engine** out) {
+    if (!out) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "out is null");
+    *out = nullptr;
+    if (dims == 0) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "dimensions must be > 0");  // :154-156
+    if (dims > WAX_HIP_MAX_DIMENSIONS)                                                     // :157-162
+        return fail(WAX_HIP_ERR_CAPACITY, "capacity exceeded: limit " + std::to_string(WAX_HIP_MAX_DIMENSIONS) +
+                                              ", requested " + std::to_string(dims));
+    if (metric > WAX_HIP_METRIC_L2) return fail(WAX_HIP_ERR_METRIC_UNSUPPORTED, "unsupported metric " + std::to_string((int)metric));
+    const int n = wax_hip_device_count();
+    if (n <= 0) return fail(WAX_HIP_ERR_NO_DEVICE, "HIP device not available");          // :167-169
+    int dev = device_id;
+    if (dev < 0) {
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    }
+    if (dev >= n) return fail(WAX_HIP_ERR_NO_DEVICE, "HIP device " + std::to_string(dev) + " not available");
+    if (!device_is_gfx950(dev)) return fail(WAX_HIP_ERR_NO_DEVICE, "HIP device " + std::to_string(dev) + " is not gfx950 (MI355X)");
+
+    DeviceGuard g(dev);
+    wax_hip_engine* e = new wax_hip_engine();
+    e->device = dev;
+    e->metric = metric;
+    e->dims = dims;
+    int rc = resize_store(e, WAX_HIP_INITIAL_RESERVE);  // :225-229
+    if (rc == WAX_HIP_OK) {
+        hipError_t err = hipMalloc(&e->d_sink, MAX_GRID_BLOCKS * sizeof(float));
+        if (err != hipSuccess) rc = fail(WAX_HIP_ERR_ALLOC, std::string("Failed to allocate sink: ") + hipGetErrorString(err));
+    }
+    for (int i = 0; i < kMaxStreams && rc == WAX_HIP_OK; ++i) {
+        hipError_t err = hipStreamCreateWithFlags(&e->streams[i], hipStreamNonBlocking);
+        if (err != hipSuccess) rc = fail(WAX_HIP_ERR_ALLOC, std::string("Failed to create stream: ") + hipGetErrorString(err));
+    }
+    if (rc == WAX_HIP_OK) {
+        Slot* s = nullptr;
+        rc = alloc_slot(e, &s);  // one pooled slot up front, like transientBufferPool's seed entry (:266-273)
+        if (rc == WAX_HIP_OK) {
+            s->index = 0;
+            s->stream = e->streams[0];
+            e->all_slots.push_back(s);
+            e->free_slots.push_back(s);
+        }
+    }
+    if (rc != WAX_HIP_OK) {
+        wax_hip_engine_destroy(e);
+        return rc;
+    }
+    *out = e;
+    return WAX_HIP_OK;
+}
+
+void wax_hip_engine_destroy(wax_hip_engine* e) {
+    if (!e) return;
+    DeviceGuard g(e->device);
+    (void)hipDeviceSynchronize();
+    for (Slot* s : e->all_slots) free_slot(s);
+    for (int i = 0; i < kMaxStreams; ++i)
+        if (e->streams[i]) (void)hipStreamDestroy(e->streams[i]);
+    for (int i = 0; i < kShardRing; ++i) {
+        (void)hipFree(e->ring_d_query[i]);
+        (void)hipHostFree(e->ring_h_query[i]);
+        (void)hipFree(e->ring_d_partials[i]);
+    }
+    (void)hipFree(e->d_store);
+    (void)hipFree(e->d_ids);
+    (void)hipFree(e->d_sink);
+    (void)hipFree(e->d_bounce);
+    delete e;
+}
+
+uint32_t wax_hip_dimensions(const wax_hip_engine* e) { return e ? e->dims : 0; }
+uint64_t wax_hip_count(const wax_hip_engine* e) { return e ? e->count : 0; }
+uint8_t wax_hip_metric_of(const wax_hip_engine* e) { return e ? e->metric : 0; }
+int wax_hip_device_of(const wax_hip_engine* e) { return e ? e->device : -1; }
+
+// ---- mutation -------------------------------------------------------------
+
+int wax_hip_reserve(wax_hip_engine* e, uint64_t rows) {
+    if (!e) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine is null");
+    DeviceGuard g(e->device);
+    WriteGuard w(e->lock);
+    int rc = reserve_rows(e, rows);
+    if (rc == WAX_HIP_OK) e->idmap.reserve(rows);
+    return rc;
+}
+
+int wax_hip_add_batch(wax_hip_engine* e, const uint64_t* frame_ids, const float* rows, uint64_t n, uint32_t dims) {
+    if (!e) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine is null");
+    if (n == 0) return WAX_HIP_OK;  // :360
+    if (!frame_ids || !rows) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "addBatch: null input");
+    if (dims != e->dims) return fail(WAX_HIP_ERR_DIM_MISMATCH, dim_mismatch_msg(e->dims, dims));  // :367-370
+    DeviceGuard g(e->device);
+    WriteGuard w(e->lock);
+    int rc = reserve_rows(e, e->count + n);  // :379-380 (upper bound: every id new)
+    if (rc != WAX_HIP_OK) return rc;
+    const size_t row_bytes = (size_t)e->dims * sizeof(float);
+    // Sequential upsert semantics of :384-398; consecutive appends are flushed as one H2D copy.
+    uint64_t run_start = 0, run_len = 0;  // pending append run: input rows [run_start, run_start+run_len)
+    auto flush = [&]() -> int {
+        if (run_len == 0) return WAX_HIP_OK;
+        const uint64_t first_row = e->count - run_len;
+        HIP_TRY(hipMemcpy(e->d_store + first_row * e->dims, rows + run_start * e->dims, (size_t)run_len * row_bytes,
+                          hipMemcpyHostToDevice), WAX_HIP_ERR_INTERNAL, "vector upload");
+        HIP_TRY(hipMemcpy(e->d_ids + first_row, e->ids.data() + first_row, (size_t)run_len * sizeof(uint64_t),
+                          hipMemcpyHostToDevice), WAX_HIP_ERR_INTERNAL, "frame id upload");
+        run_len = 0;
+        return WAX_HIP_OK;
+    };
+    for (uint64_t i = 0; i < n; ++i) {
+        const int64_t existing = e->idmap.find(frame_ids[i]);
+        if (existing >= 0) {
+            if ((rc = flush()) != WAX_HIP_OK) return rc;
+            HIP_TRY(hipMemcpy(e->d_store + (uint64_t)existing * e->dims, rows + i * e->dims, row_bytes,
+                              hipMemcpyHostToDevice), WAX_HIP_ERR_INTERNAL, "vector upload");
+        } else {
+            if (run_len == 0) run_start = i;
+            e->idmap.put(frame_ids[i], (uint32_t)e->count);
+            e->ids.push_back(frame_ids[i]);
+            e->count += 1;
+            run_len += 1;
+        }
+    }
+    return flush();
+}
+
+int wax_hip_add(wax_hip_engine* e, uint64_t frame_id, const float* vector, uint32_t dims) {
+    return wax_hip_add_batch(e, &frame_id, vector, 1, dims);  // :330-357 is the n == 1 case of :359-402
+}
+
+int wax_hip_add_batch_device(wax_hip_engine* e, const uint64_t* frame_ids, const float* d_rows, uint64_t n, uint32_t dims) {
+    if (!e) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine is null");
+    if (n == 0) return WAX_HIP_OK;
+    if (!frame_ids || !d_rows) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "addBatch: null input");
+    if (dims != e->dims) return fail(WAX_HIP_ERR_DIM_MISMATCH, dim_mismatch_msg(e->dims, dims));
+    DeviceGuard g(e->device);
+    WriteGuard w(e->lock);
+    for (uint64_t i = 0; i < n; ++i)
+        if (e->idmap.find(frame_ids[i]) >= 0)
+            return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "add_batch_device: frame id " + std::to_string(frame_ids[i]) + " already present (append-only path)");
+    int rc = reserve_rows(e, e->count + n);
+    if (rc != WAX_HIP_OK) return rc;
+    const uint64_t first_row = e->count;
+    // host bookkeeping first (detects duplicates inside the batch, rolled back on failure)
+    e->ids.reserve(e->ids.size() + n);
+    for (uint64_t i = 0; i < n; ++i) {
+        if (e->idmap.find(frame_ids[i]) >= 0) {
+            for (uint64_t j = 0; j < i; ++j) e->idmap.erase_only(frame_ids[j]);
+            e->ids.resize((size_t)first_row);
+            return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "add_batch_device: duplicate frame id " + std::to_string(frame_ids[i]) + " inside batch");
+        }
+        e->idmap.put(frame_ids[i], (uint32_t)(first_row + i));
+        e->ids.push_back(frame_ids[i]);
+    }
+    HIP_TRY(hipMemcpy(e->d_store + first_row * e->dims, d_rows, (size_t)n * e->dims * sizeof(float), hipMemcpyDeviceToDevice),
+            WAX_HIP_ERR_INTERNAL, "vector copy");
+    HIP_TRY(hipMemcpy(e->d_ids + first_row, frame_ids, (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice),
+            WAX_HIP_ERR_INTERNAL, "frame id upload");
+    e->count += n;
+    return WAX_HIP_OK;
+}
+
+int wax_hip_remove(wax_hip_engine* e, uint64_t frame_id) {
+    if (!e) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine is null");
+    DeviceGuard g(e->device);
+    WriteGuard w(e->lock);
+    if (e->count == 0) return WAX_HIP_OK;                 // :425
+    const int64_t idx = e->idmap.find(frame_id);
+    if (idx < 0) return WAX_HIP_OK;                       // :426
+    const uint64_t after = e->count - 1 - (uint64_t)idx;  // :431
+    if (after > 0) {
+        if (!e->d_bounce)
+            HIP_TRY(hipMalloc(&e->d_bounce, kBounceBytes), WAX_HIP_ERR_ALLOC, "Failed to allocate bounce buffer");
+        const uint64_t rb = (uint64_t)e->dims * sizeof(float);
+        HIP_TRY(device_shift_down(e->d_store, (uint64_t)idx * rb, (uint64_t)(idx + 1) * rb, after * rb, e->d_bounce,
+                                  kBounceBytes, nullptr), WAX_HIP_ERR_INTERNAL, "row shift");
+        HIP_TRY(device_shift_down(e->d_ids, (uint64_t)idx * 8, (uint64_t)(idx + 1) * 8, after * 8, e->d_bounce,
+                                  kBounceBytes, nullptr), WAX_HIP_ERR_INTERNAL, "frame id shift");
+        HIP_TRY(hipStreamSynchronize(nullptr), WAX_HIP_ERR_INTERNAL, "row shift sync");
+    }
+    e->ids.erase(e->ids.begin() + idx);                   // :440
+    e->idmap.erase_row(frame_id, (uint32_t)idx);
+    e->count -= 1;                                        // :441
+    return WAX_HIP_OK;
+}
+
+// ---- search ---------------------------------------------------------------
+
+int wax_hip_search_submit(wax_hip_engine* e, const float* query, uint32_t dims, int32_t top_k, uint64_t* out_ticket) {
+    if (!e || !out_ticket) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine/ticket is null");
+    DeviceGuard g(e->device);
+    e->lock.lock_shared();                                 // withReadLock (:447)
+    Slot* s = nullptr;
+    int rc = WAX_HIP_OK;
+    do {
+        if (e->count == 0) {                               // :448 — an empty ticket, no GPU work
+            rc = acquire_slot(e, &s);
+            if (rc != WAX_HIP_OK) break;
+            s->k_eff = 0; s->timed = false;
+            break;
+        }
+        if (dims != e->dims || !query) {                   // validate (:449, 830-833)
+            rc = fail(WAX_HIP_ERR_DIM_MISMATCH, dim_mismatch_msg(e->dims, query ? dims : 0));
+            break;
+        }
+        if (e->row_base + e->count > 0x100000000ull) {
+            rc = fail(WAX_HIP_ERR_CAPACITY, "row_base + count exceeds UInt32 row indices");
+            break;
+        }
+        const int limit = clamp_topk(top_k);               // :450
+        const int k_eff = (uint64_t)limit < e->count ? limit : (int)e->count;  // :451
+        rc = acquire_slot(e, &s);
+        if (rc != WAX_HIP_OK) break;
+        s->k_eff = k_eff;
+        s->timed = e->time_kernels.load() != 0;
+        std::memcpy(s->h_query, query, (size_t)dims * sizeof(float));  // :467-468
+        const float qn = query_norm(query, dims);
+        hipError_t err = hipMemcpyAsync(s->d_query, s->h_query, (size_t)dims * sizeof(float), hipMemcpyHostToDevice, s->stream);
+        if (err != hipSuccess) { rc = fail(WAX_HIP_ERR_INTERNAL, std::string("query upload: ") + hipGetErrorString(err)); break; }
+        rc = enqueue_scan(e, s->d_query, qn, k_eff, k_eff, s->d_partials, s, s->d_hits, s->stream,
+                          s->timed ? s->ev0 : nullptr, s->timed ? s->ev1 : nullptr);
+        if (rc != WAX_HIP_OK) break;
+        err = hipMemcpyAsync(s->h_hits, s->d_hits, (size_t)k_eff * sizeof(wax_hip_hit), hipMemcpyDeviceToHost, s->stream);
+        if (err != hipSuccess) { rc = fail(WAX_HIP_ERR_INTERNAL, std::string("result download: ") + hipGetErrorString(err)); break; }
+        err = hipEventRecord(s->ev_done, s->stream);
+        if (err != hipSuccess) { rc = fail(WAX_HIP_ERR_INTERNAL, std::string("event record: ") + hipGetErrorString(err)); break; }
+    } while (0);
+    if (rc != WAX_HIP_OK) {
+        if (s) { (void)hipStreamSynchronize(s->stream); release_slot(e, s); }
+        e->lock.unlock_shared();
+        return rc;
+    }
+    {
+        std::unique_lock<std::mutex> tg(e->slot_mu);
+        const uint64_t t = e->next_ticket++;
+        e->tickets[t] = s;
+        *out_ticket = t;
+    }
+    return WAX_HIP_OK;  // shared lock stays held until collect
+}
+
+int wax_hip_search_collect(wax_hip_engine* e, uint64_t ticket, uint64_t* out_ids, float* out_scores, uint32_t* out_count) {
+    if (!e || !out_count) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine/out_count is null");
+    DeviceGuard g(e->device);
+    Slot* s = nullptr;
+    {
+        std::unique_lock<std::mutex> tg(e->slot_mu);
+        auto it = e->tickets.find(ticket);
+        if (it == e->tickets.end()) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "unknown ticket " + std::to_string(ticket));
+        s = it->second;
+        e->tickets.erase(it);
+    }
+    int rc = WAX_HIP_OK;
+    *out_count = 0;
+    if (s->k_eff > 0) {
+        hipError_t err = hipEventSynchronize(s->ev_done);   // commandBuffer completion (:577-582); later queries on the stream keep running
+        if (err != hipSuccess) {
+            rc = fail(WAX_HIP_ERR_INTERNAL, std::string("search failed on device: ") + hipGetErrorString(err));
+        } else {
+            if (s->timed) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess) {
+                    std::unique_lock<std::mutex> sg(e->st_mu);
+                    e->st_last_ms = ms; e->st_total_ms += ms; e->st_timed += 1;
+                }
+            }
+            if (!out_ids || !out_scores) rc = fail(WAX_HIP_ERR_INVALID_ARGUMENT, "output arrays are null");
+            else rc = hits_to_results(e->metric, s->h_hits, (uint32_t)s->k_eff, out_ids, out_scores, out_count);
+        }
+    }
+    release_slot(e, s);
+    e->lock.unlock_shared();
+    return rc;
+}
+
+int wax_hip_search(wax_hip_engine* e, const float* query, uint32_t dims, int32_t top_k, uint64_t* out_ids,
+                   float* out_scores, uint32_t* out_count) {
+    uint64_t t = 0;
+    int rc = wax_hip_search_submit(e, query, dims, top_k, &t);
+    if (rc != WAX_HIP_OK) return rc;
+    return wax_hip_search_collect(e, t, out_ids, out_scores, out_count);
+}
+
+int wax_hip_search_batch(wax_hip_engine* e, const float* queries, uint32_t nq, uint32_t dims, int32_t top_k,
+                         uint64_t* out_ids, float* out_scores, uint32_t* out_counts) {
+    if (!e) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine is null");
+    if (nq == 0) return WAX_HIP_OK;
+    if (!queries || !out_counts) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null input");
+    const uint64_t cnt = e->count;
+    const uint64_t limit = (uint64_t)clamp_topk(top_k);
+    const uint64_t kcap = limit < cnt ? limit : cnt;
+    // Pipelined over the scratch-slot pool: up to `depth` scans in flight.
+    const uint32_t depth = (uint32_t)(e->max_slots > 1 ? e->max_slots : 1);
+    std::vector<uint64_t> tk(nq, 0);
+    uint32_t submitted = 0, collected = 0;
+    int rc = WAX_HIP_OK;
+    while (collected < nq) {
+        while (submitted < nq && submitted - collected < depth) {
+            rc = wax_hip_search_submit(e, queries + (uint64_t)submitted * dims, dims, top_k, &tk[submitted]);
+            if (rc != WAX_HIP_OK) break;
+            ++submitted;
+        }
+        if (rc != WAX_HIP_OK) break;
+        rc = wax_hip_search_collect(e, tk[collected], out_ids ? out_ids + (uint64_t)collected * kcap : nullptr,
+                                    out_scores ? out_scores + (uint64_t)collected * kcap : nullptr, &out_counts[collected]);
+        ++collected;
+        if (rc != WAX_HIP_OK) break;
+    }
+    if (rc != WAX_HIP_OK) {  // drain whatever is still in flight so the shared lock is released
+        std::string keep = g_last_error;
+        uint32_t dummy = 0;
+        std::vector<uint64_t> ids_tmp(kcap ? kcap : 1);
+        std::vector<float> sc_tmp(kcap ? kcap : 1);
+        for (uint32_t i = collected; i < submitted; ++i)
+            (void)wax_hip_search_collect(e, tk[i], ids_tmp.data(), sc_tmp.data(), &dummy);
+        g_last_error = keep;
+    }
+    return rc;
+}
+
+// ---- sharded search -------------------------------------------------------
+
+int wax_hip_set_row_base(wax_hip_engine* e, uint64_t row_base) {
+    if (!e) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine is null");
+    if (row_base > 0xffffffffull) return fail(WAX_HIP_ERR_CAPACITY, "row_base exceeds UInt32 row indices");
+    WriteGuard w(e->lock);
+    e->row_base = row_base;
+    return WAX_HIP_OK;
+}
+
+int wax_hip_search_shard_device(wax_hip_engine* e, const float* query, uint32_t dims, int32_t top_k,
+                                wax_hip_hit* d_out_hits, void* stream) {
+    if (!e || !d_out_hits) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine/output is null");
+    if (dims != e->dims || !query) return fail(WAX_HIP_ERR_DIM_MISMATCH, dim_mismatch_msg(e->dims, query ? dims : 0));
+    const int kpad = clamp_topk(top_k);
+    if (kpad > FUSED_MAX_K) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "top_k too large for the device-resident shard path (max 192)");
+    DeviceGuard g(e->device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    e->lock.lock_shared();
+    int rc = WAX_HIP_OK;
+    do {
+        if (e->row_base + e->count > 0x100000000ull) { rc = fail(WAX_HIP_ERR_CAPACITY, "row_base + count exceeds UInt32 row indices"); break; }
+        const uint32_t r = e->ring_next.fetch_add(1) % kShardRing;
+        if (!e->ring_d_query[r]) {
+            std::unique_lock<std::mutex> sg(e->slot_mu);
+            if (!e->ring_d_query[r]) {
+                hipError_t err = hipMalloc(&e->ring_d_query[r], (size_t)e->dims * sizeof(float));
+                if (err == hipSuccess) err = hipHostMalloc(&e->ring_h_query[r], (size_t)e->dims * sizeof(float), hipHostMallocDefault);
+                if (err == hipSuccess) err = hipMalloc(&e->ring_d_partials[r], (size_t)MAX_GRID_BLOCKS * FUSED_MAX_K * sizeof(int64_t));
+                if (err != hipSuccess) { rc = fail(WAX_HIP_ERR_ALLOC, std::string("Failed to allocate shard scratch: ") + hipGetErrorString(err)); break; }
+            }
+        }
+        if (e->count == 0) {  // all padding
+            std::vector<wax_hip_hit> pad((size_t)kpad, wax_hip_hit{KEY_PAD, ID_PAD});
+            hipError_t err = hipMemcpyAsync(d_out_hits, pad.data(), pad.size() * sizeof(wax_hip_hit), hipMemcpyHostToDevice, st);
+            if (err == hipSuccess) err = hipStreamSynchronize(st);
+            if (err != hipSuccess) rc = fail(WAX_HIP_ERR_INTERNAL, std::string("pad upload: ") + hipGetErrorString(err));
+            break;
+        }
+        const int k_eff = (uint64_t)kpad < e->count ? kpad : (int)e->count;
+        std::memcpy(e->ring_h_query[r], query, (size_t)dims * sizeof(float));
+        const float qn = query_norm(query, dims);
+        hipError_t err = hipMemcpyAsync(e->ring_d_query[r], e->ring_h_query[r], (size_t)dims * sizeof(float), hipMemcpyHostToDevice, st);
+        if (err != hipSuccess) { rc = fail(WAX_HIP_ERR_INTERNAL, std::string("query upload: ") + hipGetErrorString(err)); break; }
+        rc = enqueue_scan(e, e->ring_d_query[r], qn, k_eff, kpad, e->ring_d_partials[r], nullptr, d_out_hits, st, nullptr, nullptr);
+    } while (0);
+    e->lock.unlock_shared();
+    return rc;
+}
+
+int wax_hip_merge_hits_device(const wax_hip_hit* d_in, uint32_t n, uint32_t k, wax_hip_hit* d_out, void* stream) {
+    if (!d_in || !d_out) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null device buffer");
+    if (k < 1 || k > (uint32_t)FUSED_MAX_K || n > 16384u) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "merge_hits: k must be 1..192 and n <= 16384");
+    HIP_TRY(launch_merge_hits(d_in, n, (int)k, d_out, static_cast<hipStream_t>(stream)), WAX_HIP_ERR_INTERNAL, "merge kernel launch");
+    return WAX_HIP_OK;
+}
+
+int wax_hip_hits_to_results(uint8_t metric, const wax_hip_hit* hits, uint32_t n, uint64_t* out_ids, float* out_scores,
+                            uint32_t* out_count) {
+    if (!hits || !out_ids || !out_scores || !out_count) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    return hits_to_results(metric, hits, n, out_ids, out_scores, out_count);
+}
+
+// ---- persistence ----------------------------------------------------------
+
+void wax_hip_free(void* p) { std::free(p); }
+
+int wax_hip_serialize(wax_hip_engine* e, uint8_t** out_bytes, size_t* out_len) {
+    if (!e || !out_bytes || !out_len) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    DeviceGuard g(e->device);
+    e->lock.lock_shared();  // withReadLock (:683)
+    const uint64_t n = e->count;
+    const uint64_t vec_bytes = n * (uint64_t)e->dims * 4ull;  // :697
+    const uint64_t id_bytes = n * 8ull;                       // :707
+    const size_t total = 36 + (size_t)vec_bytes + 8 + (size_t)id_bytes;
+    uint8_t* buf = static_cast<uint8_t*>(std::malloc(total));
+    if (!buf) { e->lock.unlock_shared(); return fail(WAX_HIP_ERR_ALLOC, "Failed to allocate serialize buffer"); }
+    uint8_t* p = buf;
+    const uint8_t magic[4] = {0x4D, 0x56, 0x32, 0x56};        // "MV2V" :686
+    std::memcpy(p, magic, 4); p += 4;
+    const uint16_t ver = 1; std::memcpy(p, &ver, 2); p += 2;  // :687
+    *p++ = 2;                                                 // encoding 2 (flat) :689
+    *p++ = e->metric;                                         // VecSimilarity raw :690
+    std::memcpy(p, &e->dims, 4); p += 4;                      // :691
+    std::memcpy(p, &n, 8); p += 8;                            // :693
+    std::memcpy(p, &vec_bytes, 8); p += 8;                    // :698
+    std::memset(p, 0, 8); p += 8;                             // reserved :700
+    int rc = WAX_HIP_OK;
+    if (vec_bytes) {
+        hipError_t err = hipMemcpy(p, e->d_store, (size_t)vec_bytes, hipMemcpyDeviceToHost);  // :703-705
+        if (err != hipSuccess) rc = fail(WAX_HIP_ERR_INTERNAL, std::string("vector download: ") + hipGetErrorString(err));
+    }
+    p += vec_bytes;
+    std::memcpy(p, &id_bytes, 8); p += 8;                     // :708
+    if (id_bytes) std::memcpy(p, e->ids.data(), (size_t)id_bytes);  // :710
+    e->lock.unlock_shared();
+    if (rc != WAX_HIP_OK) { std::free(buf); return rc; }
+    *out_bytes = buf;
+    *out_len = total;
+    return WAX_HIP_OK;
+}
+
+int wax_hip_deserialize(wax_hip_engine* e, const uint8_t* data, size_t len) {
+    if (!e || (!data && len)) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    // Validation order and reasons: MetalVectorEngine.deserialize (:716-808)
+    if (len < 36) return fail(WAX_HIP_ERR_BAD_SEGMENT, "Metal segment too small: " + std::to_string(len) + " bytes");
+    const uint8_t magic[4] = {0x4D, 0x56, 0x32, 0x56};
+    if (std::memcmp(data, magic, 4) != 0) return fail(WAX_HIP_ERR_BAD_SEGMENT, "Metal segment magic mismatch");
+    uint16_t ver; std::memcpy(&ver, data + 4, 2);
+    if (ver != 1) return fail(WAX_HIP_ERR_BAD_SEGMENT, "Unsupported Metal segment version " + std::to_string(ver));
+    if (data[6] != 2) return fail(WAX_HIP_ERR_BAD_SEGMENT, "Unsupported Metal segment encoding " + std::to_string((int)data[6]));
+    if (data[7] > 2 || data[7] != e->metric)
+        return fail(WAX_HIP_ERR_BAD_SEGMENT, "Metric mismatch: expected " + std::to_string((int)e->metric) + ", got " + std::to_string((int)data[7]));
+    uint32_t dims; std::memcpy(&dims, data + 8, 4);
+    if (dims != e->dims) return fail(WAX_HIP_ERR_BAD_SEGMENT, "Dimension mismatch: expected " + std::to_string(e->dims) + ", got " + std::to_string(dims));
+    uint64_t n, vec_len; std::memcpy(&n, data + 12, 8); std::memcpy(&vec_len, data + 20, 8);
+    for (int i = 0; i < 8; ++i)
+        if (data[28 + i] != 0) return fail(WAX_HIP_ERR_BAD_SEGMENT, "Metal segment reserved bytes must be zero");
+    if (n > 0xffffffffull || vec_len != n * (uint64_t)dims * 4ull) return fail(WAX_HIP_ERR_BAD_SEGMENT, "Vector data length mismatch");
+    if ((uint64_t)len < 36 + vec_len + 8) return fail(WAX_HIP_ERR_BAD_SEGMENT, "Metal segment missing frameId length");
+    uint64_t id_len; std::memcpy(&id_len, data + 36 + vec_len, 8);
+    if (id_len != n * 8ull) return fail(WAX_HIP_ERR_BAD_SEGMENT, "FrameId data length mismatch");
+    if ((uint64_t)len < 36 + vec_len + 8 + id_len) return fail(WAX_HIP_ERR_BAD_SEGMENT, "Metal segment truncated frameId data");
+
+    DeviceGuard g(e->device);
+    WriteGuard w(e->lock);  // withWriteLock (:717)
+    // :790-792 — capacity only grows
+    int rc = resize_store(e, n > e->capacity ? n : e->capacity);
+    if (rc != WAX_HIP_OK) return rc;
+    e->count = n;
+    e->ids.resize((size_t)n);
+    if (n) {
+        std::memcpy(e->ids.data(), data + 36 + vec_len + 8, (size_t)id_len);  // :809-811
+        HIP_TRY(hipMemcpy(e->d_store, data + 36, (size_t)vec_len, hipMemcpyHostToDevice), WAX_HIP_ERR_INTERNAL, "vector upload");  // :794-799
+        HIP_TRY(hipMemcpy(e->d_ids, e->ids.data(), (size_t)id_len, hipMemcpyHostToDevice), WAX_HIP_ERR_INTERNAL, "frame id upload");
+    }
+    e->idmap.clear();
+    e->idmap.reserve((size_t)n);
+    for (uint64_t i = 0; i < n; ++i)
+        if (e->idmap.find(e->ids[i]) < 0) e->idmap.put(e->ids[i], (uint32_t)i);  // firstIndex(of:) semantics: first row wins
+    return WAX_HIP_OK;
+}
+
+// ---- observability / tuning -----------------------------------------------
+
+int wax_hip_stats(wax_hip_engine* e, wax_hip_stats_t* out) {
+    if (!e || !out) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    out->searches = e->st_searches.load();
+    out->rows_scanned = e->st_rows.load();
+    out->bytes_scanned = e->st_bytes.load();
+    out->transient_allocations = e->st_alloc.load();
+    out->reuse_count = e->st_reuse.load();
+    out->reserved_rows = e->capacity;
+    std::unique_lock<std::mutex> sg(e->st_mu);
+    out->last_scan_kernel_ms = e->st_last_ms;
+    out->scan_kernel_ms_total = e->st_total_ms;
+    out->scan_kernels_timed = e->st_timed;
+    return WAX_HIP_OK;
+}
+
+int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value) {
+    if (!e || !key) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    const std::string k(key);
+    if (k == "grid_blocks") e->grid_blocks = value;
+    else if (k == "variant") e->variant = value;
+    else if (k == "time_kernels") e->time_kernels = value;
+    else if (k == "force_general") e->force_general = value;
+    else if (k == "stream_nt") e->stream_nt = value;
+    else if (k == "streams") {
+        if (value < 1 || value > kMaxStreams) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "streams must be 1..4");
+        std::unique_lock<std::mutex> g(e->slot_mu);
+        e->n_streams = (int)value;
+    } else if (k == "slots") {
+        if (value < 1 || value > 64) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "slots must be 1..64");
+        std::unique_lock<std::mutex> g(e->slot_mu);
+        e->max_slots = (int)value;
+    } else if (k == "reset_stats") {
+        e->st_searches = 0; e->st_rows = 0; e->st_bytes = 0;
+        std::unique_lock<std::mutex> sg(e->st_mu);
+        e->st_last_ms = 0; e->st_total_ms = 0; e->st_timed = 0;
+    } else return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "unknown tuning key '" + k + "'");
+    return WAX_HIP_OK;
+}
+
+int64_t wax_hip_get_tuning(wax_hip_engine* e, const char* key) {
+    if (!e || !key) return -1;
+    const std::string k(key);
+    if (k == "grid_blocks") return e->grid_blocks.load();
+    if (k == "variant") return e->variant.load();
+    if (k == "time_kernels") return e->time_kernels.load();
+    if (k == "force_general") return e->force_general.load();
+    if (k == "stream_nt") return e->stream_nt.load();
+    if (k == "slots") return e->max_slots;
+    if (k == "streams") return e->n_streams;
+    if (k == "variant_count") return scan_variant_count(e->dims);
+    if (k == "scan_grid") return scan_grid_for((uint32_t)e->count, e->dims, (int)e->variant.load(), (int)e->grid_blocks.load());
+    if (k == "fused_max_k") return FUSED_MAX_K;
+    return -1;
+}
+
+int wax_hip_time_scan_kernel(wax_hip_engine* e, const float* query, uint32_t dims, int32_t top_k, uint32_t iters,
+                             double* out_avg_ms) {
+    if (!e || !out_avg_ms || !query) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    if (dims != e->dims) return fail(WAX_HIP_ERR_DIM_MISMATCH, dim_mismatch_msg(e->dims, dims));
+    if (iters == 0) iters = 1;
+    DeviceGuard g(e->device);
+    e->lock.lock_shared();
+    Slot* s = nullptr;
+    int rc = WAX_HIP_OK;
+    do {
+        if (e->count == 0) { rc = fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine is empty"); break; }
+        const int limit = clamp_topk(top_k);
+        const int k_eff = (uint64_t)limit < e->count ? limit : (int)e->count;
+        if (k_eff > FUSED_MAX_K) { rc = fail(WAX_HIP_ERR_INVALID_ARGUMENT, "time_scan_kernel: top_k must be <= 192"); break; }
+        rc = acquire_slot(e, &s);
+        if (rc != WAX_HIP_OK) break;
+        std::memcpy(s->h_query, query, (size_t)dims * sizeof(float));
+        ScanArgs a{};
+        a.store = e->d_store; a.query = s->d_query; a.partials = s->d_partials; a.dist_out = nullptr;
+        a.n_rows = (uint32_t)e->count; a.row_base = (uint32_t)e->row_base; a.dims = e->dims; a.k = k_eff;
+        a.q_norm = query_norm(query, dims);
+        const int cap = k_eff <= 64 ? 128 : 256;
+        hipError_t err = hipMemcpyAsync(s->d_query, s->h_query, (size_t)dims * sizeof(float), hipMemcpyHostToDevice, s->stream);
+        int grid = 0;
+        for (int wu = 0; wu < 2 && err == hipSuccess; ++wu)
+            err = launch_scan(a, e->metric, (int)e->variant.load(), cap, false, (int)e->grid_blocks.load(), s->stream, &grid);
+        if (err == hipSuccess) err = hipEventRecord(s->ev0, s->stream);
+        for (uint32_t i = 0; i < iters && err == hipSuccess; ++i)
+            err = launch_scan(a, e->metric, (int)e->variant.load(), cap, false, (int)e->grid_blocks.load(), s->stream, &grid);
+        if (err == hipSuccess) err = hipEventRecord(s->ev1, s->stream);
+        if (err == hipSuccess) err = hipStreamSynchronize(s->stream);
+        float ms = 0.f;
+        if (err == hipSuccess) err = hipEventElapsedTime(&ms, s->ev0, s->ev1);
+        if (err != hipSuccess) { rc = fail(WAX_HIP_ERR_INTERNAL, std::string("time_scan_kernel: ") + hipGetErrorString(err)); break; }
+        *out_avg_ms = (double)ms / (double)iters;
+    } while (0);
+    if (s) release_slot(e, s);
+    e->lock.unlock_shared();
+    return rc;
+}
+
+int wax_hip_time_stream_read(wax_hip_engine* e, uint32_t iters, double* out_avg_ms) {
+    if (!e || !out_avg_ms) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    if (iters == 0) iters = 1;
+    DeviceGuard g(e->device);
+    e->lock.lock_shared();
+    Slot* s = nullptr;
+    int rc = WAX_HIP_OK;
+    do {
+        const uint64_t bytes = (e->count * (uint64_t)e->dims * 4ull) & ~15ull;
+        if (bytes == 0) { rc = fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine is empty"); break; }
+        rc = acquire_slot(e, &s);
+        if (rc != WAX_HIP_OK) break;
+        int grid = (int)e->grid_blocks.load();
+        if (grid <= 0) grid = 2048;
+        if (grid > MAX_GRID_BLOCKS) grid = MAX_GRID_BLOCKS;
+        const int nt = (int)e->stream_nt.load();
+        hipError_t err = hipSuccess;
+        for (int wu = 0; wu < 2 && err == hipSuccess; ++wu) err = launch_stream_read(e->d_store, bytes, nt, grid, e->d_sink, s->stream);
+        if (err == hipSuccess) err = hipEventRecord(s->ev0, s->stream);
+        for (uint32_t i = 0; i < iters && err == hipSuccess; ++i) err = launch_stream_read(e->d_store, bytes, nt, grid, e->d_sink, s->stream);
+        if (err == hipSuccess) err = hipEventRecord(s->ev1, s->stream);
+        if (err == hipSuccess) err = hipStreamSynchronize(s->stream);
+        float ms = 0.f;
+        if (err == hipSuccess) err = hipEventElapsedTime(&ms, s->ev0, s->ev1);
+        if (err != hipSuccess) { rc = fail(WAX_HIP_ERR_INTERNAL, std::string("time_stream_read: ") + hipGetErrorString(err)); break; }
+        *out_avg_ms = (double)ms / (double)iters;
+    } while (0);
+    if (s) release_slot(e, s);
+    e->lock.unlock_shared();
+    return rc;
+}
+
+}  // extern "C"

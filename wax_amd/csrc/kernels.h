@@ -1,0 +1,69 @@
+// kernels.h — host-callable launchers for the gfx950 kernels (kernels.hip).
+#pragma once
+#include "common.h"
+
+namespace wax {
+
+// Arguments of one single-query scan over one shard.
+struct ScanArgs {
+    const float* store;      // [n_rows][dims] f32 row-major in HBM (a3: MetalVectorEngine vectorsBuffer)
+    const float* query;      // [dims] f32 in HBM
+    int64_t* partials;       // fused path: [grid][k] per-workgroup sorted keys
+    float* dist_out;         // general path: [n_rows] distances (the reference's distances buffer)
+    uint32_t n_rows;
+    uint32_t row_base;       // global row of local row 0 (shard offset)
+    uint32_t dims;
+    int32_t k;               // min(clamp(topK), n_rows)
+    float q_norm;            // ||query||_2 (f64-accumulated on the host, rounded to f32)
+};
+
+struct ScanVariantInfo {
+    int unroll;          // row groups in flight per wave iteration
+    int nt;              // 1 = non-temporal (streaming) loads
+    int group;           // lanes cooperating on one row
+    int rows_per_chunk;  // rows one wave consumes per loop iteration
+    int specialised;     // 1 = compile-time dims kernel, 0 = generic any-dims kernel
+};
+
+// Number of scan kernel variants available for (dims, metric); variant 0 is the default.
+int scan_variant_count(uint32_t dims);
+bool scan_variant_info(uint32_t dims, int variant, ScanVariantInfo* out);
+
+// Launch the fused scan+select (write_dist=false: per-workgroup top-k keys into
+// args.partials, *out_grid workgroups) or the distance-only scan (write_dist=true).
+// cap: 128 (k <= 64) or 256 (k <= 192). grid_cap: max workgroups (0 = default).
+hipError_t launch_scan(const ScanArgs& args, int metric, int variant, int cap, bool write_dist, int grid_cap,
+                       hipStream_t stream, int* out_grid);
+int scan_grid_for(uint32_t n_rows, uint32_t dims, int variant, int grid_cap);
+
+// n_in sorted-or-not keys -> the k smallest, ascending, as hits (frame id looked up in d_ids
+// by local row = key_row - row_base; d_ids may be null => frame_id = global row). kpad >= k
+// slots are written (tail padded). cap as above.
+hipError_t launch_merge_keys(const int64_t* d_in, uint32_t n_in, int k, int kpad, const uint64_t* d_ids,
+                             uint32_t row_base, uint32_t n_rows, wax_hip_hit* d_out, int cap, hipStream_t stream);
+// gathered shard hits (n <= 16384) -> k smallest ascending (k <= 192)
+hipError_t launch_merge_hits(const wax_hip_hit* d_in, uint32_t n, int k, wax_hip_hit* d_out, hipStream_t stream);
+
+// General (any k <= 10000) selection over a distance buffer: exact k-th key by 8-pass radix
+// select on the 64-bit key, compaction, rank sort, id lookup. Work buffers are caller-owned.
+struct SelectWork {
+    uint32_t* hist;      // [256]
+    uint64_t* state;     // [2]: prefix, remaining-k
+    uint32_t* counter;   // [1]
+    int64_t* keys_a;     // [kmax]
+    int64_t* keys_b;     // [kmax]
+};
+hipError_t launch_select_general(const float* d_dist, uint32_t n_rows, uint32_t row_base, int k, int kpad,
+                                 const uint64_t* d_ids, const SelectWork& w, wax_hip_hit* d_out,
+                                 hipStream_t stream);
+
+// Streaming-read microbenchmark: sums every float4 of [bytes] (16-B multiple), one partial per workgroup.
+hipError_t launch_stream_read(const float* d_src, uint64_t bytes, int nt, int grid, float* d_sink,
+                              hipStream_t stream);
+
+// Order-preserving in-place removal of one row (MetalVectorEngine.remove's memmove, :431-438),
+// done through a bounce buffer in chunks; also shifts the id table.
+hipError_t device_shift_down(void* base, uint64_t dst_off, uint64_t src_off, uint64_t bytes, void* bounce,
+                             uint64_t bounce_bytes, hipStream_t stream);
+
+}  // namespace wax

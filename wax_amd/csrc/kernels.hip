@@ -1,0 +1,605 @@
+// kernels.hip — hand-written CDNA4 (gfx950) kernels for the Wax vector scan + top-k path.
+//
+// Hot kernel: scan_kernel — ONE fused pass that streams the row-major f32 store
+// from HBM with fully coalesced 16-byte loads, reduces each row's dot / norm
+// with DPP cross-lane adds, and keeps a running per-wave top-k behind a
+// threshold, so the algorithmic traffic is exactly n_rows*dims*4 bytes and no
+// n-float distance buffer is written (the reference writes one and re-reads it
+// through up to six reduction launches: CosineDistance.metal:233-328 +
+// TopKReduction.metal:103-167, driven by MetalVectorEngine.swift:483-575).
+//
+// Layout / mapping (MI355X-first, not a translation of the Metal one-thread-
+// per-row scheme, which would make a 64-wide wave stride 1536 B between lanes):
+//   * a row of D floats is D4 = D/4 float4s; GROUP lanes (16/32/64) cooperate on
+//     a row, each lane owning LOADS = D4/GROUP float4s at stride GROUP, so a
+//     wave-wide dwordx4 load covers 64/GROUP consecutive rows in GROUP*16-byte
+//     (>= 256 B, 128-B-line aligned) contiguous runs — every fetched line is
+//     fully used;
+//   * the query slice a lane needs is loop-invariant => it lives in VGPRs
+//     (LOADS float4s); no LDS traffic at all on the streaming path;
+//   * each wave keeps UNROLL row-groups (UNROLL*LOADS dwordx4 loads) in flight;
+//   * waves walk the store grid-strided by chunk so that at any instant the whole
+//     chip reads one contiguous, moving window (TLB- and DRAM-page-friendly);
+//   * every row's summation order is fixed by (GROUP, LOADS) alone, so a row's
+//     distance is bit-identical wherever it sits — on any shard, any GPU count.
+#include "kernels.h"
+#include "topk.h"
+
+namespace wax {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum { M_COS = WAX_HIP_METRIC_COSINE, M_DOT = WAX_HIP_METRIC_DOT, M_L2 = WAX_HIP_METRIC_L2 };
+
+template <bool NT>
+__device__ inline f32x4 ld16(const f32x4* p) {
+    if (NT) return __builtin_nontemporal_load(p);
+    return *p;
+}
+
+// a3 + a6 (distance side): CosineDistance.metal:321-325 rule `sqrt(m) > 1e-6 ? dot/sqrt(m) : 0`,
+// extended to the true cosine the CPU path computes (divide by ||q|| as well;
+// SURVEY.md §7 "Query-norm semantics"); dot / l2 use USearch's ip / l2sq distances
+// (VectorMetric.swift:21-30). NaN -> +inf so it sorts last and is dropped on the host
+// like MetalVectorEngine.swift:597; "+ 0.0f" folds -0 into +0.
+template <int METRIC>
+__device__ inline float finish_distance(float acc, float nrm, float q_norm) {
+    float d;
+    if (METRIC == M_COS) {
+        const float vn = sqrtf(nrm);
+        const float sim = (vn > 1e-6f && q_norm > 1e-6f) ? acc / (vn * q_norm) : 0.0f;
+        d = 1.0f - sim;
+    } else if (METRIC == M_DOT) {
+        d = 1.0f - acc;
+    } else {
+        d = acc;
+    }
+    d = (d != d) ? __builtin_inff() : d;
+    return d + 0.0f;
+}
+
+template <int METRIC>
+__device__ inline void accumulate(const f32x4& q, const f32x4& v, f32x4& acc, f32x4& nrm) {
+    if (METRIC == M_L2) {
+        const f32x4 e = q - v;
+        acc = __builtin_elementwise_fma(e, e, acc);
+    } else {
+        acc = __builtin_elementwise_fma(q, v, acc);
+        if (METRIC == M_COS) nrm = __builtin_elementwise_fma(v, v, nrm);
+    }
+}
+
+__device__ inline float hsum(const f32x4& a) { return (a.x + a.y) + (a.z + a.w); }
+
+// ---------------------------------------------------------------------------
+// Fused scan + select, compile-time dims.
+template <int D4, int GROUP, int METRIC, int UNROLL, bool NT, int CAP, bool WRITE_DIST>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a) {
+    constexpr int LOADS = D4 / GROUP;       // float4s per lane per row
+    constexpr int RPW = WAVE / GROUP;       // rows per wave-wide load
+    constexpr int RPC = RPW * UNROLL;       // rows per wave per iteration
+    static_assert(D4 % GROUP == 0, "GROUP must divide D4");
+
+    __shared__ int64_t lds[WRITE_DIST ? 1 : SCAN_WAVES * CAP + SCAN_WAVES];
+
+    const int lane = lane_id();
+    const int wave = (int)(threadIdx.x >> 6);
+    const int sub = lane / GROUP;
+    const int gl = lane % GROUP;
+    const bool owner = (gl == GROUP - 1);
+    const uint32_t n = a.n_rows;
+
+    const f32x4* __restrict__ store4 = reinterpret_cast<const f32x4*>(a.store);
+    const f32x4* __restrict__ q4 = reinterpret_cast<const f32x4*>(a.query);
+
+    f32x4 q[LOADS];
+#pragma unroll
+    for (int j = 0; j < LOADS; ++j) q[j] = q4[gl + j * GROUP];
+
+    WaveTopK<CAP> tk;
+    if (!WRITE_DIST) tk.init(lds + wave * CAP, a.k);
+
+    const uint32_t nchunks = (n + RPC - 1) / RPC;
+    const uint32_t gwave = blockIdx.x * SCAN_WAVES + wave;
+    const uint32_t nwaves = gridDim.x * SCAN_WAVES;
+
+    for (uint32_t chunk = gwave; chunk < nchunks; chunk += nwaves) {
+        const uint32_t rbase = chunk * RPC + sub;
+        if (!WRITE_DIST) tk.make_room(RPC);  // one prune site per iteration keeps the streaming loop small
+        f32x4 v[UNROLL][LOADS];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const uint32_t r = rbase + u * RPW;
+            const uint32_t rc = r < n ? r : n - 1;  // clamp: tail lanes re-read the last row, result discarded
+            const f32x4* p = store4 + (size_t)rc * D4 + gl;
+#pragma unroll
+            for (int j = 0; j < LOADS; ++j) v[u][j] = ld16<NT>(p + j * GROUP);
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f}, nrm = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < LOADS; ++j) accumulate<METRIC>(q[j], v[u][j], acc, nrm);
+            float s = group_sum<GROUP>(hsum(acc));
+            float m = 0.f;
+            if (METRIC == M_COS) m = group_sum<GROUP>(hsum(nrm));
+            const float d = finish_distance<METRIC>(s, m, a.q_norm);
+            const uint32_t r = rbase + u * RPW;
+            const bool valid = owner && (r < n);
+            if (WRITE_DIST) {
+                if (valid) a.dist_out[r] = d;
+            } else {
+                tk.push(make_key(d, a.row_base + r), valid);
+            }
+        }
+    }
+
+    if (!WRITE_DIST) {
+        int* counts = reinterpret_cast<int*>(lds + SCAN_WAVES * CAP);
+        tk.finalize();
+        if (lane == 0) counts[wave] = tk.cnt;
+        __syncthreads();
+        block_rank_merge<SCAN_WAVES>(lds, CAP, counts, a.k, a.partials + (size_t)blockIdx.x * a.k);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Any-dims fallback (D not in the specialised list, including D % 4 != 0 and the
+// 2-d / 4-d toy corpora of the reference tests): one wave per row, lanes stride
+// the row; float4 loads when D % 4 == 0, scalar otherwise. Query read through L1/L2.
+template <int METRIC, int CAP, bool WRITE_DIST>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_generic_kernel(ScanArgs a) {
+    __shared__ int64_t lds[WRITE_DIST ? 1 : SCAN_WAVES * CAP + SCAN_WAVES];
+    const int lane = lane_id();
+    const int wave = (int)(threadIdx.x >> 6);
+    const uint32_t n = a.n_rows, D = a.dims;
+    const bool vec4 = (D & 3u) == 0;
+    const uint32_t D4 = D >> 2;
+
+    WaveTopK<CAP> tk;
+    if (!WRITE_DIST) tk.init(lds + wave * CAP, a.k);
+
+    const uint32_t gwave = blockIdx.x * SCAN_WAVES + wave;
+    const uint32_t nwaves = gridDim.x * SCAN_WAVES;
+    for (uint32_t r = gwave; r < n; r += nwaves) {
+        if (!WRITE_DIST) tk.make_room(1);
+        const float* row = a.store + (size_t)r * D;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, nrm = {0.f, 0.f, 0.f, 0.f};
+        if (vec4) {
+            const f32x4* row4 = reinterpret_cast<const f32x4*>(row);
+            const f32x4* q4 = reinterpret_cast<const f32x4*>(a.query);
+            for (uint32_t c = lane; c < D4; c += WAVE) accumulate<METRIC>(q4[c], row4[c], acc, nrm);
+        } else {
+            for (uint32_t c = lane; c < D; c += WAVE) {
+                const f32x4 qq = {a.query[c], 0.f, 0.f, 0.f};
+                const f32x4 vv = {row[c], 0.f, 0.f, 0.f};
+                accumulate<METRIC>(qq, vv, acc, nrm);
+            }
+        }
+        float s = group_sum<64>(hsum(acc));
+        float m = 0.f;
+        if (METRIC == M_COS) m = group_sum<64>(hsum(nrm));
+        const float d = finish_distance<METRIC>(s, m, a.q_norm);
+        const bool valid = (lane == WAVE - 1);
+        if (WRITE_DIST) {
+            if (valid) a.dist_out[r] = d;
+        } else {
+            tk.push(make_key(d, a.row_base + r), valid);
+        }
+    }
+    if (!WRITE_DIST) {
+        int* counts = reinterpret_cast<int*>(lds + SCAN_WAVES * CAP);
+        tk.finalize();
+        if (lane == 0) counts[wave] = tk.cnt;
+        __syncthreads();
+        block_rank_merge<SCAN_WAVES>(lds, CAP, counts, a.k, a.partials + (size_t)blockIdx.x * a.k);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// variant registry
+
+struct DimSpec { uint32_t dims; int group; };
+static const DimSpec kDimSpecs[] = {
+    {64, 16}, {128, 32}, {256, 64}, {384, 32}, {512, 64}, {768, 64}, {1024, 64}, {1536, 64},
+};
+
+struct VariantSpec { int unroll; int nt; };
+// variant 0 is the production default; the others exist for on-device sweeps (tools/sweep.py).
+static const VariantSpec kVariants384[] = {{4, 1}, {4, 0}, {2, 1}, {2, 0}, {8, 1}, {8, 0}, {1, 1}};
+static const VariantSpec kVariants768[] = {{2, 1}, {2, 0}, {4, 1}, {1, 1}};
+
+static int default_unroll(uint32_t dims, int group) {
+    const int loads = (int)(dims / 4) / group;
+    int u = 12 / loads;
+    if (u < 1) u = 1;
+    if (u > 4) u = 4;
+    return u;
+}
+
+static const DimSpec* find_dim(uint32_t dims) {
+    for (const auto& s : kDimSpecs)
+        if (s.dims == dims) return &s;
+    return nullptr;
+}
+
+int scan_variant_count(uint32_t dims) {
+    if (dims == 384) return (int)(sizeof(kVariants384) / sizeof(kVariants384[0]));
+    if (dims == 768) return (int)(sizeof(kVariants768) / sizeof(kVariants768[0]));
+    return 1;
+}
+
+bool scan_variant_info(uint32_t dims, int variant, ScanVariantInfo* out) {
+    if (variant < 0 || variant >= scan_variant_count(dims)) return false;
+    const DimSpec* s = find_dim(dims);
+    if (!s) {
+        *out = ScanVariantInfo{1, 0, 64, 1, 0};
+        return true;
+    }
+    VariantSpec v;
+    if (dims == 384) v = kVariants384[variant];
+    else if (dims == 768) v = kVariants768[variant];
+    else v = VariantSpec{default_unroll(dims, s->group), 1};
+    *out = ScanVariantInfo{v.unroll, v.nt, s->group, (WAVE / s->group) * v.unroll, 1};
+    return true;
+}
+
+int scan_grid_for(uint32_t n_rows, uint32_t dims, int variant, int grid_cap) {
+    ScanVariantInfo info;
+    if (!scan_variant_info(dims, variant, &info)) scan_variant_info(dims, 0, &info);
+    if (grid_cap <= 0) grid_cap = 2048;  // 256 CUs x 8 workgroups: enough waves to cover HBM latency
+    if (grid_cap > MAX_GRID_BLOCKS) grid_cap = MAX_GRID_BLOCKS;
+    const uint64_t nchunks = ((uint64_t)n_rows + info.rows_per_chunk - 1) / info.rows_per_chunk;
+    uint64_t blocks = (nchunks + SCAN_WAVES - 1) / SCAN_WAVES;
+    if (blocks < 1) blocks = 1;
+    if (blocks > (uint64_t)grid_cap) blocks = grid_cap;
+    return (int)blocks;
+}
+
+template <int D4, int GROUP, int UNROLL, bool NT, int METRIC>
+static hipError_t launch_metric(const ScanArgs& a, int cap, bool write_dist, int grid, hipStream_t st) {
+    if (write_dist) {
+        hipLaunchKernelGGL((scan_kernel<D4, GROUP, METRIC, UNROLL, NT, 128, true>), dim3(grid), dim3(SCAN_THREADS), 0, st, a);
+    } else if (cap <= 128) {
+        hipLaunchKernelGGL((scan_kernel<D4, GROUP, METRIC, UNROLL, NT, 128, false>), dim3(grid), dim3(SCAN_THREADS), 0, st, a);
+    } else {
+        hipLaunchKernelGGL((scan_kernel<D4, GROUP, METRIC, UNROLL, NT, 256, false>), dim3(grid), dim3(SCAN_THREADS), 0, st, a);
+    }
+    return hipGetLastError();
+}
+
+template <int D4, int GROUP, int UNROLL, bool NT>
+static hipError_t launch_full(const ScanArgs& a, int metric, int cap, bool write_dist, int grid, hipStream_t st) {
+    switch (metric) {
+        case M_COS: return launch_metric<D4, GROUP, UNROLL, NT, M_COS>(a, cap, write_dist, grid, st);
+        case M_DOT: return launch_metric<D4, GROUP, UNROLL, NT, M_DOT>(a, cap, write_dist, grid, st);
+        case M_L2: return launch_metric<D4, GROUP, UNROLL, NT, M_L2>(a, cap, write_dist, grid, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+// sweep-only variants: cosine, k <= 64, fused path; anything else falls back to variant 0
+template <int D4, int GROUP, int UNROLL, bool NT>
+static hipError_t launch_sweep(const ScanArgs& a, int grid, hipStream_t st) {
+    hipLaunchKernelGGL((scan_kernel<D4, GROUP, M_COS, UNROLL, NT, 128, false>), dim3(grid), dim3(SCAN_THREADS), 0, st, a);
+    return hipGetLastError();
+}
+
+template <int METRIC>
+static hipError_t launch_generic_metric(const ScanArgs& a, int cap, bool write_dist, int grid, hipStream_t st) {
+    if (write_dist) {
+        hipLaunchKernelGGL((scan_generic_kernel<METRIC, 128, true>), dim3(grid), dim3(SCAN_THREADS), 0, st, a);
+    } else if (cap <= 128) {
+        hipLaunchKernelGGL((scan_generic_kernel<METRIC, 128, false>), dim3(grid), dim3(SCAN_THREADS), 0, st, a);
+    } else {
+        hipLaunchKernelGGL((scan_generic_kernel<METRIC, 256, false>), dim3(grid), dim3(SCAN_THREADS), 0, st, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_scan(const ScanArgs& a, int metric, int variant, int cap, bool write_dist, int grid_cap,
+                       hipStream_t st, int* out_grid) {
+    if (variant < 0 || variant >= scan_variant_count(a.dims)) variant = 0;
+    const bool sweepable = (metric == M_COS && cap <= 128 && !write_dist);
+    if (!sweepable) variant = 0;
+    const int grid = scan_grid_for(a.n_rows, a.dims, variant, grid_cap);
+    if (out_grid) *out_grid = grid;
+    switch (a.dims) {
+        case 64: return launch_full<16, 16, 4, true>(a, metric, cap, write_dist, grid, st);
+        case 128: return launch_full<32, 32, 4, true>(a, metric, cap, write_dist, grid, st);
+        case 256: return launch_full<64, 64, 4, true>(a, metric, cap, write_dist, grid, st);
+        case 384:
+            switch (variant) {
+                case 1: return launch_sweep<96, 32, 4, false>(a, grid, st);
+                case 2: return launch_sweep<96, 32, 2, true>(a, grid, st);
+                case 3: return launch_sweep<96, 32, 2, false>(a, grid, st);
+                case 4: return launch_sweep<96, 32, 8, true>(a, grid, st);
+                case 5: return launch_sweep<96, 32, 8, false>(a, grid, st);
+                case 6: return launch_sweep<96, 32, 1, true>(a, grid, st);
+                default: return launch_full<96, 32, 4, true>(a, metric, cap, write_dist, grid, st);
+            }
+        case 512: return launch_full<128, 64, 4, true>(a, metric, cap, write_dist, grid, st);
+        case 768:
+            switch (variant) {
+                case 1: return launch_sweep<192, 64, 2, false>(a, grid, st);
+                case 2: return launch_sweep<192, 64, 4, true>(a, grid, st);
+                case 3: return launch_sweep<192, 64, 1, true>(a, grid, st);
+                default: return launch_full<192, 64, 2, true>(a, metric, cap, write_dist, grid, st);
+            }
+        case 1024: return launch_full<256, 64, 3, true>(a, metric, cap, write_dist, grid, st);
+        case 1536: return launch_full<384, 64, 2, true>(a, metric, cap, write_dist, grid, st);
+        default: break;
+    }
+    switch (metric) {
+        case M_COS: return launch_generic_metric<M_COS>(a, cap, write_dist, grid, st);
+        case M_DOT: return launch_generic_metric<M_DOT>(a, cap, write_dist, grid, st);
+        case M_L2: return launch_generic_metric<M_L2>(a, cap, write_dist, grid, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------
+// Final merge: grid*k per-workgroup keys -> k hits. One workgroup of 16 waves; each wave
+// filters a slice through its WaveTopK, then the workgroup rank-merges and looks up ids.
+// (a4's iterated topKReduceEntries passes, TopKReduction.metal:136-167, in one launch.)
+template <int CAP>
+__global__ __launch_bounds__(MERGE_THREADS) void merge_keys_kernel(const int64_t* __restrict__ in, uint32_t n_in,
+                                                                   int k, int kpad,
+                                                                   const uint64_t* __restrict__ ids,
+                                                                   uint32_t row_base, uint32_t n_rows,
+                                                                   wax_hip_hit* __restrict__ out) {
+    __shared__ int64_t lds[MERGE_WAVES * CAP + MERGE_WAVES + FUSED_MAX_K];
+    int* counts = reinterpret_cast<int*>(lds + MERGE_WAVES * CAP);
+    int64_t* fin = lds + MERGE_WAVES * CAP + MERGE_WAVES;
+    const int lane = lane_id();
+    const int wave = (int)(threadIdx.x >> 6);
+    WaveTopK<CAP> tk;
+    tk.init(lds + wave * CAP, k);
+    for (uint32_t base = wave * WAVE; base < n_in; base += MERGE_THREADS) {
+        const uint32_t i = base + lane;
+        const bool inb = i < n_in;
+        const int64_t key = inb ? in[i] : KEY_PAD;
+        tk.make_room(WAVE);
+        tk.push(key, inb && key != KEY_PAD);
+    }
+    tk.finalize();
+    if (lane == 0) counts[wave] = tk.cnt;
+    __syncthreads();
+    block_rank_merge<MERGE_WAVES>(lds, CAP, counts, k, fin);
+    __syncthreads();
+    for (int t = (int)threadIdx.x; t < kpad; t += MERGE_THREADS) {
+        wax_hip_hit h;
+        h.key = (t < k) ? fin[t] : KEY_PAD;
+        h.frame_id = ID_PAD;
+        if (h.key != KEY_PAD) {
+            const uint32_t local = key_row(h.key) - row_base;
+            h.frame_id = (ids != nullptr && local < n_rows) ? ids[local] : (uint64_t)key_row(h.key);
+        }
+        out[t] = h;
+    }
+}
+
+hipError_t launch_merge_keys(const int64_t* d_in, uint32_t n_in, int k, int kpad, const uint64_t* d_ids,
+                             uint32_t row_base, uint32_t n_rows, wax_hip_hit* d_out, int cap, hipStream_t st) {
+    if (k > FUSED_MAX_K || k < 1 || kpad < k) return hipErrorInvalidValue;
+    if (cap <= 128)
+        hipLaunchKernelGGL((merge_keys_kernel<128>), dim3(1), dim3(MERGE_THREADS), 0, st, d_in, n_in, k, kpad, d_ids,
+                           row_base, n_rows, d_out);
+    else
+        hipLaunchKernelGGL((merge_keys_kernel<256>), dim3(1), dim3(MERGE_THREADS), 0, st, d_in, n_in, k, kpad, d_ids,
+                           row_base, n_rows, d_out);
+    return hipGetLastError();
+}
+
+// Gathered shard hits -> global top-k (SURVEY.md §8e "merge G*k -> k"). Select on keys, then
+// every input hit binary-searches the sorted winners to deposit its frame id.
+__global__ __launch_bounds__(MERGE_THREADS) void merge_hits_kernel(const wax_hip_hit* __restrict__ in, uint32_t n,
+                                                                   int k, wax_hip_hit* __restrict__ out) {
+    constexpr int CAP = 256;
+    __shared__ int64_t lds[MERGE_WAVES * CAP + MERGE_WAVES + FUSED_MAX_K];
+    int* counts = reinterpret_cast<int*>(lds + MERGE_WAVES * CAP);
+    int64_t* fin = lds + MERGE_WAVES * CAP + MERGE_WAVES;
+    const int lane = lane_id();
+    const int wave = (int)(threadIdx.x >> 6);
+    WaveTopK<CAP> tk;
+    tk.init(lds + wave * CAP, k);
+    for (uint32_t base = wave * WAVE; base < n; base += MERGE_THREADS) {
+        const uint32_t i = base + lane;
+        const bool inb = i < n;
+        const int64_t key = inb ? in[i].key : KEY_PAD;
+        tk.make_room(WAVE);
+        tk.push(key, inb && key != KEY_PAD);
+    }
+    tk.finalize();
+    if (lane == 0) counts[wave] = tk.cnt;
+    __syncthreads();
+    block_rank_merge<MERGE_WAVES>(lds, CAP, counts, k, fin);
+    __syncthreads();
+    for (int t = (int)threadIdx.x; t < k; t += MERGE_THREADS)
+        if (fin[t] == KEY_PAD) out[t] = wax_hip_hit{KEY_PAD, ID_PAD};
+    for (uint32_t i = threadIdx.x; i < n; i += MERGE_THREADS) {
+        const wax_hip_hit h = in[i];
+        if (h.key == KEY_PAD) continue;
+        int lo = 0, hi = k;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (fin[mid] < h.key) lo = mid + 1; else hi = mid;
+        }
+        if (lo < k && fin[lo] == h.key) out[lo] = h;
+    }
+}
+
+hipError_t launch_merge_hits(const wax_hip_hit* d_in, uint32_t n, int k, wax_hip_hit* d_out, hipStream_t st) {
+    if (k > FUSED_MAX_K || k < 1 || n > 16384) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(merge_hits_kernel, dim3(1), dim3(MERGE_THREADS), 0, st, d_in, n, k, d_out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// General selection (k up to 10 000): exact k-th smallest 64-bit key by MSB-first 8-bit
+// radix select over (ordered distance : row), then compaction, rank sort and id lookup.
+// Serves MetalVectorEngine's "k > 256 => CPU heap" branch (MetalVectorEngine.swift:452-455,
+// 614-625) without leaving the device.
+
+__device__ inline uint64_t ukey_of(float d, uint32_t row) {
+    return (uint64_t)make_key(d, row) ^ 0x8000000000000000ull;  // unsigned-ordered
+}
+
+__global__ void select_init_kernel(uint32_t* hist, uint64_t* state, uint32_t* counter, uint32_t k) {
+    const int t = (int)threadIdx.x;
+    if (t < 256) hist[t] = 0;
+    if (t == 0) {
+        state[0] = 0;  // prefix (top bytes already decided)
+        state[1] = k;  // how many keys with this prefix precede-or-equal the target
+        *counter = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void select_hist_kernel(const float* __restrict__ dist, uint32_t n,
+                                                          uint32_t row_base, int pass,
+                                                          const uint64_t* __restrict__ state,
+                                                          uint32_t* __restrict__ hist) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t prefix = state[0];
+    const int shift = 56 - 8 * pass;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint64_t u = ukey_of(dist[i], row_base + i);
+        const bool match = (pass == 0) || ((u >> (shift + 8)) == prefix);
+        if (match) atomicAdd(&h[(u >> shift) & 0xff], 1u);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+
+__global__ void select_pick_kernel(uint32_t* hist, uint64_t* state) {
+    // single thread: 256 bins
+    if (threadIdx.x != 0) return;
+    uint64_t rem = state[1];
+    uint32_t cum = 0;
+    int bin = 255;
+    for (int b = 0; b < 256; ++b) {
+        const uint32_t c = hist[b];
+        if (cum + c >= rem) { bin = b; break; }
+        cum += c;
+    }
+    state[0] = (state[0] << 8) | (uint64_t)bin;
+    state[1] = rem - cum;
+    for (int b = 0; b < 256; ++b) hist[b] = 0;
+}
+
+__global__ __launch_bounds__(256) void select_compact_kernel(const float* __restrict__ dist, uint32_t n,
+                                                             uint32_t row_base, const uint64_t* __restrict__ state,
+                                                             uint32_t* counter, int64_t* __restrict__ out,
+                                                             uint32_t kmax) {
+    const uint64_t thr = state[0];  // after 8 passes: the exact k-th smallest unsigned key
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint64_t u = ukey_of(dist[i], row_base + i);
+        if (u <= thr) {
+            const uint32_t pos = atomicAdd(counter, 1u);
+            if (pos < kmax) out[pos] = (int64_t)(u ^ 0x8000000000000000ull);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void rank_sort_kernel(const int64_t* __restrict__ in, int k,
+                                                        int64_t* __restrict__ out) {
+    __shared__ int64_t tile[256];
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    const int64_t mine = (i < k) ? in[i] : KEY_PAD;
+    int rank = 0;
+    for (int base = 0; base < k; base += 256) {
+        const int j = base + (int)threadIdx.x;
+        tile[threadIdx.x] = (j < k) ? in[j] : KEY_PAD;
+        __syncthreads();
+        const int lim = (k - base) < 256 ? (k - base) : 256;
+        for (int t = 0; t < lim; ++t) rank += (tile[t] < mine) ? 1 : 0;
+        __syncthreads();
+    }
+    if (i < k) out[rank] = mine;
+}
+
+__global__ __launch_bounds__(256) void keys_to_hits_kernel(const int64_t* __restrict__ keys, int k, int kpad,
+                                                           const uint64_t* __restrict__ ids, uint32_t row_base,
+                                                           uint32_t n_rows, wax_hip_hit* __restrict__ out) {
+    const int t = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (t >= kpad) return;
+    wax_hip_hit h;
+    h.key = (t < k) ? keys[t] : KEY_PAD;
+    h.frame_id = ID_PAD;
+    if (h.key != KEY_PAD) {
+        const uint32_t local = key_row(h.key) - row_base;
+        h.frame_id = (ids != nullptr && local < n_rows) ? ids[local] : (uint64_t)key_row(h.key);
+    }
+    out[t] = h;
+}
+
+hipError_t launch_select_general(const float* d_dist, uint32_t n_rows, uint32_t row_base, int k, int kpad,
+                                 const uint64_t* d_ids, const SelectWork& w, wax_hip_hit* d_out, hipStream_t st) {
+    if (k < 1 || (uint32_t)k > n_rows || k > WAX_HIP_MAX_RESULTS || kpad < k) return hipErrorInvalidValue;
+    int grid = (int)((n_rows + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(select_init_kernel, dim3(1), dim3(256), 0, st, w.hist, w.state, w.counter, (uint32_t)k);
+    for (int pass = 0; pass < 8; ++pass) {
+        hipLaunchKernelGGL(select_hist_kernel, dim3(grid), dim3(256), 0, st, d_dist, n_rows, row_base, pass, w.state,
+                           w.hist);
+        hipLaunchKernelGGL(select_pick_kernel, dim3(1), dim3(64), 0, st, w.hist, w.state);
+    }
+    hipLaunchKernelGGL(select_compact_kernel, dim3(grid), dim3(256), 0, st, d_dist, n_rows, row_base, w.state,
+                       w.counter, w.keys_a, (uint32_t)k);
+    hipLaunchKernelGGL(rank_sort_kernel, dim3((k + 255) / 256), dim3(256), 0, st, w.keys_a, k, w.keys_b);
+    hipLaunchKernelGGL(keys_to_hits_kernel, dim3((kpad + 255) / 256), dim3(256), 0, st, w.keys_b, k, kpad, d_ids,
+                       row_base, n_rows, d_out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Streaming-read microbenchmark (roofline denominator measured on the node itself).
+template <bool NT>
+__global__ __launch_bounds__(256) void stream_read_kernel(const f32x4* __restrict__ src, uint64_t n16,
+                                                          float* __restrict__ sink) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const uint64_t stride = (uint64_t)gridDim.x * 256 * 4;
+    uint64_t i = (uint64_t)blockIdx.x * 256 * 4 + threadIdx.x;
+    for (; i + 3 * 256 < n16; i += stride) {
+        const f32x4 a = ld16<NT>(src + i), b = ld16<NT>(src + i + 256), c = ld16<NT>(src + i + 512),
+                    d = ld16<NT>(src + i + 768);
+        acc += (a + b) + (c + d);
+    }
+    for (; i < n16; i += 256) acc += ld16<NT>(src + i);
+    const float s = hsum(acc);
+    if (s == 123.456f) sink[blockIdx.x] = s;  // practically never true; keeps the loads live
+}
+
+hipError_t launch_stream_read(const float* d_src, uint64_t bytes, int nt, int grid, float* d_sink, hipStream_t st) {
+    const uint64_t n16 = bytes / 16;
+    if (grid <= 0) grid = 2048;
+    if (nt)
+        hipLaunchKernelGGL((stream_read_kernel<true>), dim3(grid), dim3(256), 0, st,
+                           reinterpret_cast<const f32x4*>(d_src), n16, d_sink);
+    else
+        hipLaunchKernelGGL((stream_read_kernel<false>), dim3(grid), dim3(256), 0, st,
+                           reinterpret_cast<const f32x4*>(d_src), n16, d_sink);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+hipError_t device_shift_down(void* base, uint64_t dst_off, uint64_t src_off, uint64_t bytes, void* bounce,
+                             uint64_t bounce_bytes, hipStream_t st) {
+    // Regions overlap (dst < src): move ascending in bounce-sized pieces; piece c's destination only
+    // overlaps source bytes of pieces <= c, which have already been consumed.
+    char* b = static_cast<char*>(base);
+    uint64_t done = 0;
+    while (done < bytes) {
+        const uint64_t len = (bytes - done) < bounce_bytes ? (bytes - done) : bounce_bytes;
+        hipError_t e = hipMemcpyAsync(bounce, b + src_off + done, len, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return e;
+        e = hipMemcpyAsync(b + dst_off + done, bounce, len, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return e;
+        done += len;
+    }
+    return hipSuccess;
+}
+
+}  // namespace wax

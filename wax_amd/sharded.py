@@ -1,0 +1,132 @@
+"""Row-sharded search across GPUs: one process per GPU, one HIPVectorEngine per process,
+a per-query exchange of per-shard top-k over RCCL (torch.distributed backend "nccl"), then a
+G*k -> k merge. The reference has no multi-device path; this is the one new
+parallelism the MI355X build adds.
+
+Exchange record: wax_hip_hit {int64 key = ordered(distance):global_row, uint64 frame_id}
+carried as an int64[kpad, 2] tensor. Payload per query is G*kpad*16 bytes (8 GPUs, k=10:
+1.3 KB) — latency-bound, so queries are software-pipelined over two HIP streams: the scan
+of query i+1 overlaps the all-gather + merge of query i.
+
+The merge has two interchangeable implementations with identical results:
+  * device: libwaxhip's merge kernel (wax_hip_merge_hits_device) on the same stream;
+  * host:   numpy sort of the gathered int64 keys (also what the gloo CPU tests exercise).
+"""
+from __future__ import annotations
+
+from collections import deque
+from typing import Deque, List, Optional, Tuple
+
+import numpy as np
+
+from . import _abi
+from .engine import HIPVectorEngine, clampTopK
+from .vector_metric import VectorMetric
+
+KEY_PAD = _abi.KEY_PAD
+
+
+def shard_bounds(n_rows: int, world: int, rank: int, align: int = 1) -> Tuple[int, int]:
+    """Contiguous row block of `rank`: [g*ceil(N/G), min(N, (g+1)*ceil(N/G))),
+    with the block size rounded up to `align` rows."""
+    per = -(-n_rows // world)
+    per = -(-per // align) * align
+    lo = min(n_rows, rank * per)
+    hi = min(n_rows, (rank + 1) * per)
+    return lo, hi
+
+
+def merge_hits_host(gathered: np.ndarray, k: int) -> np.ndarray:
+    """gathered: int64[m, 2] (key, frame_id bits). Returns the k smallest keys ascending, padded."""
+    g = np.asarray(gathered).reshape(-1, 2)
+    keys = g[:, 0]
+    order = np.argsort(keys, kind="stable")[:k]
+    out = g[order].copy()
+    if out.shape[0] < k:
+        pad = np.empty((k - out.shape[0], 2), dtype=np.int64)
+        pad[:, 0] = KEY_PAD
+        pad[:, 1] = -1
+        out = np.concatenate([out, pad], axis=0)
+    return out
+
+
+def all_gather_hits(local_hits, world: int):
+    """All-gather a [kpad, 2] int64 tensor over the default process group -> [world*kpad, 2]."""
+    import torch
+    import torch.distributed as dist
+
+    if world == 1:
+        return local_hits
+    out = torch.empty((world * local_hits.shape[0], 2), dtype=torch.int64, device=local_hits.device)
+    if local_hits.is_cuda:
+        dist.all_gather_into_tensor(out, local_hits)
+    else:  # gloo has no all_gather_into_tensor for every torch build: use the list form
+        parts = [torch.empty_like(local_hits) for _ in range(world)]
+        dist.all_gather(parts, local_hits)
+        out = torch.cat(parts, dim=0)
+    return out
+
+
+class ShardedSearcher:
+    """Pipelined sharded search for one rank. submit() enqueues; collect() returns in FIFO order."""
+
+    def __init__(self, engine: HIPVectorEngine, rank: int, world: int, topK: int, depth: int = 4,  # noqa: N803
+                 n_streams: int = 2, host_merge: bool = False):
+        import torch
+
+        self.engine = engine
+        self.rank, self.world = rank, world
+        self.kpad = clampTopK(topK)
+        self.topK = topK
+        self.host_merge = host_merge
+        self.dev = torch.device("cuda", engine.device)
+        self.streams = [torch.cuda.Stream(device=self.dev) for _ in range(max(1, n_streams))]
+        self.depth = max(1, depth)
+        self.local = [torch.empty((self.kpad, 2), dtype=torch.int64, device=self.dev) for _ in range(self.depth)]
+        self.gathered = [torch.empty((self.kpad * world, 2), dtype=torch.int64, device=self.dev)
+                         for _ in range(self.depth)]
+        self.merged = [torch.empty((self.kpad, 2), dtype=torch.int64, device=self.dev) for _ in range(self.depth)]
+        n_host = self.kpad * (world if host_merge else 1)
+        self.host = [torch.empty((n_host, 2), dtype=torch.int64).pin_memory() for _ in range(self.depth)]
+        self.events = [torch.cuda.Event() for _ in range(self.depth)]
+        self.inflight: Deque[int] = deque()
+        self.seq = 0
+
+    def submit(self, query) -> None:
+        import torch
+        import torch.distributed as dist
+
+        if len(self.inflight) >= self.depth:
+            raise RuntimeError("pipeline full: collect() first")
+        b = self.seq % self.depth
+        st = self.streams[self.seq % len(self.streams)]
+        self.seq += 1
+        with torch.cuda.stream(st):
+            self.engine.searchShardDevice(query, self.topK, self.local[b].data_ptr(), st.cuda_stream)
+            if self.world > 1:
+                dist.all_gather_into_tensor(self.gathered[b], self.local[b])  # RCCL over xGMI
+                src = self.gathered[b]
+            else:
+                src = self.local[b]
+            if self.host_merge:
+                self.host[b].copy_(src, non_blocking=True)
+            else:
+                if self.world > 1:
+                    HIPVectorEngine.mergeHitsDevice(src.data_ptr(), src.shape[0], self.kpad, self.merged[b].data_ptr(),
+                                                    st.cuda_stream)
+                    src = self.merged[b]
+                self.host[b].copy_(src, non_blocking=True)
+            self.events[b].record(st)
+        self.inflight.append(b)
+
+    def collect(self) -> Tuple[np.ndarray, np.ndarray]:
+        b = self.inflight.popleft()
+        self.events[b].synchronize()
+        hits = self.host[b].numpy()
+        if self.host_merge and self.world > 1:
+            hits = merge_hits_host(hits, self.kpad)
+        return HIPVectorEngine.hitsToResults(self.engine.metric, hits)
+
+    def search(self, query) -> Tuple[np.ndarray, np.ndarray]:
+        self.submit(query)
+        return self.collect()
