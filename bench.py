@@ -1,0 +1,273 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the Wax vector scan + top-k path on MI355X.
+
+Workload (BASELINE.json `metric`): 10M x 384-dim f32 corpus, cosine top-10, one query per step.
+A "step" is one pass of the hot path: one query scanned against the whole corpus (row-sharded
+over the N GPUs, per-shard top-k all-gathered over RCCL and merged), results back on the host.
+The corpus is resident in HBM before the timed region; the only host<->device traffic inside it
+is the 1.5 KB query in and the k results out (both included in `value`).
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 8 --steps 200 --warmup 20
+
+Rank 0 prints ONE JSON line (contract in the task statement): `value` = whole-job queries/s,
+`roofline` = achieved HBM GB/s of the scan kernel (HIP events recorded around every scan-kernel
+launch of the timed region, on the stream the kernel runs on) against the 8 TB/s MI355X peak,
+`cpu_baseline` = the oracle's multithreaded CPU scan timed on this host (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+CORPUS_SEED = 20260220
+QUERY_SEED = 7
+GRANULE = 65536
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=200)
+    p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--rows", type=int, default=10_000_000)
+    p.add_argument("--dims", type=int, default=384)
+    p.add_argument("--topk", type=int, default=10)
+    p.add_argument("--depth", type=int, default=4, help="queries in flight (software pipeline)")
+    p.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
+    p.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--host-merge", action="store_true", help="N>1: merge gathered hits on the host instead of the device")
+    return p.parse_args()
+
+
+def device_rows(torch, lo, hi, dims, dev):
+    """Rows [lo, hi) of the synthetic corpus: unit-norm Gaussian, granule g seeded with CORPUS_SEED+g,
+    so every GPU count sees the same global corpus."""
+    g = torch.Generator(device=dev)
+    r = lo
+    while r < hi:
+        gi = r // GRANULE
+        g0 = gi * GRANULE
+        g.manual_seed(CORPUS_SEED + gi)
+        block = torch.randn((GRANULE, dims), generator=g, device=dev, dtype=torch.float32)
+        block = torch.nn.functional.normalize(block, dim=1)
+        a, b = r - g0, min(hi - g0, GRANULE)
+        yield r, block[a:b].contiguous()
+        r = g0 + b
+
+
+def unit_queries(n, dims):
+    rng = np.random.Generator(np.random.PCG64(QUERY_SEED))
+    q = rng.standard_normal((n, dims))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    return q.astype(np.float32)
+
+
+def cpu_baseline(torch, args, dev, queries):
+    """The oracle's CPU scan (C restatement of the reference arithmetic, all host threads) on a
+    bounded sample of the same corpus. Reported next to the GPU number; never the thing measured."""
+    import oracle
+    oracle.build()
+    n_s = min(args.cpu_sample_rows, args.rows)
+    sample = np.empty((n_s, args.dims), dtype=np.float32)
+    for lo, x in device_rows(torch, 0, n_s, args.dims, dev):
+        sample[lo:lo + x.shape[0]] = x.cpu().numpy()
+    threads = oracle.max_threads()
+    oracle.scan_topk_mt(0, sample, queries[0], args.topk, threads)  # warm-up / page-in
+    t0 = time.perf_counter()
+    done = 0
+    while True:
+        oracle.scan_topk_mt(0, sample, queries[done % len(queries)], args.topk, threads)
+        done += 1
+        el = time.perf_counter() - t0
+        if el >= args.cpu_baseline_seconds or done >= 200:
+            break
+    qps_sample = done / el
+    qps_full = qps_sample * n_s / args.rows
+    return {
+        "value": qps_full, "unit": "queries/s", "cores": threads, "kind": "port",
+        "sample": f"{done} queries over the first {n_s} rows of the same corpus in {el:.1f} s on {threads} threads "
+                  f"({qps_sample:.2f} q/s on the sample = {n_s * args.dims * 4 * qps_sample / 1e9:.1f} GB/s), "
+                  f"scaled by {n_s}/{args.rows} rows to the full workload",
+    }
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: launch with torch.distributed.run for N>1")
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from wax_amd import HIPVectorEngine, VectorMetric, build, sharded
+    build.build()
+    if not HIPVectorEngine.isAvailable():
+        raise SystemExit("no gfx950 device visible: bench.py measures the HIP path only")
+
+    n, dims, k = args.rows, args.dims, args.topk
+    lo, hi = sharded.shard_bounds(n, world, rank, align=64)
+    t_build = time.perf_counter()
+    eng = HIPVectorEngine(metric=VectorMetric.cosine, dimensions=dims)
+    eng.reserve(max(hi - lo, 1))
+    for r0, x in device_rows(torch, lo, hi, dims, dev):
+        eng.addBatchDevice(np.arange(r0, r0 + x.shape[0], dtype=np.uint64), x)
+    eng.setRowBase(lo)
+    torch.cuda.synchronize()
+    log(f"[bench] rank {rank}/{world}: shard rows [{lo},{hi}) = {(hi - lo) * dims * 4 / 1e9:.2f} GB in HBM, "
+        f"built in {time.perf_counter() - t_build:.1f} s")
+
+    total = args.warmup + args.steps
+    queries = unit_queries(max(total, 8), dims)
+
+    # untimed sanity check: a stored row must retrieve itself
+    probe_row = min(n - 1, 123457)
+    probe = None
+    for r0, x in device_rows(torch, probe_row, probe_row + 1, dims, dev):
+        probe = x[0].cpu().numpy()
+
+    eng.setTuning("time_kernels", 1)
+    if world == 1:
+        eng.setTuning("streams", 1)   # strictly in-order scans: per-kernel event times are not inflated by overlap
+        eng.setTuning("slots", max(args.depth, 1))
+        searcher = None
+
+        def submit(q):
+            return eng.submit(q, k)
+
+        def collect(t):
+            return eng.collect(t, k)
+    else:
+        searcher = sharded.ShardedSearcher(eng, rank, world, k, depth=args.depth, n_streams=2,
+                                           host_merge=args.host_merge)
+
+        def submit(q):
+            searcher.submit(q)
+            return None
+
+        def collect(_):
+            return searcher.collect()
+
+    ids, scores = collect(submit(probe))
+    assert int(ids[0]) == probe_row and abs(float(scores[0]) - 1.0) < 1e-5, (ids[:3], scores[:3])
+
+    def run(qs):
+        pending = []
+        last = None
+        for q in qs:
+            if len(pending) >= args.depth:
+                last = collect(pending.pop(0))
+            pending.append(submit(q))
+        while pending:
+            last = collect(pending.pop(0))
+        return last
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize()
+
+    run(queries[:args.warmup])
+    eng.setTuning("reset_stats", 1)
+    barrier()
+    t0 = time.perf_counter()
+    last = run(queries[args.warmup:args.warmup + args.steps])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    st = eng.stats()
+    assert len(last[0]) == min(k, n)
+
+    if rank == 0:
+        qps = args.steps / elapsed
+        launches = int(st.scan_kernels_timed)
+        kern_ms = (st.scan_kernel_ms_total / launches) if launches else float("nan")
+        bytes_per_launch = (hi - lo) * dims * 4
+        achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if launches else float("nan")
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("rows_per_launch") == hi - lo and tj.get("dims") == dims:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:  # noqa: BLE001
+                traffic = None
+        out = {
+            "metric": "queries/sec, 10M x 384-dim f32 cosine top-10 brute-force scan (single query per step)",
+            "value": qps,
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{n} x {dims}-dim f32 unit-norm Gaussian corpus (seed {CORPUS_SEED}), cosine top-{k}, "
+                            f"one query per step, corpus resident in HBM and row-sharded over {world} GPU(s)",
+                "rows": n, "dims": dims, "top_k": k, "rows_per_gpu": hi - lo,
+                "parallelism": f"row-shard x{world}" + (" + RCCL all-gather of per-shard top-k" if world > 1 else ""),
+                "pipeline_depth": args.depth,
+                "merge": "host" if (world > 1 and args.host_merge) else "device",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS if launches else None,
+                "traffic": traffic,
+                "kernel": "wax::scan_kernel (fused scan + per-wave top-k)",
+                "kernel_avg_ms": kern_ms,
+                "kernel_launches_timed": launches,
+                "algorithmic_bytes_per_launch": bytes_per_launch,
+                "note": "rows_per_gpu*dims*4 bytes per launch / mean HIP-event duration of the scan kernel over "
+                        "the timed region" + ("; two streams overlap scans at N>1, so per-kernel durations include "
+                                              "that overlap" if world > 1 else ""),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(torch, args, dev, queries)
+        elif world == 1:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

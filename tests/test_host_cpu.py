@@ -1,0 +1,164 @@
+"""CPU tests of the host side: the C-ABI library loads and exports everything the header
+declares, fails loudly without a GPU, and the pure-host logic (error mapping, VectorMath,
+VectorSerializer header codec, hit decoding, shard bounds, host merge) is correct.
+No compute entry point is exercised here."""
+import ctypes
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+from helpers import load_golden
+
+REF = load_golden("reference_cases.json")
+
+
+def test_library_exports_every_declared_symbol(hip_lib):
+    from wax_amd import _abi
+    declared = _abi.declared_symbols()
+    assert len(declared) >= 30
+    assert set(declared) == set(_abi.SIGNATURES), (set(declared) ^ set(_abi.SIGNATURES))
+    for name in declared:
+        assert hasattr(hip_lib, name), f"libwaxhip.so does not export {name}"
+    assert hip_lib.wax_hip_abi_version() == 1
+
+
+def test_library_is_a_gfx950_code_object():
+    from wax_amd import build
+    path = build.build()
+    out = subprocess.run(["strings", "-n", "6", path], capture_output=True, text=True).stdout
+    assert "gfx950" in out
+    assert "scan_kernel" in out
+
+
+def test_header_has_no_torch_or_hip_types():
+    from wax_amd import _abi
+    text = open(_abi.HEADER_PATH).read()
+    code = "\n".join(l for l in text.splitlines() if not l.strip().startswith(("*", "/*", "//")))
+    for banned in ("torch", "at::", "hipStream_t", "hipError_t", "std::"):
+        assert banned not in code
+
+
+def test_no_device_fails_loudly(hip_lib):
+    """On a box without a gfx950 GPU every engine call errors; nothing silently falls back."""
+    from wax_amd import HIPVectorEngine, InvalidToc, VectorMetric
+    if hip_lib.wax_hip_available():
+        pytest.skip("GPU present")
+    assert HIPVectorEngine.isAvailable() is False
+    with pytest.raises(InvalidToc) as ei:
+        HIPVectorEngine(metric=VectorMetric.cosine, dimensions=384)
+    assert "not available" in str(ei.value)
+
+
+def test_product_never_imports_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for dirpath, _, files in os.walk(os.path.join(root, "wax_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "import oracle" not in text and "from oracle" not in text, f
+                assert "wax_oracle" not in text, f
+
+
+def test_create_argument_validation(hip_lib):
+    from wax_amd import _abi
+    h = ctypes.c_void_p()
+    assert hip_lib.wax_hip_engine_create(0, 0, -1, ctypes.byref(h)) == _abi.ERR_INVALID_ARGUMENT
+    assert "dimensions must be > 0" in _abi.last_error()  # MetalVectorEngine.swift:155
+    assert hip_lib.wax_hip_engine_create(0, 1000001, -1, ctypes.byref(h)) == _abi.ERR_CAPACITY
+    assert hip_lib.wax_hip_engine_create(7, 4, -1, ctypes.byref(h)) == _abi.ERR_METRIC_UNSUPPORTED
+    assert not h.value
+
+
+def test_error_mapping():
+    from wax_amd import _abi, errors
+    assert issubclass(errors.EncodingError, errors.WaxError)
+    _abi.lib()
+    for code, exc in [(_abi.ERR_DIM_MISMATCH, errors.EncodingError), (_abi.ERR_CAPACITY, errors.CapacityExceeded),
+                      (_abi.ERR_NO_DEVICE, errors.InvalidToc), (_abi.ERR_BAD_SEGMENT, errors.InvalidToc),
+                      (_abi.ERR_ALLOC, errors.InvalidToc)]:
+        with pytest.raises(exc):
+            errors.raise_for_status(code)
+    errors.raise_for_status(0)
+
+
+def test_vector_metric_and_clamp():
+    from wax_amd import VectorMetric, clampTopK
+    c = REF["constants"]
+    assert {m.name: int(m) for m in VectorMetric} == c["similarity_raw"]
+    assert clampTopK(0) == 1 and clampTopK(-3) == 1 and clampTopK(10 ** 9) == c["max_results"] and clampTopK(30) == 30
+    for m in VectorMetric:
+        for d in (0.0, 0.25, 1.5, float("inf"), float("nan")):
+            assert m.score(d) == pytest.approx(oracle.score_from_distance(int(m), d))
+
+
+def test_vector_math_matches_reference_cases():
+    from wax_amd import VectorMath
+    for c in REF["vector_math"]:
+        assert VectorMath.isNormalizedL2(c["vector"]) == c["isNormalizedL2"]
+    v = np.array([3.0, 4.0], dtype=np.float32)
+    assert np.allclose(VectorMath.normalizeL2(v), [0.6, 0.8])
+    assert np.array_equal(VectorMath.normalizeL2(np.zeros(3, np.float32)), np.zeros(3, np.float32))
+    assert VectorMath.isNormalizedL2([]) is False
+    r = oracle.gaussian_unit_queries(4, 384) * np.float32(3.0)
+    for q in r:
+        assert np.allclose(VectorMath.normalizeL2(q), oracle.normalize_l2(q), atol=1e-7)
+
+
+def test_vector_serializer_header_codec():
+    from wax_amd import InvalidToc, VectorSerializer
+    vec = oracle.gaussian_unit_rows(0, 3, 4)
+    ids = np.array([5, 6, 7], dtype=np.uint64)
+    blob = oracle.mv2v_serialize(0, vec, ids)
+    assert VectorSerializer.detectEncoding(blob) == VectorSerializer.VecEncoding.metal
+    kind, info, v2, i2 = VectorSerializer.decodeVecSegment(blob)
+    assert kind == "metal" and info.dimension == 4 and info.vectorCount == 3 and info.payloadLength == 48
+    assert np.array_equal(v2, vec) and np.array_equal(i2, ids)
+    us = b"MV2V" + struct.pack("<HBBIQQ", 1, 1, 0, 4, 3, 5) + b"\x00" * 8 + b"hello"
+    assert VectorSerializer.detectEncoding(us) == VectorSerializer.VecEncoding.uSearch
+    assert VectorSerializer.decodeVecSegment(us)[0] == "uSearch"
+    for bad in (blob[:5], b"NOPE" + blob[4:], blob + b"x", blob[:6] + b"\x09" + blob[7:]):
+        with pytest.raises(InvalidToc):
+            VectorSerializer.decodeVecSegment(bad) if len(bad) >= 8 else VectorSerializer.detectEncoding(bad)
+
+
+def test_hits_to_results_host_tail(hip_lib):
+    """The host tail of search (MetalVectorEngine.swift:592-611): padding and non-finite dropped,
+    distance -> score, key decoding is the inverse of the device encoding."""
+    from wax_amd import HIPVectorEngine, VectorMetric, _abi
+
+    def key(d, row):
+        b = struct.unpack("<i", struct.pack("<f", d))[0]
+        o = b ^ ((b >> 31) & 0x7FFFFFFF)
+        return (o << 32) | row
+
+    hits = np.array([[key(0.25, 3), 103], [key(0.5, 1), 101], [key(float("inf"), 9), 109],
+                     [_abi.KEY_PAD, -1], [key(-0.5, 2), 102]], dtype=np.int64)
+    ids, scores = HIPVectorEngine.hitsToResults(VectorMetric.cosine, hits)
+    assert list(ids) == [103, 101, 102]
+    assert np.allclose(scores, [0.75, 0.5, 1.5])
+    ids, scores = HIPVectorEngine.hitsToResults(VectorMetric.l2, hits[:2])
+    assert np.allclose(scores, [-0.25, -0.5])
+    # signed key order == (distance asc, row asc), negatives and -0 included
+    ds = [-2.0, -0.0, 0.0, 1e-30, 0.5, 0.5, 3.0, float("inf")]
+    keys = [key(d, r) for r, d in enumerate(ds)]
+    assert keys == sorted(keys)
+
+
+def test_shard_bounds_and_host_merge():
+    from wax_amd import sharded
+    n = 10_000_000
+    for world in (1, 2, 4, 8, 3):
+        spans = [sharded.shard_bounds(n, world, r) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    assert sharded.shard_bounds(10, 4, 3) == (9, 10)
+    assert sharded.shard_bounds(10, 8, 7) == (10, 10)  # empty tail shard
+    g = np.array([[5, 50], [1, 10], [sharded.KEY_PAD, -1], [3, 30], [2, 20]], dtype=np.int64)
+    m = sharded.merge_hits_host(g, 3)
+    assert m[:, 0].tolist() == [1, 2, 3] and m[:, 1].tolist() == [10, 20, 30]
+    m = sharded.merge_hits_host(g[:2], 4)
+    assert m[:, 0].tolist() == [1, 5, sharded.KEY_PAD, sharded.KEY_PAD]

@@ -1,0 +1,486 @@
+"""GPU parity tests (run with -m gpu on an MI355X): HIPVectorEngine — i.e. libwaxhip's HIP
+kernels through the C ABI — against the CPU oracle on the same seeded inputs, the committed
+golden fixtures, the reference's own test cases, and size-independent properties at the
+BASELINE.json sizes. Tolerances: scores within 1e-5 (north_star); ids identical except inside
+near-tie groups (< 2e-5 apart in the oracle), see helpers.assert_parity."""
+import hashlib
+import threading
+
+import numpy as np
+import pytest
+
+import oracle
+from helpers import OracleEngine, assert_parity, load_golden, run_reference_case
+
+pytestmark = pytest.mark.gpu
+
+REF = load_golden("reference_cases.json")
+VEC = load_golden("oracle_vectors.json")
+MARGIN = 8
+
+
+@pytest.fixture(scope="module")
+def wax(hip_lib):
+    import wax_amd
+    assert hip_lib.wax_hip_available() == 1, "no gfx950 device: the HIP path must run on the GPU box"
+    return wax_amd
+
+
+def make_engine(wax, metric, dims, corpus=None, ids=None):
+    eng = wax.HIPVectorEngine(metric=wax.VectorMetric(metric), dimensions=dims)
+    if corpus is not None and len(corpus):
+        eng.addBatch(np.arange(len(corpus), dtype=np.uint64) if ids is None else ids, corpus)
+    return eng
+
+
+def check(eng, metric, corpus, ids, q, k, ctx):
+    got_ids, got_scores = eng.searchArrays(q, k)
+    e_ids, e_scores, _, _ = oracle.search(metric, corpus, ids, q, k)
+    x_ids, x_scores, _, _ = oracle.search(metric, corpus, ids, q, min(oracle.clamp_topk(k) + MARGIN, 10000))
+    assert_parity(got_ids, got_scores, e_ids, e_scores, x_scores, ctx)
+    return got_ids, got_scores
+
+
+# ---------------------------------------------------------------------------
+# the reference's own tests, replayed on the HIP engine
+
+@pytest.mark.parametrize("case", REF["engine_cases"], ids=lambda c: c["name"])
+def test_reference_cases(wax, case):
+    run_reference_case(case, lambda m, d: wax.HIPVectorEngine(metric=wax.VectorMetric(m), dimensions=d),
+                       wax.VectorMath.normalizeL2)
+
+
+def test_reference_dimension_mismatch_and_empty(wax):
+    c = REF["dimension_mismatch"]
+    eng = wax.HIPVectorEngine(dimensions=c["dimensions"])
+    assert eng.search([1.0] * c["query_len"], 5) == []  # empty engine returns [] before validating (:448-449)
+    eng.add(0, [1.0] * c["dimensions"])
+    with pytest.raises(wax.EncodingError) as ei:
+        eng.search([1.0] * c["query_len"], 5)
+    assert str(ei.value) == c["message"]
+    with pytest.raises(wax.EncodingError) as ei:
+        eng.add(1, [1.0] * c["query_len"])
+    assert str(ei.value) == c["message"]
+    with pytest.raises(wax.EncodingError):
+        eng.addBatch([1, 2], [[1.0] * c["dimensions"]])
+    assert len(eng.search([1.0] * c["dimensions"], 0)) == 1      # topK < 1 => 1 (:843)
+    assert len(eng.search([1.0] * c["dimensions"], -7)) == 1
+    assert len(eng.search([1.0] * c["dimensions"], 10 ** 6)) == 1  # clamp to 10000, then min(count)
+
+
+def test_minilm_fixture_eight_way_tie(wax):
+    fx = REF["minilm_fixture"]
+    rows = np.full((fx["count"], fx["dimensions"]), 1.0, dtype=np.float32)
+    eng = make_engine(wax, 0, fx["dimensions"], rows, np.arange(100, 108, dtype=np.uint64))
+    ids, scores = eng.searchArrays(rows[3], 5)
+    assert list(ids) == [100, 101, 102, 103, 104]
+    assert np.allclose(scores, 1.0, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------
+# committed golden vectors (oracle outputs frozen in tests/golden/oracle_vectors.json)
+
+def _golden_inputs(case):
+    n, d = case["n"], case["d"]
+    if case["generator"] == "gauss":
+        return oracle.gaussian_unit_rows(0, n, d), oracle.gaussian_unit_queries(3, d)
+    if case["generator"] == "lcg":
+        return (np.stack([oracle.deterministic_embed(f"doc-{i}", d) for i in range(n)]),
+                np.stack([oracle.deterministic_embed(f"query-{i}", d) for i in range(3)]))
+    return oracle.tie_pattern(0, n, d), np.abs(oracle.gaussian_unit_queries(3, d))
+
+
+@pytest.mark.parametrize("case", VEC["cases"], ids=lambda c: c["name"])
+def test_golden_vectors(wax, case):
+    corpus, queries = _golden_inputs(case)
+    assert hashlib.sha256(corpus.astype("<f4").tobytes()).hexdigest() == case["corpus_sha256"]
+    eng = make_engine(wax, case["metric"], case["d"], corpus)
+    for qi, exp in enumerate(case["results"]):
+        got_ids, got_scores = eng.searchArrays(queries[qi], case["k"])
+        _, x_scores, _, _ = oracle.search(case["metric"], corpus, None, queries[qi], case["k"] + MARGIN)
+        assert_parity(got_ids, got_scores, exp["ids"], exp["scores"], x_scores, f"{case['name']} q{qi}")
+
+
+# ---------------------------------------------------------------------------
+# seeded sweeps against the live oracle
+
+SPECIALISED = [64, 128, 256, 384, 512, 768, 1024, 1536]
+GENERIC = [2, 4, 6, 20, 100, 388, 2048]
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("dims", SPECIALISED + GENERIC)
+def test_dims_and_metrics(wax, dims, metric):
+    n = 2500
+    corpus = oracle.gaussian_unit_rows(0, n, dims)
+    if metric != 0:
+        corpus = corpus * np.linspace(0.5, 2.0, n, dtype=np.float32)[:, None]  # non-unit rows
+    ids = (np.arange(n, dtype=np.uint64) * 7 + 3)
+    eng = make_engine(wax, metric, dims, corpus, ids)
+    for qi, q in enumerate(oracle.gaussian_unit_queries(2, dims)):
+        for k in (1, 10, 30):
+            check(eng, metric, corpus, ids, q, k, f"d{dims} m{metric} q{qi} k{k}")
+
+
+@pytest.mark.parametrize("k", [1, 2, 10, 30, 63, 64, 65, 128, 191, 192, 193, 256, 1000, 4999, 5000, 10000, 20000])
+def test_k_sweep_fused_and_general_paths(wax, k):
+    n, dims = 5000, 128
+    corpus = oracle.gaussian_unit_rows(0, n, dims)
+    eng = make_engine(wax, 0, dims, corpus)
+    q = oracle.gaussian_unit_queries(1, dims)[0]
+    ids, scores = check(eng, 0, corpus, None, q, k, f"k{k}")
+    assert len(ids) == min(oracle.clamp_topk(k), n)
+    assert np.all(np.diff(scores) <= 0)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 8, 9, 31, 32, 33, 63, 64, 65, 127, 255, 256, 257, 999, 1000, 1001, 8191, 8193])
+def test_ragged_row_counts(wax, n):
+    for dims in (384, 768, 100):
+        corpus = oracle.gaussian_unit_rows(0, n, dims)
+        eng = make_engine(wax, 0, dims, corpus)
+        q = oracle.gaussian_unit_queries(1, dims)[0]
+        check(eng, 0, corpus, None, q, 10, f"n{n} d{dims}")
+        check(eng, 0, corpus, None, corpus[n - 1], 1, f"n{n} d{dims} last-row")  # the tail row is reachable
+
+
+def test_force_general_path_equals_fused(wax):
+    n, dims = 20000, 384
+    corpus = oracle.gaussian_unit_rows(0, n, dims)
+    eng = make_engine(wax, 0, dims, corpus)
+    for q in oracle.gaussian_unit_queries(3, dims):
+        eng.setTuning("force_general", 0)
+        a = eng.searchArrays(q, 30)
+        eng.setTuning("force_general", 1)
+        b = eng.searchArrays(q, 30)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    eng.setTuning("force_general", 0)
+
+
+def test_scan_variants_are_bit_identical(wax):
+    for dims in (384, 768):
+        n = 30000
+        corpus = oracle.gaussian_unit_rows(0, n, dims)
+        eng = make_engine(wax, 0, dims, corpus)
+        q = oracle.gaussian_unit_queries(1, dims)[0]
+        base = None
+        for variant in range(eng.getTuning("variant_count")):
+            for grid in (0, 64, 1000):
+                eng.setTuning("variant", variant)
+                eng.setTuning("grid_blocks", grid)
+                got = eng.searchArrays(q, 10)
+                if base is None:
+                    base = got
+                    check(eng, 0, corpus, None, q, 10, f"variant{variant}")
+                assert np.array_equal(got[0], base[0]) and np.array_equal(got[1], base[1]), (dims, variant, grid)
+
+
+def test_exact_ties_resolve_by_ascending_row(wax):
+    n, dims = 5000, 128
+    corpus = oracle.tie_pattern(0, n, dims)  # rows i and i+256 are identical
+    eng = make_engine(wax, 0, dims, corpus)
+    q = np.abs(oracle.gaussian_unit_queries(1, dims)[0])
+    for k in (24, 100, 300):
+        ids, scores = eng.searchArrays(q, k)
+        e_ids, e_scores, _, _ = oracle.search(0, corpus, None, q, k)
+        assert np.max(np.abs(scores - e_scores)) <= 1e-5
+        rows = ids.astype(np.int64)
+        for i in range(len(rows) - 1):
+            if scores[i] == scores[i + 1] and rows[i] % 256 == rows[i + 1] % 256:
+                assert rows[i] < rows[i + 1]
+        dup = n // 256  # each distinct row appears ~19-20 times; the best residue comes first, ascending
+        first = rows[:min(k, dup)]
+        assert np.all(first % 256 == first[0] % 256) and np.all(np.diff(first) == 256)
+
+
+def test_special_values(wax):
+    dims = 384
+    corpus = oracle.gaussian_unit_rows(0, 300, dims)
+    corpus[5] = 0.0                      # zero row => similarity 0 (CosineDistance.metal:323)
+    corpus[7, 3] = np.nan                # NaN row => dropped (MetalVectorEngine.swift:597)
+    corpus[9] *= np.float32(1e-4)        # tiny but > 1e-6 norm: still a valid direction
+    eng = make_engine(wax, 0, dims, corpus)
+    q = oracle.gaussian_unit_queries(1, dims)[0]
+    ids, scores = eng.searchArrays(q, 300)
+    assert 7 not in ids and len(ids) == 299
+    assert scores[list(ids).index(5)] == 0.0
+    clean = corpus.copy()
+    clean[7] = 0.0
+    e_ids, e_scores, _, _ = oracle.search(0, np.delete(clean, 7, axis=0), np.delete(np.arange(300, dtype=np.uint64), 7), q, 300)
+    x = dict(zip(e_ids.tolist(), e_scores.tolist()))
+    assert max(abs(x[int(i)] - float(s)) for i, s in zip(ids, scores)) <= 1e-5
+    # zero query: every similarity is 0 => first k rows by index
+    zids, zscores = eng.searchArrays(np.zeros(dims, np.float32), 4)
+    assert list(zids) == [0, 1, 2, 3] and np.all(zscores == 0.0)
+    # scaled query: same ranking, same scores (true cosine)
+    a = eng.searchArrays(q, 10)
+    b = eng.searchArrays(q * np.float32(12.0), 10)
+    assert np.array_equal(a[0], b[0]) and np.max(np.abs(a[1] - b[1])) < 1e-6
+
+
+# ---------------------------------------------------------------------------
+# store semantics (a9) and persistence
+
+def test_random_upsert_remove_sequence_matches_reference_semantics(wax):
+    dims = 384
+    rng = np.random.default_rng(5)
+    eng = wax.HIPVectorEngine(dimensions=dims)
+    ref = OracleEngine(0, dims)
+    pool = oracle.gaussian_unit_rows(0, 600, dims)
+    q = oracle.gaussian_unit_queries(1, dims)[0]
+    for step in range(60):
+        r = rng.random()
+        if r < 0.5:
+            m = int(rng.integers(1, 40))
+            ids = rng.integers(0, 200, m).tolist()        # collisions with existing ids and inside the batch
+            vecs = pool[rng.integers(0, 600, m)]
+            eng.addBatch(ids, vecs)
+            ref.addBatch(ids, list(vecs))
+        elif r < 0.7:
+            fid = int(rng.integers(0, 200))
+            v = pool[int(rng.integers(0, 600))]
+            eng.add(fid, v)
+            ref.add(fid, v)
+        else:
+            fid = int(rng.integers(0, 220))                # sometimes absent => no-op
+            eng.remove(fid)
+            ref.remove(fid)
+        assert eng.count == ref.count
+        if ref.count:
+            got = eng.searchArrays(q, 10)
+            exp = ref.search(q, 10)
+            assert_parity(got[0], got[1], [e[0] for e in exp], [e[1] for e in exp], ctx=f"step{step}")
+    assert eng.serialize() == ref.serialize()              # same rows in the same order, byte for byte
+
+
+def test_capacity_growth_preserves_rows(wax):
+    dims = 64
+    eng = wax.HIPVectorEngine(dimensions=dims)
+    corpus = oracle.gaussian_unit_rows(0, 1000, dims)
+    assert eng.stats().reserved_rows == REF["constants"]["initial_reserve"]
+    for i in range(0, 1000, 37):                           # crosses 64 -> 128 -> ... -> 1024
+        eng.addBatch(np.arange(i, min(i + 37, 1000), dtype=np.uint64), corpus[i:i + 37])
+    assert eng.stats().reserved_rows == 1024
+    assert eng.serialize() == oracle.mv2v_serialize(0, corpus, np.arange(1000, dtype=np.uint64))
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_serialize_is_byte_identical_and_roundtrips(wax, metric):
+    dims, n = 384, 777
+    corpus = oracle.gaussian_unit_rows(0, n, dims)
+    ids = np.arange(n, dtype=np.uint64)[::-1].copy() + 2 ** 40
+    eng = make_engine(wax, metric, dims, corpus, ids)
+    blob = eng.serialize()
+    assert blob == oracle.mv2v_serialize(metric, corpus, ids)
+    kind, info, v2, i2 = wax.VectorSerializer.decodeVecSegment(blob)
+    assert kind == "metal" and np.array_equal(v2, corpus) and np.array_equal(i2, ids)
+    eng2 = wax.HIPVectorEngine(metric=wax.VectorMetric(metric), dimensions=dims)
+    eng2.deserialize(blob)
+    q = oracle.gaussian_unit_queries(1, dims)[0]
+    a, b = eng.searchArrays(q, 20), eng2.searchArrays(q, 20)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    eng2.add(int(ids[5]), corpus[0])                        # id map rebuilt by deserialize: this is an update
+    assert eng2.count == n
+    assert eng.serialize() == blob                          # serialize does not mutate
+    empty = wax.HIPVectorEngine(metric=wax.VectorMetric(metric), dimensions=dims)
+    eb = empty.serialize()
+    assert eb == oracle.mv2v_serialize(metric, np.zeros((0, dims), np.float32), np.zeros(0, np.uint64)) and len(eb) == 44
+    eng2.deserialize(eb)
+    assert eng2.count == 0 and eng2.search(q, 5) == []
+
+
+def test_deserialize_rejects_malformed_segments(wax):
+    dims = 8
+    corpus = oracle.gaussian_unit_rows(0, 5, dims)
+    blob = oracle.mv2v_serialize(0, corpus, np.arange(5, dtype=np.uint64))
+    eng = wax.HIPVectorEngine(dimensions=dims)
+    cases = {
+        "too small": blob[:20],
+        "magic mismatch": b"XXXX" + blob[4:],
+        "version": blob[:4] + b"\x02\x00" + blob[6:],
+        "encoding": blob[:6] + b"\x01" + blob[7:],
+        "Metric mismatch": blob[:7] + b"\x01" + blob[8:],
+        "Dimension mismatch": blob[:8] + b"\x10\x00\x00\x00" + blob[12:],
+        "reserved": blob[:30] + b"\x01" + blob[31:],
+        "length mismatch": blob[:20] + b"\x01" + blob[21:],
+        "frameId": blob[:-8],
+    }
+    for reason, bad in cases.items():
+        with pytest.raises(wax.InvalidToc) as ei:
+            eng.deserialize(bad)
+        assert reason.split()[0].lower() in str(ei.value).lower(), (reason, str(ei.value))
+    assert eng.count == 0
+    eng.deserialize(blob)
+    assert eng.count == 5
+
+
+# ---------------------------------------------------------------------------
+# concurrency contract: re-entrant readers, pooled scratch
+
+def test_concurrent_searches_and_pool(wax):
+    dims, n = 384, 50000
+    corpus = oracle.gaussian_unit_rows(0, n, dims)
+    eng = make_engine(wax, 0, dims, corpus)
+    queries = oracle.gaussian_unit_queries(16, dims)
+    serial = [eng.searchArrays(q, 10) for q in queries]
+    results = [None] * len(queries)
+    errors = []
+
+    def worker(lo, hi):
+        try:
+            for _ in range(5):
+                for i in range(lo, hi):
+                    results[i] = eng.searchArrays(queries[i], 10)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(i * 2, i * 2 + 2)) for i in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for a, b in zip(serial, results):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    st = eng.debugBufferPoolStats()
+    assert 1 <= st.transientAllocations <= eng.getTuning("slots") and st.reuseCount > 0
+    # pipelined tickets collected out of order
+    tickets = [eng.submit(q, 10) for q in queries[:4]]
+    for i in (2, 0, 3, 1):
+        got = eng.collect(tickets[i], 10)
+        assert np.array_equal(got[0], serial[i][0]) and np.array_equal(got[1], serial[i][1])
+    # batch API == per-query API
+    ids, scores, counts = eng.searchBatch(queries, 10)
+    assert np.all(counts == 10)
+    for i in range(len(queries)):
+        assert np.array_equal(ids[i], serial[i][0]) and np.array_equal(scores[i], serial[i][1])
+    # writer while readers are idle: still consistent
+    eng.add(10 ** 9, queries[0])
+    assert eng.search(queries[0], 1)[0][0] == 10 ** 9
+
+
+# ---------------------------------------------------------------------------
+# sharded path on one GPU: two engines = two shards, merged on device
+
+def test_shard_engines_merge_to_the_single_engine_answer(wax):
+    import torch
+    dims, n, k = 384, 40000, 10
+    corpus = oracle.gaussian_unit_rows(0, n, dims)
+    ids = np.arange(n, dtype=np.uint64) + 5000
+    whole = make_engine(wax, 0, dims, corpus, ids)
+    cuts = [0, 12800, 12800, 30016, n]  # includes an empty shard
+    shards = []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        e = wax.HIPVectorEngine(dimensions=dims)
+        if hi > lo:
+            e.addBatchDevice(ids[lo:hi], torch.from_numpy(corpus[lo:hi]).cuda().contiguous())
+        e.setRowBase(lo)
+        shards.append(e)
+    dev = torch.device("cuda", whole.device)
+    for q in oracle.gaussian_unit_queries(3, dims):
+        parts = [torch.empty((k, 2), dtype=torch.int64, device=dev) for _ in shards]
+        st = torch.cuda.current_stream().cuda_stream
+        for e, p in zip(shards, parts):
+            e.searchShardDevice(q, k, p.data_ptr(), st)
+        gathered = torch.cat(parts, dim=0).contiguous()
+        merged = torch.empty((k, 2), dtype=torch.int64, device=dev)
+        wax.HIPVectorEngine.mergeHitsDevice(gathered.data_ptr(), gathered.shape[0], k, merged.data_ptr(), st)
+        torch.cuda.synchronize()
+        got = wax.HIPVectorEngine.hitsToResults(wax.VectorMetric.cosine, merged.cpu().numpy())
+        exp = whole.searchArrays(q, k)
+        assert np.array_equal(got[0], exp[0]) and np.array_equal(got[1], exp[1])  # bit-identical at any shard count
+        from wax_amd import sharded
+        host = wax.HIPVectorEngine.hitsToResults(wax.VectorMetric.cosine,
+                                                 sharded.merge_hits_host(gathered.cpu().numpy(), k))
+        assert np.array_equal(host[0], exp[0]) and np.array_equal(host[1], exp[1])
+        check(whole, 0, corpus, ids, q, k, "whole")
+
+
+def test_sharded_searcher_single_rank_pipeline(wax):
+    from wax_amd import sharded
+    dims, n = 384, 20000
+    corpus = oracle.gaussian_unit_rows(0, n, dims)
+    eng = make_engine(wax, 0, dims, corpus)
+    queries = oracle.gaussian_unit_queries(12, dims)
+    for host_merge in (False, True):
+        s = sharded.ShardedSearcher(eng, rank=0, world=1, topK=10, depth=4, n_streams=2, host_merge=host_merge)
+        out = []
+        for i, q in enumerate(queries):
+            if len(s.inflight) == s.depth:
+                out.append(s.collect())
+            s.submit(q)
+        while s.inflight:
+            out.append(s.collect())
+        for q, got in zip(queries, out):
+            exp = eng.searchArrays(q, 10)
+            assert np.array_equal(got[0], exp[0]) and np.array_equal(got[1], exp[1])
+
+
+# ---------------------------------------------------------------------------
+# BASELINE.json sizes: size-independent properties (the oracle cannot scan these in seconds)
+
+def _device_corpus(torch, n, dims, dev, chunk=262144):
+    g = torch.Generator(device=dev)
+    for lo in range(0, n, chunk):
+        g.manual_seed(oracle.CORPUS_SEED + lo // chunk)
+        x = torch.randn((min(chunk, n - lo), dims), generator=g, device=dev, dtype=torch.float32)
+        yield lo, torch.nn.functional.normalize(x, dim=1).contiguous()
+
+
+@pytest.mark.parametrize("n,dims", [(1_000_000, 384), (10_000_000, 384), (1_000_000, 768)])
+def test_full_size_properties(wax, n, dims):
+    import torch
+    dev = torch.device("cuda", 0)
+    eng = wax.HIPVectorEngine(dimensions=dims)
+    eng.reserve(n)
+    half_a, half_b = wax.HIPVectorEngine(dimensions=dims), wax.HIPVectorEngine(dimensions=dims)
+    split = (n // 2 // 64) * 64
+    do_halves = n <= 1_000_000
+    rng = np.random.default_rng(11)
+    sample_rows = np.sort(rng.choice(n, 4096, replace=False))
+    sample = np.empty((4096, dims), dtype=np.float32)
+    for lo, x in _device_corpus(torch, n, dims, dev):
+        hi = lo + x.shape[0]
+        eng.addBatchDevice(np.arange(lo, hi, dtype=np.uint64), x)
+        if do_halves:
+            if hi <= split:
+                half_a.addBatchDevice(np.arange(lo, hi, dtype=np.uint64), x)
+            elif lo >= split:
+                half_b.addBatchDevice(np.arange(lo, hi, dtype=np.uint64), x)
+            else:
+                half_a.addBatchDevice(np.arange(lo, split, dtype=np.uint64), x[:split - lo].contiguous())
+                half_b.addBatchDevice(np.arange(split, hi, dtype=np.uint64), x[split - lo:].contiguous())
+        sel = sample_rows[(sample_rows >= lo) & (sample_rows < hi)]
+        if len(sel):
+            sample[np.searchsorted(sample_rows, sel)] = x[torch.from_numpy(sel - lo).to(dev)].cpu().numpy()
+    assert eng.count == n
+    k = 10
+    for qi, q in enumerate(oracle.gaussian_unit_queries(3, dims)):
+        ids, scores = eng.searchArrays(q, k)
+        assert len(ids) == k and np.all(np.diff(scores) <= 0) and len(set(ids.tolist())) == k
+        again = eng.searchArrays(q, k)
+        assert np.array_equal(ids, again[0]) and np.array_equal(scores, again[1])       # idempotent
+        # no sampled row may beat the k-th hit unless it is one of the hits; sampled hits score exactly
+        sd = oracle.distances(0, sample, q)
+        ss = 1.0 - sd
+        in_hits = np.isin(sample_rows, ids.astype(np.int64))
+        assert np.all(ss[~in_hits] <= scores[-1] + 1e-5)
+        for r, s in zip(sample_rows[in_hits], ss[in_hits]):
+            assert abs(scores[list(ids).index(r)] - s) <= 1e-5
+        if do_halves:                                                                   # shard-union property
+            a = half_a.searchArrays(q, k)
+            half_b.setRowBase(split)
+            b = half_b.searchArrays(q, k)
+            allids = np.concatenate([a[0], b[0]])
+            allsc = np.concatenate([a[1], b[1]])
+            order = np.lexsort((allids, -allsc.astype(np.float64)))[:k]
+            assert np.array_equal(allids[order], ids) and np.array_equal(allsc[order], scores)
+    # self-retrieval: a stored row is its own nearest neighbour with score 1
+    for r, v in zip(sample_rows[:6], sample[:6]):
+        ids, scores = eng.searchArrays(v, 1)
+        assert ids[0] == r and abs(scores[0] - 1.0) <= 1e-5
+    # the timing entry points used by bench.py work at this size
+    ms = eng.timeScanKernel(sample[0], 10, 3)
+    rd = eng.timeStreamRead(3)
+    assert ms > 0 and rd > 0
+    print(f"\n[{n}x{dims}] scan {ms:.3f} ms = {n * dims * 4 / ms / 1e6:.0f} GB/s ; stream-read {rd:.3f} ms = "
+          f"{n * dims * 4 / rd / 1e6:.0f} GB/s")

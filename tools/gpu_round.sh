@@ -1,0 +1,48 @@
+#!/bin/bash
+# One GPU-box session: smoke, GPU parity tests, bench, rocprofv3 traces, tuning sweep.
+# Usage (from the repo root, through gpurun):  bash tools/gpu_round.sh <tag> [stages...]
+# Everything is written under gpurun_out/<tag>/ ; each stage has its own timeout so a hang
+# cannot eat the whole session.
+set -u
+TAG=${1:-r01}; shift || true
+STAGES=${*:-"smoke tests bench prof pmc sweep"}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd "$R"
+export TMPDIR=/tmp
+echo "== $(date) stages: $STAGES" | tee "$OUT/session.log"
+rocm-smi --showproductname 2>/dev/null | head -8 >> "$OUT/session.log"
+nproc >> "$OUT/session.log"
+
+for s in $STAGES; do
+  t0=$(date +%s)
+  case $s in
+    smoke)
+      timeout 600 python __graft_entry__.py --smoke > "$OUT/smoke.log" 2>&1; rc=$? ;;
+    tests)
+      timeout 1500 python -m pytest tests -m gpu -q -rA --durations=15 -p no:cacheprovider > "$OUT/pytest_gpu.log" 2>&1; rc=$? ;;
+    tests_x)
+      timeout 1500 python -m pytest tests -m gpu -x -q -p no:cacheprovider > "$OUT/pytest_gpu_x.log" 2>&1; rc=$? ;;
+    bench)
+      timeout 900 python bench.py --gpus 1 > "$OUT/bench.json" 2> "$OUT/bench.err"; rc=$? ;;
+    prof)
+      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_stats" -o bench -- \
+          python "$R/bench.py" --gpus 1 --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/prof_bench.json" 2> "$OUT/prof.err"); rc=$?
+      find "$OUT/prof_stats" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \; 2>/dev/null
+      find "$OUT/prof_stats" -name "*kernel_trace.csv" -exec sh -c 'head -400 "$1" > "$2"' _ {} "$OUT/kernel_trace_head.csv" \; 2>/dev/null
+      find "$OUT/prof_stats" -name "*kernel_trace.csv" -delete 2>/dev/null ;;
+    pmc)
+      (cd /tmp && timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/prof_pmc" -o pmc -- \
+          python "$R/bench.py" --gpus 1 --steps 20 --warmup 2 --no-cpu-baseline > "$OUT/pmc_bench.json" 2> "$OUT/pmc.err"); rc=$?
+      python tools/pmc_summary.py "$OUT/prof_pmc" > "$OUT/pmc_summary.json" 2>> "$OUT/pmc.err"
+      find "$OUT/prof_pmc" -name "*.csv" -size +2M -delete 2>/dev/null ;;
+    sweep)
+      timeout 1200 python tools/sweep.py --tag "$TAG" > "$OUT/sweep.log" 2>&1; rc=$?
+      cp gpurun_out/sweep_$TAG.json "$OUT/" 2>/dev/null ;;
+    *) echo "unknown stage $s"; rc=99 ;;
+  esac
+  echo "== stage $s rc=$rc $(( $(date +%s) - t0 ))s" | tee -a "$OUT/session.log"
+done
+tail -5 "$OUT/pytest_gpu.log" 2>/dev/null
+cat "$OUT/bench.json" 2>/dev/null

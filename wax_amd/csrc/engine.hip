@@ -226,6 +226,8 @@ struct wax_hip_engine {
     float* ring_d_query[kShardRing] = {};
     float* ring_h_query[kShardRing] = {};
     int64_t* ring_d_partials[kShardRing] = {};
+    hipEvent_t ring_ev0[kShardRing] = {}, ring_ev1[kShardRing] = {};
+    bool ring_ev_pending[kShardRing] = {};
     std::atomic<uint32_t> ring_next{0};
 
     float* d_sink = nullptr;
@@ -452,6 +454,17 @@ int hits_to_results(uint8_t metric, const wax_hip_hit* hits, uint32_t n, uint64_
     return WAX_HIP_OK;
 }
 
+// Fold a finished shard-path scan's event pair into the kernel-time statistics.
+void harvest_ring_event(wax_hip_engine* e, int r) {
+    std::unique_lock<std::mutex> sg(e->st_mu);
+    if (!e->ring_ev_pending[r]) return;
+    e->ring_ev_pending[r] = false;
+    float ms = 0.f;
+    if (hipEventSynchronize(e->ring_ev1[r]) == hipSuccess && hipEventElapsedTime(&ms, e->ring_ev0[r], e->ring_ev1[r]) == hipSuccess) {
+        e->st_last_ms = ms; e->st_total_ms += ms; e->st_timed += 1;
+    }
+}
+
 bool device_is_gfx950(int dev) {
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, dev) != hipSuccess) return false;
@@ -541,6 +554,8 @@ void wax_hip_engine_destroy(wax_hip_engine* e) {
         (void)hipFree(e->ring_d_query[i]);
         (void)hipHostFree(e->ring_h_query[i]);
         (void)hipFree(e->ring_d_partials[i]);
+        if (e->ring_ev0[i]) (void)hipEventDestroy(e->ring_ev0[i]);
+        if (e->ring_ev1[i]) (void)hipEventDestroy(e->ring_ev1[i]);
     }
     (void)hipFree(e->d_store);
     (void)hipFree(e->d_ids);
@@ -827,6 +842,8 @@ int wax_hip_search_shard_device(wax_hip_engine* e, const float* query, uint32_t 
                 hipError_t err = hipMalloc(&e->ring_d_query[r], (size_t)e->dims * sizeof(float));
                 if (err == hipSuccess) err = hipHostMalloc(&e->ring_h_query[r], (size_t)e->dims * sizeof(float), hipHostMallocDefault);
                 if (err == hipSuccess) err = hipMalloc(&e->ring_d_partials[r], (size_t)MAX_GRID_BLOCKS * FUSED_MAX_K * sizeof(int64_t));
+                if (err == hipSuccess) err = hipEventCreate(&e->ring_ev0[r]);
+                if (err == hipSuccess) err = hipEventCreate(&e->ring_ev1[r]);
                 if (err != hipSuccess) { rc = fail(WAX_HIP_ERR_ALLOC, std::string("Failed to allocate shard scratch: ") + hipGetErrorString(err)); break; }
             }
         }
@@ -842,7 +859,14 @@ int wax_hip_search_shard_device(wax_hip_engine* e, const float* query, uint32_t 
         const float qn = query_norm(query, dims);
         hipError_t err = hipMemcpyAsync(e->ring_d_query[r], e->ring_h_query[r], (size_t)dims * sizeof(float), hipMemcpyHostToDevice, st);
         if (err != hipSuccess) { rc = fail(WAX_HIP_ERR_INTERNAL, std::string("query upload: ") + hipGetErrorString(err)); break; }
-        rc = enqueue_scan(e, e->ring_d_query[r], qn, k_eff, kpad, e->ring_d_partials[r], nullptr, d_out_hits, st, nullptr, nullptr);
+        harvest_ring_event(e, (int)r);  // the entry's previous use (kShardRing calls ago) has long finished
+        const bool timed = e->time_kernels.load() != 0;
+        rc = enqueue_scan(e, e->ring_d_query[r], qn, k_eff, kpad, e->ring_d_partials[r], nullptr, d_out_hits, st,
+                          timed ? e->ring_ev0[r] : nullptr, timed ? e->ring_ev1[r] : nullptr);
+        if (rc == WAX_HIP_OK && timed) {
+            std::unique_lock<std::mutex> sg(e->st_mu);
+            e->ring_ev_pending[r] = true;
+        }
     } while (0);
     e->lock.unlock_shared();
     return rc;
@@ -951,6 +975,10 @@ int wax_hip_stats(wax_hip_engine* e, wax_hip_stats_t* out) {
     out->transient_allocations = e->st_alloc.load();
     out->reuse_count = e->st_reuse.load();
     out->reserved_rows = e->capacity;
+    {
+        DeviceGuard g(e->device);
+        for (int r = 0; r < kShardRing; ++r) harvest_ring_event(e, r);
+    }
     std::unique_lock<std::mutex> sg(e->st_mu);
     out->last_scan_kernel_ms = e->st_last_ms;
     out->scan_kernel_ms_total = e->st_total_ms;
@@ -976,6 +1004,10 @@ int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value) {
         e->max_slots = (int)value;
     } else if (k == "reset_stats") {
         e->st_searches = 0; e->st_rows = 0; e->st_bytes = 0;
+        {
+            DeviceGuard g(e->device);
+            for (int r = 0; r < kShardRing; ++r) harvest_ring_event(e, r);
+        }
         std::unique_lock<std::mutex> sg(e->st_mu);
         e->st_last_ms = 0; e->st_total_ms = 0; e->st_timed = 0;
     } else return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "unknown tuning key '" + k + "'");
