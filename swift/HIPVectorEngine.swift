@@ -1,0 +1,144 @@
+//  HIPVectorEngine.swift — the reference-side binding a Wax maintainer adds under
+//  Sources/WaxVectorSearch/ to drop libwaxhip in beside MetalVectorEngine / USearchVectorEngine.
+//
+//  NOT compiled in this repository (the build image has no Swift toolchain); it is the literal
+//  counterpart of wax_amd/engine.py, which IS exercised by the tests through the same C ABI.
+//  Conforms to `VectorSearchEngine` (VectorSearchEngine.swift:10-18) and mirrors the concrete
+//  surface callers use on MetalVectorEngine (isAvailable, init(metric:dimensions:), load(from:),
+//  serialize/deserialize, addBatchStreaming).
+
+#if canImport(CWaxHIP)
+import CWaxHIP
+import Foundation
+import WaxCore
+
+public actor HIPVectorEngine {
+    private let handle: OpaquePointer
+    private let metric: VectorMetric
+    public let dimensions: Int
+    private var dirty = false
+    // Blocking C calls hop onto a dedicated queue exactly like USearchVectorEngine does
+    // (USearchVectorEngine.swift:66, 208); the library itself takes the reader/writer lock.
+    private let io = BlockingIOExecutor(label: "wax.hip.vector", qos: .userInitiated)
+
+    public static var isAvailable: Bool { wax_hip_available() != 0 }
+
+    public init(metric: VectorMetric, dimensions: Int, device: Int32 = -1) throws {
+        guard dimensions > 0 else { throw WaxError.invalidToc(reason: "dimensions must be > 0") }
+        guard dimensions <= Constants.maxEmbeddingDimensions else {
+            throw WaxError.capacityExceeded(limit: UInt64(Constants.maxEmbeddingDimensions), requested: UInt64(dimensions))
+        }
+        var h: OpaquePointer?
+        try Self.check(wax_hip_engine_create(metric.toVecSimilarity().rawValue, UInt32(dimensions), device, &h))
+        self.handle = h!
+        self.metric = metric
+        self.dimensions = dimensions
+    }
+
+    deinit { wax_hip_engine_destroy(handle) }
+
+    public static func load(from wax: Wax, metric: VectorMetric, dimensions: Int) async throws -> HIPVectorEngine {
+        let engine = try HIPVectorEngine(metric: metric, dimensions: dimensions)
+        if let bytes = try await wax.readCommittedVecIndexBytes() { try await engine.deserialize(bytes) }
+        for e in await wax.pendingEmbeddingMutations() { try await engine.add(frameId: e.frameId, vector: e.vector) }
+        return engine
+    }
+
+    /// wax_hip_status -> WaxError (INTEGRATION.md §3)
+    private static func check(_ rc: Int32) throws {
+        guard rc != 0 else { return }
+        let msg = String(cString: wax_hip_last_error())
+        switch rc {
+        case -1, -7: throw WaxError.encodingError(reason: msg)          // DIM_MISMATCH, INVALID_ARGUMENT
+        case -2: throw WaxError.capacityExceeded(limit: UInt64(UInt32.max), requested: 0)
+        default: throw WaxError.invalidToc(reason: msg)                 // NO_DEVICE, ALLOC, BAD_SEGMENT, METRIC, INTERNAL
+        }
+    }
+
+    public func search(vector: [Float], topK: Int) async throws -> [(frameId: UInt64, score: Float)] {
+        let h = handle
+        let n = Int(wax_hip_count(h))
+        let cap = max(1, min(max(1, min(topK, 10_000)), max(n, 1)))
+        let k32 = Int32(clamping: topK)
+        return try await io.run {
+            var ids = [UInt64](repeating: 0, count: cap)
+            var scores = [Float](repeating: 0, count: cap)
+            var got: UInt32 = 0
+            try Self.check(vector.withUnsafeBufferPointer { q in
+                wax_hip_search(h, q.baseAddress, UInt32(vector.count), k32, &ids, &scores, &got)
+            })
+            return (0..<Int(got)).map { (frameId: ids[$0], score: scores[$0]) }
+        }
+    }
+
+    public func add(frameId: UInt64, vector: [Float]) async throws {
+        let h = handle
+        try await io.run {
+            try Self.check(vector.withUnsafeBufferPointer { wax_hip_add(h, frameId, $0.baseAddress, UInt32(vector.count)) })
+        }
+        dirty = true
+    }
+
+    public func addBatch(frameIds: [UInt64], vectors: [[Float]]) async throws {
+        guard !frameIds.isEmpty else { return }
+        guard frameIds.count == vectors.count else {
+            throw WaxError.encodingError(reason: "addBatch: frameIds.count != vectors.count")
+        }
+        for v in vectors where v.count != dimensions {
+            throw WaxError.encodingError(reason: "vector dimension mismatch: expected \(dimensions), got \(v.count)")
+        }
+        let flat = vectors.flatMap { $0 }   // row-major n x dims, one H2D copy inside the library
+        let h = handle, d = UInt32(dimensions)
+        try await io.run {
+            try Self.check(flat.withUnsafeBufferPointer { rows in
+                frameIds.withUnsafeBufferPointer { ids in
+                    wax_hip_add_batch(h, ids.baseAddress, rows.baseAddress, UInt64(frameIds.count), d)
+                }
+            })
+        }
+        dirty = true
+    }
+
+    public func addBatchStreaming(frameIds: [UInt64], vectors: [[Float]], chunkSize: Int = 256) async throws {
+        for start in stride(from: 0, to: frameIds.count, by: chunkSize) {
+            let end = min(start + chunkSize, frameIds.count)
+            try await addBatch(frameIds: Array(frameIds[start..<end]), vectors: Array(vectors[start..<end]))
+        }
+    }
+
+    public func remove(frameId: UInt64) async throws {
+        let h = handle
+        try await io.run { try Self.check(wax_hip_remove(h, frameId)) }
+        dirty = true
+    }
+
+    public func serialize() async throws -> Data {
+        let h = handle
+        return try await io.run {
+            var p: UnsafeMutablePointer<UInt8>?
+            var len = 0
+            try Self.check(wax_hip_serialize(h, &p, &len))
+            defer { wax_hip_free(p) }
+            return Data(bytes: p!, count: len)   // "MV2V" encoding 2, byte-identical to MetalVectorEngine.serialize
+        }
+    }
+
+    public func deserialize(_ data: Data) async throws {
+        let h = handle
+        try await io.run {
+            try Self.check(data.withUnsafeBytes { wax_hip_deserialize(h, $0.bindMemory(to: UInt8.self).baseAddress, data.count) })
+        }
+        dirty = false
+    }
+
+    public func stageForCommit(into wax: Wax) async throws {
+        if !dirty { return }
+        let blob = try await serialize()
+        try await wax.stageVecIndexForNextCommit(bytes: blob, vectorCount: wax_hip_count(handle),
+                                                 dimension: UInt32(dimensions), similarity: metric.toVecSimilarity())
+        dirty = false
+    }
+}
+
+extension HIPVectorEngine: VectorSearchEngine {}
+#endif
