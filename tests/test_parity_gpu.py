@@ -196,18 +196,27 @@ def test_special_values(wax):
     dims = 384
     corpus = oracle.gaussian_unit_rows(0, 300, dims)
     corpus[5] = 0.0                      # zero row => similarity 0 (CosineDistance.metal:323)
-    corpus[7, 3] = np.nan                # NaN row => dropped (MetalVectorEngine.swift:597)
+    corpus[7, 3] = np.nan                # NaN row: `sqrt(m) > 1e-6` is false => similarity 0, like the Metal kernel
     corpus[9] *= np.float32(1e-4)        # tiny but > 1e-6 norm: still a valid direction
     eng = make_engine(wax, 0, dims, corpus)
     q = oracle.gaussian_unit_queries(1, dims)[0]
     ids, scores = eng.searchArrays(q, 300)
-    assert 7 not in ids and len(ids) == 299
-    assert scores[list(ids).index(5)] == 0.0
-    clean = corpus.copy()
-    clean[7] = 0.0
-    e_ids, e_scores, _, _ = oracle.search(0, np.delete(clean, 7, axis=0), np.delete(np.arange(300, dtype=np.uint64), 7), q, 300)
+    assert len(ids) == 300
+    assert scores[list(ids).index(5)] == 0.0 and scores[list(ids).index(7)] == 0.0
+    e_ids, e_scores, _, _ = oracle.search(0, corpus, None, q, 300)
     x = dict(zip(e_ids.tolist(), e_scores.tolist()))
     assert max(abs(x[int(i)] - float(s)) for i, s in zip(ids, scores)) <= 1e-5
+    # dot metric: a NaN row has a NaN distance => dropped on the host (MetalVectorEngine.swift:597)
+    deng = make_engine(wax, 1, dims, corpus)
+    dids, dscores = deng.searchArrays(q, 300)
+    assert 7 not in dids and len(dids) == 299 and np.all(np.isfinite(dscores))
+    # +inf component => NaN/inf distance under l2 => dropped as well
+    corpus2 = corpus.copy()
+    corpus2[7] = corpus[8]
+    corpus2[11, 0] = np.inf
+    leng = make_engine(wax, 2, dims, corpus2)
+    lids, lscores = leng.searchArrays(q, 300)
+    assert 11 not in lids and len(lids) == 299
     # zero query: every similarity is 0 => first k rows by index
     zids, zscores = eng.searchArrays(np.zeros(dims, np.float32), 4)
     assert list(zids) == [0, 1, 2, 3] and np.all(zscores == 0.0)

@@ -108,11 +108,28 @@ class LibraryMissing(RuntimeError):
 _lib = None
 
 
+def _preload_torch_hip_runtime() -> None:
+    """PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64. Two HIP runtimes
+    in one process fight over the device (whichever initialises second sees "no ROCm-capable
+    device"), so when torch is installed it must load ITS runtime first; libwaxhip.so (NEEDED
+    libamdhip64.so.7) then binds to the copy already in the process. A host without torch
+    (the Swift / C++ case) just uses the system ROCm runtime."""
+    if os.environ.get("WAX_HIP_NO_TORCH_PRELOAD"):
+        return
+    try:
+        import torch  # noqa: F401
+        if getattr(torch.version, "hip", None):
+            torch.cuda.is_available()  # dlopens torch/lib/libamdhip64.so and initialises it
+    except Exception:  # noqa: BLE001 — torch absent or broken: system runtime only
+        pass
+
+
 def lib() -> ctypes.CDLL:
     """Load libwaxhip.so and bind every declared symbol. Fails loudly if absent."""
     global _lib
     if _lib is not None:
         return _lib
+    _preload_torch_hip_runtime()
     path = _build.LIB_PATH
     if not os.path.exists(path):
         raise LibraryMissing(

@@ -712,11 +712,11 @@ int wax_hip_search_submit(wax_hip_engine* e, const float* query, uint32_t dims, 
         const float qn = query_norm(query, dims);
         hipError_t err = hipMemcpyAsync(s->d_query, s->h_query, (size_t)dims * sizeof(float), hipMemcpyHostToDevice, s->stream);
         if (err != hipSuccess) { rc = fail(WAX_HIP_ERR_INTERNAL, std::string("query upload: ") + hipGetErrorString(err)); break; }
-        rc = enqueue_scan(e, s->d_query, qn, k_eff, k_eff, s->d_partials, s, s->d_hits, s->stream,
+        // The last kernel of the chain writes the k hits straight into the slot's pinned host buffer
+        // (device-visible, 16*k bytes over PCIe): no D2H copy launch; visibility at ev_done.
+        rc = enqueue_scan(e, s->d_query, qn, k_eff, k_eff, s->d_partials, s, s->h_hits, s->stream,
                           s->timed ? s->ev0 : nullptr, s->timed ? s->ev1 : nullptr);
         if (rc != WAX_HIP_OK) break;
-        err = hipMemcpyAsync(s->h_hits, s->d_hits, (size_t)k_eff * sizeof(wax_hip_hit), hipMemcpyDeviceToHost, s->stream);
-        if (err != hipSuccess) { rc = fail(WAX_HIP_ERR_INTERNAL, std::string("result download: ") + hipGetErrorString(err)); break; }
         err = hipEventRecord(s->ev_done, s->stream);
         if (err != hipSuccess) { rc = fail(WAX_HIP_ERR_INTERNAL, std::string("event record: ") + hipGetErrorString(err)); break; }
     } while (0);

@@ -247,10 +247,20 @@ bool scan_variant_info(uint32_t dims, int variant, ScanVariantInfo* out) {
 int scan_grid_for(uint32_t n_rows, uint32_t dims, int variant, int grid_cap) {
     ScanVariantInfo info;
     if (!scan_variant_info(dims, variant, &info)) scan_variant_info(dims, 0, &info);
-    if (grid_cap <= 0) grid_cap = 2048;  // 256 CUs x 8 workgroups: enough waves to cover HBM latency
+    // Default 1024 workgroups = 4 per CU, all co-resident (89 VGPRs => 5 waves/SIMD); the on-device
+    // sweep (profiles/r01_sweep.md) shows 512..8192 within 1 % of each other at 10M x 384.
+    if (grid_cap <= 0) grid_cap = 1024;
     if (grid_cap > MAX_GRID_BLOCKS) grid_cap = MAX_GRID_BLOCKS;
     const uint64_t nchunks = ((uint64_t)n_rows + info.rows_per_chunk - 1) / info.rows_per_chunk;
-    uint64_t blocks = (nchunks + SCAN_WAVES - 1) / SCAN_WAVES;
+    const uint64_t max_waves = (uint64_t)grid_cap * SCAN_WAVES;
+    uint64_t waves = nchunks;
+    if (nchunks > max_waves) {
+        // Balance the grid-stride loop: every wave runs the same number of iterations (+-1 chunk
+        // in total) instead of leaving a mostly idle last iteration (26 % idle at 1M x 384).
+        const uint64_t iters = (nchunks + max_waves - 1) / max_waves;
+        waves = (nchunks + iters - 1) / iters;
+    }
+    uint64_t blocks = (waves + SCAN_WAVES - 1) / SCAN_WAVES;
     if (blocks < 1) blocks = 1;
     if (blocks > (uint64_t)grid_cap) blocks = grid_cap;
     return (int)blocks;
@@ -355,12 +365,21 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_keys_kernel(const int64_t
     const int wave = (int)(threadIdx.x >> 6);
     WaveTopK<CAP> tk;
     tk.init(lds + wave * CAP, k);
-    for (uint32_t base = wave * WAVE; base < n_in; base += MERGE_THREADS) {
-        const uint32_t i = base + lane;
-        const bool inb = i < n_in;
-        const int64_t key = inb ? in[i] : KEY_PAD;
-        tk.make_room(WAVE);
-        tk.push(key, inb && key != KEY_PAD);
+    // MERGE_LOADS independent coalesced loads per lane are issued before the first push, so the
+    // loop is not a chain of dependent global-load latencies (31 us -> few us at 20K keys).
+    constexpr int MERGE_LOADS = 4;
+    for (uint32_t base = 0; base < n_in; base += MERGE_THREADS * MERGE_LOADS) {
+        int64_t keys[MERGE_LOADS];
+#pragma unroll
+        for (int r = 0; r < MERGE_LOADS; ++r) {
+            const uint32_t i = base + r * MERGE_THREADS + threadIdx.x;
+            keys[r] = (i < n_in) ? in[i] : KEY_PAD;
+        }
+#pragma unroll
+        for (int r = 0; r < MERGE_LOADS; ++r) {
+            tk.make_room(WAVE);
+            tk.push(keys[r], keys[r] != KEY_PAD);
+        }
     }
     tk.finalize();
     if (lane == 0) counts[wave] = tk.cnt;
