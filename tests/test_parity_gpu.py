@@ -493,3 +493,112 @@ def test_full_size_properties(wax, n, dims):
     assert ms > 0 and rd > 0
     print(f"\n[{n}x{dims}] scan {ms:.3f} ms = {n * dims * 4 / ms / 1e6:.0f} GB/s ; stream-read {rd:.3f} ms = "
           f"{n * dims * 4 / rd / 1e6:.0f} GB/s")
+
+
+# ---------------------------------------------------------------------------
+# batched queries: bf16 MFMA GEMM + select + exact f32 re-score + certificate (BASELINE configs 3 / 5)
+
+def _batch_vs_single(eng, queries, k):
+    ids, scores, counts = eng.searchBatch(queries, k)
+    for i, q in enumerate(queries):
+        s_ids, s_scores = eng.searchArrays(q, k)
+        assert counts[i] == len(s_ids), (i, counts[i], len(s_ids))
+        assert np.array_equal(ids[i, :counts[i]], s_ids), (i, ids[i, :counts[i]], s_ids)
+        assert np.array_equal(scores[i, :counts[i]], s_scores), (i, scores[i, :counts[i]], s_scores)  # bit-identical
+    return ids, scores, counts
+
+
+@pytest.mark.parametrize("metric,dims", [(0, 384), (0, 128), (0, 768), (1, 384), (2, 384), (0, 64), (2, 1024)])
+def test_batch_mfma_path_is_exact(wax, metric, dims):
+    n, k = 40000, 10
+    corpus = oracle.gaussian_unit_rows(0, n, dims)
+    if metric != 0:
+        corpus = corpus * np.linspace(0.5, 2.0, n, dtype=np.float32)[:, None]
+    ids = np.arange(n, dtype=np.uint64) + 77
+    eng = make_engine(wax, metric, dims, corpus, ids)
+    queries = oracle.gaussian_unit_queries(200, dims)
+    before = eng.getTuning("batch_queries")
+    b_ids, b_scores, counts = _batch_vs_single(eng, queries, k)
+    assert eng.getTuning("batch_queries") - before == 200            # the MFMA path actually ran
+    fallbacks = eng.getTuning("batch_fallbacks")
+    print(f"\n[batch m{metric} d{dims}] certificate fallbacks: {fallbacks}/200")
+    if metric == 0:  # unit-norm cosine: the rank-10 .. rank-64 gap dwarfs the bf16 bound
+        assert fallbacks <= 20, f"certificate failed for {fallbacks}/200 random queries"
+    for i in (0, 57, 199):                                            # and the answers are the oracle's
+        e_ids, e_scores, _, _ = oracle.search(metric, corpus, ids, queries[i], k)
+        x = oracle.search(metric, corpus, ids, queries[i], k + MARGIN)[1]
+        assert_parity(b_ids[i], b_scores[i], e_ids, e_scores, x, f"batch m{metric} d{dims} q{i}")
+
+
+def test_batch_edge_shapes(wax):
+    dims = 384
+    corpus = oracle.gaussian_unit_rows(0, 30000, dims)
+    eng = make_engine(wax, 0, dims, corpus)
+    for nq, k in [(16, 10), (17, 1), (130, 30), (1029, 10), (64, 80)]:
+        _batch_vs_single(eng, oracle.gaussian_unit_queries(nq, dims, seed=100 + nq), k)
+    # k above the MFMA limit and batches below batch_min fall back to pipelined single-query scans
+    before = eng.getTuning("batch_queries")
+    _batch_vs_single(eng, oracle.gaussian_unit_queries(20, dims), 100)
+    _batch_vs_single(eng, oracle.gaussian_unit_queries(5, dims), 10)
+    assert eng.getTuning("batch_queries") == before
+    # fewer rows than k': every row is re-scored, certificate is trivially true
+    small = make_engine(wax, 0, dims, corpus[:50])
+    ids, scores, counts = _batch_vs_single(small, oracle.gaussian_unit_queries(40, dims), 10)
+    assert small.getTuning("batch_fallbacks") == 0
+    tiny = make_engine(wax, 0, dims, corpus[:3])
+    ids, scores, counts = _batch_vs_single(tiny, oracle.gaussian_unit_queries(32, dims), 10)
+    assert np.all(counts == 3)
+    # tiny score-tile budget => many slabs / segments
+    eng.setTuning("batch_slab_mb", 1)
+    _batch_vs_single(eng, oracle.gaussian_unit_queries(100, dims, seed=5), 10)
+    eng.setTuning("batch_slab_mb", 64)
+    # mutation invalidates the bf16 mirror
+    probe = oracle.gaussian_unit_queries(32, dims, seed=9)
+    eng.add(10 ** 7, probe[3])
+    ids, scores, counts = eng.searchBatch(probe, 5)
+    assert ids[3, 0] == 10 ** 7 and abs(scores[3, 0] - 1.0) <= 1e-5
+    eng.remove(10 ** 7)
+    ids, scores, counts = eng.searchBatch(probe, 5)
+    assert 10 ** 7 not in ids
+    # the loop path gives the same answers
+    eng.setTuning("batch_mode", 0)
+    l_ids, l_scores, l_counts = eng.searchBatch(probe, 5)
+    assert np.array_equal(ids, l_ids) and np.array_equal(scores, l_scores)
+    eng.setTuning("batch_mode", 1)
+
+
+def test_batch_certificate_falls_back_on_ties(wax):
+    """Exact duplicates tie in bf16 and in f32: the certificate must refuse them and the exact
+    path must still return the (distance asc, row asc) answer."""
+    n, dims = 20000, 128
+    corpus = oracle.tie_pattern(0, n, dims)
+    eng = make_engine(wax, 0, dims, corpus)
+    queries = np.abs(oracle.gaussian_unit_queries(48, dims))
+    _batch_vs_single(eng, queries, 24)
+    assert eng.getTuning("batch_fallbacks") > 0
+
+
+def test_batch_throughput_config3(wax):
+    """BASELINE config 3 shape: 1M x 384, 256 queries, bf16 MFMA + fused select + f32 re-score."""
+    import time
+    import torch
+    n, dims, nq, k = 1_000_000, 384, 256, 10
+    dev = torch.device("cuda", 0)
+    eng = wax.HIPVectorEngine(dimensions=dims)
+    eng.reserve(n)
+    for lo, x in _device_corpus(torch, n, dims, dev):
+        eng.addBatchDevice(np.arange(lo, lo + x.shape[0], dtype=np.uint64), x)
+    queries = oracle.gaussian_unit_queries(nq, dims)
+    eng.searchBatch(queries, k)                       # builds the mirror
+    t0 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        ids, scores, counts = eng.searchBatch(queries, k)
+    dt = (time.perf_counter() - t0) / reps
+    fb = eng.getTuning("batch_fallbacks")
+    print(f"\n[config3 1Mx384 Q=256] {dt * 1e3:.2f} ms/batch = {nq / dt:.0f} q/s, "
+          f"{2 * nq * n * dims / dt / 1e12:.1f} TFLOP/s bf16, fallbacks so far {fb}")
+    for i in (0, 100, 255):
+        s_ids, s_scores = eng.searchArrays(queries[i], k)
+        assert np.array_equal(ids[i], s_ids) and np.array_equal(scores[i], s_scores)
+    assert fb <= 3 * 26

@@ -1,0 +1,525 @@
+// batch.hip — batched queries: Q x D^T as a bf16 MFMA GEMM on the matrix cores, per-query
+// candidate selection, exact f32 re-score, and an exactness certificate.
+//
+// The reference has no batched entry point (one `search(vector:topK:)` per query,
+// MetalVectorEngine.swift:446-627); BASELINE.json configs 3 and 5 ask for this path because
+// with Q >= 32 queries the scan is a genuine dense GEMM (arithmetic intensity Q flop per
+// corpus byte) and belongs on MFMA, not on the HBM-bound VALU kernel.
+//
+// Pipeline (all on one stream, corpus processed in slabs so the score tile stays in the
+// 256 MiB Infinity Cache):
+//   mirror_kernel        f32 store -> bf16 mirror (RNE) + 1/||v||, ||v||^2, max ||v||   (once per mutation)
+//   batch_gemm_kernel    S[q][r] = approx distance from bf16 x bf16 -> f32 MFMA (v_mfma_f32_32x32x16_bf16)
+//   select_scores_kernel per (query, 16K-row segment) top-k' by the same WaveTopK machinery as the scan
+//   merge_query_keys     per query: segments*k' -> k' candidates (approx order)
+//   rescore_kernel       exact f32 distance of every candidate, SAME lane mapping / summation order
+//                        as scan_kernel => bit-identical to the single-query path
+//   finalize_batch       sort by exact key, emit top-k hits + certificate:
+//                        a non-candidate's approx distance >= a_max (the k'-th approx), so its exact
+//                        distance >= a_max - eps (eps = rigorous bf16 rounding bound); if that is
+//                        > the exact k-th best, the answer is provably the exact top-k. Otherwise the
+//                        host re-runs that query on the exact single-query path.
+#include "kernels.h"
+#include "topk.h"
+
+namespace wax {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+enum { BM_COS = WAX_HIP_METRIC_COSINE, BM_DOT = WAX_HIP_METRIC_DOT, BM_L2 = WAX_HIP_METRIC_L2 };
+
+__device__ inline unsigned short f32_to_bf16_rne(float x) {
+    unsigned int b = __float_as_uint(x);
+    if ((b & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((b >> 16) | 0x0040u);  // quiet NaN
+    b += 0x7fffu + ((b >> 16) & 1u);
+    return (unsigned short)(b >> 16);
+}
+
+// ---------------------------------------------------------------------------
+// f32 rows -> bf16 rows (RNE). normalize=1 (cosine): each row is scaled by 1/||v|| first (0 if
+// ||v|| <= 1e-6, CosineDistance.metal:323), so the GEMM epilogue is just d = 1 - acc.
+// Also emits ||v||^2 (L2 epilogue) and the global max ||v|| (certificate bound for dot / L2).
+// One wave per row; used for the corpus mirror and for the query block (rows in
+// [n_rows, n_rows_padded) are zero-filled).
+__global__ __launch_bounds__(256) void mirror_kernel(const float* __restrict__ src, uint32_t n_rows,
+                                                     uint32_t n_rows_padded, uint32_t dims, int normalize,
+                                                     unsigned short* __restrict__ dst, float* __restrict__ norm2,
+                                                     unsigned int* __restrict__ max_norm_bits) {
+    const int lane = lane_id();
+    const uint32_t gwave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t nwaves = gridDim.x * 4;
+    const bool vec4 = (dims & 3u) == 0;
+    for (uint32_t r = gwave; r < n_rows_padded; r += nwaves) {
+        unsigned short* out = dst + (size_t)r * dims;
+        if (r >= n_rows) {
+            for (uint32_t c = lane; c < dims; c += WAVE) out[c] = 0;
+            if (lane == 0) norm2[r] = 0.f;
+            continue;
+        }
+        const float* row = src + (size_t)r * dims;
+        float acc = 0.f;
+        if (vec4) {
+            const f32x4* row4 = reinterpret_cast<const f32x4*>(row);
+            for (uint32_t c = lane; c < (dims >> 2); c += WAVE) {
+                const f32x4 v = row4[c];
+                acc = fmaf(v.x, v.x, acc); acc = fmaf(v.y, v.y, acc); acc = fmaf(v.z, v.z, acc); acc = fmaf(v.w, v.w, acc);
+            }
+        } else {
+            for (uint32_t c = lane; c < dims; c += WAVE) acc = fmaf(row[c], row[c], acc);
+        }
+        acc = group_sum<64>(acc);
+        acc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 63));  // the total lives in lane 63
+        const float n = sqrtf(acc);
+        const float scale = normalize ? ((n > 1e-6f) ? 1.0f / n : 0.0f) : 1.0f;
+        if (vec4) {
+            const f32x4* row4 = reinterpret_cast<const f32x4*>(row);
+            u16x4* out4 = reinterpret_cast<u16x4*>(out);
+            for (uint32_t c = lane; c < (dims >> 2); c += WAVE) {
+                const f32x4 v = row4[c];
+                u16x4 o;
+                o.x = f32_to_bf16_rne(v.x * scale); o.y = f32_to_bf16_rne(v.y * scale);
+                o.z = f32_to_bf16_rne(v.z * scale); o.w = f32_to_bf16_rne(v.w * scale);
+                out4[c] = o;
+            }
+        } else {
+            for (uint32_t c = lane; c < dims; c += WAVE) out[c] = f32_to_bf16_rne(row[c] * scale);
+        }
+        if (lane == 0) {
+            norm2[r] = acc;
+            if (max_norm_bits != nullptr && n == n) atomicMax(max_norm_bits, __float_as_uint(n));
+        }
+    }
+}
+
+hipError_t launch_mirror(const float* src, uint32_t n_rows, uint32_t n_rows_padded, uint32_t dims, int normalize,
+                         unsigned short* dst, float* norm2, unsigned int* max_norm_bits, hipStream_t st) {
+    if (n_rows_padded == 0) return hipSuccess;
+    uint64_t blocks = ((uint64_t)n_rows_padded + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(mirror_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, n_rows, n_rows_padded, dims, normalize,
+                       dst, norm2, max_norm_bits);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// bf16 GEMM tile: 128 queries (M) x 128 corpus rows (N), K chunks of 64, 4 waves each 64x64
+// (2x2 v_mfma_f32_32x32x16_bf16 blocks). Both operands are K-contiguous ("NT" GEMM), so every
+// MFMA fragment is one 16-byte read. LDS rows are padded 128 -> 144 B: ds_read_b128 is
+// bank-conflict-free for the MFMA lane groups (MI355X_MICROARCH.md §LDS). The next K chunk is
+// prefetched into registers while the current one is multiplied.
+constexpr int GM = 128, GN = 128, GK = 64;
+constexpr int LDS_STRIDE = GK + 8;  // bf16 elements per LDS row (144 bytes)
+
+template <int METRIC>
+__global__ __launch_bounds__(256) void batch_gemm_kernel(GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned short As[GM * LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[GN * LDS_STRIDE];
+
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const uint32_t qt = blockIdx.x % a.nqt;          // query tiles of one corpus tile are adjacent in launch order
+    const uint32_t ct = blockIdx.x / a.nqt;
+    const uint32_t m0 = qt * GM;
+    const uint32_t n0 = a.slab0 + ct * GN;
+    const uint32_t D = a.dims;
+
+    // staging map: 1024 16-byte segments per operand tile, 4 per thread; 8 consecutive threads
+    // cover one 128-byte row chunk.
+    const int seg = tid & 7;
+    const int srow = tid >> 3;  // 0..31
+    const u32x4* gA[4];
+    const u32x4* gB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t qrow = m0 + srow + 32 * i;                       // always < nq_pad
+        uint32_t crow = n0 + srow + 32 * i;
+        crow = crow < a.n_rows ? crow : a.n_rows - 1;                    // clamp: masked at the store
+        gA[i] = reinterpret_cast<const u32x4*>(a.qb + (size_t)qrow * D) + seg;
+        gB[i] = reinterpret_cast<const u32x4*>(a.cb + (size_t)crow * D) + seg;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    u32x4 ra[4], rb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { ra[i] = gA[i][0]; rb[i] = gB[i][0]; }
+
+    const uint32_t nchunks = D / GK;
+    for (uint32_t kc = 0; kc < nchunks; ++kc) {
+        __syncthreads();  // previous chunk's fragment reads are done
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<u32x4*>(&As[(srow + 32 * i) * LDS_STRIDE + seg * 8]) = ra[i];
+            *reinterpret_cast<u32x4*>(&Bs[(srow + 32 * i) * LDS_STRIDE + seg * 8]) = rb[i];
+        }
+        __syncthreads();
+        if (kc + 1 < nchunks) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { ra[i] = gA[i][(kc + 1) * 8]; rb[i] = gB[i][(kc + 1) * 8]; }
+        }
+#pragma unroll
+        for (int ks = 0; ks < GK / 16; ++ks) {
+            bf16x8 fa[2], fb[2];
+            const int kofs = ks * 16 + 8 * (lane >> 5);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const u32x4 ua = *reinterpret_cast<const u32x4*>(&As[(wm * 64 + i * 32 + (lane & 31)) * LDS_STRIDE + kofs]);
+                const u32x4 ub = *reinterpret_cast<const u32x4*>(&Bs[(wn * 64 + i * 32 + (lane & 31)) * LDS_STRIDE + kofs]);
+                fa[i] = __builtin_bit_cast(bf16x8, ua);
+                fb[i] = __builtin_bit_cast(bf16x8, ub);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31 (corpus row),
+    // row = (r&3) + 8*(r>>2) + 4*(lane>>5) (query). For a fixed register the 32 lanes of a half-wave
+    // store 128 contiguous bytes of one query's score row. Padding queries (q >= nq) are stored too
+    // (the score buffer has nq_pad rows); only the corpus-row tail is masked.
+    float* qn2 = reinterpret_cast<float*>(As);
+    if (METRIC == BM_L2) {
+        __syncthreads();
+        if (tid < GM) qn2[tid] = a.q_n2[m0 + tid];
+        __syncthreads();
+    }
+    const uint32_t slab_end = a.slab0 + a.slab_rows;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const uint32_t row = n0 + wn * 64 + j * 32 + (lane & 31);
+        if (row >= slab_end) continue;
+        float vn2 = 0.f;
+        if (METRIC == BM_L2) vn2 = a.v_n2[row];
+        float* __restrict__ dst = a.scores + (row - a.slab0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qloc = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float dot = acc[i][j][r];
+                float d;
+                if (METRIC == BM_L2) d = qn2[qloc] + vn2 - 2.0f * dot;
+                else d = 1.0f - dot;  // cosine: both operands were normalised by mirror_kernel; dot: USearch ip
+                d = (d != d) ? __builtin_inff() : d;
+                dst[(size_t)(m0 + qloc) * a.slab_ld] = d + 0.0f;
+            }
+        }
+    }
+}
+
+hipError_t launch_batch_gemm(const GemmArgs& a, int metric, hipStream_t st) {
+    const uint32_t ctiles = (a.slab_rows + GN - 1) / GN;
+    const dim3 grid(ctiles * a.nqt);
+    switch (metric) {
+        case BM_COS: hipLaunchKernelGGL((batch_gemm_kernel<BM_COS>), grid, dim3(256), 0, st, a); break;
+        case BM_DOT: hipLaunchKernelGGL((batch_gemm_kernel<BM_DOT>), grid, dim3(256), 0, st, a); break;
+        case BM_L2: hipLaunchKernelGGL((batch_gemm_kernel<BM_L2>), grid, dim3(256), 0, st, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Per (query, segment) top-k' over the slab's score tile.
+constexpr uint32_t SEG_ROWS = 16384;
+
+template <int CAP>
+__global__ __launch_bounds__(SCAN_THREADS) void select_scores_kernel(const float* __restrict__ scores, uint32_t slab_ld,
+                                                                    uint32_t slab0, uint32_t slab_rows,
+                                                                    uint32_t row_base, int kp, uint32_t seg_first,
+                                                                    uint32_t segs_total, int64_t* __restrict__ partials) {
+    __shared__ int64_t lds[SCAN_WAVES * CAP + SCAN_WAVES];
+    const int lane = lane_id();
+    const int wave = (int)(threadIdx.x >> 6);
+    const uint32_t q = blockIdx.y;
+    const uint32_t s = blockIdx.x;
+    const uint32_t r0 = s * SEG_ROWS;
+    const uint32_t r1 = (r0 + SEG_ROWS < slab_rows) ? r0 + SEG_ROWS : slab_rows;
+    const float* __restrict__ src = scores + (size_t)q * slab_ld;
+    WaveTopK<CAP> tk;
+    tk.init(lds + wave * CAP, kp);
+    constexpr int LOADS = 4;
+    for (uint32_t base = r0; base < r1; base += SCAN_THREADS * LOADS) {
+        float d[LOADS];
+        uint32_t rr[LOADS];
+#pragma unroll
+        for (int i = 0; i < LOADS; ++i) {
+            rr[i] = base + i * SCAN_THREADS + threadIdx.x;
+            d[i] = (rr[i] < r1) ? src[rr[i]] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < LOADS; ++i) {
+            tk.make_room(WAVE);
+            tk.push(make_key(d[i], row_base + slab0 + rr[i]), rr[i] < r1);
+        }
+    }
+    int* counts = reinterpret_cast<int*>(lds + SCAN_WAVES * CAP);
+    tk.finalize();
+    if (lane == 0) counts[wave] = tk.cnt;
+    __syncthreads();
+    block_rank_merge<SCAN_WAVES>(lds, CAP, counts, kp, partials + ((size_t)q * segs_total + seg_first + s) * kp);
+}
+
+hipError_t launch_select_scores(const float* scores, uint32_t slab_ld, uint32_t slab0, uint32_t slab_rows,
+                                uint32_t row_base, int kp, uint32_t nq, uint32_t seg_first, uint32_t segs_total,
+                                int64_t* partials, hipStream_t st) {
+    const uint32_t segs = (slab_rows + SEG_ROWS - 1) / SEG_ROWS;
+    const dim3 grid(segs, nq);
+    if (kp <= 64)
+        hipLaunchKernelGGL((select_scores_kernel<128>), grid, dim3(SCAN_THREADS), 0, st, scores, slab_ld, slab0, slab_rows,
+                           row_base, kp, seg_first, segs_total, partials);
+    else
+        hipLaunchKernelGGL((select_scores_kernel<256>), grid, dim3(SCAN_THREADS), 0, st, scores, slab_ld, slab0, slab_rows,
+                           row_base, kp, seg_first, segs_total, partials);
+    return hipGetLastError();
+}
+
+// Per query: segs_total*kp partial keys -> kp candidates, ascending by approx key.
+template <int CAP>
+__global__ __launch_bounds__(SCAN_THREADS) void merge_query_keys_kernel(const int64_t* __restrict__ partials,
+                                                                       uint32_t n_in, int kp,
+                                                                       int64_t* __restrict__ cand) {
+    __shared__ int64_t lds[SCAN_WAVES * CAP + SCAN_WAVES];
+    const int lane = lane_id();
+    const int wave = (int)(threadIdx.x >> 6);
+    const int64_t* __restrict__ in = partials + (size_t)blockIdx.x * n_in;
+    WaveTopK<CAP> tk;
+    tk.init(lds + wave * CAP, kp);
+    constexpr int LOADS = 4;
+    for (uint32_t base = 0; base < n_in; base += SCAN_THREADS * LOADS) {
+        int64_t keys[LOADS];
+#pragma unroll
+        for (int i = 0; i < LOADS; ++i) {
+            const uint32_t idx = base + i * SCAN_THREADS + threadIdx.x;
+            keys[i] = (idx < n_in) ? in[idx] : KEY_PAD;
+        }
+#pragma unroll
+        for (int i = 0; i < LOADS; ++i) {
+            tk.make_room(WAVE);
+            tk.push(keys[i], keys[i] != KEY_PAD);
+        }
+    }
+    int* counts = reinterpret_cast<int*>(lds + SCAN_WAVES * CAP);
+    tk.finalize();
+    if (lane == 0) counts[wave] = tk.cnt;
+    __syncthreads();
+    block_rank_merge<SCAN_WAVES>(lds, CAP, counts, kp, cand + (size_t)blockIdx.x * kp);
+}
+
+hipError_t launch_merge_query_keys(const int64_t* partials, uint32_t n_in, int kp, uint32_t nq, int64_t* cand,
+                                   hipStream_t st) {
+    if (kp <= 64)
+        hipLaunchKernelGGL((merge_query_keys_kernel<128>), dim3(nq), dim3(SCAN_THREADS), 0, st, partials, n_in, kp, cand);
+    else
+        hipLaunchKernelGGL((merge_query_keys_kernel<256>), dim3(nq), dim3(SCAN_THREADS), 0, st, partials, n_in, kp, cand);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Exact f32 re-score of the candidates with scan_kernel's lane mapping and summation order.
+template <int METRIC>
+__device__ inline float finish_distance_b(float acc, float nrm, float q_norm) {
+    float d;
+    if (METRIC == BM_COS) {
+        const float vn = sqrtf(nrm);
+        const float sim = (vn > 1e-6f && q_norm > 1e-6f) ? acc / (vn * q_norm) : 0.0f;
+        d = 1.0f - sim;
+    } else if (METRIC == BM_DOT) {
+        d = 1.0f - acc;
+    } else {
+        d = acc;
+    }
+    d = (d != d) ? __builtin_inff() : d;
+    return d + 0.0f;
+}
+
+template <int METRIC>
+__device__ inline void accumulate_b(const f32x4& q, const f32x4& v, f32x4& acc, f32x4& nrm) {
+    if (METRIC == BM_L2) {
+        const f32x4 e = q - v;
+        acc = __builtin_elementwise_fma(e, e, acc);
+    } else {
+        acc = __builtin_elementwise_fma(q, v, acc);
+        if (METRIC == BM_COS) nrm = __builtin_elementwise_fma(v, v, nrm);
+    }
+}
+
+__device__ inline float hsum_b(const f32x4& a) { return (a.x + a.y) + (a.z + a.w); }
+
+template <int D4, int GROUP, int METRIC>
+__global__ __launch_bounds__(256) void rescore_kernel(RescoreArgs a) {
+    constexpr int LOADS = D4 / GROUP;
+    constexpr int RPW = WAVE / GROUP;
+    const int lane = lane_id();
+    const int sub = lane / GROUP, gl = lane % GROUP;
+    const uint32_t pair = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + sub;
+    const uint32_t total = a.nq * (uint32_t)a.kp;
+    const bool in_range = pair < total;
+    const uint32_t p = in_range ? pair : total - 1;
+    const uint32_t q = p / (uint32_t)a.kp;
+    const int64_t ck = a.cand[p];
+    const bool live = in_range && ck != KEY_PAD;
+    const uint32_t grow = key_row(ck);
+    uint32_t lrow = grow - a.row_base;
+    lrow = (live && lrow < a.n_rows) ? lrow : 0;
+    const f32x4* __restrict__ v4 = reinterpret_cast<const f32x4*>(a.store) + (size_t)lrow * D4 + gl;
+    const f32x4* __restrict__ q4 = reinterpret_cast<const f32x4*>(a.queries) + (size_t)q * D4 + gl;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, nrm = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < LOADS; ++j) accumulate_b<METRIC>(q4[j * GROUP], v4[j * GROUP], acc, nrm);
+    const float s = group_sum<GROUP>(hsum_b(acc));
+    float m = 0.f;
+    if (METRIC == BM_COS) m = group_sum<GROUP>(hsum_b(nrm));
+    const float d = finish_distance_b<METRIC>(s, m, a.q_norm[q]);
+    if (in_range && gl == GROUP - 1) a.exact[p] = live ? make_key(d, grow) : KEY_PAD;
+}
+
+template <int METRIC>
+__global__ __launch_bounds__(256) void rescore_generic_kernel(RescoreArgs a) {
+    const int lane = lane_id();
+    const uint32_t pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t total = a.nq * (uint32_t)a.kp;
+    if (pair >= total) return;  // whole wave exits together
+    const uint32_t q = pair / (uint32_t)a.kp;
+    const int64_t ck = a.cand[pair];
+    const bool live = ck != KEY_PAD;
+    const uint32_t grow = key_row(ck);
+    uint32_t lrow = grow - a.row_base;
+    lrow = (live && lrow < a.n_rows) ? lrow : 0;
+    const uint32_t D = a.dims;
+    const float* row = a.store + (size_t)lrow * D;
+    const float* qv = a.queries + (size_t)q * D;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, nrm = {0.f, 0.f, 0.f, 0.f};
+    if ((D & 3u) == 0) {
+        const f32x4* row4 = reinterpret_cast<const f32x4*>(row);
+        const f32x4* q4 = reinterpret_cast<const f32x4*>(qv);
+        for (uint32_t c = lane; c < (D >> 2); c += WAVE) accumulate_b<METRIC>(q4[c], row4[c], acc, nrm);
+    } else {
+        for (uint32_t c = lane; c < D; c += WAVE) {
+            const f32x4 qq = {qv[c], 0.f, 0.f, 0.f};
+            const f32x4 vv = {row[c], 0.f, 0.f, 0.f};
+            accumulate_b<METRIC>(qq, vv, acc, nrm);
+        }
+    }
+    const float s = group_sum<64>(hsum_b(acc));
+    float m = 0.f;
+    if (METRIC == BM_COS) m = group_sum<64>(hsum_b(nrm));
+    const float d = finish_distance_b<METRIC>(s, m, a.q_norm[q]);
+    if (lane == WAVE - 1) a.exact[pair] = live ? make_key(d, grow) : KEY_PAD;
+}
+
+template <int D4, int GROUP>
+static hipError_t launch_rescore_t(const RescoreArgs& a, int metric, hipStream_t st) {
+    constexpr int RPW = WAVE / GROUP;
+    const uint32_t total = a.nq * (uint32_t)a.kp;
+    const dim3 grid((total + 4 * RPW - 1) / (4 * RPW));
+    switch (metric) {
+        case BM_COS: hipLaunchKernelGGL((rescore_kernel<D4, GROUP, BM_COS>), grid, dim3(256), 0, st, a); break;
+        case BM_DOT: hipLaunchKernelGGL((rescore_kernel<D4, GROUP, BM_DOT>), grid, dim3(256), 0, st, a); break;
+        case BM_L2: hipLaunchKernelGGL((rescore_kernel<D4, GROUP, BM_L2>), grid, dim3(256), 0, st, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_rescore(const RescoreArgs& a, int metric, hipStream_t st) {
+    switch (a.dims) {  // must mirror launch_scan's (D4, GROUP) table so distances are bit-identical
+        case 64: return launch_rescore_t<16, 16>(a, metric, st);
+        case 128: return launch_rescore_t<32, 32>(a, metric, st);
+        case 256: return launch_rescore_t<64, 64>(a, metric, st);
+        case 384: return launch_rescore_t<96, 32>(a, metric, st);
+        case 512: return launch_rescore_t<128, 64>(a, metric, st);
+        case 768: return launch_rescore_t<192, 64>(a, metric, st);
+        case 1024: return launch_rescore_t<256, 64>(a, metric, st);
+        case 1536: return launch_rescore_t<384, 64>(a, metric, st);
+        default: break;
+    }
+    const uint32_t total = a.nq * (uint32_t)a.kp;
+    const dim3 grid((total + 3) / 4);
+    switch (metric) {
+        case BM_COS: hipLaunchKernelGGL((rescore_generic_kernel<BM_COS>), grid, dim3(256), 0, st, a); break;
+        case BM_DOT: hipLaunchKernelGGL((rescore_generic_kernel<BM_DOT>), grid, dim3(256), 0, st, a); break;
+        case BM_L2: hipLaunchKernelGGL((rescore_generic_kernel<BM_L2>), grid, dim3(256), 0, st, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Per query: order the kp exact keys, emit the best k as hits, and certify.
+__global__ __launch_bounds__(256) void finalize_batch_kernel(const int64_t* __restrict__ cand,
+                                                             const int64_t* __restrict__ exact, int kp, int k,
+                                                             const float* __restrict__ eps,
+                                                             const uint64_t* __restrict__ ids, uint32_t row_base,
+                                                             uint32_t n_rows, wax_hip_hit* __restrict__ out,
+                                                             uint32_t* __restrict__ certified) {
+    __shared__ int64_t keys[FUSED_MAX_K];
+    __shared__ int64_t sorted[FUSED_MAX_K];
+    const uint32_t q = blockIdx.x;
+    const int t = (int)threadIdx.x;
+    if (t < kp) {
+        keys[t] = exact[(size_t)q * kp + t];
+        sorted[t] = KEY_PAD;
+    }
+    __syncthreads();
+    if (t < kp) {
+        const int64_t mine = keys[t];
+        if (mine != KEY_PAD) {
+            int rank = 0;
+            for (int j = 0; j < kp; ++j) rank += (keys[j] < mine || (keys[j] == mine && j < t)) ? 1 : 0;
+            sorted[rank] = mine;
+        }
+    }
+    __syncthreads();
+    if (t < k) {
+        wax_hip_hit h;
+        h.key = sorted[t];
+        h.frame_id = ID_PAD;
+        if (h.key != KEY_PAD) {
+            const uint32_t local = key_row(h.key) - row_base;
+            h.frame_id = (ids != nullptr && local < n_rows) ? ids[local] : (uint64_t)key_row(h.key);
+        }
+        out[(size_t)q * k + t] = h;
+    }
+    if (t == 0) {
+        const int64_t last_cand = cand[(size_t)q * kp + (kp - 1)];
+        uint32_t ok;
+        if (last_cand == KEY_PAD) {
+            ok = 1;  // fewer than kp rows exist: every row was re-scored exactly
+        } else {
+            const float a_max = key_distance(last_cand);      // k'-th smallest approx distance
+            const int64_t kth = sorted[k - 1];
+            const float tau = (kth == KEY_PAD) ? __builtin_inff() : key_distance(kth);
+            ok = (a_max - eps[q] > tau) ? 1u : 0u;             // strict: ties stay uncertified
+        }
+        certified[q] = ok;
+    }
+}
+
+hipError_t launch_finalize_batch(const int64_t* cand, const int64_t* exact, int kp, int k, const float* eps,
+                                 const uint64_t* ids, uint32_t row_base, uint32_t n_rows, uint32_t nq,
+                                 wax_hip_hit* out, uint32_t* certified, hipStream_t st) {
+    if (kp > FUSED_MAX_K || k > kp || k < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(finalize_batch_kernel, dim3(nq), dim3(256), 0, st, cand, exact, kp, k, eps, ids, row_base, n_rows,
+                       out, certified);
+    return hipGetLastError();
+}
+
+uint32_t batch_seg_rows() { return SEG_ROWS; }
+
+}  // namespace wax

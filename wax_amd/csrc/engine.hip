@@ -196,6 +196,40 @@ struct Slot {
     bool timed = false;
 };
 
+// Workspace of the batched (bf16 MFMA) path; one batch at a time per engine.
+struct BatchWork {
+    std::mutex mu;
+    // corpus mirror (rebuilt lazily after any mutation)
+    unsigned short* d_cb = nullptr;
+    float* d_vn2 = nullptr;
+    unsigned int* d_maxnorm = nullptr;
+    uint64_t mirror_cap = 0;
+    bool mirror_valid = false;
+    float max_norm = 0.f;
+    // per-call buffers (sized for kBatchMaxQ queries on first use, scores/partials grown on demand)
+    float* d_q = nullptr;
+    unsigned short* d_qb = nullptr;
+    float* d_qn2 = nullptr;
+    float* d_qnorm = nullptr;
+    float* d_eps = nullptr;
+    float* d_scores = nullptr;
+    uint64_t scores_cap = 0;
+    int64_t* d_partials = nullptr;
+    uint64_t partials_cap = 0;
+    int64_t* d_cand = nullptr;
+    int64_t* d_exact = nullptr;
+    wax_hip_hit* d_hits = nullptr;
+    uint32_t* d_cert = nullptr;
+    wax_hip_hit* h_hits = nullptr;   // pinned
+    uint32_t* h_cert = nullptr;      // pinned
+    float* h_qnorm = nullptr;        // pinned
+    float* h_eps = nullptr;          // pinned
+    bool ready = false;
+};
+
+constexpr uint32_t kBatchMaxQ = 1024;   // queries per GEMM pass
+constexpr int kBatchMaxK = 80;          // largest k served by the MFMA path (k' = 2k+32 <= 192)
+
 }  // namespace
 
 struct wax_hip_engine {
@@ -239,6 +273,11 @@ struct wax_hip_engine {
     std::atomic<int64_t> time_kernels{0};
     std::atomic<int64_t> force_general{0};
     std::atomic<int64_t> stream_nt{1};
+    std::atomic<int64_t> batch_min{16};      // fewer queries than this: pipelined single-query scans
+    std::atomic<int64_t> batch_mode{1};      // 0 = never use the MFMA path
+    std::atomic<int64_t> batch_slab_mb{64};  // score-tile budget (kept inside the Infinity Cache)
+    std::atomic<uint64_t> st_batch_queries{0}, st_batch_fallbacks{0};
+    BatchWork batch;
 
     // stats
     std::atomic<uint64_t> st_searches{0}, st_rows{0}, st_bytes{0}, st_alloc{0}, st_reuse{0};
@@ -465,6 +504,149 @@ void harvest_ring_event(wax_hip_engine* e, int r) {
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Batched path: Q x D^T on the matrix cores (batch.hip). Called with the shared lock held.
+// Fills results for certified queries; `need_exact[q]` is set for the ones whose certificate
+// failed (the caller re-runs those on the exact single-query path).
+int batch_prepare(wax_hip_engine* e, uint32_t nq_pad, uint64_t scores_elems, uint64_t partial_elems, hipStream_t st) {
+    BatchWork& b = e->batch;
+    const uint32_t D = e->dims;
+    if (!b.ready) {
+        HIP_TRY(hipMalloc(&b.d_maxnorm, sizeof(unsigned int)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch scalars");
+        HIP_TRY(hipMalloc(&b.d_q, (size_t)kBatchMaxQ * D * sizeof(float)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch queries");
+        HIP_TRY(hipMalloc(&b.d_qb, (size_t)kBatchMaxQ * D * sizeof(unsigned short)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch bf16 queries");
+        HIP_TRY(hipMalloc(&b.d_qn2, kBatchMaxQ * sizeof(float)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch norms");
+        HIP_TRY(hipMalloc(&b.d_qnorm, kBatchMaxQ * sizeof(float)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch norms");
+        HIP_TRY(hipMalloc(&b.d_eps, kBatchMaxQ * sizeof(float)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch eps");
+        HIP_TRY(hipMalloc(&b.d_cand, (size_t)kBatchMaxQ * FUSED_MAX_K * sizeof(int64_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch candidates");
+        HIP_TRY(hipMalloc(&b.d_exact, (size_t)kBatchMaxQ * FUSED_MAX_K * sizeof(int64_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch candidates");
+        HIP_TRY(hipMalloc(&b.d_hits, (size_t)kBatchMaxQ * kBatchMaxK * sizeof(wax_hip_hit)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch hits");
+        HIP_TRY(hipMalloc(&b.d_cert, kBatchMaxQ * sizeof(uint32_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch flags");
+        HIP_TRY(hipHostMalloc(&b.h_hits, (size_t)kBatchMaxQ * kBatchMaxK * sizeof(wax_hip_hit), hipHostMallocDefault), WAX_HIP_ERR_ALLOC, "Failed to allocate pinned batch hits");
+        HIP_TRY(hipHostMalloc(&b.h_cert, kBatchMaxQ * sizeof(uint32_t), hipHostMallocDefault), WAX_HIP_ERR_ALLOC, "Failed to allocate pinned batch flags");
+        HIP_TRY(hipHostMalloc(&b.h_qnorm, kBatchMaxQ * sizeof(float), hipHostMallocDefault), WAX_HIP_ERR_ALLOC, "Failed to allocate pinned batch norms");
+        HIP_TRY(hipHostMalloc(&b.h_eps, kBatchMaxQ * sizeof(float), hipHostMallocDefault), WAX_HIP_ERR_ALLOC, "Failed to allocate pinned batch eps");
+        b.ready = true;
+    }
+    if (b.mirror_cap < e->capacity) {
+        HIP_TRY(hipStreamSynchronize(st), WAX_HIP_ERR_INTERNAL, "batch sync");
+        (void)hipFree(b.d_cb); (void)hipFree(b.d_vn2);
+        b.d_cb = nullptr; b.d_vn2 = nullptr; b.mirror_cap = 0; b.mirror_valid = false;
+        HIP_TRY(hipMalloc(&b.d_cb, (size_t)e->capacity * D * sizeof(unsigned short)), WAX_HIP_ERR_ALLOC, "Failed to allocate bf16 mirror");
+        HIP_TRY(hipMalloc(&b.d_vn2, (size_t)e->capacity * sizeof(float)), WAX_HIP_ERR_ALLOC, "Failed to allocate row norms");
+        b.mirror_cap = e->capacity;
+    }
+    if (!b.mirror_valid) {
+        HIP_TRY(hipMemsetAsync(b.d_maxnorm, 0, sizeof(unsigned int), st), WAX_HIP_ERR_INTERNAL, "batch memset");
+        HIP_TRY(launch_mirror(e->d_store, (uint32_t)e->count, (uint32_t)e->count, D, e->metric == WAX_HIP_METRIC_COSINE ? 1 : 0,
+                              b.d_cb, b.d_vn2, b.d_maxnorm, st), WAX_HIP_ERR_INTERNAL, "mirror kernel launch");
+        unsigned int bits = 0;
+        HIP_TRY(hipMemcpyAsync(&bits, b.d_maxnorm, sizeof(bits), hipMemcpyDeviceToHost, st), WAX_HIP_ERR_INTERNAL, "max norm download");
+        HIP_TRY(hipStreamSynchronize(st), WAX_HIP_ERR_INTERNAL, "mirror sync");
+        std::memcpy(&b.max_norm, &bits, sizeof(float));
+        b.mirror_valid = true;
+    }
+    if (b.scores_cap < scores_elems) {
+        HIP_TRY(hipStreamSynchronize(st), WAX_HIP_ERR_INTERNAL, "batch sync");
+        (void)hipFree(b.d_scores); b.d_scores = nullptr; b.scores_cap = 0;
+        HIP_TRY(hipMalloc(&b.d_scores, (size_t)scores_elems * sizeof(float)), WAX_HIP_ERR_ALLOC, "Failed to allocate score tile");
+        b.scores_cap = scores_elems;
+    }
+    if (b.partials_cap < partial_elems) {
+        HIP_TRY(hipStreamSynchronize(st), WAX_HIP_ERR_INTERNAL, "batch sync");
+        (void)hipFree(b.d_partials); b.d_partials = nullptr; b.partials_cap = 0;
+        HIP_TRY(hipMalloc(&b.d_partials, (size_t)partial_elems * sizeof(int64_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch partials");
+        b.partials_cap = partial_elems;
+    }
+    (void)nq_pad;
+    return WAX_HIP_OK;
+}
+
+// Rigorous bound on |approx distance - exact distance| from rounding both operands to bf16
+// (unit roundoff 2^-9 each => 2^-8 (1 + 2^-10) per product, Cauchy-Schwarz over the row) plus
+// f32 accumulation (dims * 2^-24) and epilogue rounding.
+float batch_eps(uint8_t metric, float q_norm, float max_norm, uint32_t dims) {
+    const double u = 0.00390625 * (1.0 + 1.0 / 1024.0) + (double)dims * 5.97e-8 + 1e-6;
+    if (metric == WAX_HIP_METRIC_COSINE) return (float)(u * 1.001 + 1e-6);
+    const double qv = (double)q_norm * (double)max_norm;
+    if (metric == WAX_HIP_METRIC_DOT) return (float)(u * qv * 1.001 + 1e-6 * (1.0 + qv));
+    const double s = (double)q_norm * q_norm + (double)max_norm * max_norm;
+    return (float)(2.0 * u * qv * 1.001 + 4e-6 * (1.0 + s));
+}
+
+int batch_search_mfma(wax_hip_engine* e, const float* queries, uint32_t nq, int k_eff, uint64_t* out_ids,
+                      float* out_scores, uint32_t* out_counts, std::vector<uint8_t>& need_exact) {
+    BatchWork& b = e->batch;
+    std::unique_lock<std::mutex> bg(b.mu);
+    hipStream_t st = e->streams[0];
+    const uint32_t D = e->dims;
+    const uint32_t n = (uint32_t)e->count;
+    int kp = 2 * k_eff + 32;
+    if (kp < 64) kp = 64;
+    if (kp > FUSED_MAX_K) kp = FUSED_MAX_K;
+    const uint32_t SEG = batch_seg_rows();
+    for (uint32_t q0 = 0; q0 < nq; q0 += kBatchMaxQ) {
+        const uint32_t qn = (nq - q0 < kBatchMaxQ) ? nq - q0 : kBatchMaxQ;
+        const uint32_t nq_pad = (qn + 127u) & ~127u;
+        uint64_t slab = ((uint64_t)e->batch_slab_mb.load() << 20) / (4ull * nq_pad);
+        slab = (slab / SEG) * SEG;
+        if (slab < SEG) slab = SEG;
+        const uint64_t n_up = ((uint64_t)n + SEG - 1) / SEG * SEG;
+        if (slab > n_up) slab = n_up;
+        const uint32_t slab_rows_max = (uint32_t)slab;
+        const uint32_t segs_total = (n + SEG - 1) / SEG;
+        int rc = batch_prepare(e, nq_pad, (uint64_t)nq_pad * slab_rows_max, (uint64_t)qn * segs_total * (uint64_t)kp, st);
+        if (rc != WAX_HIP_OK) return rc;
+        const float* qsrc = queries + (uint64_t)q0 * D;
+        for (uint32_t q = 0; q < qn; ++q) {
+            b.h_qnorm[q] = query_norm(qsrc + (uint64_t)q * D, D);
+            b.h_eps[q] = batch_eps(e->metric, b.h_qnorm[q], b.max_norm, D);
+        }
+        HIP_TRY(hipMemcpyAsync(b.d_q, qsrc, (size_t)qn * D * sizeof(float), hipMemcpyHostToDevice, st), WAX_HIP_ERR_INTERNAL, "query upload");
+        HIP_TRY(hipMemcpyAsync(b.d_qnorm, b.h_qnorm, qn * sizeof(float), hipMemcpyHostToDevice, st), WAX_HIP_ERR_INTERNAL, "query norm upload");
+        HIP_TRY(hipMemcpyAsync(b.d_eps, b.h_eps, qn * sizeof(float), hipMemcpyHostToDevice, st), WAX_HIP_ERR_INTERNAL, "eps upload");
+        HIP_TRY(launch_mirror(b.d_q, qn, nq_pad, D, e->metric == WAX_HIP_METRIC_COSINE ? 1 : 0, b.d_qb, b.d_qn2, nullptr, st),
+                WAX_HIP_ERR_INTERNAL, "query mirror launch");
+        uint32_t seg_first = 0;
+        for (uint32_t s0 = 0; s0 < n; s0 += slab_rows_max) {
+            const uint32_t rows = (n - s0 < slab_rows_max) ? n - s0 : slab_rows_max;
+            GemmArgs g{};
+            g.qb = b.d_qb; g.cb = b.d_cb; g.q_n2 = b.d_qn2; g.v_n2 = b.d_vn2; g.scores = b.d_scores;
+            g.dims = D; g.n_rows = n; g.slab0 = s0; g.slab_rows = rows; g.slab_ld = slab_rows_max; g.nq = qn; g.nqt = nq_pad / 128;
+            HIP_TRY(launch_batch_gemm(g, e->metric, st), WAX_HIP_ERR_INTERNAL, "gemm kernel launch");
+            HIP_TRY(launch_select_scores(b.d_scores, slab_rows_max, s0, rows, (uint32_t)e->row_base, kp, qn, seg_first, segs_total,
+                                         b.d_partials, st), WAX_HIP_ERR_INTERNAL, "select kernel launch");
+            seg_first += (rows + SEG - 1) / SEG;
+        }
+        HIP_TRY(launch_merge_query_keys(b.d_partials, segs_total * (uint32_t)kp, kp, qn, b.d_cand, st), WAX_HIP_ERR_INTERNAL, "candidate merge launch");
+        RescoreArgs r{};
+        r.store = e->d_store; r.queries = b.d_q; r.q_norm = b.d_qnorm; r.cand = b.d_cand; r.exact = b.d_exact;
+        r.n_rows = n; r.row_base = (uint32_t)e->row_base; r.dims = D; r.nq = qn; r.kp = kp;
+        HIP_TRY(launch_rescore(r, e->metric, st), WAX_HIP_ERR_INTERNAL, "rescore kernel launch");
+        HIP_TRY(launch_finalize_batch(b.d_cand, b.d_exact, kp, k_eff, b.d_eps, e->d_ids, (uint32_t)e->row_base, n, qn, b.d_hits,
+                                      b.d_cert, st), WAX_HIP_ERR_INTERNAL, "finalize kernel launch");
+        HIP_TRY(hipMemcpyAsync(b.h_hits, b.d_hits, (size_t)qn * k_eff * sizeof(wax_hip_hit), hipMemcpyDeviceToHost, st), WAX_HIP_ERR_INTERNAL, "hits download");
+        HIP_TRY(hipMemcpyAsync(b.h_cert, b.d_cert, qn * sizeof(uint32_t), hipMemcpyDeviceToHost, st), WAX_HIP_ERR_INTERNAL, "flags download");
+        HIP_TRY(hipStreamSynchronize(st), WAX_HIP_ERR_INTERNAL, "batch search failed on device");
+        for (uint32_t q = 0; q < qn; ++q) {
+            const uint32_t gq = q0 + q;
+            if (b.h_cert[q]) {
+                hits_to_results(e->metric, b.h_hits + (size_t)q * k_eff, (uint32_t)k_eff, out_ids + (uint64_t)gq * k_eff,
+                                out_scores + (uint64_t)gq * k_eff, &out_counts[gq]);
+            } else {
+                need_exact[gq] = 1;
+                e->st_batch_fallbacks++;
+            }
+        }
+        e->st_batch_queries += qn;
+        e->st_searches += qn;
+        e->st_rows += (uint64_t)qn * n;
+        e->st_bytes += (uint64_t)n * D * 2ull;
+    }
+    return WAX_HIP_OK;
+}
+
 bool device_is_gfx950(int dev) {
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, dev) != hipSuccess) return false;
@@ -557,6 +739,14 @@ void wax_hip_engine_destroy(wax_hip_engine* e) {
         if (e->ring_ev0[i]) (void)hipEventDestroy(e->ring_ev0[i]);
         if (e->ring_ev1[i]) (void)hipEventDestroy(e->ring_ev1[i]);
     }
+    {
+        BatchWork& b = e->batch;
+        (void)hipFree(b.d_cb); (void)hipFree(b.d_vn2); (void)hipFree(b.d_maxnorm); (void)hipFree(b.d_q); (void)hipFree(b.d_qb);
+        (void)hipFree(b.d_qn2); (void)hipFree(b.d_qnorm); (void)hipFree(b.d_eps); (void)hipFree(b.d_scores);
+        (void)hipFree(b.d_partials); (void)hipFree(b.d_cand); (void)hipFree(b.d_exact); (void)hipFree(b.d_hits);
+        (void)hipFree(b.d_cert); (void)hipHostFree(b.h_hits); (void)hipHostFree(b.h_cert); (void)hipHostFree(b.h_qnorm);
+        (void)hipHostFree(b.h_eps);
+    }
     (void)hipFree(e->d_store);
     (void)hipFree(e->d_ids);
     (void)hipFree(e->d_sink);
@@ -587,6 +777,7 @@ int wax_hip_add_batch(wax_hip_engine* e, const uint64_t* frame_ids, const float*
     if (dims != e->dims) return fail(WAX_HIP_ERR_DIM_MISMATCH, dim_mismatch_msg(e->dims, dims));  // :367-370
     DeviceGuard g(e->device);
     WriteGuard w(e->lock);
+    e->batch.mirror_valid = false;
     int rc = reserve_rows(e, e->count + n);  // :379-380 (upper bound: every id new)
     if (rc != WAX_HIP_OK) return rc;
     const size_t row_bytes = (size_t)e->dims * sizeof(float);
@@ -630,6 +821,7 @@ int wax_hip_add_batch_device(wax_hip_engine* e, const uint64_t* frame_ids, const
     if (dims != e->dims) return fail(WAX_HIP_ERR_DIM_MISMATCH, dim_mismatch_msg(e->dims, dims));
     DeviceGuard g(e->device);
     WriteGuard w(e->lock);
+    e->batch.mirror_valid = false;
     for (uint64_t i = 0; i < n; ++i)
         if (e->idmap.find(frame_ids[i]) >= 0)
             return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "add_batch_device: frame id " + std::to_string(frame_ids[i]) + " already present (append-only path)");
@@ -660,6 +852,7 @@ int wax_hip_remove(wax_hip_engine* e, uint64_t frame_id) {
     DeviceGuard g(e->device);
     WriteGuard w(e->lock);
     if (e->count == 0) return WAX_HIP_OK;                 // :425
+    e->batch.mirror_valid = false;
     const int64_t idx = e->idmap.find(frame_id);
     if (idx < 0) return WAX_HIP_OK;                       // :426
     const uint64_t after = e->count - 1 - (uint64_t)idx;  // :431
@@ -784,6 +977,33 @@ int wax_hip_search_batch(wax_hip_engine* e, const float* queries, uint32_t nq, u
     const uint64_t cnt = e->count;
     const uint64_t limit = (uint64_t)clamp_topk(top_k);
     const uint64_t kcap = limit < cnt ? limit : cnt;
+    // Enough queries for the scan to be a dense GEMM: bf16 MFMA path with exact re-score; queries
+    // whose exactness certificate fails are re-run on the exact single-query path below.
+    if (e->batch_mode.load() != 0 && (int64_t)nq >= e->batch_min.load() && dims == e->dims && (dims % 64u) == 0 &&
+        cnt > 0 && kcap <= (uint64_t)kBatchMaxK && out_ids && out_scores) {
+        std::vector<uint8_t> need_exact(nq, 0);
+        int brc;
+        {
+            DeviceGuard g(e->device);
+            e->lock.lock_shared();
+            if (e->row_base + e->count > 0x100000000ull) {
+                e->lock.unlock_shared();
+                return fail(WAX_HIP_ERR_CAPACITY, "row_base + count exceeds UInt32 row indices");
+            }
+            const int k_eff = (int)((uint64_t)clamp_topk(top_k) < e->count ? (uint64_t)clamp_topk(top_k) : e->count);
+            brc = ((uint64_t)k_eff == kcap) ? batch_search_mfma(e, queries, nq, k_eff, out_ids, out_scores, out_counts, need_exact)
+                                            : fail(WAX_HIP_ERR_INTERNAL, "engine mutated during batch search");
+            e->lock.unlock_shared();
+        }
+        if (brc != WAX_HIP_OK) return brc;
+        for (uint32_t q = 0; q < nq; ++q) {
+            if (!need_exact[q]) continue;
+            int rc1 = wax_hip_search(e, queries + (uint64_t)q * dims, dims, top_k, out_ids + (uint64_t)q * kcap,
+                                     out_scores + (uint64_t)q * kcap, &out_counts[q]);
+            if (rc1 != WAX_HIP_OK) return rc1;
+        }
+        return WAX_HIP_OK;
+    }
     // Pipelined over the scratch-slot pool: up to `depth` scans in flight.
     const uint32_t depth = (uint32_t)(e->max_slots > 1 ? e->max_slots : 1);
     std::vector<uint64_t> tk(nq, 0);
@@ -948,6 +1168,7 @@ int wax_hip_deserialize(wax_hip_engine* e, const uint8_t* data, size_t len) {
 
     DeviceGuard g(e->device);
     WriteGuard w(e->lock);  // withWriteLock (:717)
+    e->batch.mirror_valid = false;
     // :790-792 — capacity only grows
     int rc = resize_store(e, n > e->capacity ? n : e->capacity);
     if (rc != WAX_HIP_OK) return rc;
@@ -994,6 +1215,9 @@ int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value) {
     else if (k == "time_kernels") e->time_kernels = value;
     else if (k == "force_general") e->force_general = value;
     else if (k == "stream_nt") e->stream_nt = value;
+    else if (k == "batch_min") e->batch_min = value;
+    else if (k == "batch_mode") e->batch_mode = value;
+    else if (k == "batch_slab_mb") { if (value < 1 || value > 4096) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_slab_mb must be 1..4096"); e->batch_slab_mb = value; }
     else if (k == "streams") {
         if (value < 1 || value > kMaxStreams) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "streams must be 1..4");
         std::unique_lock<std::mutex> g(e->slot_mu);
@@ -1022,6 +1246,11 @@ int64_t wax_hip_get_tuning(wax_hip_engine* e, const char* key) {
     if (k == "time_kernels") return e->time_kernels.load();
     if (k == "force_general") return e->force_general.load();
     if (k == "stream_nt") return e->stream_nt.load();
+    if (k == "batch_min") return e->batch_min.load();
+    if (k == "batch_mode") return e->batch_mode.load();
+    if (k == "batch_slab_mb") return e->batch_slab_mb.load();
+    if (k == "batch_queries") return (int64_t)e->st_batch_queries.load();
+    if (k == "batch_fallbacks") return (int64_t)e->st_batch_fallbacks.load();
     if (k == "slots") return e->max_slots;
     if (k == "streams") return e->n_streams;
     if (k == "variant_count") return scan_variant_count(e->dims);

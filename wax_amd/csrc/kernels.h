@@ -66,4 +66,43 @@ hipError_t launch_stream_read(const float* d_src, uint64_t bytes, int nt, int gr
 hipError_t device_shift_down(void* base, uint64_t dst_off, uint64_t src_off, uint64_t bytes, void* bounce,
                              uint64_t bounce_bytes, hipStream_t stream);
 
+
+// ---- batched queries (batch.hip): bf16 MFMA GEMM + select + exact f32 re-score + certificate ----
+struct GemmArgs {
+    const unsigned short* qb;   // [nq_pad][dims] bf16 queries (zero padded to a multiple of 128)
+    const unsigned short* cb;   // [n_rows][dims] bf16 corpus mirror
+    const float* q_n2;          // [nq_pad] ||q||^2 (L2 epilogue)
+    const float* v_n2;          // [n_rows] ||v||^2 (L2 epilogue)
+    float* scores;              // [nq_pad][slab_ld] approx distances of this slab
+    uint32_t dims;
+    uint32_t n_rows;
+    uint32_t slab0;
+    uint32_t slab_rows;
+    uint32_t slab_ld;
+    uint32_t nq;
+    uint32_t nqt;               // nq_pad / 128
+};
+struct RescoreArgs {
+    const float* store;
+    const float* queries;       // [nq][dims] f32
+    const float* q_norm;        // [nq]
+    const int64_t* cand;        // [nq][kp]
+    int64_t* exact;             // [nq][kp]
+    uint32_t n_rows, row_base, dims, nq;
+    int kp;
+};
+hipError_t launch_mirror(const float* src, uint32_t n_rows, uint32_t n_rows_padded, uint32_t dims, int normalize,
+                         unsigned short* dst, float* norm2, unsigned int* max_norm_bits, hipStream_t stream);
+hipError_t launch_batch_gemm(const GemmArgs& a, int metric, hipStream_t stream);
+hipError_t launch_select_scores(const float* scores, uint32_t slab_ld, uint32_t slab0, uint32_t slab_rows,
+                                uint32_t row_base, int kp, uint32_t nq, uint32_t seg_first, uint32_t segs_total,
+                                int64_t* partials, hipStream_t stream);
+hipError_t launch_merge_query_keys(const int64_t* partials, uint32_t n_in, int kp, uint32_t nq, int64_t* cand,
+                                   hipStream_t stream);
+hipError_t launch_rescore(const RescoreArgs& a, int metric, hipStream_t stream);
+hipError_t launch_finalize_batch(const int64_t* cand, const int64_t* exact, int kp, int k, const float* eps,
+                                 const uint64_t* ids, uint32_t row_base, uint32_t n_rows, uint32_t nq,
+                                 wax_hip_hit* out, uint32_t* certified, hipStream_t stream);
+uint32_t batch_seg_rows();
+
 }  // namespace wax

@@ -349,31 +349,72 @@ hipError_t launch_scan(const ScanArgs& a, int metric, int variant, int cap, bool
 }
 
 // ---------------------------------------------------------------------------
-// Final merge: grid*k per-workgroup keys -> k hits. One workgroup of 16 waves; each wave
-// filters a slice through its WaveTopK, then the workgroup rank-merges and looks up ids.
-// (a4's iterated topKReduceEntries passes, TopKReduction.metal:136-167, in one launch.)
+// Final merge: `n_lists` per-workgroup lists of k ascending keys -> k hits, one launch, one workgroup
+// (a4's iterated topKReduceEntries passes, TopKReduction.metal:136-167).
+//   stage 1: top-k over the list HEADS only (one key per list). With T = the k-th smallest head,
+//            a list whose head is > T cannot contribute: k lists already hold k keys <= T.
+//   stage 2: the <= k surviving lists (k*k keys) go through the same wave-private selection,
+//            the workgroup rank-merges, and frame ids are looked up.
+// 10 240 keys (1024 workgroups, k = 10) cost ~1 push + 1 prune per wave instead of ~10 + 4.
 template <int CAP>
-__global__ __launch_bounds__(MERGE_THREADS) void merge_keys_kernel(const int64_t* __restrict__ in, uint32_t n_in,
+__global__ __launch_bounds__(MERGE_THREADS) void merge_keys_kernel(const int64_t* __restrict__ in, uint32_t n_lists,
                                                                    int k, int kpad,
                                                                    const uint64_t* __restrict__ ids,
                                                                    uint32_t row_base, uint32_t n_rows,
                                                                    wax_hip_hit* __restrict__ out) {
-    __shared__ int64_t lds[MERGE_WAVES * CAP + MERGE_WAVES + FUSED_MAX_K];
+    __shared__ int64_t lds[MERGE_WAVES * CAP + MERGE_WAVES + 2 * FUSED_MAX_K + 1];
     int* counts = reinterpret_cast<int*>(lds + MERGE_WAVES * CAP);
     int64_t* fin = lds + MERGE_WAVES * CAP + MERGE_WAVES;
+    int* sel = reinterpret_cast<int*>(fin + FUSED_MAX_K);           // FUSED_MAX_K list indices
+    int* sel_count = reinterpret_cast<int*>(fin + 2 * FUSED_MAX_K);
     const int lane = lane_id();
     const int wave = (int)(threadIdx.x >> 6);
+    constexpr int MERGE_LOADS = 4;  // independent loads in flight per lane before the first push
+
     WaveTopK<CAP> tk;
     tk.init(lds + wave * CAP, k);
-    // MERGE_LOADS independent coalesced loads per lane are issued before the first push, so the
-    // loop is not a chain of dependent global-load latencies (31 us -> few us at 20K keys).
-    constexpr int MERGE_LOADS = 4;
-    for (uint32_t base = 0; base < n_in; base += MERGE_THREADS * MERGE_LOADS) {
+    for (uint32_t base = 0; base < n_lists; base += MERGE_THREADS * MERGE_LOADS) {
+        int64_t keys[MERGE_LOADS];
+#pragma unroll
+        for (int r = 0; r < MERGE_LOADS; ++r) {
+            const uint32_t b = base + r * MERGE_THREADS + threadIdx.x;
+            keys[r] = (b < n_lists) ? in[(size_t)b * k] : KEY_PAD;
+        }
+#pragma unroll
+        for (int r = 0; r < MERGE_LOADS; ++r) {
+            tk.make_room(WAVE);
+            tk.push(keys[r], keys[r] != KEY_PAD);
+        }
+    }
+    tk.finalize();
+    if (lane == 0) counts[wave] = tk.cnt;
+    if (threadIdx.x == 0) *sel_count = 0;
+    __syncthreads();
+    block_rank_merge<MERGE_WAVES>(lds, CAP, counts, k, fin);
+    __syncthreads();
+    const int64_t head_cut = fin[k - 1];  // KEY_PAD if fewer than k non-empty lists: keep them all
+    for (uint32_t b = threadIdx.x; b < n_lists; b += MERGE_THREADS) {
+        const int64_t h = in[(size_t)b * k];
+        if (h != KEY_PAD && h <= head_cut) {
+            const int pos = atomicAdd(sel_count, 1);
+            if (pos < FUSED_MAX_K) sel[pos] = (int)b;
+        }
+    }
+    __syncthreads();
+    const int nsel = *sel_count < k ? *sel_count : k;   // keys are unique => at most k lists survive
+    const uint32_t total = (uint32_t)nsel * (uint32_t)k;
+    __syncthreads();                                     // everyone has read fin/sel_count before they are reused
+    tk.init(lds + wave * CAP, k);
+    for (uint32_t base = 0; base < total; base += MERGE_THREADS * MERGE_LOADS) {
         int64_t keys[MERGE_LOADS];
 #pragma unroll
         for (int r = 0; r < MERGE_LOADS; ++r) {
             const uint32_t i = base + r * MERGE_THREADS + threadIdx.x;
-            keys[r] = (i < n_in) ? in[i] : KEY_PAD;
+            keys[r] = KEY_PAD;
+            if (i < total) {
+                const uint32_t li = i / (uint32_t)k;
+                keys[r] = in[(size_t)sel[li] * k + (i - li * (uint32_t)k)];
+            }
         }
 #pragma unroll
         for (int r = 0; r < MERGE_LOADS; ++r) {
@@ -400,12 +441,13 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_keys_kernel(const int64_t
 
 hipError_t launch_merge_keys(const int64_t* d_in, uint32_t n_in, int k, int kpad, const uint64_t* d_ids,
                              uint32_t row_base, uint32_t n_rows, wax_hip_hit* d_out, int cap, hipStream_t st) {
-    if (k > FUSED_MAX_K || k < 1 || kpad < k) return hipErrorInvalidValue;
+    if (k > FUSED_MAX_K || k < 1 || kpad < k || n_in % (uint32_t)k != 0) return hipErrorInvalidValue;
+    const uint32_t n_lists = n_in / (uint32_t)k;
     if (cap <= 128)
-        hipLaunchKernelGGL((merge_keys_kernel<128>), dim3(1), dim3(MERGE_THREADS), 0, st, d_in, n_in, k, kpad, d_ids,
+        hipLaunchKernelGGL((merge_keys_kernel<128>), dim3(1), dim3(MERGE_THREADS), 0, st, d_in, n_lists, k, kpad, d_ids,
                            row_base, n_rows, d_out);
     else
-        hipLaunchKernelGGL((merge_keys_kernel<256>), dim3(1), dim3(MERGE_THREADS), 0, st, d_in, n_in, k, kpad, d_ids,
+        hipLaunchKernelGGL((merge_keys_kernel<256>), dim3(1), dim3(MERGE_THREADS), 0, st, d_in, n_lists, k, kpad, d_ids,
                            row_base, n_rows, d_out);
     return hipGetLastError();
 }

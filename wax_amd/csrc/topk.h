@@ -75,12 +75,28 @@ struct WaveTopK {
             rank[e] = 0;
         }
         const int live = __builtin_amdgcn_readfirstlane(cnt);
-        for (int j = 0; j < live; ++j) {
-            const int64_t o = buf[j];  // LDS broadcast read
+        // 4 broadcast keys per trip (two ds_read_b128): the loop is LDS-latency-bound otherwise
+        // (one dependent 64-cycle read per key made a 128-entry prune cost ~3.5 us).
+        int j = 0;
+        for (; j + 4 <= live; j += 4) {
+            int64_t o[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) o[u] = buf[j + u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int idx = lane + 64 * e;
+                    // total order even if a key were duplicated: ties broken by slot index
+                    rank[e] += (o[u] < mine[e] || (o[u] == mine[e] && (j + u) < idx)) ? 1 : 0;
+                }
+            }
+        }
+        for (; j < live; ++j) {
+            const int64_t o = buf[j];
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const int idx = lane + 64 * e;
-                // total order even if a key were duplicated: ties broken by slot index
                 rank[e] += (o < mine[e] || (o == mine[e] && j < idx)) ? 1 : 0;
             }
         }
