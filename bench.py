@@ -153,8 +153,11 @@ def main():
 
     eng.setTuning("time_kernels", 1)
     if world == 1:
-        eng.setTuning("streams", 1)   # strictly in-order scans: per-kernel event times are not inflated by overlap
-        eng.setTuning("slots", max(args.depth, 1))
+        # two in-order streams; the library chains the scan kernels through an event so they never
+        # overlap each other (per-kernel HIP-event times stay clean) while one query's merge / result
+        # write / next query upload hide under the neighbouring scan
+        eng.setTuning("streams", 2)
+        eng.setTuning("slots", max(args.depth, 2))
         searcher = None
 
         def submit(q):

@@ -37,6 +37,13 @@ for s in $STAGES; do
           python "$R/bench.py" --gpus 1 --steps 20 --warmup 2 --no-cpu-baseline > "$OUT/pmc_bench.json" 2> "$OUT/pmc.err"); rc=$?
       python tools/pmc_summary.py "$OUT/prof_pmc" > "$OUT/pmc_summary.json" 2>> "$OUT/pmc.err"
       find "$OUT/prof_pmc" -name "*.csv" -size +2M -delete 2>/dev/null ;;
+    batch)
+      timeout 900 python tools/batch_bench.py --nq 64 256 1024 --slab-mb 16 64 256 > "$OUT/batch_bench.log" 2>&1; rc=$? ;;
+    batchprof)
+      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_batch" -o batch -- \
+          python "$R/tools/batch_bench.py" --nq 256 --reps 3 > "$OUT/batchprof.log" 2>&1); rc=$?
+      find "$OUT/prof_batch" -name "*kernel_stats.csv" -exec cp {} "$OUT/batch_kernel_stats.csv" \; 2>/dev/null
+      find "$OUT/prof_batch" -name "*kernel_trace.csv" -delete 2>/dev/null ;;
     sweep)
       timeout 1200 python tools/sweep.py --tag "$TAG" > "$OUT/sweep.log" 2>&1; rc=$?
       cp gpurun_out/sweep_$TAG.json "$OUT/" 2>/dev/null ;;

@@ -49,10 +49,14 @@ __global__ __launch_bounds__(256) void mirror_kernel(const float* __restrict__ s
                                                      uint32_t n_rows_padded, uint32_t dims, int normalize,
                                                      unsigned short* __restrict__ dst, float* __restrict__ norm2,
                                                      unsigned int* __restrict__ max_norm_bits) {
+    __shared__ unsigned int block_max;
     const int lane = lane_id();
     const uint32_t gwave = blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint32_t nwaves = gridDim.x * 4;
     const bool vec4 = (dims & 3u) == 0;
+    if (threadIdx.x == 0) block_max = 0u;
+    __syncthreads();
+    float wave_max = 0.f;  // one global atomic per workgroup: a per-row atomicMax serialises at ~11 ns each
     for (uint32_t r = gwave; r < n_rows_padded; r += nwaves) {
         unsigned short* out = dst + (size_t)r * dims;
         if (r >= n_rows) {
@@ -88,10 +92,13 @@ __global__ __launch_bounds__(256) void mirror_kernel(const float* __restrict__ s
         } else {
             for (uint32_t c = lane; c < dims; c += WAVE) out[c] = f32_to_bf16_rne(row[c] * scale);
         }
-        if (lane == 0) {
-            norm2[r] = acc;
-            if (max_norm_bits != nullptr && n == n) atomicMax(max_norm_bits, __float_as_uint(n));
-        }
+        if (lane == 0) norm2[r] = acc;
+        if (n == n && n > wave_max) wave_max = n;
+    }
+    if (max_norm_bits != nullptr) {
+        if (lane == 0) atomicMax(&block_max, __float_as_uint(wave_max));
+        __syncthreads();
+        if (threadIdx.x == 0 && block_max != 0u) atomicMax(max_norm_bits, block_max);
     }
 }
 
@@ -264,8 +271,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void select_scores_kernel(const float
         }
 #pragma unroll
         for (int i = 0; i < LOADS; ++i) {
-            tk.make_room(WAVE);
-            tk.push(make_key(d[i], row_base + slab0 + rr[i]), rr[i] < r1);
+            tk.push_wide(make_key(d[i], row_base + slab0 + rr[i]), rr[i] < r1);
         }
     }
     int* counts = reinterpret_cast<int*>(lds + SCAN_WAVES * CAP);
@@ -280,7 +286,7 @@ hipError_t launch_select_scores(const float* scores, uint32_t slab_ld, uint32_t 
                                 int64_t* partials, hipStream_t st) {
     const uint32_t segs = (slab_rows + SEG_ROWS - 1) / SEG_ROWS;
     const dim3 grid(segs, nq);
-    if (kp <= 64)
+    if (kp <= 32)
         hipLaunchKernelGGL((select_scores_kernel<128>), grid, dim3(SCAN_THREADS), 0, st, scores, slab_ld, slab0, slab_rows,
                            row_base, kp, seg_first, segs_total, partials);
     else
@@ -310,8 +316,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void merge_query_keys_kernel(const in
         }
 #pragma unroll
         for (int i = 0; i < LOADS; ++i) {
-            tk.make_room(WAVE);
-            tk.push(keys[i], keys[i] != KEY_PAD);
+            tk.push_wide(keys[i], keys[i] != KEY_PAD);
         }
     }
     int* counts = reinterpret_cast<int*>(lds + SCAN_WAVES * CAP);
@@ -323,7 +328,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void merge_query_keys_kernel(const in
 
 hipError_t launch_merge_query_keys(const int64_t* partials, uint32_t n_in, int kp, uint32_t nq, int64_t* cand,
                                    hipStream_t st) {
-    if (kp <= 64)
+    if (kp <= 32)
         hipLaunchKernelGGL((merge_query_keys_kernel<128>), dim3(nq), dim3(SCAN_THREADS), 0, st, partials, n_in, kp, cand);
     else
         hipLaunchKernelGGL((merge_query_keys_kernel<256>), dim3(nq), dim3(SCAN_THREADS), 0, st, partials, n_in, kp, cand);

@@ -247,6 +247,12 @@ struct wax_hip_engine {
 
     hipStream_t streams[kMaxStreams] = {};
     int n_streams = 2;            // slots are spread round-robin over this many in-order streams
+    // Scan kernels are chained across streams through this event so that they never overlap each
+    // other (each one owns the whole HBM pipe and its HIP-event duration stays meaningful) while
+    // the merge kernel, the query upload and the result write of neighbouring queries do overlap.
+    hipEvent_t scan_done = nullptr;
+    bool scan_done_valid = false;
+    std::mutex chain_mu;
 
     std::mutex slot_mu;
     std::condition_variable slot_cv;
@@ -435,7 +441,8 @@ struct Enqueued { int k_eff; };
 
 // The scan + select chain for one query on `stream`; leaves kpad hits in d_hits.
 int enqueue_scan(wax_hip_engine* e, const float* d_query, float q_norm, int k_eff, int kpad, int64_t* d_partials,
-                 Slot* general_slot, wax_hip_hit* d_hits, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+                 Slot* general_slot, wax_hip_hit* d_hits, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1,
+                 bool chain = false) {
     ScanArgs a{};
     a.store = e->d_store;
     a.query = d_query;
@@ -448,12 +455,22 @@ int enqueue_scan(wax_hip_engine* e, const float* d_query, float q_norm, int k_ef
     a.q_norm = q_norm;
     const bool fused = k_eff <= FUSED_MAX_K && !(e->force_general.load() && general_slot != nullptr);
     int grid = 0;
+    std::unique_lock<std::mutex> chain_guard(e->chain_mu, std::defer_lock);
+    if (chain && e->n_streams > 1) {
+        chain_guard.lock();
+        if (e->scan_done_valid) HIP_TRY(hipStreamWaitEvent(stream, e->scan_done, 0), WAX_HIP_ERR_INTERNAL, "scan chain wait");
+    }
     if (fused) {
         const int cap = k_eff <= 64 ? 128 : 256;
         if (ev0) HIP_TRY(hipEventRecord(ev0, stream), WAX_HIP_ERR_INTERNAL, "event record");
         HIP_TRY(launch_scan(a, e->metric, (int)e->variant.load(), cap, false, (int)e->grid_blocks.load(), stream, &grid),
                 WAX_HIP_ERR_INTERNAL, "scan kernel launch");
         if (ev1) HIP_TRY(hipEventRecord(ev1, stream), WAX_HIP_ERR_INTERNAL, "event record");
+        if (chain_guard.owns_lock()) {
+            HIP_TRY(hipEventRecord(e->scan_done, stream), WAX_HIP_ERR_INTERNAL, "scan chain record");
+            e->scan_done_valid = true;
+            chain_guard.unlock();
+        }
         HIP_TRY(launch_merge_keys(d_partials, (uint32_t)grid * (uint32_t)k_eff, k_eff, kpad, e->d_ids, a.row_base,
                                   a.n_rows, d_hits, cap, stream),
                 WAX_HIP_ERR_INTERNAL, "merge kernel launch");
@@ -703,6 +720,10 @@ int wax_hip_engine_create(uint8_t metric, uint32_t dims, int device_id, wax_hip_
         hipError_t err = hipMalloc(&e->d_sink, MAX_GRID_BLOCKS * sizeof(float));
         if (err != hipSuccess) rc = fail(WAX_HIP_ERR_ALLOC, std::string("Failed to allocate sink: ") + hipGetErrorString(err));
     }
+    if (rc == WAX_HIP_OK) {
+        hipError_t err = hipEventCreateWithFlags(&e->scan_done, hipEventDisableTiming);
+        if (err != hipSuccess) rc = fail(WAX_HIP_ERR_ALLOC, std::string("Failed to create event: ") + hipGetErrorString(err));
+    }
     for (int i = 0; i < kMaxStreams && rc == WAX_HIP_OK; ++i) {
         hipError_t err = hipStreamCreateWithFlags(&e->streams[i], hipStreamNonBlocking);
         if (err != hipSuccess) rc = fail(WAX_HIP_ERR_ALLOC, std::string("Failed to create stream: ") + hipGetErrorString(err));
@@ -732,6 +753,7 @@ void wax_hip_engine_destroy(wax_hip_engine* e) {
     for (Slot* s : e->all_slots) free_slot(s);
     for (int i = 0; i < kMaxStreams; ++i)
         if (e->streams[i]) (void)hipStreamDestroy(e->streams[i]);
+    if (e->scan_done) (void)hipEventDestroy(e->scan_done);
     for (int i = 0; i < kShardRing; ++i) {
         (void)hipFree(e->ring_d_query[i]);
         (void)hipHostFree(e->ring_h_query[i]);
@@ -908,7 +930,7 @@ int wax_hip_search_submit(wax_hip_engine* e, const float* query, uint32_t dims, 
         // The last kernel of the chain writes the k hits straight into the slot's pinned host buffer
         // (device-visible, 16*k bytes over PCIe): no D2H copy launch; visibility at ev_done.
         rc = enqueue_scan(e, s->d_query, qn, k_eff, k_eff, s->d_partials, s, s->h_hits, s->stream,
-                          s->timed ? s->ev0 : nullptr, s->timed ? s->ev1 : nullptr);
+                          s->timed ? s->ev0 : nullptr, s->timed ? s->ev1 : nullptr, /*chain=*/true);
         if (rc != WAX_HIP_OK) break;
         err = hipEventRecord(s->ev_done, s->stream);
         if (err != hipSuccess) { rc = fail(WAX_HIP_ERR_INTERNAL, std::string("event record: ") + hipGetErrorString(err)); break; }

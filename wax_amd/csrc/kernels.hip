@@ -382,8 +382,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_keys_kernel(const int64_t
         }
 #pragma unroll
         for (int r = 0; r < MERGE_LOADS; ++r) {
-            tk.make_room(WAVE);
-            tk.push(keys[r], keys[r] != KEY_PAD);
+            tk.push_wide(keys[r], keys[r] != KEY_PAD);
         }
     }
     tk.finalize();
@@ -418,8 +417,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_keys_kernel(const int64_t
         }
 #pragma unroll
         for (int r = 0; r < MERGE_LOADS; ++r) {
-            tk.make_room(WAVE);
-            tk.push(keys[r], keys[r] != KEY_PAD);
+            tk.push_wide(keys[r], keys[r] != KEY_PAD);
         }
     }
     tk.finalize();
@@ -468,8 +466,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_hits_kernel(const wax_hip
         const uint32_t i = base + lane;
         const bool inb = i < n;
         const int64_t key = inb ? in[i].key : KEY_PAD;
-        tk.make_room(WAVE);
-        tk.push(key, inb && key != KEY_PAD);
+        tk.push_wide(key, inb && key != KEY_PAD);
     }
     tk.finalize();
     if (lane == 0) counts[wave] = tk.cnt;

@@ -24,13 +24,75 @@ __device__ inline void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
+typedef __attribute__((address_space(3))) int64_t lds_i64;
+
+struct PruneOut {
+    int cnt;
+    int64_t tau;
+};
+
+// Rank-sort the `cnt` live candidates of one wave's list, keep the k smallest in
+// buf[0..min(cnt,k)) ascending, return the new count and threshold. O(cnt*CAP/64) compares per
+// lane, no inter-lane shuffles. Deliberately NOT inlined: it is cold code (a wave prunes a handful
+// of times per launch) and every inlined copy is ~3 KB of instructions that a single-workgroup
+// kernel pays for in instruction-cache misses (merge_keys_kernel: 5 500 lines of ISA, 20 us).
+template <int CAP>
+__device__ __attribute__((noinline)) PruneOut wave_prune(lds_i64* buf, int cnt, int k) {
+    constexpr int E = CAP / 64;
+    wave_lds_fence();
+    const int lane = lane_id();
+    int64_t mine[E];
+    int rank[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int idx = lane + 64 * e;
+        mine[e] = (idx < cnt) ? buf[idx] : KEY_PAD;
+        rank[e] = 0;
+    }
+    const int live = __builtin_amdgcn_readfirstlane(cnt);
+    // 4 broadcast keys per trip (two ds_read_b128): the loop is LDS-latency-bound otherwise.
+    int j = 0;
+    for (; j + 4 <= live; j += 4) {
+        int64_t o[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) o[u] = buf[j + u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int idx = lane + 64 * e;
+                // total order even if a key were duplicated: ties broken by slot index
+                rank[e] += (o[u] < mine[e] || (o[u] == mine[e] && (j + u) < idx)) ? 1 : 0;
+            }
+        }
+    }
+    for (; j < live; ++j) {
+        const int64_t o = buf[j];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int idx = lane + 64 * e;
+            rank[e] += (o < mine[e] || (o == mine[e] && j < idx)) ? 1 : 0;
+        }
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int idx = lane + 64 * e;
+        if (idx < cnt && rank[e] < k) buf[rank[e]] = mine[e];
+    }
+    wave_lds_fence();
+    PruneOut r;
+    r.cnt = cnt < k ? cnt : k;
+    r.tau = (r.cnt >= k) ? buf[k - 1] : KEY_PAD;
+    return r;
+}
+
 // Streaming k-smallest over int64 keys, private to one wave.
 //   CAP  : LDS slots (power of two, >= k + 64 so that one push of up to 64
 //          candidates always fits after a prune)
 template <int CAP>
 struct WaveTopK {
     static_assert(CAP % 64 == 0, "CAP must be a multiple of the wave size");
-    static constexpr int E = CAP / 64;  // slots per lane in prune()
 
     int64_t* buf;  // CAP slots in LDS, this wave only
     int cnt;       // wave-uniform number of live candidates in buf[0..cnt)
@@ -61,54 +123,29 @@ struct WaveTopK {
         if (cnt > CAP - incoming) prune();
     }
 
-    // Rank-sort the cnt live candidates, keep the k smallest in buf[0..min(cnt,k)), sorted
-    // ascending, and tighten tau. O(cnt*CAP/64) compares per lane, no inter-lane shuffles.
+    // push() for kernels that offer up to 64 candidates at once: prunes only when the candidates
+    // that actually pass the threshold do not fit (a fixed make_room(64) would prune after every
+    // insertion once k >= CAP - 64).
+    __device__ inline void push_wide(int64_t key, bool valid) {
+        bool pass = valid && (key < tau);
+        unsigned long long mask = __ballot(pass);
+        if (mask == 0ull) return;
+        if (cnt + __popcll(mask) > CAP) {
+            prune();  // cnt <= k <= CAP - 64 afterwards, tau tightened: re-test
+            pass = valid && (key < tau);
+            mask = __ballot(pass);
+            if (mask == 0ull) return;
+        }
+        const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                     __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+        if (pass) buf[cnt + before] = key;
+        cnt += __popcll(mask);
+    }
+
     __device__ inline void prune() {
-        wave_lds_fence();
-        const int lane = lane_id();
-        int64_t mine[E];
-        int rank[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int idx = lane + 64 * e;
-            mine[e] = (idx < cnt) ? buf[idx] : KEY_PAD;
-            rank[e] = 0;
-        }
-        const int live = __builtin_amdgcn_readfirstlane(cnt);
-        // 4 broadcast keys per trip (two ds_read_b128): the loop is LDS-latency-bound otherwise
-        // (one dependent 64-cycle read per key made a 128-entry prune cost ~3.5 us).
-        int j = 0;
-        for (; j + 4 <= live; j += 4) {
-            int64_t o[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) o[u] = buf[j + u];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    const int idx = lane + 64 * e;
-                    // total order even if a key were duplicated: ties broken by slot index
-                    rank[e] += (o[u] < mine[e] || (o[u] == mine[e] && (j + u) < idx)) ? 1 : 0;
-                }
-            }
-        }
-        for (; j < live; ++j) {
-            const int64_t o = buf[j];
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const int idx = lane + 64 * e;
-                rank[e] += (o < mine[e] || (o == mine[e] && j < idx)) ? 1 : 0;
-            }
-        }
-        wave_lds_fence();
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int idx = lane + 64 * e;
-            if (idx < cnt && rank[e] < k) buf[rank[e]] = mine[e];
-        }
-        wave_lds_fence();
-        cnt = cnt < k ? cnt : k;
-        tau = (cnt >= k) ? buf[k - 1] : KEY_PAD;
+        const PruneOut r = wave_prune<CAP>((lds_i64*)buf, cnt, k);
+        cnt = r.cnt;
+        tau = r.tau;
     }
 
     __device__ inline void finalize() { prune(); }
@@ -120,26 +157,26 @@ struct WaveTopK {
 //   lists  : LDS, wave w's sorted list at lists + w*stride, length counts[w] (<= k)
 //   out    : k slots (global or LDS); slots past the merged total get KEY_PAD
 // Must be called by all threads of the block; ends with all writes issued (no trailing barrier).
-template <int NWAVES>
-__device__ inline void block_rank_merge(const int64_t* lists, int stride, const int* counts, int k,
-                                        int64_t* out) {
+typedef __attribute__((address_space(3))) int lds_i32;
+
+// Not inlined and not unrolled for the same instruction-footprint reason as wave_prune.
+__device__ __attribute__((noinline)) void block_rank_merge_impl(const lds_i64* lists, int nwaves, int stride,
+                                                                const lds_i32* counts, int k, int64_t* out) {
     const int tid = (int)threadIdx.x;
     const int nthreads = (int)blockDim.x;
     int total = 0;
-#pragma unroll
-    for (int w = 0; w < NWAVES; ++w) total += counts[w];
+    for (int w = 0; w < nwaves; ++w) total += counts[w];
     const int total_k = total < k ? total : k;
-    for (int t = tid; t < NWAVES * k; t += nthreads) {
+    for (int t = tid; t < nwaves * k; t += nthreads) {
         const int w = t / k, i = t - w * k;
         if (i >= counts[w]) continue;
         const int64_t key = lists[w * stride + i];
         int rank = i;
-#pragma unroll
-        for (int o = 0; o < NWAVES; ++o) {
+        for (int o = 0; o < nwaves; ++o) {
             if (o == w) continue;
             // number of entries in list o that precede `key` (ties: lower wave index first)
             int lo = 0, hi = counts[o];
-            const int64_t* lst = lists + o * stride;
+            const lds_i64* lst = lists + o * stride;
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
                 const int64_t v = lst[mid];
@@ -151,6 +188,12 @@ __device__ inline void block_rank_merge(const int64_t* lists, int stride, const 
         if (rank < k) out[rank] = key;
     }
     for (int t = total_k + tid; t < k; t += nthreads) out[t] = KEY_PAD;
+}
+
+template <int NWAVES>
+__device__ inline void block_rank_merge(const int64_t* lists, int stride, const int* counts, int k,
+                                        int64_t* out) {
+    block_rank_merge_impl((const lds_i64*)lists, NWAVES, stride, (const lds_i32*)counts, k, out);
 }
 
 // ---- DPP cross-lane adds (no LDS traffic) ---------------------------------

@@ -89,6 +89,10 @@ class ShardedSearcher:
         n_host = self.kpad * (world if host_merge else 1)
         self.host = [torch.empty((n_host, 2), dtype=torch.int64).pin_memory() for _ in range(self.depth)]
         self.events = [torch.cuda.Event() for _ in range(self.depth)]
+        # scans are chained across the streams (they never overlap each other: each owns the whole
+        # HBM pipe); the all-gather / merge / download of query i overlap the scan of query i+1
+        self.scan_events = [torch.cuda.Event() for _ in range(self.depth)]
+        self.prev_scan = None
         self.inflight: Deque[int] = deque()
         self.seq = 0
 
@@ -102,7 +106,11 @@ class ShardedSearcher:
         st = self.streams[self.seq % len(self.streams)]
         self.seq += 1
         with torch.cuda.stream(st):
+            if self.prev_scan is not None and len(self.streams) > 1:
+                st.wait_event(self.prev_scan)
             self.engine.searchShardDevice(query, self.topK, self.local[b].data_ptr(), st.cuda_stream)
+            self.scan_events[b].record(st)
+            self.prev_scan = self.scan_events[b]
             if self.world > 1:
                 dist.all_gather_into_tensor(self.gathered[b], self.local[b])  # RCCL over xGMI
                 src = self.gathered[b]
