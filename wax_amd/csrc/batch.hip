@@ -6,19 +6,22 @@
 // with Q >= 32 queries the scan is a genuine dense GEMM (arithmetic intensity Q flop per
 // corpus byte) and belongs on MFMA, not on the HBM-bound VALU kernel.
 //
-// Pipeline (all on one stream, corpus processed in slabs so the score tile stays in the
-// 256 MiB Infinity Cache):
-//   mirror_kernel        f32 store -> bf16 mirror (RNE) + 1/||v||, ||v||^2, max ||v||   (once per mutation)
-//   batch_gemm_kernel    S[q][r] = approx distance from bf16 x bf16 -> f32 MFMA (v_mfma_f32_32x32x16_bf16)
-//   select_scores_kernel per (query, 16K-row segment) top-k' by the same WaveTopK machinery as the scan
-//   merge_query_keys     per query: segments*k' -> k' candidates (approx order)
+// Pipeline (all on one stream; the corpus is walked in slabs whose size grows geometrically):
+//   mirror_kernel        f32 store -> bf16 mirror (RNE; cosine rows pre-normalised), ||v||^2, max ||v||
+//                        (once per mutation; the same kernel converts the query block)
+//   batch_gemm_kernel    bf16 x bf16 -> f32 MFMA (v_mfma_f32_32x32x16_bf16) over one slab, with the
+//                        selection FUSED into the epilogue: an approx distance is appended to its query's
+//                        candidate list only if it beats that query's running threshold tau_q (the k'-th
+//                        best approx distance over the slabs seen so far). The Q x N score matrix is never
+//                        written: after the first 2K rows ~k' * slab/rows_so_far appends per query per slab.
+//   tighten_kernel       per query: candidates -> best k' (sorted), tau_q tightened (between slabs)
 //   rescore_kernel       exact f32 distance of every candidate, SAME lane mapping / summation order
 //                        as scan_kernel => bit-identical to the single-query path
 //   finalize_batch       sort by exact key, emit top-k hits + certificate:
 //                        a non-candidate's approx distance >= a_max (the k'-th approx), so its exact
 //                        distance >= a_max - eps (eps = rigorous bf16 rounding bound); if that is
-//                        > the exact k-th best, the answer is provably the exact top-k. Otherwise the
-//                        host re-runs that query on the exact single-query path.
+//                        > the exact k-th best, the answer is provably the exact top-k. Otherwise (or if a
+//                        candidate list overflowed) the host re-runs that query on the exact single-query path.
 #include "kernels.h"
 #include "topk.h"
 
@@ -196,15 +199,17 @@ __global__ __launch_bounds__(256) void batch_gemm_kernel(GemmArgs a) {
     }
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31 (corpus row),
-    // row = (r&3) + 8*(r>>2) + 4*(lane>>5) (query). For a fixed register the 32 lanes of a half-wave
-    // store 128 contiguous bytes of one query's score row. Padding queries (q >= nq) are stored too
-    // (the score buffer has nq_pad rows); only the corpus-row tail is masked.
-    float* qn2 = reinterpret_cast<float*>(As);
-    if (METRIC == BM_L2) {
-        __syncthreads();
-        if (tid < GM) qn2[tid] = a.q_n2[m0 + tid];
-        __syncthreads();
+    // row = (r&3) + 8*(r>>2) + 4*(lane>>5) (query). Fused selection: each approx distance is tested
+    // against its query's threshold (staged in LDS); survivors are appended to the query's global
+    // candidate list with one atomic each. After the first slab a tile appends almost nothing.
+    float* tau_s = reinterpret_cast<float*>(As);          // [GM] thresholds of this tile's queries
+    float* qn2 = reinterpret_cast<float*>(As) + GM;       // [GM] ||q||^2 (L2 only)
+    __syncthreads();                                      // every wave is done reading As/Bs fragments
+    if (tid < GM) {
+        tau_s[tid] = a.tau[m0 + tid];
+        if (METRIC == BM_L2) qn2[tid] = a.q_n2[m0 + tid];
     }
+    __syncthreads();
     const uint32_t slab_end = a.slab0 + a.slab_rows;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -212,7 +217,6 @@ __global__ __launch_bounds__(256) void batch_gemm_kernel(GemmArgs a) {
         if (row >= slab_end) continue;
         float vn2 = 0.f;
         if (METRIC == BM_L2) vn2 = a.v_n2[row];
-        float* __restrict__ dst = a.scores + (row - a.slab0);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -222,8 +226,14 @@ __global__ __launch_bounds__(256) void batch_gemm_kernel(GemmArgs a) {
                 float d;
                 if (METRIC == BM_L2) d = qn2[qloc] + vn2 - 2.0f * dot;
                 else d = 1.0f - dot;  // cosine: both operands were normalised by mirror_kernel; dot: USearch ip
-                d = (d != d) ? __builtin_inff() : d;
-                dst[(size_t)(m0 + qloc) * a.slab_ld] = d + 0.0f;
+                d += 0.0f;
+                if (d <= tau_s[qloc]) {  // NaN fails the test: such rows can never be candidates
+                    const uint32_t q = m0 + qloc;
+                    if (q < a.nq) {
+                        const uint32_t pos = atomicAdd(&a.cand_count[q], 1u);
+                        if (pos < a.cand_cap) a.cand[(size_t)q * a.cand_cap + pos] = make_key(d, a.row_base + row);
+                    }
+                }
             }
         }
     }
@@ -242,68 +252,25 @@ hipError_t launch_batch_gemm(const GemmArgs& a, int metric, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------
-// Per (query, segment) top-k' over the slab's score tile.
-constexpr uint32_t SEG_ROWS = 16384;
-
+// Between slabs, per query: keep the best kp of the appended candidates (sorted ascending at the head
+// of the list), reset the count, tighten tau. A list that overflowed its capacity marks the query
+// (it will be answered by the exact path).
 template <int CAP>
-__global__ __launch_bounds__(SCAN_THREADS) void select_scores_kernel(const float* __restrict__ scores, uint32_t slab_ld,
-                                                                    uint32_t slab0, uint32_t slab_rows,
-                                                                    uint32_t row_base, int kp, uint32_t seg_first,
-                                                                    uint32_t segs_total, int64_t* __restrict__ partials) {
-    __shared__ int64_t lds[SCAN_WAVES * CAP + SCAN_WAVES];
-    const int lane = lane_id();
-    const int wave = (int)(threadIdx.x >> 6);
-    const uint32_t q = blockIdx.y;
-    const uint32_t s = blockIdx.x;
-    const uint32_t r0 = s * SEG_ROWS;
-    const uint32_t r1 = (r0 + SEG_ROWS < slab_rows) ? r0 + SEG_ROWS : slab_rows;
-    const float* __restrict__ src = scores + (size_t)q * slab_ld;
-    WaveTopK<CAP> tk;
-    tk.init(lds + wave * CAP, kp);
-    constexpr int LOADS = 4;
-    for (uint32_t base = r0; base < r1; base += SCAN_THREADS * LOADS) {
-        float d[LOADS];
-        uint32_t rr[LOADS];
-#pragma unroll
-        for (int i = 0; i < LOADS; ++i) {
-            rr[i] = base + i * SCAN_THREADS + threadIdx.x;
-            d[i] = (rr[i] < r1) ? src[rr[i]] : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < LOADS; ++i) {
-            tk.push_wide(make_key(d[i], row_base + slab0 + rr[i]), rr[i] < r1);
-        }
-    }
+__global__ __launch_bounds__(SCAN_THREADS) void tighten_kernel(int64_t* __restrict__ cand, uint32_t cand_cap,
+                                                              uint32_t* __restrict__ cand_count, int kp,
+                                                              float* __restrict__ tau, uint32_t* __restrict__ overflow) {
+    __shared__ int64_t lds[SCAN_WAVES * CAP + SCAN_WAVES + FUSED_MAX_K];
     int* counts = reinterpret_cast<int*>(lds + SCAN_WAVES * CAP);
-    tk.finalize();
-    if (lane == 0) counts[wave] = tk.cnt;
-    __syncthreads();
-    block_rank_merge<SCAN_WAVES>(lds, CAP, counts, kp, partials + ((size_t)q * segs_total + seg_first + s) * kp);
-}
-
-hipError_t launch_select_scores(const float* scores, uint32_t slab_ld, uint32_t slab0, uint32_t slab_rows,
-                                uint32_t row_base, int kp, uint32_t nq, uint32_t seg_first, uint32_t segs_total,
-                                int64_t* partials, hipStream_t st) {
-    const uint32_t segs = (slab_rows + SEG_ROWS - 1) / SEG_ROWS;
-    const dim3 grid(segs, nq);
-    if (kp <= 32)
-        hipLaunchKernelGGL((select_scores_kernel<128>), grid, dim3(SCAN_THREADS), 0, st, scores, slab_ld, slab0, slab_rows,
-                           row_base, kp, seg_first, segs_total, partials);
-    else
-        hipLaunchKernelGGL((select_scores_kernel<256>), grid, dim3(SCAN_THREADS), 0, st, scores, slab_ld, slab0, slab_rows,
-                           row_base, kp, seg_first, segs_total, partials);
-    return hipGetLastError();
-}
-
-// Per query: segs_total*kp partial keys -> kp candidates, ascending by approx key.
-template <int CAP>
-__global__ __launch_bounds__(SCAN_THREADS) void merge_query_keys_kernel(const int64_t* __restrict__ partials,
-                                                                       uint32_t n_in, int kp,
-                                                                       int64_t* __restrict__ cand) {
-    __shared__ int64_t lds[SCAN_WAVES * CAP + SCAN_WAVES];
+    int64_t* fin = lds + SCAN_WAVES * CAP + SCAN_WAVES;
     const int lane = lane_id();
     const int wave = (int)(threadIdx.x >> 6);
-    const int64_t* __restrict__ in = partials + (size_t)blockIdx.x * n_in;
+    const uint32_t q = blockIdx.x;
+    uint32_t n_in = cand_count[q];
+    if (n_in > cand_cap) {
+        if (threadIdx.x == 0) overflow[q] = 1u;
+        n_in = cand_cap;
+    }
+    int64_t* __restrict__ mine = cand + (size_t)q * cand_cap;
     WaveTopK<CAP> tk;
     tk.init(lds + wave * CAP, kp);
     constexpr int LOADS = 4;
@@ -312,26 +279,42 @@ __global__ __launch_bounds__(SCAN_THREADS) void merge_query_keys_kernel(const in
 #pragma unroll
         for (int i = 0; i < LOADS; ++i) {
             const uint32_t idx = base + i * SCAN_THREADS + threadIdx.x;
-            keys[i] = (idx < n_in) ? in[idx] : KEY_PAD;
+            keys[i] = (idx < n_in) ? mine[idx] : KEY_PAD;
         }
 #pragma unroll
-        for (int i = 0; i < LOADS; ++i) {
-            tk.push_wide(keys[i], keys[i] != KEY_PAD);
-        }
+        for (int i = 0; i < LOADS; ++i) tk.push_wide(keys[i], keys[i] != KEY_PAD);
     }
-    int* counts = reinterpret_cast<int*>(lds + SCAN_WAVES * CAP);
     tk.finalize();
     if (lane == 0) counts[wave] = tk.cnt;
     __syncthreads();
-    block_rank_merge<SCAN_WAVES>(lds, CAP, counts, kp, cand + (size_t)blockIdx.x * kp);
+    block_rank_merge<SCAN_WAVES>(lds, CAP, counts, kp, fin);
+    __syncthreads();   // all reads of the old list happened before the first barrier
+    for (int t = (int)threadIdx.x; t < kp; t += SCAN_THREADS) mine[t] = fin[t];
+    if (threadIdx.x == 0) {
+        const uint32_t kept = n_in < (uint32_t)kp ? n_in : (uint32_t)kp;
+        cand_count[q] = kept;
+        const int64_t last = fin[kp - 1];
+        tau[q] = (last == KEY_PAD) ? __builtin_inff() : key_distance(last);
+    }
 }
 
-hipError_t launch_merge_query_keys(const int64_t* partials, uint32_t n_in, int kp, uint32_t nq, int64_t* cand,
-                                   hipStream_t st) {
+hipError_t launch_tighten(int64_t* cand, uint32_t cand_cap, uint32_t* cand_count, int kp, uint32_t nq, float* tau,
+                          uint32_t* overflow, hipStream_t st) {
     if (kp <= 32)
-        hipLaunchKernelGGL((merge_query_keys_kernel<128>), dim3(nq), dim3(SCAN_THREADS), 0, st, partials, n_in, kp, cand);
+        hipLaunchKernelGGL((tighten_kernel<128>), dim3(nq), dim3(SCAN_THREADS), 0, st, cand, cand_cap, cand_count, kp, tau, overflow);
     else
-        hipLaunchKernelGGL((merge_query_keys_kernel<256>), dim3(nq), dim3(SCAN_THREADS), 0, st, partials, n_in, kp, cand);
+        hipLaunchKernelGGL((tighten_kernel<256>), dim3(nq), dim3(SCAN_THREADS), 0, st, cand, cand_cap, cand_count, kp, tau, overflow);
+    return hipGetLastError();
+}
+
+// Fill tau with +inf and zero the counters / overflow flags for a new batch.
+__global__ void batch_reset_kernel(float* tau, uint32_t* cand_count, uint32_t* overflow, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { tau[i] = __builtin_inff(); cand_count[i] = 0u; overflow[i] = 0u; }
+}
+
+hipError_t launch_batch_reset(float* tau, uint32_t* cand_count, uint32_t* overflow, uint32_t n, hipStream_t st) {
+    hipLaunchKernelGGL(batch_reset_kernel, dim3((n + 255) / 256), dim3(256), 0, st, tau, cand_count, overflow, n);
     return hipGetLastError();
 }
 
@@ -377,7 +360,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(RescoreArgs a) {
     const bool in_range = pair < total;
     const uint32_t p = in_range ? pair : total - 1;
     const uint32_t q = p / (uint32_t)a.kp;
-    const int64_t ck = a.cand[p];
+    const int64_t ck = a.cand[(size_t)q * a.cand_cap + (p - q * (uint32_t)a.kp)];
     const bool live = in_range && ck != KEY_PAD;
     const uint32_t grow = key_row(ck);
     uint32_t lrow = grow - a.row_base;
@@ -401,7 +384,7 @@ __global__ __launch_bounds__(256) void rescore_generic_kernel(RescoreArgs a) {
     const uint32_t total = a.nq * (uint32_t)a.kp;
     if (pair >= total) return;  // whole wave exits together
     const uint32_t q = pair / (uint32_t)a.kp;
-    const int64_t ck = a.cand[pair];
+    const int64_t ck = a.cand[(size_t)q * a.cand_cap + (pair - q * (uint32_t)a.kp)];
     const bool live = ck != KEY_PAD;
     const uint32_t grow = key_row(ck);
     uint32_t lrow = grow - a.row_base;
@@ -467,7 +450,8 @@ hipError_t launch_rescore(const RescoreArgs& a, int metric, hipStream_t st) {
 
 // ---------------------------------------------------------------------------
 // Per query: order the kp exact keys, emit the best k as hits, and certify.
-__global__ __launch_bounds__(256) void finalize_batch_kernel(const int64_t* __restrict__ cand,
+__global__ __launch_bounds__(256) void finalize_batch_kernel(const int64_t* __restrict__ cand, uint32_t cand_cap,
+                                                             const uint32_t* __restrict__ overflow,
                                                              const int64_t* __restrict__ exact, int kp, int k,
                                                              const float* __restrict__ eps,
                                                              const uint64_t* __restrict__ ids, uint32_t row_base,
@@ -502,9 +486,11 @@ __global__ __launch_bounds__(256) void finalize_batch_kernel(const int64_t* __re
         out[(size_t)q * k + t] = h;
     }
     if (t == 0) {
-        const int64_t last_cand = cand[(size_t)q * kp + (kp - 1)];
+        const int64_t last_cand = cand[(size_t)q * cand_cap + (kp - 1)];
         uint32_t ok;
-        if (last_cand == KEY_PAD) {
+        if (overflow[q] != 0u) {
+            ok = 0;  // a candidate list overflowed: some candidates were dropped
+        } else if (last_cand == KEY_PAD) {
             ok = 1;  // fewer than kp rows exist: every row was re-scored exactly
         } else {
             const float a_max = key_distance(last_cand);      // k'-th smallest approx distance
@@ -516,15 +502,15 @@ __global__ __launch_bounds__(256) void finalize_batch_kernel(const int64_t* __re
     }
 }
 
-hipError_t launch_finalize_batch(const int64_t* cand, const int64_t* exact, int kp, int k, const float* eps,
+hipError_t launch_finalize_batch(const int64_t* cand, uint32_t cand_cap, const uint32_t* overflow, const int64_t* exact,
+                                 int kp, int k, const float* eps,
                                  const uint64_t* ids, uint32_t row_base, uint32_t n_rows, uint32_t nq,
                                  wax_hip_hit* out, uint32_t* certified, hipStream_t st) {
     if (kp > FUSED_MAX_K || k > kp || k < 1) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(finalize_batch_kernel, dim3(nq), dim3(256), 0, st, cand, exact, kp, k, eps, ids, row_base, n_rows,
-                       out, certified);
+    hipLaunchKernelGGL(finalize_batch_kernel, dim3(nq), dim3(256), 0, st, cand, cand_cap, overflow, exact, kp, k, eps, ids,
+                       row_base, n_rows, out, certified);
     return hipGetLastError();
 }
 
-uint32_t batch_seg_rows() { return SEG_ROWS; }
 
 }  // namespace wax

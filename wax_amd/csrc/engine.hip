@@ -212,11 +212,10 @@ struct BatchWork {
     float* d_qn2 = nullptr;
     float* d_qnorm = nullptr;
     float* d_eps = nullptr;
-    float* d_scores = nullptr;
-    uint64_t scores_cap = 0;
-    int64_t* d_partials = nullptr;
-    uint64_t partials_cap = 0;
-    int64_t* d_cand = nullptr;
+    float* d_tau = nullptr;          // [kBatchMaxQ] running admission thresholds
+    uint32_t* d_cand_count = nullptr;
+    uint32_t* d_overflow = nullptr;
+    int64_t* d_cand = nullptr;       // [kBatchMaxQ][kBatchCandCap]
     int64_t* d_exact = nullptr;
     wax_hip_hit* d_hits = nullptr;
     uint32_t* d_cert = nullptr;
@@ -228,6 +227,8 @@ struct BatchWork {
 };
 
 constexpr uint32_t kBatchMaxQ = 1024;   // queries per GEMM pass
+constexpr uint32_t kBatchCandCap = 4096;  // appended candidates per query between two tighten passes
+constexpr uint32_t kBatchFirstSlab = 2048;  // rows of the first slab (everything passes: tau = +inf)
 constexpr int kBatchMaxK = 80;          // largest k served by the MFMA path (k' = 2k+32 <= 192)
 
 }  // namespace
@@ -526,7 +527,7 @@ void harvest_ring_event(wax_hip_engine* e, int r) {
 // Batched path: Q x D^T on the matrix cores (batch.hip). Called with the shared lock held.
 // Fills results for certified queries; `need_exact[q]` is set for the ones whose certificate
 // failed (the caller re-runs those on the exact single-query path).
-int batch_prepare(wax_hip_engine* e, uint32_t nq_pad, uint64_t scores_elems, uint64_t partial_elems, hipStream_t st) {
+int batch_prepare(wax_hip_engine* e, hipStream_t st) {
     BatchWork& b = e->batch;
     const uint32_t D = e->dims;
     if (!b.ready) {
@@ -536,7 +537,10 @@ int batch_prepare(wax_hip_engine* e, uint32_t nq_pad, uint64_t scores_elems, uin
         HIP_TRY(hipMalloc(&b.d_qn2, kBatchMaxQ * sizeof(float)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch norms");
         HIP_TRY(hipMalloc(&b.d_qnorm, kBatchMaxQ * sizeof(float)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch norms");
         HIP_TRY(hipMalloc(&b.d_eps, kBatchMaxQ * sizeof(float)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch eps");
-        HIP_TRY(hipMalloc(&b.d_cand, (size_t)kBatchMaxQ * FUSED_MAX_K * sizeof(int64_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch candidates");
+        HIP_TRY(hipMalloc(&b.d_tau, kBatchMaxQ * sizeof(float)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch thresholds");
+        HIP_TRY(hipMalloc(&b.d_cand_count, kBatchMaxQ * sizeof(uint32_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch counters");
+        HIP_TRY(hipMalloc(&b.d_overflow, kBatchMaxQ * sizeof(uint32_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch flags");
+        HIP_TRY(hipMalloc(&b.d_cand, (size_t)kBatchMaxQ * kBatchCandCap * sizeof(int64_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch candidates");
         HIP_TRY(hipMalloc(&b.d_exact, (size_t)kBatchMaxQ * FUSED_MAX_K * sizeof(int64_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch candidates");
         HIP_TRY(hipMalloc(&b.d_hits, (size_t)kBatchMaxQ * kBatchMaxK * sizeof(wax_hip_hit)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch hits");
         HIP_TRY(hipMalloc(&b.d_cert, kBatchMaxQ * sizeof(uint32_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch flags");
@@ -564,19 +568,6 @@ int batch_prepare(wax_hip_engine* e, uint32_t nq_pad, uint64_t scores_elems, uin
         std::memcpy(&b.max_norm, &bits, sizeof(float));
         b.mirror_valid = true;
     }
-    if (b.scores_cap < scores_elems) {
-        HIP_TRY(hipStreamSynchronize(st), WAX_HIP_ERR_INTERNAL, "batch sync");
-        (void)hipFree(b.d_scores); b.d_scores = nullptr; b.scores_cap = 0;
-        HIP_TRY(hipMalloc(&b.d_scores, (size_t)scores_elems * sizeof(float)), WAX_HIP_ERR_ALLOC, "Failed to allocate score tile");
-        b.scores_cap = scores_elems;
-    }
-    if (b.partials_cap < partial_elems) {
-        HIP_TRY(hipStreamSynchronize(st), WAX_HIP_ERR_INTERNAL, "batch sync");
-        (void)hipFree(b.d_partials); b.d_partials = nullptr; b.partials_cap = 0;
-        HIP_TRY(hipMalloc(&b.d_partials, (size_t)partial_elems * sizeof(int64_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch partials");
-        b.partials_cap = partial_elems;
-    }
-    (void)nq_pad;
     return WAX_HIP_OK;
 }
 
@@ -602,19 +593,13 @@ int batch_search_mfma(wax_hip_engine* e, const float* queries, uint32_t nq, int 
     int kp = 2 * k_eff + 32;
     if (kp < 64) kp = 64;
     if (kp > FUSED_MAX_K) kp = FUSED_MAX_K;
-    const uint32_t SEG = batch_seg_rows();
+    int rc = batch_prepare(e, st);
+    if (rc != WAX_HIP_OK) return rc;
+    uint64_t max_slab = (uint64_t)e->batch_slab_mb.load() * 16384ull;  // "slab_mb" MB of f32 scores per 256 queries
+    if (max_slab < 2048) max_slab = 2048;
     for (uint32_t q0 = 0; q0 < nq; q0 += kBatchMaxQ) {
         const uint32_t qn = (nq - q0 < kBatchMaxQ) ? nq - q0 : kBatchMaxQ;
         const uint32_t nq_pad = (qn + 127u) & ~127u;
-        uint64_t slab = ((uint64_t)e->batch_slab_mb.load() << 20) / (4ull * nq_pad);
-        slab = (slab / SEG) * SEG;
-        if (slab < SEG) slab = SEG;
-        const uint64_t n_up = ((uint64_t)n + SEG - 1) / SEG * SEG;
-        if (slab > n_up) slab = n_up;
-        const uint32_t slab_rows_max = (uint32_t)slab;
-        const uint32_t segs_total = (n + SEG - 1) / SEG;
-        int rc = batch_prepare(e, nq_pad, (uint64_t)nq_pad * slab_rows_max, (uint64_t)qn * segs_total * (uint64_t)kp, st);
-        if (rc != WAX_HIP_OK) return rc;
         const float* qsrc = queries + (uint64_t)q0 * D;
         for (uint32_t q = 0; q < qn; ++q) {
             b.h_qnorm[q] = query_norm(qsrc + (uint64_t)q * D, D);
@@ -625,24 +610,30 @@ int batch_search_mfma(wax_hip_engine* e, const float* queries, uint32_t nq, int 
         HIP_TRY(hipMemcpyAsync(b.d_eps, b.h_eps, qn * sizeof(float), hipMemcpyHostToDevice, st), WAX_HIP_ERR_INTERNAL, "eps upload");
         HIP_TRY(launch_mirror(b.d_q, qn, nq_pad, D, e->metric == WAX_HIP_METRIC_COSINE ? 1 : 0, b.d_qb, b.d_qn2, nullptr, st),
                 WAX_HIP_ERR_INTERNAL, "query mirror launch");
-        uint32_t seg_first = 0;
-        for (uint32_t s0 = 0; s0 < n; s0 += slab_rows_max) {
-            const uint32_t rows = (n - s0 < slab_rows_max) ? n - s0 : slab_rows_max;
+        HIP_TRY(launch_batch_reset(b.d_tau, b.d_cand_count, b.d_overflow, nq_pad, st), WAX_HIP_ERR_INTERNAL, "batch reset launch");
+        // Slabs grow geometrically: with tau tightened after each slab, a slab of s rows appends about
+        // kp * s / rows_seen candidates per query, so "next slab = 3 x rows seen" keeps every list ~3*kp long.
+        uint32_t s0 = 0;
+        while (s0 < n) {
+            uint64_t want = (s0 == 0) ? kBatchFirstSlab : 3ull * s0;
+            if (want > max_slab) want = max_slab;
+            want = (want + 127ull) & ~127ull;
+            const uint32_t rows = (n - s0 < want) ? n - s0 : (uint32_t)want;
             GemmArgs g{};
-            g.qb = b.d_qb; g.cb = b.d_cb; g.q_n2 = b.d_qn2; g.v_n2 = b.d_vn2; g.scores = b.d_scores;
-            g.dims = D; g.n_rows = n; g.slab0 = s0; g.slab_rows = rows; g.slab_ld = slab_rows_max; g.nq = qn; g.nqt = nq_pad / 128;
+            g.qb = b.d_qb; g.cb = b.d_cb; g.q_n2 = b.d_qn2; g.v_n2 = b.d_vn2; g.tau = b.d_tau;
+            g.cand = b.d_cand; g.cand_count = b.d_cand_count; g.cand_cap = kBatchCandCap; g.row_base = (uint32_t)e->row_base;
+            g.dims = D; g.n_rows = n; g.slab0 = s0; g.slab_rows = rows; g.nq = qn; g.nqt = nq_pad / 128;
             HIP_TRY(launch_batch_gemm(g, e->metric, st), WAX_HIP_ERR_INTERNAL, "gemm kernel launch");
-            HIP_TRY(launch_select_scores(b.d_scores, slab_rows_max, s0, rows, (uint32_t)e->row_base, kp, qn, seg_first, segs_total,
-                                         b.d_partials, st), WAX_HIP_ERR_INTERNAL, "select kernel launch");
-            seg_first += (rows + SEG - 1) / SEG;
+            HIP_TRY(launch_tighten(b.d_cand, kBatchCandCap, b.d_cand_count, kp, qn, b.d_tau, b.d_overflow, st),
+                    WAX_HIP_ERR_INTERNAL, "tighten kernel launch");
+            s0 += rows;
         }
-        HIP_TRY(launch_merge_query_keys(b.d_partials, segs_total * (uint32_t)kp, kp, qn, b.d_cand, st), WAX_HIP_ERR_INTERNAL, "candidate merge launch");
         RescoreArgs r{};
         r.store = e->d_store; r.queries = b.d_q; r.q_norm = b.d_qnorm; r.cand = b.d_cand; r.exact = b.d_exact;
-        r.n_rows = n; r.row_base = (uint32_t)e->row_base; r.dims = D; r.nq = qn; r.kp = kp;
+        r.n_rows = n; r.row_base = (uint32_t)e->row_base; r.dims = D; r.nq = qn; r.cand_cap = kBatchCandCap; r.kp = kp;
         HIP_TRY(launch_rescore(r, e->metric, st), WAX_HIP_ERR_INTERNAL, "rescore kernel launch");
-        HIP_TRY(launch_finalize_batch(b.d_cand, b.d_exact, kp, k_eff, b.d_eps, e->d_ids, (uint32_t)e->row_base, n, qn, b.d_hits,
-                                      b.d_cert, st), WAX_HIP_ERR_INTERNAL, "finalize kernel launch");
+        HIP_TRY(launch_finalize_batch(b.d_cand, kBatchCandCap, b.d_overflow, b.d_exact, kp, k_eff, b.d_eps, e->d_ids,
+                                      (uint32_t)e->row_base, n, qn, b.d_hits, b.d_cert, st), WAX_HIP_ERR_INTERNAL, "finalize kernel launch");
         HIP_TRY(hipMemcpyAsync(b.h_hits, b.d_hits, (size_t)qn * k_eff * sizeof(wax_hip_hit), hipMemcpyDeviceToHost, st), WAX_HIP_ERR_INTERNAL, "hits download");
         HIP_TRY(hipMemcpyAsync(b.h_cert, b.d_cert, qn * sizeof(uint32_t), hipMemcpyDeviceToHost, st), WAX_HIP_ERR_INTERNAL, "flags download");
         HIP_TRY(hipStreamSynchronize(st), WAX_HIP_ERR_INTERNAL, "batch search failed on device");
@@ -764,8 +755,8 @@ void wax_hip_engine_destroy(wax_hip_engine* e) {
     {
         BatchWork& b = e->batch;
         (void)hipFree(b.d_cb); (void)hipFree(b.d_vn2); (void)hipFree(b.d_maxnorm); (void)hipFree(b.d_q); (void)hipFree(b.d_qb);
-        (void)hipFree(b.d_qn2); (void)hipFree(b.d_qnorm); (void)hipFree(b.d_eps); (void)hipFree(b.d_scores);
-        (void)hipFree(b.d_partials); (void)hipFree(b.d_cand); (void)hipFree(b.d_exact); (void)hipFree(b.d_hits);
+        (void)hipFree(b.d_qn2); (void)hipFree(b.d_qnorm); (void)hipFree(b.d_eps); (void)hipFree(b.d_tau);
+        (void)hipFree(b.d_cand_count); (void)hipFree(b.d_overflow); (void)hipFree(b.d_cand); (void)hipFree(b.d_exact); (void)hipFree(b.d_hits);
         (void)hipFree(b.d_cert); (void)hipHostFree(b.h_hits); (void)hipHostFree(b.h_cert); (void)hipHostFree(b.h_qnorm);
         (void)hipHostFree(b.h_eps);
     }

@@ -73,12 +73,15 @@ struct GemmArgs {
     const unsigned short* cb;   // [n_rows][dims] bf16 corpus mirror
     const float* q_n2;          // [nq_pad] ||q||^2 (L2 epilogue)
     const float* v_n2;          // [n_rows] ||v||^2 (L2 epilogue)
-    float* scores;              // [nq_pad][slab_ld] approx distances of this slab
+    const float* tau;           // [nq_pad] per-query admission threshold (approx distance), +inf at the start
+    int64_t* cand;              // [nq][cand_cap] appended candidate keys
+    uint32_t* cand_count;       // [nq]
+    uint32_t cand_cap;
+    uint32_t row_base;
     uint32_t dims;
     uint32_t n_rows;
     uint32_t slab0;
     uint32_t slab_rows;
-    uint32_t slab_ld;
     uint32_t nq;
     uint32_t nqt;               // nq_pad / 128
 };
@@ -86,23 +89,21 @@ struct RescoreArgs {
     const float* store;
     const float* queries;       // [nq][dims] f32
     const float* q_norm;        // [nq]
-    const int64_t* cand;        // [nq][kp]
+    const int64_t* cand;        // [nq][cand_cap], first kp entries = the candidates (ascending approx key)
     int64_t* exact;             // [nq][kp]
-    uint32_t n_rows, row_base, dims, nq;
+    uint32_t n_rows, row_base, dims, nq, cand_cap;
     int kp;
 };
 hipError_t launch_mirror(const float* src, uint32_t n_rows, uint32_t n_rows_padded, uint32_t dims, int normalize,
                          unsigned short* dst, float* norm2, unsigned int* max_norm_bits, hipStream_t stream);
 hipError_t launch_batch_gemm(const GemmArgs& a, int metric, hipStream_t stream);
-hipError_t launch_select_scores(const float* scores, uint32_t slab_ld, uint32_t slab0, uint32_t slab_rows,
-                                uint32_t row_base, int kp, uint32_t nq, uint32_t seg_first, uint32_t segs_total,
-                                int64_t* partials, hipStream_t stream);
-hipError_t launch_merge_query_keys(const int64_t* partials, uint32_t n_in, int kp, uint32_t nq, int64_t* cand,
-                                   hipStream_t stream);
+hipError_t launch_tighten(int64_t* cand, uint32_t cand_cap, uint32_t* cand_count, int kp, uint32_t nq, float* tau,
+                          uint32_t* overflow, hipStream_t stream);
+hipError_t launch_batch_reset(float* tau, uint32_t* cand_count, uint32_t* overflow, uint32_t n, hipStream_t stream);
 hipError_t launch_rescore(const RescoreArgs& a, int metric, hipStream_t stream);
-hipError_t launch_finalize_batch(const int64_t* cand, const int64_t* exact, int kp, int k, const float* eps,
+hipError_t launch_finalize_batch(const int64_t* cand, uint32_t cand_cap, const uint32_t* overflow, const int64_t* exact,
+                                 int kp, int k, const float* eps,
                                  const uint64_t* ids, uint32_t row_base, uint32_t n_rows, uint32_t nq,
                                  wax_hip_hit* out, uint32_t* certified, hipStream_t stream);
-uint32_t batch_seg_rows();
 
 }  // namespace wax

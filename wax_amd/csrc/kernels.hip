@@ -247,9 +247,13 @@ bool scan_variant_info(uint32_t dims, int variant, ScanVariantInfo* out) {
 int scan_grid_for(uint32_t n_rows, uint32_t dims, int variant, int grid_cap) {
     ScanVariantInfo info;
     if (!scan_variant_info(dims, variant, &info)) scan_variant_info(dims, 0, &info);
-    // Default 1024 workgroups = 4 per CU, all co-resident (89 VGPRs => 5 waves/SIMD); the on-device
-    // sweep (profiles/r01_sweep.md) shows 512..8192 within 1 % of each other at 10M x 384.
-    if (grid_cap <= 0) grid_cap = 1024;
+    // Default 512 workgroups = 2 per CU (8 of the 20 wave slots the kernel's 82 VGPRs allow). The
+    // on-device sweeps (profiles/r01/*sweep.json) show 512..8192 workgroups within 1 % of each other
+    // at 10M x 384 when the kernel runs alone, but a grid that fills the chip (1024 = 4 per CU) loses
+    // 8 % as soon as anything co-runs (the merge kernel, a copy, an RCCL kernel): the co-runner displaces
+    // a few long-lived scan workgroups, which then start late and finish alone at single-workgroup
+    // bandwidth. Half occupancy keeps every scan workgroup resident from the first cycle.
+    if (grid_cap <= 0) grid_cap = 512;
     if (grid_cap > MAX_GRID_BLOCKS) grid_cap = MAX_GRID_BLOCKS;
     const uint64_t nchunks = ((uint64_t)n_rows + info.rows_per_chunk - 1) / info.rows_per_chunk;
     const uint64_t max_waves = (uint64_t)grid_cap * SCAN_WAVES;
