@@ -43,6 +43,7 @@ for s in $STAGES; do
       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_batch" -o batch -- \
           python "$R/tools/batch_bench.py" --nq 256 --reps 3 > "$OUT/batchprof.log" 2>&1); rc=$?
       find "$OUT/prof_batch" -name "*kernel_stats.csv" -exec cp {} "$OUT/batch_kernel_stats.csv" \; 2>/dev/null
+      find "$OUT/prof_batch" -name "*kernel_trace.csv" -exec sh -c 'head -1 "$1" > "$2"; grep "wax::" "$1" | tail -300 >> "$2"' _ {} "$OUT/batch_kernel_trace.csv" \; 2>/dev/null
       find "$OUT/prof_batch" -name "*kernel_trace.csv" -delete 2>/dev/null ;;
     sweep)
       timeout 1200 python tools/sweep.py --tag "$TAG" > "$OUT/sweep.log" 2>&1; rc=$?

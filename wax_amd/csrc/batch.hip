@@ -205,38 +205,132 @@ __global__ __launch_bounds__(256) void batch_gemm_kernel(GemmArgs a) {
     float* tau_s = reinterpret_cast<float*>(As);          // [GM] thresholds of this tile's queries
     float* qn2 = reinterpret_cast<float*>(As) + GM;       // [GM] ||q||^2 (L2 only)
     __syncthreads();                                      // every wave is done reading As/Bs fragments
+    unsigned int* wcnt = reinterpret_cast<unsigned int*>(As) + 2 * GM;  // [4] staged-candidate counters, one per wave
     if (tid < GM) {
         tau_s[tid] = a.tau[m0 + tid];
         if (METRIC == BM_L2) qn2[tid] = a.q_n2[m0 + tid];
+        if (tid < 4) wcnt[tid] = 0u;
     }
     __syncthreads();
+    // Thresholds (and ||q||^2) of the 32 queries this lane's accumulators belong to, fetched once:
+    // a per-element LDS read + compare + branch chain costs more than the MFMAs of the tile.
+    float tq[2][16], qq[2][16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qloc = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            tq[i][r] = tau_s[qloc];
+            qq[i][r] = (METRIC == BM_L2) ? qn2[qloc] : 0.f;
+        }
     const uint32_t slab_end = a.slab0 + a.slab_rows;
+    uint32_t rowj[2];
+    float vn2j[2];
+    unsigned long long pass = 0ull;  // bit j*32 + i*16 + r
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const uint32_t row = n0 + wn * 64 + j * 32 + (lane & 31);
-        if (row >= slab_end) continue;
-        float vn2 = 0.f;
-        if (METRIC == BM_L2) vn2 = a.v_n2[row];
+        rowj[j] = n0 + wn * 64 + j * 32 + (lane & 31);
+        const bool row_ok = rowj[j] < slab_end;
+        vn2j[j] = (METRIC == BM_L2 && row_ok) ? a.v_n2[rowj[j]] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int qloc = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const float dot = acc[i][j][r];
                 float d;
-                if (METRIC == BM_L2) d = qn2[qloc] + vn2 - 2.0f * dot;
+                if (METRIC == BM_L2) d = qq[i][r] + vn2j[j] - 2.0f * dot;
                 else d = 1.0f - dot;  // cosine: both operands were normalised by mirror_kernel; dot: USearch ip
                 d += 0.0f;
-                if (d <= tau_s[qloc]) {  // NaN fails the test: such rows can never be candidates
-                    const uint32_t q = m0 + qloc;
-                    if (q < a.nq) {
-                        const uint32_t pos = atomicAdd(&a.cand_count[q], 1u);
-                        if (pos < a.cand_cap) a.cand[(size_t)q * a.cand_cap + pos] = make_key(d, a.row_base + row);
+                // NaN fails the test (such rows can never be candidates); padded queries have tau = -inf
+                const bool p = row_ok && (d <= tq[i][r]);
+                pass |= (unsigned long long)(p ? 1u : 0u) << (j * 32 + i * 16 + r);
+            }
+    }
+    if (a.dense != nullptr) {
+        // First slab: no threshold exists yet, every distance would be appended. Store the tile densely
+        // (coalesced 128-byte runs per query row); tighten_kernel reads it back as the first candidate set.
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (rowj[j] >= slab_end) continue;
+            float* __restrict__ dst = a.dense + (rowj[j] - a.slab0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int qloc = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const float dot = acc[i][j][r];
+                    float d;
+                    if (METRIC == BM_L2) d = qq[i][r] + vn2j[j] - 2.0f * dot;
+                    else d = 1.0f - dot;
+                    d = (d != d) ? __builtin_inff() : d;
+                    dst[(size_t)(m0 + qloc) * a.dense_ld] = d + 0.0f;
+                }
+        }
+        return;
+    }
+    if (!__any(pass != 0ull)) return;  // the common case once tau is tight
+    // Survivors (~kp * slab / rows_seen per query per slab) are first compacted into a per-wave LDS
+    // stage (no global traffic), then appended with all 64 lanes' atomics in flight at once: one
+    // atomic round trip per 64 survivors instead of one per accumulator slot.
+    constexpr unsigned STAGE_CAP = 256;                                   // 16-byte entries per wave
+    u32x4* stage = reinterpret_cast<u32x4*>(Bs) + wave * STAGE_CAP;        // Bs is free after the K loop (18 KB)
+    const unsigned mine = (unsigned)__popcll(pass);
+    unsigned off = 0;
+    if (mine) off = atomicAdd(&wcnt[wave], mine);                          // LDS atomic: exclusive offset of this lane
+    wave_lds_fence();
+    const unsigned total = (unsigned)__builtin_amdgcn_readfirstlane((int)wcnt[wave]);
+    if (total <= STAGE_CAP) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if ((pass >> (j * 32 + i * 16 + r)) & 1ull) {
+                        const int qloc = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        const float dot = acc[i][j][r];
+                        float d;
+                        if (METRIC == BM_L2) d = qq[i][r] + vn2j[j] - 2.0f * dot;
+                        else d = 1.0f - dot;
+                        d += 0.0f;
+                        const int64_t key = make_key(d, a.row_base + rowj[j]);
+                        u32x4 e;
+                        e.x = (unsigned)((unsigned long long)key & 0xffffffffull);
+                        e.y = (unsigned)((unsigned long long)key >> 32);
+                        e.z = m0 + (unsigned)qloc;
+                        e.w = 0u;
+                        stage[off++] = e;
                     }
                 }
-            }
+        wave_lds_fence();
+        for (unsigned t = (unsigned)lane; t < total; t += WAVE) {
+            const u32x4 e = stage[t];
+            const uint32_t q = e.z;
+            const uint32_t pos = atomicAdd(&a.cand_count[q], 1u);
+            if (pos < a.cand_cap)
+                a.cand[(size_t)q * a.cand_cap + pos] = (int64_t)(((unsigned long long)e.y << 32) | (unsigned long long)e.x);
         }
+        return;
     }
+    // Stage overflow (a loose threshold, e.g. adversarially ordered rows): direct per-slot appends.
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if ((pass >> (j * 32 + i * 16 + r)) & 1ull) {
+                    const int qloc = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const float dot = acc[i][j][r];
+                    float d;
+                    if (METRIC == BM_L2) d = qq[i][r] + vn2j[j] - 2.0f * dot;
+                    else d = 1.0f - dot;
+                    d += 0.0f;
+                    const uint32_t q = m0 + qloc;
+                    const uint32_t pos = atomicAdd(&a.cand_count[q], 1u);
+                    if (pos < a.cand_cap) a.cand[(size_t)q * a.cand_cap + pos] = make_key(d, a.row_base + rowj[j]);
+                }
+            }
 }
 
 hipError_t launch_batch_gemm(const GemmArgs& a, int metric, hipStream_t st) {
@@ -258,19 +352,22 @@ hipError_t launch_batch_gemm(const GemmArgs& a, int metric, hipStream_t st) {
 template <int CAP>
 __global__ __launch_bounds__(SCAN_THREADS) void tighten_kernel(int64_t* __restrict__ cand, uint32_t cand_cap,
                                                               uint32_t* __restrict__ cand_count, int kp,
-                                                              float* __restrict__ tau, uint32_t* __restrict__ overflow) {
+                                                              float* __restrict__ tau, uint32_t* __restrict__ overflow,
+                                                              const float* __restrict__ dense, uint32_t dense_ld,
+                                                              uint32_t dense_rows, uint32_t dense_row0) {
     __shared__ int64_t lds[SCAN_WAVES * CAP + SCAN_WAVES + FUSED_MAX_K];
     int* counts = reinterpret_cast<int*>(lds + SCAN_WAVES * CAP);
     int64_t* fin = lds + SCAN_WAVES * CAP + SCAN_WAVES;
     const int lane = lane_id();
     const int wave = (int)(threadIdx.x >> 6);
     const uint32_t q = blockIdx.x;
-    uint32_t n_in = cand_count[q];
-    if (n_in > cand_cap) {
+    uint32_t n_in = (dense != nullptr) ? dense_rows : cand_count[q];
+    if (dense == nullptr && n_in > cand_cap) {
         if (threadIdx.x == 0) overflow[q] = 1u;
         n_in = cand_cap;
     }
     int64_t* __restrict__ mine = cand + (size_t)q * cand_cap;
+    const float* __restrict__ drow = (dense != nullptr) ? dense + (size_t)q * dense_ld : nullptr;
     WaveTopK<CAP> tk;
     tk.init(lds + wave * CAP, kp);
     constexpr int LOADS = 4;
@@ -279,7 +376,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void tighten_kernel(int64_t* __restri
 #pragma unroll
         for (int i = 0; i < LOADS; ++i) {
             const uint32_t idx = base + i * SCAN_THREADS + threadIdx.x;
-            keys[i] = (idx < n_in) ? mine[idx] : KEY_PAD;
+            if (idx >= n_in) keys[i] = KEY_PAD;
+            else if (drow != nullptr) keys[i] = make_key(drow[idx], dense_row0 + idx);  // first slab: dense tile
+            else keys[i] = mine[idx];
         }
 #pragma unroll
         for (int i = 0; i < LOADS; ++i) tk.push_wide(keys[i], keys[i] != KEY_PAD);
@@ -299,22 +398,30 @@ __global__ __launch_bounds__(SCAN_THREADS) void tighten_kernel(int64_t* __restri
 }
 
 hipError_t launch_tighten(int64_t* cand, uint32_t cand_cap, uint32_t* cand_count, int kp, uint32_t nq, float* tau,
-                          uint32_t* overflow, hipStream_t st) {
+                          uint32_t* overflow, const float* dense, uint32_t dense_ld, uint32_t dense_rows,
+                          uint32_t dense_row0, hipStream_t st) {
     if (kp <= 32)
-        hipLaunchKernelGGL((tighten_kernel<128>), dim3(nq), dim3(SCAN_THREADS), 0, st, cand, cand_cap, cand_count, kp, tau, overflow);
+        hipLaunchKernelGGL((tighten_kernel<128>), dim3(nq), dim3(SCAN_THREADS), 0, st, cand, cand_cap, cand_count, kp, tau,
+                           overflow, dense, dense_ld, dense_rows, dense_row0);
     else
-        hipLaunchKernelGGL((tighten_kernel<256>), dim3(nq), dim3(SCAN_THREADS), 0, st, cand, cand_cap, cand_count, kp, tau, overflow);
+        hipLaunchKernelGGL((tighten_kernel<256>), dim3(nq), dim3(SCAN_THREADS), 0, st, cand, cand_cap, cand_count, kp, tau,
+                           overflow, dense, dense_ld, dense_rows, dense_row0);
     return hipGetLastError();
 }
 
 // Fill tau with +inf and zero the counters / overflow flags for a new batch.
-__global__ void batch_reset_kernel(float* tau, uint32_t* cand_count, uint32_t* overflow, uint32_t n) {
+__global__ void batch_reset_kernel(float* tau, uint32_t* cand_count, uint32_t* overflow, uint32_t nq, uint32_t nq_pad) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { tau[i] = __builtin_inff(); cand_count[i] = 0u; overflow[i] = 0u; }
+    if (i < nq_pad) {
+        tau[i] = (i < nq) ? __builtin_inff() : -__builtin_inff();  // padding queries admit nothing
+        cand_count[i] = 0u;
+        overflow[i] = 0u;
+    }
 }
 
-hipError_t launch_batch_reset(float* tau, uint32_t* cand_count, uint32_t* overflow, uint32_t n, hipStream_t st) {
-    hipLaunchKernelGGL(batch_reset_kernel, dim3((n + 255) / 256), dim3(256), 0, st, tau, cand_count, overflow, n);
+hipError_t launch_batch_reset(float* tau, uint32_t* cand_count, uint32_t* overflow, uint32_t nq, uint32_t nq_pad,
+                              hipStream_t st) {
+    hipLaunchKernelGGL(batch_reset_kernel, dim3((nq_pad + 255) / 256), dim3(256), 0, st, tau, cand_count, overflow, nq, nq_pad);
     return hipGetLastError();
 }
 

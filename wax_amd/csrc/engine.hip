@@ -213,6 +213,7 @@ struct BatchWork {
     float* d_qnorm = nullptr;
     float* d_eps = nullptr;
     float* d_tau = nullptr;          // [kBatchMaxQ] running admission thresholds
+    float* d_dense = nullptr;        // [kBatchMaxQ][kBatchFirstSlab] first-slab score tile
     uint32_t* d_cand_count = nullptr;
     uint32_t* d_overflow = nullptr;
     int64_t* d_cand = nullptr;       // [kBatchMaxQ][kBatchCandCap]
@@ -538,6 +539,7 @@ int batch_prepare(wax_hip_engine* e, hipStream_t st) {
         HIP_TRY(hipMalloc(&b.d_qnorm, kBatchMaxQ * sizeof(float)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch norms");
         HIP_TRY(hipMalloc(&b.d_eps, kBatchMaxQ * sizeof(float)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch eps");
         HIP_TRY(hipMalloc(&b.d_tau, kBatchMaxQ * sizeof(float)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch thresholds");
+        HIP_TRY(hipMalloc(&b.d_dense, (size_t)kBatchMaxQ * kBatchFirstSlab * sizeof(float)), WAX_HIP_ERR_ALLOC, "Failed to allocate first-slab tile");
         HIP_TRY(hipMalloc(&b.d_cand_count, kBatchMaxQ * sizeof(uint32_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch counters");
         HIP_TRY(hipMalloc(&b.d_overflow, kBatchMaxQ * sizeof(uint32_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch flags");
         HIP_TRY(hipMalloc(&b.d_cand, (size_t)kBatchMaxQ * kBatchCandCap * sizeof(int64_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch candidates");
@@ -610,7 +612,7 @@ int batch_search_mfma(wax_hip_engine* e, const float* queries, uint32_t nq, int 
         HIP_TRY(hipMemcpyAsync(b.d_eps, b.h_eps, qn * sizeof(float), hipMemcpyHostToDevice, st), WAX_HIP_ERR_INTERNAL, "eps upload");
         HIP_TRY(launch_mirror(b.d_q, qn, nq_pad, D, e->metric == WAX_HIP_METRIC_COSINE ? 1 : 0, b.d_qb, b.d_qn2, nullptr, st),
                 WAX_HIP_ERR_INTERNAL, "query mirror launch");
-        HIP_TRY(launch_batch_reset(b.d_tau, b.d_cand_count, b.d_overflow, nq_pad, st), WAX_HIP_ERR_INTERNAL, "batch reset launch");
+        HIP_TRY(launch_batch_reset(b.d_tau, b.d_cand_count, b.d_overflow, qn, nq_pad, st), WAX_HIP_ERR_INTERNAL, "batch reset launch");
         // Slabs grow geometrically: with tau tightened after each slab, a slab of s rows appends about
         // kp * s / rows_seen candidates per query, so "next slab = 3 x rows seen" keeps every list ~3*kp long.
         uint32_t s0 = 0;
@@ -623,8 +625,12 @@ int batch_search_mfma(wax_hip_engine* e, const float* queries, uint32_t nq, int 
             g.qb = b.d_qb; g.cb = b.d_cb; g.q_n2 = b.d_qn2; g.v_n2 = b.d_vn2; g.tau = b.d_tau;
             g.cand = b.d_cand; g.cand_count = b.d_cand_count; g.cand_cap = kBatchCandCap; g.row_base = (uint32_t)e->row_base;
             g.dims = D; g.n_rows = n; g.slab0 = s0; g.slab_rows = rows; g.nq = qn; g.nqt = nq_pad / 128;
+            const bool first = (s0 == 0);  // no threshold yet: dense tile instead of appending everything
+            g.dense = first ? b.d_dense : nullptr;
+            g.dense_ld = kBatchFirstSlab;
             HIP_TRY(launch_batch_gemm(g, e->metric, st), WAX_HIP_ERR_INTERNAL, "gemm kernel launch");
-            HIP_TRY(launch_tighten(b.d_cand, kBatchCandCap, b.d_cand_count, kp, qn, b.d_tau, b.d_overflow, st),
+            HIP_TRY(launch_tighten(b.d_cand, kBatchCandCap, b.d_cand_count, kp, qn, b.d_tau, b.d_overflow,
+                                   first ? b.d_dense : nullptr, kBatchFirstSlab, rows, (uint32_t)e->row_base + s0, st),
                     WAX_HIP_ERR_INTERNAL, "tighten kernel launch");
             s0 += rows;
         }
@@ -755,7 +761,7 @@ void wax_hip_engine_destroy(wax_hip_engine* e) {
     {
         BatchWork& b = e->batch;
         (void)hipFree(b.d_cb); (void)hipFree(b.d_vn2); (void)hipFree(b.d_maxnorm); (void)hipFree(b.d_q); (void)hipFree(b.d_qb);
-        (void)hipFree(b.d_qn2); (void)hipFree(b.d_qnorm); (void)hipFree(b.d_eps); (void)hipFree(b.d_tau);
+        (void)hipFree(b.d_qn2); (void)hipFree(b.d_qnorm); (void)hipFree(b.d_eps); (void)hipFree(b.d_tau); (void)hipFree(b.d_dense);
         (void)hipFree(b.d_cand_count); (void)hipFree(b.d_overflow); (void)hipFree(b.d_cand); (void)hipFree(b.d_exact); (void)hipFree(b.d_hits);
         (void)hipFree(b.d_cert); (void)hipHostFree(b.h_hits); (void)hipHostFree(b.h_cert); (void)hipHostFree(b.h_qnorm);
         (void)hipHostFree(b.h_eps);

@@ -74,6 +74,8 @@ struct GemmArgs {
     const float* q_n2;          // [nq_pad] ||q||^2 (L2 epilogue)
     const float* v_n2;          // [n_rows] ||v||^2 (L2 epilogue)
     const float* tau;           // [nq_pad] per-query admission threshold (approx distance), +inf at the start
+    float* dense;               // non-null (first slab only): store the whole tile [nq_pad][dense_ld] instead of filtering
+    uint32_t dense_ld;
     int64_t* cand;              // [nq][cand_cap] appended candidate keys
     uint32_t* cand_count;       // [nq]
     uint32_t cand_cap;
@@ -98,8 +100,10 @@ hipError_t launch_mirror(const float* src, uint32_t n_rows, uint32_t n_rows_padd
                          unsigned short* dst, float* norm2, unsigned int* max_norm_bits, hipStream_t stream);
 hipError_t launch_batch_gemm(const GemmArgs& a, int metric, hipStream_t stream);
 hipError_t launch_tighten(int64_t* cand, uint32_t cand_cap, uint32_t* cand_count, int kp, uint32_t nq, float* tau,
-                          uint32_t* overflow, hipStream_t stream);
-hipError_t launch_batch_reset(float* tau, uint32_t* cand_count, uint32_t* overflow, uint32_t n, hipStream_t stream);
+                          uint32_t* overflow, const float* dense, uint32_t dense_ld, uint32_t dense_rows,
+                          uint32_t dense_row0, hipStream_t stream);
+hipError_t launch_batch_reset(float* tau, uint32_t* cand_count, uint32_t* overflow, uint32_t nq, uint32_t nq_pad,
+                              hipStream_t stream);
 hipError_t launch_rescore(const RescoreArgs& a, int metric, hipStream_t stream);
 hipError_t launch_finalize_batch(const int64_t* cand, uint32_t cand_cap, const uint32_t* overflow, const int64_t* exact,
                                  int kp, int k, const float* eps,
