@@ -52,6 +52,9 @@ def parse_args():
     p.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--host-merge", action="store_true", help="N>1: merge gathered hits on the host instead of the device")
+    p.add_argument("--exchange", choices=["rccl", "host"], default="rccl",
+                   help="N>1: rccl = all-gather device buffers over RCCL (default); host = download + gloo all-gather "
+                        "(control path; also lets two test ranks share one GPU with WAX_BENCH_SAME_DEVICE=1)")
     return p.parse_args()
 
 
@@ -119,11 +122,17 @@ def main():
         log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: launch with torch.distributed.run for N>1")
         if world == 1 and args.gpus > 1:
             sys.exit(2)
+    if os.environ.get("WAX_BENCH_SAME_DEVICE"):  # testing only: several ranks on one GPU (needs --exchange host)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    use_rccl = args.exchange == "rccl"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if use_rccl:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from wax_amd import HIPVectorEngine, VectorMetric, build, sharded
     build.build()
@@ -167,7 +176,7 @@ def main():
             return eng.collect(t, k)
     else:
         searcher = sharded.ShardedSearcher(eng, rank, world, k, depth=args.depth, n_streams=2,
-                                           host_merge=args.host_merge)
+                                           host_merge=args.host_merge, exchange=args.exchange)
 
         def submit(q):
             searcher.submit(q)
@@ -193,7 +202,10 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            if use_rccl:
+                dist.barrier(device_ids=[local_rank])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     run(queries[:args.warmup])
@@ -204,11 +216,14 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if use_rccl else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st = eng.stats()
     assert len(last[0]) == min(k, n)
+    import hashlib
+    checksum = hashlib.sha256(np.asarray(last[0], dtype=np.uint64).tobytes()
+                              + np.asarray(last[1], dtype=np.float32).tobytes()).hexdigest()[:16]
 
     if rank == 0:
         qps = args.steps / elapsed
@@ -244,7 +259,9 @@ def main():
                 "rows": n, "dims": dims, "top_k": k, "rows_per_gpu": hi - lo,
                 "parallelism": f"row-shard x{world}" + (" + RCCL all-gather of per-shard top-k" if world > 1 else ""),
                 "pipeline_depth": args.depth,
-                "merge": "host" if (world > 1 and args.host_merge) else "device",
+                "merge": "host" if (world > 1 and (args.host_merge or not use_rccl)) else "device",
+                "exchange": ("rccl all_gather" if use_rccl else "host (gloo)") if world > 1 else "none",
+                "last_result_checksum": checksum,
             },
             "roofline": {
                 "bound": "hbm",
@@ -268,7 +285,10 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier(device_ids=[local_rank])
+        if use_rccl:
+            dist.barrier(device_ids=[local_rank])
+        else:
+            dist.barrier()
         dist.destroy_process_group()
 
 

@@ -602,3 +602,47 @@ def test_batch_throughput_config3(wax):
         s_ids, s_scores = eng.searchArrays(queries[i], k)
         assert np.array_equal(ids[i], s_ids) and np.array_equal(scores[i], s_scores)
     assert fb <= 3 * 26
+
+
+# ---------------------------------------------------------------------------
+# the N>1 bench path end to end on one GPU: two / three ranks share GPU 0 and exchange per-shard
+# top-k through the host (gloo) — RCCL itself refuses duplicate GPUs; everything else (shard bounds,
+# global-row keys, pipelined ShardedSearcher, merge, barriers, max-over-ranks timing) is the code the
+# driver runs with --gpus N over RCCL.
+
+def _run_bench(nproc, extra, tmp_path):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--rows", "300000", "--steps", "12", "--warmup", "2", "--no-cpu-baseline"] + extra
+    env = dict(os.environ)
+    if nproc == 1:
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common
+    else:
+        env["WAX_BENCH_SAME_DEVICE"] = "1"
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+               "--master-addr", "127.0.0.1", "--master-port", str(29600 + nproc),
+               os.path.join(root, "bench.py"), "--gpus", str(nproc), "--exchange", "host"] + common
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1]
+    return json.loads(line)
+
+
+def test_bench_contract_and_shard_invariance(wax, tmp_path):
+    one = _run_bench(1, [], tmp_path)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in one, key
+    assert one["n_gpus"] == 1 and one["steps"] == 12 and one["dtype"] == "f32" and one["vs_baseline"] is None
+    r = one["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["kernel_launches_timed"] == 12
+    assert abs(one["value"] - 12 / (one["ms_per_step"] * 12e-3)) < 1e-6 * one["value"]
+    two = _run_bench(2, [], tmp_path)
+    three = _run_bench(3, [], tmp_path)
+    assert two["n_gpus"] == 2 and three["n_gpus"] == 3
+    assert one["config"]["last_result_checksum"] == two["config"]["last_result_checksum"] \
+        == three["config"]["last_result_checksum"]

@@ -45,6 +45,22 @@ for s in $STAGES; do
       find "$OUT/prof_batch" -name "*kernel_stats.csv" -exec cp {} "$OUT/batch_kernel_stats.csv" \; 2>/dev/null
       find "$OUT/prof_batch" -name "*kernel_trace.csv" -exec sh -c 'head -1 "$1" > "$2"; grep "wax::" "$1" | tail -300 >> "$2"' _ {} "$OUT/batch_kernel_trace.csv" \; 2>/dev/null
       find "$OUT/prof_batch" -name "*kernel_trace.csv" -delete 2>/dev/null ;;
+    multi)
+      # N>1 code path on a 1-GPU box: two ranks share GPU 0, exchange over gloo (RCCL refuses duplicate GPUs).
+      timeout 600 python bench.py --gpus 1 --rows 2000000 --steps 50 --warmup 5 --no-cpu-baseline > "$OUT/multi_n1.json" 2> "$OUT/multi_n1.err"
+      WAX_BENCH_SAME_DEVICE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 \
+          bench.py --gpus 2 --rows 2000000 --steps 50 --warmup 5 --exchange host > "$OUT/multi_n2_host.json" 2> "$OUT/multi_n2_host.err"; rc=$?
+      WAX_BENCH_SAME_DEVICE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 3 --master-addr 127.0.0.1 --master-port 29512 \
+          bench.py --gpus 3 --rows 2000000 --steps 50 --warmup 5 --exchange host > "$OUT/multi_n3_host.json" 2> "$OUT/multi_n3_host.err"
+      timeout 300 python tools/shard_overhead.py > "$OUT/shard_overhead.log" 2>&1
+      python - <<PYEOF >> "$OUT/session.log"
+import json
+for f in ("multi_n1","multi_n2_host","multi_n3_host"):
+    try:
+        d=json.loads(open("$OUT/"+f+".json").read().strip().splitlines()[-1]); print(f, round(d["value"],1), d["config"]["last_result_checksum"], d["roofline"]["kernel_avg_ms"])
+    except Exception as e: print(f, "ERR", e)
+PYEOF
+      ;;
     sweep)
       timeout 1200 python tools/sweep.py --tag "$TAG" > "$OUT/sweep.log" 2>&1; rc=$?
       cp gpurun_out/sweep_$TAG.json "$OUT/" 2>/dev/null ;;

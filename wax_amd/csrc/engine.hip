@@ -458,7 +458,7 @@ int enqueue_scan(wax_hip_engine* e, const float* d_query, float q_norm, int k_ef
     const bool fused = k_eff <= FUSED_MAX_K && !(e->force_general.load() && general_slot != nullptr);
     int grid = 0;
     std::unique_lock<std::mutex> chain_guard(e->chain_mu, std::defer_lock);
-    if (chain && e->n_streams > 1) {
+    if (chain) {
         chain_guard.lock();
         if (e->scan_done_valid) HIP_TRY(hipStreamWaitEvent(stream, e->scan_done, 0), WAX_HIP_ERR_INTERNAL, "scan chain wait");
     }
@@ -1100,8 +1100,11 @@ int wax_hip_search_shard_device(wax_hip_engine* e, const float* query, uint32_t 
         if (err != hipSuccess) { rc = fail(WAX_HIP_ERR_INTERNAL, std::string("query upload: ") + hipGetErrorString(err)); break; }
         harvest_ring_event(e, (int)r);  // the entry's previous use (kShardRing calls ago) has long finished
         const bool timed = e->time_kernels.load() != 0;
+        // chain=true: scans issued on different caller streams never overlap each other, while the
+        // merge kernel and whatever the caller enqueues next (RCCL all-gather, merge, download) do
+        // overlap the following scan.
         rc = enqueue_scan(e, e->ring_d_query[r], qn, k_eff, kpad, e->ring_d_partials[r], nullptr, d_out_hits, st,
-                          timed ? e->ring_ev0[r] : nullptr, timed ? e->ring_ev1[r] : nullptr);
+                          timed ? e->ring_ev0[r] : nullptr, timed ? e->ring_ev1[r] : nullptr, /*chain=*/true);
         if (rc == WAX_HIP_OK && timed) {
             std::unique_lock<std::mutex> sg(e->st_mu);
             e->ring_ev_pending[r] = true;

@@ -71,14 +71,19 @@ class ShardedSearcher:
     """Pipelined sharded search for one rank. submit() enqueues; collect() returns in FIFO order."""
 
     def __init__(self, engine: HIPVectorEngine, rank: int, world: int, topK: int, depth: int = 4,  # noqa: N803
-                 n_streams: int = 2, host_merge: bool = False):
+                 n_streams: int = 2, host_merge: bool = False, exchange: str = "rccl"):
+        """exchange="rccl": all-gather of device buffers over RCCL (the product path).
+        exchange="host": per-shard hits are downloaded and all-gathered on the host through the default
+        (gloo) group, then merged on the host — the control / fallback of SURVEY.md §8e, also what lets
+        the N>1 code run where RCCL cannot (two ranks sharing one GPU in tests)."""
         import torch
 
         self.engine = engine
         self.rank, self.world = rank, world
         self.kpad = clampTopK(topK)
         self.topK = topK
-        self.host_merge = host_merge
+        self.exchange = exchange
+        self.host_merge = host_merge or exchange == "host"
         self.dev = torch.device("cuda", engine.device)
         self.streams = [torch.cuda.Stream(device=self.dev) for _ in range(max(1, n_streams))]
         self.depth = max(1, depth)
@@ -86,13 +91,11 @@ class ShardedSearcher:
         self.gathered = [torch.empty((self.kpad * world, 2), dtype=torch.int64, device=self.dev)
                          for _ in range(self.depth)]
         self.merged = [torch.empty((self.kpad, 2), dtype=torch.int64, device=self.dev) for _ in range(self.depth)]
-        n_host = self.kpad * (world if host_merge else 1)
+        n_host = self.kpad * (world if (self.host_merge and exchange == "rccl") else 1)
         self.host = [torch.empty((n_host, 2), dtype=torch.int64).pin_memory() for _ in range(self.depth)]
         self.events = [torch.cuda.Event() for _ in range(self.depth)]
-        # scans are chained across the streams (they never overlap each other: each owns the whole
-        # HBM pipe); the all-gather / merge / download of query i overlap the scan of query i+1
-        self.scan_events = [torch.cuda.Event() for _ in range(self.depth)]
-        self.prev_scan = None
+        # The library chains the scan kernels across the streams (they never overlap each other: each
+        # owns the whole HBM pipe); the merge / all-gather / download of query i overlap the scan of i+1.
         self.inflight: Deque[int] = deque()
         self.seq = 0
 
@@ -106,12 +109,8 @@ class ShardedSearcher:
         st = self.streams[self.seq % len(self.streams)]
         self.seq += 1
         with torch.cuda.stream(st):
-            if self.prev_scan is not None and len(self.streams) > 1:
-                st.wait_event(self.prev_scan)
             self.engine.searchShardDevice(query, self.topK, self.local[b].data_ptr(), st.cuda_stream)
-            self.scan_events[b].record(st)
-            self.prev_scan = self.scan_events[b]
-            if self.world > 1:
+            if self.world > 1 and self.exchange == "rccl":
                 dist.all_gather_into_tensor(self.gathered[b], self.local[b])  # RCCL over xGMI
                 src = self.gathered[b]
             else:
@@ -131,6 +130,8 @@ class ShardedSearcher:
         b = self.inflight.popleft()
         self.events[b].synchronize()
         hits = self.host[b].numpy()
+        if self.world > 1 and self.exchange == "host":
+            hits = all_gather_hits(self.host[b], self.world).numpy()  # gloo, CPU tensors
         if self.host_merge and self.world > 1:
             hits = merge_hits_host(hits, self.kpad)
         return HIPVectorEngine.hitsToResults(self.engine.metric, hits)
