@@ -156,6 +156,13 @@ int wax_hip_search_collect(wax_hip_engine* e, uint64_t ticket,
 int wax_hip_search_batch(wax_hip_engine* e, const float* queries, uint32_t nq, uint32_t dims, int32_t top_k,
                          uint64_t* out_ids, float* out_scores, uint32_t* out_counts);
 
+/* Same search, but the raw ranked candidates are returned: out_hits is nq x kcap wax_hip_hit (ascending
+ * key, padded with key = INT64_MAX). This is what a row-sharded deployment exchanges between ranks and
+ * merges by key (exact tie order by GLOBAL row, see wax_hip_set_row_base). Large batches run Q x D^T as a
+ * bf16 MFMA GEMM with an exact f32 re-score; results are identical to nq calls of wax_hip_search. */
+int wax_hip_search_batch_hits(wax_hip_engine* e, const float* queries, uint32_t nq, uint32_t dims, int32_t top_k,
+                              wax_hip_hit* out_hits, uint32_t* out_counts);
+
 /* ---- sharded search: per-shard top-k left in HBM for the RCCL exchange ---- */
 
 /* Declares that this engine holds rows [row_base, row_base+count) of a corpus
@@ -196,8 +203,10 @@ int wax_hip_stats(wax_hip_engine* e, wax_hip_stats_t* out);
  * HIP events on its own stream and report last_scan_kernel_ms),
  * "slots" (scratch-slot pool size), "force_general" (1 = use the
  * distance-buffer + radix-select path even for small k), "stream_nt",
- * "reset_stats" (any value: zero the counters). get-only: "variant_count",
- * "scan_grid", "fused_max_k". */
+ * "reset_stats" (any value: zero the counters), "streams" (1..4 in-order streams the slots rotate over),
+ * "batch_mode" (0 = never use the MFMA batched path), "batch_min" (smallest batch that uses it),
+ * "batch_slab_mb". get-only: "variant_count", "scan_grid", "fused_max_k", "batch_queries",
+ * "batch_fallbacks". */
 int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value);
 int64_t wax_hip_get_tuning(wax_hip_engine* e, const char* key);
 /* Times `iters` back-to-back launches of ONLY the scan kernel for `query`

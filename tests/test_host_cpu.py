@@ -162,3 +162,38 @@ def test_shard_bounds_and_host_merge():
     assert m[:, 0].tolist() == [1, 2, 3] and m[:, 1].tolist() == [10, 20, 30]
     m = sharded.merge_hits_host(g[:2], 4)
     assert m[:, 0].tolist() == [1, 5, sharded.KEY_PAD, sharded.KEY_PAD]
+
+
+def test_decode_hits_matches_c_host_tail_and_batch_merge(hip_lib):
+    from wax_amd import HIPVectorEngine, VectorMetric, _abi, sharded
+
+    def key(d, row):
+        b = struct.unpack("<i", struct.pack("<f", d))[0]
+        return ((b ^ ((b >> 31) & 0x7FFFFFFF)) << 32) | row
+
+    rng = np.random.default_rng(3)
+    nq, k = 5, 6
+    hits = np.empty((nq, k, 2), dtype=np.int64)
+    for q in range(nq):
+        ds = np.sort(rng.standard_normal(k).astype(np.float32))
+        for i in range(k):
+            hits[q, i] = (key(float(ds[i]), 10 * q + i), 1000 + 10 * q + i)
+    hits[1, 4:] = (_abi.KEY_PAD, -1)
+    hits[2, 5] = (key(float("inf"), 77), 1077)
+    for metric in (VectorMetric.cosine, VectorMetric.dot, VectorMetric.l2):
+        ids, scores, valid = sharded.decode_hits(metric, hits)
+        for q in range(nq):
+            c_ids, c_scores = HIPVectorEngine.hitsToResults(metric, hits[q])
+            assert list(ids[q][valid[q]]) == list(c_ids)
+            assert np.array_equal(scores[q][valid[q]], c_scores)
+    # per-query merge over shards == global sort by key
+    world = 3
+    g = np.empty((world, nq, k, 2), dtype=np.int64)
+    allkeys = rng.permutation(world * nq * k * 4)[:world * nq * k].reshape(world, nq, k).astype(np.int64)
+    allkeys.sort(axis=2)
+    g[..., 0] = allkeys
+    g[..., 1] = allkeys + 5
+    m = sharded.merge_batch_hits_host(g, k)
+    for q in range(nq):
+        exp = np.sort(allkeys[:, q, :].reshape(-1))[:k]
+        assert np.array_equal(m[q, :, 0], exp) and np.array_equal(m[q, :, 1], exp + 5)

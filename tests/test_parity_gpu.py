@@ -646,3 +646,34 @@ def test_bench_contract_and_shard_invariance(wax, tmp_path):
     assert two["n_gpus"] == 2 and three["n_gpus"] == 3
     assert one["config"]["last_result_checksum"] == two["config"]["last_result_checksum"] \
         == three["config"]["last_result_checksum"]
+
+
+def test_search_batch_hits_and_sharded_batch_single_rank(wax):
+    from wax_amd import sharded
+    dims, n, k = 384, 30000, 10
+    corpus = oracle.gaussian_unit_rows(0, n, dims)
+    ids = np.arange(n, dtype=np.uint64) + 9
+    eng = make_engine(wax, 0, dims, corpus, ids)
+    eng.setRowBase(5000)
+    queries = oracle.gaussian_unit_queries(40, dims)
+    hits, counts = eng.searchBatchHits(queries, k)
+    assert hits.shape == (40, k, 2) and np.all(counts == k)
+    assert np.all(np.diff(hits[:, :, 0], axis=1) > 0)                       # ascending unique keys
+    assert np.all((hits[:, :, 0] & 0xFFFFFFFF) >= 5000)                      # keys carry GLOBAL rows
+    d_ids, d_scores, valid = sharded.sharded_search_batch(eng, queries, k, world=1)
+    for i, q in enumerate(queries):
+        s_ids, s_scores = eng.searchArrays(q, k)
+        assert np.array_equal(d_ids[i][valid[i]], s_ids) and np.array_equal(d_scores[i][valid[i]], s_scores)
+        assert np.array_equal((hits[i, :, 0] & 0xFFFFFFFF) - 5000 + 9, s_ids.astype(np.int64))
+    # two shard engines on one GPU, merged on the host like the N>1 exchange does
+    a = make_engine(wax, 0, dims, corpus[:12800], ids[:12800])
+    b = make_engine(wax, 0, dims, corpus[12800:], ids[12800:])
+    b.setRowBase(12800)
+    ha, _ = a.searchBatchHits(queries, k)
+    hb, _ = b.searchBatchHits(queries, k)
+    merged = sharded.merge_batch_hits_host(np.stack([ha, hb]), k)
+    m_ids, m_scores, m_valid = sharded.decode_hits(wax.VectorMetric.cosine, merged)
+    eng.setRowBase(0)
+    for i, q in enumerate(queries):
+        s_ids, s_scores = eng.searchArrays(q, k)
+        assert np.array_equal(m_ids[i], s_ids) and np.array_equal(m_scores[i], s_scores)

@@ -1,12 +1,16 @@
 #!/usr/bin/env python3
-"""Batched-query benchmark (BASELINE configs 3/5 shapes on one GPU): Q x D^T bf16 MFMA GEMM +
-per-query select + exact f32 re-score. Prints one JSON line per configuration.
+"""Batched-query benchmark (BASELINE configs 3 / 5): Q x D^T as a bf16 MFMA GEMM with fused selection
+and exact f32 re-score, optionally row-sharded over N GPUs (one process per GPU, per-shard top-k hits
+all-gathered over RCCL and merged per query). Prints one JSON line per configuration on rank 0.
 
-    python tools/batch_bench.py [--rows 1000000] [--dims 384] [--nq 256] [--topk 10] [--reps 5]
+    python tools/batch_bench.py --rows 1000000 --dims 384 --nq 256                     # config 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29501 tools/batch_bench.py --gpus 8 --rows 10000000 --dims 768 --nq 1024   # config 5
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -21,35 +25,67 @@ import bench  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--rows", type=int, default=1_000_000)
     ap.add_argument("--dims", type=int, default=384)
     ap.add_argument("--nq", type=int, nargs="+", default=[256])
     ap.add_argument("--topk", type=int, default=10)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--slab-mb", type=int, nargs="+", default=[64])
+    ap.add_argument("--exchange", choices=["rccl", "host"], default="rccl")
     args = ap.parse_args()
     import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = 0 if os.environ.get("WAX_BENCH_SAME_DEVICE") else int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.exchange == "rccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     import wax_amd as wax
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(0)
+    from wax_amd import sharded
+    lo, hi = sharded.shard_bounds(args.rows, world, rank, align=128)
     eng = wax.HIPVectorEngine(dimensions=args.dims)
-    eng.reserve(args.rows)
-    for r0, x in bench.device_rows(torch, 0, args.rows, args.dims, dev):
+    eng.reserve(max(hi - lo, 1))
+    for r0, x in bench.device_rows(torch, lo, hi, args.dims, dev):
         eng.addBatchDevice(np.arange(r0, r0 + x.shape[0], dtype=np.uint64), x)
+    eng.setRowBase(lo)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier(device_ids=[local_rank]) if args.exchange == "rccl" else dist.barrier()
+
     for nq in args.nq:
         q = bench.unit_queries(nq, args.dims)
         for slab in args.slab_mb:
             eng.setTuning("batch_slab_mb", slab)
-            eng.searchBatch(q, args.topk)  # warm-up (+ mirror build on the first call)
+            sharded.sharded_search_batch(eng, q, args.topk, world, args.exchange)  # warm-up (+ mirror build)
             fb0 = eng.getTuning("batch_fallbacks")
+            sync()
             t0 = time.perf_counter()
             for _ in range(args.reps):
-                ids, scores, counts = eng.searchBatch(q, args.topk)
+                ids, scores, valid = sharded.sharded_search_batch(eng, q, args.topk, world, args.exchange)
+            sync()
             dt = (time.perf_counter() - t0) / args.reps
-            print(json.dumps({"rows": args.rows, "dims": args.dims, "nq": nq, "topk": args.topk, "slab_mb": slab,
-                              "ms_per_batch": dt * 1e3, "qps": nq / dt,
-                              "tflops_bf16": 2.0 * nq * args.rows * args.dims / dt / 1e12,
-                              "fallbacks": eng.getTuning("batch_fallbacks") - fb0}), flush=True)
+            if world > 1:
+                t = torch.tensor([dt], dtype=torch.float64, device=dev if args.exchange == "rccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            if rank == 0:
+                chk = hashlib.sha256(np.ascontiguousarray(ids).tobytes() + np.ascontiguousarray(scores).tobytes()).hexdigest()[:16]
+                print(json.dumps({"n_gpus": world, "rows": args.rows, "dims": args.dims, "nq": nq, "topk": args.topk,
+                                  "slab_mb": slab, "ms_per_batch": dt * 1e3, "qps": nq / dt,
+                                  "tflops_bf16": 2.0 * nq * args.rows * args.dims / dt / 1e12,
+                                  "fallbacks_rank0": eng.getTuning("batch_fallbacks") - fb0,
+                                  "exchange": args.exchange if world > 1 else "none", "result_checksum": chk}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -53,6 +53,10 @@ for s in $STAGES; do
       WAX_BENCH_SAME_DEVICE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 3 --master-addr 127.0.0.1 --master-port 29512 \
           bench.py --gpus 3 --rows 2000000 --steps 50 --warmup 5 --exchange host > "$OUT/multi_n3_host.json" 2> "$OUT/multi_n3_host.err"
       timeout 300 python tools/shard_overhead.py > "$OUT/shard_overhead.log" 2>&1
+      timeout 300 python tools/batch_bench.py --rows 2000000 --nq 256 --reps 3 > "$OUT/multi_batch_n1.json" 2> "$OUT/multi_batch_n1.err"
+      WAX_BENCH_SAME_DEVICE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29513 \
+          tools/batch_bench.py --gpus 2 --rows 2000000 --nq 256 --reps 3 --exchange host > "$OUT/multi_batch_n2_host.json" 2> "$OUT/multi_batch_n2_host.err"
+      grep -h result_checksum "$OUT/multi_batch_n1.json" "$OUT/multi_batch_n2_host.json" | cut -c1-400 >> "$OUT/session.log"
       python - <<PYEOF >> "$OUT/session.log"
 import json
 for f in ("multi_n1","multi_n2_host","multi_n3_host"):

@@ -585,8 +585,8 @@ float batch_eps(uint8_t metric, float q_norm, float max_norm, uint32_t dims) {
     return (float)(2.0 * u * qv * 1.001 + 4e-6 * (1.0 + s));
 }
 
-int batch_search_mfma(wax_hip_engine* e, const float* queries, uint32_t nq, int k_eff, uint64_t* out_ids,
-                      float* out_scores, uint32_t* out_counts, std::vector<uint8_t>& need_exact) {
+int batch_search_mfma(wax_hip_engine* e, const float* queries, uint32_t nq, int k_eff, wax_hip_hit* out_hits,
+                      std::vector<uint8_t>& need_exact) {
     BatchWork& b = e->batch;
     std::unique_lock<std::mutex> bg(b.mu);
     hipStream_t st = e->streams[0];
@@ -646,8 +646,7 @@ int batch_search_mfma(wax_hip_engine* e, const float* queries, uint32_t nq, int 
         for (uint32_t q = 0; q < qn; ++q) {
             const uint32_t gq = q0 + q;
             if (b.h_cert[q]) {
-                hits_to_results(e->metric, b.h_hits + (size_t)q * k_eff, (uint32_t)k_eff, out_ids + (uint64_t)gq * k_eff,
-                                out_scores + (uint64_t)gq * k_eff, &out_counts[gq]);
+                std::memcpy(out_hits + (size_t)gq * k_eff, b.h_hits + (size_t)q * k_eff, (size_t)k_eff * sizeof(wax_hip_hit));
             } else {
                 need_exact[gq] = 1;
                 e->st_batch_fallbacks++;
@@ -946,7 +945,16 @@ int wax_hip_search_submit(wax_hip_engine* e, const float* query, uint32_t dims, 
     return WAX_HIP_OK;  // shared lock stays held until collect
 }
 
+// Shared tail of collect: either converts to (ids, scores) or hands back the raw hits (padded to kcap).
+static int collect_impl(wax_hip_engine* e, uint64_t ticket, uint64_t* out_ids, float* out_scores, uint32_t* out_count,
+                        wax_hip_hit* out_hits, uint32_t hits_cap);
+
 int wax_hip_search_collect(wax_hip_engine* e, uint64_t ticket, uint64_t* out_ids, float* out_scores, uint32_t* out_count) {
+    return collect_impl(e, ticket, out_ids, out_scores, out_count, nullptr, 0);
+}
+
+static int collect_impl(wax_hip_engine* e, uint64_t ticket, uint64_t* out_ids, float* out_scores, uint32_t* out_count,
+                        wax_hip_hit* out_hits, uint32_t hits_cap) {
     if (!e || !out_count) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine/out_count is null");
     DeviceGuard g(e->device);
     Slot* s = nullptr;
@@ -959,6 +967,8 @@ int wax_hip_search_collect(wax_hip_engine* e, uint64_t ticket, uint64_t* out_ids
     }
     int rc = WAX_HIP_OK;
     *out_count = 0;
+    if (s->k_eff == 0 && out_hits)
+        for (uint32_t i = 0; i < hits_cap; ++i) out_hits[i] = wax_hip_hit{KEY_PAD, ID_PAD};
     if (s->k_eff > 0) {
         hipError_t err = hipEventSynchronize(s->ev_done);   // commandBuffer completion (:577-582); later queries on the stream keep running
         if (err != hipSuccess) {
@@ -971,8 +981,18 @@ int wax_hip_search_collect(wax_hip_engine* e, uint64_t ticket, uint64_t* out_ids
                     e->st_last_ms = ms; e->st_total_ms += ms; e->st_timed += 1;
                 }
             }
-            if (!out_ids || !out_scores) rc = fail(WAX_HIP_ERR_INVALID_ARGUMENT, "output arrays are null");
-            else rc = hits_to_results(e->metric, s->h_hits, (uint32_t)s->k_eff, out_ids, out_scores, out_count);
+            if (out_hits) {
+                uint32_t m = 0;
+                for (uint32_t i = 0; i < hits_cap; ++i) {
+                    out_hits[i] = (i < (uint32_t)s->k_eff) ? s->h_hits[i] : wax_hip_hit{KEY_PAD, ID_PAD};
+                    if (out_hits[i].key != KEY_PAD) ++m;
+                }
+                *out_count = m;
+            } else if (!out_ids || !out_scores) {
+                rc = fail(WAX_HIP_ERR_INVALID_ARGUMENT, "output arrays are null");
+            } else {
+                rc = hits_to_results(e->metric, s->h_hits, (uint32_t)s->k_eff, out_ids, out_scores, out_count);
+            }
         }
     }
     release_slot(e, s);
@@ -988,19 +1008,18 @@ int wax_hip_search(wax_hip_engine* e, const float* query, uint32_t dims, int32_t
     return wax_hip_search_collect(e, t, out_ids, out_scores, out_count);
 }
 
-int wax_hip_search_batch(wax_hip_engine* e, const float* queries, uint32_t nq, uint32_t dims, int32_t top_k,
-                         uint64_t* out_ids, float* out_scores, uint32_t* out_counts) {
-    if (!e) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine is null");
-    if (nq == 0) return WAX_HIP_OK;
-    if (!queries || !out_counts) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null input");
+// nq queries -> nq x kcap hits (ascending key, KEY_PAD padded). Chooses the MFMA path when the batch is
+// a genuine GEMM, otherwise pipelines single-query scans over the scratch-slot pool.
+static int search_batch_hits_impl(wax_hip_engine* e, const float* queries, uint32_t nq, uint32_t dims, int32_t top_k,
+                                  wax_hip_hit* out_hits, uint32_t* out_counts, uint64_t kcap) {
     const uint64_t cnt = e->count;
-    const uint64_t limit = (uint64_t)clamp_topk(top_k);
-    const uint64_t kcap = limit < cnt ? limit : cnt;
     // Enough queries for the scan to be a dense GEMM: bf16 MFMA path with exact re-score; queries
     // whose exactness certificate fails are re-run on the exact single-query path below.
+    std::vector<uint8_t> need_exact;
+    bool all = true;
     if (e->batch_mode.load() != 0 && (int64_t)nq >= e->batch_min.load() && dims == e->dims && (dims % 64u) == 0 &&
-        cnt > 0 && kcap <= (uint64_t)kBatchMaxK && out_ids && out_scores) {
-        std::vector<uint8_t> need_exact(nq, 0);
+        cnt > 0 && kcap <= (uint64_t)kBatchMaxK && kcap > 0) {
+        need_exact.assign(nq, 0);
         int brc;
         {
             DeviceGuard g(e->device);
@@ -1010,46 +1029,85 @@ int wax_hip_search_batch(wax_hip_engine* e, const float* queries, uint32_t nq, u
                 return fail(WAX_HIP_ERR_CAPACITY, "row_base + count exceeds UInt32 row indices");
             }
             const int k_eff = (int)((uint64_t)clamp_topk(top_k) < e->count ? (uint64_t)clamp_topk(top_k) : e->count);
-            brc = ((uint64_t)k_eff == kcap) ? batch_search_mfma(e, queries, nq, k_eff, out_ids, out_scores, out_counts, need_exact)
+            brc = ((uint64_t)k_eff == kcap) ? batch_search_mfma(e, queries, nq, k_eff, out_hits, need_exact)
                                             : fail(WAX_HIP_ERR_INTERNAL, "engine mutated during batch search");
             e->lock.unlock_shared();
         }
         if (brc != WAX_HIP_OK) return brc;
-        for (uint32_t q = 0; q < nq; ++q) {
-            if (!need_exact[q]) continue;
-            int rc1 = wax_hip_search(e, queries + (uint64_t)q * dims, dims, top_k, out_ids + (uint64_t)q * kcap,
-                                     out_scores + (uint64_t)q * kcap, &out_counts[q]);
-            if (rc1 != WAX_HIP_OK) return rc1;
-        }
-        return WAX_HIP_OK;
+        all = false;
+        for (uint32_t q = 0; q < nq; ++q)
+            if (!need_exact[q]) {
+                uint32_t m = 0;
+                for (uint64_t i = 0; i < kcap; ++i) m += out_hits[(uint64_t)q * kcap + i].key != KEY_PAD;
+                out_counts[q] = m;
+            }
     }
-    // Pipelined over the scratch-slot pool: up to `depth` scans in flight.
+    // Pipelined single-query scans: all queries (loop path) or only the uncertified ones.
+    std::vector<uint32_t> todo;
+    for (uint32_t q = 0; q < nq; ++q)
+        if (all || need_exact[q]) todo.push_back(q);
     const uint32_t depth = (uint32_t)(e->max_slots > 1 ? e->max_slots : 1);
-    std::vector<uint64_t> tk(nq, 0);
-    uint32_t submitted = 0, collected = 0;
+    std::vector<uint64_t> tk(todo.size(), 0);
+    size_t submitted = 0, collected = 0;
     int rc = WAX_HIP_OK;
-    while (collected < nq) {
-        while (submitted < nq && submitted - collected < depth) {
-            rc = wax_hip_search_submit(e, queries + (uint64_t)submitted * dims, dims, top_k, &tk[submitted]);
+    while (collected < todo.size()) {
+        while (submitted < todo.size() && submitted - collected < depth) {
+            rc = wax_hip_search_submit(e, queries + (uint64_t)todo[submitted] * dims, dims, top_k, &tk[submitted]);
             if (rc != WAX_HIP_OK) break;
             ++submitted;
         }
         if (rc != WAX_HIP_OK) break;
-        rc = wax_hip_search_collect(e, tk[collected], out_ids ? out_ids + (uint64_t)collected * kcap : nullptr,
-                                    out_scores ? out_scores + (uint64_t)collected * kcap : nullptr, &out_counts[collected]);
+        const uint32_t q = todo[collected];
+        rc = collect_impl(e, tk[collected], nullptr, nullptr, &out_counts[q], out_hits + (uint64_t)q * kcap, (uint32_t)kcap);
         ++collected;
         if (rc != WAX_HIP_OK) break;
     }
     if (rc != WAX_HIP_OK) {  // drain whatever is still in flight so the shared lock is released
         std::string keep = g_last_error;
         uint32_t dummy = 0;
-        std::vector<uint64_t> ids_tmp(kcap ? kcap : 1);
-        std::vector<float> sc_tmp(kcap ? kcap : 1);
-        for (uint32_t i = collected; i < submitted; ++i)
-            (void)wax_hip_search_collect(e, tk[i], ids_tmp.data(), sc_tmp.data(), &dummy);
+        std::vector<wax_hip_hit> tmp(kcap ? kcap : 1);
+        for (size_t i = collected; i < submitted; ++i)
+            (void)collect_impl(e, tk[i], nullptr, nullptr, &dummy, tmp.data(), (uint32_t)kcap);
         g_last_error = keep;
     }
     return rc;
+}
+
+int wax_hip_search_batch_hits(wax_hip_engine* e, const float* queries, uint32_t nq, uint32_t dims, int32_t top_k,
+                              wax_hip_hit* out_hits, uint32_t* out_counts) {
+    if (!e) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine is null");
+    if (nq == 0) return WAX_HIP_OK;
+    if (!queries || !out_counts || !out_hits) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null input");
+    const uint64_t cnt = e->count;
+    const uint64_t limit = (uint64_t)clamp_topk(top_k);
+    const uint64_t kcap = limit < cnt ? limit : cnt;
+    if (kcap == 0) {
+        for (uint32_t q = 0; q < nq; ++q) out_counts[q] = 0;
+        return WAX_HIP_OK;
+    }
+    return search_batch_hits_impl(e, queries, nq, dims, top_k, out_hits, out_counts, kcap);
+}
+
+int wax_hip_search_batch(wax_hip_engine* e, const float* queries, uint32_t nq, uint32_t dims, int32_t top_k,
+                         uint64_t* out_ids, float* out_scores, uint32_t* out_counts) {
+    if (!e) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine is null");
+    if (nq == 0) return WAX_HIP_OK;
+    if (!queries || !out_counts) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null input");
+    const uint64_t cnt = e->count;
+    const uint64_t limit = (uint64_t)clamp_topk(top_k);
+    const uint64_t kcap = limit < cnt ? limit : cnt;
+    if (kcap == 0) {
+        for (uint32_t q = 0; q < nq; ++q) out_counts[q] = 0;
+        return WAX_HIP_OK;
+    }
+    if (!out_ids || !out_scores) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "output arrays are null");
+    std::vector<wax_hip_hit> hits((size_t)nq * kcap);
+    int rc = search_batch_hits_impl(e, queries, nq, dims, top_k, hits.data(), out_counts, kcap);
+    if (rc != WAX_HIP_OK) return rc;
+    for (uint32_t q = 0; q < nq; ++q)
+        hits_to_results(e->metric, hits.data() + (size_t)q * kcap, (uint32_t)kcap, out_ids + (uint64_t)q * kcap,
+                        out_scores + (uint64_t)q * kcap, &out_counts[q]);
+    return WAX_HIP_OK;
 }
 
 // ---- sharded search -------------------------------------------------------

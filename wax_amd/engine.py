@@ -227,6 +227,23 @@ class HIPVectorEngine:
         raise_for_status(rc)
         return ids, scores, counts
 
+    def searchBatchHits(self, vectors, topK: int):  # noqa: N802,N803
+        """Raw ranked candidates: int64[nq, kcap, 2] of (key, frame_id bits), ascending key, KEY_PAD padded."""
+        qs = _as_f32(vectors)
+        if qs.ndim != 2:
+            raise EncodingError("searchBatchHits: vectors must be [nq, dims]")
+        nq, width = qs.shape
+        kcap = max(1, min(clampTopK(topK), max(self.count, 1)))
+        hits = np.empty((nq, kcap, 2), dtype=np.int64)
+        hits[:, :, 0] = _abi.KEY_PAD
+        hits[:, :, 1] = -1
+        counts = np.zeros(nq, dtype=np.uint32)
+        rc = self._lib.wax_hip_search_batch_hits(self._h, _fp(qs), nq, width, int(topK),
+                                                 hits.ctypes.data_as(ctypes.POINTER(_abi.Hit)),
+                                                 counts.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)))
+        raise_for_status(rc)
+        return hits, counts
+
     # -- sharded search (one engine per GPU; exchange over RCCL by the caller) ----
     def setRowBase(self, rowBase: int) -> None:  # noqa: N802,N803
         raise_for_status(self._lib.wax_hip_set_row_base(self._h, int(rowBase)))

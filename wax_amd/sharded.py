@@ -139,3 +139,60 @@ class ShardedSearcher:
     def search(self, query) -> Tuple[np.ndarray, np.ndarray]:
         self.submit(query)
         return self.collect()
+
+
+# ---------------------------------------------------------------------------
+# batched queries over a row-sharded corpus (BASELINE config 5 shape)
+
+def decode_hits(metric: VectorMetric, hits: np.ndarray):
+    """Vectorised twin of wax_hip_hits_to_results for int64[..., k, 2] hit arrays: returns
+    (frame_ids u64[..., k], scores f32[..., k], valid bool[..., k]); padded / non-finite entries are
+    invalid (MetalVectorEngine.swift:597) and sort last because keys ascend."""
+    h = np.asarray(hits, dtype=np.int64)
+    keys = h[..., 0]
+    o = (keys >> 32).astype(np.int32)
+    bits = o ^ ((o >> 31) & np.int32(0x7FFFFFFF))
+    dist = bits.view(np.float32)
+    valid = (keys != KEY_PAD) & np.isfinite(dist) & (h[..., 1] != -1)
+    scores = (np.float32(1.0) - dist) if VectorMetric(metric) is VectorMetric.cosine else -dist
+    return h[..., 1].view(np.uint64), scores.astype(np.float32), valid
+
+
+def merge_batch_hits_host(gathered: np.ndarray, k: int) -> np.ndarray:
+    """gathered: int64[world, nq, kpad, 2] -> int64[nq, k, 2]: per query the k smallest keys over all shards."""
+    g = np.asarray(gathered, dtype=np.int64)
+    world, nq, kpad, _ = g.shape
+    flat = np.transpose(g, (1, 0, 2, 3)).reshape(nq, world * kpad, 2)
+    order = np.argsort(flat[:, :, 0], axis=1, kind="stable")[:, :k]
+    return np.take_along_axis(flat, order[:, :, None], axis=1)
+
+
+def sharded_search_batch(engine: HIPVectorEngine, queries, topK: int, world: int, exchange: str = "rccl"):  # noqa: N803
+    """Every rank scans ITS shard for all queries (bf16 MFMA path + exact re-score inside the engine),
+    the per-shard top-k hits are all-gathered (nq*kpad*16 bytes per rank) and merged per query by key
+    = (distance asc, GLOBAL row asc): the answer is identical at every shard count."""
+    import torch
+    import torch.distributed as dist
+
+    kpad = clampTopK(topK)
+    hits, _ = engine.searchBatchHits(queries, topK)
+    nq, kcap, _ = hits.shape
+    if kcap < kpad:  # a shard smaller than k: pad its lists
+        pad = np.empty((nq, kpad - kcap, 2), dtype=np.int64)
+        pad[:, :, 0] = KEY_PAD
+        pad[:, :, 1] = -1
+        hits = np.concatenate([hits, pad], axis=1)
+    if world > 1:
+        local = torch.from_numpy(np.ascontiguousarray(hits))
+        if exchange == "rccl":
+            dev = torch.device("cuda", engine.device)
+            local = local.to(dev)
+            out = torch.empty((world,) + tuple(local.shape), dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(out.view(-1), local.view(-1))
+            gathered = out.cpu().numpy()
+        else:
+            parts = [torch.empty_like(local) for _ in range(world)]
+            dist.all_gather(parts, local)
+            gathered = torch.stack(parts, dim=0).numpy()
+        hits = merge_batch_hits_host(gathered, kpad)
+    return decode_hits(engine.metric, hits)
