@@ -131,6 +131,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if use_rccl:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            probe_t = torch.ones(1, device=dev)
+            dist.all_reduce(probe_t)  # fail here, loudly, if RCCL cannot talk across the node
+            assert int(probe_t.item()) == world
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 

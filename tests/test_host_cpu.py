@@ -197,3 +197,31 @@ def test_decode_hits_matches_c_host_tail_and_batch_merge(hip_lib):
     for q in range(nq):
         exp = np.sort(allkeys[:, q, :].reshape(-1))[:k]
         assert np.array_equal(m[q, :, 0], exp) and np.array_equal(m[q, :, 1], exp + 5)
+
+
+def _build_c_smoke(tmp_path):
+    from wax_amd import build
+    lib = build.build()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_abi_smoke")
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I" + os.path.join(root, "include"),
+                    os.path.join(root, "tests", "c_abi", "smoke.c"), "-L" + os.path.dirname(lib), "-lwaxhip",
+                    "-Wl,-rpath," + os.path.dirname(lib), "-o", exe], check=True)
+    return exe
+
+
+def test_plain_c_consumer_links_and_fails_loudly_without_gpu(hip_lib, tmp_path):
+    exe = _build_c_smoke(tmp_path)
+    if hip_lib.wax_hip_available():
+        pytest.skip("GPU present: covered by the gpu-marked twin")
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "no-device" in out.stdout
+
+
+@pytest.mark.gpu
+def test_plain_c_consumer_on_gpu(hip_lib, tmp_path):
+    exe = _build_c_smoke(tmp_path)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "c-abi ok: id 20" in out.stdout

@@ -435,7 +435,8 @@ def _device_corpus(torch, n, dims, dev, chunk=262144):
         yield lo, torch.nn.functional.normalize(x, dim=1).contiguous()
 
 
-@pytest.mark.parametrize("n,dims", [(1_000_000, 384), (10_000_000, 384), (1_000_000, 768)])
+@pytest.mark.parametrize("n,dims", [(1_000_000, 384), (10_000_000, 384), (1_000_000, 768),
+                                    (6_000_000, 768)])  # 6M x 768 = 4.6e9 elements: past the reference kernels' 32-bit offset wrap (CosineDistance.metal:191, 275)
 def test_full_size_properties(wax, n, dims):
     import torch
     dev = torch.device("cuda", 0)
