@@ -65,6 +65,8 @@ for f in ("multi_n1","multi_n2_host","multi_n3_host"):
     except Exception as e: print(f, "ERR", e)
 PYEOF
       ;;
+    gemmprobe)
+      timeout 600 python tools/gemm_probe.py > "$OUT/gemm_probe.log" 2>&1; rc=$? ;;
     sweep)
       timeout 1200 python tools/sweep.py --tag "$TAG" > "$OUT/sweep.log" 2>&1; rc=$?
       cp gpurun_out/sweep_$TAG.json "$OUT/" 2>/dev/null ;;

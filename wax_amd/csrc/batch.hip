@@ -333,7 +333,221 @@ __global__ __launch_bounds__(256) void batch_gemm_kernel(GemmArgs a) {
             }
 }
 
+typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+typedef __attribute__((address_space(3))) unsigned int lds_u32;
+
+// Cold path of the register-resident-queries GEMM: some accumulator of this wave's 32 x 64 tile may beat
+// its query's threshold. Re-reads the exact thresholds, compacts the survivors into the wave's LDS
+// stage and appends them with all lanes' atomics in flight. Not inlined: inlined, its 32 predicated
+// blocks keep ~100 extra VGPRs live across the MFMA loop and spill the A fragments.
+__device__ __attribute__((noinline)) void rega_append(f32x16 acc0, f32x16 acc1, bool ok0, bool ok1, uint32_t q0,
+                                                      uint32_t grow0, const float* __restrict__ tau,
+                                                      int64_t* __restrict__ cand, uint32_t* __restrict__ cand_count,
+                                                      uint32_t cand_cap, uint32_t nq, lds_u32x4* stage, lds_u32* wcnt,
+                                                      unsigned stage_cap) {
+    const int lane = lane_id();
+    unsigned pass = 0u;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float tqr = tau[q0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
+        const float d0 = (1.0f - acc0[r]) + 0.0f, d1 = (1.0f - acc1[r]) + 0.0f;
+        pass |= ((ok0 && d0 <= tqr) ? 1u : 0u) << r;
+        pass |= ((ok1 && d1 <= tqr) ? 1u : 0u) << (16 + r);
+    }
+    if (!__any(pass != 0u)) return;
+    const unsigned mine = (unsigned)__popc(pass);
+    unsigned off = 0;
+    if (mine) off = __hip_atomic_fetch_add(wcnt, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    wave_lds_fence();
+    const unsigned total = (unsigned)__builtin_amdgcn_readfirstlane((int)*wcnt);
+    const bool staged = total <= stage_cap;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if ((pass >> (j * 16 + r)) & 1u) {
+                const float d = (1.0f - (j ? acc1[r] : acc0[r])) + 0.0f;
+                const uint32_t q = q0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int64_t key = make_key(d, grow0 + (j ? 32u : 0u));
+                if (staged) {
+                    u32x4 e;
+                    e.x = (unsigned)((unsigned long long)key & 0xffffffffull);
+                    e.y = (unsigned)((unsigned long long)key >> 32);
+                    e.z = q;
+                    e.w = 0u;
+                    stage[off++] = e;
+                } else if (q < nq) {  // stage overflow (loose threshold): direct appends
+                    const uint32_t pos = atomicAdd(&cand_count[q], 1u);
+                    if (pos < cand_cap) cand[(size_t)q * cand_cap + pos] = key;
+                }
+            }
+        }
+    wave_lds_fence();
+    if (staged) {
+        for (unsigned i = (unsigned)lane; i < total; i += WAVE) {
+            const u32x4 e = stage[i];
+            const uint32_t q = e.z;
+            if (q < nq) {
+                const uint32_t pos = atomicAdd(&cand_count[q], 1u);
+                if (pos < cand_cap) cand[(size_t)q * cand_cap + pos] = (int64_t)(((unsigned long long)e.y << 32) | (unsigned long long)e.x);
+            }
+        }
+    }
+    wave_lds_fence();
+    if (lane == 0) *wcnt = 0u;
+}
+
+// ---------------------------------------------------------------------------
+// Register-resident-queries GEMM (cosine / dot, D in {128, 256, 384, 512}; every slab after the first).
+//
+// The query block is tiny and reused against every corpus row, so it never goes through LDS: each of
+// the 8 waves of a workgroup keeps its 32 queries x D as MFMA A-fragments in VGPRs for the whole launch
+// (96 VGPRs at D = 384). Only the corpus streams: persistent workgroups walk 64-row tiles (contiguous
+// 48 KB in the bf16 mirror), double-buffered in LDS with one barrier per tile; all 8 waves read the
+// same B fragments (ds_read_b128, rows padded by 16 B => conflict-free), so per tile a SIMD issues
+// 2 waves x 48 MFMAs against 384 KB of LDS reads (50 % of the LDS pipe). At Q = 256 one pass over the
+// corpus is HBM-bound (48 KB per 3072 MFMA cycles per CU = 9.6 TB/s at MFMA peak).
+// Epilogue per tile: 32 compares against the lane's 16 thresholds, survivors staged in LDS and appended.
+template <int D>
+__global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uint32_t blocks_per_group) {
+    constexpr int KS = D / 16;                       // MFMA k-steps
+    constexpr int ROW_B = D * 2 + 16;                // LDS row stride (bytes)
+    constexpr int TROWS = 64;                        // corpus rows per tile
+    constexpr int SEG_PER_ROW = D * 2 / 16;
+    constexpr int SEGS = TROWS * SEG_PER_ROW;        // 16-byte segments per tile
+    constexpr int LOADS = SEG_PER_ROW / 8;           // per thread (8 threads per row, 64 rows)
+    constexpr int BUF_B = TROWS * ROW_B;
+    constexpr unsigned STAGE_CAP = 128;              // staged survivors per wave
+    static_assert(SEGS == 512 * LOADS && D % 64 == 0, "tile must split evenly over 512 threads");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* buf0 = smem;
+    u32x4* stage_all = reinterpret_cast<u32x4*>(smem + 2 * BUF_B);
+    unsigned int* wcnt = reinterpret_cast<unsigned int*>(smem + 2 * BUF_B + 8 * STAGE_CAP * 16);
+
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const uint32_t group = blockIdx.x / blocks_per_group;   // 256 queries per group
+    const uint32_t bidx = blockIdx.x % blocks_per_group;
+    const uint32_t q0 = group * 256 + wave * 32;             // this wave's 32 queries
+
+    // A fragments: lane l holds query (l & 31), k = 16*ks + 8*(l >> 5) .. +7
+    bf16x8 fa[KS];
+    {
+        const u32x4* qp = reinterpret_cast<const u32x4*>(a.qb + (size_t)(q0 + (lane & 31)) * D) + (lane >> 5);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) fa[ks] = __builtin_bit_cast(bf16x8, qp[ks * 2]);
+    }
+    // Hot-path filter: ONE register, the loosest threshold among the 16 queries this lane's accumulators
+    // belong to. The exact per-query thresholds are re-read (L2) only on the rare path that found a survivor.
+    float tmax = -__builtin_inff();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, a.tau[q0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)]);
+    if (tid < 8) wcnt[tid] = 0u;
+
+    const uint32_t ntiles = (a.slab_rows + TROWS - 1) / TROWS;
+    const uint32_t slab_end = a.slab0 + a.slab_rows;
+    const unsigned char* cbase = reinterpret_cast<const unsigned char*>(a.cb);
+
+    // staging map: 8 threads per tile row; a thread moves the 16-byte segments (tid & 7) + 8*p of its row,
+    // so every global / LDS address is one per-tile base plus a compile-time offset (no address arrays).
+    const uint32_t srow = (uint32_t)tid >> 3;
+    const uint32_t sseg = ((uint32_t)tid & 7u) * 16u;
+    u32x4 regs[LOADS];
+    auto issue_loads = [&](uint32_t tile) {
+        uint32_t grow = a.slab0 + tile * TROWS + srow;
+        grow = grow < a.n_rows ? grow : a.n_rows - 1;        // clamp: masked in the epilogue
+        const unsigned char* src = cbase + (size_t)grow * (D * 2) + sseg;
+#pragma unroll
+        for (int p = 0; p < LOADS; ++p) regs[p] = *reinterpret_cast<const u32x4*>(src + p * 128);
+    };
+    auto store_tile = [&](unsigned char* buf) {
+        unsigned char* dst = buf + srow * ROW_B + sseg;
+#pragma unroll
+        for (int p = 0; p < LOADS; ++p) *reinterpret_cast<u32x4*>(dst + p * 128) = regs[p];
+    };
+
+    uint32_t t = bidx;
+    if (t < ntiles) {
+        issue_loads(t);
+        store_tile(buf0);
+    }
+    __syncthreads();
+    for (uint32_t it = 0; t < ntiles; t += blocks_per_group, ++it) {
+        unsigned char* cur = buf0 + (it & 1) * BUF_B;
+        unsigned char* nxt = buf0 + ((it & 1) ^ 1) * BUF_B;
+        const uint32_t tn = t + blocks_per_group;
+        const bool dbg_noload = (a.debug & 1u) != 0, dbg_nomfma = (a.debug & 2u) != 0;  // timing experiments only
+        if (tn < ntiles && !dbg_noload) issue_loads(tn);
+
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+        const unsigned char* b0 = cur + (lane & 31) * ROW_B + (lane >> 5) * 16;
+        const unsigned char* b1 = b0 + 32 * ROW_B;
+        if (!dbg_nomfma)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 fb0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(b0 + ks * 32));
+            const bf16x8 fb1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(b1 + ks * 32));
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], fb0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], fb1, acc1, 0, 0, 0);
+            // keep at most 4 k-steps of B fragments in flight: without a fence the scheduler hoists all
+            // 2*KS ds_read_b128 (192 VGPRs at D = 384) above the MFMAs and spills the A fragments
+            if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // fused selection: C[query][row], col = lane & 31 = corpus row, reg r = query (r&3)+8(r>>2)+4(lane>>5)
+        const uint32_t row0 = a.slab0 + t * TROWS + (lane & 31);
+        const uint32_t row1 = row0 + 32;
+        const bool ok0 = row0 < slab_end, ok1 = row1 < slab_end;
+        // d <= tau  <=>  acc >= 1 - tau: compare the raw accumulators against one bound
+        const float amin = 1.0f - tmax;
+        float best = -__builtin_inff();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            best = fmaxf(best, ok0 ? acc0[r] : -__builtin_inff());
+            best = fmaxf(best, ok1 ? acc1[r] : -__builtin_inff());
+        }
+        if (__any(best >= amin - 1e-6f))
+            rega_append(acc0, acc1, ok0, ok1, q0, a.row_base + row0, a.tau, a.cand, a.cand_count, a.cand_cap, a.nq,
+                        (lds_u32x4*)(stage_all + wave * STAGE_CAP), (lds_u32*)(wcnt + wave), STAGE_CAP);
+
+        if (tn < ntiles && !dbg_noload) store_tile(nxt);
+        __syncthreads();
+    }
+}
+
+template <int D>
+static hipError_t launch_rega(const GemmArgs& a, hipStream_t st) {
+    constexpr size_t smem = 2 * 64 * (D * 2 + 16) + 8 * 128 * 16 + 64;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&batch_gemm_rega_kernel<D>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    const uint32_t groups = (a.nqt * 128 + 255) / 256;
+    const uint32_t ntiles = (a.slab_rows + 63) / 64;
+    uint32_t per_group = 256 / groups;          // one persistent workgroup per CU in total
+    if (per_group < 1) per_group = 1;
+    if (per_group > ntiles) per_group = ntiles;
+    hipLaunchKernelGGL((batch_gemm_rega_kernel<D>), dim3(groups * per_group), dim3(512), smem, st, a, per_group);
+    return hipGetLastError();
+}
+
 hipError_t launch_batch_gemm(const GemmArgs& a, int metric, hipStream_t st) {
+    // fast path: queries resident in registers (needs the query block padded to a multiple of 256 rows)
+    if (a.dense == nullptr && a.use_rega && metric != BM_L2) {
+        switch (a.dims) {
+            case 128: return launch_rega<128>(a, st);
+            case 256: return launch_rega<256>(a, st);
+            case 384: return launch_rega<384>(a, st);
+            case 512: return launch_rega<512>(a, st);
+            default: break;
+        }
+    }
     const uint32_t ctiles = (a.slab_rows + GN - 1) / GN;
     const dim3 grid(ctiles * a.nqt);
     switch (metric) {

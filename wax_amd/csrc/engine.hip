@@ -283,7 +283,9 @@ struct wax_hip_engine {
     std::atomic<int64_t> stream_nt{1};
     std::atomic<int64_t> batch_min{16};      // fewer queries than this: pipelined single-query scans
     std::atomic<int64_t> batch_mode{1};      // 0 = never use the MFMA path
-    std::atomic<int64_t> batch_slab_mb{64};  // score-tile budget (kept inside the Infinity Cache)
+    std::atomic<int64_t> batch_slab_mb{64};  // cap on slab size, in units of 16 384 rows
+    std::atomic<int64_t> batch_debug{0};     // timing experiments only (GemmArgs::debug)
+    std::atomic<int64_t> batch_rega{1};      // 1: register-resident-queries GEMM where it applies
     std::atomic<uint64_t> st_batch_queries{0}, st_batch_fallbacks{0};
     BatchWork batch;
 
@@ -601,7 +603,7 @@ int batch_search_mfma(wax_hip_engine* e, const float* queries, uint32_t nq, int 
     if (max_slab < 2048) max_slab = 2048;
     for (uint32_t q0 = 0; q0 < nq; q0 += kBatchMaxQ) {
         const uint32_t qn = (nq - q0 < kBatchMaxQ) ? nq - q0 : kBatchMaxQ;
-        const uint32_t nq_pad = (qn + 127u) & ~127u;
+        const uint32_t nq_pad = (qn + 255u) & ~255u;  // 256: the register-resident-queries GEMM works on groups of 256
         const float* qsrc = queries + (uint64_t)q0 * D;
         for (uint32_t q = 0; q < qn; ++q) {
             b.h_qnorm[q] = query_norm(qsrc + (uint64_t)q * D, D);
@@ -625,6 +627,8 @@ int batch_search_mfma(wax_hip_engine* e, const float* queries, uint32_t nq, int 
             g.qb = b.d_qb; g.cb = b.d_cb; g.q_n2 = b.d_qn2; g.v_n2 = b.d_vn2; g.tau = b.d_tau;
             g.cand = b.d_cand; g.cand_count = b.d_cand_count; g.cand_cap = kBatchCandCap; g.row_base = (uint32_t)e->row_base;
             g.dims = D; g.n_rows = n; g.slab0 = s0; g.slab_rows = rows; g.nq = qn; g.nqt = nq_pad / 128;
+            g.use_rega = e->batch_rega.load() != 0 ? 1u : 0u;
+            g.debug = (uint32_t)e->batch_debug.load();
             const bool first = (s0 == 0);  // no threshold yet: dense tile instead of appending everything
             g.dense = first ? b.d_dense : nullptr;
             g.dense_ld = kBatchFirstSlab;
@@ -1297,6 +1301,8 @@ int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value) {
     else if (k == "stream_nt") e->stream_nt = value;
     else if (k == "batch_min") e->batch_min = value;
     else if (k == "batch_mode") e->batch_mode = value;
+    else if (k == "batch_rega") e->batch_rega = value;
+    else if (k == "batch_debug") e->batch_debug = value;
     else if (k == "batch_slab_mb") { if (value < 1 || value > 4096) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_slab_mb must be 1..4096"); e->batch_slab_mb = value; }
     else if (k == "streams") {
         if (value < 1 || value > kMaxStreams) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "streams must be 1..4");
@@ -1328,6 +1334,7 @@ int64_t wax_hip_get_tuning(wax_hip_engine* e, const char* key) {
     if (k == "stream_nt") return e->stream_nt.load();
     if (k == "batch_min") return e->batch_min.load();
     if (k == "batch_mode") return e->batch_mode.load();
+    if (k == "batch_rega") return e->batch_rega.load();
     if (k == "batch_slab_mb") return e->batch_slab_mb.load();
     if (k == "batch_queries") return (int64_t)e->st_batch_queries.load();
     if (k == "batch_fallbacks") return (int64_t)e->st_batch_fallbacks.load();

@@ -86,6 +86,8 @@ struct GemmArgs {
     uint32_t slab_rows;
     uint32_t nq;
     uint32_t nqt;               // nq_pad / 128
+    uint32_t debug;             // timing experiments: bit0 skip corpus loads, bit1 skip MFMAs (results are garbage)
+    uint32_t use_rega;          // 1: queries padded to 256 rows and tau/qb sized accordingly => register-resident-queries kernel allowed
 };
 struct RescoreArgs {
     const float* store;
