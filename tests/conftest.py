@@ -25,3 +25,11 @@ def hip_lib():
     from wax_amd import _abi, build
     build.build()
     return _abi.lib()
+
+
+def pytest_collection_modifyitems(config, items):
+    """A hung GPU test must not eat the box's time budget: every gpu-marked test gets a hard timeout
+    (pytest-timeout, when installed)."""
+    for item in items:
+        if "gpu" in item.keywords and not any(m.name == "timeout" for m in item.iter_markers()):
+            item.add_marker(pytest.mark.timeout(240))

@@ -21,9 +21,9 @@ for s in $STAGES; do
     smoke)
       timeout 600 python __graft_entry__.py --smoke > "$OUT/smoke.log" 2>&1; rc=$? ;;
     tests)
-      timeout 1500 python -m pytest tests -m gpu -q -rA --durations=15 -p no:cacheprovider > "$OUT/pytest_gpu.log" 2>&1; rc=$? ;;
+      timeout 600 python -m pytest tests -m gpu -q -rA --durations=15 -p no:cacheprovider --timeout 150 > "$OUT/pytest_gpu.log" 2>&1; rc=$? ;;
     tests_x)
-      timeout 1500 python -m pytest tests -m gpu -x -q -p no:cacheprovider > "$OUT/pytest_gpu_x.log" 2>&1; rc=$? ;;
+      timeout 600 python -m pytest tests -m gpu -x -q -p no:cacheprovider --timeout 150 > "$OUT/pytest_gpu_x.log" 2>&1; rc=$? ;;
     bench)
       timeout 900 python bench.py --gpus 1 > "$OUT/bench.json" 2> "$OUT/bench.err"; rc=$? ;;
     prof)
@@ -65,6 +65,11 @@ for f in ("multi_n1","multi_n2_host","multi_n3_host"):
     except Exception as e: print(f, "ERR", e)
 PYEOF
       ;;
+    gemmpmc)
+      (cd /tmp && timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE \
+          --kernel-trace --output-format csv -d "$OUT/prof_gemmpmc" -o g -- python "$R/tools/batch_bench.py" --nq 256 --reps 2 > "$OUT/gemmpmc.log" 2>&1); rc=$?
+      python tools/pmc_summary.py "$OUT/prof_gemmpmc" > "$OUT/gemmpmc_summary.json" 2>> "$OUT/gemmpmc.log"
+      find "$OUT/prof_gemmpmc" -name "*.csv" -size +1M -delete 2>/dev/null ;;
     gemmprobe)
       timeout 600 python tools/gemm_probe.py > "$OUT/gemm_probe.log" 2>&1; rc=$? ;;
     sweep)

@@ -25,6 +25,9 @@ namespace {
 
 thread_local std::string g_last_error;
 
+// Uncollected search tickets submitted by THIS thread, per engine (see RWLock::lock_shared).
+thread_local std::map<const void*, int> g_outstanding;
+
 int fail(int code, const std::string& msg) {
     g_last_error = msg;
     return code;
@@ -56,9 +59,12 @@ struct DeviceGuard {
 // (WaxCore/Concurrency/ReadWriteLock.swift:79-156).
 class RWLock {
   public:
-    void lock_shared() {
+    // reentrant = the caller already holds a shared lock (an uncollected search ticket): it must not queue
+    // behind a waiting writer, or the writer (waiting for readers == 0) and the reader (waiting for the
+    // writer) deadlock. With readers_ > 0 no writer can be active, so skipping the preference is safe.
+    void lock_shared(bool reentrant = false) {
         std::unique_lock<std::mutex> g(m_);
-        cv_.wait(g, [&] { return !writer_ && writers_waiting_ == 0; });
+        cv_.wait(g, [&] { return !writer_ && (reentrant || writers_waiting_ == 0); });
         ++readers_;
     }
     void unlock_shared() {
@@ -349,7 +355,9 @@ void free_slot(Slot* s) {
 }
 
 // acquireTransientBuffers (MetalVectorEngine.swift:84-113): reuse a pooled slot or create one.
-int acquire_slot(wax_hip_engine* e, Slot** out) {
+constexpr int kSlotBusy = 1;  // internal: try_only and every slot is in use
+
+int acquire_slot(wax_hip_engine* e, Slot** out, bool try_only = false) {
     std::unique_lock<std::mutex> g(e->slot_mu);
     for (;;) {
         if (!e->free_slots.empty()) {
@@ -371,6 +379,7 @@ int acquire_slot(wax_hip_engine* e, Slot** out) {
             *out = s;
             return WAX_HIP_OK;
         }
+        if (try_only) return kSlotBusy;
         e->slot_cv.wait(g);
     }
 }
@@ -896,15 +905,25 @@ int wax_hip_remove(wax_hip_engine* e, uint64_t frame_id) {
 
 // ---- search ---------------------------------------------------------------
 
+// try_only: never block waiting for a scratch slot (returns kSlotBusy) — used by callers that already hold
+// tickets, which must collect one instead of waiting (two such callers would starve each other).
+static int submit_impl(wax_hip_engine* e, const float* query, uint32_t dims, int32_t top_k, uint64_t* out_ticket,
+                       bool try_only);
+
 int wax_hip_search_submit(wax_hip_engine* e, const float* query, uint32_t dims, int32_t top_k, uint64_t* out_ticket) {
+    return submit_impl(e, query, dims, top_k, out_ticket, false);
+}
+
+static int submit_impl(wax_hip_engine* e, const float* query, uint32_t dims, int32_t top_k, uint64_t* out_ticket,
+                       bool try_only) {
     if (!e || !out_ticket) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine/ticket is null");
     DeviceGuard g(e->device);
-    e->lock.lock_shared();                                 // withReadLock (:447)
+    e->lock.lock_shared(g_outstanding[e] > 0);             // withReadLock (:447)
     Slot* s = nullptr;
     int rc = WAX_HIP_OK;
     do {
         if (e->count == 0) {                               // :448 — an empty ticket, no GPU work
-            rc = acquire_slot(e, &s);
+            rc = acquire_slot(e, &s, try_only);
             if (rc != WAX_HIP_OK) break;
             s->k_eff = 0; s->timed = false;
             break;
@@ -919,7 +938,7 @@ int wax_hip_search_submit(wax_hip_engine* e, const float* query, uint32_t dims, 
         }
         const int limit = clamp_topk(top_k);               // :450
         const int k_eff = (uint64_t)limit < e->count ? limit : (int)e->count;  // :451
-        rc = acquire_slot(e, &s);
+        rc = acquire_slot(e, &s, try_only);
         if (rc != WAX_HIP_OK) break;
         s->k_eff = k_eff;
         s->timed = e->time_kernels.load() != 0;
@@ -946,6 +965,7 @@ int wax_hip_search_submit(wax_hip_engine* e, const float* query, uint32_t dims, 
         e->tickets[t] = s;
         *out_ticket = t;
     }
+    g_outstanding[e] += 1;
     return WAX_HIP_OK;  // shared lock stays held until collect
 }
 
@@ -1001,6 +1021,10 @@ static int collect_impl(wax_hip_engine* e, uint64_t ticket, uint64_t* out_ids, f
     }
     release_slot(e, s);
     e->lock.unlock_shared();
+    {
+        auto it = g_outstanding.find(e);   // tickets may be collected on another thread: clamp at zero
+        if (it != g_outstanding.end() && it->second > 0) it->second -= 1;
+    }
     return rc;
 }
 
@@ -1027,7 +1051,7 @@ static int search_batch_hits_impl(wax_hip_engine* e, const float* queries, uint3
         int brc;
         {
             DeviceGuard g(e->device);
-            e->lock.lock_shared();
+            e->lock.lock_shared(g_outstanding[e] > 0);
             if (e->row_base + e->count > 0x100000000ull) {
                 e->lock.unlock_shared();
                 return fail(WAX_HIP_ERR_CAPACITY, "row_base + count exceeds UInt32 row indices");
@@ -1056,7 +1080,10 @@ static int search_batch_hits_impl(wax_hip_engine* e, const float* queries, uint3
     int rc = WAX_HIP_OK;
     while (collected < todo.size()) {
         while (submitted < todo.size() && submitted - collected < depth) {
-            rc = wax_hip_search_submit(e, queries + (uint64_t)todo[submitted] * dims, dims, top_k, &tk[submitted]);
+            // holding tickets already => never wait for a slot (another batch may be doing the same): collect instead
+            rc = submit_impl(e, queries + (uint64_t)todo[submitted] * dims, dims, top_k, &tk[submitted],
+                             /*try_only=*/submitted > collected);
+            if (rc == kSlotBusy) { rc = WAX_HIP_OK; break; }
             if (rc != WAX_HIP_OK) break;
             ++submitted;
         }
@@ -1132,7 +1159,7 @@ int wax_hip_search_shard_device(wax_hip_engine* e, const float* query, uint32_t 
     if (kpad > FUSED_MAX_K) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "top_k too large for the device-resident shard path (max 192)");
     DeviceGuard g(e->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    e->lock.lock_shared();
+    e->lock.lock_shared(g_outstanding[e] > 0);
     int rc = WAX_HIP_OK;
     do {
         if (e->row_base + e->count > 0x100000000ull) { rc = fail(WAX_HIP_ERR_CAPACITY, "row_base + count exceeds UInt32 row indices"); break; }
@@ -1196,7 +1223,7 @@ void wax_hip_free(void* p) { std::free(p); }
 int wax_hip_serialize(wax_hip_engine* e, uint8_t** out_bytes, size_t* out_len) {
     if (!e || !out_bytes || !out_len) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null argument");
     DeviceGuard g(e->device);
-    e->lock.lock_shared();  // withReadLock (:683)
+    e->lock.lock_shared(g_outstanding[e] > 0);  // withReadLock (:683)
     const uint64_t n = e->count;
     const uint64_t vec_bytes = n * (uint64_t)e->dims * 4ull;  // :697
     const uint64_t id_bytes = n * 8ull;                       // :707
@@ -1352,7 +1379,7 @@ int wax_hip_time_scan_kernel(wax_hip_engine* e, const float* query, uint32_t dim
     if (dims != e->dims) return fail(WAX_HIP_ERR_DIM_MISMATCH, dim_mismatch_msg(e->dims, dims));
     if (iters == 0) iters = 1;
     DeviceGuard g(e->device);
-    e->lock.lock_shared();
+    e->lock.lock_shared(g_outstanding[e] > 0);
     Slot* s = nullptr;
     int rc = WAX_HIP_OK;
     do {
@@ -1391,7 +1418,7 @@ int wax_hip_time_stream_read(wax_hip_engine* e, uint32_t iters, double* out_avg_
     if (!e || !out_avg_ms) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null argument");
     if (iters == 0) iters = 1;
     DeviceGuard g(e->device);
-    e->lock.lock_shared();
+    e->lock.lock_shared(g_outstanding[e] > 0);
     Slot* s = nullptr;
     int rc = WAX_HIP_OK;
     do {
