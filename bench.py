@@ -277,9 +277,9 @@ def main():
                 "kernel_avg_ms": kern_ms,
                 "kernel_launches_timed": launches,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
-                "note": "rows_per_gpu*dims*4 bytes per launch / mean HIP-event duration of the scan kernel over "
-                        "the timed region" + ("; two streams overlap scans at N>1, so per-kernel durations include "
-                                              "that overlap" if world > 1 else ""),
+                "note": "rows_per_gpu*dims*4 bytes per launch / mean HIP-event duration of the scan kernel over the "
+                        "timed region (rank 0's shard; scans are chained across the two pipeline streams, so they "
+                        "never overlap each other)",
             },
         }
         if world == 1 and not args.no_cpu_baseline:

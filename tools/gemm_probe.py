@@ -18,7 +18,7 @@ for r0, x in bench.device_rows(torch, 0, rows, dims, dev):
 q = bench.unit_queries(256, dims)
 eng.searchBatch(q, 10)
 for rega in (1, 0):
-    for dbg in (0, 1, 2, 3):
+    for dbg in (0, 1, 5, 2, 3):
         if rega == 0 and dbg:
             continue
         eng.setTuning("batch_rega", rega)

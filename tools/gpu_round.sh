@@ -33,7 +33,7 @@ for s in $STAGES; do
       find "$OUT/prof_stats" -name "*kernel_trace.csv" -exec sh -c 'head -400 "$1" > "$2"' _ {} "$OUT/kernel_trace_head.csv" \; 2>/dev/null
       find "$OUT/prof_stats" -name "*kernel_trace.csv" -delete 2>/dev/null ;;
     pmc)
-      (cd /tmp && timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/prof_pmc" -o pmc -- \
+      (cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/prof_pmc" -o pmc -- \
           python "$R/bench.py" --gpus 1 --steps 20 --warmup 2 --no-cpu-baseline > "$OUT/pmc_bench.json" 2> "$OUT/pmc.err"); rc=$?
       python tools/pmc_summary.py "$OUT/prof_pmc" > "$OUT/pmc_summary.json" 2>> "$OUT/pmc.err"
       find "$OUT/prof_pmc" -name "*.csv" -size +2M -delete 2>/dev/null ;;
@@ -66,7 +66,7 @@ for f in ("multi_n1","multi_n2_host","multi_n3_host"):
 PYEOF
       ;;
     gemmpmc)
-      (cd /tmp && timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE \
+      (cd /tmp && timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE \
           --kernel-trace --output-format csv -d "$OUT/prof_gemmpmc" -o g -- python "$R/tools/batch_bench.py" --nq 256 --reps 2 > "$OUT/gemmpmc.log" 2>&1); rc=$?
       python tools/pmc_summary.py "$OUT/prof_gemmpmc" > "$OUT/gemmpmc_summary.json" 2>> "$OUT/gemmpmc.log"
       find "$OUT/prof_gemmpmc" -name "*.csv" -size +1M -delete 2>/dev/null ;;

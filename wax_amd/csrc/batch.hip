@@ -474,7 +474,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
     }
     __syncthreads();
     for (uint32_t it = 0; t < ntiles; t += blocks_per_group, ++it) {
-        unsigned char* cur = buf0 + (it & 1) * BUF_B;
+        unsigned char* cur = buf0 + (((a.debug & 1u) ? 0u : (it & 1u)) * BUF_B);  // debug bit0: always the prologue tile
         unsigned char* nxt = buf0 + ((it & 1) ^ 1) * BUF_B;
         const uint32_t tn = t + blocks_per_group;
         const bool dbg_noload = (a.debug & 1u) != 0, dbg_nomfma = (a.debug & 2u) != 0;  // timing experiments only
@@ -492,9 +492,22 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
             const bf16x8 fb1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(b1 + ks * 32));
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], fb0, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], fb1, acc1, 0, 0, 0);
-            // keep at most 4 k-steps of B fragments in flight: without a fence the scheduler hoists all
-            // 2*KS ds_read_b128 (192 VGPRs at D = 384) above the MFMAs and spills the A fragments
-            if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        // Software pipeline of the K loop, spelled out for the scheduler: B fragments are read AHEAD k-steps
+        // before the MFMAs that consume them (2 ds_read_b128 + 2 MFMA per k-step), so an MFMA never waits
+        // on the LDS read issued just before it, and at most AHEAD+1 k-steps of fragments are live (left
+        // alone, hipcc hoists all 2*KS reads above the MFMAs: 192 VGPRs at D = 384, spilling the A fragments).
+        {
+            constexpr int AHEAD = 2;
+#pragma unroll
+            for (int i = 0; i < AHEAD; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS read
+#pragma unroll
+            for (int ks = 0; ks < KS - AHEAD; ++ks) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                // MFMA
+            }
+#pragma unroll
+            for (int i = 0; i < AHEAD; ++i) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
         }
 
         // fused selection: C[query][row], col = lane & 31 = corpus row, reg r = query (r&3)+8(r>>2)+4(lane>>5)
@@ -514,7 +527,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
                         (lds_u32x4*)(stage_all + wave * STAGE_CAP), (lds_u32*)(wcnt + wave), STAGE_CAP);
 
         if (tn < ntiles && !dbg_noload) store_tile(nxt);
-        __syncthreads();
+        if (!(a.debug & 4u)) __syncthreads();  // debug bit2 (only with bit0): no per-tile barrier
     }
 }
 
