@@ -18,13 +18,13 @@ for r0, x in bench.device_rows(torch, 0, rows, dims, dev):
 q = bench.unit_queries(256, dims)
 eng.searchBatch(q, 10)
 for rega in (1, 0):
-    for dbg in (0, 1, 5, 2, 3):
+    for dbg in (0, 8, 9, 13, 2, 3):
         if rega == 0 and dbg:
             continue
         eng.setTuning("batch_rega", rega)
         eng.setTuning("batch_debug", dbg)
         eng.searchBatch(q, 10)
         t0 = time.perf_counter()
-        for _ in range(5):
-            eng.searchBatch(q, 10)
+        for _ in range(2):
+            eng.searchBatch(q[:256], 10)
         print(f"rega={rega} debug={dbg}: {(time.perf_counter() - t0) / 5 * 1e3:.3f} ms/batch", flush=True)

@@ -70,6 +70,10 @@ PYEOF
           --kernel-trace --output-format csv -d "$OUT/prof_gemmpmc" -o g -- python "$R/tools/batch_bench.py" --nq 256 --reps 2 > "$OUT/gemmpmc.log" 2>&1); rc=$?
       python tools/pmc_summary.py "$OUT/prof_gemmpmc" > "$OUT/gemmpmc_summary.json" 2>> "$OUT/gemmpmc.log"
       find "$OUT/prof_gemmpmc" -name "*.csv" -size +1M -delete 2>/dev/null ;;
+    gemmprobeprof)
+      (cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d "$OUT/prof_probe" -o p -- python "$R/tools/gemm_probe.py" > "$OUT/gemm_probe_prof.log" 2>&1); rc=$?
+      find "$OUT/prof_probe" -name "*kernel_trace.csv" -exec sh -c 'head -1 "$1" > "$2"; grep "gemm" "$1" >> "$2"' _ {} "$OUT/probe_gemm_trace.csv" \; 2>/dev/null
+      find "$OUT/prof_probe" -name "*kernel_trace.csv" -delete 2>/dev/null ;;
     gemmprobe)
       timeout 600 python tools/gemm_probe.py > "$OUT/gemm_probe.log" 2>&1; rc=$? ;;
     sweep)

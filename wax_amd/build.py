@@ -36,14 +36,34 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile (if needed) and return the library path. Safe when several ranks of one job call it at the
+    same time: builds are serialised by a file lock and the .so is replaced atomically, so a process never
+    dlopens a half-written file."""
     if not force and not needs_build():
         return LIB_PATH
+    import fcntl
+    import tempfile
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-I" + os.path.join(ROOT, "include"), "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True)
+    with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():  # another process built it while we waited
+                return LIB_PATH
+            fd, tmp = tempfile.mkstemp(prefix=".libwaxhip.", suffix=".so", dir=LIB_DIR)
+            os.close(fd)
+            cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
+                   "-I" + os.path.join(ROOT, "include"), "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            try:
+                subprocess.run(cmd, check=True)
+                os.chmod(tmp, 0o755)
+                os.replace(tmp, LIB_PATH)
+            finally:
+                if os.path.exists(tmp):
+                    os.unlink(tmp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 

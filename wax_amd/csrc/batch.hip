@@ -336,66 +336,7 @@ __global__ __launch_bounds__(256) void batch_gemm_kernel(GemmArgs a) {
 typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
 typedef __attribute__((address_space(3))) unsigned int lds_u32;
 
-// Cold path of the register-resident-queries GEMM: some accumulator of this wave's 32 x 64 tile may beat
-// its query's threshold. Re-reads the exact thresholds, compacts the survivors into the wave's LDS
-// stage and appends them with all lanes' atomics in flight. Not inlined: inlined, its 32 predicated
-// blocks keep ~100 extra VGPRs live across the MFMA loop and spill the A fragments.
-__device__ __attribute__((noinline)) void rega_append(f32x16 acc0, f32x16 acc1, bool ok0, bool ok1, uint32_t q0,
-                                                      uint32_t grow0, const float* __restrict__ tau,
-                                                      int64_t* __restrict__ cand, uint32_t* __restrict__ cand_count,
-                                                      uint32_t cand_cap, uint32_t nq, lds_u32x4* stage, lds_u32* wcnt,
-                                                      unsigned stage_cap) {
-    const int lane = lane_id();
-    unsigned pass = 0u;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float tqr = tau[q0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
-        const float d0 = (1.0f - acc0[r]) + 0.0f, d1 = (1.0f - acc1[r]) + 0.0f;
-        pass |= ((ok0 && d0 <= tqr) ? 1u : 0u) << r;
-        pass |= ((ok1 && d1 <= tqr) ? 1u : 0u) << (16 + r);
-    }
-    if (!__any(pass != 0u)) return;
-    const unsigned mine = (unsigned)__popc(pass);
-    unsigned off = 0;
-    if (mine) off = __hip_atomic_fetch_add(wcnt, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    wave_lds_fence();
-    const unsigned total = (unsigned)__builtin_amdgcn_readfirstlane((int)*wcnt);
-    const bool staged = total <= stage_cap;
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if ((pass >> (j * 16 + r)) & 1u) {
-                const float d = (1.0f - (j ? acc1[r] : acc0[r])) + 0.0f;
-                const uint32_t q = q0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int64_t key = make_key(d, grow0 + (j ? 32u : 0u));
-                if (staged) {
-                    u32x4 e;
-                    e.x = (unsigned)((unsigned long long)key & 0xffffffffull);
-                    e.y = (unsigned)((unsigned long long)key >> 32);
-                    e.z = q;
-                    e.w = 0u;
-                    stage[off++] = e;
-                } else if (q < nq) {  // stage overflow (loose threshold): direct appends
-                    const uint32_t pos = atomicAdd(&cand_count[q], 1u);
-                    if (pos < cand_cap) cand[(size_t)q * cand_cap + pos] = key;
-                }
-            }
-        }
-    wave_lds_fence();
-    if (staged) {
-        for (unsigned i = (unsigned)lane; i < total; i += WAVE) {
-            const u32x4 e = stage[i];
-            const uint32_t q = e.z;
-            if (q < nq) {
-                const uint32_t pos = atomicAdd(&cand_count[q], 1u);
-                if (pos < cand_cap) cand[(size_t)q * cand_cap + pos] = (int64_t)(((unsigned long long)e.y << 32) | (unsigned long long)e.x);
-            }
-        }
-    }
-    wave_lds_fence();
-    if (lane == 0) *wcnt = 0u;
-}
+typedef __attribute__((address_space(3))) float lds_f32;
 
 // ---------------------------------------------------------------------------
 // Register-resident-queries GEMM (cosine / dot, D in {128, 256, 384, 512}; every slab after the first).
@@ -417,12 +358,13 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
     constexpr int SEGS = TROWS * SEG_PER_ROW;        // 16-byte segments per tile
     constexpr int LOADS = SEG_PER_ROW / 8;           // per thread (8 threads per row, 64 rows)
     constexpr int BUF_B = TROWS * ROW_B;
-    constexpr unsigned STAGE_CAP = 128;              // staged survivors per wave
+    constexpr unsigned LIST_CAP = 2048;              // survivors a workgroup can hold before its single flush
     static_assert(SEGS == 512 * LOADS && D % 64 == 0, "tile must split evenly over 512 threads");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* buf0 = smem;
-    u32x4* stage_all = reinterpret_cast<u32x4*>(smem + 2 * BUF_B);
-    unsigned int* wcnt = reinterpret_cast<unsigned int*>(smem + 2 * BUF_B + 8 * STAGE_CAP * 16);
+    u32x4* blist = reinterpret_cast<u32x4*>(smem + 2 * BUF_B);
+    float* tau_s = reinterpret_cast<float*>(smem + 2 * BUF_B + LIST_CAP * 16);          // [8][32] exact thresholds
+    unsigned int* blist_count = reinterpret_cast<unsigned int*>(tau_s + 8 * 32);
 
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
@@ -438,12 +380,9 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) fa[ks] = __builtin_bit_cast(bf16x8, qp[ks * 2]);
     }
-    // Hot-path filter: ONE register, the loosest threshold among the 16 queries this lane's accumulators
-    // belong to. The exact per-query thresholds are re-read (L2) only on the rare path that found a survivor.
-    float tmax = -__builtin_inff();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, a.tau[q0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)]);
-    if (tid < 8) wcnt[tid] = 0u;
+    if (lane < 32) tau_s[wave * 32 + lane] = a.tau[q0 + lane];
+    if (tid == 0) *blist_count = 0u;
+    for (unsigned i = (unsigned)tid; i < LIST_CAP; i += 512u) blist[i] = u32x4{0u, 0u, 0u, 0u};
 
     const uint32_t ntiles = (a.slab_rows + TROWS - 1) / TROWS;
     const uint32_t slab_end = a.slab0 + a.slab_rows;
@@ -514,26 +453,70 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
         const uint32_t row0 = a.slab0 + t * TROWS + (lane & 31);
         const uint32_t row1 = row0 + 32;
         const bool ok0 = row0 < slab_end, ok1 = row1 < slab_end;
-        // d <= tau  <=>  acc >= 1 - tau: compare the raw accumulators against one bound
-        const float amin = 1.0f - tmax;
-        float best = -__builtin_inff();
+        // Fused selection, fully inline: 16 exact thresholds from LDS (two distinct addresses per read:
+        // the two half-waves), 32 compares; a survivor (~0.8 per wave-tile at Q = 256, k' = 64 — this is the
+        // COMMON case, so no call, no scratch, no global memory) is pushed onto the workgroup's LDS list.
+        if (!(a.debug & 8u)) {
+            const lds_f32* tau_w = (const lds_f32*)(tau_s + wave * 32);
+            lds_u32x4* bl = (lds_u32x4*)blist;
+            lds_u32* bc = (lds_u32*)blist_count;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            best = fmaxf(best, ok0 ? acc0[r] : -__builtin_inff());
-            best = fmaxf(best, ok1 ? acc1[r] : -__builtin_inff());
+            for (int r = 0; r < 16; ++r) {
+                // one accumulator pair at a time: without the fence hipcc hoists all 16 threshold reads and 32
+                // distances (and their keys) to the top and spills the A fragments
+                if (r & 1) __builtin_amdgcn_sched_barrier(0);
+                const int qo = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float tqr = tau_w[qo];
+                const float d0 = (1.0f - acc0[r]) + 0.0f, d1 = (1.0f - acc1[r]) + 0.0f;
+                const bool p0 = ok0 && d0 <= tqr, p1 = ok1 && d1 <= tqr;   // NaN fails
+                if (__any(p0 || p1)) {
+                    if (p0 || p1) {
+                        const uint32_t q = q0 + (uint32_t)qo;
+                        const unsigned n = (p0 ? 1u : 0u) + (p1 ? 1u : 0u);
+                        unsigned off = __hip_atomic_fetch_add(bc, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        const bool fits = off + n <= LIST_CAP;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            if (j ? p1 : p0) {
+                                const int64_t key = make_key(j ? d1 : d0, a.row_base + (j ? row1 : row0));
+                                if (fits) {
+                                    u32x4 e;
+                                    e.x = (unsigned)((unsigned long long)key & 0xffffffffull);
+                                    e.y = (unsigned)((unsigned long long)key >> 32);
+                                    e.z = q;
+                                    e.w = 1u;  // written marker: a lane whose range straddles the capacity writes nothing
+                                    bl[off++] = e;
+                                } else if (q < a.nq) {  // list full (very loose threshold): direct global append
+                                    const uint32_t pos = atomicAdd(&a.cand_count[q], 1u);
+                                    if (pos < a.cand_cap) a.cand[(size_t)q * a.cand_cap + pos] = key;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
         }
-        if (__any(best >= amin - 1e-6f))
-            rega_append(acc0, acc1, ok0, ok1, q0, a.row_base + row0, a.tau, a.cand, a.cand_count, a.cand_cap, a.nq,
-                        (lds_u32x4*)(stage_all + wave * STAGE_CAP), (lds_u32*)(wcnt + wave), STAGE_CAP);
 
         if (tn < ntiles && !dbg_noload) store_tile(nxt);
         if (!(a.debug & 4u)) __syncthreads();  // debug bit2 (only with bit0): no per-tile barrier
+    }
+    // single flush of the workgroup's survivor list: all 512 lanes' global atomics in flight at once
+    __syncthreads();
+    const unsigned listed = *blist_count < LIST_CAP ? *blist_count : LIST_CAP;
+    for (unsigned i = (unsigned)tid; i < listed; i += 512u) {
+        const u32x4 e = blist[i];
+        const uint32_t q = e.z;
+        if (e.w != 0u && q < a.nq) {
+            const uint32_t pos = atomicAdd(&a.cand_count[q], 1u);
+            if (pos < a.cand_cap)
+                a.cand[(size_t)q * a.cand_cap + pos] = (int64_t)(((unsigned long long)e.y << 32) | (unsigned long long)e.x);
+        }
     }
 }
 
 template <int D>
 static hipError_t launch_rega(const GemmArgs& a, hipStream_t st) {
-    constexpr size_t smem = 2 * 64 * (D * 2 + 16) + 8 * 128 * 16 + 64;
+    constexpr size_t smem = 2 * 64 * (D * 2 + 16) + 2048 * 16 + 8 * 32 * 4 + 64;
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&batch_gemm_rega_kernel<D>),
