@@ -105,7 +105,7 @@ def test_golden_vectors(wax, case):
 # seeded sweeps against the live oracle
 
 SPECIALISED = [64, 128, 256, 384, 512, 768, 1024, 1536]
-GENERIC = [2, 4, 6, 20, 100, 388, 2048]
+GENERIC = [1, 2, 3, 4, 6, 20, 100, 388, 2048]
 
 
 @pytest.mark.parametrize("metric", [0, 1, 2])

@@ -39,6 +39,13 @@ for s in $STAGES; do
       find "$OUT/prof_pmc" -name "*.csv" -size +2M -delete 2>/dev/null ;;
     batch)
       timeout 900 python tools/batch_bench.py --nq 64 256 1024 --slab-mb 16 64 256 > "$OUT/batch_bench.log" 2>&1; rc=$? ;;
+    batch768)
+      timeout 300 python tools/batch_bench.py --rows 1000000 --dims 768 --nq 256 1024 --reps 3 > "$OUT/batch768_bench.log" 2>&1; rc=$? ;;
+    profdefault)
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_default" -o bench -- \
+          python "$R/bench.py" --gpus 1 > "$OUT/profdefault_bench.json" 2> "$OUT/profdefault.err"); rc=$?
+      find "$OUT/prof_default" -name "*kernel_stats.csv" -exec cp {} "$OUT/default_kernel_stats.csv" \; 2>/dev/null
+      find "$OUT/prof_default" -name "*kernel_trace.csv" -delete 2>/dev/null ;;
     batchprof)
       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_batch" -o batch -- \
           python "$R/tools/batch_bench.py" --nq 256 --reps 3 > "$OUT/batchprof.log" 2>&1); rc=$?
