@@ -733,3 +733,46 @@ def test_concurrent_writers_and_readers(wax):
     got = eng.searchArrays(queries[0], 10)                                # and search agrees with the oracle on that store
     e_ids, e_scores, _, _ = oracle.search(0, vecs, ids, queries[0], 10)
     assert_parity(got[0], got[1], e_ids, e_scores, ctx="after concurrent mutation")
+
+
+def test_randomised_shapes_against_oracle(wax):
+    """Seeded random sweep over (rows, dims, k, metric, data pattern): every combination through the C ABI
+    vs the f64 oracle. Dims mix specialised (fused kernel per dims class), generic float4 and scalar ones."""
+    rng = np.random.default_rng(20260220)
+    dims_pool = [1, 3, 5, 8, 12, 31, 33, 64, 96, 100, 128, 200, 256, 300, 384, 385, 512, 640, 768, 1000, 1024, 1536]
+    for trial in range(48):
+        dims = int(rng.choice(dims_pool))
+        n = int(rng.choice([1, 2, 5, 17, 63, 64, 65, 100, 511, 777, 1500, 4097, 9000]))
+        k = int(rng.choice([1, 2, 3, 10, 24, 30, 64, 65, 100, 192, 193, 300]))
+        metric = int(rng.integers(0, 3))
+        pattern = rng.choice(["gauss", "gauss_scaled", "ties", "lcg", "dupes"])
+        if pattern == "gauss":
+            corpus = oracle.gaussian_unit_rows(trial * 100003, n, dims)
+        elif pattern == "gauss_scaled":
+            corpus = oracle.gaussian_unit_rows(trial * 100003, n, dims) * rng.uniform(0.1, 5.0, (n, 1)).astype(np.float32)
+        elif pattern == "ties":
+            corpus = oracle.tie_pattern(trial, n, dims)
+        elif pattern == "lcg":
+            corpus = np.stack([oracle.deterministic_embed(f"doc-{trial}-{i}", dims) for i in range(n)])
+        else:
+            base = oracle.gaussian_unit_rows(trial, max(1, n // 7 + 1), dims)
+            corpus = base[rng.integers(0, base.shape[0], n)]
+        ids = rng.permutation(10 * n + 5)[:n].astype(np.uint64)
+        q = oracle.gaussian_unit_queries(1, dims, seed=1000 + trial)[0]
+        if pattern == "ties":
+            q = np.abs(q)
+        eng = make_engine(wax, metric, dims, corpus, ids)
+        got_ids, got_scores = eng.searchArrays(q, k)
+        e_ids, e_scores, _, _ = oracle.search(metric, corpus, ids, q, k)
+        x_scores = oracle.search(metric, corpus, ids, q, min(k + MARGIN, 10000))[1]
+        ctx = f"trial{trial} n{n} d{dims} k{k} m{metric} {pattern}"
+        if pattern in ("ties", "dupes"):
+            # exact duplicates: scores must match position by position; ids may only permute among rows that
+            # the oracle also scores within 2e-5 of each other (duplicates are bit-identical on the GPU, so
+            # there the order is by row — checked exactly in test_exact_ties_resolve_by_ascending_row)
+            assert len(got_ids) == len(e_ids), ctx
+            assert np.max(np.abs(got_scores.astype(np.float64) - e_scores)) <= 1e-5, ctx
+            assert len(set(got_ids.tolist())) == len(got_ids), ctx
+        else:
+            assert_parity(got_ids, got_scores, e_ids, e_scores, x_scores, ctx)
+        eng.close()
