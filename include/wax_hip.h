@@ -128,6 +128,15 @@ int wax_hip_add_batch(wax_hip_engine* e, const uint64_t* frame_ids, const float*
  * were produced in HBM never bounce through the host). frame_ids stays a host
  * pointer. All ids must be new (append-only fast path); WAX_HIP_ERR_INVALID_ARGUMENT otherwise. */
 int wax_hip_add_batch_device(wax_hip_engine* e, const uint64_t* frame_ids, const float* d_rows, uint64_t n, uint32_t dims);
+/* Pending-embedding replay (UnifiedSearchEngineCache.applyPendingEmbeddingsIfNeeded, UnifiedSearchEngineCache.swift:252-283;
+ * MetalVectorEngine.load, MetalVectorEngine.swift:318-328): `payloads` is `len` bytes of WAL putEmbedding entry
+ * payloads laid back to back exactly as WALEntryCodec.encode writes them (WALEntryCodec.swift:39-54):
+ * u8 opcode 0x04, u64 frameId LE, u32 dimension LE, dimension x f32 LE. The stream is validated as a whole
+ * (decode rules of WALEntryCodec.swift:104-129: unknown opcode, dimension > 1 000 000, truncated record ->
+ * WAX_HIP_ERR_BAD_SEGMENT; dimension != engine dims -> WAX_HIP_ERR_DIM_MISMATCH) and then applied in order
+ * as ONE addBatch (later records of the same frame overwrite earlier ones), so a bad stream changes nothing.
+ * *out_applied (may be NULL) receives the number of records. */
+int wax_hip_apply_put_embeddings(wax_hip_engine* e, const uint8_t* payloads, uint64_t len, uint64_t* out_applied);
 /* remove(frameId:) — order-preserving delete, absent id is a no-op (MetalVectorEngine.swift:423-444). */
 int wax_hip_remove(wax_hip_engine* e, uint64_t frame_id);
 /* reserveIfNeeded(for:) (MetalVectorEngine.swift:857-871): capacity doubling from 64, cap UInt32.max rows. */
@@ -205,7 +214,7 @@ int wax_hip_stats(wax_hip_engine* e, wax_hip_stats_t* out);
  * distance-buffer + radix-select path even for small k), "stream_nt",
  * "reset_stats" (any value: zero the counters), "streams" (1..4 in-order streams the slots rotate over),
  * "batch_mode" (0 = never use the MFMA batched path), "batch_min" (smallest batch that uses it),
- * "batch_slab_mb". get-only: "variant_count", "scan_grid", "fused_max_k", "batch_queries",
+ * "batch_slab_mb", "batch_growth". get-only: "variant_count", "scan_grid", "fused_max_k", "batch_queries",
  * "batch_fallbacks". */
 int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value);
 int64_t wax_hip_get_tuning(wax_hip_engine* e, const char* key);

@@ -46,6 +46,12 @@ class VectorEngine {
         return out;
     }
     void add(uint64_t frameId, const std::vector<float>& v) { check(wax_hip_add(h_, frameId, v.data(), (uint32_t)v.size())); }
+    /// Pending-embedding replay: WAL putEmbedding payloads back to back (UnifiedSearchEngineCache.swift:252-283).
+    uint64_t applyPutEmbeddings(const uint8_t* payloads, uint64_t len) {
+        uint64_t applied = 0;
+        check(wax_hip_apply_put_embeddings(h_, payloads, len, &applied));
+        return applied;
+    }
     void addBatch(const std::vector<uint64_t>& frameIds, const std::vector<float>& rowsRowMajor) {
         if (frameIds.empty()) return;
         check(wax_hip_add_batch(h_, frameIds.data(), rowsRowMajor.data(), frameIds.size(),

@@ -106,6 +106,24 @@ public actor HIPVectorEngine {
         }
     }
 
+    /// Pending-embedding replay without the [[Float]] detour: WAL putEmbedding payloads (WALEntryCodec.encode,
+    /// WALEntryCodec.swift:39-54) concatenated, validated and applied inside the library as one addBatch.
+    /// UnifiedSearchEngineCache.applyPendingEmbeddingsIfNeeded (:252-283) can call this with the raw payloads.
+    @discardableResult
+    public func applyPutEmbeddings(payloads: Data) async throws -> Int {
+        guard !payloads.isEmpty else { return 0 }
+        let h = handle
+        let applied: UInt64 = try await io.run {
+            var n: UInt64 = 0
+            try Self.check(payloads.withUnsafeBytes { raw in
+                wax_hip_apply_put_embeddings(h, raw.bindMemory(to: UInt8.self).baseAddress, UInt64(raw.count), &n)
+            })
+            return n
+        }
+        if applied > 0 { dirty = true }
+        return Int(applied)
+    }
+
     public func remove(frameId: UInt64) async throws {
         let h = handle
         try await io.run { try Self.check(wax_hip_remove(h, frameId)) }

@@ -776,3 +776,44 @@ def test_randomised_shapes_against_oracle(wax):
         else:
             assert_parity(got_ids, got_scores, e_ids, e_scores, x_scores, ctx)
         eng.close()
+
+
+def test_pending_embedding_replay_from_wal_payloads(wax):
+    """WAL putEmbedding payloads (WALEntryCodec.swift:39-54, golden bytes from
+    WALEmbeddingCodecTests.swift:12-33) applied device-side == the same records through addBatch; a bad stream
+    changes nothing (decode rules WALEntryCodec.swift:104-129)."""
+    w = load_golden("reference_cases.json")["constants"]["put_embedding_wal"]
+    enc = wax.HIPVectorEngine.encodePutEmbedding(w["frameId"], w["vector"])
+    assert enc.hex() == w["encoded_hex"]
+    e2 = wax.HIPVectorEngine(metric=wax.VectorMetric.dot, dimensions=2)
+    assert e2.applyPutEmbeddings(enc) == 1 and e2.count == 1
+    ids, scores = e2.searchArrays(np.array([1.0, 0.0], np.float32), 1)
+    assert ids.tolist() == [1] and scores[0] == pytest.approx(1.0 - 1.0)  # dot score = q.v - 1
+    e2.close()
+
+    dims, n = 384, 700
+    corpus = oracle.gaussian_unit_rows(5, n, dims)
+    ids = (np.arange(n, dtype=np.uint64) * 3 + 11)
+    order = np.random.default_rng(2).integers(0, n, 2 * n)   # repeats: later records overwrite earlier ones
+    stream = b"".join(wax.HIPVectorEngine.encodePutEmbedding(int(ids[i]), corpus[i] * np.float32(1 + (j % 3)))
+                      for j, i in enumerate(order))
+    a = wax.HIPVectorEngine(metric=wax.VectorMetric.cosine, dimensions=dims)
+    b = wax.HIPVectorEngine(metric=wax.VectorMetric.cosine, dimensions=dims)
+    a.addBatch(ids[:50], corpus[:50])
+    b.addBatch(ids[:50], corpus[:50])
+    assert a.applyPutEmbeddings(stream) == len(order)
+    b.addBatch([int(ids[i]) for i in order], np.stack([corpus[i] * np.float32(1 + (j % 3)) for j, i in enumerate(order)]))
+    assert a.count == b.count
+    assert a.serialize() == b.serialize()
+    q = oracle.gaussian_unit_queries(1, dims)[0]
+    assert a.search(q, 10) == b.search(q, 10)
+    before = a.serialize()
+    for bad, exc in ((stream + b"\x04\x01\x02", wax.InvalidToc), (stream + b"\x09" + stream[1:50], wax.InvalidToc),
+                     (stream[:-4], wax.InvalidToc), (b"\x01" + stream[1:], wax.InvalidToc),
+                     (stream + wax.HIPVectorEngine.encodePutEmbedding(5, np.zeros(3, np.float32)), wax.EncodingError),
+                     (b"\x04" + b"\x00" * 8 + (2_000_000).to_bytes(4, "little"), wax.InvalidToc)):
+        with pytest.raises(exc):
+            a.applyPutEmbeddings(bad)
+    assert a.serialize() == before
+    assert a.applyPutEmbeddings(b"") == 0
+    a.close(); b.close()

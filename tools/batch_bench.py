@@ -32,6 +32,9 @@ def main():
     ap.add_argument("--topk", type=int, default=10)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--slab-mb", type=int, nargs="+", default=[64])
+    ap.add_argument("--growth", type=int, nargs="+", default=[0], help="slab growth factors to sweep (0 = library default)")
+    ap.add_argument("--debug", type=int, nargs="+", default=[0], help="batch_debug bit masks to sweep (timing experiments)")
+    ap.add_argument("--rega", type=int, nargs="+", default=[-1], help="batch_rega modes to sweep (-1 = library default)")
     ap.add_argument("--exchange", choices=["rccl", "host"], default="rccl")
     args = ap.parse_args()
     import torch
@@ -63,8 +66,14 @@ def main():
 
     for nq in args.nq:
         q = bench.unit_queries(nq, args.dims)
-        for slab in args.slab_mb:
+        for slab, growth, dbg, rega in [(s_, g_, d_, r_) for s_ in args.slab_mb for g_ in args.growth for d_ in args.debug
+                                        for r_ in args.rega]:
             eng.setTuning("batch_slab_mb", slab)
+            if rega >= 0:
+                eng.setTuning("batch_rega", rega)
+            eng.setTuning("batch_debug", dbg)
+            if growth:
+                eng.setTuning("batch_growth", growth)
             sharded.sharded_search_batch(eng, q, args.topk, world, args.exchange)  # warm-up (+ mirror build)
             fb0 = eng.getTuning("batch_fallbacks")
             sync()
@@ -80,7 +89,7 @@ def main():
             if rank == 0:
                 chk = hashlib.sha256(np.ascontiguousarray(ids).tobytes() + np.ascontiguousarray(scores).tobytes()).hexdigest()[:16]
                 print(json.dumps({"n_gpus": world, "rows": args.rows, "dims": args.dims, "nq": nq, "topk": args.topk,
-                                  "slab_mb": slab, "ms_per_batch": dt * 1e3, "qps": nq / dt,
+                                  "slab_mb": slab, "growth": eng.getTuning("batch_growth"), "debug": dbg, "rega": eng.getTuning("batch_rega"), "ms_per_batch": dt * 1e3, "qps": nq / dt,
                                   "tflops_bf16": 2.0 * nq * args.rows * args.dims / dt / 1e12,
                                   "fallbacks_rank0": eng.getTuning("batch_fallbacks") - fb0,
                                   "exchange": args.exchange if world > 1 else "none", "result_checksum": chk}), flush=True)

@@ -39,6 +39,27 @@ for s in $STAGES; do
       find "$OUT/prof_pmc" -name "*.csv" -size +2M -delete 2>/dev/null ;;
     batch)
       timeout 900 python tools/batch_bench.py --nq 64 256 1024 --slab-mb 16 64 256 > "$OUT/batch_bench.log" 2>&1; rc=$? ;;
+    growth)
+      timeout 600 python tools/batch_bench.py --nq 256 1024 --growth 3 4 6 8 10 12 > "$OUT/growth_bench.log" 2>&1; rc=$? ;;
+    tests_glds)
+      WAX_HIP_BATCH_REGA=2 timeout 900 python -m pytest tests -q -m gpu -x -k "batch" > "$OUT/pytest_gpu_glds.log" 2>&1; rc=$? ;;
+    glds)
+      timeout 600 python tools/batch_bench.py --nq 256 1024 --growth 8 --rega 1 2 1 2 > "$OUT/glds_bench.log" 2>&1; rc=$? ;;
+    ahead)
+      timeout 600 python tools/batch_bench.py --nq 256 1024 --growth 8 --rega 1 2 1 2 --debug 0 512 > "$OUT/ahead_bench.log" 2>&1; rc=$?
+      (cd /tmp && WAX_HIP_BATCH_REGA=2 timeout 600 rocprofv3 --kernel-trace --output-format csv -d "$OUT/prof_ahead" -o g -- \
+          python "$R/tools/batch_bench.py" --nq 256 --reps 2 --rega 1 2 --debug 0 256 512 > "$OUT/aheadprof.log" 2>&1)
+      f=$(find "$OUT/prof_ahead" -name "*kernel_trace.csv" | head -1)
+      [ -n "$f" ] && grep "rega_kernel" "$f" | python "$R/tools/trace_durations.py" > "$OUT/ahead_rega_durations.txt" 2>/dev/null
+      find "$OUT/prof_ahead" -name "*kernel_trace.csv" -delete 2>/dev/null ;;
+    pingpong)
+      timeout 600 python tools/batch_bench.py --nq 256 1024 --growth 8 --debug 0 16 0 16 > "$OUT/pingpong_bench.log" 2>&1; rc=$? ;;
+    growthprof)
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d "$OUT/prof_growth" -o g -- \
+          python "$R/tools/batch_bench.py" --nq ${WAX_NQ:-256} --reps 2 --growth ${WAX_GROWTH:-8} > "$OUT/growthprof.log" 2>&1); rc=$?
+      f=$(find "$OUT/prof_growth" -name "*kernel_trace.csv" | head -1)
+      [ -n "$f" ] && python "$R/tools/trace_tail.py" "$f" 40 > "$OUT/growth_trace_tail.csv" 2>/dev/null
+      find "$OUT/prof_growth" -name "*kernel_trace.csv" -delete 2>/dev/null ;;
     batch768)
       timeout 300 python tools/batch_bench.py --rows 1000000 --dims 768 --nq 256 1024 --reps 3 > "$OUT/batch768_bench.log" 2>&1; rc=$? ;;
     profdefault)
@@ -82,7 +103,11 @@ PYEOF
       find "$OUT/prof_probe" -name "*kernel_trace.csv" -exec sh -c 'head -1 "$1" > "$2"; grep "gemm" "$1" >> "$2"' _ {} "$OUT/probe_gemm_trace.csv" \; 2>/dev/null
       find "$OUT/prof_probe" -name "*kernel_trace.csv" -delete 2>/dev/null ;;
     gemmprobe)
-      timeout 600 python tools/gemm_probe.py > "$OUT/gemm_probe.log" 2>&1; rc=$? ;;
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d "$OUT/prof_probe" -o g -- \
+          python "$R/tools/gemm_probe.py" > "$OUT/gemm_probe.log" 2>&1); rc=$?
+      f=$(find "$OUT/prof_probe" -name "*kernel_trace.csv" | head -1)
+      [ -n "$f" ] && grep "rega_kernel" "$f" | python "$R/tools/trace_durations.py" > "$OUT/gemm_probe_durations.txt" 2>/dev/null
+      find "$OUT/prof_probe" -name "*kernel_trace.csv" -delete 2>/dev/null ;;
     sweep)
       timeout 1200 python tools/sweep.py --tag "$TAG" > "$OUT/sweep.log" 2>&1; rc=$?
       cp gpurun_out/sweep_$TAG.json "$OUT/" 2>/dev/null ;;

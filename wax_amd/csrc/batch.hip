@@ -337,6 +337,7 @@ typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
 typedef __attribute__((address_space(3))) unsigned int lds_u32;
 
 typedef __attribute__((address_space(3))) float lds_f32;
+typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
 
 // ---------------------------------------------------------------------------
 // Register-resident-queries GEMM (cosine / dot, D in {128, 256, 384, 512}; every slab after the first).
@@ -348,8 +349,27 @@ typedef __attribute__((address_space(3))) float lds_f32;
 // same B fragments (ds_read_b128, rows padded by 16 B => conflict-free), so per tile a SIMD issues
 // 2 waves x 48 MFMAs against 384 KB of LDS reads (50 % of the LDS pipe). At Q = 256 one pass over the
 // corpus is HBM-bound (48 KB per 3072 MFMA cycles per CU = 9.6 TB/s at MFMA peak).
-// Epilogue per tile: 32 compares against the lane's 16 thresholds, survivors staged in LDS and appended.
+// Epilogue per tile: 32 compares against the lane's 16 thresholds. A survivor takes a slot in THIS workgroup's
+// segment of its query's candidate row (slot index from an LDS counter, a plain 8-byte global store) — no
+// global atomics: with ~50 K survivors per slab funnelled through 256 counters in 8 cache lines, device-scope
+// atomics cost ~0.9 us per thousand survivors (a 16 K-row slab took 120 us, profiles/r01/y_growth_trace_tail.csv).
+//
+// Staging, GLDS = false: global -> VGPRs (issued at the top of an iteration) -> ds_write at its end, two LDS tiles.
+// Staging, GLDS = true: LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass). The DMA writes
+// 64 lanes x 16 B contiguously, so the padded tile image (row stride D*2 + 16) is cut into 1-KB pieces and each lane
+// FETCHES whatever belongs at its slot (the pad slot of a row re-fetches the row's last segment). With three
+// tiles in LDS (D <= 384) a tile is requested two iterations before it is read: the wait at the end of an
+// iteration is a counted vmcnt that leaves the newest tile in flight across the (raw) barrier.
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void global_cvoid;
+
+template <int N>
+__device__ inline void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 template <int D>
+constexpr int rega_lds_tiles(bool glds) { return (glds && 3 * 64 * (D * 2 + 16) + 3072 <= 160 * 1024) ? 3 : 2; }
+
+template <int D, bool GLDS, int AHEAD>
 __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uint32_t blocks_per_group) {
     constexpr int KS = D / 16;                       // MFMA k-steps
     constexpr int ROW_B = D * 2 + 16;                // LDS row stride (bytes)
@@ -358,13 +378,18 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
     constexpr int SEGS = TROWS * SEG_PER_ROW;        // 16-byte segments per tile
     constexpr int LOADS = SEG_PER_ROW / 8;           // per thread (8 threads per row, 64 rows)
     constexpr int BUF_B = TROWS * ROW_B;
-    constexpr unsigned LIST_CAP = 2048;              // survivors a workgroup can hold before its single flush
+    constexpr int NBUF = rega_lds_tiles<D>(GLDS);
+    constexpr int PRE = NBUF - 1;                    // GLDS: tiles requested ahead of the one being read
+    constexpr int SLOTS_PER_ROW = ROW_B / 16;        // 16-byte slots per padded row; == 1-KB pieces per tile (64 rows)
+    constexpr int PIECES = SLOTS_PER_ROW;
+    constexpr int PPW = (PIECES + 7) / 8;            // pieces per wave (waves with index >= PIECES % 8 carry one less)
     static_assert(SEGS == 512 * LOADS && D % 64 == 0, "tile must split evenly over 512 threads");
+    static_assert(BUF_B == PIECES * 1024, "a padded tile is a whole number of 1-KB DMA pieces");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* buf0 = smem;
-    u32x4* blist = reinterpret_cast<u32x4*>(smem + 2 * BUF_B);
-    float* tau_s = reinterpret_cast<float*>(smem + 2 * BUF_B + LIST_CAP * 16);          // [8][32] exact thresholds
-    unsigned int* blist_count = reinterpret_cast<unsigned int*>(tau_s + 8 * 32);
+    float* tau_s = reinterpret_cast<float*>(smem + NBUF * BUF_B);              // [8][32] exact thresholds
+    unsigned int* cnt_s = reinterpret_cast<unsigned int*>(tau_s + 8 * 32);     // [8][32] survivors per query (this workgroup)
+    float* sim_s = reinterpret_cast<float*>(cnt_s + 8 * 32);                   // [8][32] conservative similarity bounds
 
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
@@ -380,162 +405,298 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) fa[ks] = __builtin_bit_cast(bf16x8, qp[ks * 2]);
     }
-    if (lane < 32) tau_s[wave * 32 + lane] = a.tau[q0 + lane];
-    if (tid == 0) *blist_count = 0u;
-    for (unsigned i = (unsigned)tid; i < LIST_CAP; i += 512u) blist[i] = u32x4{0u, 0u, 0u, 0u};
+    if (lane < 32) {
+        const float tq = a.tau[q0 + lane];
+        tau_s[wave * 32 + lane] = tq;
+        // fl(1 - acc) <= tq implies acc >= (1 - tq) - 2^-23 (|1 - tq| + |tq|); 4e-7 (1 + |tq|) covers it with slack.
+        // tq = +inf (no threshold yet) gives -inf: everything is flagged; tq = -inf (padding query) gives NaN: nothing is.
+        sim_s[wave * 32 + lane] = (1.0f - tq) - 4e-7f * (1.0f + __builtin_fabsf(tq));
+    }
+    if (tid < 256) cnt_s[tid] = 0u;
+    // this workgroup's segment of every query's candidate row
+    const uint32_t seg_slots = a.seg_area / blocks_per_group;
+    // element offset (32-bit: rows * cand_cap < 2^23) of this lane's first query row, at this workgroup's segment;
+    // kept as ONE VGPR + per-query scalar multiples — 16 hoisted 64-bit row pointers would spill
+    const uint32_t seg_lane0 = (q0 + 4u * ((uint32_t)lane >> 5)) * a.cand_cap + a.seg_base + bidx * seg_slots;
 
     const uint32_t ntiles = (a.slab_rows + TROWS - 1) / TROWS;
     const uint32_t slab_end = a.slab0 + a.slab_rows;
     const unsigned char* cbase = reinterpret_cast<const unsigned char*>(a.cb);
 
-    // staging map: 8 threads per tile row; a thread moves the 16-byte segments (tid & 7) + 8*p of its row,
-    // so every global / LDS address is one per-tile base plus a compile-time offset (no address arrays).
+    // register staging map: 8 threads per tile row; a thread moves the 16-byte segments (tid & 7) + 8*p of its
+    // row, so every global / LDS address is one per-tile base plus a compile-time offset (no address arrays).
     const uint32_t srow = (uint32_t)tid >> 3;
     const uint32_t sseg = ((uint32_t)tid & 7u) * 16u;
-    u32x4 regs[LOADS];
+    u32x4 regs[GLDS ? 1 : LOADS];
     auto issue_loads = [&](uint32_t tile) {
         uint32_t grow = a.slab0 + tile * TROWS + srow;
         grow = grow < a.n_rows ? grow : a.n_rows - 1;        // clamp: masked in the epilogue
         const unsigned char* src = cbase + (size_t)grow * (D * 2) + sseg;
 #pragma unroll
-        for (int p = 0; p < LOADS; ++p) regs[p] = *reinterpret_cast<const u32x4*>(src + p * 128);
+        for (int p = 0; p < (GLDS ? 0 : LOADS); ++p) regs[p] = *reinterpret_cast<const u32x4*>(src + p * 128);
     };
     auto store_tile = [&](unsigned char* buf) {
         unsigned char* dst = buf + srow * ROW_B + sseg;
 #pragma unroll
-        for (int p = 0; p < LOADS; ++p) *reinterpret_cast<u32x4*>(dst + p * 128) = regs[p];
+        for (int p = 0; p < (GLDS ? 0 : LOADS); ++p) *reinterpret_cast<u32x4*>(dst + p * 128) = regs[p];
+    };
+    // LDS-DMA map: wave w moves pieces w, w + 8, ...; lane l of piece P fills slot P*64 + l of the padded image
+    uint32_t prow[PPW], pcol[PPW];
+    int my_pieces = 0;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const uint32_t P = (uint32_t)wave + 8u * i;
+        const uint32_t slot = P * 64u + (uint32_t)lane;
+        const uint32_t r = slot / SLOTS_PER_ROW;
+        uint32_t c = slot - r * SLOTS_PER_ROW;
+        c = c < (uint32_t)SEG_PER_ROW ? c : (uint32_t)SEG_PER_ROW - 1u;   // pad slot: any valid bytes
+        prow[i] = r;
+        pcol[i] = c * 16u;
+        if (P < (uint32_t)PIECES) ++my_pieces;
+    }
+    const bool full_wave = my_pieces == PPW;                 // wave-uniform
+    auto dma_tile = [&](uint32_t tile, uint32_t buf_off) {
+        const uint32_t row0 = a.slab0 + tile * TROWS;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const uint32_t P = (uint32_t)wave + 8u * i;
+            if (i < PPW - 1 || full_wave) {
+                uint32_t grow = row0 + prow[i];
+                grow = grow < a.n_rows ? grow : a.n_rows - 1;
+                const unsigned char* src = cbase + (size_t)grow * (D * 2) + pcol[i];
+                __builtin_amdgcn_global_load_lds((global_cvoid*)src, (lds_void*)(smem + buf_off + P * 1024u), 16, 0, 0);
+            }
+        }
+    };
+    // this wave's DMA requests still allowed in flight: `keep_tiles` whole tiles (0 or 1)
+    auto dma_wait = [&](bool keep_one_tile) {
+        if (!keep_one_tile) wait_vmcnt<0>();
+        else if (full_wave) wait_vmcnt<PPW>();
+        else wait_vmcnt<PPW - 1>();
     };
 
     uint32_t t = bidx;
-    if (t < ntiles) {
-        issue_loads(t);
-        store_tile(buf0);
+    if (GLDS) {
+        bool second = false;
+        if (t < ntiles) dma_tile(t, 0u);
+        if (PRE == 2 && t + blocks_per_group < ntiles) { dma_tile(t + blocks_per_group, (uint32_t)BUF_B); second = true; }
+        dma_wait(second);
+        __builtin_amdgcn_s_barrier();                         // also publishes tau_s / cnt_s
+        asm volatile("" ::: "memory");
+    } else {
+        if (t < ntiles) {
+            issue_loads(t);
+            store_tile(buf0);
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    for (uint32_t it = 0; t < ntiles; t += blocks_per_group, ++it) {
-        unsigned char* cur = buf0 + (((a.debug & 1u) ? 0u : (it & 1u)) * BUF_B);  // debug bit0: always the prologue tile
-        unsigned char* nxt = buf0 + ((it & 1) ^ 1) * BUF_B;
-        const uint32_t tn = t + blocks_per_group;
-        const bool dbg_noload = (a.debug & 1u) != 0, dbg_nomfma = (a.debug & 2u) != 0;  // timing experiments only
-        if (tn < ntiles && !dbg_noload) issue_loads(tn);
+    // The two waves that share a SIMD (w and w + 4: a workgroup's waves are dealt to the SIMDs cyclically) do
+    // the same work per tile in OPPOSITE order. Waves 0-3 run MFMAs(t) then select(t); waves 4-7 run
+    // select(t - 1) — on accumulators carried over from the previous iteration — then MFMAs(t). While one wave
+    // of a SIMD is in its VALU/LDS-only selection the other has the matrix pipe to itself, so the selection
+    // (~25 % of a tile's issue slots) hides under MFMAs instead of idling the pipe for both waves at once.
+    const bool late = wave >= 4 && !(a.debug & 16u);   // debug bit4: every wave in the same order
+    const bool dbg_noload = (a.debug & 1u) != 0, dbg_nomfma = (a.debug & 2u) != 0;  // timing experiments only
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
 
-        f32x16 acc0, acc1;
+    // K loop, software-pipelined in the source: the B fragments of k-step ks + AHEAD are read (2 ds_read_b128)
+    // before the two MFMAs of k-step ks issue, and a sched_barrier pins every step, so the wait in front of an
+    // MFMA is a counted lgkmcnt(2 * AHEAD) on reads issued AHEAD steps earlier — never on the reads just issued.
+    // (Left alone, hipcc hoists all 2*KS reads above the MFMAs: 192 VGPRs at D = 384, spilling the A fragments;
+    // with sched_group_barrier "2 DS, 2 MFMA" groups it emitted `ds_read x2; s_waitcnt lgkmcnt(0); mfma`, i.e. one
+    // exposed LDS round trip per k-step and a matrix pipe ~50 % idle.)
+    auto mfma_tile = [&](const unsigned char* cur) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+        if (dbg_nomfma) return;
         const unsigned char* b0 = cur + (lane & 31) * ROW_B + (lane >> 5) * 16;
         const unsigned char* b1 = b0 + 32 * ROW_B;
-        if (!dbg_nomfma)
+        constexpr int RING = AHEAD + 1;
+        u32x4 fb0[RING], fb1[RING];
+#pragma unroll
+        for (int i = 0; i < AHEAD && i < KS; ++i) {
+            fb0[i] = *reinterpret_cast<const u32x4*>(b0 + i * 32);
+            fb1[i] = *reinterpret_cast<const u32x4*>(b1 + i * 32);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 fb0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(b0 + ks * 32));
-            const bf16x8 fb1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(b1 + ks * 32));
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], fb0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], fb1, acc1, 0, 0, 0);
-        }
-        // Software pipeline of the K loop, spelled out for the scheduler: B fragments are read AHEAD k-steps
-        // before the MFMAs that consume them (2 ds_read_b128 + 2 MFMA per k-step), so an MFMA never waits
-        // on the LDS read issued just before it, and at most AHEAD+1 k-steps of fragments are live (left
-        // alone, hipcc hoists all 2*KS reads above the MFMAs: 192 VGPRs at D = 384, spilling the A fragments).
-        {
-            constexpr int AHEAD = 2;
-#pragma unroll
-            for (int i = 0; i < AHEAD; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS read
-#pragma unroll
-            for (int ks = 0; ks < KS - AHEAD; ++ks) {
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                // MFMA
+            if (ks + AHEAD < KS) {
+                fb0[(ks + AHEAD) % RING] = *reinterpret_cast<const u32x4*>(b0 + (ks + AHEAD) * 32);
+                fb1[(ks + AHEAD) % RING] = *reinterpret_cast<const u32x4*>(b1 + (ks + AHEAD) * 32);
             }
-#pragma unroll
-            for (int i = 0; i < AHEAD; ++i) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], __builtin_bit_cast(bf16x8, fb0[ks % RING]), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], __builtin_bit_cast(bf16x8, fb1[ks % RING]), acc1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
+    };
 
-        // fused selection: C[query][row], col = lane & 31 = corpus row, reg r = query (r&3)+8(r>>2)+4(lane>>5)
-        const uint32_t row0 = a.slab0 + t * TROWS + (lane & 31);
+    // Fused selection on the accumulators of `tile`: C[query][row], col = lane & 31 = corpus row,
+    // reg r = query qo(r) = (r&3) + 8(r>>2) + 4(lane>>5).
+    // Fast path, every tile: 32 compares of the accumulators (similarities) against the lane's 16 thresholds,
+    // OR-ed into four wave-level flags (one per group of four queries) — no branches, one LDS round trip. (Reading each threshold from LDS next to
+    // its compare cost 16 exposed LDS round trips per tile, ~25 % of the kernel: profiles/r01/ae_gemm_probe.txt.)
+    // sim_s[q] = (1 - tau) - 4e-7 (1 + |tau|) is a conservative similarity bound: whatever passes
+    // the exact test `1 - acc <= tau` below also passes `acc >= sim_lo`, so the mask is a superset.
+    // Slow path (a wave-tile holds ~0.8 survivors at Q = 256, k' = 64): groups of four queries are re-examined
+    // only if some lane flagged them; the group re-tests exactly (`1 - acc <= tau`, tau from LDS) and a survivor
+    // takes a slot in this workgroup's segment of the query's candidate row.
+    auto select_tile = [&](uint32_t tile) {
+        if (a.debug & 8u) return;
+        // the lane's 16 bounds are four aligned float4 in LDS (queries 8j + 4(lane>>5) .. +3 for r = 4j .. 4j+3):
+        // one batch of ds_read_b128 and ONE wait per tile; they are live only here, after the B-fragment ring died
+        const lds_f32x4* sim_w = (const lds_f32x4*)(sim_s + wave * 32 + 4 * (lane >> 5));
+        f32x4 lo[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lo[j] = sim_w[2 * j];
+        // wave-level flags per group of four queries: v_cmp into an SGPR pair + s_or_b64 (1 VALU + 1 SALU per element)
+        unsigned long long hit[4] = {0ull, 0ull, 0ull, 0ull};
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            hit[r >> 2] |= __ballot(acc0[r] >= lo[r >> 2][r & 3]) | __ballot(acc1[r] >= lo[r >> 2][r & 3]);   // NaN fails
+        if ((hit[0] | hit[1] | hit[2] | hit[3]) == 0ull) return;
+        const uint32_t row0 = a.slab0 + tile * TROWS + (lane & 31);
         const uint32_t row1 = row0 + 32;
         const bool ok0 = row0 < slab_end, ok1 = row1 < slab_end;
-        // Fused selection, fully inline: 16 exact thresholds from LDS (two distinct addresses per read:
-        // the two half-waves), 32 compares; a survivor (~0.8 per wave-tile at Q = 256, k' = 64 — this is the
-        // COMMON case, so no call, no scratch, no global memory) is pushed onto the workgroup's LDS list.
-        if (!(a.debug & 8u)) {
-            const lds_f32* tau_w = (const lds_f32*)(tau_s + wave * 32);
-            lds_u32x4* bl = (lds_u32x4*)blist;
-            lds_u32* bc = (lds_u32*)blist_count;
+        const lds_f32* tau_w = (const lds_f32*)(tau_s + wave * 32);
+        lds_u32* cnt_w = (lds_u32*)(cnt_s + wave * 32);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                // one accumulator pair at a time: without the fence hipcc hoists all 16 threshold reads and 32
-                // distances (and their keys) to the top and spills the A fragments
-                if (r & 1) __builtin_amdgcn_sched_barrier(0);
+        for (int g = 0; g < 4; ++g) {
+            if (hit[g] == 0ull) continue;
+            const f32x4 tau4 = *(const lds_f32x4*)(tau_w + 8 * g + 4 * (lane >> 5));   // exact thresholds of the group
+#pragma unroll
+            for (int r = 4 * g; r < 4 * g + 4; ++r) {
                 const int qo = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const float tqr = tau_w[qo];
+                const float tqr = tau4[r & 3];
                 const float d0 = (1.0f - acc0[r]) + 0.0f, d1 = (1.0f - acc1[r]) + 0.0f;
-                const bool p0 = ok0 && d0 <= tqr, p1 = ok1 && d1 <= tqr;   // NaN fails
-                if (__any(p0 || p1)) {
-                    if (p0 || p1) {
-                        const uint32_t q = q0 + (uint32_t)qo;
-                        const unsigned n = (p0 ? 1u : 0u) + (p1 ? 1u : 0u);
-                        unsigned off = __hip_atomic_fetch_add(bc, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        const bool fits = off + n <= LIST_CAP;
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            if (j ? p1 : p0) {
-                                const int64_t key = make_key(j ? d1 : d0, a.row_base + (j ? row1 : row0));
-                                if (fits) {
-                                    u32x4 e;
-                                    e.x = (unsigned)((unsigned long long)key & 0xffffffffull);
-                                    e.y = (unsigned)((unsigned long long)key >> 32);
-                                    e.z = q;
-                                    e.w = 1u;  // written marker: a lane whose range straddles the capacity writes nothing
-                                    bl[off++] = e;
-                                } else if (q < a.nq) {  // list full (very loose threshold): direct global append
-                                    const uint32_t pos = atomicAdd(&a.cand_count[q], 1u);
-                                    if (pos < a.cand_cap) a.cand[(size_t)q * a.cand_cap + pos] = key;
-                                }
-                            }
-                        }
+                const bool p0 = ok0 && d0 <= tqr, p1 = ok1 && d1 <= tqr;
+                if (p0 || p1) {
+                    // slot in this workgroup's segment of the query's row: one LDS atomic, plain global stores
+                    const unsigned n = (p0 ? 1u : 0u) + (p1 ? 1u : 0u);
+                    unsigned off;
+                    if (GLDS) {
+                        // opaque to hipcc on purpose: before an LDS write it can see, the compiler drains every
+                        // outstanding LDS-DMA request (s_waitcnt vmcnt(0)) — here once per tile, undoing the prefetch
+                        asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
+                                     : "=v"(off)
+                                     : "v"((unsigned)(size_t)(cnt_w + qo)), "v"(n)
+                                     : "memory");
+                    } else {
+                        off = __hip_atomic_fetch_add(cnt_w + qo, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
+                    const uint32_t e0 = seg_lane0 + (uint32_t)((r & 3) + 8 * (r >> 2)) * a.cand_cap;
+                    if (p0 && off < seg_slots) a.cand[e0 + off++] = make_key(d0, a.row_base + row0);
+                    if (p1 && off < seg_slots) a.cand[e0 + off] = make_key(d1, a.row_base + row1);
                 }
             }
         }
+    };
 
-        if (tn < ntiles && !dbg_noload) store_tile(nxt);
-        if (!(a.debug & 4u)) __syncthreads();  // debug bit2 (only with bit0): no per-tile barrier
-    }
-    // single flush of the workgroup's survivor list: all 512 lanes' global atomics in flight at once
-    __syncthreads();
-    const unsigned listed = *blist_count < LIST_CAP ? *blist_count : LIST_CAP;
-    for (unsigned i = (unsigned)tid; i < listed; i += 512u) {
-        const u32x4 e = blist[i];
-        const uint32_t q = e.z;
-        if (e.w != 0u && q < a.nq) {
-            const uint32_t pos = atomicAdd(&a.cand_count[q], 1u);
-            if (pos < a.cand_cap)
-                a.cand[(size_t)q * a.cand_cap + pos] = (int64_t)(((unsigned long long)e.y << 32) | (unsigned long long)e.x);
+    uint32_t it = 0;
+    uint32_t cur_idx = 0;                                     // GLDS: it % NBUF
+    for (; t < ntiles; t += blocks_per_group, ++it) {
+        unsigned char* cur;
+        unsigned char* nxt = buf0;
+        uint32_t tn;
+        bool issued = false;
+        if (GLDS) {
+            cur = buf0 + cur_idx * BUF_B;
+            tn = t + PRE * blocks_per_group;
+            uint32_t pre_idx = cur_idx + PRE;
+            pre_idx = pre_idx >= (uint32_t)NBUF ? pre_idx - NBUF : pre_idx;
+            if (tn < ntiles) { dma_tile(tn, pre_idx * BUF_B); issued = true; }
+        } else {
+            cur = buf0 + ((dbg_noload ? 0u : (it & 1u)) * BUF_B);  // debug bit0: always the prologue tile
+            nxt = buf0 + ((it & 1) ^ 1) * BUF_B;
+            tn = t + blocks_per_group;
+            if (tn < ntiles && !dbg_noload) issue_loads(tn);
+        }
+        if (late) {
+            if (it > 0) select_tile(t - blocks_per_group);
+            mfma_tile(cur);
+        } else {
+            mfma_tile(cur);
+            select_tile(t);
+        }
+        if (GLDS) {
+            // tile t + 1 must have landed (every wave waits for its own pieces, the barrier joins them); with
+            // three tiles in LDS the one requested in this iteration stays in flight across the barrier
+            dma_wait(PRE == 2 && issued);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            cur_idx = cur_idx + 1 == (uint32_t)NBUF ? 0u : cur_idx + 1;
+        } else {
+            if (tn < ntiles && !dbg_noload) store_tile(nxt);
+            if (!(a.debug & 4u)) __syncthreads();  // debug bit2 (only with bit0): no per-tile barrier
         }
     }
+    if (late && it > 0) select_tile(t - blocks_per_group);
+    // unclamped counts: a count above seg_slots tells tighten_kernel that survivors were dropped (query -> exact path)
+    __syncthreads();
+    if (tid < 256) a.seg_count[(size_t)bidx * (a.nqt * 128u) + group * 256u + (uint32_t)tid] = cnt_s[tid];
 }
 
-template <int D>
-static hipError_t launch_rega(const GemmArgs& a, hipStream_t st) {
-    constexpr size_t smem = 2 * 64 * (D * 2 + 16) + 2048 * 16 + 8 * 32 * 4 + 64;
+static void rega_geometry(const GemmArgs& a, uint32_t* groups, uint32_t* per_group) {
+    *groups = (a.nqt * 128 + 255) / 256;
+    const uint32_t ntiles = (a.slab_rows + 63) / 64;
+    uint32_t pg = 256 / *groups;                // one persistent workgroup per CU in total
+    if (pg < 1) pg = 1;
+    if (pg > ntiles) pg = ntiles;
+    *per_group = pg;
+}
+
+static bool rega_eligible(const GemmArgs& a, int metric) {
+    return a.dense == nullptr && a.use_rega && metric != BM_L2 &&
+           (a.dims == 128 || a.dims == 256 || a.dims == 384 || a.dims == 512);
+}
+
+bool batch_gemm_segments(const GemmArgs& a, int metric, uint32_t* nseg, uint32_t* seg_slots) {
+    if (!rega_eligible(a, metric)) return false;
+    uint32_t groups, per_group;
+    rega_geometry(a, &groups, &per_group);
+    *nseg = per_group;
+    *seg_slots = a.seg_area / per_group;
+    return true;
+}
+
+template <int D, bool GLDS, int AHEAD>
+static hipError_t launch_rega_impl(const GemmArgs& a, hipStream_t st) {
+    constexpr size_t smem = (size_t)rega_lds_tiles<D>(GLDS) * 64 * (D * 2 + 16) + 3 * 8 * 32 * 4;  // tiles, thresholds, survivor counters, bounds
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&batch_gemm_rega_kernel<D>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&batch_gemm_rega_kernel<D, GLDS, AHEAD>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
         configured = true;
     }
-    const uint32_t groups = (a.nqt * 128 + 255) / 256;
-    const uint32_t ntiles = (a.slab_rows + 63) / 64;
-    uint32_t per_group = 256 / groups;          // one persistent workgroup per CU in total
-    if (per_group < 1) per_group = 1;
-    if (per_group > ntiles) per_group = ntiles;
-    hipLaunchKernelGGL((batch_gemm_rega_kernel<D>), dim3(groups * per_group), dim3(512), smem, st, a, per_group);
+    uint32_t groups, per_group;
+    rega_geometry(a, &groups, &per_group);
+    hipLaunchKernelGGL((batch_gemm_rega_kernel<D, GLDS, AHEAD>), dim3(groups * per_group), dim3(512), smem, st, a, per_group);
     return hipGetLastError();
+}
+
+template <int D>
+static hipError_t launch_rega(const GemmArgs& a, hipStream_t st) {
+    // B-fragment read-ahead: as deep as the 256-VGPR budget allows next to the D/4 VGPRs of A fragments
+    constexpr int AHEAD = D >= 512 ? 1 : 3;
+    if (a.use_rega == 2u) {
+        if constexpr (D < 512) {
+            switch ((a.debug >> 8) & 3u) {   // timing experiments: read-ahead depth
+                case 1: return launch_rega_impl<D, true, 2>(a, st);
+                case 2: return launch_rega_impl<D, true, 4>(a, st);
+                default: break;
+            }
+        }
+        return launch_rega_impl<D, true, AHEAD>(a, st);
+    }
+    return launch_rega_impl<D, false, AHEAD>(a, st);
 }
 
 hipError_t launch_batch_gemm(const GemmArgs& a, int metric, hipStream_t st) {
     // fast path: queries resident in registers (needs the query block padded to a multiple of 256 rows)
-    if (a.dense == nullptr && a.use_rega && metric != BM_L2) {
+    if (rega_eligible(a, metric)) {
         switch (a.dims) {
             case 128: return launch_rega<128>(a, st);
             case 256: return launch_rega<256>(a, st);
@@ -560,24 +721,23 @@ hipError_t launch_batch_gemm(const GemmArgs& a, int metric, hipStream_t st) {
 // of the list), reset the count, tighten tau. A list that overflowed its capacity marks the query
 // (it will be answered by the exact path).
 template <int CAP>
-__global__ __launch_bounds__(SCAN_THREADS) void tighten_kernel(int64_t* __restrict__ cand, uint32_t cand_cap,
-                                                              uint32_t* __restrict__ cand_count, int kp,
-                                                              float* __restrict__ tau, uint32_t* __restrict__ overflow,
-                                                              const float* __restrict__ dense, uint32_t dense_ld,
-                                                              uint32_t dense_rows, uint32_t dense_row0) {
+__global__ __launch_bounds__(SCAN_THREADS) void tighten_kernel(TightenArgs a) {
     __shared__ int64_t lds[SCAN_WAVES * CAP + SCAN_WAVES + FUSED_MAX_K];
     int* counts = reinterpret_cast<int*>(lds + SCAN_WAVES * CAP);
     int64_t* fin = lds + SCAN_WAVES * CAP + SCAN_WAVES;
     const int lane = lane_id();
     const int wave = (int)(threadIdx.x >> 6);
     const uint32_t q = blockIdx.x;
-    uint32_t n_in = (dense != nullptr) ? dense_rows : cand_count[q];
-    if (dense == nullptr && n_in > cand_cap) {
-        if (threadIdx.x == 0) overflow[q] = 1u;
-        n_in = cand_cap;
+    const int kp = a.kp;
+    uint32_t n_in = (a.dense != nullptr) ? a.dense_rows : a.cand_count[q];   // dense tile / counted list (incl. the best list)
+    bool dropped = false;
+    if (a.dense == nullptr && n_in > a.cand_cap) {
+        dropped = true;
+        n_in = a.cand_cap;
     }
-    int64_t* __restrict__ mine = cand + (size_t)q * cand_cap;
-    const float* __restrict__ drow = (dense != nullptr) ? dense + (size_t)q * dense_ld : nullptr;
+    if (a.nseg != 0u && n_in > a.seg_base) n_in = a.seg_base;                 // segmented: [0, n_in) is the best list only
+    int64_t* __restrict__ mine = a.cand + (size_t)q * a.cand_cap;
+    const float* __restrict__ drow = (a.dense != nullptr) ? a.dense + (size_t)q * a.dense_ld : nullptr;
     WaveTopK<CAP> tk;
     tk.init(lds + wave * CAP, kp);
     constexpr int LOADS = 4;
@@ -587,35 +747,53 @@ __global__ __launch_bounds__(SCAN_THREADS) void tighten_kernel(int64_t* __restri
         for (int i = 0; i < LOADS; ++i) {
             const uint32_t idx = base + i * SCAN_THREADS + threadIdx.x;
             if (idx >= n_in) keys[i] = KEY_PAD;
-            else if (drow != nullptr) keys[i] = make_key(drow[idx], dense_row0 + idx);  // first slab: dense tile
+            else if (drow != nullptr) keys[i] = make_key(drow[idx], a.dense_row0 + idx);  // first slab: dense tile
             else keys[i] = mine[idx];
         }
 #pragma unroll
         for (int i = 0; i < LOADS; ++i) tk.push_wide(keys[i], keys[i] != KEY_PAD);
     }
+    // segmented survivors: thread t walks segments t, t + 256, ... (one GEMM workgroup each)
+    for (uint32_t sb = 0; sb < a.nseg; sb += SCAN_THREADS) {
+        const uint32_t seg = sb + threadIdx.x;
+        uint32_t c = (seg < a.nseg) ? a.seg_count[(size_t)seg * a.nq_pad + q] : 0u;
+        if (c > a.seg_slots) {
+            dropped = true;
+            c = a.seg_slots;
+        }
+        const int64_t* __restrict__ sp = mine + a.seg_base + (size_t)seg * a.seg_slots;
+        // 8 slots per trip, loads independent: a segment is one or two cache lines written by another XCD's
+        // workgroup, so every dependent trip is an HBM round trip
+        constexpr uint32_t SLOTS = 8;
+        for (uint32_t j0 = 0; __any(j0 < c); j0 += SLOTS) {
+            int64_t key[SLOTS];
+#pragma unroll
+            for (uint32_t u = 0; u < SLOTS; ++u) key[u] = (j0 + u < c) ? sp[j0 + u] : KEY_PAD;
+#pragma unroll
+            for (uint32_t u = 0; u < SLOTS; ++u) tk.push_wide(key[u], j0 + u < c);
+        }
+    }
     tk.finalize();
     if (lane == 0) counts[wave] = tk.cnt;
+    if (__any(dropped) && lane == 0) a.overflow[q] = 1u;
     __syncthreads();
     block_rank_merge<SCAN_WAVES>(lds, CAP, counts, kp, fin);
     __syncthreads();   // all reads of the old list happened before the first barrier
     for (int t = (int)threadIdx.x; t < kp; t += SCAN_THREADS) mine[t] = fin[t];
     if (threadIdx.x == 0) {
-        const uint32_t kept = n_in < (uint32_t)kp ? n_in : (uint32_t)kp;
-        cand_count[q] = kept;
+        int total = 0;
+        for (int w = 0; w < SCAN_WAVES; ++w) total += counts[w];
+        a.cand_count[q] = (uint32_t)(total < kp ? total : kp);
         const int64_t last = fin[kp - 1];
-        tau[q] = (last == KEY_PAD) ? __builtin_inff() : key_distance(last);
+        a.tau[q] = (last == KEY_PAD) ? __builtin_inff() : key_distance(last);
     }
 }
 
-hipError_t launch_tighten(int64_t* cand, uint32_t cand_cap, uint32_t* cand_count, int kp, uint32_t nq, float* tau,
-                          uint32_t* overflow, const float* dense, uint32_t dense_ld, uint32_t dense_rows,
-                          uint32_t dense_row0, hipStream_t st) {
-    if (kp <= 32)
-        hipLaunchKernelGGL((tighten_kernel<128>), dim3(nq), dim3(SCAN_THREADS), 0, st, cand, cand_cap, cand_count, kp, tau,
-                           overflow, dense, dense_ld, dense_rows, dense_row0);
+hipError_t launch_tighten(const TightenArgs& a, hipStream_t st) {
+    if (a.kp <= 32)
+        hipLaunchKernelGGL((tighten_kernel<128>), dim3(a.nq), dim3(SCAN_THREADS), 0, st, a);
     else
-        hipLaunchKernelGGL((tighten_kernel<256>), dim3(nq), dim3(SCAN_THREADS), 0, st, cand, cand_cap, cand_count, kp, tau,
-                           overflow, dense, dense_ld, dense_rows, dense_row0);
+        hipLaunchKernelGGL((tighten_kernel<256>), dim3(a.nq), dim3(SCAN_THREADS), 0, st, a);
     return hipGetLastError();
 }
 

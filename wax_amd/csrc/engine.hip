@@ -223,6 +223,7 @@ struct BatchWork {
     uint32_t* d_cand_count = nullptr;
     uint32_t* d_overflow = nullptr;
     int64_t* d_cand = nullptr;       // [kBatchMaxQ][kBatchCandCap]
+    uint32_t* d_seg_count = nullptr; // [kBatchMaxSegs][kBatchMaxQ] survivors per (GEMM workgroup, query)
     int64_t* d_exact = nullptr;
     wax_hip_hit* d_hits = nullptr;
     uint32_t* d_cert = nullptr;
@@ -234,7 +235,10 @@ struct BatchWork {
 };
 
 constexpr uint32_t kBatchMaxQ = 1024;   // queries per GEMM pass
-constexpr uint32_t kBatchCandCap = 4096;  // appended candidates per query between two tighten passes
+constexpr uint32_t kBatchSegBase = FUSED_MAX_K;   // a candidate row: [0, kBatchSegBase) best list, then the survivor area
+constexpr uint32_t kBatchSegArea = 4096;          // survivors per query between two tighten passes
+constexpr uint32_t kBatchCandCap = kBatchSegBase + kBatchSegArea;
+constexpr uint32_t kBatchMaxSegs = 256;           // GEMM workgroups per 256-query group
 constexpr uint32_t kBatchFirstSlab = 2048;  // rows of the first slab (everything passes: tau = +inf)
 constexpr int kBatchMaxK = 80;          // largest k served by the MFMA path (k' = 2k+32 <= 192)
 
@@ -290,8 +294,9 @@ struct wax_hip_engine {
     std::atomic<int64_t> batch_min{16};      // fewer queries than this: pipelined single-query scans
     std::atomic<int64_t> batch_mode{1};      // 0 = never use the MFMA path
     std::atomic<int64_t> batch_slab_mb{64};  // cap on slab size, in units of 16 384 rows
+    std::atomic<int64_t> batch_growth{8};    // next slab = growth x rows seen so far
     std::atomic<int64_t> batch_debug{0};     // timing experiments only (GemmArgs::debug)
-    std::atomic<int64_t> batch_rega{1};      // 1: register-resident-queries GEMM where it applies
+    std::atomic<int64_t> batch_rega{1};      // register-resident-queries GEMM where it applies: 1 register staging, 2 LDS-DMA staging; 0 off
     std::atomic<uint64_t> st_batch_queries{0}, st_batch_fallbacks{0};
     BatchWork batch;
 
@@ -554,6 +559,7 @@ int batch_prepare(wax_hip_engine* e, hipStream_t st) {
         HIP_TRY(hipMalloc(&b.d_cand_count, kBatchMaxQ * sizeof(uint32_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch counters");
         HIP_TRY(hipMalloc(&b.d_overflow, kBatchMaxQ * sizeof(uint32_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch flags");
         HIP_TRY(hipMalloc(&b.d_cand, (size_t)kBatchMaxQ * kBatchCandCap * sizeof(int64_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch candidates");
+        HIP_TRY(hipMalloc(&b.d_seg_count, (size_t)kBatchMaxSegs * kBatchMaxQ * sizeof(uint32_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch segment counters");
         HIP_TRY(hipMalloc(&b.d_exact, (size_t)kBatchMaxQ * FUSED_MAX_K * sizeof(int64_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch candidates");
         HIP_TRY(hipMalloc(&b.d_hits, (size_t)kBatchMaxQ * kBatchMaxK * sizeof(wax_hip_hit)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch hits");
         HIP_TRY(hipMalloc(&b.d_cert, kBatchMaxQ * sizeof(uint32_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch flags");
@@ -628,7 +634,7 @@ int batch_search_mfma(wax_hip_engine* e, const float* queries, uint32_t nq, int 
         // kp * s / rows_seen candidates per query, so "next slab = 3 x rows seen" keeps every list ~3*kp long.
         uint32_t s0 = 0;
         while (s0 < n) {
-            uint64_t want = (s0 == 0) ? kBatchFirstSlab : 3ull * s0;
+            uint64_t want = (s0 == 0) ? kBatchFirstSlab : (uint64_t)e->batch_growth.load() * s0;
             if (want > max_slab) want = max_slab;
             want = (want + 127ull) & ~127ull;
             const uint32_t rows = (n - s0 < want) ? n - s0 : (uint32_t)want;
@@ -636,15 +642,21 @@ int batch_search_mfma(wax_hip_engine* e, const float* queries, uint32_t nq, int 
             g.qb = b.d_qb; g.cb = b.d_cb; g.q_n2 = b.d_qn2; g.v_n2 = b.d_vn2; g.tau = b.d_tau;
             g.cand = b.d_cand; g.cand_count = b.d_cand_count; g.cand_cap = kBatchCandCap; g.row_base = (uint32_t)e->row_base;
             g.dims = D; g.n_rows = n; g.slab0 = s0; g.slab_rows = rows; g.nq = qn; g.nqt = nq_pad / 128;
-            g.use_rega = e->batch_rega.load() != 0 ? 1u : 0u;
+            g.use_rega = (uint32_t)e->batch_rega.load();  // 0 LDS-tiled kernel, 1 register staging, 2 LDS-DMA staging
             g.debug = (uint32_t)e->batch_debug.load();
             const bool first = (s0 == 0);  // no threshold yet: dense tile instead of appending everything
             g.dense = first ? b.d_dense : nullptr;
             g.dense_ld = kBatchFirstSlab;
+            g.seg_count = b.d_seg_count; g.seg_base = kBatchSegBase; g.seg_area = kBatchSegArea;
             HIP_TRY(launch_batch_gemm(g, e->metric, st), WAX_HIP_ERR_INTERNAL, "gemm kernel launch");
-            HIP_TRY(launch_tighten(b.d_cand, kBatchCandCap, b.d_cand_count, kp, qn, b.d_tau, b.d_overflow,
-                                   first ? b.d_dense : nullptr, kBatchFirstSlab, rows, (uint32_t)e->row_base + s0, st),
-                    WAX_HIP_ERR_INTERNAL, "tighten kernel launch");
+            TightenArgs t{};
+            t.cand = b.d_cand; t.cand_cap = kBatchCandCap; t.cand_count = b.d_cand_count; t.kp = kp; t.nq = qn;
+            t.tau = b.d_tau; t.overflow = b.d_overflow;
+            t.dense = first ? b.d_dense : nullptr; t.dense_ld = kBatchFirstSlab; t.dense_rows = rows;
+            t.dense_row0 = (uint32_t)e->row_base + s0;
+            t.seg_count = b.d_seg_count; t.seg_base = kBatchSegBase; t.nq_pad = nq_pad;
+            if (!batch_gemm_segments(g, e->metric, &t.nseg, &t.seg_slots)) { t.nseg = 0; t.seg_slots = 0; }
+            HIP_TRY(launch_tighten(t, st), WAX_HIP_ERR_INTERNAL, "tighten kernel launch");
             s0 += rows;
         }
         RescoreArgs r{};
@@ -724,6 +736,10 @@ int wax_hip_engine_create(uint8_t metric, uint32_t dims, int device_id, wax_hip_
     e->device = dev;
     e->metric = metric;
     e->dims = dims;
+    if (const char* v = std::getenv("WAX_HIP_BATCH_REGA")) {  // default of the "batch_rega" tunable (A/B runs of the whole test suite)
+        const long m = std::strtol(v, nullptr, 10);
+        if (m >= 0 && m <= 2) e->batch_rega = m;
+    }
     int rc = resize_store(e, WAX_HIP_INITIAL_RESERVE);  // :225-229
     if (rc == WAX_HIP_OK) {
         hipError_t err = hipMalloc(&e->d_sink, MAX_GRID_BLOCKS * sizeof(float));
@@ -774,7 +790,7 @@ void wax_hip_engine_destroy(wax_hip_engine* e) {
         BatchWork& b = e->batch;
         (void)hipFree(b.d_cb); (void)hipFree(b.d_vn2); (void)hipFree(b.d_maxnorm); (void)hipFree(b.d_q); (void)hipFree(b.d_qb);
         (void)hipFree(b.d_qn2); (void)hipFree(b.d_qnorm); (void)hipFree(b.d_eps); (void)hipFree(b.d_tau); (void)hipFree(b.d_dense);
-        (void)hipFree(b.d_cand_count); (void)hipFree(b.d_overflow); (void)hipFree(b.d_cand); (void)hipFree(b.d_exact); (void)hipFree(b.d_hits);
+        (void)hipFree(b.d_cand_count); (void)hipFree(b.d_overflow); (void)hipFree(b.d_cand); (void)hipFree(b.d_seg_count); (void)hipFree(b.d_exact); (void)hipFree(b.d_hits);
         (void)hipFree(b.d_cert); (void)hipHostFree(b.h_hits); (void)hipHostFree(b.h_cert); (void)hipHostFree(b.h_qnorm);
         (void)hipHostFree(b.h_eps);
     }
@@ -876,6 +892,42 @@ int wax_hip_add_batch_device(wax_hip_engine* e, const uint64_t* frame_ids, const
             WAX_HIP_ERR_INTERNAL, "frame id upload");
     e->count += n;
     return WAX_HIP_OK;
+}
+
+int wax_hip_apply_put_embeddings(wax_hip_engine* e, const uint8_t* payloads, uint64_t len, uint64_t* out_applied) {
+    if (out_applied) *out_applied = 0;
+    if (!e) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine is null");
+    if (len == 0) return WAX_HIP_OK;
+    if (!payloads) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "applyPutEmbeddings: null input");
+    constexpr uint64_t kHead = 1 + 8 + 4;  // opcode, frameId, dimension (WALEntryCodec.swift:39-42)
+    std::vector<uint64_t> ids;
+    std::vector<uint64_t> offs;  // byte offset of each record's f32 payload
+    uint64_t pos = 0;
+    while (pos < len) {
+        if (payloads[pos] != 0x04) {
+            char b[64];
+            snprintf(b, sizeof b, "unknown opcode 0x%02X at byte %llu", payloads[pos], (unsigned long long)pos);
+            return fail(WAX_HIP_ERR_BAD_SEGMENT, payloads[pos] >= 0x01 && payloads[pos] <= 0x03
+                                                     ? std::string("not a putEmbedding entry: ") + b : std::string(b));
+        }
+        if (len - pos < kHead) return fail(WAX_HIP_ERR_BAD_SEGMENT, "truncated putEmbedding header");
+        uint64_t id;
+        uint32_t dim;
+        memcpy(&id, payloads + pos + 1, 8);
+        memcpy(&dim, payloads + pos + 9, 4);
+        if (dim > WAX_HIP_MAX_DIMENSIONS) return fail(WAX_HIP_ERR_BAD_SEGMENT, "embedding dimension exceeds limit");  // :117-119
+        if (dim != e->dims) return fail(WAX_HIP_ERR_DIM_MISMATCH, dim_mismatch_msg(e->dims, dim));
+        const uint64_t bytes = (uint64_t)dim * 4;
+        if (len - pos - kHead < bytes) return fail(WAX_HIP_ERR_BAD_SEGMENT, "truncated putEmbedding vector");
+        ids.push_back(id);
+        offs.push_back(pos + kHead);
+        pos += kHead + bytes;
+    }
+    std::vector<float> rows((size_t)ids.size() * e->dims);
+    for (size_t i = 0; i < ids.size(); ++i) memcpy(rows.data() + i * e->dims, payloads + offs[i], (size_t)e->dims * 4);
+    const int rc = wax_hip_add_batch(e, ids.data(), rows.data(), ids.size(), e->dims);
+    if (rc == WAX_HIP_OK && out_applied) *out_applied = ids.size();
+    return rc;
 }
 
 int wax_hip_remove(wax_hip_engine* e, uint64_t frame_id) {
@@ -1330,6 +1382,7 @@ int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value) {
     else if (k == "batch_mode") e->batch_mode = value;
     else if (k == "batch_rega") e->batch_rega = value;
     else if (k == "batch_debug") e->batch_debug = value;
+    else if (k == "batch_growth") { if (value < 1 || value > 64) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_growth must be 1..64"); e->batch_growth = value; }
     else if (k == "batch_slab_mb") { if (value < 1 || value > 4096) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_slab_mb must be 1..4096"); e->batch_slab_mb = value; }
     else if (k == "streams") {
         if (value < 1 || value > kMaxStreams) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "streams must be 1..4");
@@ -1363,6 +1416,7 @@ int64_t wax_hip_get_tuning(wax_hip_engine* e, const char* key) {
     if (k == "batch_mode") return e->batch_mode.load();
     if (k == "batch_rega") return e->batch_rega.load();
     if (k == "batch_slab_mb") return e->batch_slab_mb.load();
+    if (k == "batch_growth") return e->batch_growth.load();
     if (k == "batch_queries") return (int64_t)e->st_batch_queries.load();
     if (k == "batch_fallbacks") return (int64_t)e->st_batch_fallbacks.load();
     if (k == "slots") return e->max_slots;

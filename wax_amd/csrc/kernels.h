@@ -87,8 +87,18 @@ struct GemmArgs {
     uint32_t nq;
     uint32_t nqt;               // nq_pad / 128
     uint32_t debug;             // timing experiments: bit0 skip corpus loads, bit1 skip MFMAs (results are garbage)
-    uint32_t use_rega;          // 1: queries padded to 256 rows and tau/qb sized accordingly => register-resident-queries kernel allowed
+    uint32_t use_rega;          // != 0: queries padded to 256 rows => register-resident-queries kernel allowed (1 register staging, 2 LDS-DMA staging)
+    // Register-resident kernel only: survivors go to per-(workgroup, query) segments, no global atomics.
+    // Query q's row of `cand` holds [0, seg_base) the best list and, from seg_base, `nseg` segments of `seg_slots`
+    // keys; workgroup b of a 256-query group writes its survivors for q into segment b and its (unclamped) count
+    // into seg_count[b * nq_pad + q].
+    uint32_t* seg_count;
+    uint32_t seg_base;
+    uint32_t seg_area;          // slots available after seg_base (nseg * seg_slots <= seg_area)
 };
+// Geometry the register-resident kernel will use for these arguments (false: the LDS-tiled kernel runs instead,
+// appending through cand_count).
+bool batch_gemm_segments(const GemmArgs& a, int metric, uint32_t* nseg, uint32_t* seg_slots);
 struct RescoreArgs {
     const float* store;
     const float* queries;       // [nq][dims] f32
@@ -101,9 +111,12 @@ struct RescoreArgs {
 hipError_t launch_mirror(const float* src, uint32_t n_rows, uint32_t n_rows_padded, uint32_t dims, int normalize,
                          unsigned short* dst, float* norm2, unsigned int* max_norm_bits, hipStream_t stream);
 hipError_t launch_batch_gemm(const GemmArgs& a, int metric, hipStream_t stream);
-hipError_t launch_tighten(int64_t* cand, uint32_t cand_cap, uint32_t* cand_count, int kp, uint32_t nq, float* tau,
-                          uint32_t* overflow, const float* dense, uint32_t dense_ld, uint32_t dense_rows,
-                          uint32_t dense_row0, hipStream_t stream);
+struct TightenArgs {
+    int64_t* cand; uint32_t cand_cap; uint32_t* cand_count; int kp; uint32_t nq; float* tau; uint32_t* overflow;
+    const float* dense; uint32_t dense_ld, dense_rows, dense_row0;      // first slab: dense score tile
+    const uint32_t* seg_count; uint32_t nseg, seg_slots, seg_base, nq_pad;  // nseg > 0: segmented survivors
+};
+hipError_t launch_tighten(const TightenArgs& a, hipStream_t stream);
 hipError_t launch_batch_reset(float* tau, uint32_t* cand_count, uint32_t* overflow, uint32_t nq, uint32_t nq_pad,
                               hipStream_t stream);
 hipError_t launch_rescore(const RescoreArgs& a, int metric, hipStream_t stream);

@@ -464,7 +464,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_hits_kernel(const wax_hip
     int64_t* fin = lds + MERGE_WAVES * CAP + MERGE_WAVES;
     const int lane = lane_id();
     const int wave = (int)(threadIdx.x >> 6);
-    WaveTopK<CAP> tk;
+    WaveTopK<CAP, false> tk;  // foreign keys: a misconfigured shard layout may offer a row twice
     tk.init(lds + wave * CAP, k);
     for (uint32_t base = wave * WAVE; base < n; base += MERGE_THREADS) {
         const uint32_t i = base + lane;

@@ -36,7 +36,11 @@ struct PruneOut {
 // lane, no inter-lane shuffles. Deliberately NOT inlined: it is cold code (a wave prunes a handful
 // of times per launch) and every inlined copy is ~3 KB of instructions that a single-workgroup
 // kernel pays for in instruction-cache misses (merge_keys_kernel: 5 500 lines of ISA, 20 us).
-template <int CAP>
+// UNIQUE: the caller guarantees that no key occurs twice (keys carry the global row in their low half, and every
+// internal producer offers a row once), so a rank is just the number of smaller keys: one 64-bit compare per pair
+// instead of three compares. Lists of foreign keys (gathered shard hits) use UNIQUE = false, which orders duplicates
+// by slot index. Slices of 64 slots beyond the live count are skipped (wave-uniform).
+template <int CAP, bool UNIQUE>
 __device__ __attribute__((noinline)) PruneOut wave_prune(lds_i64* buf, int cnt, int k) {
     constexpr int E = CAP / 64;
     wave_lds_fence();
@@ -57,12 +61,14 @@ __device__ __attribute__((noinline)) PruneOut wave_prune(lds_i64* buf, int cnt, 
 #pragma unroll
         for (int u = 0; u < 4; ++u) o[u] = buf[j + u];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
+        for (int e = 0; e < E; ++e) {
+            if (64 * e < live) {
                 const int idx = lane + 64 * e;
-                // total order even if a key were duplicated: ties broken by slot index
-                rank[e] += (o[u] < mine[e] || (o[u] == mine[e] && (j + u) < idx)) ? 1 : 0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (UNIQUE) rank[e] += (o[u] < mine[e]) ? 1 : 0;
+                    else rank[e] += (o[u] < mine[e] || (o[u] == mine[e] && (j + u) < idx)) ? 1 : 0;
+                }
             }
         }
     }
@@ -71,7 +77,8 @@ __device__ __attribute__((noinline)) PruneOut wave_prune(lds_i64* buf, int cnt, 
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int idx = lane + 64 * e;
-            rank[e] += (o < mine[e] || (o == mine[e] && j < idx)) ? 1 : 0;
+            if (UNIQUE) rank[e] += (o < mine[e]) ? 1 : 0;
+            else rank[e] += (o < mine[e] || (o == mine[e] && j < idx)) ? 1 : 0;
         }
     }
     wave_lds_fence();
@@ -90,7 +97,7 @@ __device__ __attribute__((noinline)) PruneOut wave_prune(lds_i64* buf, int cnt, 
 // Streaming k-smallest over int64 keys, private to one wave.
 //   CAP  : LDS slots (power of two, >= k + 64 so that one push of up to 64
 //          candidates always fits after a prune)
-template <int CAP>
+template <int CAP, bool UNIQUE = true>
 struct WaveTopK {
     static_assert(CAP % 64 == 0, "CAP must be a multiple of the wave size");
 
@@ -143,7 +150,7 @@ struct WaveTopK {
     }
 
     __device__ inline void prune() {
-        const PruneOut r = wave_prune<CAP>((lds_i64*)buf, cnt, k);
+        const PruneOut r = wave_prune<CAP, UNIQUE>((lds_i64*)buf, cnt, k);
         cnt = r.cnt;
         tau = r.tau;
     }

@@ -169,6 +169,26 @@ class HIPVectorEngine:
         raise_for_status(rc)
         self._dirty = True
 
+    def applyPutEmbeddings(self, payloads: bytes) -> int:  # noqa: N802
+        """Pending-embedding replay (UnifiedSearchEngineCache.swift:252-283): `payloads` is WAL putEmbedding entry
+        payloads back to back (WALEntryCodec.swift:39-54); validated as a whole, applied as one addBatch.
+        Returns the number of records applied."""
+        data = bytes(payloads)
+        applied = ctypes.c_uint64(0)
+        rc = self._lib.wax_hip_apply_put_embeddings(self._h, data, len(data), ctypes.byref(applied))
+        raise_for_status(rc)
+        if applied.value:
+            self._dirty = True
+        return int(applied.value)
+
+    @staticmethod
+    def encodePutEmbedding(frameId: int, vector) -> bytes:  # noqa: N802,N803
+        """WALEntryCodec.encode(.putEmbedding) (WALEntryCodec.swift:39-54): 0x04, u64 frameId, u32 dim, f32 LE."""
+        v = np.ascontiguousarray(vector, dtype="<f4").reshape(-1)
+        if v.size > 1_000_000:
+            raise EncodingError("embedding dimension exceeds limit")
+        return b"\x04" + int(frameId).to_bytes(8, "little") + int(v.size).to_bytes(4, "little") + v.tobytes()
+
     def remove(self, frameId: int) -> None:  # noqa: N803
         """remove(frameId:) (:423-444): order-preserving delete; unknown id is a no-op."""
         before = self.count
