@@ -82,6 +82,10 @@ def main():
                 ids, scores, valid = sharded.sharded_search_batch(eng, q, args.topk, world, args.exchange)
             sync()
             dt = (time.perf_counter() - t0) / args.reps
+            t1 = time.perf_counter()                       # the C-ABI call alone (no all-gather, no numpy decode)
+            for _ in range(args.reps):
+                eng.searchBatchHits(q, args.topk)
+            dt_call = (time.perf_counter() - t1) / args.reps
             if world > 1:
                 t = torch.tensor([dt], dtype=torch.float64, device=dev if args.exchange == "rccl" else "cpu")
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -89,7 +93,8 @@ def main():
             if rank == 0:
                 chk = hashlib.sha256(np.ascontiguousarray(ids).tobytes() + np.ascontiguousarray(scores).tobytes()).hexdigest()[:16]
                 print(json.dumps({"n_gpus": world, "rows": args.rows, "dims": args.dims, "nq": nq, "topk": args.topk,
-                                  "slab_mb": slab, "growth": eng.getTuning("batch_growth"), "debug": dbg, "rega": eng.getTuning("batch_rega"), "ms_per_batch": dt * 1e3, "qps": nq / dt,
+                                  "slab_mb": slab, "growth": eng.getTuning("batch_growth"), "debug": dbg, "rega": eng.getTuning("batch_rega"), "ms_per_batch": dt * 1e3, "ms_c_call": dt_call * 1e3, "qps_c_call": nq / dt_call,
+                                  "tflops_bf16_c_call": 2.0 * nq * (hi - lo) * args.dims / dt_call / 1e12, "qps": nq / dt,
                                   "tflops_bf16": 2.0 * nq * args.rows * args.dims / dt / 1e12,
                                   "fallbacks_rank0": eng.getTuning("batch_fallbacks") - fb0,
                                   "exchange": args.exchange if world > 1 else "none", "result_checksum": chk}), flush=True)

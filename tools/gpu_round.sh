@@ -38,7 +38,7 @@ for s in $STAGES; do
       python tools/pmc_summary.py "$OUT/prof_pmc" > "$OUT/pmc_summary.json" 2>> "$OUT/pmc.err"
       find "$OUT/prof_pmc" -name "*.csv" -size +2M -delete 2>/dev/null ;;
     batch)
-      timeout 900 python tools/batch_bench.py --nq 64 256 1024 --slab-mb 16 64 256 > "$OUT/batch_bench.log" 2>&1; rc=$? ;;
+      timeout 900 python tools/batch_bench.py --nq 64 256 1024 > "$OUT/batch_bench.log" 2>&1; rc=$? ;;
     growth)
       timeout 600 python tools/batch_bench.py --nq 256 1024 --growth 3 4 6 8 10 12 > "$OUT/growth_bench.log" 2>&1; rc=$? ;;
     tests_glds)
@@ -52,6 +52,8 @@ for s in $STAGES; do
       f=$(find "$OUT/prof_ahead" -name "*kernel_trace.csv" | head -1)
       [ -n "$f" ] && grep "rega_kernel" "$f" | python "$R/tools/trace_durations.py" > "$OUT/ahead_rega_durations.txt" 2>/dev/null
       find "$OUT/prof_ahead" -name "*kernel_trace.csv" -delete 2>/dev/null ;;
+    hosttrace)
+      WAX_HIP_BATCH_TRACE=1 timeout 300 python tools/batch_bench.py --nq 256 1024 --reps 3 > "$OUT/hosttrace.log" 2>&1; rc=$? ;;
     pingpong)
       timeout 600 python tools/batch_bench.py --nq 256 1024 --growth 8 --debug 0 16 0 16 > "$OUT/pingpong_bench.log" 2>&1; rc=$? ;;
     growthprof)
@@ -61,7 +63,7 @@ for s in $STAGES; do
       [ -n "$f" ] && python "$R/tools/trace_tail.py" "$f" 40 > "$OUT/growth_trace_tail.csv" 2>/dev/null
       find "$OUT/prof_growth" -name "*kernel_trace.csv" -delete 2>/dev/null ;;
     batch768)
-      timeout 300 python tools/batch_bench.py --rows 1000000 --dims 768 --nq 256 1024 --reps 3 > "$OUT/batch768_bench.log" 2>&1; rc=$? ;;
+      timeout 300 python tools/batch_bench.py --rows 1000000 --dims 768 --nq 256 1024 --reps 3 --growth ${WAX_GROWTHS:-0} > "$OUT/batch768_bench.log" 2>&1; rc=$? ;;
     profdefault)
       (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_default" -o bench -- \
           python "$R/bench.py" --gpus 1 > "$OUT/profdefault_bench.json" 2> "$OUT/profdefault.err"); rc=$?
