@@ -52,6 +52,12 @@ for s in $STAGES; do
       f=$(find "$OUT/prof_ahead" -name "*kernel_trace.csv" | head -1)
       [ -n "$f" ] && grep "rega_kernel" "$f" | python "$R/tools/trace_durations.py" > "$OUT/ahead_rega_durations.txt" 2>/dev/null
       find "$OUT/prof_ahead" -name "*kernel_trace.csv" -delete 2>/dev/null ;;
+    trace768)
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d "$OUT/prof_768" -o g -- \
+          python "$R/tools/batch_bench.py" --rows 1000000 --dims 768 --nq ${WAX_NQ:-1024} --reps 2 > "$OUT/trace768.log" 2>&1); rc=$?
+      f=$(find "$OUT/prof_768" -name "*kernel_trace.csv" | head -1)
+      [ -n "$f" ] && python "$R/tools/trace_tail.py" "$f" 40 > "$OUT/trace768_tail.csv" 2>/dev/null
+      find "$OUT/prof_768" -name "*kernel_trace.csv" -delete 2>/dev/null ;;
     hosttrace)
       WAX_HIP_BATCH_TRACE=1 timeout 300 python tools/batch_bench.py --nq 256 1024 --reps 3 > "$OUT/hosttrace.log" 2>&1; rc=$? ;;
     pingpong)

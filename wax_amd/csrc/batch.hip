@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void batch_gemm_kernel(GemmArgs a) {
         for (unsigned t = (unsigned)lane; t < total; t += WAVE) {
             const u32x4 e = stage[t];
             const uint32_t q = e.z;
-            const uint32_t pos = atomicAdd(&a.cand_count[q], 1u);
+            const uint32_t pos = atomicAdd(&a.cand_count[(size_t)q * CAND_COUNT_STRIDE], 1u);
             if (pos < a.cand_cap)
                 a.cand[(size_t)q * a.cand_cap + pos] = (int64_t)(((unsigned long long)e.y << 32) | (unsigned long long)e.x);
         }
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void batch_gemm_kernel(GemmArgs a) {
                     else d = 1.0f - dot;
                     d += 0.0f;
                     const uint32_t q = m0 + qloc;
-                    const uint32_t pos = atomicAdd(&a.cand_count[q], 1u);
+                    const uint32_t pos = atomicAdd(&a.cand_count[(size_t)q * CAND_COUNT_STRIDE], 1u);
                     if (pos < a.cand_cap) a.cand[(size_t)q * a.cand_cap + pos] = make_key(d, a.row_base + rowj[j]);
                 }
             }
@@ -729,7 +729,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void tighten_kernel(TightenArgs a) {
     const int wave = (int)(threadIdx.x >> 6);
     const uint32_t q = blockIdx.x;
     const int kp = a.kp;
-    uint32_t n_in = (a.dense != nullptr) ? a.dense_rows : a.cand_count[q];   // dense tile / counted list (incl. the best list)
+    uint32_t n_in = (a.dense != nullptr) ? a.dense_rows : a.cand_count[(size_t)q * CAND_COUNT_STRIDE];   // dense tile / counted list (incl. the best list)
     bool dropped = false;
     if (a.dense == nullptr && n_in > a.cand_cap) {
         dropped = true;
@@ -783,7 +783,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void tighten_kernel(TightenArgs a) {
     if (threadIdx.x == 0) {
         int total = 0;
         for (int w = 0; w < SCAN_WAVES; ++w) total += counts[w];
-        a.cand_count[q] = (uint32_t)(total < kp ? total : kp);
+        a.cand_count[(size_t)q * CAND_COUNT_STRIDE] = (uint32_t)(total < kp ? total : kp);
         const int64_t last = fin[kp - 1];
         a.tau[q] = (last == KEY_PAD) ? __builtin_inff() : key_distance(last);
     }
@@ -802,7 +802,7 @@ __global__ void batch_reset_kernel(float* tau, uint32_t* cand_count, uint32_t* o
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nq_pad) {
         tau[i] = (i < nq) ? __builtin_inff() : -__builtin_inff();  // padding queries admit nothing
-        cand_count[i] = 0u;
+        cand_count[(size_t)i * CAND_COUNT_STRIDE] = 0u;
         overflow[i] = 0u;
     }
 }

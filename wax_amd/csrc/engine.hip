@@ -566,7 +566,7 @@ int batch_prepare(wax_hip_engine* e, hipStream_t st) {
         HIP_TRY(hipMalloc(&b.d_eps, kBatchMaxQ * sizeof(float)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch eps");
         HIP_TRY(hipMalloc(&b.d_tau, kBatchMaxQ * sizeof(float)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch thresholds");
         HIP_TRY(hipMalloc(&b.d_dense, (size_t)kBatchMaxQ * kBatchFirstSlab * sizeof(float)), WAX_HIP_ERR_ALLOC, "Failed to allocate first-slab tile");
-        HIP_TRY(hipMalloc(&b.d_cand_count, kBatchMaxQ * sizeof(uint32_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch counters");
+        HIP_TRY(hipMalloc(&b.d_cand_count, (size_t)kBatchMaxQ * CAND_COUNT_STRIDE * sizeof(uint32_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch counters");
         HIP_TRY(hipMalloc(&b.d_overflow, kBatchMaxQ * sizeof(uint32_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch flags");
         HIP_TRY(hipMalloc(&b.d_cand, (size_t)kBatchMaxQ * kBatchCandCap * sizeof(int64_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch candidates");
         HIP_TRY(hipMalloc(&b.d_seg_count, (size_t)kBatchMaxSegs * kBatchMaxQ * sizeof(uint32_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch segment counters");

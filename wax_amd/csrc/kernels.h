@@ -68,6 +68,11 @@ hipError_t device_shift_down(void* base, uint64_t dst_off, uint64_t src_off, uin
 
 
 // ---- batched queries (batch.hip): bf16 MFMA GEMM + select + exact f32 re-score + certificate ----
+// Per-query append counters of the LDS-tiled GEMM are device-scope atomics from every CU; packed, 1024 of them share
+// 32 cache lines and serialise there (a 16 K-row slab at Q = 1024, D = 768: 161 us). One counter per line spreads them
+// over the memory channels.
+constexpr uint32_t CAND_COUNT_STRIDE = 32;
+
 struct GemmArgs {
     const unsigned short* qb;   // [nq_pad][dims] bf16 queries (zero padded to a multiple of 128)
     const unsigned short* cb;   // [n_rows][dims] bf16 corpus mirror
@@ -77,7 +82,7 @@ struct GemmArgs {
     float* dense;               // non-null (first slab only): store the whole tile [nq_pad][dense_ld] instead of filtering
     uint32_t dense_ld;
     int64_t* cand;              // [nq][cand_cap] appended candidate keys
-    uint32_t* cand_count;       // [nq]
+    uint32_t* cand_count;       // [nq * CAND_COUNT_STRIDE]: one counter per 128-byte line
     uint32_t cand_cap;
     uint32_t row_base;
     uint32_t dims;
