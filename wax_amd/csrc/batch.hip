@@ -638,9 +638,182 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
     if (tid < 256) a.seg_count[(size_t)bidx * (a.nqt * 128u) + group * 256u + (uint32_t)tid] = cnt_s[tid];
 }
 
+// ---------------------------------------------------------------------------
+// Register-resident-queries GEMM for D = 768: 32 queries x D of A fragments do not fit beside the
+// accumulators in 256 VGPRs, so the K dimension is split over the two waves that share a SIMD. Wave p (owner) and
+// wave p + 4 (helper), p = 0..3, hold the same 32 queries; the owner keeps k in [0, D/2), the helper [D/2, D)
+// (96 VGPRs each at D = 768). A workgroup therefore covers 128 queries; tiles are 32 corpus rows (48 KB at D = 768),
+// double-buffered in LDS with one barrier per tile. Per tile every wave runs D/32 MFMAs on two independent
+// accumulators; the helper then parks its partial sums in LDS (4 ds_write_b128, buffers alternate by tile parity),
+// and at the top of the NEXT iteration — after the tile barrier — the owner adds them to its own and runs the
+// selection, while the helper is already issuing the next tile's MFMAs (the pair shares a SIMD, so the owner's
+// VALU/LDS work overlaps the helper's matrix work by construction).
+// Selection, segments and thresholds are those of batch_gemm_rega_kernel (one row block per tile).
+template <int D, int AHEAD>
+__global__ __launch_bounds__(512, 2) void batch_gemm_ksplit_kernel(GemmArgs a, uint32_t blocks_per_group) {
+    constexpr int HALF = D / 2;
+    constexpr int KS = HALF / 16;                    // MFMA k-steps per wave
+    constexpr int ROW_B = D * 2 + 16;                // LDS row stride (bytes); (ROW_B / 4) % 64 == 4 => conflict-free b128 reads
+    constexpr int TROWS = 32;                        // corpus rows per tile
+    constexpr int THREADS_PER_ROW = 512 / TROWS;     // 16
+    constexpr int LOADS = D * 2 / 16 / THREADS_PER_ROW;
+    constexpr int BUF_B = TROWS * ROW_B;
+    constexpr int PART_B = 4 * 64 * 16;              // one wave's partial sums: 16 floats per lane
+    static_assert(D % 256 == 0 && LOADS * THREADS_PER_ROW * 16 == D * 2, "row must split evenly over 16 threads");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* buf0 = smem;
+    unsigned char* part0 = smem + 2 * BUF_B;                                    // [2 parities][4 pairs][4][64] float4
+    float* tau_s = reinterpret_cast<float*>(part0 + 2 * 4 * PART_B);            // [4][32] exact thresholds
+    unsigned int* cnt_s = reinterpret_cast<unsigned int*>(tau_s + 4 * 32);      // [4][32] survivors per query (this workgroup)
+    float* sim_s = reinterpret_cast<float*>(cnt_s + 4 * 32);                    // [4][32] conservative similarity bounds
+
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int pair = wave & 3;
+    const bool owner = wave < 4;
+    const uint32_t group = blockIdx.x / blocks_per_group;   // 128 queries per group
+    const uint32_t bidx = blockIdx.x % blocks_per_group;
+    const uint32_t q0 = group * 128 + pair * 32;             // this pair's 32 queries
+
+    // A fragments: lane l holds query (l & 31), k = khalf*HALF + 16*ks + 8*(l >> 5) .. +7
+    bf16x8 fa[KS];
+    {
+        const u32x4* qp = reinterpret_cast<const u32x4*>(a.qb + (size_t)(q0 + (lane & 31)) * D + (owner ? 0 : HALF)) + (lane >> 5);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) fa[ks] = __builtin_bit_cast(bf16x8, qp[ks * 2]);
+    }
+    if (owner && lane < 32) {
+        const float tq = a.tau[q0 + lane];
+        tau_s[pair * 32 + lane] = tq;
+        sim_s[pair * 32 + lane] = (1.0f - tq) - 4e-7f * (1.0f + __builtin_fabsf(tq));   // see batch_gemm_rega_kernel
+        cnt_s[pair * 32 + lane] = 0u;
+    }
+    const uint32_t seg_slots = a.seg_area / blocks_per_group;
+    const uint32_t seg_lane0 = (q0 + 4u * ((uint32_t)lane >> 5)) * a.cand_cap + a.seg_base + bidx * seg_slots;
+
+    const uint32_t ntiles = (a.slab_rows + TROWS - 1) / TROWS;
+    const uint32_t slab_end = a.slab0 + a.slab_rows;
+    const unsigned char* cbase = reinterpret_cast<const unsigned char*>(a.cb);
+
+    // staging: 16 threads per tile row, a thread moves the 16-byte segments (tid & 15) + 16*p of its row
+    const uint32_t srow = (uint32_t)tid >> 4;
+    const uint32_t sseg = ((uint32_t)tid & 15u) * 16u;
+    u32x4 regs[LOADS];
+    auto issue_loads = [&](uint32_t tile) {
+        uint32_t grow = a.slab0 + tile * TROWS + srow;
+        grow = grow < a.n_rows ? grow : a.n_rows - 1;        // clamp: masked in the selection
+        const unsigned char* src = cbase + (size_t)grow * (D * 2) + sseg;
+#pragma unroll
+        for (int p = 0; p < LOADS; ++p) regs[p] = *reinterpret_cast<const u32x4*>(src + p * 256);
+    };
+    auto store_tile = [&](unsigned char* buf) {
+        unsigned char* dst = buf + srow * ROW_B + sseg;
+#pragma unroll
+        for (int p = 0; p < LOADS; ++p) *reinterpret_cast<u32x4*>(dst + p * 256) = regs[p];
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    // this wave's K half of one tile: two independent accumulator chains, B fragments read AHEAD k-steps early
+    auto mfma_tile = [&](const unsigned char* cur) {
+        f32x16 a0, a1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+        const unsigned char* b0 = cur + (lane & 31) * ROW_B + (owner ? 0 : HALF * 2) + (lane >> 5) * 16;
+        constexpr int RING = AHEAD + 1;
+        u32x4 fb[RING];
+#pragma unroll
+        for (int i = 0; i < AHEAD && i < KS; ++i) fb[i] = *reinterpret_cast<const u32x4*>(b0 + i * 32);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + AHEAD < KS) fb[(ks + AHEAD) % RING] = *reinterpret_cast<const u32x4*>(b0 + (ks + AHEAD) * 32);
+            if (ks & 1) a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], __builtin_bit_cast(bf16x8, fb[ks % RING]), a1, 0, 0, 0);
+            else a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], __builtin_bit_cast(bf16x8, fb[ks % RING]), a0, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = a0[r] + a1[r];
+    };
+    auto park_partial = [&](uint32_t parity) {      // helper: 16 floats per lane, [j][lane] float4
+        f32x4* dst = reinterpret_cast<f32x4*>(part0 + (parity * 4 + pair) * PART_B) + lane;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[j * 64] = f32x4{acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]};
+    };
+    // owner: add the helper's half, then the fused selection of batch_gemm_rega_kernel on one 32-row block
+    auto select_tile = [&](uint32_t tile, uint32_t parity) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(part0 + (parity * 4 + pair) * PART_B) + lane;
+        const lds_f32x4* sim_w = (const lds_f32x4*)(sim_s + pair * 32 + 4 * (lane >> 5));
+        f32x4 lo[4], hp[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { hp[j] = src[j * 64]; lo[j] = sim_w[2 * j]; }
+        if (a.debug & 8u) return;
+        unsigned long long hit[4] = {0ull, 0ull, 0ull, 0ull};
+        float full[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            full[r] = acc[r] + hp[r >> 2][r & 3];
+            hit[r >> 2] |= __ballot(full[r] >= lo[r >> 2][r & 3]);   // NaN fails
+        }
+        if ((hit[0] | hit[1] | hit[2] | hit[3]) == 0ull) return;
+        const uint32_t row0 = a.slab0 + tile * TROWS + (lane & 31);
+        const bool ok0 = row0 < slab_end;
+        const lds_f32* tau_w = (const lds_f32*)(tau_s + pair * 32);
+        lds_u32* cnt_w = (lds_u32*)(cnt_s + pair * 32);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (hit[g] == 0ull) continue;
+            const f32x4 tau4 = *(const lds_f32x4*)(tau_w + 8 * g + 4 * (lane >> 5));
+#pragma unroll
+            for (int r = 4 * g; r < 4 * g + 4; ++r) {
+                const int qo = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float d0 = (1.0f - full[r]) + 0.0f;
+                if (ok0 && d0 <= tau4[r & 3]) {
+                    const unsigned off = __hip_atomic_fetch_add(cnt_w + qo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const uint32_t e0 = seg_lane0 + (uint32_t)((r & 3) + 8 * (r >> 2)) * a.cand_cap;
+                    if (off < seg_slots) a.cand[e0 + off] = make_key(d0, a.row_base + row0);
+                }
+            }
+        }
+    };
+
+    uint32_t t = bidx;
+    if (t < ntiles) {
+        issue_loads(t);
+        store_tile(buf0);
+    }
+    __syncthreads();
+    uint32_t it = 0;
+    for (; t < ntiles; t += blocks_per_group, ++it) {
+        unsigned char* cur = buf0 + (it & 1u) * BUF_B;
+        unsigned char* nxt = buf0 + ((it & 1u) ^ 1u) * BUF_B;
+        const uint32_t tn = t + blocks_per_group;
+        if (tn < ntiles) issue_loads(tn);
+        if (owner) {
+            if (it > 0) select_tile(t - blocks_per_group, (it - 1u) & 1u);   // partial of tile t-1: parked before the last barrier
+            mfma_tile(cur);
+        } else {
+            mfma_tile(cur);
+            park_partial(it & 1u);
+        }
+        if (tn < ntiles) store_tile(nxt);
+        __syncthreads();
+    }
+    if (owner && it > 0) select_tile(t - blocks_per_group, (it - 1u) & 1u);
+    __syncthreads();
+    if (tid < 128) a.seg_count[(size_t)bidx * (a.nqt * 128u) + group * 128u + (uint32_t)tid] = cnt_s[tid];
+}
+
+// D = 1024 would need 2 x 66 KB of tiles + 32 KB of partial sums (> 160 KB of LDS): it stays on the LDS-tiled kernel.
+static bool ksplit_dims(uint32_t dims) { return dims == 768; }
+
 static void rega_geometry(const GemmArgs& a, uint32_t* groups, uint32_t* per_group) {
-    *groups = (a.nqt * 128 + 255) / 256;
-    const uint32_t ntiles = (a.slab_rows + 63) / 64;
+    const bool ksplit = ksplit_dims(a.dims);                      // 128 queries / 32-row tiles per workgroup
+    *groups = ksplit ? a.nqt : (a.nqt * 128 + 255) / 256;
+    const uint32_t ntiles = ksplit ? (a.slab_rows + 31) / 32 : (a.slab_rows + 63) / 64;
     uint32_t pg = 256 / *groups;                // one persistent workgroup per CU in total
     if (pg < 1) pg = 1;
     if (pg > ntiles) pg = ntiles;
@@ -649,7 +822,7 @@ static void rega_geometry(const GemmArgs& a, uint32_t* groups, uint32_t* per_gro
 
 static bool rega_eligible(const GemmArgs& a, int metric) {
     return a.dense == nullptr && a.use_rega && metric != BM_L2 &&
-           (a.dims == 128 || a.dims == 256 || a.dims == 384 || a.dims == 512);
+           (a.dims == 128 || a.dims == 256 || a.dims == 384 || a.dims == 512 || ksplit_dims(a.dims));
 }
 
 bool batch_gemm_segments(const GemmArgs& a, int metric, uint32_t* nseg, uint32_t* seg_slots) {
@@ -659,6 +832,22 @@ bool batch_gemm_segments(const GemmArgs& a, int metric, uint32_t* nseg, uint32_t
     *nseg = per_group;
     *seg_slots = a.seg_area / per_group;
     return true;
+}
+
+template <int D, int AHEAD>
+static hipError_t launch_ksplit(const GemmArgs& a, hipStream_t st) {
+    constexpr size_t smem = 2 * 32 * (D * 2 + 16) + 2 * 4 * (4 * 64 * 16) + 3 * 4 * 32 * 4;  // tiles, partial sums, thresholds / counters / bounds
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&batch_gemm_ksplit_kernel<D, AHEAD>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    uint32_t groups, per_group;
+    rega_geometry(a, &groups, &per_group);
+    hipLaunchKernelGGL((batch_gemm_ksplit_kernel<D, AHEAD>), dim3(groups * per_group), dim3(512), smem, st, a, per_group);
+    return hipGetLastError();
 }
 
 template <int D, bool GLDS, int AHEAD>
@@ -702,6 +891,7 @@ hipError_t launch_batch_gemm(const GemmArgs& a, int metric, hipStream_t st) {
             case 256: return launch_rega<256>(a, st);
             case 384: return launch_rega<384>(a, st);
             case 512: return launch_rega<512>(a, st);
+            case 768: return launch_ksplit<768, 4>(a, st);
             default: break;
         }
     }
