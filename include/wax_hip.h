@@ -194,6 +194,21 @@ int wax_hip_merge_hits_device(const wax_hip_hit* d_in, uint32_t n, uint32_t k, w
 int wax_hip_hits_to_results(uint8_t metric, const wax_hip_hit* hits, uint32_t n,
                             uint64_t* out_ids, float* out_scores, uint32_t* out_count);
 
+/* ---- filtered search (the vector lane's candidate filters, applied on the device) -------- *
+ * UnifiedSearch applies FrameFilter.frameIds (an allow-list) and SearchRequest.minScore to the vector lane's
+ * candidates AFTER the engine returned them (passesFrameFilter, UnifiedSearch.swift:1241-1258), so it asks the engine
+ * for candidateLimit = max(topK, min(3 topK, 1000)) results (:1195-1200) and can still come back short when the
+ * allowed frames rank deeper (the reference test only covers a 4-document corpus,
+ * UnifiedSearchTests.swift:133-158). Here the allow-list is a PRE-filter: only the allowed rows are scored
+ * (cost ~ allowed rows, not corpus rows) and the top_k of THEM comes back, then results with score < min_score are
+ * dropped. has_allow = 0: no allow-list (allow_frame_ids ignored); has_allow = 1 with n_allow = 0: nothing is
+ * allowed. Ids not in the engine are ignored. has_min_score = 0: no score cut. Distances are bit-identical to
+ * wax_hip_search's for the same rows. */
+int wax_hip_search_filtered(wax_hip_engine* e, const float* query, uint32_t dims, int32_t top_k,
+                            int has_allow, const uint64_t* allow_frame_ids, uint64_t n_allow,
+                            int has_min_score, float min_score,
+                            uint64_t* out_ids, float* out_scores, uint32_t* out_count);
+
 /* ---- persistence: "MV2V" vec segment, encoding 2 ------------------------- */
 
 /* serialize() (MetalVectorEngine.swift:682-714): byte-identical layout

@@ -46,6 +46,20 @@ class VectorEngine {
         return out;
     }
     void add(uint64_t frameId, const std::vector<float>& v) { check(wax_hip_add(h_, frameId, v.data(), (uint32_t)v.size())); }
+    /// Allow-list / minScore filtered search (UnifiedSearch.swift:1241-1258): best topK among the allowed frames.
+    std::vector<std::pair<uint64_t, float>> searchFiltered(const std::vector<float>& q, int topK,
+                                                           const std::vector<uint64_t>* allow, const float* minScore) {
+        const size_t cap = topK < 1 ? 1 : (topK > 10000 ? 10000 : (size_t)topK);
+        std::vector<uint64_t> ids(cap);
+        std::vector<float> scores(cap);
+        uint32_t n = 0;
+        check(wax_hip_search_filtered(h_, q.data(), (uint32_t)q.size(), topK, allow ? 1 : 0,
+                                      allow && !allow->empty() ? allow->data() : nullptr, allow ? allow->size() : 0,
+                                      minScore ? 1 : 0, minScore ? *minScore : 0.0f, ids.data(), scores.data(), &n));
+        std::vector<std::pair<uint64_t, float>> out(n);
+        for (uint32_t i = 0; i < n; ++i) out[i] = {ids[i], scores[i]};
+        return out;
+    }
     /// Pending-embedding replay: WAL putEmbedding payloads back to back (UnifiedSearchEngineCache.swift:252-283).
     uint64_t applyPutEmbeddings(const uint8_t* payloads, uint64_t len) {
         uint64_t applied = 0;

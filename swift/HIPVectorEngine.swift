@@ -106,6 +106,28 @@ public actor HIPVectorEngine {
         }
     }
 
+    /// The vector lane's candidate filters on the device (`passesFrameFilter`, UnifiedSearch.swift:1241-1258):
+    /// the best `topK` among the frames of `allowlist` (FrameFilter.frameIds), minus results below `minScore`.
+    /// With this, UnifiedSearch no longer needs the 3x `candidateLimit` over-fetch (:1195-1200) for allow-listed requests.
+    public func search(vector: [Float], topK: Int, allowlist: Set<UInt64>?, minScore: Float?) async throws -> [(frameId: UInt64, score: Float)] {
+        let h = handle
+        let limit = max(1, min(topK, 10_000))
+        let allowed: [UInt64]? = allowlist.map(Array.init)
+        return try await io.run {
+            var ids = [UInt64](repeating: 0, count: limit)
+            var scores = [Float](repeating: 0, count: limit)
+            var n: UInt32 = 0
+            try Self.check(vector.withUnsafeBufferPointer { q in
+                (allowed ?? []).withUnsafeBufferPointer { a in
+                    wax_hip_search_filtered(h, q.baseAddress, UInt32(vector.count), Int32(clamping: topK),
+                                            allowed == nil ? 0 : 1, a.baseAddress, UInt64(a.count),
+                                            minScore == nil ? 0 : 1, minScore ?? 0, &ids, &scores, &n)
+                }
+            })
+            return (0..<Int(n)).map { (frameId: ids[$0], score: scores[$0]) }
+        }
+    }
+
     /// Pending-embedding replay without the [[Float]] detour: WAL putEmbedding payloads (WALEntryCodec.encode,
     /// WALEntryCodec.swift:39-54) concatenated, validated and applied inside the library as one addBatch.
     /// UnifiedSearchEngineCache.applyPendingEmbeddingsIfNeeded (:252-283) can call this with the raw payloads.

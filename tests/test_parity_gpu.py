@@ -817,3 +817,67 @@ def test_pending_embedding_replay_from_wal_payloads(wax):
     assert a.serialize() == before
     assert a.applyPutEmbeddings(b"") == 0
     a.close(); b.close()
+
+
+def test_filtered_search_reference_case(wax):
+    """UnifiedSearchTests.swift:133-158 (filtersAllowResultsBeyondTopK): 4 two-d documents, query [1, 0], topK 2,
+    allow-list = the two WORST matches -> exactly those two come back."""
+    eng = wax.HIPVectorEngine(metric=wax.VectorMetric.cosine, dimensions=2)
+    eng.addBatch([0, 1, 2, 3], np.array([[1.0, 0.0], [0.9, 0.1], [0.1, 0.9], [0.0, 1.0]], np.float32))
+    ids, scores = eng.searchFiltered(np.array([1.0, 0.0], np.float32), 2, frameIds=[2, 3])
+    assert ids.tolist() == [2, 3]
+    full_ids, full_scores = eng.searchArrays(np.array([1.0, 0.0], np.float32), 4)
+    assert np.array_equal(scores, full_scores[2:])
+    # minScore (UnifiedSearch.swift:1248): `score < minScore` drops the candidate
+    ids, scores = eng.searchFiltered(np.array([1.0, 0.0], np.float32), 4, minScore=0.5)
+    assert ids.tolist() == [0, 1]
+    ids, scores = eng.searchFiltered(np.array([1.0, 0.0], np.float32), 4, frameIds=[3, 1, 99], minScore=0.5)
+    assert ids.tolist() == [1]
+    assert eng.searchFiltered(np.array([1.0, 0.0], np.float32), 4, frameIds=[])[0].size == 0      # empty list allows nothing
+    assert eng.searchFiltered(np.array([1.0, 0.0], np.float32), 4, frameIds=[77, 78])[0].size == 0
+    with pytest.raises(wax.EncodingError):
+        eng.searchFiltered(np.array([1.0, 0.0, 0.0], np.float32), 2, frameIds=[1])
+    eng.close()
+
+
+@pytest.mark.parametrize("metric,dims", [(0, 384), (1, 384), (2, 128), (0, 768), (0, 100), (1, 33)])
+def test_filtered_search_equals_filtered_full_ranking(wax, metric, dims):
+    """Pre-filter on the device == post-filter of the COMPLETE ranking (what the reference's post-filter would give
+    with an unbounded candidateLimit): same ids, and for the specialised dims bit-identical scores."""
+    n = 6000
+    corpus = oracle.gaussian_unit_rows(3, n, dims)
+    if metric != 0:
+        corpus = corpus * np.linspace(0.5, 2.0, n, dtype=np.float32)[:, None]
+    ids = (np.arange(n, dtype=np.uint64) * 7 + 3)
+    eng = make_engine(wax, metric, dims, corpus, ids)
+    rng = np.random.default_rng(11)
+    q = oracle.gaussian_unit_queries(1, dims, seed=21)[0]
+    full_ids, full_scores = eng.searchArrays(q, n)           # k = N: the general (radix select) path, complete ranking
+    assert len(full_ids) == n
+    exact_dims = dims in (128, 384, 768)
+    for n_allow, k in [(1, 10), (7, 3), (250, 10), (250, 300), (3000, 30), (n, 10), (n, 250)]:
+        allow = rng.permutation(ids)[:n_allow]
+        allow_plus = np.concatenate([allow, allow[:3], np.array([10 ** 12], np.uint64)])    # duplicates and an unknown id
+        got_ids, got_scores = eng.searchFiltered(q, k, frameIds=allow_plus)
+        keep = np.isin(full_ids, allow)
+        exp_ids, exp_scores = full_ids[keep][:k], full_scores[keep][:k]
+        assert len(got_ids) == len(exp_ids) == min(k, n_allow)
+        if exact_dims:
+            assert np.array_equal(got_ids, exp_ids) and np.array_equal(got_scores, exp_scores), (n_allow, k)
+        else:
+            assert np.max(np.abs(got_scores - exp_scores)) <= 1e-6
+            assert set(got_ids.tolist()) == set(exp_ids.tolist()) or np.min(np.abs(np.diff(exp_scores))) < 1e-6
+        # with a score cut
+        cut = float(exp_scores[len(exp_scores) // 2])
+        c_ids, c_scores = eng.searchFiltered(q, k, frameIds=allow, minScore=cut)
+        assert np.all(c_scores >= cut) and len(c_ids) == int(np.sum(got_scores >= cut))
+    # no allow-list: the ordinary search + cut
+    o_ids, o_scores = eng.searchArrays(q, 20)
+    f_ids, f_scores = eng.searchFiltered(q, 20, minScore=float(o_scores[9]))
+    assert np.array_equal(f_ids, o_ids[:len(f_ids)]) and len(f_ids) == int(np.sum(o_scores >= o_scores[9]))
+    # after a removal the row list follows the shifted rows
+    victim = int(full_ids[0])
+    eng.remove(victim)
+    g_ids, _ = eng.searchFiltered(q, 5, frameIds=[victim, int(full_ids[1]), int(full_ids[2])])
+    assert g_ids.tolist() == [int(full_ids[1]), int(full_ids[2])]
+    eng.close()

@@ -1045,10 +1045,18 @@ __global__ __launch_bounds__(256) void rescore_kernel(RescoreArgs a) {
     const bool in_range = pair < total;
     const uint32_t p = in_range ? pair : total - 1;
     const uint32_t q = p / (uint32_t)a.kp;
-    const int64_t ck = a.cand[(size_t)q * a.cand_cap + (p - q * (uint32_t)a.kp)];
-    const bool live = in_range && ck != KEY_PAD;
-    const uint32_t grow = key_row(ck);
-    uint32_t lrow = grow - a.row_base;
+    bool live;
+    uint32_t grow, lrow;
+    if (a.rows != nullptr) {  // listed rows (filtered search)
+        live = in_range;
+        lrow = a.rows[p];
+        grow = a.row_base + lrow;
+    } else {
+        const int64_t ck = a.cand[(size_t)q * a.cand_cap + (p - q * (uint32_t)a.kp)];
+        live = in_range && ck != KEY_PAD;
+        grow = key_row(ck);
+        lrow = grow - a.row_base;
+    }
     lrow = (live && lrow < a.n_rows) ? lrow : 0;
     const f32x4* __restrict__ v4 = reinterpret_cast<const f32x4*>(a.store) + (size_t)lrow * D4 + gl;
     const f32x4* __restrict__ q4 = reinterpret_cast<const f32x4*>(a.queries) + (size_t)q * D4 + gl;
@@ -1059,7 +1067,10 @@ __global__ __launch_bounds__(256) void rescore_kernel(RescoreArgs a) {
     float m = 0.f;
     if (METRIC == BM_COS) m = group_sum<GROUP>(hsum_b(nrm));
     const float d = finish_distance_b<METRIC>(s, m, a.q_norm[q]);
-    if (in_range && gl == GROUP - 1) a.exact[p] = live ? make_key(d, grow) : KEY_PAD;
+    if (in_range && gl == GROUP - 1) {
+        if (a.dist_out != nullptr) a.dist_out[p] = d;
+        else a.exact[p] = live ? make_key(d, grow) : KEY_PAD;
+    }
 }
 
 template <int METRIC>
@@ -1069,10 +1080,18 @@ __global__ __launch_bounds__(256) void rescore_generic_kernel(RescoreArgs a) {
     const uint32_t total = a.nq * (uint32_t)a.kp;
     if (pair >= total) return;  // whole wave exits together
     const uint32_t q = pair / (uint32_t)a.kp;
-    const int64_t ck = a.cand[(size_t)q * a.cand_cap + (pair - q * (uint32_t)a.kp)];
-    const bool live = ck != KEY_PAD;
-    const uint32_t grow = key_row(ck);
-    uint32_t lrow = grow - a.row_base;
+    bool live;
+    uint32_t grow, lrow;
+    if (a.rows != nullptr) {
+        live = true;
+        lrow = a.rows[pair];
+        grow = a.row_base + lrow;
+    } else {
+        const int64_t ck = a.cand[(size_t)q * a.cand_cap + (pair - q * (uint32_t)a.kp)];
+        live = ck != KEY_PAD;
+        grow = key_row(ck);
+        lrow = grow - a.row_base;
+    }
     lrow = (live && lrow < a.n_rows) ? lrow : 0;
     const uint32_t D = a.dims;
     const float* row = a.store + (size_t)lrow * D;
@@ -1093,7 +1112,10 @@ __global__ __launch_bounds__(256) void rescore_generic_kernel(RescoreArgs a) {
     float m = 0.f;
     if (METRIC == BM_COS) m = group_sum<64>(hsum_b(nrm));
     const float d = finish_distance_b<METRIC>(s, m, a.q_norm[q]);
-    if (lane == WAVE - 1) a.exact[pair] = live ? make_key(d, grow) : KEY_PAD;
+    if (lane == WAVE - 1) {
+        if (a.dist_out != nullptr) a.dist_out[pair] = d;
+        else a.exact[pair] = live ? make_key(d, grow) : KEY_PAD;
+    }
 }
 
 template <int D4, int GROUP>

@@ -6,6 +6,7 @@
 // row-major (+ a u64 frame-id table beside it so id mapping also happens on device), queries
 // travel through pinned staging, every search runs on a pooled scratch slot with its own HIP
 // stream (the analogue of the transient buffer pool, :84-117), and there is no CPU fallback.
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -203,6 +204,20 @@ struct Slot {
     bool timed = false;
 };
 
+// Workspace of wax_hip_search_filtered; one filtered search at a time per engine.
+struct FilterWork {
+    std::mutex mu;
+    uint32_t* d_rows = nullptr;      // [cap] allowed local rows, ascending
+    uint64_t* d_ids = nullptr;       // [cap] their frame ids
+    float* d_dist = nullptr;         // [cap] their distances
+    uint64_t cap = 0;
+    float* d_query = nullptr;        // [dims]
+    float* d_qnorm = nullptr;        // [1]
+    wax_hip_hit* d_hits = nullptr;   // [WAX_HIP_MAX_RESULTS]
+    SelectWork sw{};
+    bool ready = false;
+};
+
 // Workspace of the batched (bf16 MFMA) path; one batch at a time per engine.
 struct BatchWork {
     std::mutex mu;
@@ -300,6 +315,7 @@ struct wax_hip_engine {
     std::atomic<int64_t> batch_rega{1};      // register-resident-queries GEMM where it applies: 1 register staging, 2 LDS-DMA staging; 0 off
     std::atomic<uint64_t> st_batch_queries{0}, st_batch_fallbacks{0};
     BatchWork batch;
+    FilterWork filter;
 
     // stats
     std::atomic<uint64_t> st_searches{0}, st_rows{0}, st_bytes{0}, st_alloc{0}, st_reuse{0};
@@ -814,6 +830,10 @@ void wax_hip_engine_destroy(wax_hip_engine* e) {
         BatchWork& b = e->batch;
         (void)hipFree(b.d_cb); (void)hipFree(b.d_vn2); (void)hipFree(b.d_maxnorm); (void)hipFree(b.d_q); (void)hipFree(b.d_qb);
         (void)hipFree(b.d_qn2); (void)hipFree(b.d_qnorm); (void)hipFree(b.d_eps); (void)hipFree(b.d_tau); (void)hipFree(b.d_dense);
+        FilterWork& f = e->filter;
+        (void)hipFree(f.d_rows); (void)hipFree(f.d_ids); (void)hipFree(f.d_dist); (void)hipFree(f.d_query); (void)hipFree(f.d_qnorm);
+        (void)hipFree(f.d_hits); (void)hipFree(f.sw.hist); (void)hipFree(f.sw.state); (void)hipFree(f.sw.counter);
+        (void)hipFree(f.sw.keys_a); (void)hipFree(f.sw.keys_b);
         (void)hipFree(b.d_cand_count); (void)hipFree(b.d_overflow); (void)hipFree(b.d_cand); (void)hipFree(b.d_seg_count); (void)hipFree(b.d_exact); (void)hipFree(b.d_hits);
         (void)hipFree(b.d_cert); (void)hipHostFree(b.h_hits); (void)hipHostFree(b.h_cert); (void)hipHostFree(b.h_qnorm);
         (void)hipHostFree(b.h_eps);
@@ -1290,6 +1310,98 @@ int wax_hip_hits_to_results(uint8_t metric, const wax_hip_hit* hits, uint32_t n,
                             uint32_t* out_count) {
     if (!hits || !out_ids || !out_scores || !out_count) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null argument");
     return hits_to_results(metric, hits, n, out_ids, out_scores, out_count);
+}
+
+// ---- filtered search --------------------------------------------------------
+
+int wax_hip_search_filtered(wax_hip_engine* e, const float* query, uint32_t dims, int32_t top_k, int has_allow,
+                            const uint64_t* allow_frame_ids, uint64_t n_allow, int has_min_score, float min_score,
+                            uint64_t* out_ids, float* out_scores, uint32_t* out_count) {
+    if (out_count) *out_count = 0;
+    if (!e) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine is null");
+    if (!query || !out_ids || !out_scores || !out_count) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    if (has_allow && n_allow > 0 && !allow_frame_ids) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "allow-list is null");
+    if (dims != e->dims) return fail(WAX_HIP_ERR_DIM_MISMATCH, dim_mismatch_msg(e->dims, dims));
+    const int kpad = clamp_topk(top_k);
+    uint32_t n = 0;
+    if (!has_allow) {
+        // no allow-list: the ordinary scan, then the score cut
+        int rc = wax_hip_search(e, query, dims, top_k, out_ids, out_scores, &n);
+        if (rc != WAX_HIP_OK) return rc;
+    } else {
+        DeviceGuard g(e->device);
+        e->lock.lock_shared(g_outstanding[e] > 0);
+        struct Unlock { RWLock& l; ~Unlock() { l.unlock_shared(); } } unlock{e->lock};
+        // allowed frame ids -> local rows, ascending and unique (row order is the tie-break order of every path)
+        std::vector<uint32_t> rows;
+        rows.reserve((size_t)n_allow);
+        for (uint64_t i = 0; i < n_allow; ++i) {
+            const int64_t r = e->idmap.find(allow_frame_ids[i]);
+            if (r >= 0) rows.push_back((uint32_t)r);
+        }
+        std::sort(rows.begin(), rows.end());
+        rows.erase(std::unique(rows.begin(), rows.end()), rows.end());
+        const uint64_t m = rows.size();
+        if (m == 0) return WAX_HIP_OK;
+        std::vector<uint64_t> ids(m);
+        for (uint64_t i = 0; i < m; ++i) ids[i] = e->ids[rows[i]];
+        const int k_eff = (uint64_t)kpad < m ? kpad : (int)m;
+
+        FilterWork& f = e->filter;
+        std::unique_lock<std::mutex> fg(f.mu);
+        hipStream_t st = e->streams[0];
+        if (!f.ready) {
+            HIP_TRY(hipMalloc(&f.d_query, (size_t)e->dims * sizeof(float)), WAX_HIP_ERR_ALLOC, "Failed to allocate filter query buffer");
+            HIP_TRY(hipMalloc(&f.d_qnorm, sizeof(float)), WAX_HIP_ERR_ALLOC, "Failed to allocate filter scalars");
+            HIP_TRY(hipMalloc(&f.d_hits, (size_t)WAX_HIP_MAX_RESULTS * sizeof(wax_hip_hit)), WAX_HIP_ERR_ALLOC, "Failed to allocate filter hits");
+            HIP_TRY(hipMalloc(&f.sw.hist, 256 * sizeof(uint32_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate select histogram");
+            HIP_TRY(hipMalloc(&f.sw.state, 2 * sizeof(uint64_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate select state");
+            HIP_TRY(hipMalloc(&f.sw.counter, sizeof(uint32_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate select counter");
+            HIP_TRY(hipMalloc(&f.sw.keys_a, (size_t)WAX_HIP_MAX_RESULTS * sizeof(int64_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate select keys");
+            HIP_TRY(hipMalloc(&f.sw.keys_b, (size_t)WAX_HIP_MAX_RESULTS * sizeof(int64_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate select keys");
+            f.ready = true;
+        }
+        if (f.cap < m) {
+            HIP_TRY(hipStreamSynchronize(st), WAX_HIP_ERR_INTERNAL, "filter sync");
+            (void)hipFree(f.d_rows); (void)hipFree(f.d_ids); (void)hipFree(f.d_dist);
+            f.d_rows = nullptr; f.d_ids = nullptr; f.d_dist = nullptr; f.cap = 0;
+            uint64_t cap = 1024;
+            while (cap < m) cap *= 2;
+            HIP_TRY(hipMalloc(&f.d_rows, (size_t)cap * sizeof(uint32_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate allowed-row list");
+            HIP_TRY(hipMalloc(&f.d_ids, (size_t)cap * sizeof(uint64_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate allowed-id list");
+            HIP_TRY(hipMalloc(&f.d_dist, (size_t)cap * sizeof(float)), WAX_HIP_ERR_ALLOC, "Failed to allocate allowed-row distances");
+            f.cap = cap;
+        }
+        const float qn = query_norm(query, dims);
+        HIP_TRY(hipMemcpyAsync(f.d_query, query, (size_t)dims * sizeof(float), hipMemcpyHostToDevice, st), WAX_HIP_ERR_INTERNAL, "query upload");
+        HIP_TRY(hipMemcpyAsync(f.d_qnorm, &qn, sizeof(float), hipMemcpyHostToDevice, st), WAX_HIP_ERR_INTERNAL, "query norm upload");
+        HIP_TRY(hipMemcpyAsync(f.d_rows, rows.data(), (size_t)m * sizeof(uint32_t), hipMemcpyHostToDevice, st), WAX_HIP_ERR_INTERNAL, "row list upload");
+        HIP_TRY(hipMemcpyAsync(f.d_ids, ids.data(), (size_t)m * sizeof(uint64_t), hipMemcpyHostToDevice, st), WAX_HIP_ERR_INTERNAL, "id list upload");
+        RescoreArgs r{};   // exact f32 distances with scan_kernel's lane mapping and summation order
+        r.store = e->d_store; r.queries = f.d_query; r.q_norm = f.d_qnorm; r.rows = f.d_rows; r.dist_out = f.d_dist;
+        r.n_rows = (uint32_t)e->count; r.row_base = 0; r.dims = dims; r.nq = 1; r.cand_cap = 0; r.kp = (int)m;
+        HIP_TRY(launch_rescore(r, e->metric, st), WAX_HIP_ERR_INTERNAL, "distance kernel launch");
+        // keys of the compact list carry the POSITION in it; positions ascend with rows, so ties order as everywhere else
+        HIP_TRY(launch_select_general(f.d_dist, (uint32_t)m, 0u, k_eff, k_eff, f.d_ids, f.sw, f.d_hits, st),
+                WAX_HIP_ERR_INTERNAL, "select kernel launch");
+        std::vector<wax_hip_hit> hits((size_t)k_eff);
+        HIP_TRY(hipMemcpyAsync(hits.data(), f.d_hits, (size_t)k_eff * sizeof(wax_hip_hit), hipMemcpyDeviceToHost, st),
+                WAX_HIP_ERR_INTERNAL, "hits download");
+        HIP_TRY(hipStreamSynchronize(st), WAX_HIP_ERR_INTERNAL, "filtered search failed on device");
+        int rc = hits_to_results(e->metric, hits.data(), (uint32_t)k_eff, out_ids, out_scores, &n);
+        if (rc != WAX_HIP_OK) return rc;
+        e->st_searches++;
+        e->st_rows += m;
+        e->st_bytes += m * (uint64_t)e->dims * 4ull;
+    }
+    if (has_min_score) {  // `score < minScore` drops a candidate (UnifiedSearch.swift:1248); results are best-first
+        uint32_t keep = 0;
+        for (uint32_t i = 0; i < n; ++i)
+            if (!(out_scores[i] < min_score)) { out_ids[keep] = out_ids[i]; out_scores[keep] = out_scores[i]; ++keep; }
+        n = keep;
+    }
+    *out_count = n;
+    return WAX_HIP_OK;
 }
 
 // ---- persistence ----------------------------------------------------------

@@ -112,6 +112,10 @@ struct RescoreArgs {
     int64_t* exact;             // [nq][kp]
     uint32_t n_rows, row_base, dims, nq, cand_cap;
     int kp;
+    // filtered single-query search (nq = 1, kp = number of listed rows): rows come from `rows` (local indices,
+    // ascending) instead of candidate keys, and plain f32 distances go to dist_out[i] instead of keys to `exact`
+    const uint32_t* rows;
+    float* dist_out;
 };
 hipError_t launch_mirror(const float* src, uint32_t n_rows, uint32_t n_rows_padded, uint32_t dims, int normalize,
                          unsigned short* dst, float* norm2, unsigned int* max_norm_bits, hipStream_t stream);

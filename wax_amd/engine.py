@@ -212,6 +212,26 @@ class HIPVectorEngine:
         raise_for_status(rc)
         return ids[:got.value].copy(), scores[:got.value].copy()
 
+    def searchFiltered(self, vector, topK: int, frameIds=None, minScore=None) -> Tuple[np.ndarray, np.ndarray]:  # noqa: N802,N803
+        """The vector lane's candidate filters applied on the device (UnifiedSearch.swift:1241-1258): `frameIds` is
+        FrameFilter.frameIds (allow-list; None = no list, empty = nothing allowed), `minScore` is SearchRequest.minScore.
+        Returns the best topK among the ALLOWED frames (a pre-filter), best first, minus those scoring below minScore."""
+        q = _as_f32(vector).reshape(-1)
+        cap = max(1, min(clampTopK(topK), max(self.count, 1)))
+        ids = np.empty(cap, dtype=np.uint64)
+        scores = np.empty(cap, dtype=np.float32)
+        got = ctypes.c_uint32(0)
+        allow = None if frameIds is None else np.ascontiguousarray(list(frameIds) if not isinstance(frameIds, np.ndarray)
+                                                                   else frameIds, dtype=np.uint64)
+        rc = self._lib.wax_hip_search_filtered(
+            self._h, _fp(q), q.size, int(max(min(topK, 2**31 - 1), -2**31)),
+            0 if allow is None else 1, None if allow is None or allow.size == 0 else _u64p(allow),
+            0 if allow is None else int(allow.size),
+            0 if minScore is None else 1, 0.0 if minScore is None else float(minScore),
+            _u64p(ids), _fp(scores), ctypes.byref(got))
+        raise_for_status(rc)
+        return ids[:got.value].copy(), scores[:got.value].copy()
+
     def search(self, vector, topK: int) -> List[Tuple[int, float]]:  # noqa: N803
         """VectorSearchEngine.search(vector:topK:) -> [(frameId, score)] best first (:446-627)."""
         ids, scores = self.searchArrays(vector, topK)
