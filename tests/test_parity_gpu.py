@@ -881,3 +881,31 @@ def test_filtered_search_equals_filtered_full_ranking(wax, metric, dims):
     g_ids, _ = eng.searchFiltered(q, 5, frameIds=[victim, int(full_ids[1]), int(full_ids[2])])
     assert g_ids.tolist() == [int(full_ids[1]), int(full_ids[2])]
     eng.close()
+
+
+@pytest.mark.parametrize("dims", [384, 128, 768])
+def test_batch_gemm_variants_agree(wax, dims):
+    """Every GEMM variant behind the batched path — LDS-tiled (batch_rega 0), register-resident with register
+    staging (1) and with LDS-DMA staging (2; D = 768 has the K-split kernel for both) — gives the single-query
+    answers bit for bit, over several slab schedules."""
+    n = 150_000
+    corpus = oracle.gaussian_unit_rows(9, n, dims)
+    eng = make_engine(wax, 0, dims, corpus)
+    queries = oracle.gaussian_unit_queries(300, dims, seed=31)
+    ref = None
+    for rega in (1, 2, 0):
+        for growth in (8, 3):
+            eng.setTuning("batch_rega", rega)
+            eng.setTuning("batch_growth", growth)
+            before = eng.getTuning("batch_queries")
+            ids, scores, counts = eng.searchBatch(queries, 10)
+            assert eng.getTuning("batch_queries") - before == 300
+            if ref is None:
+                ref = (ids, scores, counts)
+                for i in (0, 1, 150, 299):
+                    s_ids, s_scores = eng.searchArrays(queries[i], 10)
+                    assert np.array_equal(ids[i], s_ids) and np.array_equal(scores[i], s_scores)
+            else:
+                assert np.array_equal(ids, ref[0]) and np.array_equal(scores, ref[1]) and np.array_equal(counts, ref[2])
+    assert eng.getTuning("batch_fallbacks") <= 60
+    eng.close()
