@@ -229,7 +229,7 @@ int wax_hip_stats(wax_hip_engine* e, wax_hip_stats_t* out);
  * distance-buffer + radix-select path even for small k), "stream_nt",
  * "reset_stats" (any value: zero the counters), "streams" (1..4 in-order streams the slots rotate over),
  * "batch_mode" (0 = never use the MFMA batched path), "batch_min" (smallest batch that uses it),
- * "batch_slab_mb", "batch_growth". get-only: "variant_count", "scan_grid", "fused_max_k", "batch_queries",
+ * "batch_slab_mb", "batch_growth", "batch_first". get-only: "variant_count", "scan_grid", "fused_max_k", "batch_queries",
  * "batch_fallbacks". */
 int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value);
 int64_t wax_hip_get_tuning(wax_hip_engine* e, const char* key);

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--slab-mb", type=int, nargs="+", default=[64])
     ap.add_argument("--growth", type=int, nargs="+", default=[0], help="slab growth factors to sweep (0 = library default)")
     ap.add_argument("--debug", type=int, nargs="+", default=[0], help="batch_debug bit masks to sweep (timing experiments)")
+    ap.add_argument("--first", type=int, nargs="+", default=[0], help="rows of the dense first slab to sweep (0 = library default)")
     ap.add_argument("--rega", type=int, nargs="+", default=[-1], help="batch_rega modes to sweep (-1 = library default)")
     ap.add_argument("--exchange", choices=["rccl", "host"], default="rccl")
     args = ap.parse_args()
@@ -66,9 +67,11 @@ def main():
 
     for nq in args.nq:
         q = bench.unit_queries(nq, args.dims)
-        for slab, growth, dbg, rega in [(s_, g_, d_, r_) for s_ in args.slab_mb for g_ in args.growth for d_ in args.debug
-                                        for r_ in args.rega]:
+        for slab, growth, dbg, rega, first in [(s_, g_, d_, r_, f_) for s_ in args.slab_mb for g_ in args.growth
+                                               for d_ in args.debug for r_ in args.rega for f_ in args.first]:
             eng.setTuning("batch_slab_mb", slab)
+            if first:
+                eng.setTuning("batch_first", first)
             if rega >= 0:
                 eng.setTuning("batch_rega", rega)
             eng.setTuning("batch_debug", dbg)
@@ -93,7 +96,7 @@ def main():
             if rank == 0:
                 chk = hashlib.sha256(np.ascontiguousarray(ids).tobytes() + np.ascontiguousarray(scores).tobytes()).hexdigest()[:16]
                 print(json.dumps({"n_gpus": world, "rows": args.rows, "dims": args.dims, "nq": nq, "topk": args.topk,
-                                  "slab_mb": slab, "growth": eng.getTuning("batch_growth"), "debug": dbg, "rega": eng.getTuning("batch_rega"), "ms_per_batch": dt * 1e3, "ms_c_call": dt_call * 1e3, "qps_c_call": nq / dt_call,
+                                  "slab_mb": slab, "growth": eng.getTuning("batch_growth"), "debug": dbg, "first": eng.getTuning("batch_first"), "rega": eng.getTuning("batch_rega"), "ms_per_batch": dt * 1e3, "ms_c_call": dt_call * 1e3, "qps_c_call": nq / dt_call,
                                   "tflops_bf16_c_call": 2.0 * nq * (hi - lo) * args.dims / dt_call / 1e12, "qps": nq / dt,
                                   "tflops_bf16": 2.0 * nq * args.rows * args.dims / dt / 1e12,
                                   "fallbacks_rank0": eng.getTuning("batch_fallbacks") - fb0,

@@ -311,6 +311,7 @@ struct wax_hip_engine {
     std::atomic<int64_t> batch_mode{1};      // 0 = never use the MFMA path
     std::atomic<int64_t> batch_slab_mb{64};  // cap on slab size, in units of 16 384 rows
     std::atomic<int64_t> batch_growth{8};    // next slab = growth x rows seen so far
+    std::atomic<int64_t> batch_first{2048};  // rows of the dense first slab (<= kBatchFirstSlab)
     std::atomic<int64_t> batch_debug{0};     // timing experiments only (GemmArgs::debug)
     std::atomic<int64_t> batch_rega{1};      // register-resident-queries GEMM where it applies: 1 register staging, 2 LDS-DMA staging; 0 off
     std::atomic<uint64_t> st_batch_queries{0}, st_batch_fallbacks{0};
@@ -659,7 +660,7 @@ int batch_search_mfma(wax_hip_engine* e, const float* queries, uint32_t nq, int 
         // kp * s / rows_seen candidates per query, so "next slab = 3 x rows seen" keeps every list ~3*kp long.
         uint32_t s0 = 0;
         while (s0 < n) {
-            uint64_t want = (s0 == 0) ? kBatchFirstSlab : (uint64_t)e->batch_growth.load() * s0;
+            uint64_t want = (s0 == 0) ? (uint64_t)e->batch_first.load() : (uint64_t)e->batch_growth.load() * s0;
             if (want > max_slab) want = max_slab;
             want = (want + 127ull) & ~127ull;
             const uint32_t rows = (n - s0 < want) ? n - s0 : (uint32_t)want;
@@ -1518,6 +1519,7 @@ int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value) {
     else if (k == "batch_mode") e->batch_mode = value;
     else if (k == "batch_rega") e->batch_rega = value;
     else if (k == "batch_debug") e->batch_debug = value;
+    else if (k == "batch_first") { if (value < 128 || value > kBatchFirstSlab || value % 128) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_first must be a multiple of 128 in 128..2048"); e->batch_first = value; }
     else if (k == "batch_growth") { if (value < 1 || value > 64) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_growth must be 1..64"); e->batch_growth = value; }
     else if (k == "batch_slab_mb") { if (value < 1 || value > 4096) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_slab_mb must be 1..4096"); e->batch_slab_mb = value; }
     else if (k == "streams") {
@@ -1553,6 +1555,7 @@ int64_t wax_hip_get_tuning(wax_hip_engine* e, const char* key) {
     if (k == "batch_rega") return e->batch_rega.load();
     if (k == "batch_slab_mb") return e->batch_slab_mb.load();
     if (k == "batch_growth") return e->batch_growth.load();
+    if (k == "batch_first") return e->batch_first.load();
     if (k == "batch_queries") return (int64_t)e->st_batch_queries.load();
     if (k == "batch_fallbacks") return (int64_t)e->st_batch_fallbacks.load();
     if (k == "slots") return e->max_slots;
