@@ -909,3 +909,34 @@ def test_batch_gemm_variants_agree(wax, dims):
                 assert np.array_equal(ids, ref[0]) and np.array_equal(scores, ref[1]) and np.array_equal(counts, ref[2])
     assert eng.getTuning("batch_fallbacks") <= 60
     eng.close()
+
+
+def test_batch_randomised_soak(wax):
+    """Seeded random sweep of the batched path: ragged corpus sizes (partial last tiles of every GEMM variant), query
+    counts that are not multiples of the 128/256-query groups, k up to the MFMA limit, every staging mode and several
+    slab schedules — each batch must equal the single-query answers bit for bit."""
+    rng = np.random.default_rng(424242)
+    for trial in range(20):
+        dims = int(rng.choice([128, 256, 384, 512, 768, 768, 384, 64, 192]))
+        metric = int(rng.choice([0, 0, 1, 2])) if dims in (64, 192) else int(rng.choice([0, 0, 1]))
+        n = int(rng.integers(90, 70000))
+        nq = int(rng.integers(16, 400))
+        k = int(rng.choice([1, 5, 10, 30, 80]))
+        corpus = oracle.gaussian_unit_rows(1000 + trial, n, dims)
+        if metric != 0:
+            corpus = corpus * rng.uniform(0.5, 1.5, (n, 1)).astype(np.float32)
+        eng = make_engine(wax, metric, dims, corpus)
+        eng.setTuning("batch_rega", int(rng.choice([1, 2])))
+        eng.setTuning("batch_growth", int(rng.choice([3, 8, 16])))
+        eng.setTuning("batch_first", int(rng.choice([512, 2048])))
+        queries = oracle.gaussian_unit_queries(nq, dims, seed=500 + trial)
+        before = eng.getTuning("batch_queries")
+        ids, scores, counts = eng.searchBatch(queries, k)
+        assert eng.getTuning("batch_queries") - before == nq, (trial, dims, n, nq, k)
+        for i in rng.permutation(nq)[:40]:
+            s_ids, s_scores = eng.searchArrays(queries[i], k)
+            ctx = (trial, dims, metric, n, nq, k, int(i))
+            assert counts[i] == len(s_ids), ctx
+            assert np.array_equal(ids[i, :counts[i]], s_ids), ctx
+            assert np.array_equal(scores[i, :counts[i]], s_scores), ctx
+        eng.close()
