@@ -61,6 +61,9 @@ for s in $STAGES; do
     firstslab)
       timeout 600 python tools/batch_bench.py --nq 256 1024 --first 512 1024 2048 --growth 8 12 16 > "$OUT/firstslab_bench.log" 2>&1; rc=$?
       timeout 300 python tools/batch_bench.py --rows 1000000 --dims 768 --nq 1024 --reps 3 --first 1024 2048 --growth 8 12 > "$OUT/firstslab768_bench.log" 2>&1 ;;
+    setprio)
+      timeout 600 python tools/batch_bench.py --nq 256 1024 --debug 0 32 0 32 > "$OUT/setprio_bench.log" 2>&1; rc=$?
+      timeout 300 python tools/batch_bench.py --rows 1000000 --dims 768 --nq 1024 --reps 3 --debug 0 32 0 32 > "$OUT/setprio768_bench.log" 2>&1 ;;
     hosttrace)
       WAX_HIP_BATCH_TRACE=1 timeout 300 python tools/batch_bench.py --nq 256 1024 --reps 3 > "$OUT/hosttrace.log" 2>&1; rc=$? ;;
     pingpong)

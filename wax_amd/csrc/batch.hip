@@ -497,6 +497,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
     // (~25 % of a tile's issue slots) hides under MFMAs instead of idling the pipe for both waves at once.
     const bool late = wave >= 4 && !(a.debug & 16u);   // debug bit4: every wave in the same order
     const bool dbg_noload = (a.debug & 1u) != 0, dbg_nomfma = (a.debug & 2u) != 0;  // timing experiments only
+    const bool prio = (a.debug & 32u) == 0;            // s_setprio 1 around the MFMA stream (+2-3 % at Q = 1024); debug bit5 turns it off
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
@@ -520,6 +521,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
             fb0[i] = *reinterpret_cast<const u32x4*>(b0 + i * 32);
             fb1[i] = *reinterpret_cast<const u32x4*>(b1 + i * 32);
         }
+        if (prio) __builtin_amdgcn_s_setprio(1);   // the SIMD's other wave is in its selection: MFMA issue first
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -531,6 +533,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], __builtin_bit_cast(bf16x8, fb1[ks % RING]), acc1, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (prio) __builtin_amdgcn_s_setprio(0);
     };
 
     // Fused selection on the accumulators of `tile`: C[query][row], col = lane & 31 = corpus row,
@@ -727,6 +730,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_ksplit_kernel(GemmArgs a, u
         u32x4 fb[RING];
 #pragma unroll
         for (int i = 0; i < AHEAD && i < KS; ++i) fb[i] = *reinterpret_cast<const u32x4*>(b0 + i * 32);
+        if (!(a.debug & 32u)) __builtin_amdgcn_s_setprio(1);   // the pair's other wave is selecting: MFMA issue first (+3 %)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -735,6 +739,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_ksplit_kernel(GemmArgs a, u
             else a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], __builtin_bit_cast(bf16x8, fb[ks % RING]), a0, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (!(a.debug & 32u)) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = a0[r] + a1[r];
     };
