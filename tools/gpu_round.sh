@@ -64,6 +64,12 @@ for s in $STAGES; do
     setprio)
       timeout 600 python tools/batch_bench.py --nq 256 1024 --debug 0 32 0 32 > "$OUT/setprio_bench.log" 2>&1; rc=$?
       timeout 300 python tools/batch_bench.py --rows 1000000 --dims 768 --nq 1024 --reps 3 --debug 0 32 0 32 > "$OUT/setprio768_bench.log" 2>&1 ;;
+    trace1m)
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d "$OUT/prof_1m" -o g -- \
+          python "$R/bench.py" --gpus 1 --rows ${WAX_ROWS:-1000000} --steps 60 --warmup 10 --no-cpu-baseline > "$OUT/trace1m_bench.json" 2> "$OUT/trace1m.err"); rc=$?
+      f=$(find "$OUT/prof_1m" -name "*kernel_trace.csv" | head -1)
+      [ -n "$f" ] && python "$R/tools/trace_tail.py" "$f" 40 > "$OUT/trace1m_tail.csv" 2>/dev/null
+      find "$OUT/prof_1m" -name "*kernel_trace.csv" -delete 2>/dev/null ;;
     hosttrace)
       WAX_HIP_BATCH_TRACE=1 timeout 300 python tools/batch_bench.py --nq 256 1024 --reps 3 > "$OUT/hosttrace.log" 2>&1; rc=$? ;;
     pingpong)

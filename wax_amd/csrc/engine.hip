@@ -279,6 +279,7 @@ struct wax_hip_engine {
     // other (each one owns the whole HBM pipe and its HIP-event duration stays meaningful) while
     // the merge kernel, the query upload and the result write of neighbouring queries do overlap.
     hipEvent_t scan_done = nullptr;
+    hipEvent_t chain_event = nullptr;  // event the next chained scan waits on: scan_done or the last scan's end-of-kernel timing event
     bool scan_done_valid = false;
     std::mutex chain_mu;
 
@@ -352,8 +353,10 @@ int alloc_slot(wax_hip_engine* e, Slot** out) {
         return fail(code, msg);
     };
     hipError_t err;
-    if ((err = hipEventCreate(&s->ev0)) != hipSuccess) return bail(WAX_HIP_ERR_ALLOC, "event", err);
-    if ((err = hipEventCreate(&s->ev1)) != hipSuccess) return bail(WAX_HIP_ERR_ALLOC, "event", err);
+    // kernel-timing events: device-scope release (no system-scope cache flush folded into the interval or into the
+    // gap before the next scan); ev_done is what the host waits on for results in pinned memory: default (system) scope
+    if ((err = hipEventCreateWithFlags(&s->ev0, hipEventReleaseToDevice)) != hipSuccess) return bail(WAX_HIP_ERR_ALLOC, "event", err);
+    if ((err = hipEventCreateWithFlags(&s->ev1, hipEventReleaseToDevice)) != hipSuccess) return bail(WAX_HIP_ERR_ALLOC, "event", err);
     if ((err = hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming)) != hipSuccess) return bail(WAX_HIP_ERR_ALLOC, "event", err);
     const size_t qbytes = (size_t)e->dims * sizeof(float);
     if ((err = hipMalloc(&s->d_query, qbytes)) != hipSuccess) return bail(WAX_HIP_ERR_ALLOC, "transient query buffer", err);
@@ -503,7 +506,7 @@ int enqueue_scan(wax_hip_engine* e, const float* d_query, float q_norm, int k_ef
     std::unique_lock<std::mutex> chain_guard(e->chain_mu, std::defer_lock);
     if (chain) {
         chain_guard.lock();
-        if (e->scan_done_valid) HIP_TRY(hipStreamWaitEvent(stream, e->scan_done, 0), WAX_HIP_ERR_INTERNAL, "scan chain wait");
+        if (e->scan_done_valid) HIP_TRY(hipStreamWaitEvent(stream, e->chain_event, 0), WAX_HIP_ERR_INTERNAL, "scan chain wait");
     }
     if (fused) {
         const int cap = k_eff <= 64 ? 128 : 256;
@@ -512,7 +515,14 @@ int enqueue_scan(wax_hip_engine* e, const float* d_query, float q_norm, int k_ef
                 WAX_HIP_ERR_INTERNAL, "scan kernel launch");
         if (ev1) HIP_TRY(hipEventRecord(ev1, stream), WAX_HIP_ERR_INTERNAL, "event record");
         if (chain_guard.owns_lock()) {
-            HIP_TRY(hipEventRecord(e->scan_done, stream), WAX_HIP_ERR_INTERNAL, "scan chain record");
+            // the next scan (on the other stream) starts when this one ends: its end-of-kernel timing event doubles
+            // as the chain event when kernels are timed — every packet between two scans costs microseconds
+            if (ev1) {
+                e->chain_event = ev1;
+            } else {
+                HIP_TRY(hipEventRecord(e->scan_done, stream), WAX_HIP_ERR_INTERNAL, "scan chain record");
+                e->chain_event = e->scan_done;
+            }
             e->scan_done_valid = true;
             chain_guard.unlock();
         }
@@ -787,7 +797,7 @@ int wax_hip_engine_create(uint8_t metric, uint32_t dims, int device_id, wax_hip_
         if (err != hipSuccess) rc = fail(WAX_HIP_ERR_ALLOC, std::string("Failed to allocate sink: ") + hipGetErrorString(err));
     }
     if (rc == WAX_HIP_OK) {
-        hipError_t err = hipEventCreateWithFlags(&e->scan_done, hipEventDisableTiming);
+        hipError_t err = hipEventCreateWithFlags(&e->scan_done, hipEventDisableTiming | hipEventReleaseToDevice);
         if (err != hipSuccess) rc = fail(WAX_HIP_ERR_ALLOC, std::string("Failed to create event: ") + hipGetErrorString(err));
     }
     for (int i = 0; i < kMaxStreams && rc == WAX_HIP_OK; ++i) {
@@ -1267,8 +1277,8 @@ int wax_hip_search_shard_device(wax_hip_engine* e, const float* query, uint32_t 
                 hipError_t err = hipMalloc(&e->ring_d_query[r], (size_t)e->dims * sizeof(float));
                 if (err == hipSuccess) err = hipHostMalloc(&e->ring_h_query[r], (size_t)e->dims * sizeof(float), hipHostMallocDefault);
                 if (err == hipSuccess) err = hipMalloc(&e->ring_d_partials[r], (size_t)MAX_GRID_BLOCKS * FUSED_MAX_K * sizeof(int64_t));
-                if (err == hipSuccess) err = hipEventCreate(&e->ring_ev0[r]);
-                if (err == hipSuccess) err = hipEventCreate(&e->ring_ev1[r]);
+                if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ring_ev0[r], hipEventReleaseToDevice);
+                if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ring_ev1[r], hipEventReleaseToDevice);
                 if (err != hipSuccess) { rc = fail(WAX_HIP_ERR_ALLOC, std::string("Failed to allocate shard scratch: ") + hipGetErrorString(err)); break; }
             }
         }
