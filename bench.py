@@ -112,6 +112,8 @@ def cpu_baseline(torch, args, dev, queries):
 
 def main():
     args = parse_args()
+    # RCCL / CUDA-tensor IPC on this driver stack needs dmabuf IPC (the image exports it; keep it if launched bare)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
 
@@ -130,10 +132,25 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if use_rccl:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-            probe_t = torch.ones(1, device=dev)
-            dist.all_reduce(probe_t)  # fail here, loudly, if RCCL cannot talk across the node
-            assert int(probe_t.item()) == world
+            import datetime
+            try:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev,
+                                        timeout=datetime.timedelta(seconds=180))
+                probe_t = torch.ones(1, device=dev)
+                dist.all_reduce(probe_t)  # fail here if RCCL cannot talk across the node
+                assert int(probe_t.item()) == world
+            except Exception as exc:  # noqa: BLE001 - an unusable RCCL must not cost the whole measurement
+                # every rank sees the same failure (IPC / topology problems are node-wide): fall back to the host
+                # exchange over gloo and SAY SO in the JSON line (config.exchange)
+                log(f"[bench] rank {rank}: RCCL unavailable ({type(exc).__name__}: {exc}); falling back to --exchange host")
+                try:
+                    if dist.is_initialized():
+                        dist.destroy_process_group()
+                except Exception:  # noqa: BLE001
+                    pass
+                use_rccl = False
+                os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+                dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
@@ -179,7 +196,7 @@ def main():
             return eng.collect(t, k)
     else:
         searcher = sharded.ShardedSearcher(eng, rank, world, k, depth=args.depth, n_streams=2,
-                                           host_merge=args.host_merge, exchange=args.exchange)
+                                           host_merge=args.host_merge, exchange="rccl" if use_rccl else "host")
 
         def submit(q):
             searcher.submit(q)
