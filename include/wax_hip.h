@@ -189,6 +189,11 @@ int wax_hip_search_shard_device(wax_hip_engine* e, const float* query, uint32_t 
 /* Stateless G*k -> k merge of gathered shard results on the current device:
  * d_out receives the k smallest keys of d_in[0..n), ascending. n <= 16384. */
 int wax_hip_merge_hits_device(const wax_hip_hit* d_in, uint32_t n, uint32_t k, wax_hip_hit* d_out, void* stream);
+/* Batched form for the sharded batched path (BASELINE config 5): d_in = [n_shards][nq][k_in] hits (the all-gather
+ * of every shard's wax_hip_search_batch_hits result, copied to the device), d_out = [nq][k]: per query the k
+ * smallest keys, ascending. One workgroup per query. n_shards * k_in <= 16384, k <= 192. */
+int wax_hip_merge_batch_hits_device(const wax_hip_hit* d_in, uint32_t n_shards, uint32_t nq, uint32_t k_in, uint32_t k,
+                                    wax_hip_hit* d_out, void* stream);
 /* Host-side tail of search (MetalVectorEngine.swift:592-611 + VectorMetric.swift:32-43):
  * drop padded / non-finite entries, distance -> score, emit (frameId, score). */
 int wax_hip_hits_to_results(uint8_t metric, const wax_hip_hit* hits, uint32_t n,

@@ -940,3 +940,42 @@ def test_batch_randomised_soak(wax):
             assert np.array_equal(ids[i, :counts[i]], s_ids), ctx
             assert np.array_equal(scores[i, :counts[i]], s_scores), ctx
         eng.close()
+
+
+def test_merge_batch_hits_device_equals_host_merge(wax):
+    """The sharded batched exchange (config 5): [shards][nq][k] gathered hits -> [nq][k], one workgroup per query,
+    must equal the numpy host merge and the single-engine answer."""
+    import torch
+    from wax_amd import sharded
+    dims, k, nq = 384, 10, 130
+    corpus = oracle.gaussian_unit_rows(0, 30000, dims)
+    ids = np.arange(30000, dtype=np.uint64) + 5
+    bounds = [0, 9984, 20096, 30000]
+    queries = oracle.gaussian_unit_queries(nq, dims, seed=77)
+    shard_hits = []
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        e = make_engine(wax, 0, dims, corpus[lo:hi], ids[lo:hi])
+        e.setRowBase(lo)
+        h, _ = e.searchBatchHits(queries, k)
+        shard_hits.append(h)
+        e.close()
+    gathered = np.stack(shard_hits)                                   # [3][nq][k][2]
+    host = sharded.merge_batch_hits_host(gathered, k)
+    dev = torch.device("cuda", 0)
+    g = torch.from_numpy(np.ascontiguousarray(gathered)).to(dev)
+    out = torch.empty((nq, k, 2), dtype=torch.int64, device=dev)
+    wax.HIPVectorEngine.mergeBatchHitsDevice(g.data_ptr(), 3, nq, k, k, out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), host)
+    whole = make_engine(wax, 0, dims, corpus, ids)
+    w_hits, _ = whole.searchBatchHits(queries, k)
+    assert np.array_equal(out.cpu().numpy(), w_hits)
+    # lists padded with KEY_PAD (a shard smaller than k) and k_in > k
+    padded = np.concatenate([gathered, np.full((3, nq, 3, 2), -1, dtype=np.int64)], axis=2)
+    padded[:, :, k:, 0] = sharded.KEY_PAD
+    g2 = torch.from_numpy(np.ascontiguousarray(padded)).to(dev)
+    out2 = torch.empty((nq, 4, 2), dtype=torch.int64, device=dev)
+    wax.HIPVectorEngine.mergeBatchHitsDevice(g2.data_ptr(), 3, nq, k + 3, 4, out2.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(out2.cpu().numpy(), host[:, :4])
+    whole.close()

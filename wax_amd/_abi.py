@@ -76,6 +76,8 @@ SIGNATURES: Dict[str, tuple] = {
     "wax_hip_search_filtered": (ctypes.c_int, [_engine_p, _f32p, ctypes.c_uint32, ctypes.c_int32, ctypes.c_int, _u64p,
                                                ctypes.c_uint64, ctypes.c_int, ctypes.c_float, _u64p, _f32p,
                                                ctypes.POINTER(ctypes.c_uint32)]),
+    "wax_hip_merge_batch_hits_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                                       ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]),
     "wax_hip_add_batch_device": (ctypes.c_int, [_engine_p, _u64p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32]),
     "wax_hip_remove": (ctypes.c_int, [_engine_p, ctypes.c_uint64]),
     "wax_hip_reserve": (ctypes.c_int, [_engine_p, ctypes.c_uint64]),

@@ -1320,6 +1320,17 @@ int wax_hip_merge_hits_device(const wax_hip_hit* d_in, uint32_t n, uint32_t k, w
     return WAX_HIP_OK;
 }
 
+int wax_hip_merge_batch_hits_device(const wax_hip_hit* d_in, uint32_t n_shards, uint32_t nq, uint32_t k_in, uint32_t k,
+                                    wax_hip_hit* d_out, void* stream) {
+    if (!d_in || !d_out) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null device buffer");
+    if (nq == 0) return WAX_HIP_OK;
+    if (k < 1 || k > (uint32_t)FUSED_MAX_K || n_shards == 0 || k_in == 0 || (uint64_t)n_shards * k_in > 16384u)
+        return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "merge_batch_hits: k must be 1..192 and n_shards * k_in <= 16384");
+    HIP_TRY(launch_merge_batch_hits(d_in, n_shards, nq, k_in, (int)k, d_out, static_cast<hipStream_t>(stream)),
+            WAX_HIP_ERR_INTERNAL, "merge kernel launch");
+    return WAX_HIP_OK;
+}
+
 int wax_hip_hits_to_results(uint8_t metric, const wax_hip_hit* hits, uint32_t n, uint64_t* out_ids, float* out_scores,
                             uint32_t* out_count) {
     if (!hits || !out_ids || !out_scores || !out_count) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null argument");

@@ -43,6 +43,9 @@ hipError_t launch_merge_keys(const int64_t* d_in, uint32_t n_in, int k, int kpad
                              uint32_t row_base, uint32_t n_rows, wax_hip_hit* d_out, int cap, hipStream_t stream);
 // gathered shard hits (n <= 16384) -> k smallest ascending (k <= 192)
 hipError_t launch_merge_hits(const wax_hip_hit* d_in, uint32_t n, int k, wax_hip_hit* d_out, hipStream_t stream);
+// Batched form: d_in = [n_shards][nq][kin] hits (an all-gather of per-shard batch results), d_out = [nq][k].
+hipError_t launch_merge_batch_hits(const wax_hip_hit* d_in, uint32_t n_shards, uint32_t nq, uint32_t kin, int k,
+                                   wax_hip_hit* d_out, hipStream_t stream);
 
 // General (any k <= 10000) selection over a distance buffer: exact k-th key by 8-pass radix
 // select on the 64-bit key, compaction, rank sort, id lookup. Work buffers are caller-owned.

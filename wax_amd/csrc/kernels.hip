@@ -456,20 +456,30 @@ hipError_t launch_merge_keys(const int64_t* d_in, uint32_t n_in, int k, int kpad
 
 // Gathered shard hits -> global top-k (SURVEY.md §8e "merge G*k -> k"). Select on keys, then
 // every input hit binary-searches the sorted winners to deposit its frame id.
-__global__ __launch_bounds__(MERGE_THREADS) void merge_hits_kernel(const wax_hip_hit* __restrict__ in, uint32_t n,
-                                                                   int k, wax_hip_hit* __restrict__ out) {
+// One workgroup per query: blockIdx.x = q of nq. Shard s's list for query q is in[(s * nq + q) * kin .. + kin),
+// out[q * k .. + k) receives the merged top-k (nq = 1, kin = n: one flat list, the single-query exchange).
+__global__ __launch_bounds__(MERGE_THREADS) void merge_hits_kernel(const wax_hip_hit* __restrict__ in, uint32_t n_shards,
+                                                                   uint32_t nq, uint32_t kin, int k,
+                                                                   wax_hip_hit* __restrict__ out_all) {
     constexpr int CAP = 256;
     __shared__ int64_t lds[MERGE_WAVES * CAP + MERGE_WAVES + FUSED_MAX_K];
     int* counts = reinterpret_cast<int*>(lds + MERGE_WAVES * CAP);
     int64_t* fin = lds + MERGE_WAVES * CAP + MERGE_WAVES;
     const int lane = lane_id();
     const int wave = (int)(threadIdx.x >> 6);
+    const uint32_t q = blockIdx.x;
+    const uint32_t n = n_shards * kin;
+    wax_hip_hit* __restrict__ out = out_all + (size_t)q * k;
+    auto src = [&](uint32_t i) -> const wax_hip_hit* {
+        const uint32_t s = i / kin, j = i - s * kin;
+        return in + ((size_t)s * nq + q) * kin + j;
+    };
     WaveTopK<CAP, false> tk;  // foreign keys: a misconfigured shard layout may offer a row twice
     tk.init(lds + wave * CAP, k);
     for (uint32_t base = wave * WAVE; base < n; base += MERGE_THREADS) {
         const uint32_t i = base + lane;
         const bool inb = i < n;
-        const int64_t key = inb ? in[i].key : KEY_PAD;
+        const int64_t key = inb ? src(i)->key : KEY_PAD;
         tk.push_wide(key, inb && key != KEY_PAD);
     }
     tk.finalize();
@@ -480,7 +490,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_hits_kernel(const wax_hip
     for (int t = (int)threadIdx.x; t < k; t += MERGE_THREADS)
         if (fin[t] == KEY_PAD) out[t] = wax_hip_hit{KEY_PAD, ID_PAD};
     for (uint32_t i = threadIdx.x; i < n; i += MERGE_THREADS) {
-        const wax_hip_hit h = in[i];
+        const wax_hip_hit h = *src(i);
         if (h.key == KEY_PAD) continue;
         int lo = 0, hi = k;
         while (lo < hi) {
@@ -493,7 +503,15 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_hits_kernel(const wax_hip
 
 hipError_t launch_merge_hits(const wax_hip_hit* d_in, uint32_t n, int k, wax_hip_hit* d_out, hipStream_t st) {
     if (k > FUSED_MAX_K || k < 1 || n > 16384) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(merge_hits_kernel, dim3(1), dim3(MERGE_THREADS), 0, st, d_in, n, k, d_out);
+    if (n == 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(merge_hits_kernel, dim3(1), dim3(MERGE_THREADS), 0, st, d_in, 1u, 1u, n, k, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_merge_batch_hits(const wax_hip_hit* d_in, uint32_t n_shards, uint32_t nq, uint32_t kin, int k,
+                                   wax_hip_hit* d_out, hipStream_t st) {
+    if (k > FUSED_MAX_K || k < 1 || nq == 0 || n_shards == 0 || kin == 0 || (uint64_t)n_shards * kin > 16384) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(merge_hits_kernel, dim3(nq), dim3(MERGE_THREADS), 0, st, d_in, n_shards, nq, kin, k, d_out);
     return hipGetLastError();
 }
 

@@ -295,6 +295,13 @@ class HIPVectorEngine:
         raise_for_status(rc)
 
     @staticmethod
+    def mergeBatchHitsDevice(in_ptr: int, n_shards: int, nq: int, k_in: int, k: int, out_ptr: int, stream: int = 0) -> None:  # noqa: N802
+        """[n_shards][nq][k_in] gathered hits (device) -> [nq][k] merged hits (device), one workgroup per query."""
+        rc = _abi.lib().wax_hip_merge_batch_hits_device(ctypes.c_void_p(in_ptr), int(n_shards), int(nq), int(k_in), int(k),
+                                                        ctypes.c_void_p(out_ptr), ctypes.c_void_p(stream))
+        raise_for_status(rc)
+
+    @staticmethod
     def mergeHitsDevice(in_ptr: int, n: int, k: int, out_ptr: int, stream: int = 0) -> None:  # noqa: N802
         rc = _abi.lib().wax_hip_merge_hits_device(ctypes.c_void_p(in_ptr), int(n), int(k), ctypes.c_void_p(out_ptr),
                                                   ctypes.c_void_p(stream))

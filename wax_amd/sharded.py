@@ -185,11 +185,16 @@ def sharded_search_batch(engine: HIPVectorEngine, queries, topK: int, world: int
     if world > 1:
         local = torch.from_numpy(np.ascontiguousarray(hits))
         if exchange == "rccl":
+            # device-side exchange: the shard's hits go back to HBM, RCCL all-gathers them, one workgroup per query
+            # merges world*kpad -> kpad (merge_hits_kernel), and only the merged [nq][kpad] hits come down
             dev = torch.device("cuda", engine.device)
             local = local.to(dev)
             out = torch.empty((world,) + tuple(local.shape), dtype=torch.int64, device=dev)
             dist.all_gather_into_tensor(out.view(-1), local.view(-1))
-            gathered = out.cpu().numpy()
+            merged = torch.empty((nq, kpad, 2), dtype=torch.int64, device=dev)
+            HIPVectorEngine.mergeBatchHitsDevice(out.data_ptr(), world, nq, kpad, kpad, merged.data_ptr(),
+                                                 torch.cuda.current_stream(dev).cuda_stream)
+            return decode_hits(engine.metric, merged.cpu().numpy())
         else:
             parts = [torch.empty_like(local) for _ in range(world)]
             dist.all_gather(parts, local)
