@@ -979,3 +979,72 @@ def test_merge_batch_hits_device_equals_host_merge(wax):
     torch.cuda.synchronize()
     assert np.array_equal(out2.cpu().numpy(), host[:, :4])
     whole.close()
+
+
+def test_mixed_entry_points_under_concurrency(wax):
+    """Every read entry point at once — single search, submit/collect with several tickets outstanding, batched
+    (MFMA) search, filtered search, serialize — against a writer that keeps appending: no deadlock (the readers hold
+    tickets while the writer queues for the exclusive lock), no torn result."""
+    dims, n0 = 384, 30000
+    corpus = oracle.gaussian_unit_rows(0, n0 + 3000, dims)
+    eng = make_engine(wax, 0, dims, corpus[:n0])
+    eng.setTuning("slots", 4)
+    queries = oracle.gaussian_unit_queries(64, dims, seed=3)
+    stop = threading.Event()
+    errors = []
+
+    def guard(fn):
+        def run():
+            try:
+                while not stop.is_set():
+                    fn()
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+        return run
+
+    def single():
+        ids, scores = eng.searchArrays(queries[1], 10)
+        assert len(ids) == 10 and np.all(np.diff(scores) <= 0)
+
+    def pipelined():
+        tickets = [eng.submit(queries[i], 10) for i in range(3)]
+        for t in tickets:
+            ids, scores = eng.collect(t, 10)
+            assert len(set(ids.tolist())) == 10
+
+    def batched():
+        ids, scores, counts = eng.searchBatch(queries, 10)
+        assert np.all(counts == 10) and np.all(np.diff(scores, axis=1) <= 0)
+
+    def filtered():
+        allow = np.arange(0, 20000, 7, dtype=np.uint64)
+        ids, scores = eng.searchFiltered(queries[2], 10, frameIds=allow, minScore=-1.0)
+        assert len(ids) == 10 and np.all(ids % 7 == 0)
+
+    def snapshot():
+        blob = eng.serialize()
+        assert blob[:4] == b"MV2V"
+
+    def writer():
+        try:
+            for i in range(n0, n0 + 3000, 100):
+                eng.addBatch(np.arange(i, i + 100, dtype=np.uint64), corpus[i:i + 100])
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    readers = [threading.Thread(target=guard(f)) for f in (single, pipelined, batched, filtered, snapshot, pipelined)]
+    w = threading.Thread(target=writer)
+    for t in readers:
+        t.start()
+    w.start()
+    w.join(timeout=120)
+    stop.set()
+    for t in readers:
+        t.join(timeout=60)
+    assert not w.is_alive() and not any(t.is_alive() for t in readers), "deadlock"
+    assert not errors, errors
+    assert eng.count == n0 + 3000
+    got = eng.searchArrays(queries[0], 10)
+    e_ids, e_scores, _, _ = oracle.search(0, corpus, np.arange(n0 + 3000, dtype=np.uint64), queries[0], 10)
+    assert_parity(got[0], got[1], e_ids, e_scores, ctx="after mixed concurrency")
+    eng.close()
