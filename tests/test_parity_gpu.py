@@ -1037,10 +1037,10 @@ def test_mixed_entry_points_under_concurrency(wax):
     for t in readers:
         t.start()
     w.start()
-    w.join(timeout=120)
+    w.join(timeout=60)
     stop.set()
     for t in readers:
-        t.join(timeout=60)
+        t.join(timeout=10)
     assert not w.is_alive() and not any(t.is_alive() for t in readers), "deadlock"
     assert not errors, errors
     assert eng.count == n0 + 3000

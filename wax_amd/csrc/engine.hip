@@ -383,7 +383,13 @@ void free_slot(Slot* s) {
 // acquireTransientBuffers (MetalVectorEngine.swift:84-113): reuse a pooled slot or create one.
 constexpr int kSlotBusy = 1;  // internal: try_only and every slot is in use
 
-int acquire_slot(wax_hip_engine* e, Slot** out, bool try_only = false) {
+// `holding`: the calling thread already owns tickets (= slots). It must never WAIT for a slot — two threads that each
+// hold half of the pool and want one more would wait for each other forever — so, like the reference's transient
+// buffer pool (MetalVectorEngine.swift:84-117: an empty pool allocates), it gets a freshly allocated slot beyond
+// `max_slots` (counted in transient_allocations; the slot stays pooled afterwards), up to kHardSlotCap.
+constexpr int kHardSlotCap = 256;
+
+int acquire_slot(wax_hip_engine* e, Slot** out, bool try_only = false, bool holding = false) {
     std::unique_lock<std::mutex> g(e->slot_mu);
     for (;;) {
         if (!e->free_slots.empty()) {
@@ -406,6 +412,19 @@ int acquire_slot(wax_hip_engine* e, Slot** out, bool try_only = false) {
             return WAX_HIP_OK;
         }
         if (try_only) return kSlotBusy;
+        if (holding) {
+            if ((int)e->all_slots.size() >= kHardSlotCap)
+                return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "too many outstanding search tickets (collect some first)");
+            Slot* s = nullptr;
+            int rc = alloc_slot(e, &s);
+            if (rc != WAX_HIP_OK) return rc;
+            s->index = (int)e->all_slots.size();
+            s->stream = e->streams[s->index % e->n_streams];
+            e->all_slots.push_back(s);
+            e->st_alloc++;
+            *out = s;
+            return WAX_HIP_OK;
+        }
         e->slot_cv.wait(g);
     }
 }
@@ -1033,7 +1052,7 @@ static int submit_impl(wax_hip_engine* e, const float* query, uint32_t dims, int
     int rc = WAX_HIP_OK;
     do {
         if (e->count == 0) {                               // :448 — an empty ticket, no GPU work
-            rc = acquire_slot(e, &s, try_only);
+            rc = acquire_slot(e, &s, try_only, g_outstanding[e] > 0);
             if (rc != WAX_HIP_OK) break;
             s->k_eff = 0; s->timed = false;
             break;
@@ -1048,7 +1067,7 @@ static int submit_impl(wax_hip_engine* e, const float* query, uint32_t dims, int
         }
         const int limit = clamp_topk(top_k);               // :450
         const int k_eff = (uint64_t)limit < e->count ? limit : (int)e->count;  // :451
-        rc = acquire_slot(e, &s, try_only);
+        rc = acquire_slot(e, &s, try_only, g_outstanding[e] > 0);
         if (rc != WAX_HIP_OK) break;
         s->k_eff = k_eff;
         s->timed = e->time_kernels.load() != 0;
