@@ -605,6 +605,37 @@ def test_batch_throughput_config3(wax):
     assert fb <= 3 * 26
 
 
+def test_batch_config5_shard_shape(wax):
+    """BASELINE config 5, one GPU's share of the 8-way sharded corpus: 1.25M x 768, 1024 queries (K-split
+    register-resident GEMM). Spot-checked against the single-query path; no certificate fallbacks on random data."""
+    import time
+    import torch
+    n, dims, nq, k = 1_250_000, 768, 1024, 10
+    dev = torch.device("cuda", 0)
+    eng = wax.HIPVectorEngine(dimensions=dims)
+    eng.reserve(n)
+    for lo, x in _device_corpus(torch, n, dims, dev):
+        eng.addBatchDevice(np.arange(lo, lo + x.shape[0], dtype=np.uint64), x)
+    eng.setRowBase(3_750_000)                         # as rank 3 of 8
+    queries = oracle.gaussian_unit_queries(nq, dims, seed=55)
+    hits, counts = eng.searchBatchHits(queries, k)    # builds the mirror
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        hits, counts = eng.searchBatchHits(queries, k)
+    dt = (time.perf_counter() - t0) / reps
+    fb = eng.getTuning("batch_fallbacks")
+    print(f"\n[config5 shard 1.25Mx768 Q=1024] {dt * 1e3:.2f} ms/batch = {nq / dt:.0f} q/s per GPU, "
+          f"{2 * nq * n * dims / dt / 1e12:.1f} TFLOP/s bf16, fallbacks so far {fb}")
+    assert np.all(counts == k) and np.all((hits[:, :, 0] & 0xFFFFFFFF) >= 3_750_000)
+    eng.setRowBase(0)
+    for i in (0, 511, 1023):
+        s_ids, s_scores = eng.searchArrays(queries[i], k)
+        assert np.array_equal(hits[i, :, 1].astype(np.uint64), s_ids)
+    assert fb == 0
+    eng.close()
+
+
 # ---------------------------------------------------------------------------
 # the N>1 bench path end to end on one GPU: two / three ranks share GPU 0 and exchange per-shard
 # top-k through the host (gloo) — RCCL itself refuses duplicate GPUs; everything else (shard bounds,
