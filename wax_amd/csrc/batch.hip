@@ -924,48 +924,76 @@ __global__ __launch_bounds__(SCAN_THREADS) void tighten_kernel(TightenArgs a) {
     const int wave = (int)(threadIdx.x >> 6);
     const uint32_t q = blockIdx.x;
     const int kp = a.kp;
-    uint32_t n_in = (a.dense != nullptr) ? a.dense_rows : a.cand_count[(size_t)q * CAND_COUNT_STRIDE];   // dense tile / counted list (incl. the best list)
+    // The kernel is a chain of memory round trips with little work in between (waves wait ~80 % of their cycles), so
+    // every load that does not depend on another one is issued up front: the list length, this thread's segment
+    // count and a speculative best-list entry go out together; the segment slots follow in one batch of 8.
     bool dropped = false;
-    if (a.dense == nullptr && n_in > a.cand_cap) {
-        dropped = true;
-        n_in = a.cand_cap;
-    }
-    if (a.nseg != 0u && n_in > a.seg_base) n_in = a.seg_base;                 // segmented: [0, n_in) is the best list only
     int64_t* __restrict__ mine = a.cand + (size_t)q * a.cand_cap;
-    const float* __restrict__ drow = (a.dense != nullptr) ? a.dense + (size_t)q * a.dense_ld : nullptr;
     WaveTopK<CAP> tk;
     tk.init(lds + wave * CAP, kp);
-    constexpr int LOADS = 4;
-    for (uint32_t base = 0; base < n_in; base += SCAN_THREADS * LOADS) {
-        int64_t keys[LOADS];
+    if (a.dense != nullptr) {
+        // first slab: a dense tile of <= 2048 approximate distances per query, 8 independent loads per thread
+        const float* __restrict__ drow = a.dense + (size_t)q * a.dense_ld;
+        constexpr int DLOADS = 8;
+        for (uint32_t base = 0; base < a.dense_rows; base += SCAN_THREADS * DLOADS) {
+            float v[DLOADS];
 #pragma unroll
-        for (int i = 0; i < LOADS; ++i) {
-            const uint32_t idx = base + i * SCAN_THREADS + threadIdx.x;
-            if (idx >= n_in) keys[i] = KEY_PAD;
-            else if (drow != nullptr) keys[i] = make_key(drow[idx], a.dense_row0 + idx);  // first slab: dense tile
-            else keys[i] = mine[idx];
-        }
+            for (int i = 0; i < DLOADS; ++i) {
+                const uint32_t idx = base + i * SCAN_THREADS + threadIdx.x;
+                v[i] = idx < a.dense_rows ? drow[idx] : 0.f;
+            }
 #pragma unroll
-        for (int i = 0; i < LOADS; ++i) tk.push_wide(keys[i], keys[i] != KEY_PAD);
-    }
-    // segmented survivors: thread t walks segments t, t + 256, ... (one GEMM workgroup each)
-    for (uint32_t sb = 0; sb < a.nseg; sb += SCAN_THREADS) {
-        const uint32_t seg = sb + threadIdx.x;
-        uint32_t c = (seg < a.nseg) ? a.seg_count[(size_t)seg * a.nq_pad + q] : 0u;
-        if (c > a.seg_slots) {
-            dropped = true;
-            c = a.seg_slots;
+            for (int i = 0; i < DLOADS; ++i) {
+                const uint32_t idx = base + i * SCAN_THREADS + threadIdx.x;
+                tk.push_wide(make_key(v[i], a.dense_row0 + idx), idx < a.dense_rows);
+            }
         }
-        const int64_t* __restrict__ sp = mine + a.seg_base + (size_t)seg * a.seg_slots;
-        // 8 slots per trip, loads independent: a segment is one or two cache lines written by another XCD's
-        // workgroup, so every dependent trip is an HBM round trip
-        constexpr uint32_t SLOTS = 8;
-        for (uint32_t j0 = 0; __any(j0 < c); j0 += SLOTS) {
+    } else if (a.nseg != 0u) {
+        // register-resident GEMMs: [0, n_best) is the previous best list, then one segment per GEMM workgroup
+        const uint32_t n_cnt = a.cand_count[(size_t)q * CAND_COUNT_STRIDE];
+        const uint32_t seg0 = threadIdx.x;
+        uint32_t c = (seg0 < a.nseg) ? a.seg_count[(size_t)seg0 * a.nq_pad + q] : 0u;
+        const int64_t best = (threadIdx.x < a.seg_base) ? mine[threadIdx.x] : KEY_PAD;     // speculative: valid below n_best
+        const uint32_t n_best = n_cnt < a.seg_base ? n_cnt : a.seg_base;
+        for (uint32_t sb = 0; sb < a.nseg; sb += SCAN_THREADS) {
+            const uint32_t seg = sb + threadIdx.x;
+            if (sb != 0u) c = (seg < a.nseg) ? a.seg_count[(size_t)seg * a.nq_pad + q] : 0u;
+            if (c > a.seg_slots) {
+                dropped = true;
+                c = a.seg_slots;
+            }
+            const int64_t* __restrict__ sp = mine + a.seg_base + (size_t)seg * a.seg_slots;
+            constexpr uint32_t SLOTS = 8;
             int64_t key[SLOTS];
 #pragma unroll
-            for (uint32_t u = 0; u < SLOTS; ++u) key[u] = (j0 + u < c) ? sp[j0 + u] : KEY_PAD;
+            for (uint32_t u = 0; u < SLOTS; ++u) key[u] = (u < c) ? sp[u] : KEY_PAD;
+            if (sb == 0u) tk.push_wide(best, threadIdx.x < n_best);
 #pragma unroll
-            for (uint32_t u = 0; u < SLOTS; ++u) tk.push_wide(key[u], j0 + u < c);
+            for (uint32_t u = 0; u < SLOTS; ++u) tk.push_wide(key[u], u < c);
+            for (uint32_t j0 = SLOTS; __any(j0 < c); j0 += SLOTS) {       // rare: more than 8 survivors in one segment
+#pragma unroll
+                for (uint32_t u = 0; u < SLOTS; ++u) key[u] = (j0 + u < c) ? sp[j0 + u] : KEY_PAD;
+#pragma unroll
+                for (uint32_t u = 0; u < SLOTS; ++u) tk.push_wide(key[u], j0 + u < c);
+            }
+        }
+    } else {
+        // LDS-tiled GEMM: one counted list per query (best list + appended survivors)
+        uint32_t n_in = a.cand_count[(size_t)q * CAND_COUNT_STRIDE];
+        if (n_in > a.cand_cap) {
+            dropped = true;
+            n_in = a.cand_cap;
+        }
+        constexpr int LOADS = 4;
+        for (uint32_t base = 0; base < n_in; base += SCAN_THREADS * LOADS) {
+            int64_t keys[LOADS];
+#pragma unroll
+            for (int i = 0; i < LOADS; ++i) {
+                const uint32_t idx = base + i * SCAN_THREADS + threadIdx.x;
+                keys[i] = idx < n_in ? mine[idx] : KEY_PAD;
+            }
+#pragma unroll
+            for (int i = 0; i < LOADS; ++i) tk.push_wide(keys[i], keys[i] != KEY_PAD);
         }
     }
     tk.finalize();
