@@ -155,7 +155,9 @@ int wax_hip_search(wax_hip_engine* e, const float* query, uint32_t dims, int32_t
 /* Pipelined form of the same call: submit enqueues H2D + kernels + D2H on one
  * of the engine's scratch slots and returns immediately with a ticket;
  * collect blocks on that slot and fills the outputs exactly like
- * wax_hip_search. Tickets must be collected exactly once, in any order. */
+ * wax_hip_search. Tickets must be collected exactly once, in any order. A thread
+ * that already holds tickets never waits for a scratch slot (it gets a fresh one,
+ * up to 256 outstanding), so pipelining callers cannot deadlock each other. */
 int wax_hip_search_submit(wax_hip_engine* e, const float* query, uint32_t dims, int32_t top_k, uint64_t* out_ticket);
 int wax_hip_search_collect(wax_hip_engine* e, uint64_t ticket,
                            uint64_t* out_ids, float* out_scores, uint32_t* out_count);
@@ -234,13 +236,16 @@ int wax_hip_stats(wax_hip_engine* e, wax_hip_stats_t* out);
  * distance-buffer + radix-select path even for small k), "stream_nt",
  * "reset_stats" (any value: zero the counters), "streams" (1..4 in-order streams the slots rotate over),
  * "batch_mode" (0 = never use the MFMA batched path), "batch_min" (smallest batch that uses it),
- * "batch_slab_mb", "batch_growth", "batch_first". get-only: "variant_count", "scan_grid", "fused_max_k", "batch_queries",
+ * "batch_slab_mb", "batch_growth", "batch_first" (slab schedule of the batched path), "batch_rega" (0 LDS-tiled GEMM
+ * only, 1 register-resident GEMM with register staging, 2 with LDS-DMA staging), "batch_debug" (timing experiments:
+ * results are NOT valid with bits 1/2/4/8 set). get-only: "variant_count", "scan_grid", "fused_max_k", "batch_queries",
  * "batch_fallbacks". */
 int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value);
 int64_t wax_hip_get_tuning(wax_hip_engine* e, const char* key);
 /* Times `iters` back-to-back launches of ONLY the scan kernel for `query`
- * with HIP events on the engine's stream; returns average ms per launch.
- * This is what bench.py's roofline.achieved is computed from. */
+ * with HIP events on the engine's stream; returns average ms per launch
+ * (kernel sweeps; bench.py's roofline uses the per-launch events of its timed
+ * region instead: "time_kernels" + wax_hip_stats). */
 int wax_hip_time_scan_kernel(wax_hip_engine* e, const float* query, uint32_t dims, int32_t top_k,
                              uint32_t iters, double* out_avg_ms);
 /* Pure streaming-read microbenchmark over the engine's own store (sum of all
