@@ -70,6 +70,8 @@ for s in $STAGES; do
       f=$(find "$OUT/prof_1m" -name "*kernel_trace.csv" | head -1)
       [ -n "$f" ] && python "$R/tools/trace_tail.py" "$f" 40 > "$OUT/trace1m_tail.csv" 2>/dev/null
       find "$OUT/prof_1m" -name "*kernel_trace.csv" -delete 2>/dev/null ;;
+    refharness)
+      timeout 300 python tools/reference_harness_bench.py > "$OUT/reference_harness.json" 2> "$OUT/reference_harness.err"; rc=$? ;;
     hosttrace)
       WAX_HIP_BATCH_TRACE=1 timeout 300 python tools/batch_bench.py --nq 256 1024 --reps 3 > "$OUT/hosttrace.log" 2>&1; rc=$? ;;
     pingpong)
