@@ -1079,3 +1079,66 @@ def test_mixed_entry_points_under_concurrency(wax):
     e_ids, e_scores, _, _ = oracle.search(0, corpus, np.arange(n0 + 3000, dtype=np.uint64), queries[0], 10)
     assert_parity(got[0], got[1], e_ids, e_scores, ctx="after mixed concurrency")
     eng.close()
+
+
+def test_staged_single_frame_appends(wax):
+    """add(frameId:vector:) stages the row on the host and the next reader uploads everything added since (the
+    discrete-memory analogue of the reference's unified-memory append, MetalVectorEngine.swift:330-357). Interleave
+    appends, upserts of staged and of already-uploaded rows, removals, batch adds, capacity growth, serialize and every
+    kind of reader; the store must always equal the sequentially built one."""
+    dims = 384
+    rng = np.random.default_rng(5)
+    pool = oracle.gaussian_unit_rows(77, 9000, dims)
+    eng = wax.HIPVectorEngine(metric=wax.VectorMetric.cosine, dimensions=dims)
+    model_ids, model_rows = [], {}
+
+    def model_add(i, v):
+        if i not in model_rows:
+            model_ids.append(i)
+        model_rows[i] = v
+
+    def check(ctx):
+        kind, info, vecs, ids = wax.VectorSerializer.decodeVecSegment(eng.serialize())
+        assert ids.tolist() == model_ids, ctx
+        assert np.array_equal(vecs, np.stack([model_rows[i] for i in model_ids])), ctx
+        q = pool[rng.integers(0, 9000)]
+        got = eng.searchArrays(q, 5)
+        e_ids, e_scores, _, _ = oracle.search(0, vecs, ids, q, 5)
+        assert_parity(got[0], got[1], e_ids, e_scores, ctx=ctx)
+
+    step = 0
+    for i in range(300):                                   # appends crossing several capacity doublings (64, 128, 256)
+        eng.add(i, pool[step]); model_add(i, pool[step]); step += 1
+    eng.add(5, pool[step]); model_add(5, pool[step]); step += 1            # upsert of a STAGED row
+    check("after staged appends")
+    eng.add(7, pool[step]); model_add(7, pool[step]); step += 1            # upsert of an UPLOADED row
+    for i in range(300, 320):
+        eng.add(i, pool[step]); model_add(i, pool[step]); step += 1
+    eng.remove(310); model_ids.remove(310); del model_rows[310]           # removal while rows are staged
+    eng.remove(3); model_ids.remove(3); del model_rows[3]
+    check("after remove with staged rows")
+    for i in range(320, 330):
+        eng.add(i, pool[step]); model_add(i, pool[step]); step += 1
+    b_ids = list(range(1000, 1100)) + [321, 2]             # batch add with staged rows in front, touching staged / uploaded ids
+    b_rows = pool[step:step + len(b_ids)]; step += len(b_ids)
+    eng.addBatch(b_ids, b_rows)
+    for i, v in zip(b_ids, b_rows):
+        model_add(i, v)
+    for i in range(330, 340):
+        eng.add(i, pool[step]); model_add(i, pool[step]); step += 1
+    ids_b, scores_b, counts_b = eng.searchBatch(pool[:40], 3)             # batched reader flushes too
+    f_ids, _ = eng.searchFiltered(pool[0], 3, frameIds=[339, 338, 1000])  # and the filtered one
+    assert set(f_ids.tolist()) == {339, 338, 1000}
+    check("after batch add")
+    blob = eng.serialize()
+    for i in range(5000, 5010):
+        eng.add(i, pool[step]); step += 1                  # staged rows ...
+    eng.deserialize(blob)                                  # ... are dropped with the store they belonged to
+    check("after deserialize")
+    many = 8 * 1024 * 1024 // (dims * 4) + 300             # more single adds than the staging area holds
+    base = 100000
+    for j in range(many):
+        v = pool[j % 9000]
+        eng.add(base + j, v); model_add(base + j, v)
+    check("after overflowing the staging area")
+    eng.close()

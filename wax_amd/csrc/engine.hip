@@ -318,6 +318,13 @@ struct wax_hip_engine {
     std::atomic<uint64_t> st_batch_queries{0}, st_batch_fallbacks{0};
     BatchWork batch;
     FilterWork filter;
+    // Write-combining of single-frame appends (the reference appends into a unified-memory buffer and the GPU simply
+    // sees it, MetalVectorEngine.swift:340-351; with discrete HBM the analogue is a pinned staging area that the NEXT
+    // reader — or a full staging area — uploads in one copy). The last `pend_rows` rows of [0, count) live only here.
+    float* h_pend = nullptr;                 // pinned, pend_cap rows x dims
+    uint64_t pend_cap = 0;
+    std::atomic<uint64_t> pend_rows{0};
+    std::mutex pend_mu;
 
     // stats
     std::atomic<uint64_t> st_searches{0}, st_rows{0}, st_bytes{0}, st_alloc{0}, st_reuse{0};
@@ -470,9 +477,27 @@ float query_norm(const float* q, uint32_t dims) {
     return (float)std::sqrt((s0 + s1) + (s2 + s3));
 }
 
+// Upload the staged appends. Callers hold the engine lock (shared or exclusive); readers may race each other here,
+// never a writer (staging is only filled under the exclusive lock). Rows >= count - pend_rows are beyond the n_rows of
+// every scan already in flight, so writing them concurrently with those scans is safe.
+int flush_pending(wax_hip_engine* e) {
+    if (e->pend_rows.load(std::memory_order_acquire) == 0) return WAX_HIP_OK;
+    std::unique_lock<std::mutex> g(e->pend_mu);
+    const uint64_t n = e->pend_rows.load(std::memory_order_relaxed);
+    if (n == 0) return WAX_HIP_OK;
+    const uint64_t first = e->count - n;
+    HIP_TRY(hipMemcpy(e->d_store + first * e->dims, e->h_pend, (size_t)n * e->dims * sizeof(float), hipMemcpyHostToDevice),
+            WAX_HIP_ERR_INTERNAL, "vector upload");
+    HIP_TRY(hipMemcpy(e->d_ids + first, e->ids.data() + first, (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice),
+            WAX_HIP_ERR_INTERNAL, "frame id upload");
+    e->pend_rows.store(0, std::memory_order_release);
+    return WAX_HIP_OK;
+}
+
 // resizeBuffersIfNeeded (MetalVectorEngine.swift:873-890): new slab + copy of the live rows.
 int resize_store(wax_hip_engine* e, uint64_t new_cap) {
     if (new_cap <= e->capacity) return WAX_HIP_OK;
+    { const int frc = flush_pending(e); if (frc != WAX_HIP_OK) return frc; }   // the copy below reads device rows
     float* ns = nullptr;
     uint64_t* ni = nullptr;
     const size_t row_bytes = (size_t)e->dims * sizeof(float);
@@ -852,6 +877,7 @@ void wax_hip_engine_destroy(wax_hip_engine* e) {
     for (int i = 0; i < kMaxStreams; ++i)
         if (e->streams[i]) (void)hipStreamDestroy(e->streams[i]);
     if (e->scan_done) (void)hipEventDestroy(e->scan_done);
+    if (e->h_pend) (void)hipHostFree(e->h_pend);
     for (int i = 0; i < kShardRing; ++i) {
         (void)hipFree(e->ring_d_query[i]);
         (void)hipHostFree(e->ring_h_query[i]);
@@ -902,9 +928,47 @@ int wax_hip_add_batch(wax_hip_engine* e, const uint64_t* frame_ids, const float*
     DeviceGuard g(e->device);
     WriteGuard w(e->lock);
     e->batch.mirror_valid = false;
-    int rc = reserve_rows(e, e->count + n);  // :379-380 (upper bound: every id new)
-    if (rc != WAX_HIP_OK) return rc;
     const size_t row_bytes = (size_t)e->dims * sizeof(float);
+    if (n == 1) {
+        // add(frameId:vector:) (:330-357): no device call at all on the common paths — the row goes to the staging
+        // area and reaches HBM with the next reader (one copy for all rows added since)
+        const int64_t existing = e->idmap.find(frame_ids[0]);
+        const uint64_t pend = e->pend_rows.load(std::memory_order_relaxed);
+        if (existing >= 0) {
+            if ((uint64_t)existing >= e->count - pend) {     // still staged: overwrite in place
+                std::memcpy(e->h_pend + ((uint64_t)existing - (e->count - pend)) * e->dims, rows, row_bytes);
+            } else {
+                HIP_TRY(hipMemcpy(e->d_store + (uint64_t)existing * e->dims, rows, row_bytes, hipMemcpyHostToDevice),
+                        WAX_HIP_ERR_INTERNAL, "vector upload");
+            }
+            return WAX_HIP_OK;
+        }
+        int rc1 = reserve_rows(e, e->count + 1);             // :341 (flushes before it reallocates)
+        if (rc1 != WAX_HIP_OK) return rc1;
+        if (!e->h_pend) {
+            uint64_t cap = (8ull << 20) / row_bytes;
+            if (cap < 1) cap = 1;
+            if (cap > 65536) cap = 65536;
+            HIP_TRY(hipHostMalloc(&e->h_pend, (size_t)cap * row_bytes, hipHostMallocDefault), WAX_HIP_ERR_ALLOC,
+                    "Failed to allocate append staging buffer");
+            e->pend_cap = cap;
+        }
+        if (e->pend_rows.load(std::memory_order_relaxed) == e->pend_cap) {
+            rc1 = flush_pending(e);
+            if (rc1 != WAX_HIP_OK) return rc1;
+        }
+        const uint64_t slot = e->pend_rows.load(std::memory_order_relaxed);
+        std::memcpy(e->h_pend + slot * e->dims, rows, row_bytes);
+        e->idmap.put(frame_ids[0], (uint32_t)e->count);
+        e->ids.push_back(frame_ids[0]);
+        e->count += 1;
+        e->pend_rows.store(slot + 1, std::memory_order_release);
+        return WAX_HIP_OK;
+    }
+    int rc = flush_pending(e);               // batch rows go straight to HBM; keep the staged ones in front of them
+    if (rc != WAX_HIP_OK) return rc;
+    rc = reserve_rows(e, e->count + n);      // :379-380 (upper bound: every id new)
+    if (rc != WAX_HIP_OK) return rc;
     // Sequential upsert semantics of :384-398; consecutive appends are flushed as one H2D copy.
     uint64_t run_start = 0, run_len = 0;  // pending append run: input rows [run_start, run_start+run_len)
     auto flush = [&]() -> int {
@@ -946,6 +1010,7 @@ int wax_hip_add_batch_device(wax_hip_engine* e, const uint64_t* frame_ids, const
     DeviceGuard g(e->device);
     WriteGuard w(e->lock);
     e->batch.mirror_valid = false;
+    { const int frc = flush_pending(e); if (frc != WAX_HIP_OK) return frc; }
     for (uint64_t i = 0; i < n; ++i)
         if (e->idmap.find(frame_ids[i]) >= 0)
             return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "add_batch_device: frame id " + std::to_string(frame_ids[i]) + " already present (append-only path)");
@@ -1015,6 +1080,7 @@ int wax_hip_remove(wax_hip_engine* e, uint64_t frame_id) {
     e->batch.mirror_valid = false;
     const int64_t idx = e->idmap.find(frame_id);
     if (idx < 0) return WAX_HIP_OK;                       // :426
+    { const int frc = flush_pending(e); if (frc != WAX_HIP_OK) return frc; }   // the shift below works on device rows
     const uint64_t after = e->count - 1 - (uint64_t)idx;  // :431
     if (after > 0) {
         if (!e->d_bounce)
@@ -1048,6 +1114,7 @@ static int submit_impl(wax_hip_engine* e, const float* query, uint32_t dims, int
     if (!e || !out_ticket) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine/ticket is null");
     DeviceGuard g(e->device);
     e->lock.lock_shared(g_outstanding[e] > 0);             // withReadLock (:447)
+    { const int frc = flush_pending(e); if (frc != WAX_HIP_OK) { e->lock.unlock_shared(); return frc; } }   // staged single-frame appends reach HBM here
     Slot* s = nullptr;
     int rc = WAX_HIP_OK;
     do {
@@ -1181,6 +1248,7 @@ static int search_batch_hits_impl(wax_hip_engine* e, const float* queries, uint3
         {
             DeviceGuard g(e->device);
             e->lock.lock_shared(g_outstanding[e] > 0);
+            { const int frc = flush_pending(e); if (frc != WAX_HIP_OK) { e->lock.unlock_shared(); return frc; } }
             if (e->row_base + e->count > 0x100000000ull) {
                 e->lock.unlock_shared();
                 return fail(WAX_HIP_ERR_CAPACITY, "row_base + count exceeds UInt32 row indices");
@@ -1289,6 +1357,7 @@ int wax_hip_search_shard_device(wax_hip_engine* e, const float* query, uint32_t 
     DeviceGuard g(e->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
     e->lock.lock_shared(g_outstanding[e] > 0);
+    { const int frc = flush_pending(e); if (frc != WAX_HIP_OK) { e->lock.unlock_shared(); return frc; } }
     int rc = WAX_HIP_OK;
     do {
         if (e->row_base + e->count > 0x100000000ull) { rc = fail(WAX_HIP_ERR_CAPACITY, "row_base + count exceeds UInt32 row indices"); break; }
@@ -1376,6 +1445,7 @@ int wax_hip_search_filtered(wax_hip_engine* e, const float* query, uint32_t dims
         DeviceGuard g(e->device);
         e->lock.lock_shared(g_outstanding[e] > 0);
         struct Unlock { RWLock& l; ~Unlock() { l.unlock_shared(); } } unlock{e->lock};
+        { const int frc = flush_pending(e); if (frc != WAX_HIP_OK) return frc; }
         // allowed frame ids -> local rows, ascending and unique (row order is the tie-break order of every path)
         std::vector<uint32_t> rows;
         rows.reserve((size_t)n_allow);
@@ -1456,6 +1526,7 @@ int wax_hip_serialize(wax_hip_engine* e, uint8_t** out_bytes, size_t* out_len) {
     if (!e || !out_bytes || !out_len) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null argument");
     DeviceGuard g(e->device);
     e->lock.lock_shared(g_outstanding[e] > 0);  // withReadLock (:683)
+    { const int frc = flush_pending(e); if (frc != WAX_HIP_OK) { e->lock.unlock_shared(); return frc; } }
     const uint64_t n = e->count;
     const uint64_t vec_bytes = n * (uint64_t)e->dims * 4ull;  // :697
     const uint64_t id_bytes = n * 8ull;                       // :707
@@ -1512,6 +1583,7 @@ int wax_hip_deserialize(wax_hip_engine* e, const uint8_t* data, size_t len) {
     DeviceGuard g(e->device);
     WriteGuard w(e->lock);  // withWriteLock (:717)
     e->batch.mirror_valid = false;
+    e->pend_rows.store(0, std::memory_order_release);   // the store is replaced wholesale: staged appends are dropped with it
     // :790-792 — capacity only grows
     int rc = resize_store(e, n > e->capacity ? n : e->capacity);
     if (rc != WAX_HIP_OK) return rc;
@@ -1616,6 +1688,7 @@ int wax_hip_time_scan_kernel(wax_hip_engine* e, const float* query, uint32_t dim
     if (iters == 0) iters = 1;
     DeviceGuard g(e->device);
     e->lock.lock_shared(g_outstanding[e] > 0);
+    { const int frc = flush_pending(e); if (frc != WAX_HIP_OK) { e->lock.unlock_shared(); return frc; } }
     Slot* s = nullptr;
     int rc = WAX_HIP_OK;
     do {
@@ -1655,6 +1728,7 @@ int wax_hip_time_stream_read(wax_hip_engine* e, uint32_t iters, double* out_avg_
     if (iters == 0) iters = 1;
     DeviceGuard g(e->device);
     e->lock.lock_shared(g_outstanding[e] > 0);
+    { const int frc = flush_pending(e); if (frc != WAX_HIP_OK) { e->lock.unlock_shared(); return frc; } }
     Slot* s = nullptr;
     int rc = WAX_HIP_OK;
     do {
