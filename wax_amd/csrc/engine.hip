@@ -17,6 +17,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kernels.h"
@@ -1448,13 +1449,49 @@ int wax_hip_search_filtered(wax_hip_engine* e, const float* query, uint32_t dims
         { const int frc = flush_pending(e); if (frc != WAX_HIP_OK) return frc; }
         // allowed frame ids -> local rows, ascending and unique (row order is the tie-break order of every path)
         std::vector<uint32_t> rows;
-        rows.reserve((size_t)n_allow);
-        for (uint64_t i = 0; i < n_allow; ++i) {
-            const int64_t r = e->idmap.find(allow_frame_ids[i]);
-            if (r >= 0) rows.push_back((uint32_t)r);
+        if (n_allow < 4096 || n_allow < e->count / 64) {
+            rows.reserve((size_t)n_allow);
+            for (uint64_t i = 0; i < n_allow; ++i) {
+                const int64_t r = e->idmap.find(allow_frame_ids[i]);
+                if (r >= 0) rows.push_back((uint32_t)r);
+            }
+            std::sort(rows.begin(), rows.end());
+            rows.erase(std::unique(rows.begin(), rows.end()), rows.end());
+        } else {
+            // long lists: the hash probes are cache misses (~60 ns each) and a sort of the rows would cost as much
+            // again, so the probes are spread over a few threads and the rows are marked in a bitmap, which hands
+            // them back ascending and unique for free
+            std::vector<uint64_t> bits((size_t)((e->count + 63) / 64), 0ull);
+            unsigned hw = std::thread::hardware_concurrency();
+            unsigned nt = n_allow >= 65536 ? (hw > 16 ? 16u : (hw ? hw : 1u)) : 1u;
+            auto probe = [&](uint64_t lo, uint64_t hi) {
+                for (uint64_t i = lo; i < hi; ++i) {
+                    const int64_t r = e->idmap.find(allow_frame_ids[i]);
+                    if (r >= 0) __atomic_fetch_or(&bits[(size_t)(r >> 6)], 1ull << (r & 63), __ATOMIC_RELAXED);
+                }
+            };
+            if (nt <= 1) {
+                probe(0, n_allow);
+            } else {
+                std::vector<std::thread> pool;
+                const uint64_t chunk = (n_allow + nt - 1) / nt;
+                for (unsigned t = 0; t < nt; ++t) {
+                    const uint64_t lo = (uint64_t)t * chunk, hi = lo + chunk < n_allow ? lo + chunk : n_allow;
+                    if (lo < hi) pool.emplace_back(probe, lo, hi);
+                }
+                for (auto& th : pool) th.join();
+            }
+            uint64_t m_est = 0;
+            for (uint64_t w : bits) m_est += (uint64_t)__builtin_popcountll(w);
+            rows.reserve((size_t)m_est);
+            for (size_t wi = 0; wi < bits.size(); ++wi) {
+                uint64_t w = bits[wi];
+                while (w) {
+                    rows.push_back((uint32_t)(wi * 64 + (size_t)__builtin_ctzll(w)));
+                    w &= w - 1;
+                }
+            }
         }
-        std::sort(rows.begin(), rows.end());
-        rows.erase(std::unique(rows.begin(), rows.end()), rows.end());
         const uint64_t m = rows.size();
         if (m == 0) return WAX_HIP_OK;
         std::vector<uint64_t> ids(m);
