@@ -106,6 +106,28 @@ public actor HIPVectorEngine {
         }
     }
 
+    /// Many queries in one call (`wax_hip_search_batch`): from 16 queries up the scan runs as a bf16 MFMA GEMM with an
+    /// exact f32 re-score; every answer is certified exact or re-run on the single-query path, so the results equal
+    /// `vectors.count` calls of `search(vector:topK:)`. For callers with several recalls pending.
+    public func searchBatch(vectors: [[Float]], topK: Int) async throws -> [[(frameId: UInt64, score: Float)]] {
+        guard !vectors.isEmpty else { return [] }
+        for v in vectors where v.count != dimensions {
+            throw WaxError.encodingError(reason: "vector dimension mismatch: expected \(dimensions), got \(v.count)")
+        }
+        let h = handle, d = UInt32(dimensions), nq = vectors.count
+        let cap = max(1, min(max(1, min(topK, 10_000)), max(Int(wax_hip_count(h)), 1)))
+        let flat = vectors.flatMap { $0 }
+        return try await io.run {
+            var ids = [UInt64](repeating: 0, count: nq * cap)
+            var scores = [Float](repeating: 0, count: nq * cap)
+            var counts = [UInt32](repeating: 0, count: nq)
+            try Self.check(flat.withUnsafeBufferPointer { q in
+                wax_hip_search_batch(h, q.baseAddress, UInt32(nq), d, Int32(clamping: topK), &ids, &scores, &counts)
+            })
+            return (0..<nq).map { i in (0..<Int(counts[i])).map { (frameId: ids[i * cap + $0], score: scores[i * cap + $0]) } }
+        }
+    }
+
     /// The vector lane's candidate filters on the device (`passesFrameFilter`, UnifiedSearch.swift:1241-1258):
     /// the best `topK` among the frames of `allowlist` (FrameFilter.frameIds), minus results below `minScore`.
     /// With this, UnifiedSearch no longer needs the 3x `candidateLimit` over-fetch (:1195-1200) for allow-listed requests.
