@@ -132,6 +132,34 @@ REFERENCE_CASES = {
             ],
         },
         {
+            # vector lane of Wax.search with FrameFilter(frameIds:) — UnifiedSearch asks the engine for
+            # candidateLimit = max(topK, min(3*topK, 1000)) (UnifiedSearch.swift:1195-1200) and post-filters
+            # (passesFrameFilter, :1241-1258); a pre-filtering engine must return the same set here
+            "name": "filtersAllowResultsBeyondTopK (engine part)",
+            "source": T + "UnifiedSearchTests.swift:133-158",
+            "metric": "cosine", "dimensions": 2,
+            "ops": [
+                {"op": "add", "frameId": 0, "vector": [1.0, 0.0]},
+                {"op": "add", "frameId": 1, "vector": [0.9, 0.1]},
+                {"op": "add", "frameId": 2, "vector": [0.1, 0.9]},
+                {"op": "add", "frameId": 3, "vector": [0.0, 1.0]},
+                {"op": "search_filtered", "vector": [1.0, 0.0], "topK": 2, "allow": [2, 3],
+                 "expect": {"idSetEquals": [2, 3]}},
+            ],
+        },
+        {
+            # engine part of the session test: an add followed by a remove must not survive the serialized index
+            "name": "vectorSearchSessionAddThenRemoveBeforeCommitPersistsRemoval (engine part)",
+            "source": T + "VectorSearchEngineTests.swift:78-99",
+            "metric": "cosine", "dimensions": 2,
+            "ops": [
+                {"op": "add", "frameId": 0, "vector": [1.0, 0.0]},
+                {"op": "remove", "frameId": 0},
+                {"op": "serialize_deserialize_into_new_engine", "expect": {}},
+                {"op": "search", "vector": [1.0, 0.0], "topK": 10, "expect": {"notContains": [0]}},
+            ],
+        },
+        {
             "name": "metalSearchReusesTransientBuffers",
             "source": T + "MetalVectorEnginePoolTests.swift:6-20",
             "metric": "cosine", "dimensions": 2,

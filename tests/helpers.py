@@ -63,6 +63,15 @@ class OracleEngine:
             return np.zeros((0, self.dimensions), dtype=np.float32)
         return np.stack(self.rows).astype(np.float32)
 
+    def searchFilteredHits(self, vector, topK, allow):
+        """The reference's vector lane under FrameFilter(frameIds:): candidateLimit results from the engine
+        (UnifiedSearch.swift:1195-1200), post-filtered by the allow-list (:1250), first topK kept."""
+        if topK <= 0:
+            return []
+        limit = max(topK, min(topK * 3, 1000))
+        allowed = set(int(a) for a in allow)
+        return [h for h in self.search(vector, limit) if h[0] in allowed][:topK]
+
     def search(self, vector, topK):
         if self.count == 0:
             return []
@@ -133,6 +142,13 @@ def run_reference_case(case, make_engine, normalize):
             assert scores == sorted(scores, reverse=True), (case["name"], scores)
             if "save" in op:
                 saved[op["save"]] = hits
+        elif kind == "search_filtered":
+            hits = eng.searchFilteredHits(op["vector"], op["topK"], op["allow"])
+            ids = [h[0] for h in hits]
+            if "idSetEquals" in exp:
+                assert set(ids) == set(exp["idSetEquals"]), (case["name"], ids)
+            scores = [h[1] for h in hits]
+            assert scores == sorted(scores, reverse=True), (case["name"], scores)
         elif kind == "compare_first_scores":
             a, b = saved[op["a"]][0][1], saved[op["b"]][0][1]
             assert abs(a - b) < op["tolerance"], (a, b)

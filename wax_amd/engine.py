@@ -232,6 +232,11 @@ class HIPVectorEngine:
         raise_for_status(rc)
         return ids[:got.value].copy(), scores[:got.value].copy()
 
+    def searchFilteredHits(self, vector, topK: int, allow) -> List[Tuple[int, float]]:  # noqa: N802,N803
+        """searchFiltered as [(frameId, score)] (the shape the transcribed reference cases assert on)."""
+        ids, scores = self.searchFiltered(vector, topK, frameIds=allow)
+        return [(int(i), float(s)) for i, s in zip(ids, scores)]
+
     def search(self, vector, topK: int) -> List[Tuple[int, float]]:  # noqa: N803
         """VectorSearchEngine.search(vector:topK:) -> [(frameId, score)] best first (:446-627)."""
         ids, scores = self.searchArrays(vector, topK)
