@@ -540,8 +540,15 @@ def test_batch_edge_shapes(wax):
     # k above the MFMA limit and batches below batch_min fall back to pipelined single-query scans
     before = eng.getTuning("batch_queries")
     _batch_vs_single(eng, oracle.gaussian_unit_queries(20, dims), 100)
+    eng.setTuning("batch_min", 16)
     _batch_vs_single(eng, oracle.gaussian_unit_queries(5, dims), 10)
     assert eng.getTuning("batch_queries") == before
+    # default: small batches take the MFMA path when one pass over the bf16 mirror beats nq scans of the f32 store
+    eng.setTuning("batch_min", 2)
+    _batch_vs_single(eng, oracle.gaussian_unit_queries(8, dims, seed=42), 10)      # 30 000 rows: 8 scans > one GEMM pass
+    assert eng.getTuning("batch_queries") == before + 8
+    _batch_vs_single(eng, oracle.gaussian_unit_queries(2, dims, seed=43), 10)      # 2 scans are cheaper: loop path
+    assert eng.getTuning("batch_queries") == before + 8
     # fewer rows than k': every row is re-scored, certificate is trivially true
     small = make_engine(wax, 0, dims, corpus[:50])
     ids, scores, counts = _batch_vs_single(small, oracle.gaussian_unit_queries(40, dims), 10)

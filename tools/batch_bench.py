@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--growth", type=int, nargs="+", default=[0], help="slab growth factors to sweep (0 = library default)")
     ap.add_argument("--debug", type=int, nargs="+", default=[0], help="batch_debug bit masks to sweep (timing experiments)")
     ap.add_argument("--first", type=int, nargs="+", default=[0], help="rows of the dense first slab to sweep (0 = library default)")
+    ap.add_argument("--batch-min", type=int, nargs="+", default=[-1], help="batch_min values to sweep (-1 = library default)")
     ap.add_argument("--rega", type=int, nargs="+", default=[-1], help="batch_rega modes to sweep (-1 = library default)")
     ap.add_argument("--exchange", choices=["rccl", "host"], default="rccl")
     args = ap.parse_args()
@@ -67,8 +68,11 @@ def main():
 
     for nq in args.nq:
         q = bench.unit_queries(nq, args.dims)
-        for slab, growth, dbg, rega, first in [(s_, g_, d_, r_, f_) for s_ in args.slab_mb for g_ in args.growth
-                                               for d_ in args.debug for r_ in args.rega for f_ in args.first]:
+        for slab, growth, dbg, rega, first, bmin in [(s_, g_, d_, r_, f_, m_) for s_ in args.slab_mb for g_ in args.growth
+                                                     for d_ in args.debug for r_ in args.rega for f_ in args.first
+                                                     for m_ in args.batch_min]:
+            if bmin >= 0:
+                eng.setTuning("batch_min", bmin)
             eng.setTuning("batch_slab_mb", slab)
             if first:
                 eng.setTuning("batch_first", first)
@@ -96,7 +100,7 @@ def main():
             if rank == 0:
                 chk = hashlib.sha256(np.ascontiguousarray(ids).tobytes() + np.ascontiguousarray(scores).tobytes()).hexdigest()[:16]
                 print(json.dumps({"n_gpus": world, "rows": args.rows, "dims": args.dims, "nq": nq, "topk": args.topk,
-                                  "slab_mb": slab, "growth": eng.getTuning("batch_growth"), "debug": dbg, "first": eng.getTuning("batch_first"), "rega": eng.getTuning("batch_rega"), "ms_per_batch": dt * 1e3, "ms_c_call": dt_call * 1e3, "qps_c_call": nq / dt_call,
+                                  "slab_mb": slab, "growth": eng.getTuning("batch_growth"), "debug": dbg, "batch_min": eng.getTuning("batch_min"), "first": eng.getTuning("batch_first"), "rega": eng.getTuning("batch_rega"), "ms_per_batch": dt * 1e3, "ms_c_call": dt_call * 1e3, "qps_c_call": nq / dt_call,
                                   "tflops_bf16_c_call": 2.0 * nq * (hi - lo) * args.dims / dt_call / 1e12, "qps": nq / dt,
                                   "tflops_bf16": 2.0 * nq * args.rows * args.dims / dt / 1e12,
                                   "fallbacks_rank0": eng.getTuning("batch_fallbacks") - fb0,

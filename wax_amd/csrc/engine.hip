@@ -228,6 +228,7 @@ struct BatchWork {
     unsigned int* d_maxnorm = nullptr;
     uint64_t mirror_cap = 0;
     bool mirror_valid = false;
+    std::atomic<int> mirror_wanted{0};   // small batches since the last mutation that a VALID mirror would have made cheaper
     float max_norm = 0.f;
     // per-call buffers (sized for kBatchMaxQ queries on first use, scores/partials grown on demand)
     float* d_q = nullptr;
@@ -309,7 +310,7 @@ struct wax_hip_engine {
     std::atomic<int64_t> time_kernels{0};
     std::atomic<int64_t> force_general{0};
     std::atomic<int64_t> stream_nt{1};
-    std::atomic<int64_t> batch_min{16};      // fewer queries than this: pipelined single-query scans
+    std::atomic<int64_t> batch_min{2};       // fewer queries than this: always pipelined single-query scans (2..15: cost model below)
     std::atomic<int64_t> batch_mode{1};      // 0 = never use the MFMA path
     std::atomic<int64_t> batch_slab_mb{64};  // cap on slab size, in units of 16 384 rows
     std::atomic<int64_t> batch_growth{8};    // next slab = growth x rows seen so far
@@ -929,6 +930,7 @@ int wax_hip_add_batch(wax_hip_engine* e, const uint64_t* frame_ids, const float*
     DeviceGuard g(e->device);
     WriteGuard w(e->lock);
     e->batch.mirror_valid = false;
+    e->batch.mirror_wanted = 0;
     const size_t row_bytes = (size_t)e->dims * sizeof(float);
     if (n == 1) {
         // add(frameId:vector:) (:330-357): no device call at all on the common paths — the row goes to the staging
@@ -1011,6 +1013,7 @@ int wax_hip_add_batch_device(wax_hip_engine* e, const uint64_t* frame_ids, const
     DeviceGuard g(e->device);
     WriteGuard w(e->lock);
     e->batch.mirror_valid = false;
+    e->batch.mirror_wanted = 0;
     { const int frc = flush_pending(e); if (frc != WAX_HIP_OK) return frc; }
     for (uint64_t i = 0; i < n; ++i)
         if (e->idmap.find(frame_ids[i]) >= 0)
@@ -1079,6 +1082,7 @@ int wax_hip_remove(wax_hip_engine* e, uint64_t frame_id) {
     WriteGuard w(e->lock);
     if (e->count == 0) return WAX_HIP_OK;                 // :425
     e->batch.mirror_valid = false;
+    e->batch.mirror_wanted = 0;
     const int64_t idx = e->idmap.find(frame_id);
     if (idx < 0) return WAX_HIP_OK;                       // :426
     { const int frc = flush_pending(e); if (frc != WAX_HIP_OK) return frc; }   // the shift below works on device rows
@@ -1242,8 +1246,23 @@ static int search_batch_hits_impl(wax_hip_engine* e, const float* queries, uint3
     // whose exactness certificate fails are re-run on the exact single-query path below.
     std::vector<uint8_t> need_exact;
     bool all = true;
-    if (e->batch_mode.load() != 0 && (int64_t)nq >= e->batch_min.load() && dims == e->dims && (dims % 64u) == 0 &&
-        cnt > 0 && kcap <= (uint64_t)kBatchMaxK && kcap > 0) {
+    bool use_mfma = e->batch_mode.load() != 0 && (int64_t)nq >= e->batch_min.load() && dims == e->dims &&
+                    (dims % 64u) == 0 && cnt > 0 && kcap <= (uint64_t)kBatchMaxK && kcap > 0;
+    if (use_mfma && nq < 16) {
+        // A small batch costs nq scans of the f32 store on the loop path but ONE pass over the bf16 mirror (half the
+        // bytes) plus the fixed pipeline cost on the MFMA path, whatever nq is (measured, profiles/r01/bi_*: 100 K rows
+        // 0.15 ms, 1 M rows 0.30 ms, 10 M rows 1.78 ms for any nq <= 16; loop path 0.05 / 0.25 / 2.22 ms PER query).
+        // A stale mirror adds its rebuild (read f32, write bf16).
+        const double elems = (double)cnt * (double)dims;
+        const double t_loop = (double)nq * (elems * 4.0 / 6.9e12 + 25e-6);
+        const double t_pass = 135e-6 + elems * 2.0 / 4.7e12;
+        const double t_rebuild = e->batch.mirror_valid ? 0.0 : elems * 6.0 / 5.0e12;
+        use_mfma = t_pass + t_rebuild < t_loop;
+        // ... but a steady stream of small batches amortises it: the third one in a row that a valid mirror would have
+        // made cheaper pays for the rebuild
+        if (!use_mfma && t_pass < t_loop && e->batch.mirror_wanted.fetch_add(1) >= 2) use_mfma = true;
+    }
+    if (use_mfma) {
         need_exact.assign(nq, 0);
         int brc;
         {
@@ -1620,6 +1639,7 @@ int wax_hip_deserialize(wax_hip_engine* e, const uint8_t* data, size_t len) {
     DeviceGuard g(e->device);
     WriteGuard w(e->lock);  // withWriteLock (:717)
     e->batch.mirror_valid = false;
+    e->batch.mirror_wanted = 0;
     e->pend_rows.store(0, std::memory_order_release);   // the store is replaced wholesale: staged appends are dropped with it
     // :790-792 — capacity only grows
     int rc = resize_store(e, n > e->capacity ? n : e->capacity);
