@@ -235,7 +235,7 @@ int wax_hip_stats(wax_hip_engine* e, wax_hip_stats_t* out);
  * "slots" (scratch-slot pool size), "force_general" (1 = use the
  * distance-buffer + radix-select path even for small k), "stream_nt",
  * "reset_stats" (any value: zero the counters), "streams" (1..4 in-order streams the slots rotate over),
- * "batch_mode" (0 = never use the MFMA batched path), "batch_min" (smallest batch that may use it, default 2; below 16 queries a cost model picks
+ * "batch_mode" (0 = never use the MFMA batched path), "batch_min" (smallest batch that may use it, default 1; below 16 queries a cost model picks
  * the cheaper of one GEMM pass over the bf16 mirror and nq f32 scans),
  * "batch_slab_mb", "batch_growth", "batch_first" (slab schedule of the batched path), "batch_rega" (0 LDS-tiled GEMM
  * only, 1 register-resident GEMM with register staging, 2 with LDS-DMA staging), "batch_debug" (timing experiments:

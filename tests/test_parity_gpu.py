@@ -544,7 +544,7 @@ def test_batch_edge_shapes(wax):
     _batch_vs_single(eng, oracle.gaussian_unit_queries(5, dims), 10)
     assert eng.getTuning("batch_queries") == before
     # default: small batches take the MFMA path when one pass over the bf16 mirror beats nq scans of the f32 store
-    eng.setTuning("batch_min", 2)
+    eng.setTuning("batch_min", 1)
     _batch_vs_single(eng, oracle.gaussian_unit_queries(8, dims, seed=42), 10)      # 30 000 rows: 8 scans > one GEMM pass
     assert eng.getTuning("batch_queries") == before + 8
     _batch_vs_single(eng, oracle.gaussian_unit_queries(2, dims, seed=43), 10)      # 2 scans are cheaper: loop path

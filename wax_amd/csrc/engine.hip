@@ -310,7 +310,7 @@ struct wax_hip_engine {
     std::atomic<int64_t> time_kernels{0};
     std::atomic<int64_t> force_general{0};
     std::atomic<int64_t> stream_nt{1};
-    std::atomic<int64_t> batch_min{2};       // fewer queries than this: always pipelined single-query scans (2..15: cost model below)
+    std::atomic<int64_t> batch_min{1};       // fewer queries than this: always pipelined single-query scans (1..15: cost model below)
     std::atomic<int64_t> batch_mode{1};      // 0 = never use the MFMA path
     std::atomic<int64_t> batch_slab_mb{64};  // cap on slab size, in units of 16 384 rows
     std::atomic<int64_t> batch_growth{8};    // next slab = growth x rows seen so far
