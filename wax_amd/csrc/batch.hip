@@ -9,12 +9,16 @@
 // Pipeline (all on one stream; the corpus is walked in slabs whose size grows geometrically):
 //   mirror_kernel        f32 store -> bf16 mirror (RNE; cosine rows pre-normalised), ||v||^2, max ||v||
 //                        (once per mutation; the same kernel converts the query block)
-//   batch_gemm_kernel    bf16 x bf16 -> f32 MFMA (v_mfma_f32_32x32x16_bf16) over one slab, with the
-//                        selection FUSED into the epilogue: an approx distance is appended to its query's
-//                        candidate list only if it beats that query's running threshold tau_q (the k'-th
-//                        best approx distance over the slabs seen so far). The Q x N score matrix is never
-//                        written: after the first 2K rows ~k' * slab/rows_so_far appends per query per slab.
-//   tighten_kernel       per query: candidates -> best k' (sorted), tau_q tightened (between slabs)
+//   GEMM over one slab   bf16 x bf16 -> f32 MFMA (v_mfma_f32_32x32x16_bf16) with the selection FUSED into the
+//                        epilogue: an approx distance survives only if it beats its query's running threshold
+//                        tau_q (the k'-th best approx distance over the slabs seen so far). The Q x N score matrix
+//                        is never written: after the first 2K rows ~k' * slab/rows_so_far survivors per query per
+//                        slab. Three kernels:
+//     batch_gemm_rega_kernel    D in {128, 256, 384, 512}, cosine / dot: queries resident in VGPRs as A fragments,
+//                               survivors into per-workgroup segments (no global atomics)
+//     batch_gemm_ksplit_kernel  D = 768: the same with K split over the two waves of a SIMD
+//     batch_gemm_kernel         everything else (D % 64 == 0, L2, the dense first slab): LDS-tiled 128 x 128
+//   tighten_kernel       per query: best list + survivors -> best k' (sorted), tau_q tightened (between slabs)
 //   rescore_kernel       exact f32 distance of every candidate, SAME lane mapping / summation order
 //                        as scan_kernel => bit-identical to the single-query path
 //   finalize_batch       sort by exact key, emit top-k hits + certificate:
