@@ -1149,3 +1149,35 @@ def test_staged_single_frame_appends(wax):
         eng.add(base + j, v); model_add(base + j, v)
     check("after overflowing the staging area")
     eng.close()
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_batch_path_special_values(wax, metric):
+    """Zero rows, NaN / inf rows, tiny-norm rows and a zero query through the batched (MFMA) path: the answers must
+    still equal the single-query path's (which drops non-finite distances on the host, MetalVectorEngine.swift:597) —
+    either certified or via the exact fallback, never approximated."""
+    dims, n = 384, 20000
+    corpus = oracle.gaussian_unit_rows(0, n, dims)
+    if metric != 0:
+        corpus = corpus * np.linspace(0.5, 2.0, n, dtype=np.float32)[:, None]
+    corpus[5] = 0.0
+    corpus[7, 3] = np.nan
+    corpus[9] *= np.float32(1e-4)
+    corpus[11, 0] = np.inf
+    corpus[13, 1] = -np.inf
+    corpus[15] = corpus[14]                         # an exact duplicate pair
+    eng = make_engine(wax, metric, dims, corpus)
+    queries = oracle.gaussian_unit_queries(40, dims, seed=8)
+    queries[3] = 0.0                                # zero query
+    queries[4] = corpus[14]                         # hits the duplicate pair exactly
+    queries[5] = corpus[9] * np.float32(1e4)        # the tiny-norm row's direction
+    before = eng.getTuning("batch_queries")
+    ids, scores, counts = eng.searchBatch(queries, 10)
+    assert eng.getTuning("batch_queries") - before == 40
+    for i, q in enumerate(queries):
+        s_ids, s_scores = eng.searchArrays(q, 10)
+        assert counts[i] == len(s_ids), (metric, i, counts[i], len(s_ids))
+        assert np.array_equal(ids[i, :counts[i]], s_ids), (metric, i, ids[i, :counts[i]], s_ids)
+        assert np.array_equal(scores[i, :counts[i]], s_scores), (metric, i)
+        assert np.all(np.isfinite(scores[i, :counts[i]]))
+    eng.close()
