@@ -873,6 +873,7 @@ int wax_hip_engine_create(uint8_t metric, uint32_t dims, int device_id, wax_hip_
 
 void wax_hip_engine_destroy(wax_hip_engine* e) {
     if (!e) return;
+    g_outstanding.erase(e);   // a later engine may be allocated at the same address
     DeviceGuard g(e->device);
     (void)hipDeviceSynchronize();
     for (Slot* s : e->all_slots) free_slot(s);
