@@ -228,6 +228,12 @@ def main():
                 dist.barrier()
         torch.cuda.synchronize()
 
+    # Python's cyclic collector must not fire inside the timed region: with torch imported a full (generation-2)
+    # collection walks millions of objects and pauses the submitting thread for 40-70 ms (seen as a one-off stall
+    # around the 450th query of a run, tools/long_run_drift.py); nothing below creates reference cycles.
+    import gc
+    gc.collect()
+    gc.disable()
     run(queries[:args.warmup])
     eng.setTuning("reset_stats", 1)
     barrier()

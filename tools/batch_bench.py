@@ -66,6 +66,9 @@ def main():
         if world > 1:
             dist.barrier(device_ids=[local_rank]) if args.exchange == "rccl" else dist.barrier()
 
+    import gc
+    gc.collect()
+    gc.disable()    # a generation-2 collection with torch loaded pauses the thread for tens of ms (tools/long_run_drift.py)
     for nq in args.nq:
         q = bench.unit_queries(nq, args.dims)
         for slab, growth, dbg, rega, first, bmin in [(s_, g_, d_, r_, f_, m_) for s_ in args.slab_mb for g_ in args.growth
