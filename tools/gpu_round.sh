@@ -117,7 +117,7 @@ PYEOF
       ;;
     gemmpmc)
       (cd /tmp && timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE \
-          --kernel-trace --output-format csv -d "$OUT/prof_gemmpmc" -o g -- python "$R/tools/batch_bench.py" --nq ${WAX_NQ:-1024} --reps 2 > "$OUT/gemmpmc.log" 2>&1); rc=$?
+          --kernel-trace --output-format csv -d "$OUT/prof_gemmpmc" -o g -- python "$R/tools/batch_bench.py" --dims ${WAX_DIMS:-384} --nq ${WAX_NQ:-1024} --reps 2 > "$OUT/gemmpmc.log" 2>&1); rc=$?
       python tools/pmc_summary.py "$OUT/prof_gemmpmc" > "$OUT/gemmpmc_summary.json" 2>> "$OUT/gemmpmc.log"
       find "$OUT/prof_gemmpmc" -name "*.csv" -size +1M -delete 2>/dev/null ;;
     gemmprobeprof)
