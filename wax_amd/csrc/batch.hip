@@ -900,7 +900,12 @@ hipError_t launch_batch_gemm(const GemmArgs& a, int metric, hipStream_t st) {
             case 256: return launch_rega<256>(a, st);
             case 384: return launch_rega<384>(a, st);
             case 512: return launch_rega<512>(a, st);
-            case 768: return launch_ksplit<768, 4>(a, st);
+            case 768:
+                switch ((a.debug >> 8) & 3u) {   // timing experiments: B-fragment read-ahead depth
+                    case 1: return launch_ksplit<768, 6>(a, st);
+                    case 2: return launch_ksplit<768, 8>(a, st);
+                    default: return launch_ksplit<768, 4>(a, st);
+                }
             default: break;
         }
     }
