@@ -133,24 +133,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if use_rccl:
             import datetime
-            try:
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev,
-                                        timeout=datetime.timedelta(seconds=180))
-                probe_t = torch.ones(1, device=dev)
-                dist.all_reduce(probe_t)  # fail here if RCCL cannot talk across the node
-                assert int(probe_t.item()) == world
-            except Exception as exc:  # noqa: BLE001 - an unusable RCCL must not cost the whole measurement
-                # every rank sees the same failure (IPC / topology problems are node-wide): fall back to the host
-                # exchange over gloo and SAY SO in the JSON line (config.exchange)
-                log(f"[bench] rank {rank}: RCCL unavailable ({type(exc).__name__}: {exc}); falling back to --exchange host")
-                try:
-                    if dist.is_initialized():
-                        dist.destroy_process_group()
-                except Exception:  # noqa: BLE001
-                    pass
-                use_rccl = False
-                os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
-                dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev,
+                                    timeout=datetime.timedelta(seconds=300))
+            probe_t = torch.ones(1, device=dev)
+            dist.all_reduce(probe_t)  # fail here, loudly and at once, if RCCL cannot talk across the node
+            assert int(probe_t.item()) == world
+            # (A silent fall-back to the gloo host exchange was tried and removed: tearing down a half-initialised
+            # RCCL group hangs instead of failing. `--exchange host` selects the host exchange explicitly.)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
