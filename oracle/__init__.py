@@ -78,6 +78,15 @@ def lib() -> ctypes.CDLL:
         L.wax_oracle_scan_topk_mt.restype = ctypes.c_int64
         L.wax_oracle_scan_topk_mt.argtypes = [ctypes.c_int, f32p, ctypes.c_uint64, ctypes.c_uint32, f32p,
                                               ctypes.c_int64, ctypes.c_int, i64p, f32p]
+        L.wax_oracle_scan_topk_fast.restype = ctypes.c_int64
+        L.wax_oracle_scan_topk_fast.argtypes = L.wax_oracle_scan_topk_mt.argtypes
+        L.wax_oracle_search_batch.restype = ctypes.c_int64
+        L.wax_oracle_search_batch.argtypes = [ctypes.c_int, f32p, ctypes.c_uint64, ctypes.c_uint32, f32p, ctypes.c_uint32,
+                                              ctypes.c_int64, i64p, f32p, i64p]
+        L.wax_oracle_first_touch_rows.restype = None
+        L.wax_oracle_first_touch_rows.argtypes = [f32p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int]
+        L.wax_oracle_copy_rows.restype = None
+        L.wax_oracle_copy_rows.argtypes = [f32p, f32p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int]
         L.wax_oracle_mv2v_size.restype = ctypes.c_uint64
         L.wax_oracle_mv2v_size.argtypes = [ctypes.c_uint64, ctypes.c_uint32]
         L.wax_oracle_mv2v_serialize.restype = ctypes.c_uint64
@@ -195,6 +204,59 @@ def scan_topk_mt(metric: int, vectors, query, top_k: int, threads: int):
     got = lib().wax_oracle_scan_topk_mt(metric, _p(vectors, ctypes.c_float), n, d, _p(query, ctypes.c_float),
                                         int(top_k), int(threads), _p(idx, ctypes.c_int64), _p(dd, ctypes.c_float))
     return idx[:got].copy(), dd[:got].copy()
+
+
+def scan_topk_fast(metric: int, vectors, query, top_k: int, threads: int):
+    """Tuned CPU baseline: metric-specialised FMA inner loop, same selection as scan_topk_mt."""
+    vectors = _f32(vectors)
+    query = _f32(query)
+    n, d = vectors.shape
+    cap = max(1, min(clamp_topk(top_k), max(n, 1)))
+    idx = np.empty(cap, dtype=np.int64)
+    dd = np.empty(cap, dtype=np.float32)
+    got = lib().wax_oracle_scan_topk_fast(metric, _p(vectors, ctypes.c_float), n, d, _p(query, ctypes.c_float),
+                                          int(top_k), int(threads), _p(idx, ctypes.c_int64), _p(dd, ctypes.c_float))
+    return idx[:got].copy(), dd[:got].copy()
+
+
+def search_batch(metric: int, vectors, queries, top_k: int):
+    """Oracle for a whole batch in one pass over the rows: per query the (distance asc, row asc) top-k with
+    f64-accumulated distances bit-identical to `search` / `distances`. Returns (rows i64[nq, kk],
+    distances f32[nq, kk], counts i64[nq]); scores = score_from_distance(metric, distance)."""
+    vectors = _f32(vectors)
+    queries = _f32(queries)
+    n, d = vectors.shape
+    nq, dq = queries.shape
+    if dq != d:
+        raise DimensionMismatch(f"vector dimension mismatch: expected {d}, got {dq}")
+    kk = max(1, min(clamp_topk(top_k), max(n, 1)))
+    rows = np.full((nq, kk), -1, dtype=np.int64)
+    dist = np.full((nq, kk), np.inf, dtype=np.float32)
+    counts = np.zeros(nq, dtype=np.int64)
+    lib().wax_oracle_search_batch(metric, _p(vectors, ctypes.c_float), n, d, _p(queries, ctypes.c_float), nq,
+                                  int(top_k), _p(rows, ctypes.c_int64), _p(dist, ctypes.c_float),
+                                  _p(counts, ctypes.c_int64))
+    return rows, dist, counts
+
+
+def scores_from_distances(metric: int, dist) -> np.ndarray:
+    """Vectorised VectorMetric.score(fromDistance:) (VectorMetric.swift:32-43)."""
+    dist = np.asarray(dist, dtype=np.float32)
+    s = (np.float32(1.0) - dist) if metric == METRIC_COSINE else -dist
+    return np.where(np.isfinite(dist), s, np.float32(0.0)).astype(np.float32)
+
+
+def numa_sample(n: int, d: int, threads: int) -> np.ndarray:
+    """An [n, d] f32 array whose pages are first-touched by the threads that will scan them."""
+    out = np.empty((n, d), dtype=np.float32)
+    lib().wax_oracle_first_touch_rows(_p(out, ctypes.c_float), n, d, int(threads))
+    return out
+
+
+def copy_rows(dst: np.ndarray, src, threads: int) -> None:
+    src = _f32(src)
+    assert dst.shape == src.shape and dst.dtype == np.float32 and dst.flags.c_contiguous
+    lib().wax_oracle_copy_rows(_p(dst, ctypes.c_float), _p(src, ctypes.c_float), dst.shape[0], dst.shape[1], int(threads))
 
 
 def mv2v_serialize(metric: int, vectors, frame_ids) -> bytes:

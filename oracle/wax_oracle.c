@@ -409,6 +409,214 @@ WAX_ORACLE_API int64_t wax_oracle_scan_topk_mt(int metric, const float* vectors,
 }
 
 /* ------------------------------------------------------------------------ */
+/* Batched parity truth: the arithmetic of wax_oracle_distances_f64 (same f64 accumulation order per
+ * (row, query) pair, so every distance is bit-identical to the single-query truth) + the total-order
+ * selection of wax_oracle_topk_total, for nq queries in ONE pass over the rows (a row stays in L1 while
+ * all queries visit it). This is what lets the GPU parity tests compare EVERY answer of a 256- / 1024-query
+ * batch at the BASELINE sizes (1M x 384, 1.25M x 768) with the oracle in seconds. Rows are partitioned
+ * statically over the threads (ascending inside a thread), one heap per (thread, query), merged under
+ * (distance asc, row asc). out_rows / out_dist are [nq][kk] with kk = min(clamp(top_k), n) (returned);
+ * out_counts[q] <= kk after non-finite distances are dropped (MetalVectorEngine.swift:597). */
+WAX_ORACLE_API int64_t wax_oracle_search_batch(int metric, const float* vectors, uint64_t n, uint32_t d,
+                                               const float* queries, uint32_t nq, int64_t top_k,
+                                               int64_t* out_rows, float* out_dist, int64_t* out_counts) {
+    if (n == 0 || nq == 0) return 0;
+    int32_t limit = wax_oracle_clamp_topk(top_k);
+    int64_t kk = (int64_t)limit < (int64_t)n ? limit : (int64_t)n;
+    int threads = wax_oracle_max_threads();
+    if ((uint64_t)threads > n) threads = (int)n;
+    double* qn = (double*)malloc((size_t)nq * sizeof(double));
+    for (uint32_t q = 0; q < nq; ++q) {
+        const float* qv = queries + (uint64_t)q * d;
+        double qq = 0.0;
+        for (uint32_t j = 0; j < d; ++j) qq += (double)qv[j] * (double)qv[j];
+        qn[q] = sqrt(qq);
+    }
+    heap_ent* all = (heap_ent*)malloc((size_t)threads * (size_t)nq * (size_t)kk * sizeof(heap_ent));
+    int64_t* cnts = (int64_t*)calloc((size_t)threads * (size_t)nq, sizeof(int64_t));
+#pragma omp parallel num_threads(threads)
+    {
+#ifdef _OPENMP
+        int t = omp_get_thread_num(), nt = omp_get_num_threads();
+#else
+        int t = 0, nt = 1;
+#endif
+        uint64_t lo = n * (uint64_t)t / (uint64_t)nt, hi = n * (uint64_t)(t + 1) / (uint64_t)nt;
+        for (uint64_t i = lo; i < hi; ++i) {
+            const float* v = vectors + i * (uint64_t)d;
+            double m = 0.0;
+            if (metric == METRIC_COSINE)
+                for (uint32_t j = 0; j < d; ++j) { double b = (double)v[j]; m += b * b; }
+            double vn = sqrt(m);
+            for (uint32_t q = 0; q < nq; ++q) {
+                const float* qv = queries + (uint64_t)q * d;
+                double acc = 0.0;
+                if (metric == METRIC_L2) {
+                    for (uint32_t j = 0; j < d; ++j) { double a = (double)qv[j], b = (double)v[j]; acc += (a - b) * (a - b); }
+                } else {
+                    for (uint32_t j = 0; j < d; ++j) { double a = (double)qv[j], b = (double)v[j]; acc += a * b; }
+                }
+                double dist;
+                if (metric == METRIC_COSINE) {
+                    double sim = (vn > 1e-6 && qn[q] > 1e-6) ? acc / (vn * qn[q]) : 0.0;
+                    dist = 1.0 - sim;
+                } else if (metric == METRIC_DOT) {
+                    dist = 1.0 - acc;
+                } else {
+                    dist = acc;
+                }
+                heap_ent e; e.d = (float)dist; e.i = (int64_t)i;
+                heap_ent* h = all + ((size_t)t * nq + q) * (size_t)kk;
+                int64_t* c = cnts + (size_t)t * nq + q;
+                if (*c < kk) {
+                    h[*c] = e; ++*c;
+                    if (*c == kk) for (int64_t s = kk / 2; s >= 0; --s) sift_down_total(h, s, kk - 1);
+                } else if (ent_less(&e, &h[0])) {
+                    h[0] = e;
+                    sift_down_total(h, 0, kk - 1);
+                }
+            }
+        }
+    }
+    heap_ent* merged = (heap_ent*)malloc((size_t)threads * (size_t)kk * sizeof(heap_ent));
+    for (uint32_t q = 0; q < nq; ++q) {
+        int64_t total = 0;
+        for (int t = 0; t < threads; ++t) {
+            int64_t c = cnts[(size_t)t * nq + q];
+            memcpy(merged + total, all + ((size_t)t * nq + q) * (size_t)kk, (size_t)c * sizeof(heap_ent));
+            total += c;
+        }
+        qsort(merged, (size_t)total, sizeof(heap_ent), cmp_ent);
+        int64_t m = kk < total ? kk : total, outn = 0;
+        for (int64_t i = 0; i < m; ++i) {
+            if (!isfinite(merged[i].d)) continue;
+            out_rows[(size_t)q * kk + outn] = merged[i].i;
+            out_dist[(size_t)q * kk + outn] = merged[i].d;
+            ++outn;
+        }
+        out_counts[q] = outn;
+    }
+    free(merged); free(all); free(cnts); free(qn);
+    return kk;
+}
+
+/* ------------------------------------------------------------------------ */
+/* CPU baseline, tuned variant (bench.py cpu_baseline "variants"): the same scan + heap selection as
+ * wax_oracle_scan_topk_mt, but with a METRIC-SPECIALISED inner loop (cosine accumulates dot and |v|^2
+ * only, dot / l2 one sum) written with explicit fused multiply-adds on 16 independent lanes so that gcc
+ * vectorises it to AVX2 / AVX-512 FMA whatever -ffp-contract says. It is a reported baseline, not a
+ * parity reference: distances agree with the f64 truth to ~1e-6 (tests/test_oracle.py). */
+#define WAX_LANES 16
+__attribute__((target_clones("arch=skylake-avx512", "arch=haswell", "default")))
+static float row_distance_fast(int metric, const float* v, const float* q, uint32_t d, float qn) {
+    float s0[WAX_LANES] = {0}, s1[WAX_LANES] = {0};
+    uint32_t dl = d - d % WAX_LANES, j = 0;
+    if (metric == METRIC_COSINE) {
+        for (; j < dl; j += WAX_LANES)
+            for (int c = 0; c < WAX_LANES; ++c) {
+                s0[c] = __builtin_fmaf(q[j + c], v[j + c], s0[c]);
+                s1[c] = __builtin_fmaf(v[j + c], v[j + c], s1[c]);
+            }
+    } else if (metric == METRIC_DOT) {
+        for (; j < dl; j += WAX_LANES)
+            for (int c = 0; c < WAX_LANES; ++c) s0[c] = __builtin_fmaf(q[j + c], v[j + c], s0[c]);
+    } else {
+        for (; j < dl; j += WAX_LANES)
+            for (int c = 0; c < WAX_LANES; ++c) { float e = q[j + c] - v[j + c]; s0[c] = __builtin_fmaf(e, e, s0[c]); }
+    }
+    float a = 0.f, m = 0.f;
+    for (int c = 0; c < WAX_LANES; ++c) { a += s0[c]; m += s1[c]; }
+    for (; j < d; ++j) {
+        if (metric == METRIC_L2) { float e = q[j] - v[j]; a += e * e; }
+        else { a += q[j] * v[j]; m += v[j] * v[j]; }
+    }
+    if (metric == METRIC_COSINE) {
+        float vn = sqrtf(m);
+        float sim = (vn > 1e-6f && qn > 1e-6f) ? a / (vn * qn) : 0.0f;
+        return 1.0f - sim;
+    }
+    if (metric == METRIC_DOT) return 1.0f - a;
+    return a;
+}
+
+WAX_ORACLE_API int64_t wax_oracle_scan_topk_fast(int metric, const float* vectors, uint64_t n, uint32_t d,
+                                                 const float* query, int64_t top_k, int threads,
+                                                 int64_t* out_idx, float* out_dist) {
+    if (n == 0) return 0;
+    int32_t limit = wax_oracle_clamp_topk(top_k);
+    int64_t kk = (int64_t)limit < (int64_t)n ? limit : (int64_t)n;
+    if (threads < 1) threads = 1;
+    float qn = wax_oracle_magnitude(query, d);
+    heap_ent* all = (heap_ent*)malloc((size_t)threads * (size_t)kk * sizeof(heap_ent));
+    int64_t* counts = (int64_t*)calloc((size_t)threads, sizeof(int64_t));
+#pragma omp parallel num_threads(threads)
+    {
+#ifdef _OPENMP
+        int t = omp_get_thread_num(), nt = omp_get_num_threads();
+#else
+        int t = 0, nt = 1;
+#endif
+        uint64_t lo = n * (uint64_t)t / (uint64_t)nt, hi = n * (uint64_t)(t + 1) / (uint64_t)nt;
+        heap_ent* h = all + (size_t)t * (size_t)kk;
+        int64_t cnt = 0;
+        for (uint64_t i = lo; i < hi; ++i) {
+            float dist = row_distance_fast(metric, vectors + i * (uint64_t)d, query, d, qn);
+            if (cnt < kk) {
+                h[cnt].d = dist; h[cnt].i = (int64_t)i; ++cnt;
+                if (cnt == kk) for (int64_t s = kk / 2; s >= 0; --s) sift_down(h, s, kk - 1);
+            } else {
+                if (dist >= h[0].d) continue; /* MetalVectorEngine.swift:671 */
+                h[0].d = dist; h[0].i = (int64_t)i;
+                sift_down(h, 0, kk - 1);
+            }
+        }
+        counts[t] = cnt;
+    }
+    int64_t total = 0;
+    for (int t = 0; t < threads; ++t) {
+        if (counts[t] && total != (int64_t)t * kk) memmove(all + total, all + (size_t)t * (size_t)kk, (size_t)counts[t] * sizeof(heap_ent));
+        total += counts[t];
+    }
+    qsort(all, (size_t)total, sizeof(heap_ent), cmp_ent);
+    int64_t m = kk < total ? kk : total;
+    for (int64_t i = 0; i < m; ++i) { out_idx[i] = all[i].i; out_dist[i] = all[i].d; }
+    free(all); free(counts);
+    return m;
+}
+
+/* First-touch `bytes` at `p` with the SAME static partition over `threads` threads as the scans above
+ * (row r of an [n][d] f32 array is touched by the thread that will scan it), so that on a multi-socket
+ * host every thread later streams from its own NUMA node. Zero-fills. */
+WAX_ORACLE_API void wax_oracle_first_touch_rows(float* p, uint64_t n, uint32_t d, int threads) {
+    if (threads < 1) threads = 1;
+#pragma omp parallel num_threads(threads)
+    {
+#ifdef _OPENMP
+        int t = omp_get_thread_num(), nt = omp_get_num_threads();
+#else
+        int t = 0, nt = 1;
+#endif
+        uint64_t lo = n * (uint64_t)t / (uint64_t)nt, hi = n * (uint64_t)(t + 1) / (uint64_t)nt;
+        if (hi > lo) memset(p + lo * (uint64_t)d, 0, (size_t)(hi - lo) * d * sizeof(float));
+    }
+}
+
+/* Parallel copy with the same partition (fills a first-touched sample without moving its pages). */
+WAX_ORACLE_API void wax_oracle_copy_rows(float* dst, const float* src, uint64_t n, uint32_t d, int threads) {
+    if (threads < 1) threads = 1;
+#pragma omp parallel num_threads(threads)
+    {
+#ifdef _OPENMP
+        int t = omp_get_thread_num(), nt = omp_get_num_threads();
+#else
+        int t = 0, nt = 1;
+#endif
+        uint64_t lo = n * (uint64_t)t / (uint64_t)nt, hi = n * (uint64_t)(t + 1) / (uint64_t)nt;
+        if (hi > lo) memcpy(dst + lo * (uint64_t)d, src + lo * (uint64_t)d, (size_t)(hi - lo) * d * sizeof(float));
+    }
+}
+
+/* ------------------------------------------------------------------------ */
 /* Row f7: "MV2V" vec segment, encoding 2 — MetalVectorEngine.serialize
  * (MetalVectorEngine.swift:682-714) / VectorSerializer.decodeVecSegment
  * (VectorSerializer.swift:84-157, header :175-251). Little-endian host assumed. */

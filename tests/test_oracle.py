@@ -200,3 +200,45 @@ def test_multithreaded_baseline_matches_truth():
     for threads in (1, 3, oracle.max_threads()):
         mi, md = oracle.scan_topk_mt(0, corpus, q, 10, threads)
         assert_parity(mi, 1.0 - md, rows, scores, ctx=f"mt{threads}")
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_tuned_baseline_matches_truth(metric):
+    """The FMA / metric-specialised baseline kernel (bench.py cpu_baseline variants) returns the truth's ranking."""
+    corpus = oracle.gaussian_unit_rows(0, 20000, 384) * np.float32(1.0 if metric == 0 else 1.7)
+    q = oracle.gaussian_unit_queries(1, 384)[0]
+    ids, scores, dist, rows = oracle.search(metric, corpus, None, q, 10)
+    for threads in (1, 3, oracle.max_threads()):
+        mi, md = oracle.scan_topk_fast(metric, corpus, q, 10, threads)
+        assert_parity(mi, oracle.scores_from_distances(metric, md), rows, scores, ctx=f"fast m{metric} t{threads}")
+    odd = oracle.gaussian_unit_rows(0, 500, 37)       # dims not a multiple of the 16-lane unroll
+    qo = oracle.gaussian_unit_queries(1, 37)[0]
+    _, s2, _, r2 = oracle.search(metric, odd, None, qo, 5)
+    mi, md = oracle.scan_topk_fast(metric, odd, qo, 5, 2)
+    assert_parity(mi, oracle.scores_from_distances(metric, md), r2, s2, ctx=f"fast odd m{metric}")
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_batched_oracle_is_bit_identical_to_single_query_oracle(metric):
+    """oracle.search_batch (what the GPU tests use at the BASELINE sizes) == oracle.search, query by query."""
+    corpus = oracle.gaussian_unit_rows(0, 9000, 96)
+    corpus[17] = 0.0                                   # a zero row (cosine: similarity 0)
+    corpus[100] = corpus[3]                            # an exact duplicate: tie by ascending row
+    qs = oracle.gaussian_unit_queries(9, 96)
+    rows, dist, counts = oracle.search_batch(metric, corpus, qs, 20)
+    for i, q in enumerate(qs):
+        ids, scores, dd, rr = oracle.search(metric, corpus, None, q, 20)
+        assert counts[i] == len(rr)
+        assert np.array_equal(rows[i, :counts[i]], rr) and np.array_equal(dist[i, :counts[i]], dd)
+        assert np.array_equal(oracle.scores_from_distances(metric, dd), scores)
+    small = corpus[:5]
+    rows, dist, counts = oracle.search_batch(metric, small, qs[:2], 20)   # k > n
+    assert rows.shape == (2, 5) and np.all(counts == 5)
+
+
+def test_numa_sample_helpers():
+    x = oracle.numa_sample(1000, 24, 3)
+    assert x.shape == (1000, 24) and not x.any()
+    src = oracle.gaussian_unit_rows(0, 1000, 24)
+    oracle.copy_rows(x, src, 3)
+    assert np.array_equal(x, src)
