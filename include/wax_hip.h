@@ -14,8 +14,11 @@
  *     (`void* stream` is a hipStream_t passed opaquely, NULL = engine's own)
  *   - return 0 (WAX_HIP_OK) or a negative wax_hip_status; the message is in
  *     wax_hip_last_error() (thread-local)
- *   - the caller owns every in/out array; buffers returned by
- *     wax_hip_serialize() are released with wax_hip_free()
+ *   - the caller owns every in/out array and states its size: every result array comes with an
+ *     explicit capacity (entries) and the library never writes past it, whatever the engine's row
+ *     count has become by the time the call runs (a concurrent add may grow it between the caller's
+ *     sizing and the search). wax_hip_result_capacity(top_k) = clamp(top_k, 1, 10000) entries always
+ *     suffice. Buffers returned by wax_hip_serialize() are released with wax_hip_free()
  *   - search* calls are re-entrant (shared lock + per-call scratch slot),
  *     mutations take the exclusive lock — the same reader/writer contract as
  *     the reference's AsyncReadWriteLock (MetalVectorEngine.swift:56-81)
@@ -32,7 +35,7 @@
 extern "C" {
 #endif
 
-#define WAX_HIP_ABI_VERSION 1
+#define WAX_HIP_ABI_VERSION 2
 
 /* MetalVectorEngine.maxResults (MetalVectorEngine.swift:18) */
 #define WAX_HIP_MAX_RESULTS 10000
@@ -144,35 +147,43 @@ int wax_hip_reserve(wax_hip_engine* e, uint64_t rows);
 
 /* ---- search (shared lock, re-entrant) ----------------------------------- */
 
+/* clampTopK (MetalVectorEngine.swift:842-846): the number of entries a result array needs so that no
+ * result is ever truncated, independent of the engine's current row count. */
+uint32_t wax_hip_result_capacity(int32_t top_k);
+
 /* VectorSearchEngine.search(vector:topK:) (VectorSearchEngine.swift:13;
- * MetalVectorEngine.swift:446-627). Blocking. out_ids/out_scores must hold
- * min(clamp(top_k,1,10000), count) entries; *out_count receives how many were
- * written (best first: descending score == ascending distance, ties by
- * ascending row). Empty engine => OK with *out_count = 0 (:448). */
+ * MetalVectorEngine.swift:446-627). Blocking. out_ids/out_scores hold out_capacity
+ * entries; *out_count receives how many were written = min(clamp(top_k,1,10000), count,
+ * out_capacity) minus dropped non-finite entries (best first: descending score == ascending
+ * distance, ties by ascending row; a capacity below the result count keeps the best ones).
+ * Empty engine => OK with *out_count = 0 (:448). */
 int wax_hip_search(wax_hip_engine* e, const float* query, uint32_t dims, int32_t top_k,
-                   uint64_t* out_ids, float* out_scores, uint32_t* out_count);
+                   uint64_t* out_ids, float* out_scores, uint32_t out_capacity, uint32_t* out_count);
 
 /* Pipelined form of the same call: submit enqueues H2D + kernels + D2H on one
  * of the engine's scratch slots and returns immediately with a ticket;
  * collect blocks on that slot and fills the outputs exactly like
- * wax_hip_search. Tickets must be collected exactly once, in any order. A thread
- * that already holds tickets never waits for a scratch slot (it gets a fresh one,
- * up to 256 outstanding), so pipelining callers cannot deadlock each other. */
+ * wax_hip_search. Tickets must be collected exactly once, in any order (also from another
+ * thread). A thread that already holds tickets never waits for a scratch slot (it gets a fresh one,
+ * up to 256 outstanding), so pipelining callers cannot deadlock each other. A ticket holds the engine's
+ * shared lock until it is collected: a mutation (add / remove / reserve / deserialize / set_row_base)
+ * called by a thread that still holds uncollected tickets would wait for itself forever, so it fails
+ * with WAX_HIP_ERR_INVALID_ARGUMENT ("collect outstanding search tickets first") instead. */
 int wax_hip_search_submit(wax_hip_engine* e, const float* query, uint32_t dims, int32_t top_k, uint64_t* out_ticket);
 int wax_hip_search_collect(wax_hip_engine* e, uint64_t ticket,
-                           uint64_t* out_ids, float* out_scores, uint32_t* out_count);
+                           uint64_t* out_ids, float* out_scores, uint32_t out_capacity, uint32_t* out_count);
 
-/* nq queries, row-major nq x dims. out_ids/out_scores are nq x kcap where
- * kcap = min(clamp(top_k), count); out_counts[nq]. */
+/* nq queries, row-major nq x dims. out_ids/out_scores are nq rows of out_stride entries (query q's
+ * results start at q * out_stride; at most out_stride are written per query); out_counts[nq]. */
 int wax_hip_search_batch(wax_hip_engine* e, const float* queries, uint32_t nq, uint32_t dims, int32_t top_k,
-                         uint64_t* out_ids, float* out_scores, uint32_t* out_counts);
+                         uint64_t* out_ids, float* out_scores, uint32_t out_stride, uint32_t* out_counts);
 
-/* Same search, but the raw ranked candidates are returned: out_hits is nq x kcap wax_hip_hit (ascending
- * key, padded with key = INT64_MAX). This is what a row-sharded deployment exchanges between ranks and
+/* Same search, but the raw ranked candidates are returned: out_hits is nq rows of out_stride wax_hip_hit
+ * (ascending key, every row padded to out_stride with key = INT64_MAX). This is what a row-sharded deployment exchanges between ranks and
  * merges by key (exact tie order by GLOBAL row, see wax_hip_set_row_base). Large batches run Q x D^T as a
  * bf16 MFMA GEMM with an exact f32 re-score; results are identical to nq calls of wax_hip_search. */
 int wax_hip_search_batch_hits(wax_hip_engine* e, const float* queries, uint32_t nq, uint32_t dims, int32_t top_k,
-                              wax_hip_hit* out_hits, uint32_t* out_counts);
+                              wax_hip_hit* out_hits, uint32_t out_stride, uint32_t* out_counts);
 
 /* ---- sharded search: per-shard top-k left in HBM for the RCCL exchange ---- */
 
@@ -197,7 +208,7 @@ int wax_hip_merge_hits_device(const wax_hip_hit* d_in, uint32_t n, uint32_t k, w
 int wax_hip_merge_batch_hits_device(const wax_hip_hit* d_in, uint32_t n_shards, uint32_t nq, uint32_t k_in, uint32_t k,
                                     wax_hip_hit* d_out, void* stream);
 /* Host-side tail of search (MetalVectorEngine.swift:592-611 + VectorMetric.swift:32-43):
- * drop padded / non-finite entries, distance -> score, emit (frameId, score). */
+ * drop padded / non-finite entries, distance -> score, emit (frameId, score); out arrays hold n entries. */
 int wax_hip_hits_to_results(uint8_t metric, const wax_hip_hit* hits, uint32_t n,
                             uint64_t* out_ids, float* out_scores, uint32_t* out_count);
 
@@ -214,7 +225,7 @@ int wax_hip_hits_to_results(uint8_t metric, const wax_hip_hit* hits, uint32_t n,
 int wax_hip_search_filtered(wax_hip_engine* e, const float* query, uint32_t dims, int32_t top_k,
                             int has_allow, const uint64_t* allow_frame_ids, uint64_t n_allow,
                             int has_min_score, float min_score,
-                            uint64_t* out_ids, float* out_scores, uint32_t* out_count);
+                            uint64_t* out_ids, float* out_scores, uint32_t out_capacity, uint32_t* out_count);
 
 /* ---- persistence: "MV2V" vec segment, encoding 2 ------------------------- */
 

@@ -34,13 +34,12 @@ class VectorEngine {
     uint64_t count() const { return wax_hip_count(h_); }
 
     std::vector<std::pair<uint64_t, float>> search(const std::vector<float>& vector, int topK) {
-        uint64_t n = count();
-        int lim = topK < 1 ? 1 : (topK > WAX_HIP_MAX_RESULTS ? WAX_HIP_MAX_RESULTS : topK);
-        size_t cap = (uint64_t)lim < n ? (size_t)lim : (size_t)(n ? n : 1);
+        // sized by topK alone (never by a row count read outside the engine's lock) and passed as the capacity
+        const uint32_t cap = wax_hip_result_capacity(topK);
         std::vector<uint64_t> ids(cap);
         std::vector<float> scores(cap);
         uint32_t got = 0;
-        check(wax_hip_search(h_, vector.data(), (uint32_t)vector.size(), topK, ids.data(), scores.data(), &got));
+        check(wax_hip_search(h_, vector.data(), (uint32_t)vector.size(), topK, ids.data(), scores.data(), cap, &got));
         std::vector<std::pair<uint64_t, float>> out(got);
         for (uint32_t i = 0; i < got; ++i) out[i] = {ids[i], scores[i]};
         return out;
@@ -49,13 +48,13 @@ class VectorEngine {
     /// Allow-list / minScore filtered search (UnifiedSearch.swift:1241-1258): best topK among the allowed frames.
     std::vector<std::pair<uint64_t, float>> searchFiltered(const std::vector<float>& q, int topK,
                                                            const std::vector<uint64_t>* allow, const float* minScore) {
-        const size_t cap = topK < 1 ? 1 : (topK > 10000 ? 10000 : (size_t)topK);
+        const uint32_t cap = wax_hip_result_capacity(topK);
         std::vector<uint64_t> ids(cap);
         std::vector<float> scores(cap);
         uint32_t n = 0;
         check(wax_hip_search_filtered(h_, q.data(), (uint32_t)q.size(), topK, allow ? 1 : 0,
                                       allow && !allow->empty() ? allow->data() : nullptr, allow ? allow->size() : 0,
-                                      minScore ? 1 : 0, minScore ? *minScore : 0.0f, ids.data(), scores.data(), &n));
+                                      minScore ? 1 : 0, minScore ? *minScore : 0.0f, ids.data(), scores.data(), cap, &n));
         std::vector<std::pair<uint64_t, float>> out(n);
         for (uint32_t i = 0; i < n; ++i) out[i] = {ids[i], scores[i]};
         return out;

@@ -57,15 +57,16 @@ public actor HIPVectorEngine {
 
     public func search(vector: [Float], topK: Int) async throws -> [(frameId: UInt64, score: Float)] {
         let h = handle
-        let n = Int(wax_hip_count(h))
-        let cap = max(1, min(max(1, min(topK, 10_000)), max(n, 1)))
         let k32 = Int32(clamping: topK)
+        // Sized by clampTopK alone and handed over as the capacity: the row count may grow between this line and the
+        // search (another task's add runs while this one is suspended in io.run); the library never writes past `cap`.
+        let cap = Int(wax_hip_result_capacity(k32))
         return try await io.run {
             var ids = [UInt64](repeating: 0, count: cap)
             var scores = [Float](repeating: 0, count: cap)
             var got: UInt32 = 0
             try Self.check(vector.withUnsafeBufferPointer { q in
-                wax_hip_search(h, q.baseAddress, UInt32(vector.count), k32, &ids, &scores, &got)
+                wax_hip_search(h, q.baseAddress, UInt32(vector.count), k32, &ids, &scores, UInt32(cap), &got)
             })
             return (0..<Int(got)).map { (frameId: ids[$0], score: scores[$0]) }
         }
@@ -115,14 +116,14 @@ public actor HIPVectorEngine {
             throw WaxError.encodingError(reason: "vector dimension mismatch: expected \(dimensions), got \(v.count)")
         }
         let h = handle, d = UInt32(dimensions), nq = vectors.count
-        let cap = max(1, min(max(1, min(topK, 10_000)), max(Int(wax_hip_count(h)), 1)))
+        let cap = Int(wax_hip_result_capacity(Int32(clamping: topK)))   // row stride of the result arrays
         let flat = vectors.flatMap { $0 }
         return try await io.run {
             var ids = [UInt64](repeating: 0, count: nq * cap)
             var scores = [Float](repeating: 0, count: nq * cap)
             var counts = [UInt32](repeating: 0, count: nq)
             try Self.check(flat.withUnsafeBufferPointer { q in
-                wax_hip_search_batch(h, q.baseAddress, UInt32(nq), d, Int32(clamping: topK), &ids, &scores, &counts)
+                wax_hip_search_batch(h, q.baseAddress, UInt32(nq), d, Int32(clamping: topK), &ids, &scores, UInt32(cap), &counts)
             })
             return (0..<nq).map { i in (0..<Int(counts[i])).map { (frameId: ids[i * cap + $0], score: scores[i * cap + $0]) } }
         }
@@ -143,7 +144,7 @@ public actor HIPVectorEngine {
                 (allowed ?? []).withUnsafeBufferPointer { a in
                     wax_hip_search_filtered(h, q.baseAddress, UInt32(vector.count), Int32(clamping: topK),
                                             allowed == nil ? 0 : 1, a.baseAddress, UInt64(a.count),
-                                            minScore == nil ? 0 : 1, minScore ?? 0, &ids, &scores, &n)
+                                            minScore == nil ? 0 : 1, minScore ?? 0, &ids, &scores, UInt32(limit), &n)
                 }
             })
             return (0..<Int(n)).map { (frameId: ids[$0], score: scores[$0]) }

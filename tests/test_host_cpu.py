@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
     assert set(declared) == set(_abi.SIGNATURES), (set(declared) ^ set(_abi.SIGNATURES))
     for name in declared:
         assert hasattr(hip_lib, name), f"libwaxhip.so does not export {name}"
-    assert hip_lib.wax_hip_abi_version() == 1
+    assert hip_lib.wax_hip_abi_version() == 2
 
 
 def test_library_is_a_gfx950_code_object():
@@ -221,7 +221,68 @@ def test_plain_c_consumer_links_and_fails_loudly_without_gpu(hip_lib, tmp_path):
 
 @pytest.mark.gpu
 def test_plain_c_consumer_on_gpu(hip_lib, tmp_path):
+    if hip_lib.wax_hip_device_count() == 0:
+        pytest.skip("no HIP device on this host")
     exe = _build_c_smoke(tmp_path)
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "c-abi ok: id 20" in out.stdout
+
+
+def _run_hpp_consumer(tmp_path):
+    """include/wax_hip.hpp (the C++17 convenience wrapper) is compiled and linked against libwaxhip by a real
+    consumer; without a GPU the program checks the loud NO_DEVICE error through the wrapper's exception."""
+    from wax_amd import build
+    lib = build.build()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "hpp_consumer.cpp"
+    src.write_text(r'''
+#include <cstdio>
+#include <cstring>
+#include "wax_hip.hpp"
+int main() {
+    try {
+        wax_hip::VectorEngine e(WAX_HIP_METRIC_COSINE, 4);
+        e.add(1, {1.f, 0.f, 0.f, 0.f});
+        e.addBatch({2, 3}, {0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f});
+        auto hits = e.search({0.9f, 0.1f, 0.f, 0.f}, 2);
+        if (hits.size() != 2 || hits[0].first != 1) return 5;
+        std::vector<uint64_t> allow{2, 3};
+        auto f = e.searchFiltered({0.9f, 0.1f, 0.f, 0.f}, 5, &allow, nullptr);
+        if (f.size() != 2 || f[0].first != 2) return 6;
+        auto blob = e.serialize();
+        wax_hip::VectorEngine e2(WAX_HIP_METRIC_COSINE, 4);
+        e2.deserialize(blob);
+        if (e2.count() != 3 || e2.dimensions() != 4) return 7;
+        e2.remove(2);
+        if (e2.count() != 2) return 8;
+        std::printf("hpp ok\n");
+        return 0;
+    } catch (const wax_hip::Error& err) {
+        if (!wax_hip::VectorEngine::isAvailable() && err.status == WAX_HIP_ERR_NO_DEVICE && std::strlen(err.what()) > 0) {
+            std::printf("no-device: %s\n", err.what());
+            return 0;
+        }
+        std::printf("unexpected error %d: %s\n", err.status, err.what());
+        return 9;
+    }
+}
+''')
+    exe = str(tmp_path / "hpp_consumer")
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"), str(src),
+                    "-L" + os.path.dirname(lib), "-lwaxhip", "-Wl,-rpath," + os.path.dirname(lib), "-o", exe], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    return out.stdout
+
+
+def test_cpp_wrapper_header_compiles_against_the_c_abi(hip_lib, tmp_path):
+    out = _run_hpp_consumer(tmp_path)
+    assert ("hpp ok" in out) if hip_lib.wax_hip_available() else ("no-device" in out)
+
+
+@pytest.mark.gpu
+def test_cpp_wrapper_on_gpu(hip_lib, tmp_path):
+    if hip_lib.wax_hip_device_count() == 0:
+        pytest.skip("no HIP device on this host")
+    assert "hpp ok" in _run_hpp_consumer(tmp_path)

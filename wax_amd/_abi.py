@@ -75,17 +75,18 @@ SIGNATURES: Dict[str, tuple] = {
     "wax_hip_apply_put_embeddings": (ctypes.c_int, [_engine_p, ctypes.c_char_p, ctypes.c_uint64, _u64p]),
     "wax_hip_search_filtered": (ctypes.c_int, [_engine_p, _f32p, ctypes.c_uint32, ctypes.c_int32, ctypes.c_int, _u64p,
                                                ctypes.c_uint64, ctypes.c_int, ctypes.c_float, _u64p, _f32p,
-                                               ctypes.POINTER(ctypes.c_uint32)]),
+                                               ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]),
     "wax_hip_merge_batch_hits_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
                                                        ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]),
     "wax_hip_add_batch_device": (ctypes.c_int, [_engine_p, _u64p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32]),
     "wax_hip_remove": (ctypes.c_int, [_engine_p, ctypes.c_uint64]),
     "wax_hip_reserve": (ctypes.c_int, [_engine_p, ctypes.c_uint64]),
-    "wax_hip_search": (ctypes.c_int, [_engine_p, _f32p, ctypes.c_uint32, ctypes.c_int32, _u64p, _f32p, _u32p]),
+    "wax_hip_result_capacity": (ctypes.c_uint32, [ctypes.c_int32]),
+    "wax_hip_search": (ctypes.c_int, [_engine_p, _f32p, ctypes.c_uint32, ctypes.c_int32, _u64p, _f32p, ctypes.c_uint32, _u32p]),
     "wax_hip_search_submit": (ctypes.c_int, [_engine_p, _f32p, ctypes.c_uint32, ctypes.c_int32, _u64p]),
-    "wax_hip_search_collect": (ctypes.c_int, [_engine_p, ctypes.c_uint64, _u64p, _f32p, _u32p]),
-    "wax_hip_search_batch": (ctypes.c_int, [_engine_p, _f32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int32, _u64p, _f32p, _u32p]),
-    "wax_hip_search_batch_hits": (ctypes.c_int, [_engine_p, _f32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int32, _hitp, _u32p]),
+    "wax_hip_search_collect": (ctypes.c_int, [_engine_p, ctypes.c_uint64, _u64p, _f32p, ctypes.c_uint32, _u32p]),
+    "wax_hip_search_batch": (ctypes.c_int, [_engine_p, _f32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int32, _u64p, _f32p, ctypes.c_uint32, _u32p]),
+    "wax_hip_search_batch_hits": (ctypes.c_int, [_engine_p, _f32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int32, _hitp, ctypes.c_uint32, _u32p]),
     "wax_hip_set_row_base": (ctypes.c_int, [_engine_p, ctypes.c_uint64]),
     "wax_hip_search_shard_device": (ctypes.c_int, [_engine_p, _f32p, ctypes.c_uint32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     "wax_hip_merge_hits_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]),

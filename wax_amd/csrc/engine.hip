@@ -28,8 +28,6 @@ namespace {
 
 thread_local std::string g_last_error;
 
-// Uncollected search tickets submitted by THIS thread, per engine (see RWLock::lock_shared).
-thread_local std::map<const void*, int> g_outstanding;
 
 int fail(int code, const std::string& msg) {
     g_last_error = msg;
@@ -203,6 +201,7 @@ struct Slot {
     // per-ticket state
     int k_eff = 0;
     bool timed = false;
+    std::thread::id owner;         // the submitting thread (its outstanding-ticket count drops at collect, whoever collects)
 };
 
 // Workspace of wax_hip_search_filtered; one filtered search at a time per engine.
@@ -292,6 +291,11 @@ struct wax_hip_engine {
     int max_slots = 4;
     std::map<uint64_t, Slot*> tickets;
     uint64_t next_ticket = 1;
+    // Uncollected search tickets per SUBMITTING thread (a ticket holds the shared lock until it is collected, possibly
+    // by another thread): lets a thread that already holds the lock re-enter past a queued writer, never wait for a
+    // scratch slot, and be refused by the mutating entry points instead of dead-locking on itself.
+    std::mutex out_mu;
+    std::map<std::thread::id, int> outstanding;
 
     // shard-search scratch ring (caller-stream async work)
     float* ring_d_query[kShardRing] = {};
@@ -299,6 +303,12 @@ struct wax_hip_engine {
     int64_t* ring_d_partials[kShardRing] = {};
     hipEvent_t ring_ev0[kShardRing] = {}, ring_ev1[kShardRing] = {};
     bool ring_ev_pending[kShardRing] = {};
+    // Completion of everything the entry's last use enqueued on the caller's stream (query upload, scan, merge):
+    // waited for before the entry is reused (its pinned query and partials are still being read until then) and by
+    // every writer (the caller-stream work runs after the shared lock was released).
+    hipEvent_t ring_done[kShardRing] = {};
+    bool ring_busy[kShardRing] = {};
+    std::mutex ring_mu[kShardRing];
     std::atomic<uint32_t> ring_next{0};
 
     float* d_sink = nullptr;
@@ -338,6 +348,40 @@ struct wax_hip_engine {
 namespace {
 
 constexpr uint64_t kBounceBytes = 64ull << 20;
+
+// Wait until no shard-path work (wax_hip_search_shard_device: enqueued on caller streams, not synchronised by the
+// call) is in flight. Called by writers under the exclusive lock, so no new shard work can start meanwhile.
+void sync_shard_work(wax_hip_engine* e) {
+    for (int r = 0; r < kShardRing; ++r) {
+        std::unique_lock<std::mutex> g(e->ring_mu[r]);
+        if (e->ring_busy[r]) {
+            (void)hipEventSynchronize(e->ring_done[r]);
+            e->ring_busy[r] = false;
+        }
+    }
+}
+
+int holding(wax_hip_engine* e) {   // uncollected tickets submitted by the calling thread
+    std::unique_lock<std::mutex> g(e->out_mu);
+    auto it = e->outstanding.find(std::this_thread::get_id());
+    return it == e->outstanding.end() ? 0 : it->second;
+}
+void note_submit(wax_hip_engine* e, Slot* s) {
+    s->owner = std::this_thread::get_id();
+    std::unique_lock<std::mutex> g(e->out_mu);
+    e->outstanding[s->owner] += 1;
+}
+void note_collect(wax_hip_engine* e, Slot* s) {
+    std::unique_lock<std::mutex> g(e->out_mu);
+    auto it = e->outstanding.find(s->owner);
+    if (it != e->outstanding.end() && --it->second <= 0) e->outstanding.erase(it);
+}
+// Mutating entry points: a thread holding uncollected tickets holds the shared lock and would wait for itself.
+#define REFUSE_IF_HOLDING(e)                                                                                        \
+    do {                                                                                                            \
+        if (holding(e) > 0)                                                                                         \
+            return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "collect outstanding search tickets first (a ticket holds the engine's read lock)"); \
+    } while (0)
 
 int clamp_topk(int64_t top_k) {  // MetalVectorEngine.swift:842-846
     if (top_k < 1) return 1;
@@ -595,9 +639,9 @@ int enqueue_scan(wax_hip_engine* e, const float* d_query, float q_norm, int k_ef
 }
 
 int hits_to_results(uint8_t metric, const wax_hip_hit* hits, uint32_t n, uint64_t* out_ids, float* out_scores,
-                    uint32_t* out_count) {
+                    uint32_t capacity, uint32_t* out_count) {
     uint32_t m = 0;
-    for (uint32_t i = 0; i < n; ++i) {
+    for (uint32_t i = 0; i < n && m < capacity; ++i) {
         if (hits[i].key == KEY_PAD) continue;                    // idx == UInt32.max (:597)
         const float d = key_distance(hits[i].key);
         if (!std::isfinite(d)) continue;                         // !distance.isFinite (:597)
@@ -686,7 +730,7 @@ float batch_eps(uint8_t metric, float q_norm, float max_norm, uint32_t dims) {
 }
 
 int batch_search_mfma(wax_hip_engine* e, const float* queries, uint32_t nq, int k_eff, wax_hip_hit* out_hits,
-                      std::vector<uint8_t>& need_exact) {
+                      uint32_t stride, std::vector<uint8_t>& need_exact) {
     BatchWork& b = e->batch;
     std::unique_lock<std::mutex> bg(b.mu);
     hipStream_t st = e->streams[0];
@@ -765,7 +809,8 @@ int batch_search_mfma(wax_hip_engine* e, const float* queries, uint32_t nq, int 
         for (uint32_t q = 0; q < qn; ++q) {
             const uint32_t gq = q0 + q;
             if (b.h_cert[q]) {
-                std::memcpy(out_hits + (size_t)gq * k_eff, b.h_hits + (size_t)q * k_eff, (size_t)k_eff * sizeof(wax_hip_hit));
+                const uint32_t w = (uint32_t)k_eff < stride ? (uint32_t)k_eff : stride;   // the rest of the row stays padded
+                std::memcpy(out_hits + (size_t)gq * stride, b.h_hits + (size_t)q * k_eff, (size_t)w * sizeof(wax_hip_hit));
             } else {
                 need_exact[gq] = 1;
                 e->st_batch_fallbacks++;
@@ -873,7 +918,6 @@ int wax_hip_engine_create(uint8_t metric, uint32_t dims, int device_id, wax_hip_
 
 void wax_hip_engine_destroy(wax_hip_engine* e) {
     if (!e) return;
-    g_outstanding.erase(e);   // a later engine may be allocated at the same address
     DeviceGuard g(e->device);
     (void)hipDeviceSynchronize();
     for (Slot* s : e->all_slots) free_slot(s);
@@ -887,6 +931,7 @@ void wax_hip_engine_destroy(wax_hip_engine* e) {
         (void)hipFree(e->ring_d_partials[i]);
         if (e->ring_ev0[i]) (void)hipEventDestroy(e->ring_ev0[i]);
         if (e->ring_ev1[i]) (void)hipEventDestroy(e->ring_ev1[i]);
+        if (e->ring_done[i]) (void)hipEventDestroy(e->ring_done[i]);
     }
     {
         BatchWork& b = e->batch;
@@ -916,8 +961,10 @@ int wax_hip_device_of(const wax_hip_engine* e) { return e ? e->device : -1; }
 
 int wax_hip_reserve(wax_hip_engine* e, uint64_t rows) {
     if (!e) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine is null");
+    REFUSE_IF_HOLDING(e);
     DeviceGuard g(e->device);
     WriteGuard w(e->lock);
+    sync_shard_work(e);
     int rc = reserve_rows(e, rows);
     if (rc == WAX_HIP_OK) e->idmap.reserve(rows);
     return rc;
@@ -928,8 +975,10 @@ int wax_hip_add_batch(wax_hip_engine* e, const uint64_t* frame_ids, const float*
     if (n == 0) return WAX_HIP_OK;  // :360
     if (!frame_ids || !rows) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "addBatch: null input");
     if (dims != e->dims) return fail(WAX_HIP_ERR_DIM_MISMATCH, dim_mismatch_msg(e->dims, dims));  // :367-370
+    REFUSE_IF_HOLDING(e);
     DeviceGuard g(e->device);
     WriteGuard w(e->lock);
+    sync_shard_work(e);
     e->batch.mirror_valid = false;
     e->batch.mirror_wanted = 0;
     const size_t row_bytes = (size_t)e->dims * sizeof(float);
@@ -1011,8 +1060,10 @@ int wax_hip_add_batch_device(wax_hip_engine* e, const uint64_t* frame_ids, const
     if (n == 0) return WAX_HIP_OK;
     if (!frame_ids || !d_rows) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "addBatch: null input");
     if (dims != e->dims) return fail(WAX_HIP_ERR_DIM_MISMATCH, dim_mismatch_msg(e->dims, dims));
+    REFUSE_IF_HOLDING(e);
     DeviceGuard g(e->device);
     WriteGuard w(e->lock);
+    sync_shard_work(e);
     e->batch.mirror_valid = false;
     e->batch.mirror_wanted = 0;
     { const int frc = flush_pending(e); if (frc != WAX_HIP_OK) return frc; }
@@ -1079,8 +1130,10 @@ int wax_hip_apply_put_embeddings(wax_hip_engine* e, const uint8_t* payloads, uin
 
 int wax_hip_remove(wax_hip_engine* e, uint64_t frame_id) {
     if (!e) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine is null");
+    REFUSE_IF_HOLDING(e);
     DeviceGuard g(e->device);
     WriteGuard w(e->lock);
+    sync_shard_work(e);
     if (e->count == 0) return WAX_HIP_OK;                 // :425
     e->batch.mirror_valid = false;
     e->batch.mirror_wanted = 0;
@@ -1119,13 +1172,13 @@ static int submit_impl(wax_hip_engine* e, const float* query, uint32_t dims, int
                        bool try_only) {
     if (!e || !out_ticket) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine/ticket is null");
     DeviceGuard g(e->device);
-    e->lock.lock_shared(g_outstanding[e] > 0);             // withReadLock (:447)
+    e->lock.lock_shared(holding(e) > 0);             // withReadLock (:447)
     { const int frc = flush_pending(e); if (frc != WAX_HIP_OK) { e->lock.unlock_shared(); return frc; } }   // staged single-frame appends reach HBM here
     Slot* s = nullptr;
     int rc = WAX_HIP_OK;
     do {
         if (e->count == 0) {                               // :448 — an empty ticket, no GPU work
-            rc = acquire_slot(e, &s, try_only, g_outstanding[e] > 0);
+            rc = acquire_slot(e, &s, try_only, holding(e) > 0);
             if (rc != WAX_HIP_OK) break;
             s->k_eff = 0; s->timed = false;
             break;
@@ -1140,7 +1193,7 @@ static int submit_impl(wax_hip_engine* e, const float* query, uint32_t dims, int
         }
         const int limit = clamp_topk(top_k);               // :450
         const int k_eff = (uint64_t)limit < e->count ? limit : (int)e->count;  // :451
-        rc = acquire_slot(e, &s, try_only, g_outstanding[e] > 0);
+        rc = acquire_slot(e, &s, try_only, holding(e) > 0);
         if (rc != WAX_HIP_OK) break;
         s->k_eff = k_eff;
         s->timed = e->time_kernels.load() != 0;
@@ -1167,20 +1220,22 @@ static int submit_impl(wax_hip_engine* e, const float* query, uint32_t dims, int
         e->tickets[t] = s;
         *out_ticket = t;
     }
-    g_outstanding[e] += 1;
+    note_submit(e, s);
     return WAX_HIP_OK;  // shared lock stays held until collect
 }
 
 // Shared tail of collect: either converts to (ids, scores) or hands back the raw hits (padded to kcap).
-static int collect_impl(wax_hip_engine* e, uint64_t ticket, uint64_t* out_ids, float* out_scores, uint32_t* out_count,
-                        wax_hip_hit* out_hits, uint32_t hits_cap);
+// `capacity`: entries the (ids, scores) arrays hold; `hits_cap`: entries of out_hits (every one is written).
+static int collect_impl(wax_hip_engine* e, uint64_t ticket, uint64_t* out_ids, float* out_scores, uint32_t capacity,
+                        uint32_t* out_count, wax_hip_hit* out_hits, uint32_t hits_cap);
 
-int wax_hip_search_collect(wax_hip_engine* e, uint64_t ticket, uint64_t* out_ids, float* out_scores, uint32_t* out_count) {
-    return collect_impl(e, ticket, out_ids, out_scores, out_count, nullptr, 0);
+int wax_hip_search_collect(wax_hip_engine* e, uint64_t ticket, uint64_t* out_ids, float* out_scores, uint32_t out_capacity,
+                           uint32_t* out_count) {
+    return collect_impl(e, ticket, out_ids, out_scores, out_capacity, out_count, nullptr, 0);
 }
 
-static int collect_impl(wax_hip_engine* e, uint64_t ticket, uint64_t* out_ids, float* out_scores, uint32_t* out_count,
-                        wax_hip_hit* out_hits, uint32_t hits_cap) {
+static int collect_impl(wax_hip_engine* e, uint64_t ticket, uint64_t* out_ids, float* out_scores, uint32_t capacity,
+                        uint32_t* out_count, wax_hip_hit* out_hits, uint32_t hits_cap) {
     if (!e || !out_count) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine/out_count is null");
     DeviceGuard g(e->device);
     Slot* s = nullptr;
@@ -1214,41 +1269,47 @@ static int collect_impl(wax_hip_engine* e, uint64_t ticket, uint64_t* out_ids, f
                     if (out_hits[i].key != KEY_PAD) ++m;
                 }
                 *out_count = m;
-            } else if (!out_ids || !out_scores) {
+            } else if ((!out_ids || !out_scores) && capacity > 0) {
                 rc = fail(WAX_HIP_ERR_INVALID_ARGUMENT, "output arrays are null");
             } else {
-                rc = hits_to_results(e->metric, s->h_hits, (uint32_t)s->k_eff, out_ids, out_scores, out_count);
+                rc = hits_to_results(e->metric, s->h_hits, (uint32_t)s->k_eff, out_ids, out_scores, capacity, out_count);
             }
         }
     }
+    note_collect(e, s);
     release_slot(e, s);
     e->lock.unlock_shared();
-    {
-        auto it = g_outstanding.find(e);   // tickets may be collected on another thread: clamp at zero
-        if (it != g_outstanding.end() && it->second > 0) it->second -= 1;
-    }
     return rc;
 }
 
+uint32_t wax_hip_result_capacity(int32_t top_k) { return (uint32_t)clamp_topk(top_k); }
+
 int wax_hip_search(wax_hip_engine* e, const float* query, uint32_t dims, int32_t top_k, uint64_t* out_ids,
-                   float* out_scores, uint32_t* out_count) {
+                   float* out_scores, uint32_t out_capacity, uint32_t* out_count) {
     uint64_t t = 0;
     int rc = wax_hip_search_submit(e, query, dims, top_k, &t);
     if (rc != WAX_HIP_OK) return rc;
-    return wax_hip_search_collect(e, t, out_ids, out_scores, out_count);
+    return wax_hip_search_collect(e, t, out_ids, out_scores, out_capacity, out_count);
 }
 
-// nq queries -> nq x kcap hits (ascending key, KEY_PAD padded). Chooses the MFMA path when the batch is
-// a genuine GEMM, otherwise pipelines single-query scans over the scratch-slot pool.
+// nq queries -> nq rows of `stride` hits (ascending key, every row KEY_PAD padded to `stride`). Chooses the MFMA path
+// when the batch is a genuine GEMM, otherwise pipelines single-query scans over the scratch-slot pool. The row
+// count is read under the lock by whichever path runs; the output layout depends on `stride` alone, so a
+// concurrent add can never make the library write past the caller's arrays.
 static int search_batch_hits_impl(wax_hip_engine* e, const float* queries, uint32_t nq, uint32_t dims, int32_t top_k,
-                                  wax_hip_hit* out_hits, uint32_t* out_counts, uint64_t kcap) {
-    const uint64_t cnt = e->count;
+                                  wax_hip_hit* out_hits, uint32_t stride, uint32_t* out_counts) {
+    for (uint32_t q = 0; q < nq; ++q) out_counts[q] = 0;
+    for (size_t i = 0; i < (size_t)nq * stride; ++i) out_hits[i] = wax_hip_hit{KEY_PAD, ID_PAD};
+    if (stride == 0) return WAX_HIP_OK;
+    const uint64_t cnt = e->count;                       // heuristics only; every path re-reads it under the lock
+    const uint64_t limit = (uint64_t)clamp_topk(top_k);
+    const uint64_t kguess = limit < cnt ? limit : cnt;
     // Enough queries for the scan to be a dense GEMM: bf16 MFMA path with exact re-score; queries
     // whose exactness certificate fails are re-run on the exact single-query path below.
     std::vector<uint8_t> need_exact;
     bool all = true;
     bool use_mfma = e->batch_mode.load() != 0 && (int64_t)nq >= e->batch_min.load() && dims == e->dims &&
-                    (dims % 64u) == 0 && cnt > 0 && kcap <= (uint64_t)kBatchMaxK && kcap > 0;
+                    (dims % 64u) == 0 && cnt > 0 && kguess <= (uint64_t)kBatchMaxK && kguess > 0;
     if (use_mfma && nq < 16) {
         // A small batch costs nq scans of the f32 store on the loop path but ONE pass over the bf16 mirror (half the
         // bytes) plus the fixed pipeline cost on the MFMA path, whatever nq is (measured, profiles/r01/bi_*: 100 K rows
@@ -1265,28 +1326,33 @@ static int search_batch_hits_impl(wax_hip_engine* e, const float* queries, uint3
     }
     if (use_mfma) {
         need_exact.assign(nq, 0);
-        int brc;
+        int brc = WAX_HIP_OK;
+        bool ran = false;
         {
             DeviceGuard g(e->device);
-            e->lock.lock_shared(g_outstanding[e] > 0);
+            e->lock.lock_shared(holding(e) > 0);
             { const int frc = flush_pending(e); if (frc != WAX_HIP_OK) { e->lock.unlock_shared(); return frc; } }
             if (e->row_base + e->count > 0x100000000ull) {
                 e->lock.unlock_shared();
                 return fail(WAX_HIP_ERR_CAPACITY, "row_base + count exceeds UInt32 row indices");
             }
-            const int k_eff = (int)((uint64_t)clamp_topk(top_k) < e->count ? (uint64_t)clamp_topk(top_k) : e->count);
-            brc = ((uint64_t)k_eff == kcap) ? batch_search_mfma(e, queries, nq, k_eff, out_hits, need_exact)
-                                            : fail(WAX_HIP_ERR_INTERNAL, "engine mutated during batch search");
+            const uint64_t k_eff = limit < e->count ? limit : e->count;   // the row count this batch is answered on
+            if (k_eff > 0 && k_eff <= (uint64_t)kBatchMaxK) {
+                brc = batch_search_mfma(e, queries, nq, (int)k_eff, out_hits, stride, need_exact);
+                ran = true;
+            }
             e->lock.unlock_shared();
         }
         if (brc != WAX_HIP_OK) return brc;
-        all = false;
-        for (uint32_t q = 0; q < nq; ++q)
-            if (!need_exact[q]) {
-                uint32_t m = 0;
-                for (uint64_t i = 0; i < kcap; ++i) m += out_hits[(uint64_t)q * kcap + i].key != KEY_PAD;
-                out_counts[q] = m;
-            }
+        if (ran) {
+            all = false;
+            for (uint32_t q = 0; q < nq; ++q)
+                if (!need_exact[q]) {
+                    uint32_t m = 0;
+                    for (uint32_t i = 0; i < stride; ++i) m += out_hits[(uint64_t)q * stride + i].key != KEY_PAD;
+                    out_counts[q] = m;
+                }
+        }
     }
     // Pipelined single-query scans: all queries (loop path) or only the uncertified ones.
     std::vector<uint32_t> todo;
@@ -1307,55 +1373,43 @@ static int search_batch_hits_impl(wax_hip_engine* e, const float* queries, uint3
         }
         if (rc != WAX_HIP_OK) break;
         const uint32_t q = todo[collected];
-        rc = collect_impl(e, tk[collected], nullptr, nullptr, &out_counts[q], out_hits + (uint64_t)q * kcap, (uint32_t)kcap);
+        rc = collect_impl(e, tk[collected], nullptr, nullptr, 0, &out_counts[q], out_hits + (uint64_t)q * stride, stride);
         ++collected;
         if (rc != WAX_HIP_OK) break;
     }
     if (rc != WAX_HIP_OK) {  // drain whatever is still in flight so the shared lock is released
         std::string keep = g_last_error;
         uint32_t dummy = 0;
-        std::vector<wax_hip_hit> tmp(kcap ? kcap : 1);
+        std::vector<wax_hip_hit> tmp(stride ? stride : 1);
         for (size_t i = collected; i < submitted; ++i)
-            (void)collect_impl(e, tk[i], nullptr, nullptr, &dummy, tmp.data(), (uint32_t)kcap);
+            (void)collect_impl(e, tk[i], nullptr, nullptr, 0, &dummy, tmp.data(), stride);
         g_last_error = keep;
     }
     return rc;
 }
 
 int wax_hip_search_batch_hits(wax_hip_engine* e, const float* queries, uint32_t nq, uint32_t dims, int32_t top_k,
-                              wax_hip_hit* out_hits, uint32_t* out_counts) {
+                              wax_hip_hit* out_hits, uint32_t out_stride, uint32_t* out_counts) {
     if (!e) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine is null");
     if (nq == 0) return WAX_HIP_OK;
-    if (!queries || !out_counts || !out_hits) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null input");
-    const uint64_t cnt = e->count;
-    const uint64_t limit = (uint64_t)clamp_topk(top_k);
-    const uint64_t kcap = limit < cnt ? limit : cnt;
-    if (kcap == 0) {
-        for (uint32_t q = 0; q < nq; ++q) out_counts[q] = 0;
-        return WAX_HIP_OK;
-    }
-    return search_batch_hits_impl(e, queries, nq, dims, top_k, out_hits, out_counts, kcap);
+    if (!queries || !out_counts || (!out_hits && out_stride)) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null input");
+    return search_batch_hits_impl(e, queries, nq, dims, top_k, out_hits, out_stride, out_counts);
 }
 
 int wax_hip_search_batch(wax_hip_engine* e, const float* queries, uint32_t nq, uint32_t dims, int32_t top_k,
-                         uint64_t* out_ids, float* out_scores, uint32_t* out_counts) {
+                         uint64_t* out_ids, float* out_scores, uint32_t out_stride, uint32_t* out_counts) {
     if (!e) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine is null");
     if (nq == 0) return WAX_HIP_OK;
     if (!queries || !out_counts) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null input");
-    const uint64_t cnt = e->count;
-    const uint64_t limit = (uint64_t)clamp_topk(top_k);
-    const uint64_t kcap = limit < cnt ? limit : cnt;
-    if (kcap == 0) {
-        for (uint32_t q = 0; q < nq; ++q) out_counts[q] = 0;
-        return WAX_HIP_OK;
-    }
-    if (!out_ids || !out_scores) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "output arrays are null");
-    std::vector<wax_hip_hit> hits((size_t)nq * kcap);
-    int rc = search_batch_hits_impl(e, queries, nq, dims, top_k, hits.data(), out_counts, kcap);
+    if ((!out_ids || !out_scores) && out_stride) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "output arrays are null");
+    const uint32_t limit = (uint32_t)clamp_topk(top_k);
+    const uint32_t w = limit < out_stride ? limit : out_stride;          // hits per query worth fetching
+    std::vector<wax_hip_hit> hits((size_t)nq * (w ? w : 1));
+    int rc = search_batch_hits_impl(e, queries, nq, dims, top_k, hits.data(), w, out_counts);
     if (rc != WAX_HIP_OK) return rc;
     for (uint32_t q = 0; q < nq; ++q)
-        hits_to_results(e->metric, hits.data() + (size_t)q * kcap, (uint32_t)kcap, out_ids + (uint64_t)q * kcap,
-                        out_scores + (uint64_t)q * kcap, &out_counts[q]);
+        hits_to_results(e->metric, hits.data() + (size_t)q * w, w, out_ids + (uint64_t)q * out_stride,
+                        out_scores + (uint64_t)q * out_stride, out_stride, &out_counts[q]);
     return WAX_HIP_OK;
 }
 
@@ -1364,6 +1418,7 @@ int wax_hip_search_batch(wax_hip_engine* e, const float* queries, uint32_t nq, u
 int wax_hip_set_row_base(wax_hip_engine* e, uint64_t row_base) {
     if (!e) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine is null");
     if (row_base > 0xffffffffull) return fail(WAX_HIP_ERR_CAPACITY, "row_base exceeds UInt32 row indices");
+    REFUSE_IF_HOLDING(e);
     WriteGuard w(e->lock);
     e->row_base = row_base;
     return WAX_HIP_OK;
@@ -1377,20 +1432,28 @@ int wax_hip_search_shard_device(wax_hip_engine* e, const float* query, uint32_t 
     if (kpad > FUSED_MAX_K) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "top_k too large for the device-resident shard path (max 192)");
     DeviceGuard g(e->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    e->lock.lock_shared(g_outstanding[e] > 0);
+    e->lock.lock_shared(holding(e) > 0);
     { const int frc = flush_pending(e); if (frc != WAX_HIP_OK) { e->lock.unlock_shared(); return frc; } }
     int rc = WAX_HIP_OK;
     do {
         if (e->row_base + e->count > 0x100000000ull) { rc = fail(WAX_HIP_ERR_CAPACITY, "row_base + count exceeds UInt32 row indices"); break; }
         const uint32_t r = e->ring_next.fetch_add(1) % kShardRing;
+        // One user of a ring entry at a time; the entry's previous use (kShardRing calls ago) must have finished on
+        // ITS stream before the pinned query is overwritten and the partials are reused.
+        std::unique_lock<std::mutex> rg(e->ring_mu[r]);
+        if (e->ring_busy[r]) {
+            hipError_t werr = hipEventSynchronize(e->ring_done[r]);
+            e->ring_busy[r] = false;
+            if (werr != hipSuccess) { rc = fail(WAX_HIP_ERR_INTERNAL, std::string("shard scratch wait: ") + hipGetErrorString(werr)); break; }
+        }
         if (!e->ring_d_query[r]) {
-            std::unique_lock<std::mutex> sg(e->slot_mu);
-            if (!e->ring_d_query[r]) {
+            {
                 hipError_t err = hipMalloc(&e->ring_d_query[r], (size_t)e->dims * sizeof(float));
                 if (err == hipSuccess) err = hipHostMalloc(&e->ring_h_query[r], (size_t)e->dims * sizeof(float), hipHostMallocDefault);
                 if (err == hipSuccess) err = hipMalloc(&e->ring_d_partials[r], (size_t)MAX_GRID_BLOCKS * FUSED_MAX_K * sizeof(int64_t));
                 if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ring_ev0[r], hipEventReleaseToDevice);
                 if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ring_ev1[r], hipEventReleaseToDevice);
+                if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ring_done[r], hipEventDisableTiming);
                 if (err != hipSuccess) { rc = fail(WAX_HIP_ERR_ALLOC, std::string("Failed to allocate shard scratch: ") + hipGetErrorString(err)); break; }
             }
         }
@@ -1406,7 +1469,7 @@ int wax_hip_search_shard_device(wax_hip_engine* e, const float* query, uint32_t 
         const float qn = query_norm(query, dims);
         hipError_t err = hipMemcpyAsync(e->ring_d_query[r], e->ring_h_query[r], (size_t)dims * sizeof(float), hipMemcpyHostToDevice, st);
         if (err != hipSuccess) { rc = fail(WAX_HIP_ERR_INTERNAL, std::string("query upload: ") + hipGetErrorString(err)); break; }
-        harvest_ring_event(e, (int)r);  // the entry's previous use (kShardRing calls ago) has long finished
+        harvest_ring_event(e, (int)r);  // the entry's previous use has finished (waited for above)
         const bool timed = e->time_kernels.load() != 0;
         // chain=true: scans issued on different caller streams never overlap each other, while the
         // merge kernel and whatever the caller enqueues next (RCCL all-gather, merge, download) do
@@ -1417,6 +1480,9 @@ int wax_hip_search_shard_device(wax_hip_engine* e, const float* query, uint32_t 
             std::unique_lock<std::mutex> sg(e->st_mu);
             e->ring_ev_pending[r] = true;
         }
+        // whatever was enqueued (even a partial chain after an error) must drain before the entry is reused
+        if (hipEventRecord(e->ring_done[r], st) == hipSuccess) e->ring_busy[r] = true;
+        else (void)hipStreamSynchronize(st);
     } while (0);
     e->lock.unlock_shared();
     return rc;
@@ -1443,28 +1509,28 @@ int wax_hip_merge_batch_hits_device(const wax_hip_hit* d_in, uint32_t n_shards, 
 int wax_hip_hits_to_results(uint8_t metric, const wax_hip_hit* hits, uint32_t n, uint64_t* out_ids, float* out_scores,
                             uint32_t* out_count) {
     if (!hits || !out_ids || !out_scores || !out_count) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null argument");
-    return hits_to_results(metric, hits, n, out_ids, out_scores, out_count);
+    return hits_to_results(metric, hits, n, out_ids, out_scores, n, out_count);
 }
 
 // ---- filtered search --------------------------------------------------------
 
 int wax_hip_search_filtered(wax_hip_engine* e, const float* query, uint32_t dims, int32_t top_k, int has_allow,
                             const uint64_t* allow_frame_ids, uint64_t n_allow, int has_min_score, float min_score,
-                            uint64_t* out_ids, float* out_scores, uint32_t* out_count) {
+                            uint64_t* out_ids, float* out_scores, uint32_t out_capacity, uint32_t* out_count) {
     if (out_count) *out_count = 0;
     if (!e) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine is null");
-    if (!query || !out_ids || !out_scores || !out_count) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    if (!query || !out_count || ((!out_ids || !out_scores) && out_capacity)) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null argument");
     if (has_allow && n_allow > 0 && !allow_frame_ids) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "allow-list is null");
     if (dims != e->dims) return fail(WAX_HIP_ERR_DIM_MISMATCH, dim_mismatch_msg(e->dims, dims));
     const int kpad = clamp_topk(top_k);
     uint32_t n = 0;
     if (!has_allow) {
         // no allow-list: the ordinary scan, then the score cut
-        int rc = wax_hip_search(e, query, dims, top_k, out_ids, out_scores, &n);
+        int rc = wax_hip_search(e, query, dims, top_k, out_ids, out_scores, out_capacity, &n);
         if (rc != WAX_HIP_OK) return rc;
     } else {
         DeviceGuard g(e->device);
-        e->lock.lock_shared(g_outstanding[e] > 0);
+        e->lock.lock_shared(holding(e) > 0);
         struct Unlock { RWLock& l; ~Unlock() { l.unlock_shared(); } } unlock{e->lock};
         { const int frc = flush_pending(e); if (frc != WAX_HIP_OK) return frc; }
         // allowed frame ids -> local rows, ascending and unique (row order is the tie-break order of every path)
@@ -1559,7 +1625,7 @@ int wax_hip_search_filtered(wax_hip_engine* e, const float* query, uint32_t dims
         HIP_TRY(hipMemcpyAsync(hits.data(), f.d_hits, (size_t)k_eff * sizeof(wax_hip_hit), hipMemcpyDeviceToHost, st),
                 WAX_HIP_ERR_INTERNAL, "hits download");
         HIP_TRY(hipStreamSynchronize(st), WAX_HIP_ERR_INTERNAL, "filtered search failed on device");
-        int rc = hits_to_results(e->metric, hits.data(), (uint32_t)k_eff, out_ids, out_scores, &n);
+        int rc = hits_to_results(e->metric, hits.data(), (uint32_t)k_eff, out_ids, out_scores, out_capacity, &n);
         if (rc != WAX_HIP_OK) return rc;
         e->st_searches++;
         e->st_rows += m;
@@ -1582,7 +1648,7 @@ void wax_hip_free(void* p) { std::free(p); }
 int wax_hip_serialize(wax_hip_engine* e, uint8_t** out_bytes, size_t* out_len) {
     if (!e || !out_bytes || !out_len) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null argument");
     DeviceGuard g(e->device);
-    e->lock.lock_shared(g_outstanding[e] > 0);  // withReadLock (:683)
+    e->lock.lock_shared(holding(e) > 0);  // withReadLock (:683)
     { const int frc = flush_pending(e); if (frc != WAX_HIP_OK) { e->lock.unlock_shared(); return frc; } }
     const uint64_t n = e->count;
     const uint64_t vec_bytes = n * (uint64_t)e->dims * 4ull;  // :697
@@ -1637,8 +1703,10 @@ int wax_hip_deserialize(wax_hip_engine* e, const uint8_t* data, size_t len) {
     if (id_len != n * 8ull) return fail(WAX_HIP_ERR_BAD_SEGMENT, "FrameId data length mismatch");
     if ((uint64_t)len < 36 + vec_len + 8 + id_len) return fail(WAX_HIP_ERR_BAD_SEGMENT, "Metal segment truncated frameId data");
 
+    REFUSE_IF_HOLDING(e);
     DeviceGuard g(e->device);
     WriteGuard w(e->lock);  // withWriteLock (:717)
+    sync_shard_work(e);
     e->batch.mirror_valid = false;
     e->batch.mirror_wanted = 0;
     e->pend_rows.store(0, std::memory_order_release);   // the store is replaced wholesale: staged appends are dropped with it
@@ -1745,7 +1813,7 @@ int wax_hip_time_scan_kernel(wax_hip_engine* e, const float* query, uint32_t dim
     if (dims != e->dims) return fail(WAX_HIP_ERR_DIM_MISMATCH, dim_mismatch_msg(e->dims, dims));
     if (iters == 0) iters = 1;
     DeviceGuard g(e->device);
-    e->lock.lock_shared(g_outstanding[e] > 0);
+    e->lock.lock_shared(holding(e) > 0);
     { const int frc = flush_pending(e); if (frc != WAX_HIP_OK) { e->lock.unlock_shared(); return frc; } }
     Slot* s = nullptr;
     int rc = WAX_HIP_OK;
@@ -1785,7 +1853,7 @@ int wax_hip_time_stream_read(wax_hip_engine* e, uint32_t iters, double* out_avg_
     if (!e || !out_avg_ms) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null argument");
     if (iters == 0) iters = 1;
     DeviceGuard g(e->device);
-    e->lock.lock_shared(g_outstanding[e] > 0);
+    e->lock.lock_shared(holding(e) > 0);
     { const int frc = flush_pending(e); if (frc != WAX_HIP_OK) { e->lock.unlock_shared(); return frc; } }
     Slot* s = nullptr;
     int rc = WAX_HIP_OK;

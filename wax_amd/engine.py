@@ -201,14 +201,20 @@ class HIPVectorEngine:
         raise_for_status(self._lib.wax_hip_reserve(self._h, int(rows)))
 
     # -- search -------------------------------------------------------------
+    def _result_capacity(self, topK: int) -> int:  # noqa: N803
+        """Entries to allocate for one query's results. The row count is only a hint that keeps the arrays small on
+        small engines (+64: room for rows added concurrently); the library is told the capacity and never writes
+        past it, so a racing add can at worst truncate to the best `cap` results, never overflow."""
+        return max(1, min(clampTopK(topK), self.count + 64))
+
     def searchArrays(self, vector, topK: int) -> Tuple[np.ndarray, np.ndarray]:  # noqa: N802,N803
         q = _as_f32(vector).reshape(-1)
-        cap = max(1, min(clampTopK(topK), max(self.count, 1)))
+        cap = self._result_capacity(topK)
         ids = np.empty(cap, dtype=np.uint64)
         scores = np.empty(cap, dtype=np.float32)
         got = ctypes.c_uint32(0)
         rc = self._lib.wax_hip_search(self._h, _fp(q), q.size, int(max(min(topK, 2**31 - 1), -2**31)), _u64p(ids),
-                                      _fp(scores), ctypes.byref(got))
+                                      _fp(scores), cap, ctypes.byref(got))
         raise_for_status(rc)
         return ids[:got.value].copy(), scores[:got.value].copy()
 
@@ -217,7 +223,7 @@ class HIPVectorEngine:
         FrameFilter.frameIds (allow-list; None = no list, empty = nothing allowed), `minScore` is SearchRequest.minScore.
         Returns the best topK among the ALLOWED frames (a pre-filter), best first, minus those scoring below minScore."""
         q = _as_f32(vector).reshape(-1)
-        cap = max(1, min(clampTopK(topK), max(self.count, 1)))
+        cap = self._result_capacity(topK)
         ids = np.empty(cap, dtype=np.uint64)
         scores = np.empty(cap, dtype=np.float32)
         got = ctypes.c_uint32(0)
@@ -228,7 +234,7 @@ class HIPVectorEngine:
             0 if allow is None else 1, None if allow is None or allow.size == 0 else _u64p(allow),
             0 if allow is None else int(allow.size),
             0 if minScore is None else 1, 0.0 if minScore is None else float(minScore),
-            _u64p(ids), _fp(scores), ctypes.byref(got))
+            _u64p(ids), _fp(scores), cap, ctypes.byref(got))
         raise_for_status(rc)
         return ids[:got.value].copy(), scores[:got.value].copy()
 
@@ -250,11 +256,12 @@ class HIPVectorEngine:
         return int(t.value)
 
     def collect(self, ticket: int, topK: int) -> Tuple[np.ndarray, np.ndarray]:  # noqa: N803
-        cap = max(1, min(clampTopK(topK), max(self.count, 1)))
+        """`topK` sizes the result arrays: pass what was given to submit() (a smaller value truncates to the best)."""
+        cap = clampTopK(topK)   # the ticket was answered on the row count at submit time: size by topK alone
         ids = np.empty(cap, dtype=np.uint64)
         scores = np.empty(cap, dtype=np.float32)
         got = ctypes.c_uint32(0)
-        rc = self._lib.wax_hip_search_collect(self._h, int(ticket), _u64p(ids), _fp(scores), ctypes.byref(got))
+        rc = self._lib.wax_hip_search_collect(self._h, int(ticket), _u64p(ids), _fp(scores), cap, ctypes.byref(got))
         raise_for_status(rc)
         return ids[:got.value].copy(), scores[:got.value].copy()
 
@@ -263,11 +270,11 @@ class HIPVectorEngine:
         if qs.ndim != 2:
             raise EncodingError("searchBatch: vectors must be [nq, dims]")
         nq, width = qs.shape
-        kcap = max(1, min(clampTopK(topK), max(self.count, 1)))
-        ids = np.empty((nq, kcap), dtype=np.uint64)
-        scores = np.empty((nq, kcap), dtype=np.float32)
+        kcap = max(1, min(clampTopK(topK), max(self.count, 1)))   # row width of the arrays (passed as the stride)
+        ids = np.zeros((nq, kcap), dtype=np.uint64)
+        scores = np.zeros((nq, kcap), dtype=np.float32)
         counts = np.zeros(nq, dtype=np.uint32)
-        rc = self._lib.wax_hip_search_batch(self._h, _fp(qs), nq, width, int(topK), _u64p(ids), _fp(scores),
+        rc = self._lib.wax_hip_search_batch(self._h, _fp(qs), nq, width, int(topK), _u64p(ids), _fp(scores), kcap,
                                             counts.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)))
         raise_for_status(rc)
         return ids, scores, counts
@@ -284,7 +291,7 @@ class HIPVectorEngine:
         hits[:, :, 1] = -1
         counts = np.zeros(nq, dtype=np.uint32)
         rc = self._lib.wax_hip_search_batch_hits(self._h, _fp(qs), nq, width, int(topK),
-                                                 hits.ctypes.data_as(ctypes.POINTER(_abi.Hit)),
+                                                 hits.ctypes.data_as(ctypes.POINTER(_abi.Hit)), kcap,
                                                  counts.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)))
         raise_for_status(rc)
         return hits, counts
