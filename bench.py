@@ -14,7 +14,11 @@ is the 1.5 KB query in and the k results out (both included in `value`).
 Rank 0 prints ONE JSON line (contract in the task statement): `value` = whole-job queries/s,
 `roofline` = achieved HBM GB/s of the scan kernel (HIP events recorded around every scan-kernel
 launch of the timed region, on the stream the kernel runs on) against the 8 TB/s MI355X peak,
-`cpu_baseline` = the oracle's multithreaded CPU scan timed on this host (rank 0, N=1 only).
+`cpu_baseline` = the oracle's CPU scan timed on this host (rank 0, N=1 only; one thread and all threads),
+`secondary` (N=1 only) = the other single-GPU BASELINE configurations, timed after the headline with the same
+barrier/synchronise bracket, each with its own roofline block: 1M x 384 single query (config 2), 1M x 384 with
+256 queries per step (config 3: bf16 MFMA GEMM + fused top-k) and one GPU's share of config 5 (1.25M x 768,
+1024 queries per step); the batched ones go through the device-resident entry point (queries already in HBM).
 """
 from __future__ import annotations
 
@@ -30,6 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PF dense)
 CORPUS_SEED = 20260220
 QUERY_SEED = 7
 GRANULE = 65536
@@ -51,6 +56,7 @@ def parse_args():
     p.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     p.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-secondary", action="store_true", help="skip the secondary configurations (N=1 only)")
     p.add_argument("--host-merge", action="store_true", help="N>1: merge gathered hits on the host instead of the device")
     p.add_argument("--exchange", choices=["rccl", "host"], default="rccl",
                    help="N>1: rccl = all-gather device buffers over RCCL (default); host = download + gloo all-gather "
@@ -74,6 +80,14 @@ def device_rows(torch, lo, hi, dims, dev):
         r = g0 + b
 
 
+def _human_rows(n):
+    if n % 1_000_000 == 0:
+        return f"{n // 1_000_000}M"
+    if n % 1000 == 0:
+        return f"{n // 1000}K"
+    return str(n)
+
+
 def unit_queries(n, dims):
     rng = np.random.Generator(np.random.PCG64(QUERY_SEED))
     q = rng.standard_normal((n, dims))
@@ -82,32 +96,158 @@ def unit_queries(n, dims):
 
 
 def cpu_baseline(torch, args, dev, queries):
-    """The oracle's CPU scan (C restatement of the reference arithmetic, all host threads) on a
-    bounded sample of the same corpus. Reported next to the GPU number; never the thing measured."""
+    """The oracle's CPU scan (C restatement of the reference's arithmetic: a3 + a5) on a bounded sample of the same
+    corpus, timed on this host as BASELINE.md §3 prescribes: (i) one thread, (ii) all host threads (static row
+    partition, per-thread heap, merge). The inner loop is the metric-specialised FMA kernel (cosine: dot and |v|^2
+    only), and the sample is first-touched by the threads that scan it (NUMA-local pages). Reported next to the GPU
+    number; never the thing measured. Wax's actual CPU engine (USearch HNSW through Swift) cannot run here."""
     import oracle
     oracle.build()
     n_s = min(args.cpu_sample_rows, args.rows)
-    sample = np.empty((n_s, args.dims), dtype=np.float32)
-    for lo, x in device_rows(torch, 0, n_s, args.dims, dev):
-        sample[lo:lo + x.shape[0]] = x.cpu().numpy()
     threads = oracle.max_threads()
-    oracle.scan_topk_mt(0, sample, queries[0], args.topk, threads)  # warm-up / page-in
-    t0 = time.perf_counter()
-    done = 0
-    while True:
-        oracle.scan_topk_mt(0, sample, queries[done % len(queries)], args.topk, threads)
-        done += 1
-        el = time.perf_counter() - t0
-        if el >= args.cpu_baseline_seconds or done >= 200:
-            break
-    qps_sample = done / el
-    qps_full = qps_sample * n_s / args.rows
+    sample = oracle.numa_sample(n_s, args.dims, threads)
+    for lo, x in device_rows(torch, 0, n_s, args.dims, dev):
+        blk = x.cpu().numpy()
+        oracle.copy_rows(sample[lo:lo + blk.shape[0]], blk, max(1, min(threads, 16)))
+
+    def timed(nthreads, budget_s, max_queries):
+        oracle.scan_topk_fast(0, sample, queries[0], args.topk, nthreads)  # warm-up / page-in
+        t0 = time.perf_counter()
+        done = 0
+        while True:
+            oracle.scan_topk_fast(0, sample, queries[done % len(queries)], args.topk, nthreads)
+            done += 1
+            el = time.perf_counter() - t0
+            if el >= budget_s or done >= max_queries:
+                break
+        return done, el
+
+    variants = []
+    for nthreads, budget, cap in ((1, args.cpu_baseline_seconds / 3.0, 40), (threads, args.cpu_baseline_seconds, 400)):
+        done, el = timed(nthreads, budget, cap)
+        qps_sample = done / el
+        variants.append({
+            "threads": nthreads, "value": qps_sample * n_s / args.rows, "unit": "queries/s",
+            "sample_qps": qps_sample, "sample_gbps": n_s * args.dims * 4 * qps_sample / 1e9,
+            "sample": f"{done} queries over the first {n_s} rows in {el:.1f} s",
+        })
+    best = variants[-1]
     return {
-        "value": qps_full, "unit": "queries/s", "cores": threads, "kind": "port",
-        "sample": f"{done} queries over the first {n_s} rows of the same corpus in {el:.1f} s on {threads} threads "
-                  f"({qps_sample:.2f} q/s on the sample = {n_s * args.dims * 4 * qps_sample / 1e9:.1f} GB/s), "
-                  f"scaled by {n_s}/{args.rows} rows to the full workload",
+        "value": best["value"], "unit": "queries/s", "cores": threads, "kind": "port",
+        "sample": f"{best['sample']} of the same corpus on {threads} threads ({best['sample_qps']:.2f} q/s on the sample = "
+                  f"{best['sample_gbps']:.1f} GB/s), scaled by {n_s}/{args.rows} rows to the full workload; "
+                  f"metric-specialised FMA inner loop, NUMA first-touch by the scanning threads",
+        "variants": variants,
     }
+
+
+# ---------------------------------------------------------------------------
+# secondary configurations (world == 1): same bracket as the headline, each with its own roofline block
+
+def _bracket(torch):
+    torch.cuda.synchronize()
+
+
+def secondary_single_query(torch, dev, rows, dims, k, steps, warmup, depth):
+    """BASELINE config 2: rows x dims f32, one query per step, the headline's code path at another size."""
+    from wax_amd import HIPVectorEngine, VectorMetric
+    eng = HIPVectorEngine(metric=VectorMetric.cosine, dimensions=dims)
+    eng.reserve(rows)
+    for r0, x in device_rows(torch, 0, rows, dims, dev):
+        eng.addBatchDevice(np.arange(r0, r0 + x.shape[0], dtype=np.uint64), x)
+    queries = unit_queries(warmup + steps, dims)
+    eng.setTuning("time_kernels", 1)
+    eng.setTuning("streams", 2)
+    eng.setTuning("slots", max(depth, 2))
+
+    def run(qs):
+        pending = []
+        for q in qs:
+            if len(pending) >= depth:
+                eng.collect(pending.pop(0), k)
+            pending.append(eng.submit(q, k))
+        while pending:
+            eng.collect(pending.pop(0), k)
+
+    run(queries[:warmup])
+    eng.setTuning("reset_stats", 1)
+    _bracket(torch)
+    t0 = time.perf_counter()
+    run(queries[warmup:])
+    _bracket(torch)
+    el = time.perf_counter() - t0
+    st = eng.stats()
+    launches = int(st.scan_kernels_timed)
+    kern_ms = st.scan_kernel_ms_total / launches if launches else float("nan")
+    nbytes = rows * dims * 4
+    achieved = nbytes / (kern_ms * 1e-3) / 1e9
+    eng.close()
+    return {
+        "config": f"{rows} x {dims} f32 cosine top-{k}, one query per step, 1 GPU (BASELINE config 2)",
+        "value": steps / el, "unit": "queries/s", "steps": steps, "warmup": warmup, "ms_per_step": el / steps * 1e3,
+        "dtype": "f32",
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                     "kernel": "wax::scan_kernel", "kernel_avg_ms": kern_ms, "kernel_launches_timed": launches,
+                     "algorithmic_bytes_per_launch": nbytes},
+    }
+
+
+def secondary_batched(torch, dev, rows, dims, nq, k, steps, warmup, label, row_base=0):
+    """BASELINE configs 3 / 5 (one GPU's share): nq queries per step as a bf16 MFMA GEMM + fused top-k + exact f32
+    re-score. Queries and results stay in HBM (wax_hip_search_batch_hits_device): the timed region holds no
+    host<->device traffic except nq certificate flags per step."""
+    from wax_amd import HIPVectorEngine, VectorMetric
+    eng = HIPVectorEngine(metric=VectorMetric.cosine, dimensions=dims)
+    eng.reserve(rows)
+    for r0, x in device_rows(torch, 0, rows, dims, dev):
+        eng.addBatchDevice(np.arange(r0, r0 + x.shape[0], dtype=np.uint64), x)
+    eng.setRowBase(row_base)
+    dq = torch.from_numpy(unit_queries(nq, dims)).to(dev)
+    out = torch.empty((nq, k, 2), dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def step():
+        eng.searchBatchHitsDevice(dq.data_ptr(), nq, k, out.data_ptr(), k, stream)
+
+    step()                                   # builds the bf16 mirror (untimed, like the corpus upload)
+    for _ in range(warmup):
+        step()
+    fb0 = eng.getTuning("batch_fallbacks")
+    eng.setTuning("time_kernels", 1)
+    eng.setTuning("reset_stats", 1)
+    _bracket(torch)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    _bracket(torch)
+    el = time.perf_counter() - t0
+    st = eng.stats()
+    launches = int(st.batch_gemms_timed)
+    kern_ms = st.batch_gemm_ms_total / launches if launches else float("nan")
+    flops = 2.0 * nq * rows * dims
+    nbytes = rows * dims * 2                  # bf16 mirror, streamed once per launch
+    t_hbm, t_mfma = nbytes / (HBM_PEAK_GBPS * 1e9), flops / (MFMA_BF16_PEAK_TFLOPS * 1e12)
+    bound = "hbm" if t_hbm >= t_mfma else "mfma"
+    if bound == "hbm":
+        achieved, peak, unit = nbytes / (kern_ms * 1e-3) / 1e9, HBM_PEAK_GBPS, "GB/s"
+    else:
+        achieved, peak, unit = flops / (kern_ms * 1e-3) / 1e12, MFMA_BF16_PEAK_TFLOPS, "TFLOP/s"
+    res = {
+        "config": label,
+        "value": nq * steps / el, "unit": "queries/s", "steps": steps, "warmup": warmup, "ms_per_step": el / steps * 1e3,
+        "dtype": "bf16 GEMM, exact f32 re-score", "queries_per_step": nq,
+        "end_to_end_tflops_bf16": flops / (el / steps) / 1e12,
+        "end_to_end_frac_of_roof": max(t_hbm, t_mfma) / (el / steps),
+        "certificate_fallbacks": int(eng.getTuning("batch_fallbacks") - fb0),
+        "pipeline": "one-pass" if eng.getTuning("onepass_queries") > 0 else "slab",
+        "roofline": {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
+                     "kernel": "wax::batch_gemm_rega_kernel" if dims != 768 else "wax::batch_gemm_ksplit_kernel",
+                     "kernel_avg_ms": kern_ms, "kernel_launches_timed": launches,
+                     "algorithmic_bytes_per_launch": nbytes, "algorithmic_flops_per_launch": flops,
+                     "hbm_floor_ms": t_hbm * 1e3, "mfma_floor_ms": t_mfma * 1e3},
+    }
+    eng.close()
+    return res
 
 
 def main():
@@ -246,17 +386,21 @@ def main():
         kern_ms = (st.scan_kernel_ms_total / launches) if launches else float("nan")
         bytes_per_launch = (hi - lo) * dims * 4
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if launches else float("nan")
-        traffic = None
+        # HBM traffic needs a PMC pass of its own (rocprofv3 --pmc FETCH_SIZE, never combined with tracing): it cannot be
+        # measured inside this run. A figure REPLAYED from the committed counter pass of this same command is reported
+        # with its source; without a matching pass the field is null.
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 if tj.get("rows_per_launch") == hi - lo and tj.get("dims") == dims:
                     traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_source = "replayed from profiles/latest_traffic.json (" + str(tj.get("source", "rocprofv3 --pmc FETCH_SIZE pass of this command")) + "), not measured in this run"
             except Exception:  # noqa: BLE001
                 traffic = None
         out = {
-            "metric": "queries/sec, 10M x 384-dim f32 cosine top-10 brute-force scan (single query per step)",
+            "metric": f"queries/sec, {_human_rows(n)} x {dims}-dim f32 cosine top-{k} brute-force scan (single query per step)",
             "value": qps,
             "unit": "queries/s",
             "n_gpus": world,
@@ -272,7 +416,8 @@ def main():
                 "workload": f"{n} x {dims}-dim f32 unit-norm Gaussian corpus (seed {CORPUS_SEED}), cosine top-{k}, "
                             f"one query per step, corpus resident in HBM and row-sharded over {world} GPU(s)",
                 "rows": n, "dims": dims, "top_k": k, "rows_per_gpu": hi - lo,
-                "parallelism": f"row-shard x{world}" + (" + RCCL all-gather of per-shard top-k" if world > 1 else ""),
+                "parallelism": f"row-shard x{world}" + ((" + RCCL all-gather of per-shard top-k" if use_rccl else
+                                                          " + host (gloo) all-gather of per-shard top-k") if world > 1 else ""),
                 "pipeline_depth": args.depth,
                 "merge": "host" if (world > 1 and (args.host_merge or not use_rccl)) else "device",
                 "exchange": ("rccl all_gather" if use_rccl else "host (gloo)") if world > 1 else "none",
@@ -285,6 +430,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS if launches else None,
                 "traffic": traffic,
+                "traffic_source": traffic_source,
                 "kernel": "wax::scan_kernel (fused scan + per-wave top-k)",
                 "kernel_avg_ms": kern_ms,
                 "kernel_launches_timed": launches,
@@ -298,6 +444,26 @@ def main():
             out["cpu_baseline"] = cpu_baseline(torch, args, dev, queries)
         elif world == 1:
             out["cpu_baseline"] = None
+        if world == 1 and not args.no_secondary:
+            # the other single-GPU BASELINE configurations, timed after the headline (its engine is released first)
+            gc.enable()
+            eng.close()
+            gc.collect()
+            gc.disable()
+            sec = []
+            for fn in (lambda: secondary_single_query(torch, dev, 1_000_000, 384, k, max(args.steps, 100), max(args.warmup, 10), args.depth),
+                       lambda: secondary_batched(torch, dev, 1_000_000, 384, 256, k, max(args.steps, 20), max(args.warmup, 3),
+                                                 "1000000 x 384, 256 queries per step, cosine top-10, bf16 MFMA GEMM + fused top-k, 1 GPU "
+                                                 "(BASELINE config 3), queries and results resident in HBM"),
+                       lambda: secondary_batched(torch, dev, 1_250_000, 768, 1024, k, max(args.steps // 2, 10), max(args.warmup, 3),
+                                                 "1250000 x 768 (one GPU's share of 10M x 768 over 8 GPUs), 1024 queries per step, cosine "
+                                                 "top-10, bf16 MFMA GEMM + fused top-k (BASELINE config 5, per-GPU part), queries and "
+                                                 "results resident in HBM", row_base=3_750_000)):
+                try:
+                    sec.append(fn())
+                except Exception as ex:  # noqa: BLE001 — a secondary failure must not lose the headline line
+                    sec.append({"error": f"{type(ex).__name__}: {ex}"})
+            out["secondary"] = sec
         print(json.dumps(out), flush=True)
     if world > 1:
         if use_rccl:

@@ -93,6 +93,10 @@ typedef struct wax_hip_stats_t {
     double   last_scan_kernel_ms;  /* HIP-event time of the most recent timed scan kernel (0 if timing off) */
     double   scan_kernel_ms_total; /* sum of HIP-event scan-kernel times since "reset_stats" ("time_kernels"=1) */
     uint64_t scan_kernels_timed;   /* number of scan-kernel launches in that sum */
+    double   batch_gemm_ms_total;  /* sum of HIP-event times of the batched path's filtering GEMM launches ("time_kernels"=1) */
+    uint64_t batch_gemms_timed;    /* number of GEMM launches in that sum */
+    uint64_t batch_gemm_rows;      /* corpus rows those launches covered, summed (algorithmic bytes = rows * dims * 2, bf16 mirror) */
+    uint64_t batch_gemm_queries;   /* queries those launches served, summed (flops = 2 * queries * rows-per-launch * dims) */
 } wax_hip_stats_t;
 
 /* ---- availability ------------------------------------------------------- */
@@ -185,6 +189,16 @@ int wax_hip_search_batch(wax_hip_engine* e, const float* queries, uint32_t nq, u
 int wax_hip_search_batch_hits(wax_hip_engine* e, const float* queries, uint32_t nq, uint32_t dims, int32_t top_k,
                               wax_hip_hit* out_hits, uint32_t out_stride, uint32_t* out_counts);
 
+/* Device-resident form of the same search: d_queries is nq x dims f32 in HBM on the engine's device (embeddings that
+ * were produced on the GPU never bounce through the host), d_out_hits receives nq rows of out_stride hits in HBM
+ * (ascending key, padded). Blocking. `stream` (a hipStream_t, NULL = the null stream) is the stream whose earlier
+ * work produced d_queries; the library orders its own work behind it, and on return all results are complete.
+ * Inside, the batch runs without a host round trip (certificate flags come back once, at the end); uncertified
+ * queries are re-run on the exact path in place. This is the entry point the batched BASELINE configs are timed on
+ * (inputs resident in HBM), and what a row-sharded deployment feeds to its RCCL all-gather. */
+int wax_hip_search_batch_hits_device(wax_hip_engine* e, const float* d_queries, uint32_t nq, uint32_t dims, int32_t top_k,
+                                     wax_hip_hit* d_out_hits, uint32_t out_stride, void* stream);
+
 /* ---- sharded search: per-shard top-k left in HBM for the RCCL exchange ---- */
 
 /* Declares that this engine holds rows [row_base, row_base+count) of a corpus
@@ -248,10 +262,14 @@ int wax_hip_stats(wax_hip_engine* e, wax_hip_stats_t* out);
  * "reset_stats" (any value: zero the counters), "streams" (1..4 in-order streams the slots rotate over),
  * "batch_mode" (0 = never use the MFMA batched path), "batch_min" (smallest batch that may use it, default 1; below 16 queries a cost model picks
  * the cheaper of one GEMM pass over the bf16 mirror and nq f32 scans),
- * "batch_slab_mb", "batch_growth", "batch_first" (slab schedule of the batched path), "batch_rega" (0 LDS-tiled GEMM
+ * "batch_onepass" (0 = always the slab pipeline), "batch_onepass_tiles" (smallest store, in 64-row GEMM tiles, that the one-pass
+ * pipeline takes; default 1024), "batch_survivors" (one-pass: expected survivors per query as a multiple of k', default 8),
+ * "batch_sample_div" (one-pass: 1/this of the tiles are sampled for the thresholds, default 64), "batch_workspaces" (concurrent
+ * batched searches per engine, default 4),
+ * "batch_slab_mb", "batch_growth", "batch_first" (slab schedule of the slab pipeline), "batch_rega" (0 LDS-tiled GEMM
  * only, 1 register-resident GEMM with register staging, 2 with LDS-DMA staging), "batch_debug" (timing experiments:
  * results are NOT valid with bits 1/2/4/8 set). get-only: "variant_count", "scan_grid", "fused_max_k", "batch_queries",
- * "batch_fallbacks". */
+ * "batch_fallbacks", "onepass_queries", "batch_max_k". */
 int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value);
 int64_t wax_hip_get_tuning(wax_hip_engine* e, const char* key);
 /* Times `iters` back-to-back launches of ONLY the scan kernel for `query`

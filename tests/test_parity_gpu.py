@@ -713,7 +713,19 @@ def test_bench_contract_and_shard_invariance(wax, tmp_path):
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["kernel_launches_timed"] == 12
     assert abs(one["value"] - 12 / (one["ms_per_step"] * 12e-3)) < 1e-6 * one["value"]
+    assert "300K x 384" in one["metric"] and one["config"]["parallelism"] == "row-shard x1"
+    assert r["traffic"] is None and r["traffic_source"] is None      # no counter pass exists for this row count
+    sec = one["secondary"]
+    assert len(sec) == 3 and all("error" not in x for x in sec), sec
+    for x in sec:
+        rr = x["roofline"]
+        assert x["value"] > 0 and x["ms_per_step"] > 0 and rr["kernel_launches_timed"] >= x["steps"]
+        assert rr["bound"] in ("hbm", "mfma") and 0 < rr["frac"] < 1.2 and abs(rr["frac"] - rr["achieved"] / rr["peak"]) < 1e-9
+    assert sec[1]["pipeline"] == "one-pass" and sec[2]["pipeline"] == "one-pass"
+    assert sec[1]["certificate_fallbacks"] == 0 and sec[2]["certificate_fallbacks"] == 0
+    print("\n[bench secondary] " + " | ".join(f"{x['value']:.0f} q/s, {x['ms_per_step']:.3f} ms/step, frac {x['roofline']['frac']:.3f}" for x in sec))
     two = _run_bench(2, [], tmp_path)
+    assert "host (gloo)" in two["config"]["parallelism"]
     three = _run_bench(3, [], tmp_path)
     assert two["n_gpus"] == 2 and three["n_gpus"] == 3
     assert one["config"]["last_result_checksum"] == two["config"]["last_result_checksum"] \
@@ -958,27 +970,28 @@ def test_filtered_search_equals_filtered_full_ranking(wax, metric, dims):
 def test_batch_gemm_variants_agree(wax, dims):
     """Every GEMM variant behind the batched path — LDS-tiled (batch_rega 0), register-resident with register
     staging (1) and with LDS-DMA staging (2; D = 768 has the K-split kernel for both) — gives the single-query
-    answers bit for bit, over several slab schedules."""
+    answers bit for bit, over several slab schedules of the slab pipeline and through the one-pass pipeline."""
     n = 150_000
     corpus = oracle.gaussian_unit_rows(9, n, dims)
     eng = make_engine(wax, 0, dims, corpus)
     queries = oracle.gaussian_unit_queries(300, dims, seed=31)
     ref = None
-    for rega in (1, 2, 0):
-        for growth in (8, 3):
-            eng.setTuning("batch_rega", rega)
-            eng.setTuning("batch_growth", growth)
-            before = eng.getTuning("batch_queries")
-            ids, scores, counts = eng.searchBatch(queries, 10)
-            assert eng.getTuning("batch_queries") - before == 300
-            if ref is None:
-                ref = (ids, scores, counts)
-                for i in (0, 1, 150, 299):
-                    s_ids, s_scores = eng.searchArrays(queries[i], 10)
-                    assert np.array_equal(ids[i], s_ids) and np.array_equal(scores[i], s_scores)
-            else:
-                assert np.array_equal(ids, ref[0]) and np.array_equal(scores, ref[1]) and np.array_equal(counts, ref[2])
-    assert eng.getTuning("batch_fallbacks") <= 60
+    for onepass, rega, growth in [(0, 1, 8), (0, 1, 3), (0, 2, 8), (0, 2, 3), (0, 0, 8), (0, 0, 3), (1, 1, 8), (1, 2, 8)]:
+        eng.setTuning("batch_onepass", onepass)
+        eng.setTuning("batch_rega", rega)
+        eng.setTuning("batch_growth", growth)
+        before, before1 = eng.getTuning("batch_queries"), eng.getTuning("onepass_queries")
+        ids, scores, counts = eng.searchBatch(queries, 10)
+        assert eng.getTuning("batch_queries") - before == 300
+        assert eng.getTuning("onepass_queries") - before1 == (300 if onepass else 0)
+        if ref is None:
+            ref = (ids, scores, counts)
+            for i in (0, 1, 150, 299):
+                s_ids, s_scores = eng.searchArrays(queries[i], 10)
+                assert np.array_equal(ids[i], s_ids) and np.array_equal(scores[i], s_scores)
+        else:
+            assert np.array_equal(ids, ref[0]) and np.array_equal(scores, ref[1]) and np.array_equal(counts, ref[2])
+    assert eng.getTuning("batch_fallbacks") <= 80
     eng.close()
 
 
@@ -1365,3 +1378,157 @@ def test_shard_scratch_ring_is_safe_beyond_its_depth(wax):
     torch.cuda.synchronize()
     ids, _ = eng.searchArrays(queries[0], k)
     assert int(expect[0][0][0]) not in ids
+
+
+# ---------------------------------------------------------------------------
+# one-pass batched pipeline (sampled thresholds -> one filtering GEMM -> fused finish) and the device-resident entry point
+
+@pytest.mark.parametrize("metric,dims", [(0, 384), (1, 384), (0, 128), (0, 768), (1, 768), (0, 256), (0, 512)])
+def test_batch_onepass_pipeline_is_exact(wax, metric, dims):
+    """Stores of >= 1024 GEMM tiles take the one-pass pipeline: every answer equals the single-query path bit for bit
+    (ids, scores, counts), for k from 1 to 300 (k' = 2k + 32 up to 632: the real caller's candidateLimit range,
+    UnifiedSearch.swift:1195-1200), with a row_base, with a query count that is not a multiple of 256; spot-checked
+    against the f64 oracle."""
+    n = 90_000 if dims != 768 else 50_000
+    corpus = oracle.gaussian_unit_rows(3, n, dims)
+    if metric != 0:
+        corpus = corpus * np.linspace(0.6, 1.8, n, dtype=np.float32)[:, None]
+    ids = np.arange(n, dtype=np.uint64) * 3 + 11
+    eng = make_engine(wax, metric, dims, corpus, ids)
+    eng.setRowBase(4096)
+    queries = oracle.gaussian_unit_queries(301, dims, seed=77)
+    rng = np.random.default_rng(5)
+    for k in (10, 1, 80, 150, 300):
+        before, before1 = eng.getTuning("batch_queries"), eng.getTuning("onepass_queries")
+        b_ids, b_scores, counts = eng.searchBatch(queries, k)
+        assert eng.getTuning("batch_queries") - before == 301 and eng.getTuning("onepass_queries") - before1 == 301, k
+        for i in list(rng.permutation(301)[:24]) + [0, 300]:
+            s_ids, s_scores = eng.searchArrays(queries[i], k)
+            assert counts[i] == len(s_ids) == k
+            assert np.array_equal(b_ids[i, :k], s_ids), (metric, dims, k, i)
+            assert np.array_equal(b_scores[i, :k], s_scores), (metric, dims, k, i)
+        for i in (7, 123):
+            e_ids, e_scores, _, _ = oracle.search(metric, corpus, ids, queries[i], k)
+            x = oracle.search(metric, corpus, ids, queries[i], k + MARGIN)[1]
+            assert_parity(b_ids[i, :k], b_scores[i, :k], e_ids, e_scores, x, f"onepass m{metric} d{dims} k{k} q{i}")
+    fb = eng.getTuning("batch_fallbacks")
+    print(f"\n[onepass m{metric} d{dims}] fallbacks {fb} of {5 * 301}")
+    if metric == 0:
+        assert fb <= 30
+    # the slab pipeline gives the same answers where it applies (k <= 80)
+    o_ids, o_scores, _ = eng.searchBatch(queries, 10)
+    eng.setTuning("batch_onepass", 0)
+    before1 = eng.getTuning("onepass_queries")
+    s_ids, s_scores, _ = eng.searchBatch(queries, 10)
+    assert eng.getTuning("onepass_queries") == before1
+    assert np.array_equal(o_ids, s_ids) and np.array_equal(o_scores, s_scores)
+    eng.close()
+
+
+def test_batch_onepass_adversarial_corpora(wax):
+    """Where the sampled threshold cannot certify — exact duplicates (period-256 tie corpus), a clustered corpus whose
+    near neighbours sit in one contiguous block, a zero query, NaN / inf rows — the answer still equals the single-query
+    path (certificate refuses, exact path answers), and thresholds tuned far too tight or too loose change nothing."""
+    dims = 128
+    n = 100_000
+    ties = oracle.tie_pattern(0, n, dims)
+    eng = make_engine(wax, 0, dims, ties)
+    queries = np.abs(oracle.gaussian_unit_queries(40, dims))
+    before1 = eng.getTuning("onepass_queries")
+    _batch_vs_single(eng, queries, 24)
+    assert eng.getTuning("onepass_queries") - before1 == 40 and eng.getTuning("batch_fallbacks") > 0
+    eng.close()
+    # clustered: rows [40000, 40600) are tight around one direction, queries aim at it; special values sprinkled in
+    corpus = oracle.gaussian_unit_rows(1, n, dims)
+    centre = oracle.gaussian_unit_queries(1, dims, seed=99)[0]
+    noise = oracle.gaussian_unit_rows(2, 600, dims)
+    corpus[40000:40600] = centre[None, :] + np.float32(0.05) * noise
+    corpus[5] = 0.0
+    corpus[7, 3] = np.nan
+    corpus[11, 0] = np.inf
+    corpus[13, 1] = -np.inf
+    corpus[15] = corpus[14]
+    eng = make_engine(wax, 0, dims, corpus)
+    queries = oracle.gaussian_unit_queries(64, dims, seed=3)
+    queries[:32] = centre[None, :] + np.float32(0.02) * oracle.gaussian_unit_rows(4, 32, dims)
+    queries[40] = 0.0
+    queries[41] = corpus[14]
+    for survivors, div in [(8, 64), (2, 64), (64, 64), (8, 4), (8, 4096)]:
+        eng.setTuning("batch_survivors", survivors)
+        eng.setTuning("batch_sample_div", div)
+        before1 = eng.getTuning("onepass_queries")
+        _batch_vs_single(eng, queries, 30)
+        assert eng.getTuning("onepass_queries") - before1 == 64
+    eng.close()
+
+
+def test_search_batch_hits_device_resident(wax):
+    """wax_hip_search_batch_hits_device: queries and hits stay in HBM; equals the host-pointer call bit for bit — through
+    the one-pass pipeline, the slab pipeline, the loop path (small batch / unsupported dims), with wider and narrower
+    row strides, more than 1024 queries, and an empty engine."""
+    import torch
+    from wax_amd import sharded
+    dev = torch.device("cuda", 0)
+    KEY_PAD = (1 << 63) - 1
+
+    def run(eng, queries, k, stride):
+        dq = torch.from_numpy(np.ascontiguousarray(queries)).to(dev)
+        out = torch.full((len(queries), stride, 2), 5, dtype=torch.int64, device=dev)
+        guard = torch.full((8,), 77, dtype=torch.int64, device=dev)
+        eng.searchBatchHitsDevice(dq.data_ptr(), len(queries), k, out.data_ptr(), stride, torch.cuda.current_stream(dev).cuda_stream)
+        assert torch.all(guard == 77)
+        return out.cpu().numpy()
+
+    for dims, n, nq in [(384, 80_000, 300), (384, 20_000, 300), (100, 5_000, 20), (384, 80_000, 3), (384, 70_000, 1500)]:
+        corpus = oracle.gaussian_unit_rows(21, n, dims)
+        eng = make_engine(wax, 0, dims, corpus, np.arange(n, dtype=np.uint64) + 1000)
+        queries = oracle.gaussian_unit_queries(nq, dims, seed=n % 97)
+        for k, stride in [(10, 10), (10, 16), (10, 4)]:
+            hits = run(eng, queries, k, stride)
+            ref, _ = eng.searchBatchHits(queries, k)
+            w = min(k, stride)
+            assert np.array_equal(hits[:, :w], ref[:, :w]), (dims, n, nq, k, stride)
+            assert np.all(hits[:, w:, 0] == KEY_PAD) and np.all(hits[:, w:, 1] == -1)
+        d_ids, d_scores, valid = sharded.sharded_search_batch(eng, queries[:64], 10, world=1)       # device-resident exchange path
+        for i in (0, 63):
+            s_ids, s_scores = eng.searchArrays(queries[i], 10)
+            assert np.array_equal(d_ids[i][valid[i]], s_ids) and np.array_equal(d_scores[i][valid[i]], s_scores)
+        eng.close()
+    empty = wax.HIPVectorEngine(dimensions=64)
+    hits = run(empty, oracle.gaussian_unit_queries(5, 64), 10, 10)
+    assert np.all(hits[:, :, 0] == KEY_PAD)
+    with pytest.raises(wax.EncodingError):
+        empty.searchBatchHitsDevice(0, 4, 10, 0, 10)
+
+
+def test_concurrent_batched_searches_share_the_mirror(wax):
+    """Batched searches are re-entrant like every other read entry point: four threads batch-search at once (pooled
+    per-call workspaces, one shared bf16 mirror), interleaved with single-query searches and a writer."""
+    dims, n = 384, 80_000
+    corpus = oracle.gaussian_unit_rows(31, n, dims)
+    eng = make_engine(wax, 0, dims, corpus)
+    queries = oracle.gaussian_unit_queries(128, dims, seed=12)
+    ref = eng.searchBatch(queries, 10)
+    errors = []
+
+    def worker(tid):
+        try:
+            for it in range(6):
+                ids, scores, counts = eng.searchBatch(queries, 10)
+                assert np.array_equal(ids, ref[0]) and np.array_equal(scores, ref[1])
+                s_ids, _ = eng.searchArrays(queries[tid], 10)
+                assert np.array_equal(s_ids, ref[0][tid])
+        except Exception as ex:  # noqa: BLE001
+            errors.append((tid, ex))
+
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    # a mutation in between invalidates the mirror for everyone
+    eng.add(10 ** 9, queries[5])
+    ids, scores, _ = eng.searchBatch(queries, 10)
+    assert ids[5, 0] == 10 ** 9 and abs(scores[5, 0] - 1.0) <= 1e-5
+    eng.close()

@@ -48,6 +48,10 @@ class Stats(ctypes.Structure):
         ("last_scan_kernel_ms", ctypes.c_double),
         ("scan_kernel_ms_total", ctypes.c_double),
         ("scan_kernels_timed", ctypes.c_uint64),
+        ("batch_gemm_ms_total", ctypes.c_double),
+        ("batch_gemms_timed", ctypes.c_uint64),
+        ("batch_gemm_rows", ctypes.c_uint64),
+        ("batch_gemm_queries", ctypes.c_uint64),
     ]
 
 
@@ -87,6 +91,8 @@ SIGNATURES: Dict[str, tuple] = {
     "wax_hip_search_collect": (ctypes.c_int, [_engine_p, ctypes.c_uint64, _u64p, _f32p, ctypes.c_uint32, _u32p]),
     "wax_hip_search_batch": (ctypes.c_int, [_engine_p, _f32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int32, _u64p, _f32p, ctypes.c_uint32, _u32p]),
     "wax_hip_search_batch_hits": (ctypes.c_int, [_engine_p, _f32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int32, _hitp, ctypes.c_uint32, _u32p]),
+    "wax_hip_search_batch_hits_device": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int32,
+                                                        ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]),
     "wax_hip_set_row_base": (ctypes.c_int, [_engine_p, ctypes.c_uint64]),
     "wax_hip_search_shard_device": (ctypes.c_int, [_engine_p, _f32p, ctypes.c_uint32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     "wax_hip_merge_hits_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]),

@@ -119,6 +119,22 @@ hipError_t launch_mirror(const float* src, uint32_t n_rows, uint32_t n_rows_padd
     return hipGetLastError();
 }
 
+// Maximum over each aligned group of 32 lanes, valid in the group's LAST lane (31 / 63). DPP only, like group_sum.
+template <int CTRL, int ROW_MASK>
+__device__ inline float dpp_max(float v) {
+    // lanes in rows excluded by ROW_MASK receive `old` = their own value: max(v, v) = v
+    const int moved = __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
+    return __builtin_fmaxf(v, __int_as_float(moved));
+}
+__device__ inline float group_max32(float v) {
+    v = dpp_max<0xB1, 0xF>(v);      // quad_perm [1,0,3,2]
+    v = dpp_max<0x4E, 0xF>(v);      // quad_perm [2,3,0,1]
+    v = dpp_max<0x141, 0xF>(v);     // row_half_mirror
+    v = dpp_max<0x140, 0xF>(v);     // row_mirror
+    v = dpp_max<0x142, 0xA>(v);     // row_bcast15 into rows 1, 3
+    return v;
+}
+
 // ---------------------------------------------------------------------------
 // bf16 GEMM tile: 128 queries (M) x 128 corpus rows (N), K chunks of 64, 4 waves each 64x64
 // (2x2 v_mfma_f32_32x32x16_bf16 blocks). Both operands are K-contiguous ("NT" GEMM), so every
@@ -373,7 +389,11 @@ __device__ inline void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N
 template <int D>
 constexpr int rega_lds_tiles(bool glds) { return (glds && 3 * 64 * (D * 2 + 16) + 3072 <= 160 * 1024) ? 3 : 2; }
 
-template <int D, bool GLDS, int AHEAD>
+// SAMPLE = true (one-pass pipeline, threshold estimation): instead of filtering against a threshold, the workgroup
+// visits `a.sample_tiles` tiles spread evenly over the slab (logical index i -> tile i * ntiles / sample_tiles) and
+// records, per query, the best similarity of each visited tile in a.tile_max[i][query] (pick_tau_kernel turns the
+// j-th best tile maximum into the query's admission threshold).
+template <int D, bool GLDS, int AHEAD, bool SAMPLE = false>
 __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uint32_t blocks_per_group) {
     constexpr int KS = D / 16;                       // MFMA k-steps
     constexpr int ROW_B = D * 2 + 16;                // LDS row stride (bytes)
@@ -409,7 +429,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) fa[ks] = __builtin_bit_cast(bf16x8, qp[ks * 2]);
     }
-    if (lane < 32) {
+    if (!SAMPLE && lane < 32) {
         const float tq = a.tau[q0 + lane];
         tau_s[wave * 32 + lane] = tq;
         // fl(1 - acc) <= tq implies acc >= (1 - tq) - 2^-23 (|1 - tq| + |tq|); 4e-7 (1 + |tq|) covers it with slack.
@@ -423,9 +443,14 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
     // kept as ONE VGPR + per-query scalar multiples — 16 hoisted 64-bit row pointers would spill
     const uint32_t seg_lane0 = (q0 + 4u * ((uint32_t)lane >> 5)) * a.cand_cap + a.seg_base + bidx * seg_slots;
 
-    const uint32_t ntiles = (a.slab_rows + TROWS - 1) / TROWS;
+    const uint32_t ntiles_all = (a.slab_rows + TROWS - 1) / TROWS;
+    const uint32_t ntiles = SAMPLE ? a.sample_tiles : ntiles_all;   // loop range (logical tiles)
     const uint32_t slab_end = a.slab0 + a.slab_rows;
     const unsigned char* cbase = reinterpret_cast<const unsigned char*>(a.cb);
+    // logical -> physical tile (identity unless sampling)
+    auto phys = [&](uint32_t tile) -> uint32_t {
+        return SAMPLE ? (uint32_t)(((unsigned long long)tile * ntiles_all) / a.sample_tiles) : tile;
+    };
 
     // register staging map: 8 threads per tile row; a thread moves the 16-byte segments (tid & 7) + 8*p of its
     // row, so every global / LDS address is one per-tile base plus a compile-time offset (no address arrays).
@@ -433,7 +458,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
     const uint32_t sseg = ((uint32_t)tid & 7u) * 16u;
     u32x4 regs[GLDS ? 1 : LOADS];
     auto issue_loads = [&](uint32_t tile) {
-        uint32_t grow = a.slab0 + tile * TROWS + srow;
+        uint32_t grow = a.slab0 + phys(tile) * TROWS + srow;
         grow = grow < a.n_rows ? grow : a.n_rows - 1;        // clamp: masked in the epilogue
         const unsigned char* src = cbase + (size_t)grow * (D * 2) + sseg;
 #pragma unroll
@@ -460,7 +485,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
     }
     const bool full_wave = my_pieces == PPW;                 // wave-uniform
     auto dma_tile = [&](uint32_t tile, uint32_t buf_off) {
-        const uint32_t row0 = a.slab0 + tile * TROWS;
+        const uint32_t row0 = a.slab0 + phys(tile) * TROWS;
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             const uint32_t P = (uint32_t)wave + 8u * i;
@@ -552,6 +577,17 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
     // takes a slot in this workgroup's segment of the query's candidate row.
     auto select_tile = [&](uint32_t tile) {
         if (a.debug & 8u) return;
+        if (SAMPLE) {
+            // best similarity of this tile per query: rows sit in lanes (lane & 31) of both accumulators; a clamped
+            // row past the end of the store duplicates the last row and cannot raise a maximum. NaN never wins (maxNum).
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float m = group_max32(__builtin_fmaxf(acc0[r], acc1[r]));
+                if ((lane & 31) == 31)
+                    a.tile_max[(size_t)tile * (a.nqt * 128u) + q0 + (uint32_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5))] = m;
+            }
+            return;
+        }
         // the lane's 16 bounds are four aligned float4 in LDS (queries 8j + 4(lane>>5) .. +3 for r = 4j .. 4j+3):
         // one batch of ds_read_b128 and ONE wait per tile; they are live only here, after the B-fragment ring died
         const lds_f32x4* sim_w = (const lds_f32x4*)(sim_s + wave * 32 + 4 * (lane >> 5));
@@ -642,7 +678,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
     if (late && it > 0) select_tile(t - blocks_per_group);
     // unclamped counts: a count above seg_slots tells tighten_kernel that survivors were dropped (query -> exact path)
     __syncthreads();
-    if (tid < 256) a.seg_count[(size_t)bidx * (a.nqt * 128u) + group * 256u + (uint32_t)tid] = cnt_s[tid];
+    if (!SAMPLE && tid < 256) a.seg_count[(size_t)bidx * (a.nqt * 128u) + group * 256u + (uint32_t)tid] = cnt_s[tid];
 }
 
 // ---------------------------------------------------------------------------
@@ -656,7 +692,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
 // selection, while the helper is already issuing the next tile's MFMAs (the pair shares a SIMD, so the owner's
 // VALU/LDS work overlaps the helper's matrix work by construction).
 // Selection, segments and thresholds are those of batch_gemm_rega_kernel (one row block per tile).
-template <int D, int AHEAD>
+template <int D, int AHEAD, bool SAMPLE = false>
 __global__ __launch_bounds__(512, 2) void batch_gemm_ksplit_kernel(GemmArgs a, uint32_t blocks_per_group) {
     constexpr int HALF = D / 2;
     constexpr int KS = HALF / 16;                    // MFMA k-steps per wave
@@ -691,7 +727,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_ksplit_kernel(GemmArgs a, u
         for (int ks = 0; ks < KS; ++ks) fa[ks] = __builtin_bit_cast(bf16x8, qp[ks * 2]);
     }
     if (owner && lane < 32) {
-        const float tq = a.tau[q0 + lane];
+        const float tq = SAMPLE ? 0.f : a.tau[q0 + lane];
         tau_s[pair * 32 + lane] = tq;
         sim_s[pair * 32 + lane] = (1.0f - tq) - 4e-7f * (1.0f + __builtin_fabsf(tq));   // see batch_gemm_rega_kernel
         cnt_s[pair * 32 + lane] = 0u;
@@ -699,16 +735,20 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_ksplit_kernel(GemmArgs a, u
     const uint32_t seg_slots = a.seg_area / blocks_per_group;
     const uint32_t seg_lane0 = (q0 + 4u * ((uint32_t)lane >> 5)) * a.cand_cap + a.seg_base + bidx * seg_slots;
 
-    const uint32_t ntiles = (a.slab_rows + TROWS - 1) / TROWS;
+    const uint32_t ntiles_all = (a.slab_rows + TROWS - 1) / TROWS;
+    const uint32_t ntiles = SAMPLE ? a.sample_tiles : ntiles_all;
     const uint32_t slab_end = a.slab0 + a.slab_rows;
     const unsigned char* cbase = reinterpret_cast<const unsigned char*>(a.cb);
+    auto phys = [&](uint32_t tile) -> uint32_t {
+        return SAMPLE ? (uint32_t)(((unsigned long long)tile * ntiles_all) / a.sample_tiles) : tile;
+    };
 
     // staging: 16 threads per tile row, a thread moves the 16-byte segments (tid & 15) + 16*p of its row
     const uint32_t srow = (uint32_t)tid >> 4;
     const uint32_t sseg = ((uint32_t)tid & 15u) * 16u;
     u32x4 regs[LOADS];
     auto issue_loads = [&](uint32_t tile) {
-        uint32_t grow = a.slab0 + tile * TROWS + srow;
+        uint32_t grow = a.slab0 + phys(tile) * TROWS + srow;
         grow = grow < a.n_rows ? grow : a.n_rows - 1;        // clamp: masked in the selection
         const unsigned char* src = cbase + (size_t)grow * (D * 2) + sseg;
 #pragma unroll
@@ -767,6 +807,15 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_ksplit_kernel(GemmArgs a, u
             full[r] = acc[r] + hp[r >> 2][r & 3];
             hit[r >> 2] |= __ballot(full[r] >= lo[r >> 2][r & 3]);   // NaN fails
         }
+        if (SAMPLE) {   // per-query best similarity of this 32-row tile (see batch_gemm_rega_kernel)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float m = group_max32(full[r]);
+                if ((lane & 31) == 31)
+                    a.tile_max[(size_t)tile * (a.nqt * 128u) + q0 + (uint32_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5))] = m;
+            }
+            return;
+        }
         if ((hit[0] | hit[1] | hit[2] | hit[3]) == 0ull) return;
         const uint32_t row0 = a.slab0 + tile * TROWS + (lane & 31);
         const bool ok0 = row0 < slab_end;
@@ -813,7 +862,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_ksplit_kernel(GemmArgs a, u
     }
     if (owner && it > 0) select_tile(t - blocks_per_group, (it - 1u) & 1u);
     __syncthreads();
-    if (tid < 128) a.seg_count[(size_t)bidx * (a.nqt * 128u) + group * 128u + (uint32_t)tid] = cnt_s[tid];
+    if (!SAMPLE && tid < 128) a.seg_count[(size_t)bidx * (a.nqt * 128u) + group * 128u + (uint32_t)tid] = cnt_s[tid];
 }
 
 // D = 1024 would need 2 x 66 KB of tiles + 32 KB of partial sums (> 160 KB of LDS): it stays on the LDS-tiled kernel.
@@ -1205,7 +1254,7 @@ __global__ __launch_bounds__(256) void finalize_batch_kernel(const int64_t* __re
                                                              const float* __restrict__ eps,
                                                              const uint64_t* __restrict__ ids, uint32_t row_base,
                                                              uint32_t n_rows, wax_hip_hit* __restrict__ out,
-                                                             uint32_t* __restrict__ certified) {
+                                                             uint32_t out_stride, uint32_t* __restrict__ certified) {
     __shared__ int64_t keys[FUSED_MAX_K];
     __shared__ int64_t sorted[FUSED_MAX_K];
     const uint32_t q = blockIdx.x;
@@ -1224,15 +1273,15 @@ __global__ __launch_bounds__(256) void finalize_batch_kernel(const int64_t* __re
         }
     }
     __syncthreads();
-    if (t < k) {
+    for (uint32_t o = threadIdx.x; o < out_stride; o += 256) {   // the row is padded to out_stride
         wax_hip_hit h;
-        h.key = sorted[t];
+        h.key = ((int)o < k) ? sorted[o] : KEY_PAD;
         h.frame_id = ID_PAD;
         if (h.key != KEY_PAD) {
             const uint32_t local = key_row(h.key) - row_base;
             h.frame_id = (ids != nullptr && local < n_rows) ? ids[local] : (uint64_t)key_row(h.key);
         }
-        out[(size_t)q * k + t] = h;
+        out[(size_t)q * out_stride + o] = h;
     }
     if (t == 0) {
         const int64_t last_cand = cand[(size_t)q * cand_cap + (kp - 1)];
@@ -1254,10 +1303,391 @@ __global__ __launch_bounds__(256) void finalize_batch_kernel(const int64_t* __re
 hipError_t launch_finalize_batch(const int64_t* cand, uint32_t cand_cap, const uint32_t* overflow, const int64_t* exact,
                                  int kp, int k, const float* eps,
                                  const uint64_t* ids, uint32_t row_base, uint32_t n_rows, uint32_t nq,
-                                 wax_hip_hit* out, uint32_t* certified, hipStream_t st) {
-    if (kp > FUSED_MAX_K || k > kp || k < 1) return hipErrorInvalidValue;
+                                 wax_hip_hit* out, uint32_t out_stride, uint32_t* certified, hipStream_t st) {
+    if (kp > FUSED_MAX_K || k > kp || k < 1 || out_stride < (uint32_t)k) return hipErrorInvalidValue;
     hipLaunchKernelGGL(finalize_batch_kernel, dim3(nq), dim3(256), 0, st, cand, cand_cap, overflow, exact, kp, k, eps, ids,
-                       row_base, n_rows, out, certified);
+                       row_base, n_rows, out, out_stride, certified);
+    return hipGetLastError();
+}
+
+
+// ===========================================================================
+// One-pass batched pipeline (large stores). The slab pipeline above tightens every query's threshold between
+// geometrically growing slabs: 4 GEMM launches + 4 latency-bound tighten launches per batch at 1M rows. Here the
+// threshold comes from a SAMPLE instead, so the store is filtered in ONE uninterrupted GEMM launch:
+//   batch_prep_kernel      queries (already in HBM) -> bf16 block, exact norms, certificate bounds, per-batch state
+//   sampling GEMM          ~1/64 of the tiles, spread evenly over the store (a sorted / clustered corpus is sampled
+//                          across its whole range): per (tile, query) the best similarity of the tile
+//   pick_tau_kernel        tau_q = 1 - (rank-th best tile maximum): at least `rank` sampled rows pass it, and about
+//                          rank * tiles / sampled_tiles rows of the whole store (~8 k', see batch_onepass_plan)
+//   filtering GEMM         batch_gemm_rega_kernel / batch_gemm_ksplit_kernel over ALL tiles with that fixed tau;
+//                          survivors into per-workgroup segments
+//   batch_finish_kernel    per query: survivors -> best k' (approximate keys) -> exact f32 re-score (scan_kernel's
+//                          arithmetic) -> top-k + certificate, one launch
+// Exactness is unchanged: the candidate set is "the k' smallest approximate distances of the whole store" (or every
+// row below tau when fewer than k' pass), every non-candidate's approximate distance is >= a_max, and the certificate
+// a_max - eps > exact k-th decides whether the answer is provably exact; anything else is re-run on the exact path.
+
+bool batch_onepass_dims(uint32_t dims, int metric) {
+    return metric != BM_L2 && (dims == 128 || dims == 256 || dims == 384 || dims == 512 || dims == 768);
+}
+uint32_t batch_tile_rows(uint32_t dims) { return dims == 768 ? 32u : 64u; }
+
+__global__ __launch_bounds__(256) void batch_prep_kernel(PrepArgs a) {
+    const int lane = lane_id();
+    const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= a.nq_pad) return;
+    const uint32_t D = a.dims;
+    unsigned short* out = a.qb + (size_t)q * D;
+    if (q >= a.nq) {                                     // padding query: admits nothing, matches nothing
+        for (uint32_t c = lane; c < D; c += WAVE) out[c] = 0;
+        if (lane == 0) {
+            a.q_n2[q] = 0.f; a.q_norm[q] = 0.f; a.eps[q] = 0.f; a.tau[q] = -__builtin_inff(); a.overflow[q] = 0u;
+            if (a.cand_count) a.cand_count[(size_t)q * CAND_COUNT_STRIDE] = 0u;
+        }
+        return;
+    }
+    const float* row = a.queries + (size_t)q * D;
+    // bf16 block (approximate path only): same arithmetic as mirror_kernel
+    float acc = 0.f;
+    for (uint32_t c = lane; c < D; c += WAVE) acc = fmaf(row[c], row[c], acc);
+    acc = group_sum<64>(acc);
+    acc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 63));
+    const float nf = sqrtf(acc);
+    const float scale = (a.metric == BM_COS) ? ((nf > 1e-6f) ? 1.0f / nf : 0.0f) : 1.0f;
+    for (uint32_t c = lane; c < D; c += WAVE) out[c] = f32_to_bf16_rne(row[c] * scale);
+    // exact ||q|| exactly as the host computes it for the single-query path (engine.hip query_norm): four f64
+    // partial sums over j = c, c + 4, ... in ascending order (every product of two floats is exact in f64, so a
+    // fused multiply-add rounds like multiply-then-add), a tail into the first, (s0 + s1) + (s2 + s3), sqrt, one
+    // rounding to f32. Lanes 0..3 each run one chain.
+    double part = 0.0;
+    const uint32_t d4 = D & ~3u;
+    if (lane < 4)
+        for (uint32_t j = (uint32_t)lane; j < d4; j += 4) part += (double)row[j] * (double)row[j];
+    if (lane == 0)
+        for (uint32_t j = d4; j < D; ++j) part += (double)row[j] * (double)row[j];
+    const double s0 = __shfl(part, 0), s1 = __shfl(part, 1), s2 = __shfl(part, 2), s3 = __shfl(part, 3);
+    if (lane == 0) {
+        const double total = (s0 + s1) + (s2 + s3);
+        float c = (float)sqrt(total);
+        // make the f32 result independent of the last bit of the device's f64 sqrt: c must be the float nearest to
+        // sqrt(total); the midpoints to its neighbours are 25-bit numbers whose squares are exact in f64
+        const float cp = nextafterf(c, 0.0f), cn = nextafterf(c, __builtin_inff());
+        const double ml = 0.5 * ((double)c + (double)cp), mu = 0.5 * ((double)c + (double)cn);
+        if (ml * ml > total) c = cp;
+        else if (mu * mu < total) c = cn;
+        a.q_norm[q] = c;
+        a.q_n2[q] = acc;
+        // certificate bound: engine.hip batch_eps, same formula
+        const double u = 0.00390625 * (1.0 + 1.0 / 1024.0) + (double)D * 5.97e-8 + 1e-6;
+        float eps;
+        if (a.metric == BM_COS) eps = (float)(u * 1.001 + 1e-6);
+        else {
+            const double qv = (double)c * (double)a.max_norm;
+            if (a.metric == BM_DOT) eps = (float)(u * qv * 1.001 + 1e-6 * (1.0 + qv));
+            else {
+                const double ss = (double)c * (double)c + (double)a.max_norm * (double)a.max_norm;
+                eps = (float)(2.0 * u * qv * 1.001 + 4e-6 * (1.0 + ss));
+            }
+        }
+        a.eps[q] = eps;
+        a.tau[q] = __builtin_inff();
+        a.overflow[q] = 0u;
+        if (a.cand_count) a.cand_count[(size_t)q * CAND_COUNT_STRIDE] = 0u;
+    }
+}
+
+hipError_t launch_batch_prep(const PrepArgs& a, hipStream_t st) {
+    if (a.nq_pad == 0) return hipSuccess;
+    hipLaunchKernelGGL(batch_prep_kernel, dim3((a.nq_pad + 3) / 4), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+template <int D>
+static hipError_t launch_rega_sample(const GemmArgs& a, hipStream_t st) {
+    constexpr int AHEAD = D >= 512 ? 1 : 3;
+    constexpr size_t smem = (size_t)rega_lds_tiles<D>(false) * 64 * (D * 2 + 16) + 3 * 8 * 32 * 4;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&batch_gemm_rega_kernel<D, false, AHEAD, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    const uint32_t groups = (a.nqt * 128 + 255) / 256;
+    uint32_t pg = 256 / groups;
+    if (pg < 1) pg = 1;
+    if (pg > a.sample_tiles) pg = a.sample_tiles;
+    hipLaunchKernelGGL((batch_gemm_rega_kernel<D, false, AHEAD, true>), dim3(groups * pg), dim3(512), smem, st, a, pg);
+    return hipGetLastError();
+}
+
+hipError_t launch_batch_gemm_sample(const GemmArgs& a, int metric, hipStream_t st) {
+    if (!batch_onepass_dims(a.dims, metric) || a.tile_max == nullptr || a.sample_tiles == 0) return hipErrorInvalidValue;
+    switch (a.dims) {
+        case 128: return launch_rega_sample<128>(a, st);
+        case 256: return launch_rega_sample<256>(a, st);
+        case 384: return launch_rega_sample<384>(a, st);
+        case 512: return launch_rega_sample<512>(a, st);
+        case 768: {
+            constexpr int D = 768;
+            constexpr size_t smem = 2 * 32 * (D * 2 + 16) + 2 * 4 * (4 * 64 * 16) + 3 * 4 * 32 * 4;
+            static bool configured = false;
+            if (!configured) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&batch_gemm_ksplit_kernel<D, 4, true>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                if (e != hipSuccess) return e;
+                configured = true;
+            }
+            const uint32_t groups = a.nqt;
+            uint32_t pg = 256 / groups;
+            if (pg < 1) pg = 1;
+            if (pg > a.sample_tiles) pg = a.sample_tiles;
+            hipLaunchKernelGGL((batch_gemm_ksplit_kernel<D, 4, true>), dim3(groups * pg), dim3(512), smem, st, a, pg);
+            return hipGetLastError();
+        }
+        default: break;
+    }
+    return hipErrorInvalidValue;
+}
+
+// One wave per query: the rank-th largest of its sampled tile maxima becomes the admission threshold.
+__global__ __launch_bounds__(256) void pick_tau_kernel(const float* __restrict__ tile_max, uint32_t sample_tiles,
+                                                       uint32_t nq, uint32_t nq_pad, uint32_t rank,
+                                                       float* __restrict__ tau) {
+    constexpr int CAP = 256;
+    __shared__ int64_t lds[4 * CAP];
+    const int lane = lane_id();
+    const int wave = (int)(threadIdx.x >> 6);
+    const uint32_t q = blockIdx.x * 4 + (uint32_t)wave;
+    if (q >= nq) return;                                   // whole wave
+    WaveTopK<CAP> tk;
+    tk.init(lds + wave * CAP, (int)rank);
+    for (uint32_t base = 0; base < sample_tiles; base += WAVE) {
+        const uint32_t i = base + (uint32_t)lane;
+        float sim = (i < sample_tiles) ? tile_max[(size_t)i * nq_pad + q] : 0.f;
+        sim = (sim == sim) ? sim : -__builtin_inff();      // a tile of NaN similarities never sets a threshold
+        tk.push_wide(make_key(-sim, i), i < sample_tiles); // ascending -sim == descending similarity; unique by tile index
+    }
+    tk.finalize();
+    if (lane == 0) {
+        // fewer sampled tiles than `rank` (the host never plans that): no threshold, everything is admitted
+        tau[q] = (tk.cnt >= (int)rank) ? (1.0f - (-key_distance(tk.buf[rank - 1]))) : __builtin_inff();
+    }
+}
+
+hipError_t launch_pick_tau(const float* tile_max, uint32_t sample_tiles, uint32_t nq, uint32_t nq_pad, uint32_t rank,
+                           float* tau, hipStream_t st) {
+    if (rank < 1 || rank > (uint32_t)FUSED_MAX_K || sample_tiles == 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pick_tau_kernel, dim3((nq + 3) / 4), dim3(256), 0, st, tile_max, sample_tiles, nq, nq_pad, rank, tau);
+    return hipGetLastError();
+}
+
+// Gather one query's survivors from the GEMM workgroups' segments into the wave-private lists.
+template <int CAP>
+__device__ inline bool gather_segments(WaveTopK<CAP>& tk, const int64_t* __restrict__ mine, const uint32_t* __restrict__ seg_count,
+                                       uint32_t nseg, uint32_t seg_slots, uint32_t nq_pad, uint32_t q) {
+    bool dropped = false;
+    for (uint32_t sb = 0; sb < nseg; sb += SCAN_THREADS) {
+        const uint32_t seg = sb + threadIdx.x;
+        uint32_t c = (seg < nseg) ? seg_count[(size_t)seg * nq_pad + q] : 0u;
+        if (c > seg_slots) {
+            dropped = true;
+            c = seg_slots;
+        }
+        const int64_t* __restrict__ sp = mine + (size_t)seg * seg_slots;
+        constexpr uint32_t SLOTS = 8;
+        for (uint32_t j0 = 0; __any(j0 < c); j0 += SLOTS) {
+            int64_t key[SLOTS];
+#pragma unroll
+            for (uint32_t u = 0; u < SLOTS; ++u) key[u] = (j0 + u < c) ? sp[j0 + u] : KEY_PAD;
+#pragma unroll
+            for (uint32_t u = 0; u < SLOTS; ++u) tk.push_wide(key[u], j0 + u < c);
+        }
+    }
+    return dropped;
+}
+
+template <int D4, int GROUP, int METRIC>
+__global__ __launch_bounds__(SCAN_THREADS) void batch_finish_kernel(FinishArgs a) {
+    constexpr int CAP = 256;
+    constexpr int LOADS = D4 / GROUP;
+    constexpr int RPW = WAVE / GROUP;
+    __shared__ int64_t lds[SCAN_WAVES * CAP + SCAN_WAVES + 2 * FUSED_MAX_K];
+    int* counts = reinterpret_cast<int*>(lds + SCAN_WAVES * CAP);
+    int64_t* fin = lds + SCAN_WAVES * CAP + SCAN_WAVES;     // [kp] best approximate keys, ascending
+    int64_t* ex = fin + FUSED_MAX_K;                        // [kp] their exact keys
+    int64_t* sorted = lds;                                  // [kp] exact keys ascending (the wave lists are dead by then)
+    const int lane = lane_id();
+    const int wave = (int)(threadIdx.x >> 6);
+    const uint32_t q = blockIdx.x;
+    const int kp = a.kp;
+    WaveTopK<CAP> tk;
+    tk.init(lds + wave * CAP, kp);
+    const bool dropped = gather_segments<CAP>(tk, a.cand + (size_t)q * a.cand_cap, a.seg_count, a.nseg, a.seg_slots, a.nq_pad, q);
+    tk.finalize();
+    if (lane == 0) counts[wave] = tk.cnt;
+    const int any_dropped = __syncthreads_or(dropped ? 1 : 0);
+    block_rank_merge<SCAN_WAVES>(lds, CAP, counts, kp, fin);
+    __syncthreads();
+    int total = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_WAVES; ++w) total += counts[w];
+    const int m = total < kp ? total : kp;                  // candidates to re-score
+    __syncthreads();                                        // everyone has read counts / the lists before `sorted` reuses them
+    // exact f32 distance of every candidate with scan_kernel's (D4, GROUP) lane mapping and summation order
+    {
+        const int sub = lane / GROUP, gl = lane % GROUP;
+        const float qn = a.q_norm[q];
+        const f32x4* __restrict__ q4 = reinterpret_cast<const f32x4*>(a.queries) + (size_t)q * D4 + gl;
+        f32x4 qv[LOADS];
+#pragma unroll
+        for (int j = 0; j < LOADS; ++j) qv[j] = q4[j * GROUP];
+        for (int c0 = wave * RPW; c0 < m; c0 += SCAN_WAVES * RPW) {
+            const int c = c0 + sub;
+            const int64_t ck = fin[c < m ? c : m - 1];
+            uint32_t lrow = key_row(ck) - a.row_base;
+            lrow = lrow < a.n_rows ? lrow : 0;
+            const f32x4* __restrict__ v4 = reinterpret_cast<const f32x4*>(a.store) + (size_t)lrow * D4 + gl;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f}, nrm = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < LOADS; ++j) accumulate_b<METRIC>(qv[j], v4[j * GROUP], acc, nrm);
+            const float s = group_sum<GROUP>(hsum_b(acc));
+            float mm = 0.f;
+            if (METRIC == BM_COS) mm = group_sum<GROUP>(hsum_b(nrm));
+            const float d = finish_distance_b<METRIC>(s, mm, qn);
+            if (c < m && gl == GROUP - 1) ex[c] = make_key(d, key_row(ck));
+        }
+    }
+    __syncthreads();
+    const int t = (int)threadIdx.x;
+    if (t < m) {                                            // keys are unique (distinct rows): rank = number of smaller keys
+        const int64_t mine = ex[t];
+        int rank = 0;
+        for (int j = 0; j < m; ++j) rank += (ex[j] < mine) ? 1 : 0;
+        sorted[rank] = mine;
+    }
+    __syncthreads();
+    const int k = a.k;
+    for (uint32_t o = threadIdx.x; o < a.out_stride; o += SCAN_THREADS) {   // the row is padded to out_stride
+        wax_hip_hit h;
+        h.key = ((int)o < k && (int)o < m) ? sorted[o] : KEY_PAD;
+        h.frame_id = ID_PAD;
+        if (h.key != KEY_PAD) {
+            const uint32_t local = key_row(h.key) - a.row_base;
+            h.frame_id = (a.ids != nullptr && local < a.n_rows) ? a.ids[local] : (uint64_t)key_row(h.key);
+        }
+        a.out[(size_t)q * a.out_stride + o] = h;
+    }
+    if (t == 0) {
+        uint32_t ok = 0;
+        if (!any_dropped && a.overflow[q] == 0u && m >= k) {
+            // every row outside the candidate set has an approximate distance >= a_max: the kp-th best approximate
+            // distance when the list is full, else the admission threshold itself (everything below it is a candidate)
+            const float a_max = (total >= kp) ? key_distance(fin[kp - 1]) : a.tau[q];
+            const float kth = key_distance(sorted[k - 1]);
+            ok = (a_max - a.eps[q] > kth) ? 1u : 0u;        // strict: ties stay uncertified
+        }
+        a.certified[q] = ok;
+    }
+}
+
+// Large k' (193 .. 960): the same steps as three launches.
+template <int CAP>
+__global__ __launch_bounds__(SCAN_THREADS) void select_segments_kernel(FinishArgs a, uint32_t* __restrict__ overflow_out) {
+    extern __shared__ __attribute__((aligned(16))) int64_t lds_dyn[];   // [SCAN_WAVES * CAP + SCAN_WAVES]
+    int* counts = reinterpret_cast<int*>(lds_dyn + SCAN_WAVES * CAP);
+    const int lane = lane_id();
+    const int wave = (int)(threadIdx.x >> 6);
+    const uint32_t q = blockIdx.x;
+    const int kp = a.kp;
+    WaveTopK<CAP> tk;
+    tk.init(lds_dyn + wave * CAP, kp);
+    const bool dropped = gather_segments<CAP>(tk, a.cand + (size_t)q * a.cand_cap, a.seg_count, a.nseg, a.seg_slots, a.nq_pad, q);
+    tk.finalize();
+    if (lane == 0) counts[wave] = tk.cnt;
+    const int any_dropped = __syncthreads_or(dropped ? 1 : 0);
+    block_rank_merge<SCAN_WAVES>(lds_dyn, CAP, counts, kp, a.sel + (size_t)q * kp);   // pads with KEY_PAD
+    if (threadIdx.x == 0 && any_dropped) overflow_out[q] = 1u;
+}
+
+// exact[q][0..kp) -> sorted, top-k hits, certificate; sel[q][kp-1] != KEY_PAD <=> the candidate list is full.
+__global__ __launch_bounds__(1024) void finalize_big_kernel(FinishArgs a) {
+    extern __shared__ __attribute__((aligned(16))) int64_t lds_dyn[];   // [2 * kp]
+    const int kp = a.kp, k = a.k;
+    int64_t* keys = lds_dyn;
+    int64_t* sorted = lds_dyn + kp;
+    const uint32_t q = blockIdx.x;
+    for (int t = (int)threadIdx.x; t < kp; t += 1024) {
+        keys[t] = a.exact[(size_t)q * kp + t];
+        sorted[t] = KEY_PAD;
+    }
+    __syncthreads();
+    for (int t = (int)threadIdx.x; t < kp; t += 1024) {
+        const int64_t mine = keys[t];
+        if (mine == KEY_PAD) continue;
+        int rank = 0;
+        for (int j = 0; j < kp; ++j) rank += (keys[j] < mine) ? 1 : 0;   // unique keys (distinct rows); PAD is the maximum
+        sorted[rank] = mine;
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < a.out_stride; t += 1024) {   // the row is padded to out_stride
+        wax_hip_hit h;
+        h.key = ((int)t < k) ? sorted[t] : KEY_PAD;
+        h.frame_id = ID_PAD;
+        if (h.key != KEY_PAD) {
+            const uint32_t local = key_row(h.key) - a.row_base;
+            h.frame_id = (a.ids != nullptr && local < a.n_rows) ? a.ids[local] : (uint64_t)key_row(h.key);
+        }
+        a.out[(size_t)q * a.out_stride + t] = h;
+    }
+    if (threadIdx.x == 0) {
+        uint32_t ok = 0;
+        const int64_t kth_key = sorted[k - 1];
+        if (a.overflow[q] == 0u && kth_key != KEY_PAD) {
+            const int64_t last = a.sel[(size_t)q * kp + (kp - 1)];
+            const float a_max = (last != KEY_PAD) ? key_distance(last) : a.tau[q];
+            ok = (a_max - a.eps[q] > key_distance(kth_key)) ? 1u : 0u;
+        }
+        a.certified[q] = ok;
+    }
+}
+
+template <int D4, int GROUP>
+static hipError_t launch_finish_t(const FinishArgs& a, int metric, hipStream_t st) {
+    if (metric == BM_COS) hipLaunchKernelGGL((batch_finish_kernel<D4, GROUP, BM_COS>), dim3(a.nq), dim3(SCAN_THREADS), 0, st, a);
+    else hipLaunchKernelGGL((batch_finish_kernel<D4, GROUP, BM_DOT>), dim3(a.nq), dim3(SCAN_THREADS), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_batch_finish(const FinishArgs& a, int metric, hipStream_t st) {
+    if (a.nq == 0) return hipSuccess;
+    if (!batch_onepass_dims(a.dims, metric) || a.k < 1 || a.k > a.kp) return hipErrorInvalidValue;
+    if (a.kp <= FUSED_MAX_K) {
+        switch (a.dims) {   // (D4, GROUP) must mirror launch_scan's table: distances bit-identical to the single-query path
+            case 128: return launch_finish_t<32, 32>(a, metric, st);
+            case 256: return launch_finish_t<64, 64>(a, metric, st);
+            case 384: return launch_finish_t<96, 32>(a, metric, st);
+            case 512: return launch_finish_t<128, 64>(a, metric, st);
+            case 768: return launch_finish_t<192, 64>(a, metric, st);
+            default: return hipErrorInvalidValue;
+        }
+    }
+    if (a.kp > 960 || a.sel == nullptr || a.exact == nullptr) return hipErrorInvalidValue;
+    {
+        constexpr int CAP = 1024;
+        constexpr size_t smem = (size_t)(SCAN_WAVES * CAP + SCAN_WAVES) * sizeof(int64_t);
+        hipLaunchKernelGGL((select_segments_kernel<CAP>), dim3(a.nq), dim3(SCAN_THREADS), smem, st, a,
+                           const_cast<uint32_t*>(a.overflow));
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    RescoreArgs r{};
+    r.store = a.store; r.queries = a.queries; r.q_norm = a.q_norm; r.cand = a.sel; r.exact = a.exact;
+    r.n_rows = a.n_rows; r.row_base = a.row_base; r.dims = a.dims; r.nq = a.nq; r.cand_cap = (uint32_t)a.kp; r.kp = a.kp;
+    hipError_t e = launch_rescore(r, metric, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(finalize_big_kernel, dim3(a.nq), dim3(1024), (size_t)2 * a.kp * sizeof(int64_t), st, a);
     return hipGetLastError();
 }
 

@@ -218,46 +218,63 @@ struct FilterWork {
     bool ready = false;
 };
 
-// Workspace of the batched (bf16 MFMA) path; one batch at a time per engine.
-struct BatchWork {
-    std::mutex mu;
-    // corpus mirror (rebuilt lazily after any mutation)
-    unsigned short* d_cb = nullptr;
-    float* d_vn2 = nullptr;
+// Batched (bf16 MFMA) path. The corpus mirror is shared by every batch (read-only during searches, rebuilt lazily by
+// the first batch after a mutation); everything a call writes lives in a pooled per-call workspace with its own
+// stream, so batched searches run concurrently with each other like every other read entry point.
+struct BatchMirror {
+    std::mutex mu;                       // serialises the (re)build only
+    unsigned short* d_cb = nullptr;      // [mirror_cap][dims] bf16 (cosine rows pre-normalised)
+    float* d_vn2 = nullptr;              // [mirror_cap] ||v||^2
     unsigned int* d_maxnorm = nullptr;
     uint64_t mirror_cap = 0;
-    bool mirror_valid = false;
+    std::atomic<bool> mirror_valid{false};
     std::atomic<int> mirror_wanted{0};   // small batches since the last mutation that a VALID mirror would have made cheaper
     float max_norm = 0.f;
-    // per-call buffers (sized for kBatchMaxQ queries on first use, scores/partials grown on demand)
-    float* d_q = nullptr;
+};
+
+constexpr uint32_t kBatchMaxQ = 1024;   // queries per GEMM pass
+constexpr uint32_t kBatchSegBase = FUSED_MAX_K;   // slab pipeline: a candidate row = [0, kBatchSegBase) best list, then the survivor area
+constexpr uint32_t kBatchSegArea = 4096;          // survivors per query between two tighten passes (slab pipeline) / of the one pass
+constexpr uint32_t kBatchCandCap = kBatchSegBase + kBatchSegArea;
+constexpr uint32_t kBatchMaxSegs = 256;           // GEMM workgroups per query group
+constexpr uint32_t kBatchFirstSlab = 2048;  // rows of the first slab (everything passes: tau = +inf)
+constexpr int kBatchMaxKSlab = 80;      // largest k served by the slab pipeline (k' = 2k+32 <= 192)
+constexpr int kBatchMaxK = 464;         // largest k served by the one-pass pipeline (k' = 2k+32 <= 960): covers the real caller's
+                                        // candidateLimit = max(topK, min(3 topK, 1000)) up to topK 154 (UnifiedSearch.swift:1195-1200)
+
+struct BatchCtx {
+    hipStream_t stream = nullptr;        // owned
+    hipEvent_t ev_in = nullptr;          // caller-stream -> ctx-stream ordering for device-resident inputs
+    hipEvent_t ev_g0 = nullptr, ev_g1 = nullptr;   // "time_kernels": around the filtering GEMM of the last enqueued block
+    bool gemm_timed = false;
+    uint32_t gemm_rows = 0, gemm_queries = 0;
+    float* d_q = nullptr;                // [q_cap][dims] staging for host queries
+    uint64_t q_cap = 0;
     unsigned short* d_qb = nullptr;
     float* d_qn2 = nullptr;
     float* d_qnorm = nullptr;
     float* d_eps = nullptr;
-    float* d_tau = nullptr;          // [kBatchMaxQ] running admission thresholds
-    float* d_dense = nullptr;        // [kBatchMaxQ][kBatchFirstSlab] first-slab score tile
+    float* d_tau = nullptr;              // [kBatchMaxQ] admission thresholds
+    float* d_dense = nullptr;            // slab pipeline: [kBatchMaxQ][kBatchFirstSlab] first-slab score tile
     uint32_t* d_cand_count = nullptr;
     uint32_t* d_overflow = nullptr;
-    int64_t* d_cand = nullptr;       // [kBatchMaxQ][kBatchCandCap]
-    uint32_t* d_seg_count = nullptr; // [kBatchMaxSegs][kBatchMaxQ] survivors per (GEMM workgroup, query)
-    int64_t* d_exact = nullptr;
-    wax_hip_hit* d_hits = nullptr;
-    uint32_t* d_cert = nullptr;
-    wax_hip_hit* h_hits = nullptr;   // pinned
-    uint32_t* h_cert = nullptr;      // pinned
-    float* h_qnorm = nullptr;        // pinned
-    float* h_eps = nullptr;          // pinned
-    bool ready = false;
+    int64_t* d_cand = nullptr;           // [kBatchMaxQ][cand_slots]
+    uint64_t cand_slots = 0;
+    uint32_t* d_seg_count = nullptr;     // [kBatchMaxSegs][kBatchMaxQ] survivors per (GEMM workgroup, query)
+    int64_t* d_exact = nullptr;          // [kBatchMaxQ][kp_cap]
+    int64_t* d_sel = nullptr;            // [kBatchMaxQ][kp_cap] (one-pass pipeline, k' > 192)
+    uint64_t kp_cap = 0;
+    float* d_tile_max = nullptr;         // one-pass pipeline: [tile_max_rows][kBatchMaxQ]
+    uint64_t tile_max_rows = 0;
+    wax_hip_hit* d_hits = nullptr;       // [hits_cap] hits of a whole host-pointer call
+    uint64_t hits_cap = 0;
+    uint32_t* d_cert = nullptr;          // [cert_cap] certificate flags of a whole call
+    uint64_t cert_cap = 0;
+    wax_hip_hit* h_hits = nullptr;       // pinned [hits_cap]
+    uint32_t* h_cert = nullptr;          // pinned [cert_cap]
+    float* h_qnorm = nullptr;            // pinned [cert_cap]: exact norms (the exact-path fallback needs them on the host)
+    float* d_qnorm_all = nullptr;        // [cert_cap]
 };
-
-constexpr uint32_t kBatchMaxQ = 1024;   // queries per GEMM pass
-constexpr uint32_t kBatchSegBase = FUSED_MAX_K;   // a candidate row: [0, kBatchSegBase) best list, then the survivor area
-constexpr uint32_t kBatchSegArea = 4096;          // survivors per query between two tighten passes
-constexpr uint32_t kBatchCandCap = kBatchSegBase + kBatchSegArea;
-constexpr uint32_t kBatchMaxSegs = 256;           // GEMM workgroups per 256-query group
-constexpr uint32_t kBatchFirstSlab = 2048;  // rows of the first slab (everything passes: tau = +inf)
-constexpr int kBatchMaxK = 80;          // largest k served by the MFMA path (k' = 2k+32 <= 192)
 
 }  // namespace
 
@@ -328,7 +345,16 @@ struct wax_hip_engine {
     std::atomic<int64_t> batch_debug{0};     // timing experiments only (GemmArgs::debug)
     std::atomic<int64_t> batch_rega{1};      // register-resident-queries GEMM where it applies: 1 register staging, 2 LDS-DMA staging; 0 off
     std::atomic<uint64_t> st_batch_queries{0}, st_batch_fallbacks{0};
-    BatchWork batch;
+    BatchMirror batch;
+    std::mutex bctx_mu;
+    std::condition_variable bctx_cv;
+    std::vector<BatchCtx*> bctx_all, bctx_free;
+    int bctx_max = 4;
+    std::atomic<int64_t> batch_onepass{1};        // 0 = always the slab pipeline
+    std::atomic<int64_t> batch_onepass_tiles{1024};   // smallest store (in GEMM tiles) the one-pass pipeline takes
+    std::atomic<int64_t> batch_survivors{8};      // one-pass pipeline: expected survivors per query = this x k'
+    std::atomic<int64_t> batch_sample_div{64};    // one-pass pipeline: 1 / this of the tiles are sampled (at least 256)
+    std::atomic<uint64_t> st_onepass_queries{0};
     FilterWork filter;
     // Write-combining of single-frame appends (the reference appends into a unified-memory buffer and the GPU simply
     // sees it, MetalVectorEngine.swift:340-351; with discrete HBM the analogue is a pinned staging area that the NEXT
@@ -343,6 +369,8 @@ struct wax_hip_engine {
     std::mutex st_mu;
     double st_last_ms = 0.0, st_total_ms = 0.0;
     uint64_t st_timed = 0;
+    double st_gemm_ms = 0.0;
+    uint64_t st_gemm_timed = 0, st_gemm_rows = 0, st_gemm_queries = 0;
 };
 
 namespace {
@@ -668,43 +696,26 @@ void harvest_ring_event(wax_hip_engine* e, int r) {
 
 
 // ---------------------------------------------------------------------------
-// Batched path: Q x D^T on the matrix cores (batch.hip). Called with the shared lock held.
-// Fills results for certified queries; `need_exact[q]` is set for the ones whose certificate
-// failed (the caller re-runs those on the exact single-query path).
-int batch_prepare(wax_hip_engine* e, hipStream_t st) {
-    BatchWork& b = e->batch;
+// Batched path: Q x D^T on the matrix cores (batch.hip). Everything here is called with the shared lock held.
+
+// The bf16 mirror of the store (+ ||v||^2, max ||v||): allocated at the first batched search, rebuilt lazily after
+// any mutation. Concurrent batches serialise on the rebuild only.
+int ensure_mirror(wax_hip_engine* e, hipStream_t st) {
+    BatchMirror& b = e->batch;
+    if (b.mirror_valid.load(std::memory_order_acquire) && b.mirror_cap >= e->capacity) return WAX_HIP_OK;
+    std::unique_lock<std::mutex> g(b.mu);
     const uint32_t D = e->dims;
-    if (!b.ready) {
-        HIP_TRY(hipMalloc(&b.d_maxnorm, sizeof(unsigned int)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch scalars");
-        HIP_TRY(hipMalloc(&b.d_q, (size_t)kBatchMaxQ * D * sizeof(float)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch queries");
-        HIP_TRY(hipMalloc(&b.d_qb, (size_t)kBatchMaxQ * D * sizeof(unsigned short)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch bf16 queries");
-        HIP_TRY(hipMalloc(&b.d_qn2, kBatchMaxQ * sizeof(float)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch norms");
-        HIP_TRY(hipMalloc(&b.d_qnorm, kBatchMaxQ * sizeof(float)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch norms");
-        HIP_TRY(hipMalloc(&b.d_eps, kBatchMaxQ * sizeof(float)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch eps");
-        HIP_TRY(hipMalloc(&b.d_tau, kBatchMaxQ * sizeof(float)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch thresholds");
-        HIP_TRY(hipMalloc(&b.d_dense, (size_t)kBatchMaxQ * kBatchFirstSlab * sizeof(float)), WAX_HIP_ERR_ALLOC, "Failed to allocate first-slab tile");
-        HIP_TRY(hipMalloc(&b.d_cand_count, (size_t)kBatchMaxQ * CAND_COUNT_STRIDE * sizeof(uint32_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch counters");
-        HIP_TRY(hipMalloc(&b.d_overflow, kBatchMaxQ * sizeof(uint32_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch flags");
-        HIP_TRY(hipMalloc(&b.d_cand, (size_t)kBatchMaxQ * kBatchCandCap * sizeof(int64_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch candidates");
-        HIP_TRY(hipMalloc(&b.d_seg_count, (size_t)kBatchMaxSegs * kBatchMaxQ * sizeof(uint32_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch segment counters");
-        HIP_TRY(hipMalloc(&b.d_exact, (size_t)kBatchMaxQ * FUSED_MAX_K * sizeof(int64_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch candidates");
-        HIP_TRY(hipMalloc(&b.d_hits, (size_t)kBatchMaxQ * kBatchMaxK * sizeof(wax_hip_hit)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch hits");
-        HIP_TRY(hipMalloc(&b.d_cert, kBatchMaxQ * sizeof(uint32_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch flags");
-        HIP_TRY(hipHostMalloc(&b.h_hits, (size_t)kBatchMaxQ * kBatchMaxK * sizeof(wax_hip_hit), hipHostMallocDefault), WAX_HIP_ERR_ALLOC, "Failed to allocate pinned batch hits");
-        HIP_TRY(hipHostMalloc(&b.h_cert, kBatchMaxQ * sizeof(uint32_t), hipHostMallocDefault), WAX_HIP_ERR_ALLOC, "Failed to allocate pinned batch flags");
-        HIP_TRY(hipHostMalloc(&b.h_qnorm, kBatchMaxQ * sizeof(float), hipHostMallocDefault), WAX_HIP_ERR_ALLOC, "Failed to allocate pinned batch norms");
-        HIP_TRY(hipHostMalloc(&b.h_eps, kBatchMaxQ * sizeof(float), hipHostMallocDefault), WAX_HIP_ERR_ALLOC, "Failed to allocate pinned batch eps");
-        b.ready = true;
-    }
+    if (!b.d_maxnorm) HIP_TRY(hipMalloc(&b.d_maxnorm, sizeof(unsigned int)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch scalars");
     if (b.mirror_cap < e->capacity) {
-        HIP_TRY(hipStreamSynchronize(st), WAX_HIP_ERR_INTERNAL, "batch sync");
+        // no batch can be reading the old mirror: a stale (smaller) mirror is only possible after a mutation, which
+        // took the exclusive lock after every reader had finished
         (void)hipFree(b.d_cb); (void)hipFree(b.d_vn2);
         b.d_cb = nullptr; b.d_vn2 = nullptr; b.mirror_cap = 0; b.mirror_valid = false;
         HIP_TRY(hipMalloc(&b.d_cb, (size_t)e->capacity * D * sizeof(unsigned short)), WAX_HIP_ERR_ALLOC, "Failed to allocate bf16 mirror");
         HIP_TRY(hipMalloc(&b.d_vn2, (size_t)e->capacity * sizeof(float)), WAX_HIP_ERR_ALLOC, "Failed to allocate row norms");
         b.mirror_cap = e->capacity;
     }
-    if (!b.mirror_valid) {
+    if (!b.mirror_valid.load(std::memory_order_acquire)) {
         HIP_TRY(hipMemsetAsync(b.d_maxnorm, 0, sizeof(unsigned int), st), WAX_HIP_ERR_INTERNAL, "batch memset");
         HIP_TRY(launch_mirror(e->d_store, (uint32_t)e->count, (uint32_t)e->count, D, e->metric == WAX_HIP_METRIC_COSINE ? 1 : 0,
                               b.d_cb, b.d_vn2, b.d_maxnorm, st), WAX_HIP_ERR_INTERNAL, "mirror kernel launch");
@@ -712,14 +723,135 @@ int batch_prepare(wax_hip_engine* e, hipStream_t st) {
         HIP_TRY(hipMemcpyAsync(&bits, b.d_maxnorm, sizeof(bits), hipMemcpyDeviceToHost, st), WAX_HIP_ERR_INTERNAL, "max norm download");
         HIP_TRY(hipStreamSynchronize(st), WAX_HIP_ERR_INTERNAL, "mirror sync");
         std::memcpy(&b.max_norm, &bits, sizeof(float));
-        b.mirror_valid = true;
+        b.mirror_valid.store(true, std::memory_order_release);
+    }
+    return WAX_HIP_OK;
+}
+
+void free_bctx(BatchCtx* c) {
+    if (!c) return;
+    (void)hipFree(c->d_q); (void)hipFree(c->d_qb); (void)hipFree(c->d_qn2); (void)hipFree(c->d_qnorm); (void)hipFree(c->d_eps);
+    (void)hipFree(c->d_tau); (void)hipFree(c->d_dense); (void)hipFree(c->d_cand_count); (void)hipFree(c->d_overflow);
+    (void)hipFree(c->d_cand); (void)hipFree(c->d_seg_count); (void)hipFree(c->d_exact); (void)hipFree(c->d_sel);
+    (void)hipFree(c->d_tile_max); (void)hipFree(c->d_hits); (void)hipFree(c->d_cert); (void)hipFree(c->d_qnorm_all);
+    (void)hipHostFree(c->h_hits); (void)hipHostFree(c->h_cert); (void)hipHostFree(c->h_qnorm);
+    if (c->ev_in) (void)hipEventDestroy(c->ev_in);
+    if (c->ev_g0) (void)hipEventDestroy(c->ev_g0);
+    if (c->ev_g1) (void)hipEventDestroy(c->ev_g1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int alloc_bctx(wax_hip_engine* e, BatchCtx** out) {
+    BatchCtx* c = new BatchCtx();
+    const uint32_t D = e->dims;
+    (void)D;
+    hipError_t err = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    auto A = [&](auto** p, size_t bytes) { if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(p), bytes); };
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&c->ev_g0, hipEventReleaseToDevice);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&c->ev_g1, hipEventReleaseToDevice);
+    A(&c->d_qb, (size_t)kBatchMaxQ * D * sizeof(unsigned short));
+    A(&c->d_qn2, kBatchMaxQ * sizeof(float));
+    A(&c->d_qnorm, kBatchMaxQ * sizeof(float));
+    A(&c->d_eps, kBatchMaxQ * sizeof(float));
+    A(&c->d_tau, kBatchMaxQ * sizeof(float));
+    A(&c->d_cand_count, (size_t)kBatchMaxQ * CAND_COUNT_STRIDE * sizeof(uint32_t));
+    A(&c->d_overflow, kBatchMaxQ * sizeof(uint32_t));
+    A(&c->d_seg_count, (size_t)kBatchMaxSegs * kBatchMaxQ * sizeof(uint32_t));
+    if (err != hipSuccess) {
+        free_bctx(c);
+        return fail(WAX_HIP_ERR_ALLOC, std::string("Failed to allocate batch workspace: ") + hipGetErrorString(err));
+    }
+    *out = c;
+    return WAX_HIP_OK;
+}
+
+int acquire_bctx(wax_hip_engine* e, BatchCtx** out) {
+    std::unique_lock<std::mutex> g(e->bctx_mu);
+    for (;;) {
+        if (!e->bctx_free.empty()) {
+            *out = e->bctx_free.back();
+            e->bctx_free.pop_back();
+            return WAX_HIP_OK;
+        }
+        if ((int)e->bctx_all.size() < e->bctx_max) {
+            BatchCtx* c = nullptr;
+            int rc = alloc_bctx(e, &c);
+            if (rc != WAX_HIP_OK) return rc;
+            e->bctx_all.push_back(c);
+            *out = c;
+            return WAX_HIP_OK;
+        }
+        e->bctx_cv.wait(g);
+    }
+}
+
+void release_bctx(wax_hip_engine* e, BatchCtx* c) {
+    std::unique_lock<std::mutex> g(e->bctx_mu);
+    e->bctx_free.push_back(c);
+    e->bctx_cv.notify_one();
+}
+
+// Grow-on-demand buffers of a workspace (idle on its stream when called: a call owns its workspace and starts here).
+template <typename T>
+int grow_dev(T** p, uint64_t* cap, uint64_t want, size_t elem, const char* what) {
+    if (*cap >= want) return WAX_HIP_OK;
+    (void)hipFree(*p);
+    *p = nullptr; *cap = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(p), (size_t)want * elem), WAX_HIP_ERR_ALLOC, what);
+    *cap = want;
+    return WAX_HIP_OK;
+}
+
+int bctx_reserve(BatchCtx* c, uint64_t cand_slots, uint64_t kp, uint64_t tile_rows, uint64_t n_queries, bool dense) {
+    int rc = grow_dev(&c->d_cand, &c->cand_slots, cand_slots, (size_t)kBatchMaxQ * sizeof(int64_t), "Failed to allocate batch candidates");
+    if (rc != WAX_HIP_OK) return rc;
+    if (c->kp_cap < kp) {
+        (void)hipFree(c->d_exact); (void)hipFree(c->d_sel);
+        c->d_exact = nullptr; c->d_sel = nullptr; c->kp_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_exact, (size_t)kBatchMaxQ * kp * sizeof(int64_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch re-score keys");
+        HIP_TRY(hipMalloc(&c->d_sel, (size_t)kBatchMaxQ * kp * sizeof(int64_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch selection");
+        c->kp_cap = kp;
+    }
+    rc = grow_dev(&c->d_tile_max, &c->tile_max_rows, tile_rows, (size_t)kBatchMaxQ * sizeof(float), "Failed to allocate sample maxima");
+    if (rc != WAX_HIP_OK) return rc;
+    if (dense && !c->d_dense)
+        HIP_TRY(hipMalloc(&c->d_dense, (size_t)kBatchMaxQ * kBatchFirstSlab * sizeof(float)), WAX_HIP_ERR_ALLOC, "Failed to allocate first-slab tile");
+    if (c->cert_cap < n_queries) {
+        uint64_t want = 1024;
+        while (want < n_queries) want *= 2;
+        (void)hipFree(c->d_cert); (void)hipFree(c->d_qnorm_all); (void)hipHostFree(c->h_cert); (void)hipHostFree(c->h_qnorm);
+        c->d_cert = nullptr; c->d_qnorm_all = nullptr; c->h_cert = nullptr; c->h_qnorm = nullptr; c->cert_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_cert, want * sizeof(uint32_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch flags");
+        HIP_TRY(hipMalloc(&c->d_qnorm_all, want * sizeof(float)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch norms");
+        HIP_TRY(hipHostMalloc(&c->h_cert, want * sizeof(uint32_t), hipHostMallocDefault), WAX_HIP_ERR_ALLOC, "Failed to allocate pinned batch flags");
+        HIP_TRY(hipHostMalloc(&c->h_qnorm, want * sizeof(float), hipHostMallocDefault), WAX_HIP_ERR_ALLOC, "Failed to allocate pinned batch norms");
+        c->cert_cap = want;
+    }
+    return WAX_HIP_OK;
+}
+
+// Staging of a host-pointer call: the query block in HBM and the hits on their way back.
+int bctx_reserve_host(wax_hip_engine* e, BatchCtx* c, uint64_t nq, uint64_t hits) {
+    int rc = grow_dev(&c->d_q, &c->q_cap, nq, (size_t)e->dims * sizeof(float), "Failed to allocate batch queries");
+    if (rc != WAX_HIP_OK) return rc;
+    if (c->hits_cap < hits) {
+        uint64_t want = (uint64_t)kBatchMaxQ * 16;
+        while (want < hits) want *= 2;
+        (void)hipFree(c->d_hits); (void)hipHostFree(c->h_hits);
+        c->d_hits = nullptr; c->h_hits = nullptr; c->hits_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_hits, want * sizeof(wax_hip_hit)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch hits");
+        HIP_TRY(hipHostMalloc(&c->h_hits, want * sizeof(wax_hip_hit), hipHostMallocDefault), WAX_HIP_ERR_ALLOC, "Failed to allocate pinned batch hits");
+        c->hits_cap = want;
     }
     return WAX_HIP_OK;
 }
 
 // Rigorous bound on |approx distance - exact distance| from rounding both operands to bf16
 // (unit roundoff 2^-9 each => 2^-8 (1 + 2^-10) per product, Cauchy-Schwarz over the row) plus
-// f32 accumulation (dims * 2^-24) and epilogue rounding.
+// f32 accumulation (dims * 2^-24) and epilogue rounding. The device evaluates the same formula (batch_prep_kernel);
+// L2 (slab pipeline only) adds its own term here.
 float batch_eps(uint8_t metric, float q_norm, float max_norm, uint32_t dims) {
     const double u = 0.00390625 * (1.0 + 1.0 / 1024.0) + (double)dims * 5.97e-8 + 1e-6;
     if (metric == WAX_HIP_METRIC_COSINE) return (float)(u * 1.001 + 1e-6);
@@ -729,102 +861,200 @@ float batch_eps(uint8_t metric, float q_norm, float max_norm, uint32_t dims) {
     return (float)(2.0 * u * qv * 1.001 + 4e-6 * (1.0 + s));
 }
 
-int batch_search_mfma(wax_hip_engine* e, const float* queries, uint32_t nq, int k_eff, wax_hip_hit* out_hits,
-                      uint32_t stride, std::vector<uint8_t>& need_exact) {
-    BatchWork& b = e->batch;
-    std::unique_lock<std::mutex> bg(b.mu);
-    hipStream_t st = e->streams[0];
-    const uint32_t D = e->dims;
-    const uint32_t n = (uint32_t)e->count;
+int batch_kp(int k_eff, int kp_max) {
     int kp = 2 * k_eff + 32;
     if (kp < 64) kp = 64;
-    if (kp > FUSED_MAX_K) kp = FUSED_MAX_K;
-    int rc = batch_prepare(e, st);
-    if (rc != WAX_HIP_OK) return rc;
-    uint64_t max_slab = (uint64_t)e->batch_slab_mb.load() * 16384ull;  // "slab_mb" MB of f32 scores per 256 queries
-    if (max_slab < 2048) max_slab = 2048;
-    // WAX_HIP_BATCH_TRACE=1: host-side phase times of every batch on stderr (diagnostics only)
-    static const bool trace = std::getenv("WAX_HIP_BATCH_TRACE") != nullptr;
-    using clk = std::chrono::steady_clock;
-    auto us_since = [](clk::time_point t) { return std::chrono::duration<double, std::micro>(clk::now() - t).count(); };
-    for (uint32_t q0 = 0; q0 < nq; q0 += kBatchMaxQ) {
-        const uint32_t qn = (nq - q0 < kBatchMaxQ) ? nq - q0 : kBatchMaxQ;
-        const uint32_t nq_pad = (qn + 255u) & ~255u;  // 256: the register-resident-queries GEMM works on groups of 256
-        const float* qsrc = queries + (uint64_t)q0 * D;
-        const clk::time_point t_begin = clk::now();
-        HIP_TRY(hipMemcpyAsync(b.d_q, qsrc, (size_t)qn * D * sizeof(float), hipMemcpyHostToDevice, st), WAX_HIP_ERR_INTERNAL, "query upload");
-        HIP_TRY(launch_mirror(b.d_q, qn, nq_pad, D, e->metric == WAX_HIP_METRIC_COSINE ? 1 : 0, b.d_qb, b.d_qn2, nullptr, st),
-                WAX_HIP_ERR_INTERNAL, "query mirror launch");
-        HIP_TRY(launch_batch_reset(b.d_tau, b.d_cand_count, b.d_overflow, qn, nq_pad, st), WAX_HIP_ERR_INTERNAL, "batch reset launch");
+    if (kp > kp_max) kp = kp_max;
+    return kp;
+}
+
+// ---- one-pass pipeline: plan -------------------------------------------------------------------------------------
+struct OnepassPlan {
+    uint32_t tile_rows, ntiles, sample_tiles, rank, seg_area;
+    int kp;
+};
+
+bool plan_onepass(wax_hip_engine* e, uint32_t n, int k_eff, OnepassPlan* p) {
+    if (e->batch_onepass.load() == 0 || !batch_onepass_dims(e->dims, e->metric) || k_eff > kBatchMaxK) return false;
+    p->tile_rows = batch_tile_rows(e->dims);
+    p->ntiles = (n + p->tile_rows - 1) / p->tile_rows;
+    if ((int64_t)p->ntiles < e->batch_onepass_tiles.load() || p->ntiles < 1024) return false;
+    p->kp = batch_kp(k_eff, 960);
+    // ~1/64 of the tiles, at least one per GEMM workgroup, at most a quarter of the store
+    uint64_t S = p->ntiles / (uint64_t)e->batch_sample_div.load();
+    if (S < 256) S = 256;
+    if (S > p->ntiles / 4) S = p->ntiles / 4;
+    p->sample_tiles = (uint32_t)S;
+    // tau = the rank-th best sampled tile maximum. Tiles whose best row beats tau are then a fraction f = rank / S of
+    // all tiles; with hits spread like a Poisson process that is lambda = -ln(1 - f) hits per tile, lambda * ntiles
+    // survivors per query in the filtering pass. Aim at `batch_survivors` x k' of them (default 8 k': >= k' with
+    // overwhelming probability — P(Gamma(8) < 1) ~ 1e-5 — and ~2 per (workgroup, query) segment).
+    const double target = (double)e->batch_survivors.load() * (double)p->kp;
+    const double f = 1.0 - std::exp(-target / (double)p->ntiles);
+    double r = std::ceil(f * (double)S);
+    if (r < 8.0) r = 8.0;
+    if (r > 192.0) {
+        // the threshold pick keeps <= 192 maxima per query: a small store with a large k' cannot reach the target;
+        // take the plan only if the reachable survivor count still covers 2 k'
+        r = 192.0;
+        const double reach = -std::log(1.0 - r / (double)S) * (double)p->ntiles;
+        if (reach < 2.0 * (double)p->kp) return false;
+    }
+    p->rank = (uint32_t)r;
+    const double expect = -std::log(1.0 - (double)p->rank / (double)S) * (double)p->ntiles;
+    uint64_t area = kBatchSegArea;
+    while ((double)area < 4.0 * expect) area *= 2;   // mean segment fill <= 1/4: an overflowing segment is a ~1e-9 event
+    if (area > 65536) return false;
+    p->seg_area = (uint32_t)area;
+    return true;
+}
+
+// Enqueue the whole batch pipeline for <= kBatchMaxQ device-resident queries on the workspace's stream: hits land in
+// d_out[q * out_stride .. + out_stride) (k_eff real entries, the rest padded), certificate flags in ctx->d_cert +
+// cert_off, exact norms in ctx->d_qnorm_all + cert_off. Nothing is synchronised here.
+int batch_enqueue(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32_t qn, int k_eff, const OnepassPlan* plan,
+                  wax_hip_hit* d_out, uint32_t out_stride, uint32_t cert_off) {
+    BatchMirror& b = e->batch;
+    hipStream_t st = c->stream;
+    const uint32_t D = e->dims;
+    const uint32_t n = (uint32_t)e->count;
+    const uint32_t nq_pad = (qn + 255u) & ~255u;  // 256: the register-resident-queries GEMM works on groups of 256
+    PrepArgs pa{};
+    pa.queries = d_queries; pa.nq = qn; pa.nq_pad = nq_pad; pa.dims = D; pa.metric = e->metric; pa.max_norm = b.max_norm;
+    pa.qb = c->d_qb; pa.q_n2 = c->d_qn2; pa.q_norm = c->d_qnorm; pa.eps = c->d_eps; pa.tau = c->d_tau; pa.overflow = c->d_overflow;
+    pa.cand_count = plan ? nullptr : c->d_cand_count;
+    HIP_TRY(launch_batch_prep(pa, st), WAX_HIP_ERR_INTERNAL, "batch prep launch");
+    GemmArgs g{};
+    g.qb = c->d_qb; g.cb = b.d_cb; g.q_n2 = c->d_qn2; g.v_n2 = b.d_vn2; g.tau = c->d_tau;
+    g.cand = c->d_cand; g.cand_count = c->d_cand_count; g.row_base = (uint32_t)e->row_base;
+    g.dims = D; g.n_rows = n; g.nq = qn; g.nqt = nq_pad / 128;
+    g.use_rega = (uint32_t)e->batch_rega.load();  // 0 LDS-tiled kernel, 1 register staging, 2 LDS-DMA staging
+    g.debug = (uint32_t)e->batch_debug.load();
+    g.seg_count = c->d_seg_count;
+    if (plan) {
+        // ---- one pass: sample -> threshold -> filter everything -> finish ----
+        g.slab0 = 0; g.slab_rows = n; g.dense = nullptr; g.dense_ld = 0;
+        g.cand_cap = plan->seg_area; g.seg_base = 0; g.seg_area = plan->seg_area;
+        if (g.use_rega == 0) g.use_rega = 1;
+        GemmArgs gs = g;
+        gs.tile_max = c->d_tile_max; gs.sample_tiles = plan->sample_tiles;
+        HIP_TRY(launch_batch_gemm_sample(gs, e->metric, st), WAX_HIP_ERR_INTERNAL, "sampling gemm launch");
+        HIP_TRY(launch_pick_tau(c->d_tile_max, plan->sample_tiles, qn, nq_pad, plan->rank, c->d_tau, st), WAX_HIP_ERR_INTERNAL,
+                "threshold kernel launch");
+        const bool timed = e->time_kernels.load() != 0;
+        if (timed) HIP_TRY(hipEventRecord(c->ev_g0, st), WAX_HIP_ERR_INTERNAL, "event record");
+        HIP_TRY(launch_batch_gemm(g, e->metric, st), WAX_HIP_ERR_INTERNAL, "gemm kernel launch");
+        if (timed) {
+            HIP_TRY(hipEventRecord(c->ev_g1, st), WAX_HIP_ERR_INTERNAL, "event record");
+            c->gemm_timed = true; c->gemm_rows = n; c->gemm_queries = qn;
+        }
+        FinishArgs f{};
+        f.cand = c->d_cand; f.cand_cap = plan->seg_area; f.seg_count = c->d_seg_count; f.nq_pad = nq_pad;
+        if (!batch_gemm_segments(g, e->metric, &f.nseg, &f.seg_slots)) return fail(WAX_HIP_ERR_INTERNAL, "one-pass plan without a segment kernel");
+        f.tau = c->d_tau; f.overflow = c->d_overflow; f.store = e->d_store; f.queries = d_queries; f.q_norm = c->d_qnorm;
+        f.eps = c->d_eps; f.ids = e->d_ids; f.n_rows = n; f.row_base = (uint32_t)e->row_base; f.dims = D; f.nq = qn;
+        f.kp = plan->kp; f.k = k_eff; f.sel = c->d_sel; f.exact = c->d_exact; f.out = d_out; f.out_stride = out_stride;
+        f.certified = c->d_cert + cert_off;
+        HIP_TRY(launch_batch_finish(f, e->metric, st), WAX_HIP_ERR_INTERNAL, "finish kernel launch");
+        e->st_onepass_queries += qn;
+    } else {
+        // ---- slab pipeline (small stores, L2, other dims): thresholds tightened between geometrically growing slabs ----
+        const int kp = batch_kp(k_eff, FUSED_MAX_K);
+        uint64_t max_slab = (uint64_t)e->batch_slab_mb.load() * 16384ull;  // "slab_mb" MB of f32 scores per 256 queries
+        if (max_slab < 2048) max_slab = 2048;
+        g.cand_cap = kBatchCandCap; g.seg_base = kBatchSegBase; g.seg_area = kBatchSegArea; g.dense_ld = kBatchFirstSlab;
         // Slabs grow geometrically: with tau tightened after each slab, a slab of s rows appends about
-        // kp * s / rows_seen candidates per query, so "next slab = 3 x rows seen" keeps every list ~3*kp long.
+        // kp * s / rows_seen candidates per query, so "next slab = growth x rows seen" keeps every list ~growth*kp long.
         uint32_t s0 = 0;
         while (s0 < n) {
             uint64_t want = (s0 == 0) ? (uint64_t)e->batch_first.load() : (uint64_t)e->batch_growth.load() * s0;
             if (want > max_slab) want = max_slab;
             want = (want + 127ull) & ~127ull;
             const uint32_t rows = (n - s0 < want) ? n - s0 : (uint32_t)want;
-            GemmArgs g{};
-            g.qb = b.d_qb; g.cb = b.d_cb; g.q_n2 = b.d_qn2; g.v_n2 = b.d_vn2; g.tau = b.d_tau;
-            g.cand = b.d_cand; g.cand_count = b.d_cand_count; g.cand_cap = kBatchCandCap; g.row_base = (uint32_t)e->row_base;
-            g.dims = D; g.n_rows = n; g.slab0 = s0; g.slab_rows = rows; g.nq = qn; g.nqt = nq_pad / 128;
-            g.use_rega = (uint32_t)e->batch_rega.load();  // 0 LDS-tiled kernel, 1 register staging, 2 LDS-DMA staging
-            g.debug = (uint32_t)e->batch_debug.load();
             const bool first = (s0 == 0);  // no threshold yet: dense tile instead of appending everything
-            g.dense = first ? b.d_dense : nullptr;
-            g.dense_ld = kBatchFirstSlab;
-            g.seg_count = b.d_seg_count; g.seg_base = kBatchSegBase; g.seg_area = kBatchSegArea;
+            g.slab0 = s0; g.slab_rows = rows; g.dense = first ? c->d_dense : nullptr;
             HIP_TRY(launch_batch_gemm(g, e->metric, st), WAX_HIP_ERR_INTERNAL, "gemm kernel launch");
             TightenArgs t{};
-            t.cand = b.d_cand; t.cand_cap = kBatchCandCap; t.cand_count = b.d_cand_count; t.kp = kp; t.nq = qn;
-            t.tau = b.d_tau; t.overflow = b.d_overflow;
-            t.dense = first ? b.d_dense : nullptr; t.dense_ld = kBatchFirstSlab; t.dense_rows = rows;
+            t.cand = c->d_cand; t.cand_cap = kBatchCandCap; t.cand_count = c->d_cand_count; t.kp = kp; t.nq = qn;
+            t.tau = c->d_tau; t.overflow = c->d_overflow;
+            t.dense = first ? c->d_dense : nullptr; t.dense_ld = kBatchFirstSlab; t.dense_rows = rows;
             t.dense_row0 = (uint32_t)e->row_base + s0;
-            t.seg_count = b.d_seg_count; t.seg_base = kBatchSegBase; t.nq_pad = nq_pad;
+            t.seg_count = c->d_seg_count; t.seg_base = kBatchSegBase; t.nq_pad = nq_pad;
             if (!batch_gemm_segments(g, e->metric, &t.nseg, &t.seg_slots)) { t.nseg = 0; t.seg_slots = 0; }
             HIP_TRY(launch_tighten(t, st), WAX_HIP_ERR_INTERNAL, "tighten kernel launch");
             s0 += rows;
         }
-        // exact query norms and certificate bounds are only needed by the re-score / finalize kernels: computed on the
-        // host while the device works through the slabs queued above
-        const clk::time_point t_norms = clk::now();
-        for (uint32_t q = 0; q < qn; ++q) {
-            b.h_qnorm[q] = query_norm(qsrc + (uint64_t)q * D, D);
-            b.h_eps[q] = batch_eps(e->metric, b.h_qnorm[q], b.max_norm, D);
-        }
-        const double us_norms = us_since(t_norms);
-        HIP_TRY(hipMemcpyAsync(b.d_qnorm, b.h_qnorm, qn * sizeof(float), hipMemcpyHostToDevice, st), WAX_HIP_ERR_INTERNAL, "query norm upload");
-        HIP_TRY(hipMemcpyAsync(b.d_eps, b.h_eps, qn * sizeof(float), hipMemcpyHostToDevice, st), WAX_HIP_ERR_INTERNAL, "eps upload");
         RescoreArgs r{};
-        r.store = e->d_store; r.queries = b.d_q; r.q_norm = b.d_qnorm; r.cand = b.d_cand; r.exact = b.d_exact;
+        r.store = e->d_store; r.queries = d_queries; r.q_norm = c->d_qnorm; r.cand = c->d_cand; r.exact = c->d_exact;
         r.n_rows = n; r.row_base = (uint32_t)e->row_base; r.dims = D; r.nq = qn; r.cand_cap = kBatchCandCap; r.kp = kp;
         HIP_TRY(launch_rescore(r, e->metric, st), WAX_HIP_ERR_INTERNAL, "rescore kernel launch");
-        HIP_TRY(launch_finalize_batch(b.d_cand, kBatchCandCap, b.d_overflow, b.d_exact, kp, k_eff, b.d_eps, e->d_ids,
-                                      (uint32_t)e->row_base, n, qn, b.d_hits, b.d_cert, st), WAX_HIP_ERR_INTERNAL, "finalize kernel launch");
-        HIP_TRY(hipMemcpyAsync(b.h_hits, b.d_hits, (size_t)qn * k_eff * sizeof(wax_hip_hit), hipMemcpyDeviceToHost, st), WAX_HIP_ERR_INTERNAL, "hits download");
-        HIP_TRY(hipMemcpyAsync(b.h_cert, b.d_cert, qn * sizeof(uint32_t), hipMemcpyDeviceToHost, st), WAX_HIP_ERR_INTERNAL, "flags download");
-        const double us_enqueued = us_since(t_begin);
-        HIP_TRY(hipStreamSynchronize(st), WAX_HIP_ERR_INTERNAL, "batch search failed on device");
-        const double us_synced = us_since(t_begin);
-        for (uint32_t q = 0; q < qn; ++q) {
-            const uint32_t gq = q0 + q;
-            if (b.h_cert[q]) {
-                const uint32_t w = (uint32_t)k_eff < stride ? (uint32_t)k_eff : stride;   // the rest of the row stays padded
-                std::memcpy(out_hits + (size_t)gq * stride, b.h_hits + (size_t)q * k_eff, (size_t)w * sizeof(wax_hip_hit));
-            } else {
-                need_exact[gq] = 1;
-                e->st_batch_fallbacks++;
-            }
-        }
-        if (trace)
-            fprintf(stderr, "[wax batch] nq=%u norms %.1f us, enqueued at %.1f, device done at %.1f, results copied at %.1f\n", qn,
-                    us_norms, us_enqueued, us_synced, us_since(t_begin));
-        e->st_batch_queries += qn;
-        e->st_searches += qn;
-        e->st_rows += (uint64_t)qn * n;
-        e->st_bytes += (uint64_t)n * D * 2ull;
+        HIP_TRY(launch_finalize_batch(c->d_cand, kBatchCandCap, c->d_overflow, c->d_exact, kp, k_eff, c->d_eps, e->d_ids,
+                                      (uint32_t)e->row_base, n, qn, d_out, out_stride, c->d_cert + cert_off, st),
+                WAX_HIP_ERR_INTERNAL, "finalize kernel launch");
     }
+    HIP_TRY(hipMemcpyAsync(c->d_qnorm_all + cert_off, c->d_qnorm, qn * sizeof(float), hipMemcpyDeviceToDevice, st),
+            WAX_HIP_ERR_INTERNAL, "norm copy");
+    e->st_batch_queries += qn;
+    e->st_searches += qn;
+    e->st_rows += (uint64_t)qn * n;
+    e->st_bytes += (uint64_t)n * D * 2ull;
     return WAX_HIP_OK;
+}
+
+// Can the MFMA pipelines answer (nq queries, k_eff) on this engine at all?
+bool batch_mfma_applicable(wax_hip_engine* e, uint32_t dims, int k_eff, OnepassPlan* plan, bool* onepass) {
+    if (e->batch_mode.load() == 0 || dims != e->dims || (dims % 64u) != 0 || e->count == 0 || k_eff <= 0) return false;
+    *onepass = plan_onepass(e, (uint32_t)e->count, k_eff, plan);
+    return *onepass || k_eff <= kBatchMaxKSlab;
+}
+
+// The whole batched search on device-resident queries (shared lock held, mirror ready): enqueue every block of
+// kBatchMaxQ queries back to back (no host round trip in between), one synchronisation, then the uncertified queries are
+// re-run on the exact single-query path, their hits written over the same rows of d_out. d_out rows are out_stride wide.
+int batch_search_device_locked(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32_t nq, int k_eff,
+                               const OnepassPlan* plan, wax_hip_hit* d_out, uint32_t out_stride, uint32_t* out_fallbacks) {
+    hipStream_t st = c->stream;
+    const uint32_t D = e->dims;
+    int rc = bctx_reserve(c, plan ? plan->seg_area : kBatchCandCap, plan ? (uint64_t)plan->kp : (uint64_t)FUSED_MAX_K,
+                          plan ? plan->sample_tiles : 0, nq, plan == nullptr);
+    if (rc != WAX_HIP_OK) return rc;
+    for (uint32_t q0 = 0; q0 < nq; q0 += kBatchMaxQ) {
+        const uint32_t qn = (nq - q0 < kBatchMaxQ) ? nq - q0 : kBatchMaxQ;
+        rc = batch_enqueue(e, c, d_queries + (uint64_t)q0 * D, qn, k_eff, plan, d_out + (uint64_t)q0 * out_stride, out_stride, q0);
+        if (rc != WAX_HIP_OK) { (void)hipStreamSynchronize(st); return rc; }
+    }
+    HIP_TRY(hipMemcpyAsync(c->h_cert, c->d_cert, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st), WAX_HIP_ERR_INTERNAL, "flags download");
+    HIP_TRY(hipMemcpyAsync(c->h_qnorm, c->d_qnorm_all, nq * sizeof(float), hipMemcpyDeviceToHost, st), WAX_HIP_ERR_INTERNAL, "norm download");
+    HIP_TRY(hipStreamSynchronize(st), WAX_HIP_ERR_INTERNAL, "batch search failed on device");
+    if (c->gemm_timed) {
+        c->gemm_timed = false;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->ev_g0, c->ev_g1) == hipSuccess) {
+            std::unique_lock<std::mutex> sg(e->st_mu);
+            e->st_gemm_ms += ms; e->st_gemm_timed += 1; e->st_gemm_rows += c->gemm_rows; e->st_gemm_queries += c->gemm_queries;
+        }
+    }
+    uint32_t fallbacks = 0;
+    Slot* s = nullptr;
+    for (uint32_t q = 0; q < nq; ++q) {
+        if (c->h_cert[q]) continue;
+        // certificate failed (ties, clustered data, an overflowed list): the exact path answers, never an approximation
+        if (!s) {
+            rc = acquire_slot(e, &s, /*try_only=*/false, /*holding=*/true);
+            if (rc != WAX_HIP_OK) return rc;
+        }
+        rc = enqueue_scan(e, d_queries + (uint64_t)q * D, c->h_qnorm[q], k_eff, (int)out_stride, s->d_partials, s,
+                          d_out + (uint64_t)q * out_stride, st, nullptr, nullptr, /*chain=*/false);
+        if (rc != WAX_HIP_OK) break;
+        ++fallbacks;
+    }
+    if (s) {
+        (void)hipStreamSynchronize(st);
+        release_slot(e, s);
+    }
+    e->st_batch_fallbacks += fallbacks;
+    if (out_fallbacks) *out_fallbacks = fallbacks;
+    return rc;
 }
 
 bool device_is_gfx950(int dev) {
@@ -934,16 +1164,13 @@ void wax_hip_engine_destroy(wax_hip_engine* e) {
         if (e->ring_done[i]) (void)hipEventDestroy(e->ring_done[i]);
     }
     {
-        BatchWork& b = e->batch;
-        (void)hipFree(b.d_cb); (void)hipFree(b.d_vn2); (void)hipFree(b.d_maxnorm); (void)hipFree(b.d_q); (void)hipFree(b.d_qb);
-        (void)hipFree(b.d_qn2); (void)hipFree(b.d_qnorm); (void)hipFree(b.d_eps); (void)hipFree(b.d_tau); (void)hipFree(b.d_dense);
+        BatchMirror& b = e->batch;
+        (void)hipFree(b.d_cb); (void)hipFree(b.d_vn2); (void)hipFree(b.d_maxnorm);
+        for (BatchCtx* c : e->bctx_all) free_bctx(c);
         FilterWork& f = e->filter;
         (void)hipFree(f.d_rows); (void)hipFree(f.d_ids); (void)hipFree(f.d_dist); (void)hipFree(f.d_query); (void)hipFree(f.d_qnorm);
         (void)hipFree(f.d_hits); (void)hipFree(f.sw.hist); (void)hipFree(f.sw.state); (void)hipFree(f.sw.counter);
         (void)hipFree(f.sw.keys_a); (void)hipFree(f.sw.keys_b);
-        (void)hipFree(b.d_cand_count); (void)hipFree(b.d_overflow); (void)hipFree(b.d_cand); (void)hipFree(b.d_seg_count); (void)hipFree(b.d_exact); (void)hipFree(b.d_hits);
-        (void)hipFree(b.d_cert); (void)hipHostFree(b.h_hits); (void)hipHostFree(b.h_cert); (void)hipHostFree(b.h_qnorm);
-        (void)hipHostFree(b.h_eps);
     }
     (void)hipFree(e->d_store);
     (void)hipFree(e->d_ids);
@@ -1305,9 +1532,7 @@ static int search_batch_hits_impl(wax_hip_engine* e, const float* queries, uint3
     const uint64_t limit = (uint64_t)clamp_topk(top_k);
     const uint64_t kguess = limit < cnt ? limit : cnt;
     // Enough queries for the scan to be a dense GEMM: bf16 MFMA path with exact re-score; queries
-    // whose exactness certificate fails are re-run on the exact single-query path below.
-    std::vector<uint8_t> need_exact;
-    bool all = true;
+    // whose exactness certificate fails are re-run on the exact single-query path inside it.
     bool use_mfma = e->batch_mode.load() != 0 && (int64_t)nq >= e->batch_min.load() && dims == e->dims &&
                     (dims % 64u) == 0 && cnt > 0 && kguess <= (uint64_t)kBatchMaxK && kguess > 0;
     if (use_mfma && nq < 16) {
@@ -1318,46 +1543,64 @@ static int search_batch_hits_impl(wax_hip_engine* e, const float* queries, uint3
         const double elems = (double)cnt * (double)dims;
         const double t_loop = (double)nq * (elems * 4.0 / 6.9e12 + 25e-6);
         const double t_pass = 135e-6 + elems * 2.0 / 4.7e12;
-        const double t_rebuild = e->batch.mirror_valid ? 0.0 : elems * 6.0 / 5.0e12;
+        const double t_rebuild = e->batch.mirror_valid.load() ? 0.0 : elems * 6.0 / 5.0e12;
         use_mfma = t_pass + t_rebuild < t_loop;
         // ... but a steady stream of small batches amortises it: the third one in a row that a valid mirror would have
         // made cheaper pays for the rebuild
         if (!use_mfma && t_pass < t_loop && e->batch.mirror_wanted.fetch_add(1) >= 2) use_mfma = true;
     }
     if (use_mfma) {
-        need_exact.assign(nq, 0);
         int brc = WAX_HIP_OK;
         bool ran = false;
         {
             DeviceGuard g(e->device);
             e->lock.lock_shared(holding(e) > 0);
-            { const int frc = flush_pending(e); if (frc != WAX_HIP_OK) { e->lock.unlock_shared(); return frc; } }
-            if (e->row_base + e->count > 0x100000000ull) {
-                e->lock.unlock_shared();
+            struct Unlock { RWLock& l; ~Unlock() { l.unlock_shared(); } } unlock{e->lock};
+            { const int frc = flush_pending(e); if (frc != WAX_HIP_OK) return frc; }
+            if (e->row_base + e->count > 0x100000000ull)
                 return fail(WAX_HIP_ERR_CAPACITY, "row_base + count exceeds UInt32 row indices");
+            uint64_t k64 = limit < e->count ? limit : e->count;   // the row count this batch is answered on
+            if (k64 > stride) k64 = stride;                       // a smaller result array: the best `stride` of them
+            OnepassPlan plan{};
+            bool onepass = false;
+            if (batch_mfma_applicable(e, dims, (int)k64, &plan, &onepass)) {
+                const int k_eff = (int)k64;
+                BatchCtx* c = nullptr;
+                brc = acquire_bctx(e, &c);
+                if (brc != WAX_HIP_OK) return brc;
+                brc = ensure_mirror(e, c->stream);
+                if (brc == WAX_HIP_OK) brc = bctx_reserve_host(e, c, nq, (uint64_t)nq * k_eff);
+                if (brc == WAX_HIP_OK) {
+                    hipError_t err = hipMemcpyAsync(c->d_q, queries, (size_t)nq * dims * sizeof(float), hipMemcpyHostToDevice, c->stream);
+                    if (err != hipSuccess) brc = fail(WAX_HIP_ERR_INTERNAL, std::string("query upload: ") + hipGetErrorString(err));
+                }
+                if (brc == WAX_HIP_OK)
+                    brc = batch_search_device_locked(e, c, c->d_q, nq, k_eff, onepass ? &plan : nullptr, c->d_hits, (uint32_t)k_eff, nullptr);
+                if (brc == WAX_HIP_OK) {
+                    hipError_t err = hipMemcpyAsync(c->h_hits, c->d_hits, (size_t)nq * k_eff * sizeof(wax_hip_hit), hipMemcpyDeviceToHost, c->stream);
+                    if (err == hipSuccess) err = hipStreamSynchronize(c->stream);
+                    if (err != hipSuccess) brc = fail(WAX_HIP_ERR_INTERNAL, std::string("hits download: ") + hipGetErrorString(err));
+                }
+                if (brc == WAX_HIP_OK) {
+                    for (uint32_t q = 0; q < nq; ++q) {
+                        std::memcpy(out_hits + (size_t)q * stride, c->h_hits + (size_t)q * k_eff, (size_t)k_eff * sizeof(wax_hip_hit));
+                        uint32_t m = 0;
+                        for (int i = 0; i < k_eff; ++i) m += c->h_hits[(size_t)q * k_eff + i].key != KEY_PAD;
+                        out_counts[q] = m;
+                    }
+                    ran = true;
+                } else {
+                    (void)hipStreamSynchronize(c->stream);
+                }
+                release_bctx(e, c);
             }
-            const uint64_t k_eff = limit < e->count ? limit : e->count;   // the row count this batch is answered on
-            if (k_eff > 0 && k_eff <= (uint64_t)kBatchMaxK) {
-                brc = batch_search_mfma(e, queries, nq, (int)k_eff, out_hits, stride, need_exact);
-                ran = true;
-            }
-            e->lock.unlock_shared();
         }
         if (brc != WAX_HIP_OK) return brc;
-        if (ran) {
-            all = false;
-            for (uint32_t q = 0; q < nq; ++q)
-                if (!need_exact[q]) {
-                    uint32_t m = 0;
-                    for (uint32_t i = 0; i < stride; ++i) m += out_hits[(uint64_t)q * stride + i].key != KEY_PAD;
-                    out_counts[q] = m;
-                }
-        }
+        if (ran) return WAX_HIP_OK;
     }
-    // Pipelined single-query scans: all queries (loop path) or only the uncertified ones.
-    std::vector<uint32_t> todo;
-    for (uint32_t q = 0; q < nq; ++q)
-        if (all || need_exact[q]) todo.push_back(q);
+    // Loop path: pipelined single-query scans over the scratch-slot pool.
+    std::vector<uint32_t> todo(nq);
+    for (uint32_t q = 0; q < nq; ++q) todo[q] = q;
     const uint32_t depth = (uint32_t)(e->max_slots > 1 ? e->max_slots : 1);
     std::vector<uint64_t> tk(todo.size(), 0);
     size_t submitted = 0, collected = 0;
@@ -1411,6 +1654,71 @@ int wax_hip_search_batch(wax_hip_engine* e, const float* queries, uint32_t nq, u
         hits_to_results(e->metric, hits.data() + (size_t)q * w, w, out_ids + (uint64_t)q * out_stride,
                         out_scores + (uint64_t)q * out_stride, out_stride, &out_counts[q]);
     return WAX_HIP_OK;
+}
+
+// Device-resident form: queries already in HBM (row-major nq x dims f32 on the engine's device), hits left in HBM
+// ([nq][out_stride], rows padded). Blocking; `stream` is the stream whose earlier work produced d_queries (the
+// library's own stream waits for it), and on return every result is complete. The only PCIe traffic is nq
+// certificate flags + norms (8 bytes per query) — or the query block itself when the batch has to take the loop path.
+int wax_hip_search_batch_hits_device(wax_hip_engine* e, const float* d_queries, uint32_t nq, uint32_t dims, int32_t top_k,
+                                     wax_hip_hit* d_out_hits, uint32_t out_stride, void* stream) {
+    if (!e) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine is null");
+    if (nq == 0) return WAX_HIP_OK;
+    if (!d_queries || !d_out_hits || out_stride == 0) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null input");
+    if (dims != e->dims) return fail(WAX_HIP_ERR_DIM_MISMATCH, dim_mismatch_msg(e->dims, dims));
+    DeviceGuard g(e->device);
+    e->lock.lock_shared(holding(e) > 0);
+    struct Unlock { RWLock& l; ~Unlock() { l.unlock_shared(); } } unlock{e->lock};
+    { const int frc = flush_pending(e); if (frc != WAX_HIP_OK) return frc; }
+    if (e->row_base + e->count > 0x100000000ull) return fail(WAX_HIP_ERR_CAPACITY, "row_base + count exceeds UInt32 row indices");
+    const uint64_t limit = (uint64_t)clamp_topk(top_k);
+    uint64_t k64 = limit < e->count ? limit : e->count;
+    if (k64 > out_stride) k64 = out_stride;
+    const int k_eff = (int)k64;
+    BatchCtx* c = nullptr;
+    int rc = acquire_bctx(e, &c);
+    if (rc != WAX_HIP_OK) return rc;
+    struct Release { wax_hip_engine* e; BatchCtx* c; ~Release() { release_bctx(e, c); } } release{e, c};
+    hipStream_t st = c->stream;
+    // inputs are produced on the caller's stream
+    HIP_TRY(hipEventRecord(c->ev_in, static_cast<hipStream_t>(stream)), WAX_HIP_ERR_INTERNAL, "input event record");
+    HIP_TRY(hipStreamWaitEvent(st, c->ev_in, 0), WAX_HIP_ERR_INTERNAL, "input event wait");
+    if (k_eff == 0) {   // empty engine: all padding
+        std::vector<wax_hip_hit> pad((size_t)nq * out_stride, wax_hip_hit{KEY_PAD, ID_PAD});
+        HIP_TRY(hipMemcpyAsync(d_out_hits, pad.data(), pad.size() * sizeof(wax_hip_hit), hipMemcpyHostToDevice, st), WAX_HIP_ERR_INTERNAL, "pad upload");
+        HIP_TRY(hipStreamSynchronize(st), WAX_HIP_ERR_INTERNAL, "pad upload");
+        return WAX_HIP_OK;
+    }
+    OnepassPlan plan{};
+    bool onepass = false;
+    bool use_mfma = (int64_t)nq >= e->batch_min.load() && batch_mfma_applicable(e, dims, k_eff, &plan, &onepass);
+    if (use_mfma && nq < 16) {   // same cost model as the host-pointer form
+        const double elems = (double)e->count * (double)dims;
+        const double t_loop = (double)nq * (elems * 4.0 / 6.9e12 + 25e-6);
+        const double t_pass = 135e-6 + elems * 2.0 / 4.7e12;
+        const double t_rebuild = e->batch.mirror_valid.load() ? 0.0 : elems * 6.0 / 5.0e12;
+        use_mfma = t_pass + t_rebuild < t_loop;
+        if (!use_mfma && t_pass < t_loop && e->batch.mirror_wanted.fetch_add(1) >= 2) use_mfma = true;
+    }
+    if (use_mfma) {
+        rc = ensure_mirror(e, st);
+        if (rc != WAX_HIP_OK) return rc;
+        return batch_search_device_locked(e, c, d_queries, nq, k_eff, onepass ? &plan : nullptr, d_out_hits, out_stride, nullptr);
+    }
+    // loop path: one exact scan per query, back to back on the workspace's stream; the norms come from the host
+    std::vector<float> hq((size_t)nq * dims);
+    HIP_TRY(hipMemcpyAsync(hq.data(), d_queries, hq.size() * sizeof(float), hipMemcpyDeviceToHost, st), WAX_HIP_ERR_INTERNAL, "query download");
+    HIP_TRY(hipStreamSynchronize(st), WAX_HIP_ERR_INTERNAL, "query download");
+    Slot* s = nullptr;
+    rc = acquire_slot(e, &s, /*try_only=*/false, /*holding=*/true);
+    if (rc != WAX_HIP_OK) return rc;
+    for (uint32_t q = 0; q < nq && rc == WAX_HIP_OK; ++q)
+        rc = enqueue_scan(e, d_queries + (uint64_t)q * dims, query_norm(hq.data() + (size_t)q * dims, dims), k_eff, (int)out_stride,
+                          s->d_partials, s, d_out_hits + (uint64_t)q * out_stride, st, nullptr, nullptr, /*chain=*/false);
+    hipError_t serr = hipStreamSynchronize(st);
+    release_slot(e, s);
+    if (rc == WAX_HIP_OK && serr != hipSuccess) rc = fail(WAX_HIP_ERR_INTERNAL, std::string("batch search failed on device: ") + hipGetErrorString(serr));
+    return rc;
 }
 
 // ---- sharded search -------------------------------------------------------
@@ -1745,6 +2053,10 @@ int wax_hip_stats(wax_hip_engine* e, wax_hip_stats_t* out) {
     out->last_scan_kernel_ms = e->st_last_ms;
     out->scan_kernel_ms_total = e->st_total_ms;
     out->scan_kernels_timed = e->st_timed;
+    out->batch_gemm_ms_total = e->st_gemm_ms;
+    out->batch_gemms_timed = e->st_gemm_timed;
+    out->batch_gemm_rows = e->st_gemm_rows;
+    out->batch_gemm_queries = e->st_gemm_queries;
     return WAX_HIP_OK;
 }
 
@@ -1760,6 +2072,15 @@ int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value) {
     else if (k == "batch_mode") e->batch_mode = value;
     else if (k == "batch_rega") e->batch_rega = value;
     else if (k == "batch_debug") e->batch_debug = value;
+    else if (k == "batch_onepass") e->batch_onepass = value;
+    else if (k == "batch_onepass_tiles") { if (value < 1024) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_onepass_tiles must be >= 1024"); e->batch_onepass_tiles = value; }
+    else if (k == "batch_survivors") { if (value < 2 || value > 64) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_survivors must be 2..64"); e->batch_survivors = value; }
+    else if (k == "batch_sample_div") { if (value < 4 || value > 4096) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_sample_div must be 4..4096"); e->batch_sample_div = value; }
+    else if (k == "batch_workspaces") {
+        if (value < 1 || value > 16) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_workspaces must be 1..16");
+        std::unique_lock<std::mutex> g(e->bctx_mu);
+        e->bctx_max = (int)value;
+    }
     else if (k == "batch_first") { if (value < 128 || value > kBatchFirstSlab || value % 128) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_first must be a multiple of 128 in 128..2048"); e->batch_first = value; }
     else if (k == "batch_growth") { if (value < 1 || value > 64) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_growth must be 1..64"); e->batch_growth = value; }
     else if (k == "batch_slab_mb") { if (value < 1 || value > 4096) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_slab_mb must be 1..4096"); e->batch_slab_mb = value; }
@@ -1779,6 +2100,7 @@ int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value) {
         }
         std::unique_lock<std::mutex> sg(e->st_mu);
         e->st_last_ms = 0; e->st_total_ms = 0; e->st_timed = 0;
+        e->st_gemm_ms = 0; e->st_gemm_timed = 0; e->st_gemm_rows = 0; e->st_gemm_queries = 0;
     } else return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "unknown tuning key '" + k + "'");
     return WAX_HIP_OK;
 }
@@ -1797,6 +2119,13 @@ int64_t wax_hip_get_tuning(wax_hip_engine* e, const char* key) {
     if (k == "batch_slab_mb") return e->batch_slab_mb.load();
     if (k == "batch_growth") return e->batch_growth.load();
     if (k == "batch_first") return e->batch_first.load();
+    if (k == "batch_onepass") return e->batch_onepass.load();
+    if (k == "batch_onepass_tiles") return e->batch_onepass_tiles.load();
+    if (k == "batch_survivors") return e->batch_survivors.load();
+    if (k == "batch_sample_div") return e->batch_sample_div.load();
+    if (k == "batch_workspaces") return e->bctx_max;
+    if (k == "batch_max_k") return kBatchMaxK;
+    if (k == "onepass_queries") return (int64_t)e->st_onepass_queries.load();
     if (k == "batch_queries") return (int64_t)e->st_batch_queries.load();
     if (k == "batch_fallbacks") return (int64_t)e->st_batch_fallbacks.load();
     if (k == "slots") return e->max_slots;

@@ -103,6 +103,10 @@ struct GemmArgs {
     uint32_t* seg_count;
     uint32_t seg_base;
     uint32_t seg_area;          // slots available after seg_base (nseg * seg_slots <= seg_area)
+    // One-pass pipeline, sampling launch only (launch_batch_gemm_sample): per-query best similarity of each of
+    // `sample_tiles` tiles spread evenly over the slab, tile_max[sample_tiles][nq_pad].
+    float* tile_max;
+    uint32_t sample_tiles;
 };
 // Geometry the register-resident kernel will use for these arguments (false: the LDS-tiled kernel runs instead,
 // appending through cand_count).
@@ -123,6 +127,41 @@ struct RescoreArgs {
 hipError_t launch_mirror(const float* src, uint32_t n_rows, uint32_t n_rows_padded, uint32_t dims, int normalize,
                          unsigned short* dst, float* norm2, unsigned int* max_norm_bits, hipStream_t stream);
 hipError_t launch_batch_gemm(const GemmArgs& a, int metric, hipStream_t stream);
+
+// ---- one-pass batched pipeline (large stores; cosine / dot at the register-resident GEMM dims) ----
+// prep -> sampling GEMM -> pick_tau -> ONE filtering GEMM over the whole store -> finish. No host round trip, no slabs.
+bool batch_onepass_dims(uint32_t dims, int metric);
+// rows per GEMM tile of the kernel that serves `dims` (64, or 32 for the K-split kernel)
+uint32_t batch_tile_rows(uint32_t dims);
+// Queries f32 [nq][dims] in HBM -> bf16 block (cosine: normalised; rows [nq, nq_pad) zero), exact ||q|| as the
+// single-query path computes it (f64 accumulation, the host's summation order), certificate eps, and the per-batch
+// state (tau = +inf / -inf for padding, overflow = 0).
+struct PrepArgs {
+    const float* queries; uint32_t nq, nq_pad, dims; int metric; float max_norm;
+    unsigned short* qb; float* q_n2; float* q_norm; float* eps; float* tau; uint32_t* overflow;
+    uint32_t* cand_count;       // slab pipeline: per-query append counters to zero (stride CAND_COUNT_STRIDE); may be null
+};
+hipError_t launch_batch_prep(const PrepArgs& a, hipStream_t stream);
+hipError_t launch_batch_gemm_sample(const GemmArgs& a, int metric, hipStream_t stream);
+// tau[q] = 1 - (rank-th largest of tile_max[0..sample_tiles)[q]); padding queries keep -inf. rank <= 192.
+hipError_t launch_pick_tau(const float* tile_max, uint32_t sample_tiles, uint32_t nq, uint32_t nq_pad, uint32_t rank,
+                           float* tau, hipStream_t stream);
+// Per query: survivors of the filtering GEMM (per-workgroup segments) -> best kp by approximate key -> exact f32
+// re-score with the scan kernel's arithmetic -> top-k hits + exactness certificate. kp <= 192: one fused kernel;
+// larger kp (k up to 464): segment select, re-score and finalize as three launches.
+struct FinishArgs {
+    const int64_t* cand; uint32_t cand_cap;              // [nq][cand_cap]: nseg segments of seg_slots keys from slot 0
+    const uint32_t* seg_count; uint32_t nseg, seg_slots, nq_pad;
+    const float* tau; const uint32_t* overflow;          // admission threshold the GEMM used; pre-set overflow flags
+    const float* store; const float* queries; const float* q_norm; const float* eps;
+    const uint64_t* ids; uint32_t n_rows, row_base, dims, nq;
+    int kp, k;
+    int64_t* sel;                                        // [nq][kp] scratch: selected approximate keys (large-kp path)
+    int64_t* exact;                                      // [nq][kp] scratch (large-kp path)
+    wax_hip_hit* out; uint32_t out_stride;               // [nq][out_stride], k written per query
+    uint32_t* certified;                                 // [nq]
+};
+hipError_t launch_batch_finish(const FinishArgs& a, int metric, hipStream_t stream);
 struct TightenArgs {
     int64_t* cand; uint32_t cand_cap; uint32_t* cand_count; int kp; uint32_t nq; float* tau; uint32_t* overflow;
     const float* dense; uint32_t dense_ld, dense_rows, dense_row0;      // first slab: dense score tile
@@ -135,6 +174,6 @@ hipError_t launch_rescore(const RescoreArgs& a, int metric, hipStream_t stream);
 hipError_t launch_finalize_batch(const int64_t* cand, uint32_t cand_cap, const uint32_t* overflow, const int64_t* exact,
                                  int kp, int k, const float* eps,
                                  const uint64_t* ids, uint32_t row_base, uint32_t n_rows, uint32_t nq,
-                                 wax_hip_hit* out, uint32_t* certified, hipStream_t stream);
+                                 wax_hip_hit* out, uint32_t out_stride, uint32_t* certified, hipStream_t stream);
 
 }  // namespace wax

@@ -296,6 +296,16 @@ class HIPVectorEngine:
         raise_for_status(rc)
         return hits, counts
 
+    def searchBatchHitsDevice(self, d_queries_ptr: int, nq: int, topK: int, d_out_hits_ptr: int, out_stride: int,  # noqa: N802,N803
+                              stream: int = 0) -> None:
+        """Device-resident batch search: queries [nq, dims] f32 and the output [nq, out_stride] wax_hip_hit both live
+        in this GPU's HBM (raw device pointers, e.g. torch tensors' data_ptr()); blocking; `stream` is the stream that
+        produced the queries. Results are complete on return."""
+        rc = self._lib.wax_hip_search_batch_hits_device(self._h, ctypes.c_void_p(d_queries_ptr), int(nq), self.dimensions,
+                                                        int(topK), ctypes.c_void_p(d_out_hits_ptr), int(out_stride),
+                                                        ctypes.c_void_p(stream))
+        raise_for_status(rc)
+
     # -- sharded search (one engine per GPU; exchange over RCCL by the caller) ----
     def setRowBase(self, rowBase: int) -> None:  # noqa: N802,N803
         raise_for_status(self._lib.wax_hip_set_row_base(self._h, int(rowBase)))

@@ -170,11 +170,30 @@ def merge_batch_hits_host(gathered: np.ndarray, k: int) -> np.ndarray:
 def sharded_search_batch(engine: HIPVectorEngine, queries, topK: int, world: int, exchange: str = "rccl"):  # noqa: N803
     """Every rank scans ITS shard for all queries (bf16 MFMA path + exact re-score inside the engine),
     the per-shard top-k hits are all-gathered (nq*kpad*16 bytes per rank) and merged per query by key
-    = (distance asc, GLOBAL row asc): the answer is identical at every shard count."""
+    = (distance asc, GLOBAL row asc): the answer is identical at every shard count.
+
+    exchange="rccl": device-resident end to end — the queries go up once, the shard's hits stay in HBM
+    (wax_hip_search_batch_hits_device), RCCL all-gathers them, one workgroup per query merges world*kpad -> kpad, and
+    only the merged [nq][kpad] hits come down. `queries` may also be a CUDA tensor already in HBM."""
     import torch
     import torch.distributed as dist
 
     kpad = clampTopK(topK)
+    if exchange == "rccl":
+        dev = torch.device("cuda", engine.device)
+        q = queries if isinstance(queries, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(queries, dtype=np.float32))
+        q = q.to(device=dev, dtype=torch.float32).contiguous()
+        nq = int(q.shape[0])
+        st = torch.cuda.current_stream(dev)
+        local = torch.empty((nq, kpad, 2), dtype=torch.int64, device=dev)
+        engine.searchBatchHitsDevice(q.data_ptr(), nq, topK, local.data_ptr(), kpad, st.cuda_stream)
+        if world == 1:
+            return decode_hits(engine.metric, local.cpu().numpy())
+        out = torch.empty((world,) + tuple(local.shape), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(out.view(-1), local.view(-1))   # RCCL over xGMI
+        merged = torch.empty((nq, kpad, 2), dtype=torch.int64, device=dev)
+        HIPVectorEngine.mergeBatchHitsDevice(out.data_ptr(), world, nq, kpad, kpad, merged.data_ptr(), st.cuda_stream)
+        return decode_hits(engine.metric, merged.cpu().numpy())
     hits, _ = engine.searchBatchHits(queries, topK)
     nq, kcap, _ = hits.shape
     if kcap < kpad:  # a shard smaller than k: pad its lists
@@ -184,20 +203,8 @@ def sharded_search_batch(engine: HIPVectorEngine, queries, topK: int, world: int
         hits = np.concatenate([hits, pad], axis=1)
     if world > 1:
         local = torch.from_numpy(np.ascontiguousarray(hits))
-        if exchange == "rccl":
-            # device-side exchange: the shard's hits go back to HBM, RCCL all-gathers them, one workgroup per query
-            # merges world*kpad -> kpad (merge_hits_kernel), and only the merged [nq][kpad] hits come down
-            dev = torch.device("cuda", engine.device)
-            local = local.to(dev)
-            out = torch.empty((world,) + tuple(local.shape), dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(out.view(-1), local.view(-1))
-            merged = torch.empty((nq, kpad, 2), dtype=torch.int64, device=dev)
-            HIPVectorEngine.mergeBatchHitsDevice(out.data_ptr(), world, nq, kpad, kpad, merged.data_ptr(),
-                                                 torch.cuda.current_stream(dev).cuda_stream)
-            return decode_hits(engine.metric, merged.cpu().numpy())
-        else:
-            parts = [torch.empty_like(local) for _ in range(world)]
-            dist.all_gather(parts, local)
-            gathered = torch.stack(parts, dim=0).numpy()
+        parts = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(parts, local)
+        gathered = torch.stack(parts, dim=0).numpy()
         hits = merge_batch_hits_host(gathered, kpad)
     return decode_hits(engine.metric, hits)
