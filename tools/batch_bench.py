@@ -37,6 +37,9 @@ def main():
     ap.add_argument("--first", type=int, nargs="+", default=[0], help="rows of the dense first slab to sweep (0 = library default)")
     ap.add_argument("--batch-min", type=int, nargs="+", default=[-1], help="batch_min values to sweep (-1 = library default)")
     ap.add_argument("--rega", type=int, nargs="+", default=[-1], help="batch_rega modes to sweep (-1 = library default)")
+    ap.add_argument("--onepass", type=int, nargs="+", default=[-1], help="batch_onepass values to sweep (-1 = library default)")
+    ap.add_argument("--survivors", type=int, nargs="+", default=[0], help="batch_survivors values to sweep (0 = library default)")
+    ap.add_argument("--sample-div", type=int, nargs="+", default=[0], help="batch_sample_div values to sweep (0 = library default)")
     ap.add_argument("--exchange", choices=["rccl", "host"], default="rccl")
     args = ap.parse_args()
     import torch
@@ -71,9 +74,18 @@ def main():
     gc.disable()    # a generation-2 collection with torch loaded pauses the thread for tens of ms (tools/long_run_drift.py)
     for nq in args.nq:
         q = bench.unit_queries(nq, args.dims)
-        for slab, growth, dbg, rega, first, bmin in [(s_, g_, d_, r_, f_, m_) for s_ in args.slab_mb for g_ in args.growth
-                                                     for d_ in args.debug for r_ in args.rega for f_ in args.first
-                                                     for m_ in args.batch_min]:
+        dq = torch.from_numpy(q).to(dev)
+        dout = torch.empty((nq, args.topk, 2), dtype=torch.int64, device=dev)
+        for slab, growth, dbg, rega, first, bmin, onepass, surv, sdiv in [
+                (s_, g_, d_, r_, f_, m_, o_, v_, x_) for s_ in args.slab_mb for g_ in args.growth for d_ in args.debug
+                for r_ in args.rega for f_ in args.first for m_ in args.batch_min for o_ in args.onepass
+                for v_ in args.survivors for x_ in args.sample_div]:
+            if onepass >= 0:
+                eng.setTuning("batch_onepass", onepass)
+            if surv:
+                eng.setTuning("batch_survivors", surv)
+            if sdiv:
+                eng.setTuning("batch_sample_div", sdiv)
             if bmin >= 0:
                 eng.setTuning("batch_min", bmin)
             eng.setTuning("batch_slab_mb", slab)
@@ -96,6 +108,14 @@ def main():
             for _ in range(args.reps):
                 eng.searchBatchHits(q, args.topk)
             dt_call = (time.perf_counter() - t1) / args.reps
+            st = torch.cuda.current_stream(dev).cuda_stream          # device-resident call: queries and hits stay in HBM
+            eng.searchBatchHitsDevice(dq.data_ptr(), nq, args.topk, dout.data_ptr(), args.topk, st)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for _ in range(args.reps):
+                eng.searchBatchHitsDevice(dq.data_ptr(), nq, args.topk, dout.data_ptr(), args.topk, st)
+            torch.cuda.synchronize()
+            dt_dev = (time.perf_counter() - t2) / args.reps
             if world > 1:
                 t = torch.tensor([dt], dtype=torch.float64, device=dev if args.exchange == "rccl" else "cpu")
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -104,6 +124,8 @@ def main():
                 chk = hashlib.sha256(np.ascontiguousarray(ids).tobytes() + np.ascontiguousarray(scores).tobytes()).hexdigest()[:16]
                 print(json.dumps({"n_gpus": world, "rows": args.rows, "dims": args.dims, "nq": nq, "topk": args.topk,
                                   "slab_mb": slab, "growth": eng.getTuning("batch_growth"), "debug": dbg, "batch_min": eng.getTuning("batch_min"), "first": eng.getTuning("batch_first"), "rega": eng.getTuning("batch_rega"), "ms_per_batch": dt * 1e3, "ms_c_call": dt_call * 1e3, "qps_c_call": nq / dt_call,
+                                  "ms_device_call": dt_dev * 1e3, "tflops_bf16_device_call": 2.0 * nq * (hi - lo) * args.dims / dt_dev / 1e12,
+                                  "onepass": eng.getTuning("batch_onepass"), "survivors": eng.getTuning("batch_survivors"), "sample_div": eng.getTuning("batch_sample_div"),
                                   "tflops_bf16_c_call": 2.0 * nq * (hi - lo) * args.dims / dt_call / 1e12, "qps": nq / dt,
                                   "tflops_bf16": 2.0 * nq * args.rows * args.dims / dt / 1e12,
                                   "fallbacks_rank0": eng.getTuning("batch_fallbacks") - fb0,

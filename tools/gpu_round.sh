@@ -130,6 +130,16 @@ PYEOF
       f=$(find "$OUT/prof_probe" -name "*kernel_trace.csv" | head -1)
       [ -n "$f" ] && grep "rega_kernel" "$f" | python "$R/tools/trace_durations.py" > "$OUT/gemm_probe_durations.txt" 2>/dev/null
       find "$OUT/prof_probe" -name "*kernel_trace.csv" -delete 2>/dev/null ;;
+    onepass)
+      timeout 600 python tools/batch_bench.py --nq 256 1024 --onepass 1 0 > "$OUT/onepass_bench.log" 2>&1; rc=$?
+      timeout 300 python tools/batch_bench.py --rows 1250000 --dims 768 --nq 1024 --reps 3 --onepass 1 0 > "$OUT/onepass768_bench.log" 2>&1 ;;
+    onepassprof)
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_onepass" -o op -- \
+          python "$R/tools/batch_bench.py" --nq ${WAX_NQ:-256} --reps 3 > "$OUT/onepassprof.log" 2>&1); rc=$?
+      find "$OUT/prof_onepass" -name "*kernel_stats.csv" -exec cp {} "$OUT/onepass_kernel_stats.csv" \; 2>/dev/null
+      f=$(find "$OUT/prof_onepass" -name "*kernel_trace.csv" | head -1)
+      [ -n "$f" ] && python "$R/tools/trace_tail.py" "$f" 60 > "$OUT/onepass_trace_tail.csv" 2>/dev/null
+      find "$OUT/prof_onepass" -name "*kernel_trace.csv" -delete 2>/dev/null ;;
     sweep)
       timeout 1200 python tools/sweep.py --tag "$TAG" > "$OUT/sweep.log" 2>&1; rc=$?
       cp gpurun_out/sweep_$TAG.json "$OUT/" 2>/dev/null ;;
