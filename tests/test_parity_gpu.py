@@ -976,7 +976,8 @@ def test_batch_gemm_variants_agree(wax, dims):
     eng = make_engine(wax, 0, dims, corpus)
     queries = oracle.gaussian_unit_queries(300, dims, seed=31)
     ref = None
-    for onepass, rega, growth in [(0, 1, 8), (0, 1, 3), (0, 2, 8), (0, 2, 3), (0, 0, 8), (0, 0, 3), (1, 1, 8), (1, 2, 8)]:
+    for onepass, rega, growth in [(0, 1, 8), (0, 1, 3), (0, 2, 8), (0, 2, 3), (0, 0, 8), (0, 0, 3), (0, 3, 8), (0, 3, 3), (1, 1, 8), (1, 2, 8),
+                                  (1, 3, 8)]:   # rega 3 = one wave per SIMD (D <= 512), LDS-DMA ring
         eng.setTuning("batch_onepass", onepass)
         eng.setTuning("batch_rega", rega)
         eng.setTuning("batch_growth", growth)
@@ -1010,7 +1011,7 @@ def test_batch_randomised_soak(wax):
         if metric != 0:
             corpus = corpus * rng.uniform(0.5, 1.5, (n, 1)).astype(np.float32)
         eng = make_engine(wax, metric, dims, corpus)
-        eng.setTuning("batch_rega", int(rng.choice([1, 2])))
+        eng.setTuning("batch_rega", int(rng.choice([1, 2, 3, 3])))
         eng.setTuning("batch_growth", int(rng.choice([3, 8, 16])))
         eng.setTuning("batch_first", int(rng.choice([512, 2048])))
         queries = oracle.gaussian_unit_queries(nq, dims, seed=500 + trial)
@@ -1411,8 +1412,14 @@ def test_batch_onepass_pipeline_is_exact(wax, metric, dims):
             e_ids, e_scores, _, _ = oracle.search(metric, corpus, ids, queries[i], k)
             x = oracle.search(metric, corpus, ids, queries[i], k + MARGIN)[1]
             assert_parity(b_ids[i, :k], b_scores[i, :k], e_ids, e_scores, x, f"onepass m{metric} d{dims} k{k} q{i}")
+    # the one-wave-per-SIMD GEMM (batch_rega 3; D <= 512) gives the same answers
+    ref_ids, ref_scores, _ = eng.searchBatch(queries, 30)
+    eng.setTuning("batch_rega", 3)
+    w_ids, w_scores, _ = eng.searchBatch(queries, 30)
+    eng.setTuning("batch_rega", 1)
+    assert np.array_equal(ref_ids, w_ids) and np.array_equal(ref_scores, w_scores)
     fb = eng.getTuning("batch_fallbacks")
-    print(f"\n[onepass m{metric} d{dims}] fallbacks {fb} of {5 * 301}")
+    print(f"\n[onepass m{metric} d{dims}] fallbacks {fb} of {7 * 301}")
     if metric == 0:
         assert fb <= 30
     # the slab pipeline gives the same answers where it applies (k <= 80)

@@ -133,6 +133,14 @@ PYEOF
     onepass)
       timeout 600 python tools/batch_bench.py --nq 256 1024 --onepass 1 0 > "$OUT/onepass_bench.log" 2>&1; rc=$?
       timeout 300 python tools/batch_bench.py --rows 1250000 --dims 768 --nq 1024 --reps 3 --onepass 1 0 > "$OUT/onepass768_bench.log" 2>&1 ;;
+    w4)
+      timeout 600 python tools/batch_bench.py --nq 256 1024 --rega 1 3 1 3 > "$OUT/w4_bench.log" 2>&1; rc=$?
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_w4" -o w4 -- \
+          python "$R/tools/batch_bench.py" --nq 256 1024 --reps 3 --rega 3 > "$OUT/w4prof.log" 2>&1)
+      find "$OUT/prof_w4" -name "*kernel_stats.csv" -exec cp {} "$OUT/w4_kernel_stats.csv" \; 2>/dev/null
+      f=$(find "$OUT/prof_w4" -name "*kernel_trace.csv" | head -1)
+      [ -n "$f" ] && python "$R/tools/trace_tail.py" "$f" 40 > "$OUT/w4_trace_tail.csv" 2>/dev/null
+      find "$OUT/prof_w4" -name "*kernel_trace.csv" -delete 2>/dev/null ;;
     onepassprof)
       (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_onepass" -o op -- \
           python "$R/tools/batch_bench.py" --nq ${WAX_NQ:-256} --reps 3 > "$OUT/onepassprof.log" 2>&1); rc=$?

@@ -26,10 +26,22 @@
 //                        distance >= a_max - eps (eps = rigorous bf16 rounding bound); if that is
 //                        > the exact k-th best, the answer is provably the exact top-k. Otherwise (or if a
 //                        candidate list overflowed) the host re-runs that query on the exact single-query path.
+#include <type_traits>
+
 #include "kernels.h"
 #include "topk.h"
 
 namespace wax {
+
+// Compile-time loop: f(std::integral_constant<int, I>{}) for I in [I0, N) — the index is a constant expression inside
+// f (inline-asm immediates need one; an unrolled loop variable is not).
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -865,6 +877,322 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_ksplit_kernel(GemmArgs a, u
     if (!SAMPLE && tid < 128) a.seg_count[(size_t)bidx * (a.nqt * 128u) + group * 128u + (uint32_t)tid] = cnt_s[tid];
 }
 
+// ---------------------------------------------------------------------------
+// Register-resident-queries GEMM, ONE wave per SIMD ("w4": batch_rega = 3; D in {128, 256, 384, 512}).
+//
+// batch_gemm_rega_kernel keeps 32 queries per wave and two waves per SIMD: every B fragment read from LDS feeds one
+// MFMA, the two waves of a SIMD split the matrix pipe, only ONE 48 KB tile per CU is in flight from HBM (which caps
+// the stream near 6 TB/s: bytes in flight / latency), and its counters say the pipe is busy 48 % of the time with
+// the waves parked on LDS / barriers for most of the rest (profiles/r01/ay_*). Here a workgroup is 4 waves — one per
+// SIMD, 512 registers each — and a wave keeps 64 queries (two A-fragment sets, 192 VGPRs at D = 384):
+//   * every B fragment feeds TWO MFMAs (both query sets): half the LDS reads per flop;
+//   * a k-step is 1 ds_read_b128 + 2 MFMAs on two independent accumulators, ~2 other instructions per MFMA issue
+//     slot, far below the ~5 a wave can hide behind a 32-cycle MFMA;
+//   * tiles are 32 rows (24.5 KB at D = 384) in a ring of NBUF LDS buffers filled by LDS-DMA
+//     (global_load_lds_dwordx4: no staging registers, no ds_write pass), requested PRE = NBUF - 2 tiles ahead
+//     (D = 384: 6 buffers, 4 tiles = 98 KB per CU in flight) with counted vmcnt waits and a raw s_barrier per tile,
+//     so the requests stay in flight across barriers;
+//   * the threshold test costs no compare against a per-query value: the accumulators start at -(sim_lo_q) instead
+//     of 0 (the first MFMA of a tile takes its C operand from 32 loop-invariant registers), so "passes its query's
+//     threshold" is the SIGN of the accumulator. The selection of tile t-1 (second accumulator set) is spread over
+//     the k-steps of tile t: one quad of accumulators at a time — v_max3, v_max, v_cmp, branch — in the shadow of
+//     the MFMAs; only a quad with a hit (~1 per tile at ~500 survivors per query) leaves the stream for ~40
+//     instructions (exact re-test d = 1 - (acc + sim_lo) <= tau, slot from an LDS counter, 8-byte store).
+// The padded tile image (row stride 2D + 16 bytes) is cut into 1-KB DMA pieces; lane l of piece P fetches whatever
+// belongs at slot 64 P + l (a row's pad slot re-fetches its last segment); the last piece may run past the 32 rows
+// into the rows that follow — the mirror is allocated with slack rows for that, and rows past the slab are masked by
+// the selection. Survivor segments, thresholds and the exact test are those of batch_gemm_rega_kernel, so the host
+// side and batch_finish_kernel do not know which of the two ran. A query whose threshold is not finite (no usable
+// sample) is marked as overflowed (count 2^30) and answered by the exact path.
+template <int D>
+struct W4Geom {
+    static constexpr int KS = D / 16;                                   // MFMA k-steps
+    static constexpr int ROW_B = D * 2 + 16;                            // LDS row stride (bytes): conflict-free ds_read_b128
+    static constexpr int TROWS = 32;
+    static constexpr int PIECES = (TROWS * ROW_B + 1023) / 1024;        // 1-KB DMA pieces per tile
+    static constexpr int BUF_B = PIECES * 1024;
+    static constexpr int NBUF_RAW = (160 * 1024 - 3 * 256 * 4) / BUF_B;
+    static constexpr int NBUF = NBUF_RAW > 8 ? 8 : NBUF_RAW;
+    static constexpr int PRE = NBUF - 2;                                // tiles requested ahead of the one being read
+    static constexpr size_t SMEM = (size_t)NBUF * BUF_B + 3 * 256 * 4;
+    static constexpr int AHEAD = 3, RING = AHEAD + 1;                   // B-fragment read-ahead (k-steps)
+    static constexpr int UNITS = 8;                                     // selection units per tile: 2 accumulators x 4 quads
+    static_assert(NBUF >= 4, "need at least two tiles in flight");
+};
+
+// Per-wave state of batch_gemm_w4_kernel shared by its (compile-time unrolled) helper functions. Everything is
+// loop-invariant; after inlining it lives in registers.
+template <int D>
+struct W4Ctx {
+    bf16x8 fa0[W4Geom<D>::KS], fa1[W4Geom<D>::KS];     // A fragments of the wave's two query sets
+    int64_t* cand;
+    uint32_t cand_cap, row_base, slab0, slab_end, seg_slots, seg_w0;
+    const lds_f32* tau_w;        // this wave's 64 exact thresholds
+    const lds_f32* neg_w;        // this wave's 64 -(conservative similarity bounds)
+    lds_u32* cnt_w;              // this wave's 64 survivor counters
+    int lane;
+};
+
+// One quad of accumulators of a finished tile: a clear sign bit => some (query, row) reached its threshold.
+// Hot part: 3 integer ANDs, one compare, one branch. Cold part (one copy per unit): the lane's hits are taken one at a
+// time (lowest register first), so the exact test / slot / store code exists once per unit, not once per register.
+template <int D, int U>
+__device__ __forceinline__ void w4_select_unit(const W4Ctx<D>& c, const f32x16 (&P)[2], uint32_t tile) {
+    constexpr int set = U >> 2, qd = U & 3;
+    const float v0 = P[set][4 * qd], v1 = P[set][4 * qd + 1], v2 = P[set][4 * qd + 2], v3 = P[set][4 * qd + 3];
+    const int all_neg = __float_as_int(v0) & __float_as_int(v1) & __float_as_int(v2) & __float_as_int(v3);
+    if (__ballot(all_neg >= 0) == 0ull) return;           // every sign bit set: nothing reached its threshold
+    unsigned hits = (v0 >= 0.0f ? 1u : 0u) | (v1 >= 0.0f ? 2u : 0u) | (v2 >= 0.0f ? 4u : 0u) | (v3 >= 0.0f ? 8u : 0u);   // NaN fails
+    const uint32_t row = c.slab0 + tile * (uint32_t)W4Geom<D>::TROWS + (uint32_t)(c.lane & 31);
+    const bool ok = row < c.slab_end;
+    // register 4 qd + j of set s belongs to query 32 s + j + 8 qd + 4 (lane >> 5)
+    const uint32_t qq0 = 32u * (uint32_t)set + 8u * (uint32_t)qd + 4u * ((uint32_t)c.lane >> 5);
+    while (__ballot(hits != 0u) != 0ull) {
+        if (hits != 0u) {
+            const unsigned j = (unsigned)__builtin_ctz(hits);
+            hits &= hits - 1u;
+            const float v = j == 0u ? v0 : (j == 1u ? v1 : (j == 2u ? v2 : v3));
+            const uint32_t qq = qq0 + j;
+            const float tq = c.tau_w[qq];
+            const float d = (1.0f - (v - c.neg_w[qq])) + 0.0f;   // v = sim - sim_lo, neg = -sim_lo
+            if (ok && d <= tq) {
+                // opaque to hipcc on purpose: before an LDS write it can see, the compiler drains every outstanding
+                // LDS-DMA request (s_waitcnt vmcnt(0)), undoing the prefetch
+                unsigned off;
+                asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
+                             : "=v"(off)
+                             : "v"((unsigned)(size_t)(c.cnt_w + qq)), "v"(1u)
+                             : "memory");
+                if (off < c.seg_slots) c.cand[c.seg_w0 + qq * c.cand_cap + off] = make_key(d, c.row_base + row);
+            }
+        }
+    }
+}
+
+template <int D, int U0, int U1>
+__device__ __forceinline__ void w4_select_units(const W4Ctx<D>& c, const f32x16 (&P)[2], uint32_t tile) {
+    if constexpr (U0 < U1) {
+        w4_select_unit<D, U0>(c, P, tile);
+        w4_select_units<D, U0 + 1, U1>(c, P, tile);
+    }
+}
+
+// k-steps KSI .. KS-1 of one tile: read-ahead of B fragment KSI + AHEAD (inline asm), counted wait for fragment KSI,
+// two MFMAs, then the selection units of the previous tile that are scheduled after this k-step.
+// The B-fragment reads are inline asm with hand-counted waits: with branches inside the k-loop hipcc falls back to
+// `s_waitcnt lgkmcnt(0)` in front of every MFMA pair (one exposed LDS round trip per k-step). LDS operations return
+// in order, so "at most N younger operations outstanding" implies that read KSI has landed whatever else (the cold
+// path's reads, scalar loads) is in the queue: extra operations only make a counted wait stricter.
+template <int D, int KSI>
+__device__ __forceinline__ void w4_ksteps(const W4Ctx<D>& c, f32x16 (&cur)[2], const f32x16 (&prev)[2], uint32_t prev_tile,
+                                          uint32_t baddr, u32x4 (&fb)[W4Geom<D>::RING]) {
+    using G = W4Geom<D>;
+    if constexpr (KSI < G::KS) {
+        if constexpr (KSI + G::AHEAD < G::KS)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[(KSI + G::AHEAD) % G::RING]) : "v"(baddr), "n"((KSI + G::AHEAD) * 32));
+        constexpr int younger = (G::KS - 1 - KSI) < G::AHEAD ? (G::KS - 1 - KSI) : G::AHEAD;
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(younger) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        const bf16x8 B = __builtin_bit_cast(bf16x8, fb[KSI % G::RING]);
+        cur[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c.fa0[KSI], B, cur[0], 0, 0, 0);
+        cur[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c.fa1[KSI], B, cur[1], 0, 0, 0);
+        // selection units spread evenly over the k-steps: unit u runs after k-step floor(u * KS / UNITS)
+        constexpr int u0 = (KSI * G::UNITS + G::KS - 1) / G::KS;            // first u with floor(u KS / UNITS) >= KSI
+        constexpr int u1 = ((KSI + 1) * G::UNITS + G::KS - 1) / G::KS;      // first u with floor(u KS / UNITS) >= KSI + 1
+        w4_select_units<D, u0, (u1 < G::UNITS ? u1 : G::UNITS)>(c, prev, prev_tile);
+        __builtin_amdgcn_sched_barrier(0);
+        w4_ksteps<D, KSI + 1>(c, cur, prev, prev_tile, baddr, fb);
+    }
+}
+
+template <int D, int I>
+__device__ __forceinline__ void w4_prefetch_b(uint32_t baddr, u32x4 (&fb)[W4Geom<D>::RING]) {
+    using G = W4Geom<D>;
+    if constexpr (I < G::AHEAD && I < G::KS) {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[I]) : "v"(baddr), "n"(I * 32));
+        w4_prefetch_b<D, I + 1>(baddr, fb);
+    }
+}
+
+// MFMAs of one tile into `cur`, with the selection of the PREVIOUS tile (`prev`) interleaved between the k-steps.
+template <int D>
+__device__ __forceinline__ void w4_tile_step(const W4Ctx<D>& c, f32x16 (&cur)[2], const f32x16 (&prev)[2], uint32_t prev_tile,
+                                             uint32_t baddr, const lds_f32x4* neg4) {
+    // accumulators start at -(sim_lo) of their query: register 4 j + i of set s <- neg[32 s + 8 j + 4 (lane >> 5) + i]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x4 n0 = neg4[2 * j], n1 = neg4[8 + 2 * j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { cur[0][4 * j + i] = n0[i]; cur[1][4 * j + i] = n1[i]; }
+    }
+    u32x4 fb[W4Geom<D>::RING];
+    w4_prefetch_b<D, 0>(baddr, fb);
+    __builtin_amdgcn_sched_barrier(0);
+    w4_ksteps<D, 0>(c, cur, prev, prev_tile, baddr, fb);
+}
+
+template <int D>
+__global__ __launch_bounds__(256, 1) void batch_gemm_w4_kernel(GemmArgs a, uint32_t blocks_per_group) {
+    using G = W4Geom<D>;
+    constexpr int KS = G::KS;
+    constexpr int ROW_B = G::ROW_B, TROWS = G::TROWS, PIECES = G::PIECES, BUF_B = G::BUF_B, NBUF = G::NBUF, PRE = G::PRE;
+    constexpr int SPR = ROW_B / 16;                  // 16-byte slots per padded row
+    constexpr int PPW = (PIECES + 3) / 4;            // pieces per wave (waves with index >= PIECES % 4 carry one less, if PIECES % 4)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* tau_s = reinterpret_cast<float*>(smem + NBUF * BUF_B);          // [256] exact thresholds
+    unsigned int* cnt_s = reinterpret_cast<unsigned int*>(tau_s + 256);    // [256] survivors per query (this workgroup)
+    float* neg_s = reinterpret_cast<float*>(cnt_s + 256);                  // [256] -(conservative similarity bound)
+
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const uint32_t group = blockIdx.x / blocks_per_group;    // 256 queries per group
+    const uint32_t bidx = blockIdx.x % blocks_per_group;
+    const uint32_t q0 = group * 256 + wave * 64;              // this wave's 64 queries
+
+    W4Ctx<D> c;
+    // A fragments: set s, lane l holds query 32 s + (l & 31), k = 16 ks + 8 (l >> 5) .. +7
+    {
+        const u32x4* qp0 = reinterpret_cast<const u32x4*>(a.qb + (size_t)(q0 + (lane & 31)) * D) + (lane >> 5);
+        const u32x4* qp1 = reinterpret_cast<const u32x4*>(a.qb + (size_t)(q0 + 32 + (lane & 31)) * D) + (lane >> 5);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            c.fa0[ks] = __builtin_bit_cast(bf16x8, qp0[ks * 2]);
+            c.fa1[ks] = __builtin_bit_cast(bf16x8, qp1[ks * 2]);
+        }
+    }
+    {
+        const float tq = a.tau[q0 + lane];
+        const bool usable = (tq == tq) && (tq < __builtin_inff());        // -inf (padding query) is usable: it admits nothing
+        tau_s[wave * 64 + lane] = tq;
+        cnt_s[wave * 64 + lane] = usable ? 0u : 0x40000000u;
+        // fl(1 - sim) <= tq implies sim >= (1 - tq) - 2^-23 (|1 - tq| + |tq|); 4e-7 (1 + |tq|) covers it and the rounding of
+        // (acc + sim_lo) with slack. tq = -inf gives NaN: nothing is flagged.
+        const float sim_lo = (1.0f - tq) - 4e-7f * (1.0f + __builtin_fabsf(tq));
+        neg_s[wave * 64 + lane] = usable ? -sim_lo : __builtin_nanf("");
+    }
+    __syncthreads();     // the only compiler-visible LDS writes of the kernel: all before the first DMA request
+    c.cand = a.cand; c.cand_cap = a.cand_cap; c.row_base = a.row_base; c.slab0 = a.slab0;
+    c.slab_end = a.slab0 + a.slab_rows;
+    c.seg_slots = a.seg_area / blocks_per_group;
+    c.seg_w0 = q0 * a.cand_cap + a.seg_base + bidx * c.seg_slots;   // element offset of the wave's first query row, this workgroup's segment
+    c.tau_w = (const lds_f32*)(tau_s + wave * 64);
+    c.neg_w = (const lds_f32*)(neg_s + wave * 64);
+    c.cnt_w = (lds_u32*)(cnt_s + wave * 64);
+    c.lane = lane;
+
+    const uint32_t ntiles = (a.slab_rows + TROWS - 1) / TROWS;
+    const unsigned char* cbase = reinterpret_cast<const unsigned char*>(a.cb) + (size_t)a.slab0 * (D * 2);
+
+    // LDS-DMA map: wave w moves pieces w, w + 4, ...; lane l of piece P fills slot 64 P + l of the padded image.
+    // Source offset of that slot inside the tile's contiguous rows (loop-invariant: one register per piece).
+    uint32_t poff[PPW];
+    int my_pieces = 0;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const uint32_t P = (uint32_t)wave + 4u * i;
+        const uint32_t slot = P * 64u + (uint32_t)lane;
+        const uint32_t r = slot / SPR;
+        uint32_t cc = slot - r * SPR;
+        cc = cc < (uint32_t)(SPR - 1) ? cc : (uint32_t)(SPR - 2);         // pad slot: re-fetch the row's last segment
+        poff[i] = r * (uint32_t)(D * 2) + cc * 16u;                       // r may reach a few rows past the tile (last piece): slack rows
+        if (P < (uint32_t)PIECES) ++my_pieces;
+    }
+    const bool full_wave = my_pieces == PPW;                  // wave-uniform
+    auto dma_tile = [&](uint32_t tile, uint32_t buf_idx) {
+        const unsigned char* src0 = cbase + (size_t)tile * (TROWS * D * 2);
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const uint32_t P = (uint32_t)wave + 4u * i;
+            if (i < PPW - 1 || full_wave)
+                __builtin_amdgcn_global_load_lds((global_cvoid*)(src0 + poff[i]), (lds_void*)(smem + buf_idx * BUF_B + P * 1024u), 16, 0, 0);
+        }
+    };
+    // wait until this wave's DMA requests of all but the newest PRE - 1 tiles have landed (steady state), or all of them
+    auto dma_wait_keep = [&](bool steady) {
+        if (!steady) wait_vmcnt<0>();
+        else if (full_wave) wait_vmcnt<(PRE - 1) * PPW>();
+        else wait_vmcnt<(PRE - 1) * (PPW - 1)>();
+    };
+
+    const uint32_t lane_boff = (uint32_t)(lane & 31) * (uint32_t)ROW_B + (uint32_t)(lane >> 5) * 16u;
+    const uint32_t smem_lds = (uint32_t)(size_t)(lds_void*)smem;
+    const lds_f32x4* neg4 = (const lds_f32x4*)(neg_s + wave * 64 + 4 * (lane >> 5));
+
+    f32x16 accA[2], accB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accA[i][r] = -1.0f; accB[i][r] = -1.0f; }   // "no hit": nothing to select before the first tile
+
+    // The A fragments are ordinary loads: make them land BEFORE the first DMA request (beside a DMA in flight hipcc waits
+    // vmcnt(0) for an ordinary load's first use, which would drain the prologue's prefetch). Loads return in order.
+    asm volatile("" ::"v"(c.fa0[KS - 1]), "v"(c.fa1[KS - 1]));
+    // prologue: request the first PRE tiles, wait for the first
+    uint32_t t = bidx;
+    {
+        uint32_t tt = t;
+        int issued = 0;
+#pragma unroll
+        for (int i = 0; i < PRE; ++i, tt += blocks_per_group)
+            if (tt < ntiles) { dma_tile(tt, (uint32_t)i); ++issued; }
+        dma_wait_keep(issued == PRE);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    uint32_t cur_idx = 0;                                      // ring position of tile t
+    while (t < ntiles) {
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            const uint32_t tp = t + (uint32_t)PRE * blocks_per_group;
+            uint32_t pre_idx = cur_idx + (uint32_t)PRE;
+            pre_idx = pre_idx >= (uint32_t)NBUF ? pre_idx - (uint32_t)NBUF : pre_idx;
+            const bool issued = tp < ntiles;
+            if (issued) dma_tile(tp, pre_idx);
+            const uint32_t baddr = smem_lds + cur_idx * (uint32_t)BUF_B + lane_boff;
+            if (par == 0) w4_tile_step<D>(c, accA, accB, t - blocks_per_group, baddr, neg4);   // first iteration: accB is all -1, its tile index is never used
+            else w4_tile_step<D>(c, accB, accA, t - blocks_per_group, baddr, neg4);
+            // tile t + 1 must have landed (every wave waits for its own pieces, the barrier joins them); the younger
+            // requests stay in flight across the barrier
+            dma_wait_keep(issued);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            cur_idx = cur_idx + 1 == (uint32_t)NBUF ? 0u : cur_idx + 1;
+            const uint32_t tn = t + blocks_per_group;
+            if (tn >= ntiles) {
+                if (par == 0) w4_select_units<D, 0, G::UNITS>(c, accA, t);
+                else w4_select_units<D, 0, G::UNITS>(c, accB, t);
+                t = tn;
+                break;
+            }
+            t = tn;
+        }
+    }
+    // unclamped counts: a count above seg_slots tells the consumer that survivors were dropped (query -> exact path)
+    __syncthreads();
+    a.seg_count[(size_t)bidx * (a.nqt * 128u) + group * 256u + (uint32_t)tid] = cnt_s[tid];
+}
+
+static void rega_geometry(const GemmArgs& a, uint32_t* groups, uint32_t* per_group);
+static bool w4_dims(uint32_t dims) { return dims == 128 || dims == 256 || dims == 384 || dims == 512; }
+uint32_t batch_w4_slack_rows() { return 64; }   // rows the w4 kernel's last DMA piece may read past the end of the store
+
+template <int D>
+static hipError_t launch_w4(const GemmArgs& a, hipStream_t st) {
+    constexpr size_t smem = W4Geom<D>::SMEM;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&batch_gemm_w4_kernel<D>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    uint32_t groups, pg;
+    rega_geometry(a, &groups, &pg);          // the same workgroups-per-group (= survivor segments) as batch_gemm_rega_kernel
+    hipLaunchKernelGGL((batch_gemm_w4_kernel<D>), dim3(groups * pg), dim3(256), smem, st, a, pg);
+    return hipGetLastError();
+}
+
 // D = 1024 would need 2 x 66 KB of tiles + 32 KB of partial sums (> 160 KB of LDS): it stays on the LDS-tiled kernel.
 static bool ksplit_dims(uint32_t dims) { return dims == 768; }
 
@@ -944,6 +1272,14 @@ static hipError_t launch_rega(const GemmArgs& a, hipStream_t st) {
 hipError_t launch_batch_gemm(const GemmArgs& a, int metric, hipStream_t st) {
     // fast path: queries resident in registers (needs the query block padded to a multiple of 256 rows)
     if (rega_eligible(a, metric)) {
+        if (a.use_rega == 3u && w4_dims(a.dims)) {   // one wave per SIMD, 64 queries per wave (same segments / geometry)
+            switch (a.dims) {
+                case 128: return launch_w4<128>(a, st);
+                case 256: return launch_w4<256>(a, st);
+                case 512: return launch_w4<512>(a, st);
+                default: return launch_w4<384>(a, st);
+            }
+        }
         switch (a.dims) {
             case 128: return launch_rega<128>(a, st);
             case 256: return launch_rega<256>(a, st);
@@ -1334,8 +1670,11 @@ bool batch_onepass_dims(uint32_t dims, int metric) {
 uint32_t batch_tile_rows(uint32_t dims) { return dims == 768 ? 32u : 64u; }
 
 __global__ __launch_bounds__(256) void batch_prep_kernel(PrepArgs a) {
+    constexpr uint32_t CHUNK = 1024;                     // floats staged per wave at a time
+    __shared__ float stage_s[4][CHUNK];
     const int lane = lane_id();
-    const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wave = (int)(threadIdx.x >> 6);
+    const uint32_t q = blockIdx.x * 4 + (uint32_t)wave;
     if (q >= a.nq_pad) return;
     const uint32_t D = a.dims;
     unsigned short* out = a.qb + (size_t)q * D;
@@ -1348,24 +1687,35 @@ __global__ __launch_bounds__(256) void batch_prep_kernel(PrepArgs a) {
         return;
     }
     const float* row = a.queries + (size_t)q * D;
-    // bf16 block (approximate path only): same arithmetic as mirror_kernel
+    float* st = stage_s[wave];
+    // (1) f32 norm for the bf16 block (approximate path only; same arithmetic as mirror_kernel) and
+    // (2) the exact ||q|| exactly as the host computes it for the single-query path (engine.hip query_norm): four f64
+    // partial sums over j = c, c + 4, ... in ascending order (every product of two floats is exact in f64, so a fused
+    // multiply-add rounds like multiply-then-add), a tail into the first, (s0 + s1) + (s2 + s3), sqrt, one rounding
+    // to f32. Lanes 0..3 each run one chain, reading the row from LDS (staged with coalesced loads: a chain of
+    // dependent global loads cost 12 us per launch).
     float acc = 0.f;
+    double part = 0.0;
+    const uint32_t d4 = D & ~3u;
+    for (uint32_t c0 = 0; c0 < D; c0 += CHUNK) {
+        const uint32_t len = (D - c0 < CHUNK) ? D - c0 : CHUNK;
+        wave_lds_fence();
+        for (uint32_t c = lane; c < len; c += WAVE) st[c] = row[c0 + c];
+        wave_lds_fence();
+        if (lane < 4) {
+            const uint32_t lim = (c0 + len <= d4) ? len : (d4 > c0 ? d4 - c0 : 0u);   // the 4-aligned part of this chunk
+#pragma unroll 8
+            for (uint32_t j = (uint32_t)lane; j < lim; j += 4) part += (double)st[j] * (double)st[j];
+            if (lane == 0)
+                for (uint32_t j = lim; j < len; ++j) part += (double)st[j] * (double)st[j];   // tail (last chunk only)
+        }
+    }
     for (uint32_t c = lane; c < D; c += WAVE) acc = fmaf(row[c], row[c], acc);
     acc = group_sum<64>(acc);
     acc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 63));
     const float nf = sqrtf(acc);
     const float scale = (a.metric == BM_COS) ? ((nf > 1e-6f) ? 1.0f / nf : 0.0f) : 1.0f;
     for (uint32_t c = lane; c < D; c += WAVE) out[c] = f32_to_bf16_rne(row[c] * scale);
-    // exact ||q|| exactly as the host computes it for the single-query path (engine.hip query_norm): four f64
-    // partial sums over j = c, c + 4, ... in ascending order (every product of two floats is exact in f64, so a
-    // fused multiply-add rounds like multiply-then-add), a tail into the first, (s0 + s1) + (s2 + s3), sqrt, one
-    // rounding to f32. Lanes 0..3 each run one chain.
-    double part = 0.0;
-    const uint32_t d4 = D & ~3u;
-    if (lane < 4)
-        for (uint32_t j = (uint32_t)lane; j < d4; j += 4) part += (double)row[j] * (double)row[j];
-    if (lane == 0)
-        for (uint32_t j = d4; j < D; ++j) part += (double)row[j] * (double)row[j];
     const double s0 = __shfl(part, 0), s1 = __shfl(part, 1), s2 = __shfl(part, 2), s3 = __shfl(part, 3);
     if (lane == 0) {
         const double total = (s0 + s1) + (s2 + s3);
@@ -1451,35 +1801,50 @@ hipError_t launch_batch_gemm_sample(const GemmArgs& a, int metric, hipStream_t s
     return hipErrorInvalidValue;
 }
 
-// One wave per query: the rank-th largest of its sampled tile maxima becomes the admission threshold.
-__global__ __launch_bounds__(256) void pick_tau_kernel(const float* __restrict__ tile_max, uint32_t sample_tiles,
-                                                       uint32_t nq, uint32_t nq_pad, uint32_t rank,
-                                                       float* __restrict__ tau) {
-    constexpr int CAP = 256;
-    __shared__ int64_t lds[4 * CAP];
-    const int lane = lane_id();
-    const int wave = (int)(threadIdx.x >> 6);
-    const uint32_t q = blockIdx.x * 4 + (uint32_t)wave;
-    if (q >= nq) return;                                   // whole wave
-    WaveTopK<CAP> tk;
-    tk.init(lds + wave * CAP, (int)rank);
-    for (uint32_t base = 0; base < sample_tiles; base += WAVE) {
-        const uint32_t i = base + (uint32_t)lane;
-        float sim = (i < sample_tiles) ? tile_max[(size_t)i * nq_pad + q] : 0.f;
-        sim = (sim == sim) ? sim : -__builtin_inff();      // a tile of NaN similarities never sets a threshold
-        tk.push_wide(make_key(-sim, i), i < sample_tiles); // ascending -sim == descending similarity; unique by tile index
+// Admission thresholds from the sampled tile maxima, by pure reductions: the sampled tiles are dealt round-robin into
+// G groups (every group spans the whole store), tau_sim = min over the groups of the group's best tile maximum. At
+// least G sampled rows (one per group) reach it; for well-mixed data the number of sampled TILES whose best row
+// reaches it has median ~ c(G) G with c(G) = -ln(1 - 2^(-1/G)) (G = 4: 7.4, 8: 20, 16: 51, 32: 123), and a short
+// upper tail: P(more than x) <= G (1 - x/S)^(S/G). (A rank-th order statistic by sorting — the first version — was a
+// 18 us latency chain per batch; this is ~3 us.) Workgroup = 32 queries x 32 slices; thread (query, slice) takes the
+// maximum over tiles i = slice, slice + 32, ...; G divides 32, so a slice lies in group slice % G.
+__global__ __launch_bounds__(1024) void pick_tau_kernel(const float* __restrict__ tile_max, uint32_t sample_tiles,
+                                                        uint32_t nq, uint32_t nq_pad, uint32_t groups,
+                                                        float* __restrict__ tau) {
+    __shared__ float part[32][33];
+    const uint32_t qi = threadIdx.x & 31u, slice = threadIdx.x >> 5;
+    const uint32_t q = blockIdx.x * 32u + qi;                 // < nq_pad (tile_max rows are nq_pad wide)
+    float m = -__builtin_inff();
+    constexpr uint32_t U = 8;
+    for (uint32_t i0 = slice; i0 < sample_tiles; i0 += 32u * U) {
+        float v[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+            const uint32_t i = i0 + 32u * u;
+            v[u] = (i < sample_tiles) ? tile_max[(size_t)i * nq_pad + q] : -__builtin_inff();
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) m = __builtin_fmaxf(m, v[u]);     // maxNum: a NaN tile maximum never wins
     }
-    tk.finalize();
-    if (lane == 0) {
-        // fewer sampled tiles than `rank` (the host never plans that): no threshold, everything is admitted
-        tau[q] = (tk.cnt >= (int)rank) ? (1.0f - (-key_distance(tk.buf[rank - 1]))) : __builtin_inff();
+    part[slice][qi] = m;
+    __syncthreads();
+    if (slice == 0 && q < nq) {
+        float t = __builtin_inff();
+        for (uint32_t g = 0; g < groups; ++g) {
+            float gm = -__builtin_inff();
+            for (uint32_t sl = g; sl < 32u; sl += groups) gm = __builtin_fmaxf(gm, part[sl][qi]);
+            t = __builtin_fminf(t, gm);
+        }
+        // a group without a finite maximum (NaN query / no sampled tile): no threshold => +inf, the GEMM marks the query
+        // for the exact path instead of admitting the whole store
+        tau[q] = (t > -__builtin_inff()) ? 1.0f - t : __builtin_inff();
     }
 }
 
-hipError_t launch_pick_tau(const float* tile_max, uint32_t sample_tiles, uint32_t nq, uint32_t nq_pad, uint32_t rank,
+hipError_t launch_pick_tau(const float* tile_max, uint32_t sample_tiles, uint32_t nq, uint32_t nq_pad, uint32_t groups,
                            float* tau, hipStream_t st) {
-    if (rank < 1 || rank > (uint32_t)FUSED_MAX_K || sample_tiles == 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(pick_tau_kernel, dim3((nq + 3) / 4), dim3(256), 0, st, tile_max, sample_tiles, nq, nq_pad, rank, tau);
+    if (groups < 1 || groups > 32 || (32u % groups) != 0 || sample_tiles == 0 || (nq_pad % 32u) != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pick_tau_kernel, dim3((nq + 31) / 32), dim3(1024), 0, st, tile_max, sample_tiles, nq, nq_pad, groups, tau);
     return hipGetLastError();
 }
 
@@ -1543,20 +1908,33 @@ __global__ __launch_bounds__(SCAN_THREADS) void batch_finish_kernel(FinishArgs a
         f32x4 qv[LOADS];
 #pragma unroll
         for (int j = 0; j < LOADS; ++j) qv[j] = q4[j * GROUP];
-        for (int c0 = wave * RPW; c0 < m; c0 += SCAN_WAVES * RPW) {
-            const int c = c0 + sub;
-            const int64_t ck = fin[c < m ? c : m - 1];
-            uint32_t lrow = key_row(ck) - a.row_base;
-            lrow = lrow < a.n_rows ? lrow : 0;
-            const f32x4* __restrict__ v4 = reinterpret_cast<const f32x4*>(a.store) + (size_t)lrow * D4 + gl;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f}, nrm = {0.f, 0.f, 0.f, 0.f};
+        // U row fetches in flight per lane group (one dependent HBM round trip per U candidates instead of per candidate)
+        constexpr int U = (LOADS <= 3) ? 4 : 2;
+        for (int c0 = wave * RPW; c0 < m; c0 += SCAN_WAVES * RPW * U) {
+            int64_t ck[U];
+            f32x4 v[U][LOADS];
 #pragma unroll
-            for (int j = 0; j < LOADS; ++j) accumulate_b<METRIC>(qv[j], v4[j * GROUP], acc, nrm);
-            const float s = group_sum<GROUP>(hsum_b(acc));
-            float mm = 0.f;
-            if (METRIC == BM_COS) mm = group_sum<GROUP>(hsum_b(nrm));
-            const float d = finish_distance_b<METRIC>(s, mm, qn);
-            if (c < m && gl == GROUP - 1) ex[c] = make_key(d, key_row(ck));
+            for (int u = 0; u < U; ++u) {
+                const int c = c0 + u * SCAN_WAVES * RPW + sub;
+                ck[u] = fin[c < m ? c : m - 1];
+                uint32_t lrow = key_row(ck[u]) - a.row_base;
+                lrow = lrow < a.n_rows ? lrow : 0;
+                const f32x4* __restrict__ v4 = reinterpret_cast<const f32x4*>(a.store) + (size_t)lrow * D4 + gl;
+#pragma unroll
+                for (int j = 0; j < LOADS; ++j) v[u][j] = v4[j * GROUP];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int c = c0 + u * SCAN_WAVES * RPW + sub;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f}, nrm = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < LOADS; ++j) accumulate_b<METRIC>(qv[j], v[u][j], acc, nrm);
+                const float s = group_sum<GROUP>(hsum_b(acc));
+                float mm = 0.f;
+                if (METRIC == BM_COS) mm = group_sum<GROUP>(hsum_b(nrm));
+                const float d = finish_distance_b<METRIC>(s, mm, qn);
+                if (c < m && gl == GROUP - 1) ex[c] = make_key(d, key_row(ck[u]));
+            }
         }
     }
     __syncthreads();

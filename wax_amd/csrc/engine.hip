@@ -711,7 +711,9 @@ int ensure_mirror(wax_hip_engine* e, hipStream_t st) {
         // took the exclusive lock after every reader had finished
         (void)hipFree(b.d_cb); (void)hipFree(b.d_vn2);
         b.d_cb = nullptr; b.d_vn2 = nullptr; b.mirror_cap = 0; b.mirror_valid = false;
-        HIP_TRY(hipMalloc(&b.d_cb, (size_t)e->capacity * D * sizeof(unsigned short)), WAX_HIP_ERR_ALLOC, "Failed to allocate bf16 mirror");
+        // + slack rows: the one-wave-per-SIMD GEMM's last DMA piece of a tile reads a few rows past it (never used: masked)
+        HIP_TRY(hipMalloc(&b.d_cb, ((size_t)e->capacity + 64) * D * sizeof(unsigned short)), WAX_HIP_ERR_ALLOC, "Failed to allocate bf16 mirror");
+        HIP_TRY(hipMemsetAsync(b.d_cb + (size_t)e->capacity * D, 0, (size_t)64 * D * sizeof(unsigned short), st), WAX_HIP_ERR_INTERNAL, "mirror slack clear");
         HIP_TRY(hipMalloc(&b.d_vn2, (size_t)e->capacity * sizeof(float)), WAX_HIP_ERR_ALLOC, "Failed to allocate row norms");
         b.mirror_cap = e->capacity;
     }
@@ -870,40 +872,50 @@ int batch_kp(int k_eff, int kp_max) {
 
 // ---- one-pass pipeline: plan -------------------------------------------------------------------------------------
 struct OnepassPlan {
-    uint32_t tile_rows, ntiles, sample_tiles, rank, seg_area;
+    uint32_t tile_rows, ntiles, sample_tiles, groups, seg_area;
     int kp;
+    double expect;       // expected survivors per query
 };
 
+// tau_sim = min over G interleaved groups (L sampled tiles each) of the group's best similarity (pick_tau_kernel).
+// With well-mixed rows: a tile holds no row above tau with probability F_t; the group maxima are i.i.d. with CDF F_t^L;
+// the median of their minimum solves F_t^L = a_G := 1 - 2^(-1/G). Wanting a fraction p = target / n of all rows above
+// tau means F_t = (1 - p)^tile_rows, hence L = ln a_G / ln F_t. Small G keeps the sample (S = G L tiles) small for big
+// stores; large G is what reaches the loose thresholds a small store / a large k' needs.
 bool plan_onepass(wax_hip_engine* e, uint32_t n, int k_eff, OnepassPlan* p) {
     if (e->batch_onepass.load() == 0 || !batch_onepass_dims(e->dims, e->metric) || k_eff > kBatchMaxK) return false;
     p->tile_rows = batch_tile_rows(e->dims);
     p->ntiles = (n + p->tile_rows - 1) / p->tile_rows;
     if ((int64_t)p->ntiles < e->batch_onepass_tiles.load() || p->ntiles < 1024) return false;
     p->kp = batch_kp(k_eff, 960);
-    // ~1/64 of the tiles, at least one per GEMM workgroup, at most a quarter of the store
-    uint64_t S = p->ntiles / (uint64_t)e->batch_sample_div.load();
-    if (S < 256) S = 256;
-    if (S > p->ntiles / 4) S = p->ntiles / 4;
-    p->sample_tiles = (uint32_t)S;
-    // tau = the rank-th best sampled tile maximum. Tiles whose best row beats tau are then a fraction f = rank / S of
-    // all tiles; with hits spread like a Poisson process that is lambda = -ln(1 - f) hits per tile, lambda * ntiles
-    // survivors per query in the filtering pass. Aim at `batch_survivors` x k' of them (default 8 k': >= k' with
-    // overwhelming probability — P(Gamma(8) < 1) ~ 1e-5 — and ~2 per (workgroup, query) segment).
+    // survivors aimed at: `batch_survivors` x k' (default 8 k': >= k' with overwhelming probability, ~2 per
+    // (workgroup, query) segment at the default segment area)
     const double target = (double)e->batch_survivors.load() * (double)p->kp;
-    const double f = 1.0 - std::exp(-target / (double)p->ntiles);
-    double r = std::ceil(f * (double)S);
-    if (r < 8.0) r = 8.0;
-    if (r > 192.0) {
-        // the threshold pick keeps <= 192 maxima per query: a small store with a large k' cannot reach the target;
-        // take the plan only if the reachable survivor count still covers 2 k'
-        r = 192.0;
-        const double reach = -std::log(1.0 - r / (double)S) * (double)p->ntiles;
-        if (reach < 2.0 * (double)p->kp) return false;
+    double prow = target / (double)n;
+    if (prow > 0.25) return false;                       // a quarter of the store as candidates: not a filter any more
+    const double neg_ln_ft = -(double)p->tile_rows * std::log1p(-prow);
+    uint64_t s_pref = p->ntiles / (uint64_t)e->batch_sample_div.load();
+    if (s_pref < 64) s_pref = 64;
+    if (s_pref > 192) s_pref = 192;
+    uint32_t G = 0, L = 0;
+    for (uint32_t g = 4; g <= 32; g *= 2) {
+        const double a_g = 1.0 - std::exp2(-1.0 / (double)g);
+        double l = std::floor(-std::log(a_g) / neg_ln_ft + 0.5);
+        if (l < 1.0) l = 1.0;
+        if (l * g > (double)(p->ntiles / 2)) l = std::floor((double)(p->ntiles / 2) / g);
+        G = g; L = (uint32_t)l;
+        if ((uint64_t)g * L >= s_pref) break;
     }
-    p->rank = (uint32_t)r;
-    const double expect = -std::log(1.0 - (double)p->rank / (double)S) * (double)p->ntiles;
+    p->groups = G;
+    p->sample_tiles = G * L;
+    // what this (G, L) is expected to admit
+    const double a_g = 1.0 - std::exp2(-1.0 / (double)G);
+    const double ft = std::pow(a_g, 1.0 / (double)L);
+    const double p_real = 1.0 - std::pow(ft, 1.0 / (double)p->tile_rows);
+    p->expect = p_real * (double)n;
+    if (p->expect < 2.0 * (double)p->kp) return false;   // cannot reach enough candidates for the certificate: other paths
     uint64_t area = kBatchSegArea;
-    while ((double)area < 4.0 * expect) area *= 2;   // mean segment fill <= 1/4: an overflowing segment is a ~1e-9 event
+    while ((double)area < 4.0 * p->expect) area *= 2;     // mean segment fill <= 1/4: an overflowing segment is a ~1e-9 event
     if (area > 65536) return false;
     p->seg_area = (uint32_t)area;
     return true;
@@ -939,7 +951,7 @@ int batch_enqueue(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32
         GemmArgs gs = g;
         gs.tile_max = c->d_tile_max; gs.sample_tiles = plan->sample_tiles;
         HIP_TRY(launch_batch_gemm_sample(gs, e->metric, st), WAX_HIP_ERR_INTERNAL, "sampling gemm launch");
-        HIP_TRY(launch_pick_tau(c->d_tile_max, plan->sample_tiles, qn, nq_pad, plan->rank, c->d_tau, st), WAX_HIP_ERR_INTERNAL,
+        HIP_TRY(launch_pick_tau(c->d_tile_max, plan->sample_tiles, qn, nq_pad, plan->groups, c->d_tau, st), WAX_HIP_ERR_INTERNAL,
                 "threshold kernel launch");
         const bool timed = e->time_kernels.load() != 0;
         if (timed) HIP_TRY(hipEventRecord(c->ev_g0, st), WAX_HIP_ERR_INTERNAL, "event record");
@@ -1110,7 +1122,7 @@ int wax_hip_engine_create(uint8_t metric, uint32_t dims, int device_id, wax_hip_
     e->dims = dims;
     if (const char* v = std::getenv("WAX_HIP_BATCH_REGA")) {  // default of the "batch_rega" tunable (A/B runs of the whole test suite)
         const long m = std::strtol(v, nullptr, 10);
-        if (m >= 0 && m <= 2) e->batch_rega = m;
+        if (m >= 0 && m <= 3) e->batch_rega = m;
     }
     int rc = resize_store(e, WAX_HIP_INITIAL_RESERVE);  // :225-229
     if (rc == WAX_HIP_OK) {

@@ -143,8 +143,9 @@ struct PrepArgs {
 };
 hipError_t launch_batch_prep(const PrepArgs& a, hipStream_t stream);
 hipError_t launch_batch_gemm_sample(const GemmArgs& a, int metric, hipStream_t stream);
-// tau[q] = 1 - (rank-th largest of tile_max[0..sample_tiles)[q]); padding queries keep -inf. rank <= 192.
-hipError_t launch_pick_tau(const float* tile_max, uint32_t sample_tiles, uint32_t nq, uint32_t nq_pad, uint32_t rank,
+// tau[q] = 1 - min over `groups` interleaved groups of sampled tiles of (the group's best tile maximum); padding queries
+// keep -inf. groups divides 32.
+hipError_t launch_pick_tau(const float* tile_max, uint32_t sample_tiles, uint32_t nq, uint32_t nq_pad, uint32_t groups,
                            float* tau, hipStream_t stream);
 // Per query: survivors of the filtering GEMM (per-workgroup segments) -> best kp by approximate key -> exact f32
 // re-score with the scan kernel's arithmetic -> top-k hits + exactness certificate. kp <= 192: one fused kernel;
