@@ -927,6 +927,8 @@ struct W4Ctx {
     bf16x8 fa0[W4Geom<D>::KS], fa1[W4Geom<D>::KS];     // A fragments of the wave's two query sets
     int64_t* cand;
     uint32_t cand_cap, row_base, slab0, slab_end, seg_slots, seg_w0;
+    f32x16 nl0, nl1;             // accumulator start values: -(conservative similarity bound) of the register's query, per set
+    uint32_t debug;              // timing experiments (GemmArgs::debug)
     const lds_f32* tau_w;        // this wave's 64 exact thresholds
     const lds_f32* neg_w;        // this wave's 64 -(conservative similarity bounds)
     lds_u32* cnt_w;              // this wave's 64 survivor counters
@@ -994,12 +996,17 @@ __device__ __forceinline__ void w4_ksteps(const W4Ctx<D>& c, f32x16 (&cur)[2], c
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(younger) : "memory");
         __builtin_amdgcn_sched_barrier(0);
         const bf16x8 B = __builtin_bit_cast(bf16x8, fb[KSI % G::RING]);
-        cur[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c.fa0[KSI], B, cur[0], 0, 0, 0);
-        cur[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c.fa1[KSI], B, cur[1], 0, 0, 0);
+        if constexpr (KSI == 0) {   // C operand = the per-query start values: no accumulator initialisation pass
+            cur[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c.fa0[0], B, c.nl0, 0, 0, 0);
+            cur[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c.fa1[0], B, c.nl1, 0, 0, 0);
+        } else {
+            cur[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c.fa0[KSI], B, cur[0], 0, 0, 0);
+            cur[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c.fa1[KSI], B, cur[1], 0, 0, 0);
+        }
         // selection units spread evenly over the k-steps: unit u runs after k-step floor(u * KS / UNITS)
         constexpr int u0 = (KSI * G::UNITS + G::KS - 1) / G::KS;            // first u with floor(u KS / UNITS) >= KSI
         constexpr int u1 = ((KSI + 1) * G::UNITS + G::KS - 1) / G::KS;      // first u with floor(u KS / UNITS) >= KSI + 1
-        w4_select_units<D, u0, (u1 < G::UNITS ? u1 : G::UNITS)>(c, prev, prev_tile);
+        if (!(c.debug & 8u)) w4_select_units<D, u0, (u1 < G::UNITS ? u1 : G::UNITS)>(c, prev, prev_tile);   // debug bit3: no selection
         __builtin_amdgcn_sched_barrier(0);
         w4_ksteps<D, KSI + 1>(c, cur, prev, prev_tile, baddr, fb);
     }
@@ -1017,14 +1024,7 @@ __device__ __forceinline__ void w4_prefetch_b(uint32_t baddr, u32x4 (&fb)[W4Geom
 // MFMAs of one tile into `cur`, with the selection of the PREVIOUS tile (`prev`) interleaved between the k-steps.
 template <int D>
 __device__ __forceinline__ void w4_tile_step(const W4Ctx<D>& c, f32x16 (&cur)[2], const f32x16 (&prev)[2], uint32_t prev_tile,
-                                             uint32_t baddr, const lds_f32x4* neg4) {
-    // accumulators start at -(sim_lo) of their query: register 4 j + i of set s <- neg[32 s + 8 j + 4 (lane >> 5) + i]
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const f32x4 n0 = neg4[2 * j], n1 = neg4[8 + 2 * j];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { cur[0][4 * j + i] = n0[i]; cur[1][4 * j + i] = n1[i]; }
-    }
+                                             uint32_t baddr) {
     u32x4 fb[W4Geom<D>::RING];
     w4_prefetch_b<D, 0>(baddr, fb);
     __builtin_amdgcn_sched_barrier(0);
@@ -1080,6 +1080,16 @@ __global__ __launch_bounds__(256, 1) void batch_gemm_w4_kernel(GemmArgs a, uint3
     c.neg_w = (const lds_f32*)(neg_s + wave * 64);
     c.cnt_w = (lds_u32*)(cnt_s + wave * 64);
     c.lane = lane;
+    c.debug = a.debug;
+    // the lane's 32 accumulator start values: register r of set s belongs to query 32 s + (r&3) + 8 (r>>2) + 4 (lane>>5)
+    {
+        const float* nw = neg_s + wave * 64 + 4 * (lane >> 5);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            c.nl0[r] = nw[(r & 3) + 8 * (r >> 2)];
+            c.nl1[r] = nw[32 + (r & 3) + 8 * (r >> 2)];
+        }
+    }
 
     const uint32_t ntiles = (a.slab_rows + TROWS - 1) / TROWS;
     const unsigned char* cbase = reinterpret_cast<const unsigned char*>(a.cb) + (size_t)a.slab0 * (D * 2);
@@ -1117,7 +1127,9 @@ __global__ __launch_bounds__(256, 1) void batch_gemm_w4_kernel(GemmArgs a, uint3
 
     const uint32_t lane_boff = (uint32_t)(lane & 31) * (uint32_t)ROW_B + (uint32_t)(lane >> 5) * 16u;
     const uint32_t smem_lds = (uint32_t)(size_t)(lds_void*)smem;
-    const lds_f32x4* neg4 = (const lds_f32x4*)(neg_s + wave * 64 + 4 * (lane >> 5));
+    // timing experiments (results are garbage): bit0 no DMA after the prologue, bit1 no MFMA tile work, bit2 no per-tile
+    // barrier, bit3 no selection
+    const bool dbg_nodma = (a.debug & 1u) != 0, dbg_nomfma = (a.debug & 2u) != 0, dbg_nobar = (a.debug & 4u) != 0;
 
     f32x16 accA[2], accB[2];
 #pragma unroll
@@ -1147,15 +1159,17 @@ __global__ __launch_bounds__(256, 1) void batch_gemm_w4_kernel(GemmArgs a, uint3
             const uint32_t tp = t + (uint32_t)PRE * blocks_per_group;
             uint32_t pre_idx = cur_idx + (uint32_t)PRE;
             pre_idx = pre_idx >= (uint32_t)NBUF ? pre_idx - (uint32_t)NBUF : pre_idx;
-            const bool issued = tp < ntiles;
+            const bool issued = tp < ntiles && !dbg_nodma;
             if (issued) dma_tile(tp, pre_idx);
             const uint32_t baddr = smem_lds + cur_idx * (uint32_t)BUF_B + lane_boff;
-            if (par == 0) w4_tile_step<D>(c, accA, accB, t - blocks_per_group, baddr, neg4);   // first iteration: accB is all -1, its tile index is never used
-            else w4_tile_step<D>(c, accB, accA, t - blocks_per_group, baddr, neg4);
+            if (!dbg_nomfma) {
+                if (par == 0) w4_tile_step<D>(c, accA, accB, t - blocks_per_group, baddr);   // first iteration: accB is all -1, its tile index is never used
+                else w4_tile_step<D>(c, accB, accA, t - blocks_per_group, baddr);
+            }
             // tile t + 1 must have landed (every wave waits for its own pieces, the barrier joins them); the younger
             // requests stay in flight across the barrier
             dma_wait_keep(issued);
-            __builtin_amdgcn_s_barrier();
+            if (!dbg_nobar) __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             cur_idx = cur_idx + 1 == (uint32_t)NBUF ? 0u : cur_idx + 1;
             const uint32_t tn = t + blocks_per_group;

@@ -258,7 +258,7 @@ struct BatchCtx {
     float* d_dense = nullptr;            // slab pipeline: [kBatchMaxQ][kBatchFirstSlab] first-slab score tile
     uint32_t* d_cand_count = nullptr;
     uint32_t* d_overflow = nullptr;
-    int64_t* d_cand = nullptr;           // [kBatchMaxQ][cand_slots]
+    int64_t* d_cand = nullptr;           // [rows of a block][slots per query]; cand_slots = capacity in keys
     uint64_t cand_slots = 0;
     uint32_t* d_seg_count = nullptr;     // [kBatchMaxSegs][kBatchMaxQ] survivors per (GEMM workgroup, query)
     int64_t* d_exact = nullptr;          // [kBatchMaxQ][kp_cap]
@@ -807,7 +807,9 @@ int grow_dev(T** p, uint64_t* cap, uint64_t want, size_t elem, const char* what)
 }
 
 int bctx_reserve(BatchCtx* c, uint64_t cand_slots, uint64_t kp, uint64_t tile_rows, uint64_t n_queries, bool dense) {
-    int rc = grow_dev(&c->d_cand, &c->cand_slots, cand_slots, (size_t)kBatchMaxQ * sizeof(int64_t), "Failed to allocate batch candidates");
+    // [rows of the largest block][cand_slots] keys; capacity tracked in keys
+    const uint64_t rows_blk = n_queries < kBatchMaxQ ? ((n_queries + 255ull) & ~255ull) : (uint64_t)kBatchMaxQ;
+    int rc = grow_dev(&c->d_cand, &c->cand_slots, rows_blk * cand_slots, sizeof(int64_t), "Failed to allocate batch candidates");
     if (rc != WAX_HIP_OK) return rc;
     if (c->kp_cap < kp) {
         (void)hipFree(c->d_exact); (void)hipFree(c->d_sel);
@@ -882,7 +884,7 @@ struct OnepassPlan {
 // the median of their minimum solves F_t^L = a_G := 1 - 2^(-1/G). Wanting a fraction p = target / n of all rows above
 // tau means F_t = (1 - p)^tile_rows, hence L = ln a_G / ln F_t. Small G keeps the sample (S = G L tiles) small for big
 // stores; large G is what reaches the loose thresholds a small store / a large k' needs.
-bool plan_onepass(wax_hip_engine* e, uint32_t n, int k_eff, OnepassPlan* p) {
+bool plan_onepass(wax_hip_engine* e, uint32_t n, int k_eff, uint32_t nq, OnepassPlan* p) {
     if (e->batch_onepass.load() == 0 || !batch_onepass_dims(e->dims, e->metric) || k_eff > kBatchMaxK) return false;
     p->tile_rows = batch_tile_rows(e->dims);
     p->ntiles = (n + p->tile_rows - 1) / p->tile_rows;
@@ -914,9 +916,22 @@ bool plan_onepass(wax_hip_engine* e, uint32_t n, int k_eff, OnepassPlan* p) {
     const double p_real = 1.0 - std::pow(ft, 1.0 / (double)p->tile_rows);
     p->expect = p_real * (double)n;
     if (p->expect < 2.0 * (double)p->kp) return false;   // cannot reach enough candidates for the certificate: other paths
-    uint64_t area = kBatchSegArea;
-    while ((double)area < 4.0 * p->expect) area *= 2;     // mean segment fill <= 1/4: an overflowing segment is a ~1e-9 event
-    if (area > 65536) return false;
+    // Survivor segments: one per (GEMM workgroup of the query's group, query). The survivor count of a query spreads
+    // widely around `expect` (measured at 1M x 384, G = 4: median 583, 56 .. 1828 over 256 queries — the threshold is the
+    // minimum of a few maxima), and a segment overflows when ITS fill does: size every segment for 8 x expect spread
+    // over the group's workgroups, + 6 sigma of a Poisson fill (an overflow only costs that query the exact path, but at
+    // 0.25 ms each two of them per batch doubled the batch time: profiles/r02/c_onepass_diag.txt).
+    const uint32_t nq_blk = nq < kBatchMaxQ ? nq : kBatchMaxQ;
+    const uint32_t nq_pad = (nq_blk + 255u) & ~255u;
+    const uint32_t groups = e->dims == 768 ? nq_pad / 128 : nq_pad / 256;
+    uint32_t nseg = 256 / (groups ? groups : 1);
+    if (nseg < 1) nseg = 1;
+    if (nseg > p->ntiles) nseg = p->ntiles;
+    const double fill = 8.0 * p->expect / (double)nseg;
+    uint64_t slots = 16;
+    while ((double)slots < fill + 6.0 * std::sqrt(fill) + 4.0) slots *= 2;
+    const uint64_t area = slots * nseg;
+    if (area > 262144) return false;
     p->seg_area = (uint32_t)area;
     return true;
 }
@@ -1014,9 +1029,9 @@ int batch_enqueue(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32
 }
 
 // Can the MFMA pipelines answer (nq queries, k_eff) on this engine at all?
-bool batch_mfma_applicable(wax_hip_engine* e, uint32_t dims, int k_eff, OnepassPlan* plan, bool* onepass) {
+bool batch_mfma_applicable(wax_hip_engine* e, uint32_t dims, int k_eff, uint32_t nq, OnepassPlan* plan, bool* onepass) {
     if (e->batch_mode.load() == 0 || dims != e->dims || (dims % 64u) != 0 || e->count == 0 || k_eff <= 0) return false;
-    *onepass = plan_onepass(e, (uint32_t)e->count, k_eff, plan);
+    *onepass = plan_onepass(e, (uint32_t)e->count, k_eff, nq, plan);
     return *onepass || k_eff <= kBatchMaxKSlab;
 }
 
@@ -1575,7 +1590,7 @@ static int search_batch_hits_impl(wax_hip_engine* e, const float* queries, uint3
             if (k64 > stride) k64 = stride;                       // a smaller result array: the best `stride` of them
             OnepassPlan plan{};
             bool onepass = false;
-            if (batch_mfma_applicable(e, dims, (int)k64, &plan, &onepass)) {
+            if (batch_mfma_applicable(e, dims, (int)k64, nq, &plan, &onepass)) {
                 const int k_eff = (int)k64;
                 BatchCtx* c = nullptr;
                 brc = acquire_bctx(e, &c);
@@ -1703,7 +1718,7 @@ int wax_hip_search_batch_hits_device(wax_hip_engine* e, const float* d_queries, 
     }
     OnepassPlan plan{};
     bool onepass = false;
-    bool use_mfma = (int64_t)nq >= e->batch_min.load() && batch_mfma_applicable(e, dims, k_eff, &plan, &onepass);
+    bool use_mfma = (int64_t)nq >= e->batch_min.load() && batch_mfma_applicable(e, dims, k_eff, nq, &plan, &onepass);
     if (use_mfma && nq < 16) {   // same cost model as the host-pointer form
         const double elems = (double)e->count * (double)dims;
         const double t_loop = (double)nq * (elems * 4.0 / 6.9e12 + 25e-6);
