@@ -1465,7 +1465,8 @@ def test_batch_onepass_adversarial_corpora(wax):
         eng.setTuning("batch_sample_div", div)
         before1 = eng.getTuning("onepass_queries")
         _batch_vs_single(eng, queries, 30)
-        assert eng.getTuning("onepass_queries") - before1 == 64
+        # (a target below 2 k' survivors is declined by the planner: that batch takes the slab pipeline)
+        assert eng.getTuning("onepass_queries") - before1 == (64 if survivors >= 4 else 0), (survivors, div)
     eng.close()
 
 

@@ -144,7 +144,7 @@ PYEOF
     w4ablate)
       # ablation of batch_gemm_w4_kernel by debug bits (1 no DMA after the prologue, 2 no MFMA work, 4 no tile barrier, 8 no selection)
       (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d "$OUT/prof_w4a" -o w4a -- \
-          python "$R/tools/batch_bench.py" --nq ${WAX_NQ:-256} --reps 2 --rega 3 --debug 0 8 1 9 2 3 4 12 0 > "$OUT/w4ablate.log" 2>&1); rc=$?
+          python "$R/tools/batch_bench.py" --nq ${WAX_NQ:-256} --reps 2 --rega 3 --debug ${WAX_DEBUGS:-0 8 1 9 2 3 4 12 0} > "$OUT/w4ablate.log" 2>&1); rc=$?
       f=$(find "$OUT/prof_w4a" -name "*kernel_trace.csv" | head -1)
       [ -n "$f" ] && python "$R/tools/trace_durations.py" "$f" w4_kernel > "$OUT/w4ablate_durations.txt" 2>/dev/null
       find "$OUT/prof_w4a" -name "*kernel_trace.csv" -delete 2>/dev/null ;;

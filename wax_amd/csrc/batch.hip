@@ -904,7 +904,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_ksplit_kernel(GemmArgs a, u
 // the selection. Survivor segments, thresholds and the exact test are those of batch_gemm_rega_kernel, so the host
 // side and batch_finish_kernel do not know which of the two ran. A query whose threshold is not finite (no usable
 // sample) is marked as overflowed (count 2^30) and answered by the exact path.
-template <int D>
+template <int D, int AH = 3>
 struct W4Geom {
     static constexpr int KS = D / 16;                                   // MFMA k-steps
     static constexpr int ROW_B = D * 2 + 16;                            // LDS row stride (bytes): conflict-free ds_read_b128
@@ -914,68 +914,75 @@ struct W4Geom {
     static constexpr int NBUF_RAW = (160 * 1024 - 3 * 256 * 4) / BUF_B;
     static constexpr int NBUF = NBUF_RAW > 8 ? 8 : NBUF_RAW;
     static constexpr int PRE = NBUF - 2;                                // tiles requested ahead of the one being read
-    static constexpr size_t SMEM = (size_t)NBUF * BUF_B + 3 * 256 * 4;
-    static constexpr int AHEAD = 3, RING = AHEAD + 1;                   // B-fragment read-ahead (k-steps)
+    static constexpr size_t SMEM = (size_t)NBUF * BUF_B + 256 * 4;
+    static constexpr int AHEAD = AH, RING = AHEAD + 1;                  // B-fragment read-ahead (k-steps)
     static constexpr int UNITS = 8;                                     // selection units per tile: 2 accumulators x 4 quads
     static_assert(NBUF >= 4, "need at least two tiles in flight");
 };
 
 // Per-wave state of batch_gemm_w4_kernel shared by its (compile-time unrolled) helper functions. Everything is
 // loop-invariant; after inlining it lives in registers.
-template <int D>
+template <int D, int AH>
 struct W4Ctx {
-    bf16x8 fa0[W4Geom<D>::KS], fa1[W4Geom<D>::KS];     // A fragments of the wave's two query sets
+    bf16x8 fa0[W4Geom<D, AH>::KS], fa1[W4Geom<D, AH>::KS];     // A fragments of the wave's two query sets
     int64_t* cand;
     uint32_t cand_cap, row_base, slab0, slab_end, seg_slots, seg_w0;
     f32x16 nl0, nl1;             // accumulator start values: -(conservative similarity bound) of the register's query, per set
     uint32_t debug;              // timing experiments (GemmArgs::debug)
-    const lds_f32* tau_w;        // this wave's 64 exact thresholds
-    const lds_f32* neg_w;        // this wave's 64 -(conservative similarity bounds)
-    lds_u32* cnt_w;              // this wave's 64 survivor counters
+    int cnt_v;                   // lane l: survivors of the wave's query l so far (this workgroup's segment fill)
     int lane;
 };
 
 // One quad of accumulators of a finished tile: a clear sign bit => some (query, row) reached its threshold.
-// Hot part: 3 integer ANDs, one compare, one branch. Cold part (one copy per unit): the lane's hits are taken one at a
-// time (lowest register first), so the exact test / slot / store code exists once per unit, not once per register.
-template <int D, int U>
-__device__ __forceinline__ void w4_select_unit(const W4Ctx<D>& c, const f32x16 (&P)[2], uint32_t tile) {
+// Hot part: 3 integer ANDs, one compare, one branch. Cold part (one copy per unit; ~1 visit per wave and tile): with one
+// wave per SIMD nothing hides a memory round trip, so it makes none: admission is the sign test itself (the conservative
+// bound: a superset of "d <= tau"; every row it rejects has d > tau, which is what the certificate needs), the start
+// value comes from the registers, and the slot in the query's segment comes from a per-wave counter kept in a VGPR
+// (lane l = the wave's query l; only this wave ever appends to its 64 queries' segments of this workgroup), advanced
+// with readlane + lane-compare adds in a scalar loop over the hit lanes. The only memory operation is the 8-byte store.
+template <int D, int AH, int U>
+__device__ __forceinline__ void w4_select_unit(W4Ctx<D, AH>& c, const f32x16 (&P)[2], uint32_t tile) {
     constexpr int set = U >> 2, qd = U & 3;
     const float v0 = P[set][4 * qd], v1 = P[set][4 * qd + 1], v2 = P[set][4 * qd + 2], v3 = P[set][4 * qd + 3];
     const int all_neg = __float_as_int(v0) & __float_as_int(v1) & __float_as_int(v2) & __float_as_int(v3);
     if (__ballot(all_neg >= 0) == 0ull) return;           // every sign bit set: nothing reached its threshold
+    if (c.debug & 16u) return;                            // timing experiments: hot test only
+    const uint32_t row = c.slab0 + tile * (uint32_t)W4Geom<D, AH>::TROWS + (uint32_t)(c.lane & 31);
     unsigned hits = (v0 >= 0.0f ? 1u : 0u) | (v1 >= 0.0f ? 2u : 0u) | (v2 >= 0.0f ? 4u : 0u) | (v3 >= 0.0f ? 8u : 0u);   // NaN fails
-    const uint32_t row = c.slab0 + tile * (uint32_t)W4Geom<D>::TROWS + (uint32_t)(c.lane & 31);
-    const bool ok = row < c.slab_end;
-    // register 4 qd + j of set s belongs to query 32 s + j + 8 qd + 4 (lane >> 5)
+    hits = row < c.slab_end ? hits : 0u;                  // rows past the slab (clamped / slack rows of the last tile)
+    const f32x16& nl = set ? c.nl1 : c.nl0;
+    const float n0 = nl[4 * qd], n1 = nl[4 * qd + 1], n2 = nl[4 * qd + 2], n3 = nl[4 * qd + 3];
+    // register 4 qd + j of set s belongs to the wave's query 32 s + j + 8 qd + 4 (lane >> 5)
     const uint32_t qq0 = 32u * (uint32_t)set + 8u * (uint32_t)qd + 4u * ((uint32_t)c.lane >> 5);
-    while (__ballot(hits != 0u) != 0ull) {
-        if (hits != 0u) {
-            const unsigned j = (unsigned)__builtin_ctz(hits);
-            hits &= hits - 1u;
-            const float v = j == 0u ? v0 : (j == 1u ? v1 : (j == 2u ? v2 : v3));
-            const uint32_t qq = qq0 + j;
-            const float tq = c.tau_w[qq];
-            const float d = (1.0f - (v - c.neg_w[qq])) + 0.0f;   // v = sim - sim_lo, neg = -sim_lo
-            if (ok && d <= tq) {
-                // opaque to hipcc on purpose: before an LDS write it can see, the compiler drains every outstanding
-                // LDS-DMA request (s_waitcnt vmcnt(0)), undoing the prefetch
-                unsigned off;
-                asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
-                             : "=v"(off)
-                             : "v"((unsigned)(size_t)(c.cnt_w + qq)), "v"(1u)
-                             : "memory");
-                if (off < c.seg_slots) c.cand[c.seg_w0 + qq * c.cand_cap + off] = make_key(d, c.row_base + row);
-            }
-        }
+    for (;;) {
+        const bool has = hits != 0u;
+        unsigned long long todo = __ballot(has);
+        if (todo == 0ull) break;
+        const unsigned j = has ? (unsigned)__builtin_ctz(hits) : 0u;   // the lane's lowest pending register
+        hits &= hits - 1u;
+        const float v = j == 0u ? v0 : (j == 1u ? v1 : (j == 2u ? v2 : v3));
+        const float ng = j == 0u ? n0 : (j == 1u ? n1 : (j == 2u ? n2 : n3));
+        const int qq = (int)(qq0 + j);
+        const float d = (1.0f - (v - ng)) + 0.0f;           // v = sim - sim_lo, ng = -sim_lo
+        int slot = 0;
+        do {                                                // scalar loop over the hit lanes (usually one)
+            const int L = (int)__builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const int qL = __builtin_amdgcn_readlane(qq, L);
+            const int cL = __builtin_amdgcn_readlane(c.cnt_v, qL);
+            c.cnt_v += (c.lane == qL) ? 1 : 0;              // (no v_writelane builtin in this toolchain: compare + add)
+            slot = (c.lane == L) ? cL : slot;
+        } while (todo != 0ull);
+        if (has && (uint32_t)slot < c.seg_slots && !(c.debug & 32u))   // debug bit5: no survivor store
+            c.cand[c.seg_w0 + (uint32_t)qq * c.cand_cap + (uint32_t)slot] = make_key(d, c.row_base + row);
     }
 }
 
-template <int D, int U0, int U1>
-__device__ __forceinline__ void w4_select_units(const W4Ctx<D>& c, const f32x16 (&P)[2], uint32_t tile) {
+template <int D, int AH, int U0, int U1>
+__device__ __forceinline__ void w4_select_units(W4Ctx<D, AH>& c, const f32x16 (&P)[2], uint32_t tile) {
     if constexpr (U0 < U1) {
-        w4_select_unit<D, U0>(c, P, tile);
-        w4_select_units<D, U0 + 1, U1>(c, P, tile);
+        w4_select_unit<D, AH, U0>(c, P, tile);
+        w4_select_units<D, AH, U0 + 1, U1>(c, P, tile);
     }
 }
 
@@ -985,10 +992,10 @@ __device__ __forceinline__ void w4_select_units(const W4Ctx<D>& c, const f32x16 
 // `s_waitcnt lgkmcnt(0)` in front of every MFMA pair (one exposed LDS round trip per k-step). LDS operations return
 // in order, so "at most N younger operations outstanding" implies that read KSI has landed whatever else (the cold
 // path's reads, scalar loads) is in the queue: extra operations only make a counted wait stricter.
-template <int D, int KSI>
-__device__ __forceinline__ void w4_ksteps(const W4Ctx<D>& c, f32x16 (&cur)[2], const f32x16 (&prev)[2], uint32_t prev_tile,
-                                          uint32_t baddr, u32x4 (&fb)[W4Geom<D>::RING]) {
-    using G = W4Geom<D>;
+template <int D, int AH, int KSI>
+__device__ __forceinline__ void w4_ksteps(W4Ctx<D, AH>& c, f32x16 (&cur)[2], const f32x16 (&prev)[2], uint32_t prev_tile,
+                                          uint32_t baddr, u32x4 (&fb)[W4Geom<D, AH>::RING]) {
+    using G = W4Geom<D, AH>;
     if constexpr (KSI < G::KS) {
         if constexpr (KSI + G::AHEAD < G::KS)
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[(KSI + G::AHEAD) % G::RING]) : "v"(baddr), "n"((KSI + G::AHEAD) * 32));
@@ -1006,42 +1013,40 @@ __device__ __forceinline__ void w4_ksteps(const W4Ctx<D>& c, f32x16 (&cur)[2], c
         // selection units spread evenly over the k-steps: unit u runs after k-step floor(u * KS / UNITS)
         constexpr int u0 = (KSI * G::UNITS + G::KS - 1) / G::KS;            // first u with floor(u KS / UNITS) >= KSI
         constexpr int u1 = ((KSI + 1) * G::UNITS + G::KS - 1) / G::KS;      // first u with floor(u KS / UNITS) >= KSI + 1
-        if (!(c.debug & 8u)) w4_select_units<D, u0, (u1 < G::UNITS ? u1 : G::UNITS)>(c, prev, prev_tile);   // debug bit3: no selection
+        if (!(c.debug & 8u)) w4_select_units<D, AH, u0, (u1 < G::UNITS ? u1 : G::UNITS)>(c, prev, prev_tile);   // debug bit3: no selection
         __builtin_amdgcn_sched_barrier(0);
-        w4_ksteps<D, KSI + 1>(c, cur, prev, prev_tile, baddr, fb);
+        w4_ksteps<D, AH, KSI + 1>(c, cur, prev, prev_tile, baddr, fb);
     }
 }
 
-template <int D, int I>
-__device__ __forceinline__ void w4_prefetch_b(uint32_t baddr, u32x4 (&fb)[W4Geom<D>::RING]) {
-    using G = W4Geom<D>;
+template <int D, int AH, int I>
+__device__ __forceinline__ void w4_prefetch_b(uint32_t baddr, u32x4 (&fb)[W4Geom<D, AH>::RING]) {
+    using G = W4Geom<D, AH>;
     if constexpr (I < G::AHEAD && I < G::KS) {
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[I]) : "v"(baddr), "n"(I * 32));
-        w4_prefetch_b<D, I + 1>(baddr, fb);
+        w4_prefetch_b<D, AH, I + 1>(baddr, fb);
     }
 }
 
 // MFMAs of one tile into `cur`, with the selection of the PREVIOUS tile (`prev`) interleaved between the k-steps.
-template <int D>
-__device__ __forceinline__ void w4_tile_step(const W4Ctx<D>& c, f32x16 (&cur)[2], const f32x16 (&prev)[2], uint32_t prev_tile,
+template <int D, int AH>
+__device__ __forceinline__ void w4_tile_step(W4Ctx<D, AH>& c, f32x16 (&cur)[2], const f32x16 (&prev)[2], uint32_t prev_tile,
                                              uint32_t baddr) {
-    u32x4 fb[W4Geom<D>::RING];
-    w4_prefetch_b<D, 0>(baddr, fb);
+    u32x4 fb[W4Geom<D, AH>::RING];
+    w4_prefetch_b<D, AH, 0>(baddr, fb);
     __builtin_amdgcn_sched_barrier(0);
-    w4_ksteps<D, 0>(c, cur, prev, prev_tile, baddr, fb);
+    w4_ksteps<D, AH, 0>(c, cur, prev, prev_tile, baddr, fb);
 }
 
-template <int D>
+template <int D, int AH>
 __global__ __launch_bounds__(256, 1) void batch_gemm_w4_kernel(GemmArgs a, uint32_t blocks_per_group) {
-    using G = W4Geom<D>;
+    using G = W4Geom<D, AH>;
     constexpr int KS = G::KS;
     constexpr int ROW_B = G::ROW_B, TROWS = G::TROWS, PIECES = G::PIECES, BUF_B = G::BUF_B, NBUF = G::NBUF, PRE = G::PRE;
     constexpr int SPR = ROW_B / 16;                  // 16-byte slots per padded row
     constexpr int PPW = (PIECES + 3) / 4;            // pieces per wave (waves with index >= PIECES % 4 carry one less, if PIECES % 4)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* tau_s = reinterpret_cast<float*>(smem + NBUF * BUF_B);          // [256] exact thresholds
-    unsigned int* cnt_s = reinterpret_cast<unsigned int*>(tau_s + 256);    // [256] survivors per query (this workgroup)
-    float* neg_s = reinterpret_cast<float*>(cnt_s + 256);                  // [256] -(conservative similarity bound)
+    float* neg_s = reinterpret_cast<float*>(smem + NBUF * BUF_B);          // [256] -(conservative similarity bound) (set-up only)
 
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
@@ -1050,7 +1055,7 @@ __global__ __launch_bounds__(256, 1) void batch_gemm_w4_kernel(GemmArgs a, uint3
     const uint32_t bidx = blockIdx.x % blocks_per_group;
     const uint32_t q0 = group * 256 + wave * 64;              // this wave's 64 queries
 
-    W4Ctx<D> c;
+    W4Ctx<D, AH> c;
     // A fragments: set s, lane l holds query 32 s + (l & 31), k = 16 ks + 8 (l >> 5) .. +7
     {
         const u32x4* qp0 = reinterpret_cast<const u32x4*>(a.qb + (size_t)(q0 + (lane & 31)) * D) + (lane >> 5);
@@ -1064,8 +1069,7 @@ __global__ __launch_bounds__(256, 1) void batch_gemm_w4_kernel(GemmArgs a, uint3
     {
         const float tq = a.tau[q0 + lane];
         const bool usable = (tq == tq) && (tq < __builtin_inff());        // -inf (padding query) is usable: it admits nothing
-        tau_s[wave * 64 + lane] = tq;
-        cnt_s[wave * 64 + lane] = usable ? 0u : 0x40000000u;
+        c.cnt_v = usable ? 0 : 0x40000000;                                 // lane l counts the wave's query l
         // fl(1 - sim) <= tq implies sim >= (1 - tq) - 2^-23 (|1 - tq| + |tq|); 4e-7 (1 + |tq|) covers it and the rounding of
         // (acc + sim_lo) with slack. tq = -inf gives NaN: nothing is flagged.
         const float sim_lo = (1.0f - tq) - 4e-7f * (1.0f + __builtin_fabsf(tq));
@@ -1076,9 +1080,6 @@ __global__ __launch_bounds__(256, 1) void batch_gemm_w4_kernel(GemmArgs a, uint3
     c.slab_end = a.slab0 + a.slab_rows;
     c.seg_slots = a.seg_area / blocks_per_group;
     c.seg_w0 = q0 * a.cand_cap + a.seg_base + bidx * c.seg_slots;   // element offset of the wave's first query row, this workgroup's segment
-    c.tau_w = (const lds_f32*)(tau_s + wave * 64);
-    c.neg_w = (const lds_f32*)(neg_s + wave * 64);
-    c.cnt_w = (lds_u32*)(cnt_s + wave * 64);
     c.lane = lane;
     c.debug = a.debug;
     // the lane's 32 accumulator start values: register r of set s belongs to query 32 s + (r&3) + 8 (r>>2) + 4 (lane>>5)
@@ -1163,8 +1164,8 @@ __global__ __launch_bounds__(256, 1) void batch_gemm_w4_kernel(GemmArgs a, uint3
             if (issued) dma_tile(tp, pre_idx);
             const uint32_t baddr = smem_lds + cur_idx * (uint32_t)BUF_B + lane_boff;
             if (!dbg_nomfma) {
-                if (par == 0) w4_tile_step<D>(c, accA, accB, t - blocks_per_group, baddr);   // first iteration: accB is all -1, its tile index is never used
-                else w4_tile_step<D>(c, accB, accA, t - blocks_per_group, baddr);
+                if (par == 0) w4_tile_step<D, AH>(c, accA, accB, t - blocks_per_group, baddr);   // first iteration: accB is all -1, its tile index is never used
+                else w4_tile_step<D, AH>(c, accB, accA, t - blocks_per_group, baddr);
             }
             // tile t + 1 must have landed (every wave waits for its own pieces, the barrier joins them); the younger
             // requests stay in flight across the barrier
@@ -1174,8 +1175,8 @@ __global__ __launch_bounds__(256, 1) void batch_gemm_w4_kernel(GemmArgs a, uint3
             cur_idx = cur_idx + 1 == (uint32_t)NBUF ? 0u : cur_idx + 1;
             const uint32_t tn = t + blocks_per_group;
             if (tn >= ntiles) {
-                if (par == 0) w4_select_units<D, 0, G::UNITS>(c, accA, t);
-                else w4_select_units<D, 0, G::UNITS>(c, accB, t);
+                if (par == 0) w4_select_units<D, AH, 0, G::UNITS>(c, accA, t);
+                else w4_select_units<D, AH, 0, G::UNITS>(c, accB, t);
                 t = tn;
                 break;
             }
@@ -1183,28 +1184,33 @@ __global__ __launch_bounds__(256, 1) void batch_gemm_w4_kernel(GemmArgs a, uint3
         }
     }
     // unclamped counts: a count above seg_slots tells the consumer that survivors were dropped (query -> exact path)
-    __syncthreads();
-    a.seg_count[(size_t)bidx * (a.nqt * 128u) + group * 256u + (uint32_t)tid] = cnt_s[tid];
+    a.seg_count[(size_t)bidx * (a.nqt * 128u) + q0 + (uint32_t)lane] = (uint32_t)c.cnt_v;
 }
 
 static void rega_geometry(const GemmArgs& a, uint32_t* groups, uint32_t* per_group);
 static bool w4_dims(uint32_t dims) { return dims == 128 || dims == 256 || dims == 384 || dims == 512; }
 uint32_t batch_w4_slack_rows() { return 64; }   // rows the w4 kernel's last DMA piece may read past the end of the store
 
-template <int D>
-static hipError_t launch_w4(const GemmArgs& a, hipStream_t st) {
-    constexpr size_t smem = W4Geom<D>::SMEM;
+template <int D, int AH>
+static hipError_t launch_w4_ah(const GemmArgs& a, hipStream_t st) {
+    constexpr size_t smem = W4Geom<D, AH>::SMEM;
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&batch_gemm_w4_kernel<D>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&batch_gemm_w4_kernel<D, AH>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
         configured = true;
     }
     uint32_t groups, pg;
     rega_geometry(a, &groups, &pg);          // the same workgroups-per-group (= survivor segments) as batch_gemm_rega_kernel
-    hipLaunchKernelGGL((batch_gemm_w4_kernel<D>), dim3(groups * pg), dim3(256), smem, st, a, pg);
+    hipLaunchKernelGGL((batch_gemm_w4_kernel<D, AH>), dim3(groups * pg), dim3(256), smem, st, a, pg);
     return hipGetLastError();
+}
+
+template <int D>
+static hipError_t launch_w4(const GemmArgs& a, hipStream_t st) {
+    // read-ahead 3 and 6 k-steps measure the same (profiles/r02/i_w4_ahead.txt): the kernel is issue-bound, not LDS-latency-bound
+    return launch_w4_ah<D, 3>(a, st);
 }
 
 // D = 1024 would need 2 x 66 KB of tiles + 32 KB of partial sums (> 160 KB of LDS): it stays on the LDS-tiled kernel.
@@ -1976,7 +1982,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void batch_finish_kernel(FinishArgs a
         if (!any_dropped && a.overflow[q] == 0u && m >= k) {
             // every row outside the candidate set has an approximate distance >= a_max: the kp-th best approximate
             // distance when the list is full, else the admission threshold itself (everything below it is a candidate)
-            const float a_max = (total >= kp) ? key_distance(fin[kp - 1]) : a.tau[q];
+            // (the one-wave-per-SIMD GEMM admits on the conservative bound, i.e. slightly past tau: rows it rejected have
+            // d > tau, rows beyond the kp-th candidate have d >= that candidate's)
+            const float a_max = (total >= kp) ? __builtin_fminf(key_distance(fin[kp - 1]), a.tau[q]) : a.tau[q];
             const float kth = key_distance(sorted[k - 1]);
             ok = (a_max - a.eps[q] > kth) ? 1u : 0u;        // strict: ties stay uncertified
         }
@@ -2038,7 +2046,7 @@ __global__ __launch_bounds__(1024) void finalize_big_kernel(FinishArgs a) {
         const int64_t kth_key = sorted[k - 1];
         if (a.overflow[q] == 0u && kth_key != KEY_PAD) {
             const int64_t last = a.sel[(size_t)q * kp + (kp - 1)];
-            const float a_max = (last != KEY_PAD) ? key_distance(last) : a.tau[q];
+            const float a_max = (last != KEY_PAD) ? __builtin_fminf(key_distance(last), a.tau[q]) : a.tau[q];
             ok = (a_max - a.eps[q] > key_distance(kth_key)) ? 1u : 0u;
         }
         a.certified[q] = ok;
