@@ -115,6 +115,22 @@ const char* wax_hip_last_error(void);
  * backend also implements dot and l2 with USearch's distance conventions,
  * VectorMetric.swift:21-43). device_id: HIP ordinal, -1 = current device. */
 int wax_hip_engine_create(uint8_t metric, uint32_t dims, int device_id, wax_hip_engine** out);
+/* The same engine over several GPUs of one node, in ONE process (the reference has no multi-device path):
+ * the handle owns one single-device engine ("shard") per listed HIP ordinal (duplicates allowed: two shards on one GPU, for
+ * tests). Rows are kept in contiguous blocks — shard g holds global rows [base_g, base_g + count_g), base_g = the rows before
+ * it — so the concatenation of the shards is the insertion order of ONE engine: every entry point of this header that takes
+ * a handle works on it with identical results (same tie rule, same serialize bytes). A shard is full at ceil(N / n_devices)
+ * rows after wax_hip_reserve(N) (or the first batch); when every shard is full the block size doubles (peer-copy rebalance).
+ * search: per shard on its own stream, query upload + fused scan + per-shard top-k, then the k hits (16 k bytes per shard)
+ * are peer-copied to the first device and merged there by key (tuning "exchange" = 1: one ncclAllGather per query on a
+ * single-process RCCL communicator instead). Batched search: every shard answers the batch on its rows from its own host
+ * thread, the first device merges per query. An unavailable ordinal fails with WAX_HIP_ERR_NO_DEVICE.
+ * Single-device-only entry points (wax_hip_set_row_base, wax_hip_search_shard_device, wax_hip_search_batch_hits_device, the
+ * two wax_hip_time_* probes) return WAX_HIP_ERR_INVALID_ARGUMENT on such a handle. */
+int wax_hip_engine_create_sharded(uint8_t metric, uint32_t dims, const int* device_ids, int n_devices, wax_hip_engine** out);
+/* 1 for a single-device engine; shard -> (device ordinal, first global row, rows). */
+int wax_hip_shard_count(const wax_hip_engine* e);
+int wax_hip_shard_info(const wax_hip_engine* e, int shard, int* out_device, uint64_t* out_row_base, uint64_t* out_rows);
 void wax_hip_engine_destroy(wax_hip_engine* e);
 
 /* VectorSearchEngine.dimensions (VectorSearchEngine.swift:11) */
@@ -269,7 +285,9 @@ int wax_hip_stats(wax_hip_engine* e, wax_hip_stats_t* out);
  * "batch_slab_mb", "batch_growth", "batch_first" (slab schedule of the slab pipeline), "batch_rega" (0 LDS-tiled GEMM
  * only, 1 register-resident GEMM with register staging, 2 with LDS-DMA staging), "batch_debug" (timing experiments:
  * results are NOT valid with bits 1/2/4/8 set). get-only: "variant_count", "scan_grid", "fused_max_k", "batch_queries",
- * "batch_fallbacks", "onepass_queries", "batch_max_k". */
+ * "batch_fallbacks", "onepass_queries", "batch_max_k". Sharded handles: every key above is forwarded to all shards; plus
+ * "exchange" (0 peer copies + merge on the first device, 1 RCCL all-gather per query) and the get-only "shards", "block_rows",
+ * "rebalances", "rccl_collectives". */
 int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value);
 int64_t wax_hip_get_tuning(wax_hip_engine* e, const char* key);
 /* Times `iters` back-to-back launches of ONLY the scan kernel for `query`

@@ -286,3 +286,16 @@ def test_cpp_wrapper_on_gpu(hip_lib, tmp_path):
     if hip_lib.wax_hip_device_count() == 0:
         pytest.skip("no HIP device on this host")
     assert "hpp ok" in _run_hpp_consumer(tmp_path)
+
+
+def test_sharded_create_validates_the_device_list(hip_lib):
+    """wax_hip_engine_create_sharded fails loudly for an unavailable ordinal or an empty list (no GPU needed to see it)."""
+    from wax_amd import _abi
+    h = ctypes.c_void_p()
+    n = hip_lib.wax_hip_device_count()
+    devs = (ctypes.c_int * 2)(0, n + 7)
+    assert hip_lib.wax_hip_engine_create_sharded(0, 384, devs, 2, ctypes.byref(h)) == _abi.ERR_NO_DEVICE
+    assert f"HIP device {n + 7 if n else 0} not available" in _abi.last_error() and not h.value
+    assert hip_lib.wax_hip_engine_create_sharded(0, 384, devs, 0, ctypes.byref(h)) == _abi.ERR_INVALID_ARGUMENT
+    assert hip_lib.wax_hip_engine_create_sharded(0, 384, None, 2, ctypes.byref(h)) == _abi.ERR_INVALID_ARGUMENT
+    assert hip_lib.wax_hip_shard_count(None) == 0

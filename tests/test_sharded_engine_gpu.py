@@ -1,0 +1,258 @@
+"""The in-library multi-GPU engine (wax_hip_engine_create_sharded) against ONE single-device engine on the same
+operations: identical results at every shard count — ids, scores, tie order, serialize bytes. On the 1-GPU test box the
+shards share GPU 0 (duplicate ordinals are allowed for exactly this); everything except the xGMI hop itself is the code
+an 8-GPU host runs: block layout, global-row keys, per-shard streams, peer-copy gather, device merge, rebalancing."""
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+import oracle
+from helpers import assert_parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def wax(hip_lib):
+    import wax_amd
+    if hip_lib.wax_hip_device_count() == 0:
+        pytest.skip("no HIP device on this host: the gpu-marked tests run on the MI355X box (pytest -m gpu)")
+    assert hip_lib.wax_hip_available() == 1
+    return wax_amd
+
+
+def pair(wax, metric, dims, shards):
+    one = wax.HIPVectorEngine(metric=wax.VectorMetric(metric), dimensions=dims)
+    many = wax.HIPVectorEngine(metric=wax.VectorMetric(metric), dimensions=dims, devices=[0] * shards)
+    assert many.shardCount == shards and one.shardCount == 1
+    return one, many
+
+
+def same_search(one, many, q, k):
+    a, b = one.searchArrays(q, k), many.searchArrays(q, k)
+    assert np.array_equal(a[0], b[0]), (k, a[0][:8], b[0][:8])
+    assert np.array_equal(a[1], b[1]), k
+
+
+@pytest.mark.parametrize("shards", [1, 2, 3])
+@pytest.mark.parametrize("metric,dims", [(0, 384), (1, 100), (2, 64)])
+def test_sharded_engine_equals_single_engine(wax, shards, metric, dims):
+    rng = np.random.default_rng(100 * shards + dims)
+    one, many = pair(wax, metric, dims, shards)
+    n = 30_000
+    corpus = oracle.gaussian_unit_rows(5, n, dims) * (np.float32(1.0) if metric == 0 else rng.uniform(0.5, 1.5, (n, 1)).astype(np.float32))
+    ids = rng.permutation(n).astype(np.uint64) * 7 + 3
+    for eng in (one, many):
+        eng.reserve(n)
+        eng.addBatch(ids[:20_000], corpus[:20_000])
+    if shards > 1:
+        info = [many.shardInfo(g) for g in range(shards)]
+        assert [i[1] for i in info] == list(np.cumsum([0] + [i[2] for i in info[:-1]]))      # bases are prefix sums
+        assert info[0][2] == -(-n // shards + 63) // 64 * 64 or info[0][2] == ((n + shards - 1) // shards + 63) // 64 * 64
+    queries = oracle.gaussian_unit_queries(12, dims, seed=shards)
+    for q in queries[:4]:
+        for k in (1, 10, 192, 193, 1000):
+            same_search(one, many, q, k)
+    # mutations: single adds (staged appends), upserts of existing ids (any shard), a batch with repeated and existing ids,
+    # removals from every shard, then the rest of the corpus
+    for eng in (one, many):
+        for i in range(20_000, 20_050):
+            eng.add(int(ids[i]), corpus[i])
+        eng.add(int(ids[17]), corpus[25_000])                       # upsert, first shard
+        eng.add(int(ids[19_990]), corpus[25_001])                   # upsert, last occupied shard
+        mix_ids = np.concatenate([ids[20_050:20_060], ids[5:7], ids[20_050:20_052]])
+        mix_rows = np.concatenate([corpus[20_050:20_060], corpus[26_000:26_002], corpus[26_002:26_004]])
+        eng.addBatch(mix_ids, mix_rows)
+        for i in (0, 9_999, 10_000, 19_999, 20_055):
+            eng.remove(int(ids[i]))
+        eng.remove(123456789012)                                     # absent id: no-op
+        eng.addBatch(ids[20_060:], corpus[20_060:])
+    assert one.count == many.count
+    for q in queries[4:8]:
+        for k in (10, 300):
+            same_search(one, many, q, k)
+    assert one.serialize() == many.serialize()                       # byte-identical MV2V segment: same rows, same order
+    # batched search (MFMA path inside every shard; merged per query on the first device)
+    b1, b2 = one.searchBatch(queries, 10), many.searchBatch(queries, 10)
+    assert np.array_equal(b1[0], b2[0]) and np.array_equal(b1[1], b2[1]) and np.array_equal(b1[2], b2[2])
+    h1, h2 = one.searchBatchHits(queries, 25), many.searchBatchHits(queries, 25)
+    assert np.array_equal(h1[0], h2[0])                              # keys carry the same GLOBAL rows
+    # filtered search: allow-list spanning the shards, minScore
+    allow = rng.choice(ids, 500, replace=False)
+    for q in queries[8:10]:
+        f1, f2 = one.searchFiltered(q, 20, frameIds=allow), many.searchFiltered(q, 20, frameIds=allow)
+        assert np.array_equal(f1[0], f2[0]) and np.array_equal(f1[1], f2[1])
+        f1, f2 = one.searchFiltered(q, 20, minScore=0.1), many.searchFiltered(q, 20, minScore=0.1)
+        assert np.array_equal(f1[0], f2[0])
+    # round trip through a fresh sharded engine
+    blob = many.serialize()
+    again = wax.HIPVectorEngine(metric=wax.VectorMetric(metric), dimensions=dims, devices=[0] * shards)
+    again.deserialize(blob)
+    assert again.count == one.count and again.serialize() == blob
+    for q in queries[10:]:
+        a, b = one.searchArrays(q, 10), again.searchArrays(q, 10)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    # and against the oracle
+    m = one.count
+    blob_rows = np.frombuffer(blob, dtype="<f4", count=m * dims, offset=36).reshape(m, dims)
+    blob_ids = np.frombuffer(blob, dtype="<u8", count=m, offset=36 + m * dims * 4 + 8)
+    got = many.searchArrays(queries[0], 10)
+    e_ids, e_scores, _, _ = oracle.search(metric, blob_rows, blob_ids, queries[0], 10)
+    x = oracle.search(metric, blob_rows, blob_ids, queries[0], 18)[1]
+    assert_parity(got[0], got[1], e_ids, e_scores, x, f"sharded x{shards} m{metric}")
+    for eng in (one, many, again):
+        eng.close()
+
+
+def test_sharded_tie_order_and_growth_without_reserve(wax):
+    """Exact duplicates spread over the shards resolve by ascending GLOBAL row exactly as in one engine, also while the
+    layout grows by doubling (no reserve): the period-256 tie corpus of MetalVectorEngineBenchmark.swift:33-38."""
+    dims = 128
+    one, many = pair(wax, 0, dims, 3)
+    ties = oracle.tie_pattern(0, 9_000, dims)
+    q = np.abs(oracle.gaussian_unit_queries(3, dims))
+    done = 0
+    for step in (100, 700, 64, 3000, 1, 5135):
+        chunk = ties[done:done + step]
+        ids = np.arange(done, done + step, dtype=np.uint64)
+        for eng in (one, many):
+            if step == 1:
+                eng.add(int(ids[0]), chunk[0])
+            else:
+                eng.addBatch(ids, chunk)
+        done += step
+        for qq in q:
+            same_search(one, many, qq, 30)
+    assert many.getTuning("rebalances") >= 1 and many.getTuning("shards") == 3
+    assert one.serialize() == many.serialize()
+    for r in (0, 4500, 8999, 256):
+        one.remove(r), many.remove(r)
+    for qq in q:
+        same_search(one, many, qq, 40)
+    assert one.serialize() == many.serialize()
+    one.close(), many.close()
+
+
+def test_sharded_pipelined_tickets_and_concurrency(wax):
+    dims, n = 384, 60_000
+    corpus = oracle.gaussian_unit_rows(8, n, dims)
+    one, many = pair(wax, 0, dims, 2)
+    for eng in (one, many):
+        eng.reserve(n)
+        eng.addBatch(np.arange(n, dtype=np.uint64), corpus)
+    queries = oracle.gaussian_unit_queries(40, dims, seed=4)
+    expect = [one.searchArrays(q, 10) for q in queries]
+    tickets = []
+    out = []
+    for q in queries:                                                 # more tickets than the handle's slots: collect as we go
+        if len(tickets) >= 6:
+            out.append(many.collect(tickets.pop(0), 10))
+        tickets.append(many.submit(q, 10))
+    while tickets:
+        out.append(many.collect(tickets.pop(0), 10))
+    for (ids, scores), (e_ids, e_scores) in zip(out, expect):
+        assert np.array_equal(ids, e_ids) and np.array_equal(scores, e_scores)
+    t = many.submit(queries[0], 10)                                   # a writer is refused while this thread holds a ticket
+    with pytest.raises(wax.EncodingError):
+        many.add(10 ** 9, corpus[0])
+    many.collect(t, 10)
+    errors = []
+
+    def reader(tid):
+        try:
+            for i in range(30):
+                ids, scores = many.searchArrays(queries[(tid + i) % 40], 10)
+                assert len(ids) == 10 and np.all(np.diff(scores) <= 0)
+        except Exception as ex:  # noqa: BLE001
+            errors.append(ex)
+
+    def writer():
+        try:
+            for i in range(40):
+                many.add(10 ** 9 + i, corpus[i])
+                if i % 8 == 0:
+                    many.remove(10 ** 9 + i)
+        except Exception as ex:  # noqa: BLE001
+            errors.append(ex)
+
+    ts = [threading.Thread(target=reader, args=(t_,)) for t_ in range(3)] + [threading.Thread(target=writer)]
+    for th in ts:
+        th.start()
+    for th in ts:
+        th.join()
+    assert not errors, errors
+    assert many.count == n + 35
+    one.close(), many.close()
+
+
+def test_sharded_device_rows_and_single_device_entry_points(wax):
+    import torch
+    dims, n = 128, 20_000
+    dev = torch.device("cuda", 0)
+    rows = torch.nn.functional.normalize(torch.randn((n, dims), device=dev), dim=1).contiguous()
+    one, many = pair(wax, 0, dims, 3)
+    for eng in (one, many):
+        eng.reserve(n)
+        eng.addBatchDevice(np.arange(n, dtype=np.uint64), rows)
+    assert sum(many.shardInfo(g)[2] for g in range(3)) == n and many.count == n
+    q = rows[777].cpu().numpy()
+    same_search(one, many, q, 10)
+    assert many.searchArrays(q, 1)[0][0] == 777
+    with pytest.raises(wax.EncodingError):
+        many.addBatchDevice(np.arange(5, dtype=np.uint64), rows[:5].contiguous())       # ids already present
+    for call in (lambda: many.setRowBase(5), lambda: many.timeStreamRead(1), lambda: many.timeScanKernel(q, 10, 1),
+                 lambda: many.searchShardDevice(q, 10, 0), lambda: many.searchBatchHitsDevice(rows.data_ptr(), 4, 10, rows.data_ptr(), 10)):
+        with pytest.raises(wax.EncodingError) as ei:
+            call()
+        assert "sharded" in str(ei.value)
+    with pytest.raises(wax.InvalidToc) as ei:
+        wax.HIPVectorEngine(dimensions=dims, devices=[0, 99])
+    assert "HIP device 99 not available" in str(ei.value)
+    with pytest.raises(wax.EncodingError):
+        wax.HIPVectorEngine(dimensions=dims, devices=[])
+    one.close(), many.close()
+
+
+def test_rccl_exchange_on_a_one_rank_communicator():
+    """exchange = 1: one ncclAllGather per query through librccl on a single-process communicator (ncclCommInitAll).
+    A 1-GPU box can only form a 1-rank communicator (RCCL refuses duplicate devices — checked too); run in a subprocess
+    so that a wedged collective cannot take the test session with it."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+import oracle, wax_amd as wax
+if not wax.HIPVectorEngine.isAvailable():
+    print("NO_GPU"); sys.exit(0)
+dims, n = 384, 50000
+corpus = oracle.gaussian_unit_rows(2, n, dims)
+one = wax.HIPVectorEngine(dimensions=dims)
+many = wax.HIPVectorEngine(dimensions=dims, devices=[0])
+for e in (one, many):
+    e.addBatch(np.arange(n, dtype=np.uint64), corpus)
+many.setTuning("exchange", 1)
+assert many.getTuning("exchange") == 1
+for q in oracle.gaussian_unit_queries(20, dims):
+    a, b = one.searchArrays(q, 10), many.searchArrays(q, 10)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+assert many.getTuning("rccl_collectives") == 20
+dup = wax.HIPVectorEngine(dimensions=dims, devices=[0, 0])
+try:
+    dup.setTuning("exchange", 1)
+    print("DUP_ACCEPTED")
+except wax.InvalidToc as ex:
+    assert "ncclCommInitAll" in str(ex), ex
+    print("DUP_REFUSED")
+dup.addBatch(np.arange(100, dtype=np.uint64), corpus[:100])
+assert dup.searchArrays(corpus[5], 1)[0][0] == 5          # the peer-copy exchange keeps working
+print("RCCL_OK")
+''' % root
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    if "NO_GPU" in out.stdout:
+        pytest.skip("no gfx950 device")
+    assert out.returncode == 0 and "RCCL_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

@@ -69,6 +69,10 @@ SIGNATURES: Dict[str, tuple] = {
     "wax_hip_abi_version": (ctypes.c_uint32, []),
     "wax_hip_last_error": (ctypes.c_char_p, []),
     "wax_hip_engine_create": (ctypes.c_int, [ctypes.c_uint8, ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(_engine_p)]),
+    "wax_hip_engine_create_sharded": (ctypes.c_int, [ctypes.c_uint8, ctypes.c_uint32, ctypes.POINTER(ctypes.c_int), ctypes.c_int,
+                                                     ctypes.POINTER(_engine_p)]),
+    "wax_hip_shard_count": (ctypes.c_int, [_engine_p]),
+    "wax_hip_shard_info": (ctypes.c_int, [_engine_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int), _u64p, _u64p]),
     "wax_hip_engine_destroy": (None, [_engine_p]),
     "wax_hip_dimensions": (ctypes.c_uint32, [_engine_p]),
     "wax_hip_count": (ctypes.c_uint64, [_engine_p]),

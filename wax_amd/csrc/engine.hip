@@ -276,9 +276,12 @@ struct BatchCtx {
     float* d_qnorm_all = nullptr;        // [cert_cap]
 };
 
+struct ShardedState;   // sharded.inc: the multi-GPU handle's state (null for a single-device engine)
+
 }  // namespace
 
 struct wax_hip_engine {
+    ShardedState* sh = nullptr;
     int device = 0;
     uint8_t metric = 0;
     uint32_t dims = 0;
@@ -394,16 +397,42 @@ int holding(wax_hip_engine* e) {   // uncollected tickets submitted by the calli
     auto it = e->outstanding.find(std::this_thread::get_id());
     return it == e->outstanding.end() ? 0 : it->second;
 }
-void note_submit(wax_hip_engine* e, Slot* s) {
-    s->owner = std::this_thread::get_id();
+void note_submit_id(wax_hip_engine* e, std::thread::id* owner) {
+    *owner = std::this_thread::get_id();
     std::unique_lock<std::mutex> g(e->out_mu);
-    e->outstanding[s->owner] += 1;
+    e->outstanding[*owner] += 1;
 }
-void note_collect(wax_hip_engine* e, Slot* s) {
+void note_collect_id(wax_hip_engine* e, std::thread::id owner) {
     std::unique_lock<std::mutex> g(e->out_mu);
-    auto it = e->outstanding.find(s->owner);
+    auto it = e->outstanding.find(owner);
     if (it != e->outstanding.end() && --it->second <= 0) e->outstanding.erase(it);
 }
+void note_submit(wax_hip_engine* e, Slot* s) { note_submit_id(e, &s->owner); }
+void note_collect(wax_hip_engine* e, Slot* s) { note_collect_id(e, s->owner); }
+
+// sharded.inc (included at the end of this file)
+int sh_add_batch(wax_hip_engine* e, const uint64_t* frame_ids, const float* rows, uint64_t n, uint32_t dims);
+int sh_add_batch_device(wax_hip_engine* e, const uint64_t* frame_ids, const float* d_rows, uint64_t n, uint32_t dims);
+int sh_remove(wax_hip_engine* e, uint64_t frame_id);
+int sh_reserve(wax_hip_engine* e, uint64_t rows);
+int sh_submit(wax_hip_engine* e, const float* query, uint32_t dims, int32_t top_k, uint64_t* out_ticket);
+int sh_collect(wax_hip_engine* e, uint64_t ticket, uint64_t* out_ids, float* out_scores, uint32_t capacity, uint32_t* out_count);
+int sh_search_batch_hits(wax_hip_engine* e, const float* queries, uint32_t nq, uint32_t dims, int32_t top_k, wax_hip_hit* out_hits,
+                         uint32_t stride, uint32_t* out_counts);
+int sh_search_filtered(wax_hip_engine* e, const float* query, uint32_t dims, int32_t top_k, int has_allow, const uint64_t* allow,
+                       uint64_t n_allow, int has_min, float min_score, uint64_t* out_ids, float* out_scores, uint32_t capacity,
+                       uint32_t* out_count);
+int sh_serialize(wax_hip_engine* e, uint8_t** out_bytes, size_t* out_len);
+int sh_deserialize(wax_hip_engine* e, const uint8_t* data, size_t len);
+void sh_destroy(wax_hip_engine* e);
+uint64_t sh_total_count(const wax_hip_engine* e);
+int sh_stats(wax_hip_engine* e, wax_hip_stats_t* out);
+int sh_set_tuning(wax_hip_engine* e, const std::string& k, int64_t value);
+int64_t sh_get_tuning(wax_hip_engine* e, const std::string& k);
+#define SHARDED_UNSUPPORTED(e, what)                                                                                 \
+    do {                                                                                                             \
+        if ((e) && (e)->sh) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, what " is a single-device entry point: not available on a sharded engine"); \
+    } while (0)
 // Mutating entry points: a thread holding uncollected tickets holds the shared lock and would wait for itself.
 #define REFUSE_IF_HOLDING(e)                                                                                        \
     do {                                                                                                            \
@@ -1175,6 +1204,7 @@ int wax_hip_engine_create(uint8_t metric, uint32_t dims, int device_id, wax_hip_
 
 void wax_hip_engine_destroy(wax_hip_engine* e) {
     if (!e) return;
+    if (e->sh) { sh_destroy(e); delete e; return; }
     DeviceGuard g(e->device);
     (void)hipDeviceSynchronize();
     for (Slot* s : e->all_slots) free_slot(s);
@@ -1207,7 +1237,7 @@ void wax_hip_engine_destroy(wax_hip_engine* e) {
 }
 
 uint32_t wax_hip_dimensions(const wax_hip_engine* e) { return e ? e->dims : 0; }
-uint64_t wax_hip_count(const wax_hip_engine* e) { return e ? e->count : 0; }
+uint64_t wax_hip_count(const wax_hip_engine* e) { return e ? (e->sh ? sh_total_count(e) : e->count) : 0; }
 uint8_t wax_hip_metric_of(const wax_hip_engine* e) { return e ? e->metric : 0; }
 int wax_hip_device_of(const wax_hip_engine* e) { return e ? e->device : -1; }
 
@@ -1215,6 +1245,7 @@ int wax_hip_device_of(const wax_hip_engine* e) { return e ? e->device : -1; }
 
 int wax_hip_reserve(wax_hip_engine* e, uint64_t rows) {
     if (!e) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine is null");
+    if (e->sh) return sh_reserve(e, rows);
     REFUSE_IF_HOLDING(e);
     DeviceGuard g(e->device);
     WriteGuard w(e->lock);
@@ -1226,6 +1257,7 @@ int wax_hip_reserve(wax_hip_engine* e, uint64_t rows) {
 
 int wax_hip_add_batch(wax_hip_engine* e, const uint64_t* frame_ids, const float* rows, uint64_t n, uint32_t dims) {
     if (!e) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine is null");
+    if (e->sh) return sh_add_batch(e, frame_ids, rows, n, dims);
     if (n == 0) return WAX_HIP_OK;  // :360
     if (!frame_ids || !rows) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "addBatch: null input");
     if (dims != e->dims) return fail(WAX_HIP_ERR_DIM_MISMATCH, dim_mismatch_msg(e->dims, dims));  // :367-370
@@ -1311,6 +1343,7 @@ int wax_hip_add(wax_hip_engine* e, uint64_t frame_id, const float* vector, uint3
 
 int wax_hip_add_batch_device(wax_hip_engine* e, const uint64_t* frame_ids, const float* d_rows, uint64_t n, uint32_t dims) {
     if (!e) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine is null");
+    if (e->sh) return sh_add_batch_device(e, frame_ids, d_rows, n, dims);
     if (n == 0) return WAX_HIP_OK;
     if (!frame_ids || !d_rows) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "addBatch: null input");
     if (dims != e->dims) return fail(WAX_HIP_ERR_DIM_MISMATCH, dim_mismatch_msg(e->dims, dims));
@@ -1384,6 +1417,7 @@ int wax_hip_apply_put_embeddings(wax_hip_engine* e, const uint8_t* payloads, uin
 
 int wax_hip_remove(wax_hip_engine* e, uint64_t frame_id) {
     if (!e) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine is null");
+    if (e->sh) return sh_remove(e, frame_id);
     REFUSE_IF_HOLDING(e);
     DeviceGuard g(e->device);
     WriteGuard w(e->lock);
@@ -1419,6 +1453,7 @@ static int submit_impl(wax_hip_engine* e, const float* query, uint32_t dims, int
                        bool try_only);
 
 int wax_hip_search_submit(wax_hip_engine* e, const float* query, uint32_t dims, int32_t top_k, uint64_t* out_ticket) {
+    if (e && e->sh) return sh_submit(e, query, dims, top_k, out_ticket);
     return submit_impl(e, query, dims, top_k, out_ticket, false);
 }
 
@@ -1485,6 +1520,7 @@ static int collect_impl(wax_hip_engine* e, uint64_t ticket, uint64_t* out_ids, f
 
 int wax_hip_search_collect(wax_hip_engine* e, uint64_t ticket, uint64_t* out_ids, float* out_scores, uint32_t out_capacity,
                            uint32_t* out_count) {
+    if (e && e->sh) return sh_collect(e, ticket, out_ids, out_scores, out_capacity, out_count);
     return collect_impl(e, ticket, out_ids, out_scores, out_capacity, out_count, nullptr, 0);
 }
 
@@ -1663,6 +1699,7 @@ int wax_hip_search_batch_hits(wax_hip_engine* e, const float* queries, uint32_t 
     if (!e) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine is null");
     if (nq == 0) return WAX_HIP_OK;
     if (!queries || !out_counts || (!out_hits && out_stride)) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null input");
+    if (e->sh) return sh_search_batch_hits(e, queries, nq, dims, top_k, out_hits, out_stride, out_counts);
     return search_batch_hits_impl(e, queries, nq, dims, top_k, out_hits, out_stride, out_counts);
 }
 
@@ -1675,7 +1712,8 @@ int wax_hip_search_batch(wax_hip_engine* e, const float* queries, uint32_t nq, u
     const uint32_t limit = (uint32_t)clamp_topk(top_k);
     const uint32_t w = limit < out_stride ? limit : out_stride;          // hits per query worth fetching
     std::vector<wax_hip_hit> hits((size_t)nq * (w ? w : 1));
-    int rc = search_batch_hits_impl(e, queries, nq, dims, top_k, hits.data(), w, out_counts);
+    int rc = e->sh ? sh_search_batch_hits(e, queries, nq, dims, top_k, hits.data(), w, out_counts)
+                   : search_batch_hits_impl(e, queries, nq, dims, top_k, hits.data(), w, out_counts);
     if (rc != WAX_HIP_OK) return rc;
     for (uint32_t q = 0; q < nq; ++q)
         hits_to_results(e->metric, hits.data() + (size_t)q * w, w, out_ids + (uint64_t)q * out_stride,
@@ -1692,6 +1730,7 @@ int wax_hip_search_batch_hits_device(wax_hip_engine* e, const float* d_queries, 
     if (!e) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine is null");
     if (nq == 0) return WAX_HIP_OK;
     if (!d_queries || !d_out_hits || out_stride == 0) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null input");
+    SHARDED_UNSUPPORTED(e, "wax_hip_search_batch_hits_device");
     if (dims != e->dims) return fail(WAX_HIP_ERR_DIM_MISMATCH, dim_mismatch_msg(e->dims, dims));
     DeviceGuard g(e->device);
     e->lock.lock_shared(holding(e) > 0);
@@ -1753,6 +1792,7 @@ int wax_hip_search_batch_hits_device(wax_hip_engine* e, const float* d_queries, 
 int wax_hip_set_row_base(wax_hip_engine* e, uint64_t row_base) {
     if (!e) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine is null");
     if (row_base > 0xffffffffull) return fail(WAX_HIP_ERR_CAPACITY, "row_base exceeds UInt32 row indices");
+    SHARDED_UNSUPPORTED(e, "wax_hip_set_row_base");
     REFUSE_IF_HOLDING(e);
     WriteGuard w(e->lock);
     e->row_base = row_base;
@@ -1762,6 +1802,7 @@ int wax_hip_set_row_base(wax_hip_engine* e, uint64_t row_base) {
 int wax_hip_search_shard_device(wax_hip_engine* e, const float* query, uint32_t dims, int32_t top_k,
                                 wax_hip_hit* d_out_hits, void* stream) {
     if (!e || !d_out_hits) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine/output is null");
+    SHARDED_UNSUPPORTED(e, "wax_hip_search_shard_device");
     if (dims != e->dims || !query) return fail(WAX_HIP_ERR_DIM_MISMATCH, dim_mismatch_msg(e->dims, query ? dims : 0));
     const int kpad = clamp_topk(top_k);
     if (kpad > FUSED_MAX_K) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "top_k too large for the device-resident shard path (max 192)");
@@ -1856,6 +1897,8 @@ int wax_hip_search_filtered(wax_hip_engine* e, const float* query, uint32_t dims
     if (!e) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine is null");
     if (!query || !out_count || ((!out_ids || !out_scores) && out_capacity)) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null argument");
     if (has_allow && n_allow > 0 && !allow_frame_ids) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "allow-list is null");
+    if (e->sh) return sh_search_filtered(e, query, dims, top_k, has_allow, allow_frame_ids, n_allow, has_min_score, min_score, out_ids,
+                                         out_scores, out_capacity, out_count);
     if (dims != e->dims) return fail(WAX_HIP_ERR_DIM_MISMATCH, dim_mismatch_msg(e->dims, dims));
     const int kpad = clamp_topk(top_k);
     uint32_t n = 0;
@@ -1982,6 +2025,7 @@ void wax_hip_free(void* p) { std::free(p); }
 
 int wax_hip_serialize(wax_hip_engine* e, uint8_t** out_bytes, size_t* out_len) {
     if (!e || !out_bytes || !out_len) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    if (e->sh) return sh_serialize(e, out_bytes, out_len);
     DeviceGuard g(e->device);
     e->lock.lock_shared(holding(e) > 0);  // withReadLock (:683)
     { const int frc = flush_pending(e); if (frc != WAX_HIP_OK) { e->lock.unlock_shared(); return frc; } }
@@ -2018,6 +2062,7 @@ int wax_hip_serialize(wax_hip_engine* e, uint8_t** out_bytes, size_t* out_len) {
 
 int wax_hip_deserialize(wax_hip_engine* e, const uint8_t* data, size_t len) {
     if (!e || (!data && len)) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    if (e->sh) return sh_deserialize(e, data, len);
     // Validation order and reasons: MetalVectorEngine.deserialize (:716-808)
     if (len < 36) return fail(WAX_HIP_ERR_BAD_SEGMENT, "Metal segment too small: " + std::to_string(len) + " bytes");
     const uint8_t magic[4] = {0x4D, 0x56, 0x32, 0x56};
@@ -2066,6 +2111,7 @@ int wax_hip_deserialize(wax_hip_engine* e, const uint8_t* data, size_t len) {
 
 int wax_hip_stats(wax_hip_engine* e, wax_hip_stats_t* out) {
     if (!e || !out) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    if (e->sh) return sh_stats(e, out);
     out->searches = e->st_searches.load();
     out->rows_scanned = e->st_rows.load();
     out->bytes_scanned = e->st_bytes.load();
@@ -2090,6 +2136,7 @@ int wax_hip_stats(wax_hip_engine* e, wax_hip_stats_t* out) {
 int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value) {
     if (!e || !key) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null argument");
     const std::string k(key);
+    if (e->sh) return sh_set_tuning(e, k, value);
     if (k == "grid_blocks") e->grid_blocks = value;
     else if (k == "variant") e->variant = value;
     else if (k == "time_kernels") e->time_kernels = value;
@@ -2135,6 +2182,7 @@ int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value) {
 int64_t wax_hip_get_tuning(wax_hip_engine* e, const char* key) {
     if (!e || !key) return -1;
     const std::string k(key);
+    if (e->sh) return sh_get_tuning(e, k);
     if (k == "grid_blocks") return e->grid_blocks.load();
     if (k == "variant") return e->variant.load();
     if (k == "time_kernels") return e->time_kernels.load();
@@ -2166,6 +2214,7 @@ int64_t wax_hip_get_tuning(wax_hip_engine* e, const char* key) {
 int wax_hip_time_scan_kernel(wax_hip_engine* e, const float* query, uint32_t dims, int32_t top_k, uint32_t iters,
                              double* out_avg_ms) {
     if (!e || !out_avg_ms || !query) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    SHARDED_UNSUPPORTED(e, "wax_hip_time_scan_kernel");
     if (dims != e->dims) return fail(WAX_HIP_ERR_DIM_MISMATCH, dim_mismatch_msg(e->dims, dims));
     if (iters == 0) iters = 1;
     DeviceGuard g(e->device);
@@ -2207,6 +2256,7 @@ int wax_hip_time_scan_kernel(wax_hip_engine* e, const float* query, uint32_t dim
 
 int wax_hip_time_stream_read(wax_hip_engine* e, uint32_t iters, double* out_avg_ms) {
     if (!e || !out_avg_ms) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    SHARDED_UNSUPPORTED(e, "wax_hip_time_stream_read");
     if (iters == 0) iters = 1;
     DeviceGuard g(e->device);
     e->lock.lock_shared(holding(e) > 0);
@@ -2239,3 +2289,5 @@ int wax_hip_time_stream_read(wax_hip_engine* e, uint32_t iters, double* out_avg_
 }
 
 }  // extern "C"
+
+#include "sharded.inc"

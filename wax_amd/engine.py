@@ -58,16 +58,23 @@ class HIPVectorEngine:
         return bool(_abi.lib().wax_hip_available())
 
     # -- lifecycle ----------------------------------------------------------
-    def __init__(self, metric: VectorMetric = VectorMetric.cosine, dimensions: int = 0, device: int = -1):
-        """MetalVectorEngine.init(metric:dimensions:) (:153-274)."""
+    def __init__(self, metric: VectorMetric = VectorMetric.cosine, dimensions: int = 0, device: int = -1,
+                 devices: Optional[Sequence[int]] = None):
+        """MetalVectorEngine.init(metric:dimensions:) (:153-274). `devices=[...]`: one engine row-sharded over several
+        GPUs inside the library (wax_hip_engine_create_sharded): same API, same results."""
         self._lib = _abi.lib()
         self._h = ctypes.c_void_p()
         self.metric = VectorMetric(metric)
         self._dirty = False
         if dimensions < 0:
             raise InvalidToc("dimensions must be > 0")
-        rc = self._lib.wax_hip_engine_create(int(self.metric), int(min(dimensions, 2**32 - 1)), int(device),
-                                             ctypes.byref(self._h))
+        if devices is not None:
+            devs = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+            rc = self._lib.wax_hip_engine_create_sharded(int(self.metric), int(min(dimensions, 2**32 - 1)), devs, len(devices),
+                                                         ctypes.byref(self._h))
+        else:
+            rc = self._lib.wax_hip_engine_create(int(self.metric), int(min(dimensions, 2**32 - 1)), int(device),
+                                                 ctypes.byref(self._h))
         if rc != _abi.OK and rc == _abi.ERR_INVALID_ARGUMENT:
             raise InvalidToc(_abi.last_error())  # "dimensions must be > 0" is invalidToc in the reference (:155)
         raise_for_status(rc)
@@ -109,6 +116,18 @@ class HIPVectorEngine:
     @property
     def device(self) -> int:
         return int(self._lib.wax_hip_device_of(self._h))
+
+    @property
+    def shardCount(self) -> int:  # noqa: N802
+        return int(self._lib.wax_hip_shard_count(self._h))
+
+    def shardInfo(self, shard: int) -> Tuple[int, int, int]:  # noqa: N802
+        """(device ordinal, first global row, rows) of one shard."""
+        dev = ctypes.c_int(0)
+        base = ctypes.c_uint64(0)
+        rows = ctypes.c_uint64(0)
+        raise_for_status(self._lib.wax_hip_shard_info(self._h, int(shard), ctypes.byref(dev), ctypes.byref(base), ctypes.byref(rows)))
+        return int(dev.value), int(base.value), int(rows.value)
 
     # -- mutation -----------------------------------------------------------
     def add(self, frameId: int, vector) -> None:  # noqa: N803
