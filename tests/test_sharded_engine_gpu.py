@@ -205,15 +205,16 @@ def test_sharded_device_rows_and_single_device_entry_points(wax):
     with pytest.raises(wax.EncodingError):
         many.addBatchDevice(np.arange(5, dtype=np.uint64), rows[:5].contiguous())       # ids already present
     for call in (lambda: many.setRowBase(5), lambda: many.timeStreamRead(1), lambda: many.timeScanKernel(q, 10, 1),
-                 lambda: many.searchShardDevice(q, 10, 0), lambda: many.searchBatchHitsDevice(rows.data_ptr(), 4, 10, rows.data_ptr(), 10)):
+                 lambda: many.searchShardDevice(q, 10, rows.data_ptr()), lambda: many.searchBatchHitsDevice(rows.data_ptr(), 4, 10, rows.data_ptr(), 10)):
         with pytest.raises(wax.EncodingError) as ei:
             call()
         assert "sharded" in str(ei.value)
     with pytest.raises(wax.InvalidToc) as ei:
         wax.HIPVectorEngine(dimensions=dims, devices=[0, 99])
     assert "HIP device 99 not available" in str(ei.value)
-    with pytest.raises(wax.EncodingError):
+    with pytest.raises(wax.InvalidToc) as ei:
         wax.HIPVectorEngine(dimensions=dims, devices=[])
+    assert "device list" in str(ei.value)
     one.close(), many.close()
 
 
