@@ -260,10 +260,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
+    # `--gpus N` in ONE process (no torch.distributed launcher): the library's own multi-GPU engine
+    # (wax_hip_engine_create_sharded) spreads the corpus over devices 0..N-1 behind the same handle.
+    in_library = world == 1 and args.gpus > 1
+    if world != args.gpus and not in_library:
         log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: launch with torch.distributed.run for N>1")
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
     if os.environ.get("WAX_BENCH_SAME_DEVICE"):  # testing only: several ranks on one GPU (needs --exchange host)
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -291,11 +292,30 @@ def main():
     n, dims, k = args.rows, args.dims, args.topk
     lo, hi = sharded.shard_bounds(n, world, rank, align=64)
     t_build = time.perf_counter()
-    eng = HIPVectorEngine(metric=VectorMetric.cosine, dimensions=dims)
-    eng.reserve(max(hi - lo, 1))
-    for r0, x in device_rows(torch, lo, hi, dims, dev):
-        eng.addBatchDevice(np.arange(r0, r0 + x.shape[0], dtype=np.uint64), x)
-    eng.setRowBase(lo)
+    if in_library:
+        same = bool(os.environ.get("WAX_BENCH_SAME_DEVICE"))          # testing only: every shard on GPU 0
+        devs = [0 if same else g for g in range(args.gpus)]
+        eng = HIPVectorEngine(metric=VectorMetric.cosine, dimensions=dims, devices=devs)
+        eng.reserve(n)                                                 # block layout: ceil(n / N) rows per shard
+        per = -(-n // args.gpus)
+        per = -(-per // 64) * 64
+        r = 0
+        while r < n:                                                   # every granule is generated on the device that will hold it
+            g_ = min(r // per, args.gpus - 1)
+            gdev = torch.device("cuda", devs[g_])
+            r_hi = min(n, (r // GRANULE + 1) * GRANULE, (g_ + 1) * per if g_ + 1 < args.gpus else n)
+            for r0, x in device_rows(torch, r, r_hi, dims, gdev):
+                eng.addBatchDevice(np.arange(r0, r0 + x.shape[0], dtype=np.uint64), x)
+            r = r_hi
+        for d_ in set(devs):
+            torch.cuda.synchronize(d_)
+        lo, hi = 0, -(-n // args.gpus)                                  # rows per launch of ONE shard's scan kernel (roofline)
+    else:
+        eng = HIPVectorEngine(metric=VectorMetric.cosine, dimensions=dims)
+        eng.reserve(max(hi - lo, 1))
+        for r0, x in device_rows(torch, lo, hi, dims, dev):
+            eng.addBatchDevice(np.arange(r0, r0 + x.shape[0], dtype=np.uint64), x)
+        eng.setRowBase(lo)
     torch.cuda.synchronize()
     log(f"[bench] rank {rank}/{world}: shard rows [{lo},{hi}) = {(hi - lo) * dims * 4 / 1e9:.2f} GB in HBM, "
         f"built in {time.perf_counter() - t_build:.1f} s")
@@ -310,6 +330,8 @@ def main():
         probe = x[0].cpu().numpy()
 
     eng.setTuning("time_kernels", 1)
+    if in_library and args.exchange == "rccl" and not os.environ.get("WAX_BENCH_SAME_DEVICE"):
+        eng.setTuning("exchange", 1)        # one ncclAllGather per query on the library's single-process communicator
     if world == 1:
         # two in-order streams; the library chains the scan kernels through an event so they never
         # overlap each other (per-kernel HIP-event times stay clean) while one query's merge / result
@@ -403,7 +425,7 @@ def main():
             "metric": f"queries/sec, {_human_rows(n)} x {dims}-dim f32 cosine top-{k} brute-force scan (single query per step)",
             "value": qps,
             "unit": "queries/s",
-            "n_gpus": world,
+            "n_gpus": args.gpus if in_library else world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -414,13 +436,16 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{n} x {dims}-dim f32 unit-norm Gaussian corpus (seed {CORPUS_SEED}), cosine top-{k}, "
-                            f"one query per step, corpus resident in HBM and row-sharded over {world} GPU(s)",
+                            f"one query per step, corpus resident in HBM and row-sharded over {args.gpus if in_library else world} GPU(s)",
                 "rows": n, "dims": dims, "top_k": k, "rows_per_gpu": hi - lo,
-                "parallelism": f"row-shard x{world}" + ((" + RCCL all-gather of per-shard top-k" if use_rccl else
-                                                          " + host (gloo) all-gather of per-shard top-k") if world > 1 else ""),
+                "parallelism": (f"row-shard x{args.gpus}, ONE process: the library's multi-GPU engine (wax_hip_engine_create_sharded), "
+                                + ("single-process RCCL all-gather" if eng.getTuning("exchange") == 1 else "peer-copy gather")
+                                + " of per-shard top-k + merge on the first device") if in_library else
+                               (f"row-shard x{world}" + ((" + RCCL all-gather of per-shard top-k" if use_rccl else
+                                                          " + host (gloo) all-gather of per-shard top-k") if world > 1 else "")),
                 "pipeline_depth": args.depth,
                 "merge": "host" if (world > 1 and (args.host_merge or not use_rccl)) else "device",
-                "exchange": ("rccl all_gather" if use_rccl else "host (gloo)") if world > 1 else "none",
+                "exchange": ("in-library" if in_library else (("rccl all_gather" if use_rccl else "host (gloo)") if world > 1 else "none")),
                 "last_result_checksum": checksum,
             },
             "roofline": {
@@ -440,11 +465,11 @@ def main():
                         "never overlap each other)",
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not in_library and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(torch, args, dev, queries)
         elif world == 1:
             out["cpu_baseline"] = None
-        if world == 1 and not args.no_secondary:
+        if world == 1 and not in_library and not args.no_secondary:
             # the other single-GPU BASELINE configurations, timed after the headline (its engine is released first)
             gc.enable()
             eng.close()

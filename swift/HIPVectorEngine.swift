@@ -35,10 +35,32 @@ public actor HIPVectorEngine {
         self.dimensions = dimensions
     }
 
+    /// One engine row-sharded over several GPUs of the node, inside the library (`wax_hip_engine_create_sharded`): same
+    /// protocol, same results as one engine holding all the rows (tie order and `serialize()` bytes included). The
+    /// scan of every query runs on all listed devices at once; only the per-shard top-k crosses xGMI.
+    public init(metric: VectorMetric, dimensions: Int, devices: [Int32]) throws {
+        guard dimensions > 0 else { throw WaxError.invalidToc(reason: "dimensions must be > 0") }
+        guard dimensions <= Constants.maxEmbeddingDimensions else {
+            throw WaxError.capacityExceeded(limit: UInt64(Constants.maxEmbeddingDimensions), requested: UInt64(dimensions))
+        }
+        var h: OpaquePointer?
+        try Self.check(devices.withUnsafeBufferPointer {
+            wax_hip_engine_create_sharded(metric.toVecSimilarity().rawValue, UInt32(dimensions), $0.baseAddress, Int32(devices.count), &h)
+        })
+        self.handle = h!
+        self.metric = metric
+        self.dimensions = dimensions
+    }
+
+    /// Every gfx950 device of the node (what `.auto` / `.hipPreferred` use when more than one is visible).
+    public static var allDevices: [Int32] { (0..<wax_hip_device_count()).map { Int32($0) } }
+
     deinit { wax_hip_engine_destroy(handle) }
 
     public static func load(from wax: Wax, metric: VectorMetric, dimensions: Int) async throws -> HIPVectorEngine {
-        let engine = try HIPVectorEngine(metric: metric, dimensions: dimensions)
+        let devices = allDevices
+        let engine = devices.count > 1 ? try HIPVectorEngine(metric: metric, dimensions: dimensions, devices: devices)
+                                       : try HIPVectorEngine(metric: metric, dimensions: dimensions)
         if let bytes = try await wax.readCommittedVecIndexBytes() { try await engine.deserialize(bytes) }
         for e in await wax.pendingEmbeddingMutations() { try await engine.add(frameId: e.frameId, vector: e.vector) }
         return engine

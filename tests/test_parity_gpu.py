@@ -726,6 +726,19 @@ def test_bench_contract_and_shard_invariance(wax, tmp_path):
     print("\n[bench secondary] " + " | ".join(f"{x['value']:.0f} q/s, {x['ms_per_step']:.3f} ms/step, frac {x['roofline']['frac']:.3f}" for x in sec))
     two = _run_bench(2, [], tmp_path)
     assert "host (gloo)" in two["config"]["parallelism"]
+    # ONE process, three shards inside the library (all on GPU 0 here): same answers again
+    import os
+    import subprocess
+    import sys
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--rows", "300000", "--steps", "12", "--warmup", "2",
+                          "--no-cpu-baseline"], env=dict(os.environ, WAX_BENCH_SAME_DEVICE="1"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lib3 = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert lib3["n_gpus"] == 3 and "wax_hip_engine_create_sharded" in lib3["config"]["parallelism"]
+    assert lib3["config"]["last_result_checksum"] == one["config"]["last_result_checksum"]
+    assert lib3["roofline"]["kernel_launches_timed"] == 36           # 12 steps x 3 shard scans
     three = _run_bench(3, [], tmp_path)
     assert two["n_gpus"] == 2 and three["n_gpus"] == 3
     assert one["config"]["last_result_checksum"] == two["config"]["last_result_checksum"] \
