@@ -507,22 +507,25 @@ WAX_ORACLE_API int64_t wax_oracle_search_batch(int metric, const float* vectors,
  * vectorises it to AVX2 / AVX-512 FMA whatever -ffp-contract says. It is a reported baseline, not a
  * parity reference: distances agree with the f64 truth to ~1e-6 (tests/test_oracle.py). */
 #define WAX_LANES 16
-__attribute__((target_clones("arch=skylake-avx512", "arch=haswell", "default")))
+/* Clones by ISA FEATURE, not by CPU model (an "arch=skylake-avx512" clone is never chosen on an AMD EPYC host and the
+ * default clone would then run): avx512f (implies FMA), fma (AVX + FMA3: 256-bit vfmadd), baseline. fp-contract=fast
+ * lets gcc fuse a*b+c where the clone has FMA and keeps mul+add where it has not (no libm fmaf call anywhere). */
+__attribute__((target_clones("avx512f", "fma", "default"), optimize("fp-contract=fast")))
 static float row_distance_fast(int metric, const float* v, const float* q, uint32_t d, float qn) {
     float s0[WAX_LANES] = {0}, s1[WAX_LANES] = {0};
     uint32_t dl = d - d % WAX_LANES, j = 0;
     if (metric == METRIC_COSINE) {
         for (; j < dl; j += WAX_LANES)
             for (int c = 0; c < WAX_LANES; ++c) {
-                s0[c] = __builtin_fmaf(q[j + c], v[j + c], s0[c]);
-                s1[c] = __builtin_fmaf(v[j + c], v[j + c], s1[c]);
+                s0[c] += q[j + c] * v[j + c];
+                s1[c] += v[j + c] * v[j + c];
             }
     } else if (metric == METRIC_DOT) {
         for (; j < dl; j += WAX_LANES)
-            for (int c = 0; c < WAX_LANES; ++c) s0[c] = __builtin_fmaf(q[j + c], v[j + c], s0[c]);
+            for (int c = 0; c < WAX_LANES; ++c) s0[c] += q[j + c] * v[j + c];
     } else {
         for (; j < dl; j += WAX_LANES)
-            for (int c = 0; c < WAX_LANES; ++c) { float e = q[j + c] - v[j + c]; s0[c] = __builtin_fmaf(e, e, s0[c]); }
+            for (int c = 0; c < WAX_LANES; ++c) { float e = q[j + c] - v[j + c]; s0[c] += e * e; }
     }
     float a = 0.f, m = 0.f;
     for (int c = 0; c < WAX_LANES; ++c) { a += s0[c]; m += s1[c]; }

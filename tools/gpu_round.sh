@@ -13,7 +13,7 @@ cd "$R"
 export TMPDIR=/tmp
 echo "== $(date) stages: $STAGES" | tee "$OUT/session.log"
 rocm-smi --showproductname 2>/dev/null | head -8 >> "$OUT/session.log"
-nproc >> "$OUT/session.log"
+nproc >> "$OUT/session.log"; grep -m1 "model name" /proc/cpuinfo >> "$OUT/session.log"; grep -m1 -o -w "avx512f" /proc/cpuinfo >> "$OUT/session.log"
 
 for s in $STAGES; do
   t0=$(date +%s)
@@ -34,7 +34,7 @@ for s in $STAGES; do
       find "$OUT/prof_stats" -name "*kernel_trace.csv" -delete 2>/dev/null ;;
     pmc)
       (cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/prof_pmc" -o pmc -- \
-          python "$R/bench.py" --gpus 1 --steps 20 --warmup 2 --no-cpu-baseline > "$OUT/pmc_bench.json" 2> "$OUT/pmc.err"); rc=$?
+          python "$R/bench.py" --gpus 1 --steps 20 --warmup 2 --no-cpu-baseline --no-secondary > "$OUT/pmc_bench.json" 2> "$OUT/pmc.err"); rc=$?
       python tools/pmc_summary.py "$OUT/prof_pmc" > "$OUT/pmc_summary.json" 2>> "$OUT/pmc.err"
       find "$OUT/prof_pmc" -name "*.csv" -size +2M -delete 2>/dev/null ;;
     batch)
@@ -88,7 +88,14 @@ for s in $STAGES; do
       (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_default" -o bench -- \
           python "$R/bench.py" --gpus 1 > "$OUT/profdefault_bench.json" 2> "$OUT/profdefault.err"); rc=$?
       find "$OUT/prof_default" -name "*kernel_stats.csv" -exec cp {} "$OUT/default_kernel_stats.csv" \; 2>/dev/null
-      find "$OUT/prof_default" -name "*kernel_trace.csv" -delete 2>/dev/null ;;
+      f=$(find "$OUT/prof_default" -name "*kernel_trace.csv" | head -1)
+      [ -n "$f" ] && python "$R/tools/split_kernel_trace.py" "$f" > "$OUT/default_kernel_stats_split.csv" 2>/dev/null
+      find "$OUT/prof_default" -name "*kernel_trace.csv" -delete 2>/dev/null
+      # the headline alone (no secondary configurations): scan_kernel's --stats row is then one workload
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_headline" -o bench -- \
+          python "$R/bench.py" --gpus 1 --no-secondary --no-cpu-baseline > "$OUT/profheadline_bench.json" 2> "$OUT/profheadline.err")
+      find "$OUT/prof_headline" -name "*kernel_stats.csv" -exec cp {} "$OUT/headline_kernel_stats.csv" \; 2>/dev/null
+      find "$OUT/prof_headline" -name "*kernel_trace.csv" -delete 2>/dev/null ;;
     batchprof)
       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_batch" -o batch -- \
           python "$R/tools/batch_bench.py" --nq 256 --reps 3 > "$OUT/batchprof.log" 2>&1); rc=$?
