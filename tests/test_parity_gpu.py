@@ -936,16 +936,19 @@ def test_filtered_search_reference_case(wax):
     eng.close()
 
 
+@pytest.mark.parametrize("device_min", [4096, 0, -1])
 @pytest.mark.parametrize("metric,dims", [(0, 384), (1, 384), (2, 128), (0, 768), (0, 100), (1, 33)])
-def test_filtered_search_equals_filtered_full_ranking(wax, metric, dims):
+def test_filtered_search_equals_filtered_full_ranking(wax, metric, dims, device_min):
     """Pre-filter on the device == post-filter of the COMPLETE ranking (what the reference's post-filter would give
-    with an unbounded candidateLimit): same ids, and for the specialised dims bit-identical scores."""
+    with an unbounded candidateLimit): same ids, and for the specialised dims bit-identical scores. device_min: the
+    allow-list length from which ids are resolved by the id -> row table in HBM (0 = always, -1 = host probes only)."""
     n = 6000
     corpus = oracle.gaussian_unit_rows(3, n, dims)
     if metric != 0:
         corpus = corpus * np.linspace(0.5, 2.0, n, dtype=np.float32)[:, None]
     ids = (np.arange(n, dtype=np.uint64) * 7 + 3)
     eng = make_engine(wax, metric, dims, corpus, ids)
+    eng.setTuning("filter_device_min", device_min)
     rng = np.random.default_rng(11)
     q = oracle.gaussian_unit_queries(1, dims, seed=21)[0]
     full_ids, full_scores = eng.searchArrays(q, n)           # k = N: the general (radix select) path, complete ranking
@@ -976,6 +979,70 @@ def test_filtered_search_equals_filtered_full_ranking(wax, metric, dims):
     eng.remove(victim)
     g_ids, _ = eng.searchFiltered(q, 5, frameIds=[victim, int(full_ids[1]), int(full_ids[2])])
     assert g_ids.tolist() == [int(full_ids[1]), int(full_ids[2])]
+    used = eng.getTuning("filter_device_searches")
+    assert (used > 0) if device_min == 0 else (used == 0 if device_min < 0 else used >= 1)
+    eng.close()
+
+
+def test_filtered_search_long_allow_list_on_device(wax):
+    """A long allow-list (FrameFilter.frameIds with 10^5 ids) is resolved by the id -> row table in HBM: same answer as
+    the host-probe path bit for bit, also after removals (rows shift), appends and an upsert; concurrent callers each
+    take their own workspace."""
+    n, dims = 300_000, 128
+    corpus = oracle.gaussian_unit_rows(5, n + 1000, dims)
+    ids = np.arange(n + 1000, dtype=np.uint64) * 3 + 11
+    eng = make_engine(wax, 0, dims, corpus[:n], ids[:n])
+    rng = np.random.default_rng(2)
+    queries = oracle.gaussian_unit_queries(6, dims, seed=8)
+
+    def both(allow, k, q):
+        eng.setTuning("filter_device_min", -1)
+        h = eng.searchFiltered(q, k, frameIds=allow)
+        eng.setTuning("filter_device_min", 4096)
+        before = eng.getTuning("filter_device_searches")
+        d = eng.searchFiltered(q, k, frameIds=allow)
+        assert eng.getTuning("filter_device_searches") == before + (1 if len(allow) >= 4096 else 0)
+        assert np.array_equal(h[0], d[0]) and np.array_equal(h[1], d[1])
+        return d
+
+    allow = np.concatenate([rng.permutation(ids[:n])[:100_000], np.array([1, 2, 10 ** 15], np.uint64)])   # + unknown ids
+    allow = np.concatenate([allow, allow[:5000]])                                                         # + duplicates
+    got_ids, got_scores = both(allow, 50, queries[0])
+    assert len(got_ids) == 50 and np.all(np.isin(got_ids, allow)) and np.all(np.diff(got_scores) <= 0)
+    # against the complete ranking
+    full_ids, full_scores = eng.searchArrays(queries[0], 10_000)
+    keep = np.isin(full_ids, allow)
+    assert np.array_equal(got_ids[:int(min(50, keep.sum()))], full_ids[keep][:50])
+    # every id allowed: the filtered search IS the plain search
+    a_ids, a_scores = both(ids[:n], 25, queries[1])
+    p_ids, p_scores = eng.searchArrays(queries[1], 25)
+    assert np.array_equal(a_ids, p_ids) and np.array_equal(a_scores, p_scores)
+    # mutations invalidate the table: removal (rows shift down), append, upsert in place
+    for victim in (int(got_ids[0]), int(ids[0]), int(ids[n - 1])):
+        eng.remove(victim)
+    eng.addBatch(ids[n:n + 1000], corpus[n:n + 1000])
+    eng.add(int(ids[77]), corpus[n + 5])
+    allow2 = np.concatenate([allow, ids[n:n + 500]])
+    r_ids, _ = both(allow2, 50, queries[0])
+    assert int(got_ids[0]) not in r_ids.tolist()
+    # concurrent filtered searches (pooled workspaces, one stream each)
+    expect = [both(allow2, 20, q) for q in queries]
+    errors = []
+
+    def worker(i):
+        try:
+            for _ in range(5):
+                g = eng.searchFiltered(queries[i], 20, frameIds=allow2)
+                assert np.array_equal(g[0], expect[i][0]) and np.array_equal(g[1], expect[i][1])
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(queries))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
     eng.close()
 
 

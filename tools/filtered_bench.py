@@ -30,11 +30,13 @@ for i in range(50):
 out["unfiltered_ms"] = round((time.perf_counter() - t0) / 50 * 1e3, 4)
 for n_allow in (100, 10_000, 100_000, 1_000_000):
     allow = rng.permutation(rows)[:n_allow].astype(np.uint64)
-    eng.searchFiltered(q[0], 10, frameIds=allow)
-    t0 = time.perf_counter()
-    reps = 20 if n_allow <= 100_000 else 5
-    for i in range(reps):
-        ids, scores = eng.searchFiltered(q[i % 4], 10, frameIds=allow)
-    out[f"allow_{n_allow}_ms"] = round((time.perf_counter() - t0) / reps * 1e3, 4)
-    assert len(ids) == 10 and np.all(np.isin(ids, allow))
+    for label, device_min in (("host_probe", -1), ("device_probe", 0)):   # id -> row on the host / by the table in HBM
+        eng.setTuning("filter_device_min", device_min)
+        eng.searchFiltered(q[0], 10, frameIds=allow)
+        t0 = time.perf_counter()
+        reps = 20 if n_allow <= 100_000 else 5
+        for i in range(reps):
+            ids, scores = eng.searchFiltered(q[i % 4], 10, frameIds=allow)
+        out[f"allow_{n_allow}_{label}_ms"] = round((time.perf_counter() - t0) / reps * 1e3, 4)
+        assert len(ids) == 10 and np.all(np.isin(ids, allow))
 print(json.dumps(out))

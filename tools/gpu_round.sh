@@ -24,6 +24,8 @@ for s in $STAGES; do
       timeout 600 python -m pytest tests -m gpu -q -rA --durations=15 -p no:cacheprovider --timeout 150 > "$OUT/pytest_gpu.log" 2>&1; rc=$? ;;
     tests_x)
       timeout 600 python -m pytest tests -m gpu -x -q -p no:cacheprovider --timeout 150 > "$OUT/pytest_gpu_x.log" 2>&1; rc=$? ;;
+    filtered)
+      timeout 300 python tools/filtered_bench.py > "$OUT/filtered_bench.json" 2> "$OUT/filtered_bench.err"; rc=$? ;;
     cpusweep)
       timeout 300 python tools/cpu_sweep.py > "$OUT/cpu_sweep.json" 2> "$OUT/cpu_sweep.err"; rc=$? ;;
     bench)

@@ -204,18 +204,37 @@ struct Slot {
     std::thread::id owner;         // the submitting thread (its outstanding-ticket count drops at collect, whoever collects)
 };
 
-// Workspace of wax_hip_search_filtered; one filtered search at a time per engine.
+// Workspace of one wax_hip_search_filtered call: pooled (filter_max per engine, allocated on demand) with its own stream,
+// so filtered searches run concurrently with each other and with every other read entry point.
 struct FilterWork {
-    std::mutex mu;
+    hipStream_t stream = nullptr;
     uint32_t* d_rows = nullptr;      // [cap] allowed local rows, ascending
     uint64_t* d_ids = nullptr;       // [cap] their frame ids
     float* d_dist = nullptr;         // [cap] their distances
     uint64_t cap = 0;
+    uint64_t* d_allow = nullptr;     // [allow_cap] the caller's allow-list (device-side probe)
+    uint64_t allow_cap = 0;
+    uint32_t* d_bitmap = nullptr;    // [bitmap_words] one bit per store row
+    uint64_t bitmap_words = 0;
+    uint32_t* d_block_sum = nullptr; // [block_cap] per-block popcounts -> exclusive offsets
+    uint64_t block_cap = 0;
+    uint32_t* d_total = nullptr;     // [1]
+    uint32_t* h_total = nullptr;     // pinned [1]
     float* d_query = nullptr;        // [dims]
     float* d_qnorm = nullptr;        // [1]
     wax_hip_hit* d_hits = nullptr;   // [WAX_HIP_MAX_RESULTS]
+    wax_hip_hit* h_hits = nullptr;   // pinned [WAX_HIP_MAX_RESULTS]
     SelectWork sw{};
-    bool ready = false;
+};
+
+void free_filter_work(FilterWork* f);
+
+// id -> row table in HBM (filter.hip): built at the first long allow-list, rebuilt lazily after a mutation.
+struct IdHash {
+    std::mutex mu;                   // serialises the (re)build only
+    uint32_t* d_table = nullptr;
+    uint64_t slots = 0;
+    std::atomic<bool> valid{false};
 };
 
 // Batched (bf16 MFMA) path. The corpus mirror is shared by every batch (read-only during searches, rebuilt lazily by
@@ -358,7 +377,13 @@ struct wax_hip_engine {
     std::atomic<int64_t> batch_survivors{8};      // one-pass pipeline: expected survivors per query = this x k'
     std::atomic<int64_t> batch_sample_div{64};    // one-pass pipeline: 1 / this of the tiles are sampled (at least 256)
     std::atomic<uint64_t> st_onepass_queries{0};
-    FilterWork filter;
+    std::mutex filter_mu;                         // pool of filtered-search workspaces
+    std::condition_variable filter_cv;
+    std::vector<FilterWork*> filter_all, filter_free;
+    int filter_max = 4;
+    IdHash idhash;
+    std::atomic<int64_t> filter_device_min{4096}; // allow-lists at least this long are resolved on the device
+    std::atomic<uint64_t> st_filter_device{0};    // filtered searches whose allow-list was resolved on the device
     // Write-combining of single-frame appends (the reference appends into a unified-memory buffer and the GPU simply
     // sees it, MetalVectorEngine.swift:340-351; with discrete HBM the analogue is a pinned staging area that the NEXT
     // reader — or a full staging area — uploads in one copy). The last `pend_rows` rows of [0, count) live only here.
@@ -835,6 +860,88 @@ int grow_dev(T** p, uint64_t* cap, uint64_t want, size_t elem, const char* what)
     return WAX_HIP_OK;
 }
 
+// ---- filtered-search workspaces and the id -> row table ----
+
+void free_filter_work(FilterWork* f) {
+    if (!f) return;
+    (void)hipFree(f->d_rows); (void)hipFree(f->d_ids); (void)hipFree(f->d_dist); (void)hipFree(f->d_allow); (void)hipFree(f->d_bitmap);
+    (void)hipFree(f->d_block_sum); (void)hipFree(f->d_total); (void)hipFree(f->d_query); (void)hipFree(f->d_qnorm); (void)hipFree(f->d_hits);
+    (void)hipFree(f->sw.hist); (void)hipFree(f->sw.state); (void)hipFree(f->sw.counter); (void)hipFree(f->sw.keys_a); (void)hipFree(f->sw.keys_b);
+    if (f->h_total) (void)hipHostFree(f->h_total);
+    if (f->h_hits) (void)hipHostFree(f->h_hits);
+    if (f->stream) (void)hipStreamDestroy(f->stream);
+    delete f;
+}
+
+static int alloc_filter_work(wax_hip_engine* e, FilterWork** out) {
+    FilterWork* f = new FilterWork();
+    struct Guard { FilterWork* f; ~Guard() { if (f) free_filter_work(f); } } guard{f};
+    HIP_TRY(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking), WAX_HIP_ERR_INTERNAL, "Failed to create filter stream");
+    HIP_TRY(hipMalloc(&f->d_query, (size_t)e->dims * sizeof(float)), WAX_HIP_ERR_ALLOC, "Failed to allocate filter query buffer");
+    HIP_TRY(hipMalloc(&f->d_qnorm, sizeof(float)), WAX_HIP_ERR_ALLOC, "Failed to allocate filter scalars");
+    HIP_TRY(hipMalloc(&f->d_total, sizeof(uint32_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate filter scalars");
+    HIP_TRY(hipHostMalloc(&f->h_total, sizeof(uint32_t), hipHostMallocDefault), WAX_HIP_ERR_ALLOC, "Failed to allocate filter scalars");
+    HIP_TRY(hipMalloc(&f->d_hits, (size_t)WAX_HIP_MAX_RESULTS * sizeof(wax_hip_hit)), WAX_HIP_ERR_ALLOC, "Failed to allocate filter hits");
+    HIP_TRY(hipHostMalloc(&f->h_hits, (size_t)WAX_HIP_MAX_RESULTS * sizeof(wax_hip_hit), hipHostMallocDefault), WAX_HIP_ERR_ALLOC,
+            "Failed to allocate filter hits staging");
+    HIP_TRY(hipMalloc(&f->sw.hist, 256 * sizeof(uint32_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate select histogram");
+    HIP_TRY(hipMalloc(&f->sw.state, 2 * sizeof(uint64_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate select state");
+    HIP_TRY(hipMalloc(&f->sw.counter, sizeof(uint32_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate select counter");
+    HIP_TRY(hipMalloc(&f->sw.keys_a, (size_t)WAX_HIP_MAX_RESULTS * sizeof(int64_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate select keys");
+    HIP_TRY(hipMalloc(&f->sw.keys_b, (size_t)WAX_HIP_MAX_RESULTS * sizeof(int64_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate select keys");
+    guard.f = nullptr;
+    *out = f;
+    return WAX_HIP_OK;
+}
+
+static int acquire_filter_work(wax_hip_engine* e, FilterWork** out) {
+    std::unique_lock<std::mutex> g(e->filter_mu);
+    for (;;) {
+        if (!e->filter_free.empty()) {
+            *out = e->filter_free.back();
+            e->filter_free.pop_back();
+            return WAX_HIP_OK;
+        }
+        if ((int)e->filter_all.size() < e->filter_max) {
+            FilterWork* f = nullptr;
+            int rc = alloc_filter_work(e, &f);
+            if (rc != WAX_HIP_OK) return rc;
+            e->filter_all.push_back(f);
+            *out = f;
+            return WAX_HIP_OK;
+        }
+        e->filter_cv.wait(g);
+    }
+}
+
+static void release_filter_work(wax_hip_engine* e, FilterWork* f) {
+    std::unique_lock<std::mutex> g(e->filter_mu);
+    e->filter_free.push_back(f);
+    e->filter_cv.notify_one();
+}
+
+// The id -> row table of the store as it is now (shared lock held; pending rows flushed). Concurrent filtered searches
+// serialise on the rebuild only.
+static int ensure_idhash(wax_hip_engine* e, hipStream_t st) {
+    IdHash& h = e->idhash;
+    if (h.valid.load(std::memory_order_acquire)) return WAX_HIP_OK;
+    std::unique_lock<std::mutex> g(h.mu);
+    if (h.valid.load(std::memory_order_acquire)) return WAX_HIP_OK;
+    uint64_t want = 1024;
+    while (want < 2 * e->count) want *= 2;   // load factor <= 0.5
+    if (h.slots < want) {
+        (void)hipFree(h.d_table);
+        h.d_table = nullptr; h.slots = 0;
+        HIP_TRY(hipMalloc(&h.d_table, (size_t)want * sizeof(uint32_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate id table");
+        h.slots = want;
+    }
+    HIP_TRY(launch_idhash_build(e->d_ids, (uint32_t)e->count, h.d_table, h.slots, st), WAX_HIP_ERR_INTERNAL, "id table kernel launch");
+    HIP_TRY(hipStreamSynchronize(st), WAX_HIP_ERR_INTERNAL, "id table build failed on device");
+    h.valid.store(true, std::memory_order_release);
+    return WAX_HIP_OK;
+}
+
+
 int bctx_reserve(BatchCtx* c, uint64_t cand_slots, uint64_t kp, uint64_t tile_rows, uint64_t n_queries, bool dense) {
     // [rows of the largest block][cand_slots] keys; capacity tracked in keys
     const uint64_t rows_blk = n_queries < kBatchMaxQ ? ((n_queries + 255ull) & ~255ull) : (uint64_t)kBatchMaxQ;
@@ -1224,10 +1331,8 @@ void wax_hip_engine_destroy(wax_hip_engine* e) {
         BatchMirror& b = e->batch;
         (void)hipFree(b.d_cb); (void)hipFree(b.d_vn2); (void)hipFree(b.d_maxnorm);
         for (BatchCtx* c : e->bctx_all) free_bctx(c);
-        FilterWork& f = e->filter;
-        (void)hipFree(f.d_rows); (void)hipFree(f.d_ids); (void)hipFree(f.d_dist); (void)hipFree(f.d_query); (void)hipFree(f.d_qnorm);
-        (void)hipFree(f.d_hits); (void)hipFree(f.sw.hist); (void)hipFree(f.sw.state); (void)hipFree(f.sw.counter);
-        (void)hipFree(f.sw.keys_a); (void)hipFree(f.sw.keys_b);
+        for (FilterWork* f : e->filter_all) free_filter_work(f);
+        (void)hipFree(e->idhash.d_table);
     }
     (void)hipFree(e->d_store);
     (void)hipFree(e->d_ids);
@@ -1266,6 +1371,7 @@ int wax_hip_add_batch(wax_hip_engine* e, const uint64_t* frame_ids, const float*
     WriteGuard w(e->lock);
     sync_shard_work(e);
     e->batch.mirror_valid = false;
+    e->idhash.valid = false;
     e->batch.mirror_wanted = 0;
     const size_t row_bytes = (size_t)e->dims * sizeof(float);
     if (n == 1) {
@@ -1352,6 +1458,7 @@ int wax_hip_add_batch_device(wax_hip_engine* e, const uint64_t* frame_ids, const
     WriteGuard w(e->lock);
     sync_shard_work(e);
     e->batch.mirror_valid = false;
+    e->idhash.valid = false;
     e->batch.mirror_wanted = 0;
     { const int frc = flush_pending(e); if (frc != WAX_HIP_OK) return frc; }
     for (uint64_t i = 0; i < n; ++i)
@@ -1424,6 +1531,7 @@ int wax_hip_remove(wax_hip_engine* e, uint64_t frame_id) {
     sync_shard_work(e);
     if (e->count == 0) return WAX_HIP_OK;                 // :425
     e->batch.mirror_valid = false;
+    e->idhash.valid = false;
     e->batch.mirror_wanted = 0;
     const int64_t idx = e->idmap.find(frame_id);
     if (idx < 0) return WAX_HIP_OK;                       // :426
@@ -1911,9 +2019,48 @@ int wax_hip_search_filtered(wax_hip_engine* e, const float* query, uint32_t dims
         e->lock.lock_shared(holding(e) > 0);
         struct Unlock { RWLock& l; ~Unlock() { l.unlock_shared(); } } unlock{e->lock};
         { const int frc = flush_pending(e); if (frc != WAX_HIP_OK) return frc; }
+        FilterWork* fp = nullptr;
+        { const int arc = acquire_filter_work(e, &fp); if (arc != WAX_HIP_OK) return arc; }
+        struct Release { wax_hip_engine* e; FilterWork* f; ~Release() { (void)hipStreamSynchronize(f->stream); release_filter_work(e, f); } } release{e, fp};
+        FilterWork& f = *fp;
+        hipStream_t st = f.stream;
         // allowed frame ids -> local rows, ascending and unique (row order is the tie-break order of every path)
-        std::vector<uint32_t> rows;
-        if (n_allow < 4096 || n_allow < e->count / 64) {
+        uint64_t m = 0;
+        const int64_t dev_min = e->filter_device_min.load();
+        if (e->count == 0 || n_allow == 0) {
+            m = 0;
+        } else if (dev_min >= 0 && n_allow >= (uint64_t)dev_min) {
+            // long lists: the probes are cache misses (~60 ns each on the host, 5.65 ms for 1M ids); on the device the
+            // same probes are a few tens of microseconds against the id -> row table in HBM (filter.hip), and the
+            // bitmap they mark hands the rows back ascending and unique
+            { const int hrc = ensure_idhash(e, st); if (hrc != WAX_HIP_OK) return hrc; }
+            const uint64_t n_words = (e->count + 31) / 32, n_blocks = filter_bitmap_blocks((uint32_t)e->count);
+            int grc = grow_dev(&f.d_allow, &f.allow_cap, n_allow, sizeof(uint64_t), "Failed to allocate allow-list");
+            if (grc == WAX_HIP_OK) grc = grow_dev(&f.d_bitmap, &f.bitmap_words, n_words, sizeof(uint32_t), "Failed to allocate row bitmap");
+            if (grc == WAX_HIP_OK) grc = grow_dev(&f.d_block_sum, &f.block_cap, n_blocks, sizeof(uint32_t), "Failed to allocate bitmap offsets");
+            const uint64_t m_max = n_allow < e->count ? n_allow : e->count;
+            if (grc == WAX_HIP_OK && f.cap < m_max) {
+                uint64_t cap = 1024;
+                while (cap < m_max) cap *= 2;
+                uint64_t c1 = f.cap, c2 = f.cap, c3 = f.cap;
+                grc = grow_dev(&f.d_rows, &c1, cap, sizeof(uint32_t), "Failed to allocate allowed-row list");
+                if (grc == WAX_HIP_OK) grc = grow_dev(&f.d_ids, &c2, cap, sizeof(uint64_t), "Failed to allocate allowed-id list");
+                if (grc == WAX_HIP_OK) grc = grow_dev(&f.d_dist, &c3, cap, sizeof(float), "Failed to allocate allowed-row distances");
+                f.cap = grc == WAX_HIP_OK ? cap : 0;
+            }
+            if (grc != WAX_HIP_OK) return grc;
+            HIP_TRY(hipMemcpyAsync(f.d_allow, allow_frame_ids, (size_t)n_allow * sizeof(uint64_t), hipMemcpyHostToDevice, st),
+                    WAX_HIP_ERR_INTERNAL, "allow-list upload");
+            HIP_TRY(launch_allow_probe(f.d_allow, n_allow, e->d_ids, (uint32_t)e->count, e->idhash.d_table, e->idhash.slots, f.d_bitmap,
+                                       f.d_block_sum, f.d_total, st), WAX_HIP_ERR_INTERNAL, "allow-list probe launch");
+            HIP_TRY(launch_allow_emit(f.d_bitmap, (uint32_t)e->count, f.d_block_sum, e->d_ids, f.d_rows, f.d_ids, st),
+                    WAX_HIP_ERR_INTERNAL, "allow-list compaction launch");
+            HIP_TRY(hipMemcpyAsync(f.h_total, f.d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, st), WAX_HIP_ERR_INTERNAL, "row count download");
+            HIP_TRY(hipStreamSynchronize(st), WAX_HIP_ERR_INTERNAL, "allow-list probe failed on device");
+            m = *f.h_total;
+            e->st_filter_device++;
+        } else {
+            std::vector<uint32_t> rows;
             rows.reserve((size_t)n_allow);
             for (uint64_t i = 0; i < n_allow; ++i) {
                 const int64_t r = e->idmap.find(allow_frame_ids[i]);
@@ -1921,77 +2068,31 @@ int wax_hip_search_filtered(wax_hip_engine* e, const float* query, uint32_t dims
             }
             std::sort(rows.begin(), rows.end());
             rows.erase(std::unique(rows.begin(), rows.end()), rows.end());
-        } else {
-            // long lists: the hash probes are cache misses (~60 ns each) and a sort of the rows would cost as much
-            // again, so the probes are spread over a few threads and the rows are marked in a bitmap, which hands
-            // them back ascending and unique for free
-            std::vector<uint64_t> bits((size_t)((e->count + 63) / 64), 0ull);
-            unsigned hw = std::thread::hardware_concurrency();
-            unsigned nt = n_allow >= 65536 ? (hw > 16 ? 16u : (hw ? hw : 1u)) : 1u;
-            auto probe = [&](uint64_t lo, uint64_t hi) {
-                for (uint64_t i = lo; i < hi; ++i) {
-                    const int64_t r = e->idmap.find(allow_frame_ids[i]);
-                    if (r >= 0) __atomic_fetch_or(&bits[(size_t)(r >> 6)], 1ull << (r & 63), __ATOMIC_RELAXED);
+            m = rows.size();
+            if (m) {
+                std::vector<uint64_t> ids((size_t)m);
+                for (uint64_t i = 0; i < m; ++i) ids[i] = e->ids[rows[i]];
+                if (f.cap < m) {
+                    uint64_t cap = 1024;
+                    while (cap < m) cap *= 2;
+                    uint64_t c1 = f.cap, c2 = f.cap, c3 = f.cap;
+                    int grc = grow_dev(&f.d_rows, &c1, cap, sizeof(uint32_t), "Failed to allocate allowed-row list");
+                    if (grc == WAX_HIP_OK) grc = grow_dev(&f.d_ids, &c2, cap, sizeof(uint64_t), "Failed to allocate allowed-id list");
+                    if (grc == WAX_HIP_OK) grc = grow_dev(&f.d_dist, &c3, cap, sizeof(float), "Failed to allocate allowed-row distances");
+                    f.cap = grc == WAX_HIP_OK ? cap : 0;
+                    if (grc != WAX_HIP_OK) return grc;
                 }
-            };
-            if (nt <= 1) {
-                probe(0, n_allow);
-            } else {
-                std::vector<std::thread> pool;
-                const uint64_t chunk = (n_allow + nt - 1) / nt;
-                for (unsigned t = 0; t < nt; ++t) {
-                    const uint64_t lo = (uint64_t)t * chunk, hi = lo + chunk < n_allow ? lo + chunk : n_allow;
-                    if (lo < hi) pool.emplace_back(probe, lo, hi);
-                }
-                for (auto& th : pool) th.join();
-            }
-            uint64_t m_est = 0;
-            for (uint64_t w : bits) m_est += (uint64_t)__builtin_popcountll(w);
-            rows.reserve((size_t)m_est);
-            for (size_t wi = 0; wi < bits.size(); ++wi) {
-                uint64_t w = bits[wi];
-                while (w) {
-                    rows.push_back((uint32_t)(wi * 64 + (size_t)__builtin_ctzll(w)));
-                    w &= w - 1;
-                }
+                // pageable sources: the runtime stages them before returning, so the vectors may die at the end of this block
+                HIP_TRY(hipMemcpyAsync(f.d_rows, rows.data(), (size_t)m * sizeof(uint32_t), hipMemcpyHostToDevice, st), WAX_HIP_ERR_INTERNAL, "row list upload");
+                HIP_TRY(hipMemcpyAsync(f.d_ids, ids.data(), (size_t)m * sizeof(uint64_t), hipMemcpyHostToDevice, st), WAX_HIP_ERR_INTERNAL, "id list upload");
+                HIP_TRY(hipStreamSynchronize(st), WAX_HIP_ERR_INTERNAL, "row list upload");
             }
         }
-        const uint64_t m = rows.size();
-        if (m == 0) return WAX_HIP_OK;
-        std::vector<uint64_t> ids(m);
-        for (uint64_t i = 0; i < m; ++i) ids[i] = e->ids[rows[i]];
+        if (m == 0) { *out_count = 0; return WAX_HIP_OK; }
         const int k_eff = (uint64_t)kpad < m ? kpad : (int)m;
-
-        FilterWork& f = e->filter;
-        std::unique_lock<std::mutex> fg(f.mu);
-        hipStream_t st = e->streams[0];
-        if (!f.ready) {
-            HIP_TRY(hipMalloc(&f.d_query, (size_t)e->dims * sizeof(float)), WAX_HIP_ERR_ALLOC, "Failed to allocate filter query buffer");
-            HIP_TRY(hipMalloc(&f.d_qnorm, sizeof(float)), WAX_HIP_ERR_ALLOC, "Failed to allocate filter scalars");
-            HIP_TRY(hipMalloc(&f.d_hits, (size_t)WAX_HIP_MAX_RESULTS * sizeof(wax_hip_hit)), WAX_HIP_ERR_ALLOC, "Failed to allocate filter hits");
-            HIP_TRY(hipMalloc(&f.sw.hist, 256 * sizeof(uint32_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate select histogram");
-            HIP_TRY(hipMalloc(&f.sw.state, 2 * sizeof(uint64_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate select state");
-            HIP_TRY(hipMalloc(&f.sw.counter, sizeof(uint32_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate select counter");
-            HIP_TRY(hipMalloc(&f.sw.keys_a, (size_t)WAX_HIP_MAX_RESULTS * sizeof(int64_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate select keys");
-            HIP_TRY(hipMalloc(&f.sw.keys_b, (size_t)WAX_HIP_MAX_RESULTS * sizeof(int64_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate select keys");
-            f.ready = true;
-        }
-        if (f.cap < m) {
-            HIP_TRY(hipStreamSynchronize(st), WAX_HIP_ERR_INTERNAL, "filter sync");
-            (void)hipFree(f.d_rows); (void)hipFree(f.d_ids); (void)hipFree(f.d_dist);
-            f.d_rows = nullptr; f.d_ids = nullptr; f.d_dist = nullptr; f.cap = 0;
-            uint64_t cap = 1024;
-            while (cap < m) cap *= 2;
-            HIP_TRY(hipMalloc(&f.d_rows, (size_t)cap * sizeof(uint32_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate allowed-row list");
-            HIP_TRY(hipMalloc(&f.d_ids, (size_t)cap * sizeof(uint64_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate allowed-id list");
-            HIP_TRY(hipMalloc(&f.d_dist, (size_t)cap * sizeof(float)), WAX_HIP_ERR_ALLOC, "Failed to allocate allowed-row distances");
-            f.cap = cap;
-        }
         const float qn = query_norm(query, dims);
         HIP_TRY(hipMemcpyAsync(f.d_query, query, (size_t)dims * sizeof(float), hipMemcpyHostToDevice, st), WAX_HIP_ERR_INTERNAL, "query upload");
         HIP_TRY(hipMemcpyAsync(f.d_qnorm, &qn, sizeof(float), hipMemcpyHostToDevice, st), WAX_HIP_ERR_INTERNAL, "query norm upload");
-        HIP_TRY(hipMemcpyAsync(f.d_rows, rows.data(), (size_t)m * sizeof(uint32_t), hipMemcpyHostToDevice, st), WAX_HIP_ERR_INTERNAL, "row list upload");
-        HIP_TRY(hipMemcpyAsync(f.d_ids, ids.data(), (size_t)m * sizeof(uint64_t), hipMemcpyHostToDevice, st), WAX_HIP_ERR_INTERNAL, "id list upload");
         RescoreArgs r{};   // exact f32 distances with scan_kernel's lane mapping and summation order
         r.store = e->d_store; r.queries = f.d_query; r.q_norm = f.d_qnorm; r.rows = f.d_rows; r.dist_out = f.d_dist;
         r.n_rows = (uint32_t)e->count; r.row_base = 0; r.dims = dims; r.nq = 1; r.cand_cap = 0; r.kp = (int)m;
@@ -1999,11 +2100,10 @@ int wax_hip_search_filtered(wax_hip_engine* e, const float* query, uint32_t dims
         // keys of the compact list carry the POSITION in it; positions ascend with rows, so ties order as everywhere else
         HIP_TRY(launch_select_general(f.d_dist, (uint32_t)m, 0u, k_eff, k_eff, f.d_ids, f.sw, f.d_hits, st),
                 WAX_HIP_ERR_INTERNAL, "select kernel launch");
-        std::vector<wax_hip_hit> hits((size_t)k_eff);
-        HIP_TRY(hipMemcpyAsync(hits.data(), f.d_hits, (size_t)k_eff * sizeof(wax_hip_hit), hipMemcpyDeviceToHost, st),
+        HIP_TRY(hipMemcpyAsync(f.h_hits, f.d_hits, (size_t)k_eff * sizeof(wax_hip_hit), hipMemcpyDeviceToHost, st),
                 WAX_HIP_ERR_INTERNAL, "hits download");
         HIP_TRY(hipStreamSynchronize(st), WAX_HIP_ERR_INTERNAL, "filtered search failed on device");
-        int rc = hits_to_results(e->metric, hits.data(), (uint32_t)k_eff, out_ids, out_scores, out_capacity, &n);
+        int rc = hits_to_results(e->metric, f.h_hits, (uint32_t)k_eff, out_ids, out_scores, out_capacity, &n);
         if (rc != WAX_HIP_OK) return rc;
         e->st_searches++;
         e->st_rows += m;
@@ -2088,6 +2188,7 @@ int wax_hip_deserialize(wax_hip_engine* e, const uint8_t* data, size_t len) {
     WriteGuard w(e->lock);  // withWriteLock (:717)
     sync_shard_work(e);
     e->batch.mirror_valid = false;
+    e->idhash.valid = false;
     e->batch.mirror_wanted = 0;
     e->pend_rows.store(0, std::memory_order_release);   // the store is replaced wholesale: staged appends are dropped with it
     // :790-792 — capacity only grows
@@ -2149,6 +2250,7 @@ int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value) {
     else if (k == "batch_onepass") e->batch_onepass = value;
     else if (k == "batch_onepass_tiles") { if (value < 1024) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_onepass_tiles must be >= 1024"); e->batch_onepass_tiles = value; }
     else if (k == "batch_survivors") { if (value < 2 || value > 64) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_survivors must be 2..64"); e->batch_survivors = value; }
+    else if (k == "filter_device_min") { if (value < -1) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "filter_device_min must be >= -1"); e->filter_device_min = value; }
     else if (k == "batch_sample_div") { if (value < 4 || value > 4096) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_sample_div must be 4..4096"); e->batch_sample_div = value; }
     else if (k == "batch_workspaces") {
         if (value < 1 || value > 16) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_workspaces must be 1..16");
@@ -2201,6 +2303,8 @@ int64_t wax_hip_get_tuning(wax_hip_engine* e, const char* key) {
     if (k == "batch_workspaces") return e->bctx_max;
     if (k == "batch_max_k") return kBatchMaxK;
     if (k == "onepass_queries") return (int64_t)e->st_onepass_queries.load();
+    if (k == "filter_device_min") return e->filter_device_min.load();
+    if (k == "filter_device_searches") return (int64_t)e->st_filter_device.load();
     if (k == "batch_queries") return (int64_t)e->st_batch_queries.load();
     if (k == "batch_fallbacks") return (int64_t)e->st_batch_fallbacks.load();
     if (k == "slots") return e->max_slots;

@@ -177,4 +177,15 @@ hipError_t launch_finalize_batch(const int64_t* cand, uint32_t cand_cap, const u
                                  const uint64_t* ids, uint32_t row_base, uint32_t n_rows, uint32_t nq,
                                  wax_hip_hit* out, uint32_t out_stride, uint32_t* certified, hipStream_t stream);
 
+
+// ---- filter.hip: allow-list pre-filter on the device (id -> row table in HBM, bitmap, compaction) ----
+hipError_t launch_idhash_build(const uint64_t* ids, uint32_t n, uint32_t* table, uint64_t slots, hipStream_t st);
+uint32_t filter_bitmap_blocks(uint32_t n_rows);
+// probe + per-block popcounts + exclusive scan; *total = number of distinct allowed rows present in the store
+hipError_t launch_allow_probe(const uint64_t* d_allow, uint64_t n_allow, const uint64_t* ids, uint32_t n_rows,
+                              const uint32_t* table, uint64_t slots, uint32_t* bitmap, uint32_t* block_sum, uint32_t* total,
+                              hipStream_t st);
+hipError_t launch_allow_emit(const uint32_t* bitmap, uint32_t n_rows, const uint32_t* block_off, const uint64_t* ids,
+                             uint32_t* rows_out, uint64_t* ids_out, hipStream_t st);
+
 }  // namespace wax
