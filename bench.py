@@ -56,12 +56,23 @@ def parse_args():
     p.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     p.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
+                   help="experiments: wax_hip_set_tuning(KEY, VALUE) on every engine the bench creates (repeatable)")
     p.add_argument("--no-secondary", action="store_true", help="skip the secondary configurations (N=1 only)")
     p.add_argument("--host-merge", action="store_true", help="N>1: merge gathered hits on the host instead of the device")
     p.add_argument("--exchange", choices=["rccl", "host"], default="rccl",
                    help="N>1: rccl = all-gather device buffers over RCCL (default); host = download + gloo all-gather "
                         "(control path; also lets two test ranks share one GPU with WAX_BENCH_SAME_DEVICE=1)")
     return p.parse_args()
+
+
+TUNES = []
+
+
+def apply_tunes(eng):
+    for kv in TUNES:
+        k, v = kv.split("=", 1)
+        eng.setTuning(k, int(v))
 
 
 def device_rows(torch, lo, hi, dims, dev):
@@ -95,16 +106,34 @@ def unit_queries(n, dims):
     return q.astype(np.float32)
 
 
+def usable_host_threads(omp_max):
+    """Threads this process can actually run at once: the OpenMP default capped by the affinity mask and by the cgroup
+    CPU quota (the GPU box is a container slice: 256 logical CPUs visible, cpu.max = 16 CPUs; oversubscribing the quota
+    gets the process throttled — 256 threads scan at 9.6 GB/s, 16 threads at 133 GB/s, profiles/r02/m_cpu_sweep.json)."""
+    n = omp_max
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(torch, args, dev, queries):
     """The oracle's CPU scan (C restatement of the reference's arithmetic: a3 + a5) on a bounded sample of the same
     corpus, timed on this host as BASELINE.md §3 prescribes: (i) one thread, (ii) all host threads (static row
-    partition, per-thread heap, merge). The inner loop is the metric-specialised FMA kernel (cosine: dot and |v|^2
+    partition, per-thread heap, merge; "all" = what the cgroup quota lets run at once). The inner loop is the metric-specialised FMA kernel (cosine: dot and |v|^2
     only), and the sample is first-touched by the threads that scan it (NUMA-local pages). Reported next to the GPU
     number; never the thing measured. Wax's actual CPU engine (USearch HNSW through Swift) cannot run here."""
     import oracle
     oracle.build()
     n_s = min(args.cpu_sample_rows, args.rows)
-    threads = oracle.max_threads()
+    threads = usable_host_threads(oracle.max_threads())
     sample = oracle.numa_sample(n_s, args.dims, threads)
     for lo, x in device_rows(torch, 0, n_s, args.dims, dev):
         blk = x.cpu().numpy()
@@ -159,6 +188,7 @@ def secondary_single_query(torch, dev, rows, dims, k, steps, warmup, depth):
     eng.setTuning("time_kernels", 1)
     eng.setTuning("streams", 2)
     eng.setTuning("slots", max(depth, 2))
+    apply_tunes(eng)
 
     def run(qs):
         pending = []
@@ -214,6 +244,7 @@ def secondary_batched(torch, dev, rows, dims, nq, k, steps, warmup, label, row_b
         step()
     fb0 = eng.getTuning("batch_fallbacks")
     eng.setTuning("time_kernels", 1)
+    apply_tunes(eng)
     eng.setTuning("reset_stats", 1)
     _bracket(torch)
     t0 = time.perf_counter()
@@ -252,6 +283,7 @@ def secondary_batched(torch, dev, rows, dims, nq, k, steps, warmup, label, row_b
 
 def main():
     args = parse_args()
+    TUNES.extend(args.tune)
     # RCCL / CUDA-tensor IPC on this driver stack needs dmabuf IPC (the image exports it; keep it if launched bare)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
@@ -330,6 +362,7 @@ def main():
         probe = x[0].cpu().numpy()
 
     eng.setTuning("time_kernels", 1)
+    apply_tunes(eng)
     if in_library and args.exchange == "rccl" and not os.environ.get("WAX_BENCH_SAME_DEVICE"):
         eng.setTuning("exchange", 1)        # one ncclAllGather per query on the library's single-process communicator
     if world == 1:

@@ -281,7 +281,8 @@ int wax_hip_stats(wax_hip_engine* e, wax_hip_stats_t* out);
  * "batch_onepass" (0 = always the slab pipeline), "batch_onepass_tiles" (smallest store, in 64-row GEMM tiles, that the one-pass
  * pipeline takes; default 1024), "batch_survivors" (one-pass: expected survivors per query as a multiple of k', default 8),
  * "batch_sample_div" (one-pass: 1/this of the tiles are sampled for the thresholds, default 64), "batch_workspaces" (concurrent
- * batched searches per engine, default 4), "filter_device_min" (wax_hip_search_filtered: allow-lists at least this long are resolved by
+ * batched searches per engine, default 4), "share_timing" (1 = a chained scan whose predecessor is still in flight uses that scan's end-of-kernel event as its own start
+ * event: one packet less between scans; 0 = every scan records its own start), "filter_device_min" (wax_hip_search_filtered: allow-lists at least this long are resolved by
  * the device-side id -> row table instead of host probes, default 4096; -1 = never),
  * "batch_slab_mb", "batch_growth", "batch_first" (slab schedule of the slab pipeline), "batch_rega" (0 LDS-tiled GEMM
  * only, 1 register-resident GEMM with register staging, 2 with LDS-DMA staging), "batch_debug" (timing experiments:

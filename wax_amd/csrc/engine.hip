@@ -188,6 +188,7 @@ struct Slot {
     int index = 0;
     hipStream_t stream = nullptr;  // one of the engine's streams (not owned)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr;
+    hipEvent_t t_start = nullptr, t_end = nullptr;   // the events that bracket this ticket's scan kernel (not owned)
     float* d_query = nullptr;
     float* h_query = nullptr;  // pinned
     int64_t* d_partials = nullptr;
@@ -321,6 +322,15 @@ struct wax_hip_engine {
     hipEvent_t scan_done = nullptr;
     hipEvent_t chain_event = nullptr;  // event the next chained scan waits on: scan_done or the last scan's end-of-kernel timing event
     bool scan_done_valid = false;
+    // End-of-kernel timing events of chained scans come from this ring (not from the slot): the end of scan i is also
+    // the START of scan i+1 when i is still in flight at i+1's submit, so only two packets (record, wait) sit between
+    // two scans instead of three. A ring entry is re-recorded kTimingRing chained scans later — more than the
+    // kHardSlotCap tickets that can be outstanding — so both tickets that read it have been collected by then.
+    static constexpr int kTimingRing = 1024;
+    hipEvent_t tev[kTimingRing] = {};
+    uint32_t tev_next = 0;
+    bool chain_is_timing = false;
+    std::atomic<int64_t> share_timing{1};
     std::mutex chain_mu;
 
     std::mutex slot_mu;
@@ -341,6 +351,7 @@ struct wax_hip_engine {
     float* ring_h_query[kShardRing] = {};
     int64_t* ring_d_partials[kShardRing] = {};
     hipEvent_t ring_ev0[kShardRing] = {}, ring_ev1[kShardRing] = {};
+    hipEvent_t ring_t0[kShardRing] = {}, ring_t1[kShardRing] = {};   // the events that bracket the entry's scan (not owned)
     bool ring_ev_pending[kShardRing] = {};
     // Completion of everything the entry's last use enqueued on the caller's stream (query upload, scan, merge):
     // waited for before the entry is reused (its pinned query and partials are still being read until then) and by
@@ -662,7 +673,7 @@ struct Enqueued { int k_eff; };
 // The scan + select chain for one query on `stream`; leaves kpad hits in d_hits.
 int enqueue_scan(wax_hip_engine* e, const float* d_query, float q_norm, int k_eff, int kpad, int64_t* d_partials,
                  Slot* general_slot, wax_hip_hit* d_hits, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1,
-                 bool chain = false) {
+                 bool chain = false, hipEvent_t* used_start = nullptr, hipEvent_t* used_end = nullptr) {
     ScanArgs a{};
     a.store = e->d_store;
     a.query = d_query;
@@ -680,9 +691,27 @@ int enqueue_scan(wax_hip_engine* e, const float* d_query, float q_norm, int k_ef
         chain_guard.lock();
         if (e->scan_done_valid) HIP_TRY(hipStreamWaitEvent(stream, e->chain_event, 0), WAX_HIP_ERR_INTERNAL, "scan chain wait");
     }
+    if (used_start) *used_start = ev0;
+    if (used_end) *used_end = ev1;
     if (fused) {
         const int cap = k_eff <= 64 ? 128 : 256;
-        if (ev0) HIP_TRY(hipEventRecord(ev0, stream), WAX_HIP_ERR_INTERNAL, "event record");
+        bool record_start = ev0 != nullptr;
+        if (chain_guard.owns_lock() && ev0 && ev1 && used_start && used_end && e->share_timing.load() != 0) {
+            hipEvent_t& slot_ev = e->tev[e->tev_next % wax_hip_engine::kTimingRing];
+            if (!slot_ev && hipEventCreateWithFlags(&slot_ev, hipEventReleaseToDevice) != hipSuccess) slot_ev = nullptr;
+            if (slot_ev) {
+                ++e->tev_next;
+                ev1 = slot_ev;
+                // previous scan still in flight: this one starts when that one ends, and that moment is already recorded
+                if (e->scan_done_valid && e->chain_is_timing && hipEventQuery(e->chain_event) == hipErrorNotReady) {
+                    ev0 = e->chain_event;
+                    record_start = false;
+                }
+                *used_start = ev0;
+                *used_end = ev1;
+            }
+        }
+        if (record_start) HIP_TRY(hipEventRecord(ev0, stream), WAX_HIP_ERR_INTERNAL, "event record");
         HIP_TRY(launch_scan(a, e->metric, (int)e->variant.load(), cap, false, (int)e->grid_blocks.load(), stream, &grid),
                 WAX_HIP_ERR_INTERNAL, "scan kernel launch");
         if (ev1) HIP_TRY(hipEventRecord(ev1, stream), WAX_HIP_ERR_INTERNAL, "event record");
@@ -691,9 +720,11 @@ int enqueue_scan(wax_hip_engine* e, const float* d_query, float q_norm, int k_ef
             // as the chain event when kernels are timed — every packet between two scans costs microseconds
             if (ev1) {
                 e->chain_event = ev1;
+                e->chain_is_timing = true;
             } else {
                 HIP_TRY(hipEventRecord(e->scan_done, stream), WAX_HIP_ERR_INTERNAL, "scan chain record");
                 e->chain_event = e->scan_done;
+                e->chain_is_timing = false;
             }
             e->scan_done_valid = true;
             chain_guard.unlock();
@@ -743,7 +774,8 @@ void harvest_ring_event(wax_hip_engine* e, int r) {
     if (!e->ring_ev_pending[r]) return;
     e->ring_ev_pending[r] = false;
     float ms = 0.f;
-    if (hipEventSynchronize(e->ring_ev1[r]) == hipSuccess && hipEventElapsedTime(&ms, e->ring_ev0[r], e->ring_ev1[r]) == hipSuccess) {
+    if (e->ring_t0[r] && e->ring_t1[r] && hipEventSynchronize(e->ring_t1[r]) == hipSuccess &&
+        hipEventElapsedTime(&ms, e->ring_t0[r], e->ring_t1[r]) == hipSuccess) {
         e->st_last_ms = ms; e->st_total_ms += ms; e->st_timed += 1;
     }
 }
@@ -1318,6 +1350,7 @@ void wax_hip_engine_destroy(wax_hip_engine* e) {
     for (int i = 0; i < kMaxStreams; ++i)
         if (e->streams[i]) (void)hipStreamDestroy(e->streams[i]);
     if (e->scan_done) (void)hipEventDestroy(e->scan_done);
+    for (hipEvent_t ev : e->tev) if (ev) (void)hipEventDestroy(ev);
     if (e->h_pend) (void)hipHostFree(e->h_pend);
     for (int i = 0; i < kShardRing; ++i) {
         (void)hipFree(e->ring_d_query[i]);
@@ -1601,7 +1634,7 @@ static int submit_impl(wax_hip_engine* e, const float* query, uint32_t dims, int
         // The last kernel of the chain writes the k hits straight into the slot's pinned host buffer
         // (device-visible, 16*k bytes over PCIe): no D2H copy launch; visibility at ev_done.
         rc = enqueue_scan(e, s->d_query, qn, k_eff, k_eff, s->d_partials, s, s->h_hits, s->stream,
-                          s->timed ? s->ev0 : nullptr, s->timed ? s->ev1 : nullptr, /*chain=*/true);
+                          s->timed ? s->ev0 : nullptr, s->timed ? s->ev1 : nullptr, /*chain=*/true, &s->t_start, &s->t_end);
         if (rc != WAX_HIP_OK) break;
         err = hipEventRecord(s->ev_done, s->stream);
         if (err != hipSuccess) { rc = fail(WAX_HIP_ERR_INTERNAL, std::string("event record: ") + hipGetErrorString(err)); break; }
@@ -1655,7 +1688,7 @@ static int collect_impl(wax_hip_engine* e, uint64_t ticket, uint64_t* out_ids, f
         } else {
             if (s->timed) {
                 float ms = 0.f;
-                if (hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess) {
+                if (s->t_start && s->t_end && hipEventElapsedTime(&ms, s->t_start, s->t_end) == hipSuccess) {
                     std::unique_lock<std::mutex> sg(e->st_mu);
                     e->st_last_ms = ms; e->st_total_ms += ms; e->st_timed += 1;
                 }
@@ -1959,7 +1992,7 @@ int wax_hip_search_shard_device(wax_hip_engine* e, const float* query, uint32_t 
         // merge kernel and whatever the caller enqueues next (RCCL all-gather, merge, download) do
         // overlap the following scan.
         rc = enqueue_scan(e, e->ring_d_query[r], qn, k_eff, kpad, e->ring_d_partials[r], nullptr, d_out_hits, st,
-                          timed ? e->ring_ev0[r] : nullptr, timed ? e->ring_ev1[r] : nullptr, /*chain=*/true);
+                          timed ? e->ring_ev0[r] : nullptr, timed ? e->ring_ev1[r] : nullptr, /*chain=*/true, &e->ring_t0[r], &e->ring_t1[r]);
         if (rc == WAX_HIP_OK && timed) {
             std::unique_lock<std::mutex> sg(e->st_mu);
             e->ring_ev_pending[r] = true;
@@ -2250,6 +2283,7 @@ int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value) {
     else if (k == "batch_onepass") e->batch_onepass = value;
     else if (k == "batch_onepass_tiles") { if (value < 1024) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_onepass_tiles must be >= 1024"); e->batch_onepass_tiles = value; }
     else if (k == "batch_survivors") { if (value < 2 || value > 64) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_survivors must be 2..64"); e->batch_survivors = value; }
+    else if (k == "share_timing") e->share_timing = value != 0;   // 0: every chained scan records its own start event (one more packet between scans)
     else if (k == "filter_device_min") { if (value < -1) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "filter_device_min must be >= -1"); e->filter_device_min = value; }
     else if (k == "batch_sample_div") { if (value < 4 || value > 4096) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_sample_div must be 4..4096"); e->batch_sample_div = value; }
     else if (k == "batch_workspaces") {
@@ -2303,6 +2337,7 @@ int64_t wax_hip_get_tuning(wax_hip_engine* e, const char* key) {
     if (k == "batch_workspaces") return e->bctx_max;
     if (k == "batch_max_k") return kBatchMaxK;
     if (k == "onepass_queries") return (int64_t)e->st_onepass_queries.load();
+    if (k == "share_timing") return e->share_timing.load();
     if (k == "filter_device_min") return e->filter_device_min.load();
     if (k == "filter_device_searches") return (int64_t)e->st_filter_device.load();
     if (k == "batch_queries") return (int64_t)e->st_batch_queries.load();
