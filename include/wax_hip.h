@@ -215,6 +215,17 @@ int wax_hip_search_batch_hits(wax_hip_engine* e, const float* queries, uint32_t 
 int wax_hip_search_batch_hits_device(wax_hip_engine* e, const float* d_queries, uint32_t nq, uint32_t dims, int32_t top_k,
                                      wax_hip_hit* d_out_hits, uint32_t out_stride, void* stream);
 
+/* Pipelined form (the batched counterpart of wax_hip_search_submit / _collect, i.e. of the command-buffer overlap the
+ * reference gets from MTLCommandQueue): submit enqueues the whole batch on one of the engine's batch workspaces, ordered
+ * behind `stream`, and returns at once with a ticket; collect waits for it, re-runs uncertified queries on the exact path
+ * in place, and reports how many that were (out_fallbacks may be NULL). With two or more tickets in flight the next batch's
+ * launches and the host's wake-up hide under the running batch. d_queries / d_out_hits must stay valid and untouched until
+ * collect. At most "batch_workspaces" (default 4) tickets per engine; a ticket holds the engine's read lock like a
+ * single-query ticket (writers are refused with WAX_HIP_ERR_INVALID_ARGUMENT while the calling thread holds one). */
+int wax_hip_search_batch_submit_device(wax_hip_engine* e, const float* d_queries, uint32_t nq, uint32_t dims, int32_t top_k,
+                                       wax_hip_hit* d_out_hits, uint32_t out_stride, void* stream, uint64_t* out_ticket);
+int wax_hip_search_batch_collect_device(wax_hip_engine* e, uint64_t ticket, uint32_t* out_fallbacks);
+
 /* ---- sharded search: per-shard top-k left in HBM for the RCCL exchange ---- */
 
 /* Declares that this engine holds rows [row_base, row_base+count) of a corpus
@@ -279,9 +290,10 @@ int wax_hip_stats(wax_hip_engine* e, wax_hip_stats_t* out);
  * "batch_mode" (0 = never use the MFMA batched path), "batch_min" (smallest batch that may use it, default 1; below 16 queries a cost model picks
  * the cheaper of one GEMM pass over the bf16 mirror and nq f32 scans),
  * "batch_onepass" (0 = always the slab pipeline), "batch_onepass_tiles" (smallest store, in 64-row GEMM tiles, that the one-pass
- * pipeline takes; default 1024), "batch_survivors" (one-pass: expected survivors per query as a multiple of k', default 8),
- * "batch_sample_div" (one-pass: 1/this of the tiles are sampled for the thresholds, default 64), "batch_workspaces" (concurrent
- * batched searches per engine, default 4), "share_timing" (1 = a chained scan whose predecessor is still in flight uses that scan's end-of-kernel event as its own start
+ * pipeline takes; default 1024), "batch_survivors" (one-pass: floor of the expected survivors per query as a multiple of k', default 3),
+ * "batch_sample_div" (one-pass: 1/this of the tiles are sampled for the thresholds, default 32, at most 512 tiles / 8 tile rounds), "batch_workspaces" (concurrent
+ * batched searches per engine, default 4), "batch_dynamic" (one-pass pipeline: 1 = the filtering GEMM's workgroups claim their tiles from a counter instead of a static
+ * stride, so that a workgroup delayed by another batch's kernels does not finish last; default 1), "share_timing" (1 = a chained scan whose predecessor is still in flight uses that scan's end-of-kernel event as its own start
  * event: one packet less between scans; 0 = every scan records its own start), "filter_device_min" (wax_hip_search_filtered: allow-lists at least this long are resolved by
  * the device-side id -> row table instead of host probes, default 4096; -1 = never),
  * "batch_slab_mb", "batch_growth", "batch_first" (slab schedule of the slab pipeline), "batch_rega" (0 LDS-tiled GEMM

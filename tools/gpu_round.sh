@@ -144,6 +144,26 @@ PYEOF
     onepass)
       timeout 600 python tools/batch_bench.py --nq 256 1024 --onepass 1 0 > "$OUT/onepass_bench.log" 2>&1; rc=$?
       timeout 300 python tools/batch_bench.py --rows 1250000 --dims 768 --nq 1024 --reps 3 --onepass 1 0 > "$OUT/onepass768_bench.log" 2>&1 ;;
+    regaablate)
+      # ablation of the filtering GEMM (one-pass pipeline) by debug bits: 1 no corpus loads after the prologue, 2 no MFMA work,
+      # 4 no per-tile barrier (with 1), 8 no selection, 16 both waves of a SIMD in the same order. gemm_kernel_us is the number to read.
+      timeout 900 python tools/batch_bench.py --nq 256 --reps 4 --rega 1 2 --debug 0 8 9 10 11 15 16 > "$OUT/rega_ablate.log" 2>&1; rc=$?
+      timeout 600 python tools/batch_bench.py --nq 1024 --reps 3 --rega 1 --debug 0 8 9 10 11 > "$OUT/rega_ablate_q1024.log" 2>&1 ;;
+    pipetrace)
+      for timed in 1 0; do
+        (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/prof_pipe$timed" -o p -- \
+            python "$R/tools/pipeline_trace.py" --timed $timed > "$OUT/pipe_timed$timed.log" 2>&1)
+        f=$(find "$OUT/prof_pipe$timed" -name "*kernel_trace.csv" | head -1)
+        [ -n "$f" ] && python "$R/tools/trace_timeline.py" "$f" 36 > "$OUT/pipe_timeline_timed$timed.csv" 2>/dev/null
+        rm -rf "$OUT/prof_pipe$timed"
+      done
+      python tools/pipeline_trace.py --timed 0 > "$OUT/pipe_untimed_noprof.log" 2>&1
+      python tools/pipeline_trace.py --timed 1 > "$OUT/pipe_timed_noprof.log" 2>&1; rc=$? ;;
+    selablate)
+      # selection cost split (filtering GEMM, one-pass): debug 8 = no selection, 64 = hot test only, 0 = full; survivor targets 8 / 4 / 2
+      timeout 900 python tools/batch_bench.py --nq 256 1024 --reps 20 --rega 1 --debug 0 64 8 --survivors 8 > "$OUT/sel_ablate.log" 2>&1; rc=$?
+      timeout 600 python tools/batch_bench.py --nq 256 1024 --reps 20 --rega 1 --survivors 4 2 > "$OUT/sel_survivors.log" 2>&1
+      timeout 600 python tools/batch_bench.py --rows 1250000 --dims 768 --nq 1024 --reps 10 --debug 0 64 8 > "$OUT/sel_ablate768.log" 2>&1 ;;
     w4)
       timeout 600 python tools/batch_bench.py --nq 256 1024 --rega 1 3 1 3 > "$OUT/w4_bench.log" 2>&1; rc=$?
       (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_w4" -o w4 -- \

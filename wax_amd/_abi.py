@@ -97,6 +97,9 @@ SIGNATURES: Dict[str, tuple] = {
     "wax_hip_search_batch_hits": (ctypes.c_int, [_engine_p, _f32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int32, _hitp, ctypes.c_uint32, _u32p]),
     "wax_hip_search_batch_hits_device": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int32,
                                                         ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]),
+    "wax_hip_search_batch_submit_device": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int32,
+                                                          ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, _u64p]),
+    "wax_hip_search_batch_collect_device": (ctypes.c_int, [_engine_p, ctypes.c_uint64, _u32p]),
     "wax_hip_set_row_base": (ctypes.c_int, [_engine_p, ctypes.c_uint64]),
     "wax_hip_search_shard_device": (ctypes.c_int, [_engine_p, _f32p, ctypes.c_uint32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     "wax_hip_merge_hits_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]),

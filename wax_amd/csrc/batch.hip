@@ -398,8 +398,20 @@ typedef __attribute__((address_space(1))) const void global_cvoid;
 template <int N>
 __device__ inline void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// Claim the next tile of a group: a returning global atomic whose result is NOT waited for here. (HIP's atomicAdd is
+// rewritten by the compiler's atomic optimizer into bcnt + atomic + `s_waitcnt vmcnt(0)` + readfirstlane on the spot,
+// which also drains the tile loads issued just before it — the whole prefetch.) The caller executes
+// `s_waitcnt vmcnt(0)` (claim_wait) before reading the value; the compiler's own counted waits only ever over-wait
+// because of the extra request in flight.
+__device__ __forceinline__ unsigned int claim_tile_async(uint32_t* ctr) {
+    unsigned int old;
+    asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(old) : "v"(ctr), "v"(1u) : "memory");
+    return old;
+}
+__device__ __forceinline__ void claim_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 template <int D>
-constexpr int rega_lds_tiles(bool glds) { return (glds && 3 * 64 * (D * 2 + 16) + 3072 <= 160 * 1024) ? 3 : 2; }
+constexpr int rega_lds_tiles(bool glds) { return (glds && 3 * 64 * (D * 2 + 16) + 3088 <= 160 * 1024) ? 3 : 2; }
 
 // SAMPLE = true (one-pass pipeline, threshold estimation): instead of filtering against a threshold, the workgroup
 // visits `a.sample_tiles` tiles spread evenly over the slab (logical index i -> tile i * ntiles / sample_tiles) and
@@ -426,6 +438,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
     float* tau_s = reinterpret_cast<float*>(smem + NBUF * BUF_B);              // [8][32] exact thresholds
     unsigned int* cnt_s = reinterpret_cast<unsigned int*>(tau_s + 8 * 32);     // [8][32] survivors per query (this workgroup)
     float* sim_s = reinterpret_cast<float*>(cnt_s + 8 * 32);                   // [8][32] conservative similarity bounds
+    unsigned int* next_s = reinterpret_cast<unsigned int*>(sim_s + 8 * 32);    // [2] claimed tile indices (dynamic tile order)
 
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
@@ -516,7 +529,17 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
         else wait_vmcnt<PPW - 1>();
     };
 
+    // Tile order. Static: bidx, bidx + W, bidx + 2W, ... (W = workgroups per group). Dynamic (a.tile_ctr, register
+    // staging only): the first two tiles are the static ones, every further one is claimed from the group's counter one
+    // iteration before its loads are issued — thread 0 starts the atomic at the top of an iteration and parks the
+    // result in LDS at its end, next to the tile barrier, so its latency never sits on the critical path.
+    const bool dyn = !SAMPLE && !GLDS && a.tile_ctr != nullptr;
     uint32_t t = bidx;
+    if (dyn && tid == 0) {
+        const unsigned int c0 = claim_tile_async(a.tile_ctr + group * 32u);
+        claim_wait();
+        next_s[0] = 2u * blocks_per_group + c0;
+    }
     if (GLDS) {
         bool second = false;
         if (t < ntiles) dma_tile(t, 0u);
@@ -611,7 +634,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             hit[r >> 2] |= __ballot(acc0[r] >= lo[r >> 2][r & 3]) | __ballot(acc1[r] >= lo[r >> 2][r & 3]);   // NaN fails
-        if ((hit[0] | hit[1] | hit[2] | hit[3]) == 0ull) return;
+        if ((hit[0] | hit[1] | hit[2] | hit[3]) == 0ull || (a.debug & 64u)) return;   // debug bit6: hot test only (timing experiments)
         const uint32_t row0 = a.slab0 + tile * TROWS + (lane & 31);
         const uint32_t row1 = row0 + 32;
         const bool ok0 = row0 < slab_end, ok1 = row1 < slab_end;
@@ -651,10 +674,14 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
 
     uint32_t it = 0;
     uint32_t cur_idx = 0;                                     // GLDS: it % NBUF
-    for (; t < ntiles; t += blocks_per_group, ++it) {
+    uint32_t t_prev = 0;                                      // the tile of the previous iteration (late waves select it now)
+    uint32_t t_next = t + blocks_per_group;                   // register staging: the tile whose loads this iteration issues
+    for (; t < ntiles; ++it) {
         unsigned char* cur;
         unsigned char* nxt = buf0;
         uint32_t tn;
+        uint32_t t_after = 0;                                 // register staging: the tile after t_next
+        unsigned int claimed = 0;
         bool issued = false;
         if (GLDS) {
             cur = buf0 + cur_idx * BUF_B;
@@ -665,16 +692,23 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
         } else {
             cur = buf0 + ((dbg_noload ? 0u : (it & 1u)) * BUF_B);  // debug bit0: always the prologue tile
             nxt = buf0 + ((it & 1) ^ 1) * BUF_B;
-            tn = t + blocks_per_group;
+            tn = t_next;
             if (tn < ntiles && !dbg_noload) issue_loads(tn);
+            if (dyn) {
+                t_after = next_s[it & 1u];
+                if (tid == 0 && t_after < ntiles) claimed = claim_tile_async(a.tile_ctr + group * 32u);   // read at the end of the iteration
+            } else {
+                t_after = tn + blocks_per_group;
+            }
         }
         if (late) {
-            if (it > 0) select_tile(t - blocks_per_group);
+            if (it > 0) select_tile(t_prev);
             mfma_tile(cur);
         } else {
             mfma_tile(cur);
             select_tile(t);
         }
+        t_prev = t;
         if (GLDS) {
             // tile t + 1 must have landed (every wave waits for its own pieces, the barrier joins them); with
             // three tiles in LDS the one requested in this iteration stays in flight across the barrier
@@ -682,12 +716,19 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             cur_idx = cur_idx + 1 == (uint32_t)NBUF ? 0u : cur_idx + 1;
+            t += blocks_per_group;
         } else {
             if (tn < ntiles && !dbg_noload) store_tile(nxt);
+            if (dyn && tid == 0) {
+                claim_wait();
+                next_s[(it + 1u) & 1u] = t_after < ntiles ? 2u * blocks_per_group + claimed : t_after;
+            }
             if (!(a.debug & 4u)) __syncthreads();  // debug bit2 (only with bit0): no per-tile barrier
+            t = tn;
+            t_next = t_after;
         }
     }
-    if (late && it > 0) select_tile(t - blocks_per_group);
+    if (late && it > 0) select_tile(t_prev);
     // unclamped counts: a count above seg_slots tells tighten_kernel that survivors were dropped (query -> exact path)
     __syncthreads();
     if (!SAMPLE && tid < 256) a.seg_count[(size_t)bidx * (a.nqt * 128u) + group * 256u + (uint32_t)tid] = cnt_s[tid];
@@ -721,6 +762,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_ksplit_kernel(GemmArgs a, u
     float* tau_s = reinterpret_cast<float*>(part0 + 2 * 4 * PART_B);            // [4][32] exact thresholds
     unsigned int* cnt_s = reinterpret_cast<unsigned int*>(tau_s + 4 * 32);      // [4][32] survivors per query (this workgroup)
     float* sim_s = reinterpret_cast<float*>(cnt_s + 4 * 32);                    // [4][32] conservative similarity bounds
+    unsigned int* next_s = reinterpret_cast<unsigned int*>(sim_s + 4 * 32);     // [2] claimed tile indices (dynamic tile order)
 
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
@@ -828,7 +870,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_ksplit_kernel(GemmArgs a, u
             }
             return;
         }
-        if ((hit[0] | hit[1] | hit[2] | hit[3]) == 0ull) return;
+        if ((hit[0] | hit[1] | hit[2] | hit[3]) == 0ull || (a.debug & 64u)) return;   // debug bit6: hot test only (timing experiments)
         const uint32_t row0 = a.slab0 + tile * TROWS + (lane & 31);
         const bool ok0 = row0 < slab_end;
         const lds_f32* tau_w = (const lds_f32*)(tau_s + pair * 32);
@@ -850,29 +892,53 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_ksplit_kernel(GemmArgs a, u
         }
     };
 
+    // tile order: static stride, or (a.tile_ctr) claimed from the group's counter — see batch_gemm_rega_kernel
+    const bool dyn = !SAMPLE && a.tile_ctr != nullptr;
     uint32_t t = bidx;
+    if (dyn && tid == 0) {
+        const unsigned int c0 = claim_tile_async(a.tile_ctr + group * 32u);
+        claim_wait();
+        next_s[0] = 2u * blocks_per_group + c0;
+    }
     if (t < ntiles) {
         issue_loads(t);
         store_tile(buf0);
     }
     __syncthreads();
     uint32_t it = 0;
-    for (; t < ntiles; t += blocks_per_group, ++it) {
+    uint32_t t_prev = 0;
+    uint32_t t_next = t + blocks_per_group;
+    for (; t < ntiles; ++it) {
         unsigned char* cur = buf0 + (it & 1u) * BUF_B;
         unsigned char* nxt = buf0 + ((it & 1u) ^ 1u) * BUF_B;
-        const uint32_t tn = t + blocks_per_group;
+        const uint32_t tn = t_next;
         if (tn < ntiles) issue_loads(tn);
+        uint32_t t_after;
+        unsigned int claimed = 0;
+        if (dyn) {
+            t_after = next_s[it & 1u];
+            if (tid == 0 && t_after < ntiles) claimed = claim_tile_async(a.tile_ctr + group * 32u);   // read at the end of the iteration
+        } else {
+            t_after = tn + blocks_per_group;
+        }
         if (owner) {
-            if (it > 0) select_tile(t - blocks_per_group, (it - 1u) & 1u);   // partial of tile t-1: parked before the last barrier
+            if (it > 0) select_tile(t_prev, (it - 1u) & 1u);   // partial of the previous tile: parked before the last barrier
             mfma_tile(cur);
         } else {
             mfma_tile(cur);
             park_partial(it & 1u);
         }
         if (tn < ntiles) store_tile(nxt);
+        if (dyn && tid == 0) {
+            claim_wait();
+            next_s[(it + 1u) & 1u] = t_after < ntiles ? 2u * blocks_per_group + claimed : t_after;
+        }
         __syncthreads();
+        t_prev = t;
+        t = tn;
+        t_next = t_after;
     }
-    if (owner && it > 0) select_tile(t - blocks_per_group, (it - 1u) & 1u);
+    if (owner && it > 0) select_tile(t_prev, (it - 1u) & 1u);
     __syncthreads();
     if (!SAMPLE && tid < 128) a.seg_count[(size_t)bidx * (a.nqt * 128u) + group * 128u + (uint32_t)tid] = cnt_s[tid];
 }
@@ -1242,7 +1308,7 @@ bool batch_gemm_segments(const GemmArgs& a, int metric, uint32_t* nseg, uint32_t
 
 template <int D, int AHEAD>
 static hipError_t launch_ksplit(const GemmArgs& a, hipStream_t st) {
-    constexpr size_t smem = 2 * 32 * (D * 2 + 16) + 2 * 4 * (4 * 64 * 16) + 3 * 4 * 32 * 4;  // tiles, partial sums, thresholds / counters / bounds
+    constexpr size_t smem = 2 * 32 * (D * 2 + 16) + 2 * 4 * (4 * 64 * 16) + 3 * 4 * 32 * 4 + 16;  // tiles, partial sums, thresholds / counters / bounds
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&batch_gemm_ksplit_kernel<D, AHEAD>),
@@ -1258,7 +1324,7 @@ static hipError_t launch_ksplit(const GemmArgs& a, hipStream_t st) {
 
 template <int D, bool GLDS, int AHEAD>
 static hipError_t launch_rega_impl(const GemmArgs& a, hipStream_t st) {
-    constexpr size_t smem = (size_t)rega_lds_tiles<D>(GLDS) * 64 * (D * 2 + 16) + 3 * 8 * 32 * 4;  // tiles, thresholds, survivor counters, bounds
+    constexpr size_t smem = (size_t)rega_lds_tiles<D>(GLDS) * 64 * (D * 2 + 16) + 3 * 8 * 32 * 4 + 16;  // tiles, thresholds, survivor counters, bounds
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&batch_gemm_rega_kernel<D, GLDS, AHEAD>),
@@ -1696,6 +1762,7 @@ __global__ __launch_bounds__(256) void batch_prep_kernel(PrepArgs a) {
     const int wave = (int)(threadIdx.x >> 6);
     const uint32_t q = blockIdx.x * 4 + (uint32_t)wave;
     if (q >= a.nq_pad) return;
+    if (q == 0 && a.tile_ctr) for (uint32_t i = lane; i < BATCH_TILE_CTRS * 32u; i += WAVE) a.tile_ctr[i] = 0u;   // one counter per 128-byte line
     const uint32_t D = a.dims;
     unsigned short* out = a.qb + (size_t)q * D;
     if (q >= a.nq) {                                     // padding query: admits nothing, matches nothing
@@ -1776,7 +1843,7 @@ hipError_t launch_batch_prep(const PrepArgs& a, hipStream_t st) {
 template <int D>
 static hipError_t launch_rega_sample(const GemmArgs& a, hipStream_t st) {
     constexpr int AHEAD = D >= 512 ? 1 : 3;
-    constexpr size_t smem = (size_t)rega_lds_tiles<D>(false) * 64 * (D * 2 + 16) + 3 * 8 * 32 * 4;
+    constexpr size_t smem = (size_t)rega_lds_tiles<D>(false) * 64 * (D * 2 + 16) + 3 * 8 * 32 * 4 + 16;
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&batch_gemm_rega_kernel<D, false, AHEAD, true>),
@@ -1801,7 +1868,7 @@ hipError_t launch_batch_gemm_sample(const GemmArgs& a, int metric, hipStream_t s
         case 512: return launch_rega_sample<512>(a, st);
         case 768: {
             constexpr int D = 768;
-            constexpr size_t smem = 2 * 32 * (D * 2 + 16) + 2 * 4 * (4 * 64 * 16) + 3 * 4 * 32 * 4;
+            constexpr size_t smem = 2 * 32 * (D * 2 + 16) + 2 * 4 * (4 * 64 * 16) + 3 * 4 * 32 * 4 + 16;
             static bool configured = false;
             if (!configured) {
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&batch_gemm_ksplit_kernel<D, 4, true>),
@@ -1821,20 +1888,27 @@ hipError_t launch_batch_gemm_sample(const GemmArgs& a, int metric, hipStream_t s
     return hipErrorInvalidValue;
 }
 
-// Admission thresholds from the sampled tile maxima, by pure reductions: the sampled tiles are dealt round-robin into
-// G groups (every group spans the whole store), tau_sim = min over the groups of the group's best tile maximum. At
-// least G sampled rows (one per group) reach it; for well-mixed data the number of sampled TILES whose best row
-// reaches it has median ~ c(G) G with c(G) = -ln(1 - 2^(-1/G)) (G = 4: 7.4, 8: 20, 16: 51, 32: 123), and a short
-// upper tail: P(more than x) <= G (1 - x/S)^(S/G). (A rank-th order statistic by sorting — the first version — was a
-// 18 us latency chain per batch; this is ~3 us.) Workgroup = 32 queries x 32 slices; thread (query, slice) takes the
-// maximum over tiles i = slice, slice + 32, ...; G divides 32, so a slice lies in group slice % G.
+// One-pass pipeline, step 3: per query, the admission threshold of the filtering GEMM from the sampled tile maxima:
+// tau_sim = the `rank`-th largest of the `sample_tiles` per-tile best similarities (rank <= PICK_J). A sampled row above
+// the threshold puts its tile's maximum above it, and the top few rows of a sample sit in distinct tiles, so the
+// number of SAMPLED rows above tau_sim is ~rank and the number in the whole store is Gamma(rank) / f (f = sampled
+// fraction): relative spread 1/sqrt(rank) (29 % at rank 12), against ~50 % with a heavy lower tail for the minimum of
+// a few group maxima used before — what lets the planner aim at ~3 k' survivors instead of ~10 k' for the same risk of
+// a threshold that admits fewer than k rows. (Two top rows sharing a tile only loosen the threshold.)
+// Workgroup = 32 queries x 32 slices. Phase 1: thread (query, slice) keeps the PICK_J largest of its tiles i = slice,
+// slice + 32, ... in a sorted register list (coalesced: 32 consecutive queries per tile row). Phase 2, through LDS:
+// a wave takes two queries, lane = slice; `rank` rounds of {maximum of the 32 list heads by DPP, the first lane holding
+// it pops}; the last maximum is the answer. ~4 us; a full sort per query — the first version — was an 18 us chain.
+constexpr int PICK_J = 12;
 __global__ __launch_bounds__(1024) void pick_tau_kernel(const float* __restrict__ tile_max, uint32_t sample_tiles,
-                                                        uint32_t nq, uint32_t nq_pad, uint32_t groups,
+                                                        uint32_t nq, uint32_t nq_pad, uint32_t rank,
                                                         float* __restrict__ tau) {
-    __shared__ float part[32][33];
+    __shared__ float lists[PICK_J][32][33];                   // [position][slice][query]
     const uint32_t qi = threadIdx.x & 31u, slice = threadIdx.x >> 5;
     const uint32_t q = blockIdx.x * 32u + qi;                 // < nq_pad (tile_max rows are nq_pad wide)
-    float m = -__builtin_inff();
+    float top[PICK_J];
+#pragma unroll
+    for (int p = 0; p < PICK_J; ++p) top[p] = -__builtin_inff();
     constexpr uint32_t U = 8;
     for (uint32_t i0 = slice; i0 < sample_tiles; i0 += 32u * U) {
         float v[U];
@@ -1844,27 +1918,50 @@ __global__ __launch_bounds__(1024) void pick_tau_kernel(const float* __restrict_
             v[u] = (i < sample_tiles) ? tile_max[(size_t)i * nq_pad + q] : -__builtin_inff();
         }
 #pragma unroll
-        for (uint32_t u = 0; u < U; ++u) m = __builtin_fmaxf(m, v[u]);     // maxNum: a NaN tile maximum never wins
-    }
-    part[slice][qi] = m;
-    __syncthreads();
-    if (slice == 0 && q < nq) {
-        float t = __builtin_inff();
-        for (uint32_t g = 0; g < groups; ++g) {
-            float gm = -__builtin_inff();
-            for (uint32_t sl = g; sl < 32u; sl += groups) gm = __builtin_fmaxf(gm, part[sl][qi]);
-            t = __builtin_fminf(t, gm);
+        for (uint32_t u = 0; u < U; ++u) {
+            float x = v[u];
+            if (!(x > top[PICK_J - 1])) continue;             // also drops NaN
+#pragma unroll
+            for (int p = 0; p < PICK_J; ++p) {                // insertion: top stays sorted, descending
+                const float hi = __builtin_fmaxf(top[p], x);
+                x = __builtin_fminf(top[p], x);
+                top[p] = hi;
+            }
         }
-        // a group without a finite maximum (NaN query / no sampled tile): no threshold => +inf, the GEMM marks the query
+    }
+#pragma unroll
+    for (int p = 0; p < PICK_J; ++p) lists[p][slice][qi] = top[p];
+    __syncthreads();
+    // wave w: queries 2w, 2w + 1; lane l: query 2w + (l >> 5), slice l & 31
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t q2 = 2u * wave + (lane >> 5);
+    float mine[PICK_J];
+#pragma unroll
+    for (int p = 0; p < PICK_J; ++p) mine[p] = lists[p][lane & 31u][q2];
+    float kth = -__builtin_inff();
+    for (uint32_t r = 0; r < rank; ++r) {
+        kth = group_max32(mine[0]);                           // lanes 31 / 63 hold their group's maximum
+        kth = __shfl(kth, (int)(lane | 31u), 64);
+        const unsigned long long holders = __ballot(mine[0] == kth) >> (lane & 32u) & 0xffffffffull;
+        const bool pop = holders != 0ull && (uint32_t)__builtin_ctzll(holders) == (lane & 31u) && kth > -__builtin_inff();
+        if (pop) {
+#pragma unroll
+            for (int p = 0; p + 1 < PICK_J; ++p) mine[p] = mine[p + 1];
+            mine[PICK_J - 1] = -__builtin_inff();
+        }
+    }
+    const uint32_t qg = blockIdx.x * 32u + q2;
+    if ((lane & 31u) == 0u && qg < nq) {
+        // fewer than `rank` finite tile maxima (NaN query / tiny sample): no threshold => +inf, the GEMM marks the query
         // for the exact path instead of admitting the whole store
-        tau[q] = (t > -__builtin_inff()) ? 1.0f - t : __builtin_inff();
+        tau[qg] = (kth > -__builtin_inff()) ? 1.0f - kth : __builtin_inff();
     }
 }
 
-hipError_t launch_pick_tau(const float* tile_max, uint32_t sample_tiles, uint32_t nq, uint32_t nq_pad, uint32_t groups,
+hipError_t launch_pick_tau(const float* tile_max, uint32_t sample_tiles, uint32_t nq, uint32_t nq_pad, uint32_t rank,
                            float* tau, hipStream_t st) {
-    if (groups < 1 || groups > 32 || (32u % groups) != 0 || sample_tiles == 0 || (nq_pad % 32u) != 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(pick_tau_kernel, dim3((nq + 31) / 32), dim3(1024), 0, st, tile_max, sample_tiles, nq, nq_pad, groups, tau);
+    if (rank < 1 || rank > (uint32_t)PICK_J || sample_tiles == 0 || (nq_pad % 32u) != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pick_tau_kernel, dim3((nq + 31) / 32), dim3(1024), 0, st, tile_max, sample_tiles, nq, nq_pad, rank, tau);
     return hipGetLastError();
 }
 
@@ -1894,7 +1991,9 @@ __device__ inline bool gather_segments(WaveTopK<CAP>& tk, const int64_t* __restr
 }
 
 template <int D4, int GROUP, int METRIC>
-__global__ __launch_bounds__(SCAN_THREADS) void batch_finish_kernel(FinishArgs a) {
+// At most 80 VGPRs (6 waves per SIMD): the filtering GEMM of the NEXT batch in flight leaves exactly that much of
+// every SIMD's register file free (2 waves x 216), so this kernel's workgroups can run beside it instead of behind it.
+__global__ __launch_bounds__(SCAN_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8))) void batch_finish_kernel(FinishArgs a) {
     constexpr int CAP = 256;
     constexpr int LOADS = D4 / GROUP;
     constexpr int RPW = WAVE / GROUP;

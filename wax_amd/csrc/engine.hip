@@ -385,9 +385,24 @@ struct wax_hip_engine {
     int bctx_max = 4;
     std::atomic<int64_t> batch_onepass{1};        // 0 = always the slab pipeline
     std::atomic<int64_t> batch_onepass_tiles{1024};   // smallest store (in GEMM tiles) the one-pass pipeline takes
-    std::atomic<int64_t> batch_survivors{8};      // one-pass pipeline: expected survivors per query = this x k'
-    std::atomic<int64_t> batch_sample_div{64};    // one-pass pipeline: 1 / this of the tiles are sampled (at least 256)
+    std::atomic<int64_t> batch_survivors{3};      // one-pass pipeline: expected survivors per query = this x k'
+    std::atomic<int64_t> batch_dynamic{1};        // one-pass pipeline: filtering-GEMM workgroups claim their tiles from a counter
+    std::atomic<int64_t> batch_sample_div{32};    // one-pass pipeline: 1 / this of the tiles are sampled (at least 256)
     std::atomic<uint64_t> st_onepass_queries{0};
+    // wax_hip_search_batch_submit_device tickets (guarded by bticket_mu)
+    struct BatchTicket {
+        BatchCtx* c = nullptr;           // null: the batch was answered at submit time (empty engine / loop path)
+        const float* d_queries = nullptr;
+        wax_hip_hit* d_out = nullptr;
+        uint32_t nq = 0, out_stride = 0;
+        int k_eff = 0;
+        std::thread::id owner;
+    };
+    std::mutex gemm_chain_mu;                     // "time_kernels": filtering GEMMs of concurrent batches run one after another
+    hipEvent_t gemm_chain_ev = nullptr;           // the last one's end-of-kernel event (owned by its workspace)
+    std::mutex bticket_mu;
+    std::map<uint64_t, BatchTicket> btickets;
+    uint64_t next_bticket = 1;
     std::mutex filter_mu;                         // pool of filtered-search workspaces
     std::condition_variable filter_cv;
     std::vector<FilterWork*> filter_all, filter_free;
@@ -845,7 +860,7 @@ int alloc_bctx(wax_hip_engine* e, BatchCtx** out) {
     A(&c->d_eps, kBatchMaxQ * sizeof(float));
     A(&c->d_tau, kBatchMaxQ * sizeof(float));
     A(&c->d_cand_count, (size_t)kBatchMaxQ * CAND_COUNT_STRIDE * sizeof(uint32_t));
-    A(&c->d_overflow, kBatchMaxQ * sizeof(uint32_t));
+    A(&c->d_overflow, (kBatchMaxQ + BATCH_TILE_CTRS * 32) * sizeof(uint32_t));   // + the filtering GEMM's tile counters
     A(&c->d_seg_count, (size_t)kBatchMaxSegs * kBatchMaxQ * sizeof(uint32_t));
     if (err != hipSuccess) {
         free_bctx(c);
@@ -855,7 +870,7 @@ int alloc_bctx(wax_hip_engine* e, BatchCtx** out) {
     return WAX_HIP_OK;
 }
 
-int acquire_bctx(wax_hip_engine* e, BatchCtx** out) {
+int acquire_bctx(wax_hip_engine* e, BatchCtx** out, bool try_only = false) {
     std::unique_lock<std::mutex> g(e->bctx_mu);
     for (;;) {
         if (!e->bctx_free.empty()) {
@@ -871,6 +886,8 @@ int acquire_bctx(wax_hip_engine* e, BatchCtx** out) {
             *out = c;
             return WAX_HIP_OK;
         }
+        if (try_only)
+            return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "every batch workspace is in use: collect outstanding batch tickets first (or raise \"batch_workspaces\")");
         e->bctx_cv.wait(g);
     }
 }
@@ -1042,60 +1059,86 @@ int batch_kp(int k_eff, int kp_max) {
 
 // ---- one-pass pipeline: plan -------------------------------------------------------------------------------------
 struct OnepassPlan {
-    uint32_t tile_rows, ntiles, sample_tiles, groups, seg_area;
+    uint32_t tile_rows, ntiles, sample_tiles, rank, seg_area;
     int kp;
     double expect;       // expected survivors per query
 };
 
-// tau_sim = min over G interleaved groups (L sampled tiles each) of the group's best similarity (pick_tau_kernel).
-// With well-mixed rows: a tile holds no row above tau with probability F_t; the group maxima are i.i.d. with CDF F_t^L;
-// the median of their minimum solves F_t^L = a_G := 1 - 2^(-1/G). Wanting a fraction p = target / n of all rows above
-// tau means F_t = (1 - p)^tile_rows, hence L = ln a_G / ln F_t. Small G keeps the sample (S = G L tiles) small for big
-// stores; large G is what reaches the loose thresholds a small store / a large k' needs.
+// tau_sim = the j-th largest of the S sampled tiles' best similarities (pick_tau_kernel). With well-mixed rows the
+// number of store rows above it is Gamma(j) / f, f = S * tile_rows / n the sampled fraction: mean j / f, relative spread
+// 1 / sqrt(j). The filter fails a query (exact path, ~0.25 ms) when fewer than m ~ 2.2 k rows pass — k for the answer
+// plus the rows within the bf16 error band of the k-th — i.e. with probability P(Gamma(j) < m f). The plan takes the
+// rank and sample size of least modelled cost among those whose failure probability is below 1e-6 per query (and whose
+// expected survivors are at least `batch_survivors` x k', a floor for stores that are not well mixed): survivors cost the filtering GEMM its cold path
+// (~10 % of the kernel at 10 k' survivors) and the finish kernel its gather. The minimum of G = 4 group maxima used
+// before needed ~10 k' survivors for 1e-5. Sampling costs a tile round (~3 us) per `workgroups per group` tiles and
+// visits scattered tiles, so S is held to a few rounds.
+constexpr uint32_t kPickJ = 12;      // == PICK_J (batch.hip)
+double gamma_cdf_below(uint32_t j, double x) {   // P(Gamma(j, 1) < x) = P(Poisson(x) >= j)
+    double term = std::exp(-x), sum = 0.0;
+    for (uint32_t i = 1; i <= j + 60; ++i) {
+        term *= x / (double)i;               // e^-x x^i / i!
+        if (i >= j) sum += term;
+    }
+    return sum;
+}
 bool plan_onepass(wax_hip_engine* e, uint32_t n, int k_eff, uint32_t nq, OnepassPlan* p) {
     if (e->batch_onepass.load() == 0 || !batch_onepass_dims(e->dims, e->metric) || k_eff > kBatchMaxK) return false;
     p->tile_rows = batch_tile_rows(e->dims);
     p->ntiles = (n + p->tile_rows - 1) / p->tile_rows;
     if ((int64_t)p->ntiles < e->batch_onepass_tiles.load() || p->ntiles < 1024) return false;
     p->kp = batch_kp(k_eff, 960);
-    // survivors aimed at: `batch_survivors` x k' (default 8 k': >= k' with overwhelming probability, ~2 per
-    // (workgroup, query) segment at the default segment area)
-    const double target = (double)e->batch_survivors.load() * (double)p->kp;
-    double prow = target / (double)n;
-    if (prow > 0.25) return false;                       // a quarter of the store as candidates: not a filter any more
-    const double neg_ln_ft = -(double)p->tile_rows * std::log1p(-prow);
-    uint64_t s_pref = p->ntiles / (uint64_t)e->batch_sample_div.load();
-    if (s_pref < 64) s_pref = 64;
-    if (s_pref > 192) s_pref = 192;
-    uint32_t G = 0, L = 0;
-    for (uint32_t g = 4; g <= 32; g *= 2) {
-        const double a_g = 1.0 - std::exp2(-1.0 / (double)g);
-        double l = std::floor(-std::log(a_g) / neg_ln_ft + 0.5);
-        if (l < 1.0) l = 1.0;
-        if (l * g > (double)(p->ntiles / 2)) l = std::floor((double)(p->ntiles / 2) / g);
-        G = g; L = (uint32_t)l;
-        if ((uint64_t)g * L >= s_pref) break;
-    }
-    p->groups = G;
-    p->sample_tiles = G * L;
-    // what this (G, L) is expected to admit
-    const double a_g = 1.0 - std::exp2(-1.0 / (double)G);
-    const double ft = std::pow(a_g, 1.0 / (double)L);
-    const double p_real = 1.0 - std::pow(ft, 1.0 / (double)p->tile_rows);
-    p->expect = p_real * (double)n;
-    if (p->expect < 2.0 * (double)p->kp) return false;   // cannot reach enough candidates for the certificate: other paths
-    // Survivor segments: one per (GEMM workgroup of the query's group, query). The survivor count of a query spreads
-    // widely around `expect` (measured at 1M x 384, G = 4: median 583, 56 .. 1828 over 256 queries — the threshold is the
-    // minimum of a few maxima), and a segment overflows when ITS fill does: size every segment for 8 x expect spread
-    // over the group's workgroups, + 6 sigma of a Poisson fill (an overflow only costs that query the exact path, but at
-    // 0.25 ms each two of them per batch doubled the batch time: profiles/r02/c_onepass_diag.txt).
     const uint32_t nq_blk = nq < kBatchMaxQ ? nq : kBatchMaxQ;
     const uint32_t nq_pad = (nq_blk + 255u) & ~255u;
     const uint32_t groups = e->dims == 768 ? nq_pad / 128 : nq_pad / 256;
-    uint32_t nseg = 256 / (groups ? groups : 1);
+    uint32_t nseg = 256 / (groups ? groups : 1);         // workgroups per query group == survivor segments per query
     if (nseg < 1) nseg = 1;
     if (nseg > p->ntiles) nseg = p->ntiles;
-    const double fill = 8.0 * p->expect / (double)nseg;
+    const double floor_e = (double)e->batch_survivors.load() * (double)p->kp;
+    uint64_t s_pref = p->ntiles / (uint64_t)e->batch_sample_div.load();
+    if (s_pref < 192) s_pref = 192;
+    if (s_pref > 2048) s_pref = 2048;
+    if (s_pref > 8ull * nseg) s_pref = 8ull * nseg > 192 ? 8ull * nseg : 192;   // at most 8 tile rounds
+    if (s_pref > p->ntiles / 2) s_pref = p->ntiles / 2;
+    const double rows = (double)p->tile_rows, nn = (double)n;
+    const double need = 2.2 * (double)k_eff;             // rows that must pass: k + those inside the bf16 error band of the k-th
+    // Per rank j: the expected survivors E that keep P(Gamma(j) < need * j / E) below 1e-6 (a fallback costs ~0.25 ms: 1e-6 x 1024 queries = 0.3 us per batch), the sample size that gives
+    // that E — in general E(j, S) = n (1 - (1 - j/S)^(1/tile_rows)): a fraction j/S of the tiles holds a row above the
+    // threshold; ~ j n / (S tile_rows) while j << S, and still a valid (looser) threshold when a small store or a large
+    // k forces j close to S — and a cost in microseconds: sampling rounds + cold-path survivors (profiles/r02).
+    double best_cost = 0.0;
+    p->rank = 0;
+    for (uint32_t j = 5; j <= kPickJ; ++j) {
+        double lo = 0.0, hi = (double)j;                  // x_j: P(Gamma(j) < x_j) = 1e-6
+        for (int it = 0; it < 40; ++it) {
+            const double mid = 0.5 * (lo + hi);
+            if (gamma_cdf_below(j, mid) > 1e-6) hi = mid; else lo = mid;
+        }
+        double e_need = need * (double)j / lo;
+        if (e_need < floor_e) e_need = floor_e;
+        if (e_need / nn > 0.25) continue;                 // a quarter of the store as candidates: not a filter any more
+        double s_exact = (double)j / (1.0 - std::pow(1.0 - e_need / nn, rows));
+        double st = std::floor(s_exact);
+        if (st > (double)s_pref) st = (double)s_pref;
+        if (st < (double)j + 1.0) st = (double)j + 1.0;
+        const double expect = nn * (1.0 - std::pow(1.0 - (double)j / st, 1.0 / rows));
+        if (expect / nn > 0.25) continue;
+        const double cost = std::ceil(st / (double)nseg) * 3.0 + expect * 0.031 * 256.0 / (double)nseg;
+        if (p->rank == 0 || cost < best_cost) {
+            best_cost = cost;
+            p->rank = j;
+            p->sample_tiles = (uint32_t)st;
+            p->expect = expect;
+        }
+    }
+    if (p->rank == 0) return false;
+    if (p->expect < 2.0 * (double)k_eff + 8.0) return false;   // cannot reach enough candidates for the certificate: other paths
+    // Survivor segments: one per (GEMM workgroup of the query's group, query). A query's survivor count spreads around
+    // `expect` like Gamma(rank) (x 2.3 at 1e-4 for rank 12; clustered stores spread more), and a segment overflows when
+    // ITS fill does: size every segment for 4 x expect spread over the group's workgroups, + 6 sigma of a Poisson fill
+    // (an overflow only costs that query the exact path, but at 0.25 ms each two of them per batch doubled the batch
+    // time: profiles/r02/c_onepass_diag.txt).
+    const double fill = 4.0 * p->expect / (double)nseg;
     uint64_t slots = 16;
     while ((double)slots < fill + 6.0 * std::sqrt(fill) + 4.0) slots *= 2;
     const uint64_t area = slots * nseg;
@@ -1118,6 +1161,8 @@ int batch_enqueue(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32
     pa.queries = d_queries; pa.nq = qn; pa.nq_pad = nq_pad; pa.dims = D; pa.metric = e->metric; pa.max_norm = b.max_norm;
     pa.qb = c->d_qb; pa.q_n2 = c->d_qn2; pa.q_norm = c->d_qnorm; pa.eps = c->d_eps; pa.tau = c->d_tau; pa.overflow = c->d_overflow;
     pa.cand_count = plan ? nullptr : c->d_cand_count;
+    const bool dynamic_tiles = plan != nullptr && e->batch_dynamic.load() != 0;
+    pa.tile_ctr = dynamic_tiles ? c->d_overflow + kBatchMaxQ : nullptr;
     HIP_TRY(launch_batch_prep(pa, st), WAX_HIP_ERR_INTERNAL, "batch prep launch");
     GemmArgs g{};
     g.qb = c->d_qb; g.cb = b.d_cb; g.q_n2 = c->d_qn2; g.v_n2 = b.d_vn2; g.tau = c->d_tau;
@@ -1133,15 +1178,27 @@ int batch_enqueue(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32
         if (g.use_rega == 0) g.use_rega = 1;
         GemmArgs gs = g;
         gs.tile_max = c->d_tile_max; gs.sample_tiles = plan->sample_tiles;
+        g.tile_ctr = pa.tile_ctr;
         HIP_TRY(launch_batch_gemm_sample(gs, e->metric, st), WAX_HIP_ERR_INTERNAL, "sampling gemm launch");
-        HIP_TRY(launch_pick_tau(c->d_tile_max, plan->sample_tiles, qn, nq_pad, plan->groups, c->d_tau, st), WAX_HIP_ERR_INTERNAL,
+        HIP_TRY(launch_pick_tau(c->d_tile_max, plan->sample_tiles, qn, nq_pad, plan->rank, c->d_tau, st), WAX_HIP_ERR_INTERNAL,
                 "threshold kernel launch");
         const bool timed = e->time_kernels.load() != 0;
-        if (timed) HIP_TRY(hipEventRecord(c->ev_g0, st), WAX_HIP_ERR_INTERNAL, "event record");
-        HIP_TRY(launch_batch_gemm(g, e->metric, st), WAX_HIP_ERR_INTERNAL, "gemm kernel launch");
         if (timed) {
+            // With several batches in flight (submit / collect) the filtering GEMMs of different workspaces would queue
+            // for the same CUs (one workgroup's LDS fills a CU) and an event interval would include that wait: chain
+            // them, like the single-query scans, so that a timed interval is one GEMM running alone. The small
+            // kernels before this point (prep, sampling, thresholds) still overlap the previous batch's GEMM tail
+            // and finish kernel.
+            std::unique_lock<std::mutex> cg(e->gemm_chain_mu);
+            if (e->gemm_chain_ev && e->gemm_chain_ev != c->ev_g1)
+                HIP_TRY(hipStreamWaitEvent(st, e->gemm_chain_ev, 0), WAX_HIP_ERR_INTERNAL, "gemm chain wait");
+            HIP_TRY(hipEventRecord(c->ev_g0, st), WAX_HIP_ERR_INTERNAL, "event record");
+            HIP_TRY(launch_batch_gemm(g, e->metric, st), WAX_HIP_ERR_INTERNAL, "gemm kernel launch");
             HIP_TRY(hipEventRecord(c->ev_g1, st), WAX_HIP_ERR_INTERNAL, "event record");
+            e->gemm_chain_ev = c->ev_g1;
             c->gemm_timed = true; c->gemm_rows = n; c->gemm_queries = qn;
+        } else {
+            HIP_TRY(launch_batch_gemm(g, e->metric, st), WAX_HIP_ERR_INTERNAL, "gemm kernel launch");
         }
         FinishArgs f{};
         f.cand = c->d_cand; f.cand_cap = plan->seg_area; f.seg_count = c->d_seg_count; f.nq_pad = nq_pad;
@@ -1206,8 +1263,10 @@ bool batch_mfma_applicable(wax_hip_engine* e, uint32_t dims, int k_eff, uint32_t
 // The whole batched search on device-resident queries (shared lock held, mirror ready): enqueue every block of
 // kBatchMaxQ queries back to back (no host round trip in between), one synchronisation, then the uncertified queries are
 // re-run on the exact single-query path, their hits written over the same rows of d_out. d_out rows are out_stride wide.
-int batch_search_device_locked(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32_t nq, int k_eff,
-                               const OnepassPlan* plan, wax_hip_hit* d_out, uint32_t out_stride, uint32_t* out_fallbacks) {
+// Enqueue a whole device-resident batch (blocks of <= kBatchMaxQ queries) on the workspace's stream, followed by the
+// download of the certificate flags and exact norms. Nothing is synchronised: batch_finish_device_locked completes it.
+int batch_submit_device_locked(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32_t nq, int k_eff,
+                               const OnepassPlan* plan, wax_hip_hit* d_out, uint32_t out_stride) {
     hipStream_t st = c->stream;
     const uint32_t D = e->dims;
     int rc = bctx_reserve(c, plan ? plan->seg_area : kBatchCandCap, plan ? (uint64_t)plan->kp : (uint64_t)FUSED_MAX_K,
@@ -1220,6 +1279,15 @@ int batch_search_device_locked(wax_hip_engine* e, BatchCtx* c, const float* d_qu
     }
     HIP_TRY(hipMemcpyAsync(c->h_cert, c->d_cert, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st), WAX_HIP_ERR_INTERNAL, "flags download");
     HIP_TRY(hipMemcpyAsync(c->h_qnorm, c->d_qnorm_all, nq * sizeof(float), hipMemcpyDeviceToHost, st), WAX_HIP_ERR_INTERNAL, "norm download");
+    return WAX_HIP_OK;
+}
+
+// Wait for a submitted batch; queries whose certificate failed (ties, clustered data, an overflowed list) are answered
+// by the exact path in place — never an approximation.
+int batch_finish_device_locked(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32_t nq, int k_eff,
+                               wax_hip_hit* d_out, uint32_t out_stride, uint32_t* out_fallbacks) {
+    hipStream_t st = c->stream;
+    const uint32_t D = e->dims;
     HIP_TRY(hipStreamSynchronize(st), WAX_HIP_ERR_INTERNAL, "batch search failed on device");
     if (c->gemm_timed) {
         c->gemm_timed = false;
@@ -1229,11 +1297,11 @@ int batch_search_device_locked(wax_hip_engine* e, BatchCtx* c, const float* d_qu
             e->st_gemm_ms += ms; e->st_gemm_timed += 1; e->st_gemm_rows += c->gemm_rows; e->st_gemm_queries += c->gemm_queries;
         }
     }
+    int rc = WAX_HIP_OK;
     uint32_t fallbacks = 0;
     Slot* s = nullptr;
     for (uint32_t q = 0; q < nq; ++q) {
         if (c->h_cert[q]) continue;
-        // certificate failed (ties, clustered data, an overflowed list): the exact path answers, never an approximation
         if (!s) {
             rc = acquire_slot(e, &s, /*try_only=*/false, /*holding=*/true);
             if (rc != WAX_HIP_OK) return rc;
@@ -1250,6 +1318,13 @@ int batch_search_device_locked(wax_hip_engine* e, BatchCtx* c, const float* d_qu
     e->st_batch_fallbacks += fallbacks;
     if (out_fallbacks) *out_fallbacks = fallbacks;
     return rc;
+}
+
+int batch_search_device_locked(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32_t nq, int k_eff,
+                               const OnepassPlan* plan, wax_hip_hit* d_out, uint32_t out_stride, uint32_t* out_fallbacks) {
+    int rc = batch_submit_device_locked(e, c, d_queries, nq, k_eff, plan, d_out, out_stride);
+    if (rc != WAX_HIP_OK) return rc;
+    return batch_finish_device_locked(e, c, d_queries, nq, k_eff, d_out, out_stride, out_fallbacks);
 }
 
 bool device_is_gfx950(int dev) {
@@ -1866,16 +1941,26 @@ int wax_hip_search_batch(wax_hip_engine* e, const float* queries, uint32_t nq, u
 // ([nq][out_stride], rows padded). Blocking; `stream` is the stream whose earlier work produced d_queries (the
 // library's own stream waits for it), and on return every result is complete. The only PCIe traffic is nq
 // certificate flags + norms (8 bytes per query) — or the query block itself when the batch has to take the loop path.
-int wax_hip_search_batch_hits_device(wax_hip_engine* e, const float* d_queries, uint32_t nq, uint32_t dims, int32_t top_k,
-                                     wax_hip_hit* d_out_hits, uint32_t out_stride, void* stream) {
+// Shared body of the blocking and the pipelined device-resident batch search. ticket == nullptr: blocking.
+static int batch_device_impl(wax_hip_engine* e, const float* d_queries, uint32_t nq, uint32_t dims, int32_t top_k,
+                             wax_hip_hit* d_out_hits, uint32_t out_stride, void* stream, uint64_t* ticket, const char* what) {
+    if (ticket) *ticket = 0;
     if (!e) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine is null");
-    if (nq == 0) return WAX_HIP_OK;
-    if (!d_queries || !d_out_hits || out_stride == 0) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null input");
-    SHARDED_UNSUPPORTED(e, "wax_hip_search_batch_hits_device");
-    if (dims != e->dims) return fail(WAX_HIP_ERR_DIM_MISMATCH, dim_mismatch_msg(e->dims, dims));
+    if (e->sh) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, std::string(what) + " is a single-device entry point: not available on a sharded engine");
+    if (nq > 0 && (!d_queries || !d_out_hits || out_stride == 0)) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null input");
+    if (nq > 0 && dims != e->dims) return fail(WAX_HIP_ERR_DIM_MISMATCH, dim_mismatch_msg(e->dims, dims));
     DeviceGuard g(e->device);
-    e->lock.lock_shared(holding(e) > 0);
-    struct Unlock { RWLock& l; ~Unlock() { l.unlock_shared(); } } unlock{e->lock};
+    const bool holder = holding(e) > 0;
+    e->lock.lock_shared(holder);
+    bool keep_lock = false;   // a pending ticket keeps the shared lock until its collect
+    struct Unlock { RWLock& l; bool& keep; ~Unlock() { if (!keep) l.unlock_shared(); } } unlock{e->lock, keep_lock};
+    auto done_ticket = [&]() {   // answered (or nothing to do) at submit time: a ticket whose collect is a no-op
+        if (!ticket) return;
+        std::unique_lock<std::mutex> tg(e->bticket_mu);
+        *ticket = e->next_bticket++;
+        e->btickets[*ticket] = wax_hip_engine::BatchTicket{};
+    };
+    if (nq == 0) { done_ticket(); return WAX_HIP_OK; }
     { const int frc = flush_pending(e); if (frc != WAX_HIP_OK) return frc; }
     if (e->row_base + e->count > 0x100000000ull) return fail(WAX_HIP_ERR_CAPACITY, "row_base + count exceeds UInt32 row indices");
     const uint64_t limit = (uint64_t)clamp_topk(top_k);
@@ -1883,9 +1968,10 @@ int wax_hip_search_batch_hits_device(wax_hip_engine* e, const float* d_queries, 
     if (k64 > out_stride) k64 = out_stride;
     const int k_eff = (int)k64;
     BatchCtx* c = nullptr;
-    int rc = acquire_bctx(e, &c);
+    int rc = acquire_bctx(e, &c, /*try_only=*/ticket != nullptr && holder);
     if (rc != WAX_HIP_OK) return rc;
-    struct Release { wax_hip_engine* e; BatchCtx* c; ~Release() { release_bctx(e, c); } } release{e, c};
+    bool keep_ctx = false;
+    struct Release { wax_hip_engine* e; BatchCtx* c; bool& keep; ~Release() { if (!keep) release_bctx(e, c); } } release{e, c, keep_ctx};
     hipStream_t st = c->stream;
     // inputs are produced on the caller's stream
     HIP_TRY(hipEventRecord(c->ev_in, static_cast<hipStream_t>(stream)), WAX_HIP_ERR_INTERNAL, "input event record");
@@ -1894,6 +1980,7 @@ int wax_hip_search_batch_hits_device(wax_hip_engine* e, const float* d_queries, 
         std::vector<wax_hip_hit> pad((size_t)nq * out_stride, wax_hip_hit{KEY_PAD, ID_PAD});
         HIP_TRY(hipMemcpyAsync(d_out_hits, pad.data(), pad.size() * sizeof(wax_hip_hit), hipMemcpyHostToDevice, st), WAX_HIP_ERR_INTERNAL, "pad upload");
         HIP_TRY(hipStreamSynchronize(st), WAX_HIP_ERR_INTERNAL, "pad upload");
+        done_ticket();
         return WAX_HIP_OK;
     }
     OnepassPlan plan{};
@@ -1910,7 +1997,20 @@ int wax_hip_search_batch_hits_device(wax_hip_engine* e, const float* d_queries, 
     if (use_mfma) {
         rc = ensure_mirror(e, st);
         if (rc != WAX_HIP_OK) return rc;
-        return batch_search_device_locked(e, c, d_queries, nq, k_eff, onepass ? &plan : nullptr, d_out_hits, out_stride, nullptr);
+        if (!ticket) return batch_search_device_locked(e, c, d_queries, nq, k_eff, onepass ? &plan : nullptr, d_out_hits, out_stride, nullptr);
+        rc = batch_submit_device_locked(e, c, d_queries, nq, k_eff, onepass ? &plan : nullptr, d_out_hits, out_stride);
+        if (rc != WAX_HIP_OK) return rc;
+        wax_hip_engine::BatchTicket t;
+        t.c = c; t.d_queries = d_queries; t.d_out = d_out_hits; t.nq = nq; t.out_stride = out_stride; t.k_eff = k_eff;
+        note_submit_id(e, &t.owner);
+        {
+            std::unique_lock<std::mutex> tg(e->bticket_mu);
+            *ticket = e->next_bticket++;
+            e->btickets[*ticket] = t;
+        }
+        keep_ctx = true;
+        keep_lock = true;
+        return WAX_HIP_OK;
     }
     // loop path: one exact scan per query, back to back on the workspace's stream; the norms come from the host
     std::vector<float> hq((size_t)nq * dims);
@@ -1925,6 +2025,39 @@ int wax_hip_search_batch_hits_device(wax_hip_engine* e, const float* d_queries, 
     hipError_t serr = hipStreamSynchronize(st);
     release_slot(e, s);
     if (rc == WAX_HIP_OK && serr != hipSuccess) rc = fail(WAX_HIP_ERR_INTERNAL, std::string("batch search failed on device: ") + hipGetErrorString(serr));
+    if (rc == WAX_HIP_OK) done_ticket();
+    return rc;
+}
+
+int wax_hip_search_batch_hits_device(wax_hip_engine* e, const float* d_queries, uint32_t nq, uint32_t dims, int32_t top_k,
+                                     wax_hip_hit* d_out_hits, uint32_t out_stride, void* stream) {
+    return batch_device_impl(e, d_queries, nq, dims, top_k, d_out_hits, out_stride, stream, nullptr, "wax_hip_search_batch_hits_device");
+}
+
+int wax_hip_search_batch_submit_device(wax_hip_engine* e, const float* d_queries, uint32_t nq, uint32_t dims, int32_t top_k,
+                                       wax_hip_hit* d_out_hits, uint32_t out_stride, void* stream, uint64_t* out_ticket) {
+    if (!out_ticket) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "ticket is null");
+    return batch_device_impl(e, d_queries, nq, dims, top_k, d_out_hits, out_stride, stream, out_ticket, "wax_hip_search_batch_submit_device");
+}
+
+int wax_hip_search_batch_collect_device(wax_hip_engine* e, uint64_t ticket, uint32_t* out_fallbacks) {
+    if (out_fallbacks) *out_fallbacks = 0;
+    if (!e) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine is null");
+    wax_hip_engine::BatchTicket t;
+    {
+        std::unique_lock<std::mutex> tg(e->bticket_mu);
+        auto it = e->btickets.find(ticket);
+        if (it == e->btickets.end()) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "unknown batch ticket " + std::to_string(ticket));
+        t = it->second;
+        e->btickets.erase(it);
+    }
+    if (!t.c) return WAX_HIP_OK;   // answered at submit time
+    DeviceGuard g(e->device);
+    const int rc = batch_finish_device_locked(e, t.c, t.d_queries, t.nq, t.k_eff, t.d_out, t.out_stride, out_fallbacks);
+    if (rc != WAX_HIP_OK) (void)hipStreamSynchronize(t.c->stream);
+    release_bctx(e, t.c);
+    note_collect_id(e, t.owner);
+    e->lock.unlock_shared();
     return rc;
 }
 
@@ -2283,6 +2416,7 @@ int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value) {
     else if (k == "batch_onepass") e->batch_onepass = value;
     else if (k == "batch_onepass_tiles") { if (value < 1024) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_onepass_tiles must be >= 1024"); e->batch_onepass_tiles = value; }
     else if (k == "batch_survivors") { if (value < 2 || value > 64) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_survivors must be 2..64"); e->batch_survivors = value; }
+    else if (k == "batch_dynamic") e->batch_dynamic = value != 0;
     else if (k == "share_timing") e->share_timing = value != 0;   // 0: every chained scan records its own start event (one more packet between scans)
     else if (k == "filter_device_min") { if (value < -1) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "filter_device_min must be >= -1"); e->filter_device_min = value; }
     else if (k == "batch_sample_div") { if (value < 4 || value > 4096) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_sample_div must be 4..4096"); e->batch_sample_div = value; }
@@ -2338,6 +2472,7 @@ int64_t wax_hip_get_tuning(wax_hip_engine* e, const char* key) {
     if (k == "batch_max_k") return kBatchMaxK;
     if (k == "onepass_queries") return (int64_t)e->st_onepass_queries.load();
     if (k == "share_timing") return e->share_timing.load();
+    if (k == "batch_dynamic") return e->batch_dynamic.load();
     if (k == "filter_device_min") return e->filter_device_min.load();
     if (k == "filter_device_searches") return (int64_t)e->st_filter_device.load();
     if (k == "batch_queries") return (int64_t)e->st_batch_queries.load();

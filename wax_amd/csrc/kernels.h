@@ -107,6 +107,11 @@ struct GemmArgs {
     // `sample_tiles` tiles spread evenly over the slab, tile_max[sample_tiles][nq_pad].
     float* tile_max;
     uint32_t sample_tiles;
+    // One-pass pipeline, filtering launch: non-null = a workgroup's first two tiles are its static ones (bidx,
+    // bidx + workgroups-per-group) and every further tile is claimed from tile_ctr[group] (zeroed before the launch;
+    // tile = 2 * workgroups-per-group + old counter value). A workgroup that is delayed — by another batch's kernels
+    // sharing the GPU — then simply claims fewer tiles instead of finishing last.
+    uint32_t* tile_ctr;
 };
 // Geometry the register-resident kernel will use for these arguments (false: the LDS-tiled kernel runs instead,
 // appending through cand_count).
@@ -140,12 +145,13 @@ struct PrepArgs {
     const float* queries; uint32_t nq, nq_pad, dims; int metric; float max_norm;
     unsigned short* qb; float* q_n2; float* q_norm; float* eps; float* tau; uint32_t* overflow;
     uint32_t* cand_count;       // slab pipeline: per-query append counters to zero (stride CAND_COUNT_STRIDE); may be null
+    uint32_t* tile_ctr;         // one-pass pipeline: [BATCH_TILE_CTRS] tile counters of the filtering GEMM to zero; may be null
 };
+constexpr uint32_t BATCH_TILE_CTRS = 32;
 hipError_t launch_batch_prep(const PrepArgs& a, hipStream_t stream);
 hipError_t launch_batch_gemm_sample(const GemmArgs& a, int metric, hipStream_t stream);
-// tau[q] = 1 - min over `groups` interleaved groups of sampled tiles of (the group's best tile maximum); padding queries
-// keep -inf. groups divides 32.
-hipError_t launch_pick_tau(const float* tile_max, uint32_t sample_tiles, uint32_t nq, uint32_t nq_pad, uint32_t groups,
+// tau[q] = 1 - (the rank-th largest of the sampled tiles' best similarities), rank <= 12; padding queries keep -inf.
+hipError_t launch_pick_tau(const float* tile_max, uint32_t sample_tiles, uint32_t nq, uint32_t nq_pad, uint32_t rank,
                            float* tau, hipStream_t stream);
 // Per query: survivors of the filtering GEMM (per-workgroup segments) -> best kp by approximate key -> exact f32
 // re-score with the scan kernel's arithmetic -> top-k hits + exactness certificate. kp <= 192: one fused kernel;

@@ -325,6 +325,23 @@ class HIPVectorEngine:
                                                         ctypes.c_void_p(stream))
         raise_for_status(rc)
 
+    def searchBatchSubmitDevice(self, d_queries_ptr: int, nq: int, topK: int, d_out_hits_ptr: int, out_stride: int,  # noqa: N802,N803
+                                stream: int = 0) -> int:
+        """Pipelined form of searchBatchHitsDevice: enqueues the batch and returns a ticket at once; the buffers must
+        stay untouched until searchBatchCollectDevice(ticket)."""
+        t = ctypes.c_uint64(0)
+        rc = self._lib.wax_hip_search_batch_submit_device(self._h, ctypes.c_void_p(d_queries_ptr), int(nq), self.dimensions,
+                                                          int(topK), ctypes.c_void_p(d_out_hits_ptr), int(out_stride),
+                                                          ctypes.c_void_p(stream), ctypes.byref(t))
+        raise_for_status(rc)
+        return int(t.value)
+
+    def searchBatchCollectDevice(self, ticket: int) -> int:  # noqa: N802
+        """Waits for a submitted batch (uncertified queries are re-run exactly, in place); returns how many were."""
+        fb = ctypes.c_uint32(0)
+        raise_for_status(self._lib.wax_hip_search_batch_collect_device(self._h, int(ticket), ctypes.byref(fb)))
+        return int(fb.value)
+
     # -- sharded search (one engine per GPU; exchange over RCCL by the caller) ----
     def setRowBase(self, rowBase: int) -> None:  # noqa: N802,N803
         raise_for_status(self._lib.wax_hip_set_row_base(self._h, int(rowBase)))
