@@ -1814,6 +1814,7 @@ __global__ __launch_bounds__(256) void batch_prep_kernel(PrepArgs a) {
         if (ml * ml > total) c = cp;
         else if (mu * mu < total) c = cn;
         a.q_norm[q] = c;
+        if (a.q_norm_host) a.q_norm_host[q] = c;
         a.q_n2[q] = acc;
         // certificate bound: engine.hip batch_eps, same formula
         const double u = 0.00390625 * (1.0 + 1.0 / 1024.0) + (double)D * 5.97e-8 + 1e-6;
@@ -1909,7 +1910,7 @@ __global__ __launch_bounds__(1024) void pick_tau_kernel(const float* __restrict_
     float top[PICK_J];
 #pragma unroll
     for (int p = 0; p < PICK_J; ++p) top[p] = -__builtin_inff();
-    constexpr uint32_t U = 8;
+    constexpr uint32_t U = 16;                                // 512 sampled tiles: every load of a thread in flight at once
     for (uint32_t i0 = slice; i0 < sample_tiles; i0 += 32u * U) {
         float v[U];
 #pragma unroll
@@ -1940,8 +1941,10 @@ __global__ __launch_bounds__(1024) void pick_tau_kernel(const float* __restrict_
     for (int p = 0; p < PICK_J; ++p) mine[p] = lists[p][lane & 31u][q2];
     float kth = -__builtin_inff();
     for (uint32_t r = 0; r < rank; ++r) {
-        kth = group_max32(mine[0]);                           // lanes 31 / 63 hold their group's maximum
-        kth = __shfl(kth, (int)(lane | 31u), 64);
+        const float gm = group_max32(mine[0]);                // lanes 31 / 63 hold their group's maximum
+        const float m_lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gm), 31));
+        const float m_hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gm), 63));
+        kth = (lane & 32u) ? m_hi : m_lo;
         const unsigned long long holders = __ballot(mine[0] == kth) >> (lane & 32u) & 0xffffffffull;
         const bool pop = holders != 0ull && (uint32_t)__builtin_ctzll(holders) == (lane & 31u) && kth > -__builtin_inff();
         if (pop) {
@@ -1993,7 +1996,7 @@ __device__ inline bool gather_segments(WaveTopK<CAP>& tk, const int64_t* __restr
 template <int D4, int GROUP, int METRIC>
 // At most 80 VGPRs (6 waves per SIMD): the filtering GEMM of the NEXT batch in flight leaves exactly that much of
 // every SIMD's register file free (2 waves x 216), so this kernel's workgroups can run beside it instead of behind it.
-__global__ __launch_bounds__(SCAN_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8))) void batch_finish_kernel(FinishArgs a) {
+__global__ __launch_bounds__(SCAN_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void batch_finish_kernel(FinishArgs a) {
     constexpr int CAP = 256;
     constexpr int LOADS = D4 / GROUP;
     constexpr int RPW = WAVE / GROUP;
@@ -2028,7 +2031,7 @@ __global__ __launch_bounds__(SCAN_THREADS) __attribute__((amdgpu_waves_per_eu(6,
 #pragma unroll
         for (int j = 0; j < LOADS; ++j) qv[j] = q4[j * GROUP];
         // U row fetches in flight per lane group (one dependent HBM round trip per U candidates instead of per candidate)
-        constexpr int U = (LOADS <= 3) ? 4 : 2;
+        constexpr int U = 2;
         for (int c0 = wave * RPW; c0 < m; c0 += SCAN_WAVES * RPW * U) {
             int64_t ck[U];
             f32x4 v[U][LOADS];

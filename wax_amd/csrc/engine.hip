@@ -288,12 +288,10 @@ struct BatchCtx {
     uint64_t tile_max_rows = 0;
     wax_hip_hit* d_hits = nullptr;       // [hits_cap] hits of a whole host-pointer call
     uint64_t hits_cap = 0;
-    uint32_t* d_cert = nullptr;          // [cert_cap] certificate flags of a whole call
     uint64_t cert_cap = 0;
     wax_hip_hit* h_hits = nullptr;       // pinned [hits_cap]
     uint32_t* h_cert = nullptr;          // pinned [cert_cap]
     float* h_qnorm = nullptr;            // pinned [cert_cap]: exact norms (the exact-path fallback needs them on the host)
-    float* d_qnorm_all = nullptr;        // [cert_cap]
 };
 
 struct ShardedState;   // sharded.inc: the multi-GPU handle's state (null for a single-device engine)
@@ -386,7 +384,7 @@ struct wax_hip_engine {
     std::atomic<int64_t> batch_onepass{1};        // 0 = always the slab pipeline
     std::atomic<int64_t> batch_onepass_tiles{1024};   // smallest store (in GEMM tiles) the one-pass pipeline takes
     std::atomic<int64_t> batch_survivors{3};      // one-pass pipeline: expected survivors per query = this x k'
-    std::atomic<int64_t> batch_dynamic{1};        // one-pass pipeline: filtering-GEMM workgroups claim their tiles from a counter
+    std::atomic<int64_t> batch_dynamic{0};        // one-pass pipeline: filtering-GEMM workgroups claim their tiles from a counter
     std::atomic<int64_t> batch_sample_div{32};    // one-pass pipeline: 1 / this of the tiles are sampled (at least 256)
     std::atomic<uint64_t> st_onepass_queries{0};
     // wax_hip_search_batch_submit_device tickets (guarded by bticket_mu)
@@ -836,7 +834,7 @@ void free_bctx(BatchCtx* c) {
     (void)hipFree(c->d_q); (void)hipFree(c->d_qb); (void)hipFree(c->d_qn2); (void)hipFree(c->d_qnorm); (void)hipFree(c->d_eps);
     (void)hipFree(c->d_tau); (void)hipFree(c->d_dense); (void)hipFree(c->d_cand_count); (void)hipFree(c->d_overflow);
     (void)hipFree(c->d_cand); (void)hipFree(c->d_seg_count); (void)hipFree(c->d_exact); (void)hipFree(c->d_sel);
-    (void)hipFree(c->d_tile_max); (void)hipFree(c->d_hits); (void)hipFree(c->d_cert); (void)hipFree(c->d_qnorm_all);
+    (void)hipFree(c->d_tile_max); (void)hipFree(c->d_hits);
     (void)hipHostFree(c->h_hits); (void)hipHostFree(c->h_cert); (void)hipHostFree(c->h_qnorm);
     if (c->ev_in) (void)hipEventDestroy(c->ev_in);
     if (c->ev_g0) (void)hipEventDestroy(c->ev_g0);
@@ -1010,10 +1008,8 @@ int bctx_reserve(BatchCtx* c, uint64_t cand_slots, uint64_t kp, uint64_t tile_ro
     if (c->cert_cap < n_queries) {
         uint64_t want = 1024;
         while (want < n_queries) want *= 2;
-        (void)hipFree(c->d_cert); (void)hipFree(c->d_qnorm_all); (void)hipHostFree(c->h_cert); (void)hipHostFree(c->h_qnorm);
-        c->d_cert = nullptr; c->d_qnorm_all = nullptr; c->h_cert = nullptr; c->h_qnorm = nullptr; c->cert_cap = 0;
-        HIP_TRY(hipMalloc(&c->d_cert, want * sizeof(uint32_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch flags");
-        HIP_TRY(hipMalloc(&c->d_qnorm_all, want * sizeof(float)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch norms");
+        (void)hipHostFree(c->h_cert); (void)hipHostFree(c->h_qnorm);
+        c->h_cert = nullptr; c->h_qnorm = nullptr; c->cert_cap = 0;
         HIP_TRY(hipHostMalloc(&c->h_cert, want * sizeof(uint32_t), hipHostMallocDefault), WAX_HIP_ERR_ALLOC, "Failed to allocate pinned batch flags");
         HIP_TRY(hipHostMalloc(&c->h_qnorm, want * sizeof(float), hipHostMallocDefault), WAX_HIP_ERR_ALLOC, "Failed to allocate pinned batch norms");
         c->cert_cap = want;
@@ -1148,8 +1144,8 @@ bool plan_onepass(wax_hip_engine* e, uint32_t n, int k_eff, uint32_t nq, Onepass
 }
 
 // Enqueue the whole batch pipeline for <= kBatchMaxQ device-resident queries on the workspace's stream: hits land in
-// d_out[q * out_stride .. + out_stride) (k_eff real entries, the rest padded), certificate flags in ctx->d_cert +
-// cert_off, exact norms in ctx->d_qnorm_all + cert_off. Nothing is synchronised here.
+// d_out[q * out_stride .. + out_stride) (k_eff real entries, the rest padded), certificate flags in ctx->h_cert +
+// cert_off, exact norms in ctx->h_qnorm + cert_off (pinned host memory the kernels write directly). Nothing is synchronised here.
 int batch_enqueue(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32_t qn, int k_eff, const OnepassPlan* plan,
                   wax_hip_hit* d_out, uint32_t out_stride, uint32_t cert_off) {
     BatchMirror& b = e->batch;
@@ -1161,6 +1157,7 @@ int batch_enqueue(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32
     pa.queries = d_queries; pa.nq = qn; pa.nq_pad = nq_pad; pa.dims = D; pa.metric = e->metric; pa.max_norm = b.max_norm;
     pa.qb = c->d_qb; pa.q_n2 = c->d_qn2; pa.q_norm = c->d_qnorm; pa.eps = c->d_eps; pa.tau = c->d_tau; pa.overflow = c->d_overflow;
     pa.cand_count = plan ? nullptr : c->d_cand_count;
+    pa.q_norm_host = c->h_qnorm + cert_off;
     const bool dynamic_tiles = plan != nullptr && e->batch_dynamic.load() != 0;
     pa.tile_ctr = dynamic_tiles ? c->d_overflow + kBatchMaxQ : nullptr;
     HIP_TRY(launch_batch_prep(pa, st), WAX_HIP_ERR_INTERNAL, "batch prep launch");
@@ -1180,18 +1177,23 @@ int batch_enqueue(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32
         gs.tile_max = c->d_tile_max; gs.sample_tiles = plan->sample_tiles;
         g.tile_ctr = pa.tile_ctr;
         HIP_TRY(launch_batch_gemm_sample(gs, e->metric, st), WAX_HIP_ERR_INTERNAL, "sampling gemm launch");
+        const bool timed = e->time_kernels.load() != 0;
+        std::unique_lock<std::mutex> cg(e->gemm_chain_mu, std::defer_lock);
+        if (timed) {
+            // (the chain wait sits in front of the threshold kernel: the sampling GEMM before it could not get a CU
+            // until the previous batch's filtering GEMM left anyway, and one packet less separates threshold and GEMM)
+            cg.lock();
+            if (e->gemm_chain_ev && e->gemm_chain_ev != c->ev_g1)
+                HIP_TRY(hipStreamWaitEvent(st, e->gemm_chain_ev, 0), WAX_HIP_ERR_INTERNAL, "gemm chain wait");
+        }
         HIP_TRY(launch_pick_tau(c->d_tile_max, plan->sample_tiles, qn, nq_pad, plan->rank, c->d_tau, st), WAX_HIP_ERR_INTERNAL,
                 "threshold kernel launch");
-        const bool timed = e->time_kernels.load() != 0;
         if (timed) {
             // With several batches in flight (submit / collect) the filtering GEMMs of different workspaces would queue
             // for the same CUs (one workgroup's LDS fills a CU) and an event interval would include that wait: chain
             // them, like the single-query scans, so that a timed interval is one GEMM running alone. The small
             // kernels before this point (prep, sampling, thresholds) still overlap the previous batch's GEMM tail
             // and finish kernel.
-            std::unique_lock<std::mutex> cg(e->gemm_chain_mu);
-            if (e->gemm_chain_ev && e->gemm_chain_ev != c->ev_g1)
-                HIP_TRY(hipStreamWaitEvent(st, e->gemm_chain_ev, 0), WAX_HIP_ERR_INTERNAL, "gemm chain wait");
             HIP_TRY(hipEventRecord(c->ev_g0, st), WAX_HIP_ERR_INTERNAL, "event record");
             HIP_TRY(launch_batch_gemm(g, e->metric, st), WAX_HIP_ERR_INTERNAL, "gemm kernel launch");
             HIP_TRY(hipEventRecord(c->ev_g1, st), WAX_HIP_ERR_INTERNAL, "event record");
@@ -1206,7 +1208,7 @@ int batch_enqueue(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32
         f.tau = c->d_tau; f.overflow = c->d_overflow; f.store = e->d_store; f.queries = d_queries; f.q_norm = c->d_qnorm;
         f.eps = c->d_eps; f.ids = e->d_ids; f.n_rows = n; f.row_base = (uint32_t)e->row_base; f.dims = D; f.nq = qn;
         f.kp = plan->kp; f.k = k_eff; f.sel = c->d_sel; f.exact = c->d_exact; f.out = d_out; f.out_stride = out_stride;
-        f.certified = c->d_cert + cert_off;
+        f.certified = c->h_cert + cert_off;   // pinned host memory, written by the kernel: no copy launch behind the finish kernel
         HIP_TRY(launch_batch_finish(f, e->metric, st), WAX_HIP_ERR_INTERNAL, "finish kernel launch");
         e->st_onepass_queries += qn;
     } else {
@@ -1241,11 +1243,9 @@ int batch_enqueue(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32
         r.n_rows = n; r.row_base = (uint32_t)e->row_base; r.dims = D; r.nq = qn; r.cand_cap = kBatchCandCap; r.kp = kp;
         HIP_TRY(launch_rescore(r, e->metric, st), WAX_HIP_ERR_INTERNAL, "rescore kernel launch");
         HIP_TRY(launch_finalize_batch(c->d_cand, kBatchCandCap, c->d_overflow, c->d_exact, kp, k_eff, c->d_eps, e->d_ids,
-                                      (uint32_t)e->row_base, n, qn, d_out, out_stride, c->d_cert + cert_off, st),
+                                      (uint32_t)e->row_base, n, qn, d_out, out_stride, c->h_cert + cert_off, st),
                 WAX_HIP_ERR_INTERNAL, "finalize kernel launch");
     }
-    HIP_TRY(hipMemcpyAsync(c->d_qnorm_all + cert_off, c->d_qnorm, qn * sizeof(float), hipMemcpyDeviceToDevice, st),
-            WAX_HIP_ERR_INTERNAL, "norm copy");
     e->st_batch_queries += qn;
     e->st_searches += qn;
     e->st_rows += (uint64_t)qn * n;
@@ -1277,8 +1277,7 @@ int batch_submit_device_locked(wax_hip_engine* e, BatchCtx* c, const float* d_qu
         rc = batch_enqueue(e, c, d_queries + (uint64_t)q0 * D, qn, k_eff, plan, d_out + (uint64_t)q0 * out_stride, out_stride, q0);
         if (rc != WAX_HIP_OK) { (void)hipStreamSynchronize(st); return rc; }
     }
-    HIP_TRY(hipMemcpyAsync(c->h_cert, c->d_cert, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st), WAX_HIP_ERR_INTERNAL, "flags download");
-    HIP_TRY(hipMemcpyAsync(c->h_qnorm, c->d_qnorm_all, nq * sizeof(float), hipMemcpyDeviceToHost, st), WAX_HIP_ERR_INTERNAL, "norm download");
+    // certificate flags and exact norms are written by the kernels straight into pinned host memory (h_cert, h_qnorm)
     return WAX_HIP_OK;
 }
 

@@ -146,6 +146,7 @@ struct PrepArgs {
     unsigned short* qb; float* q_n2; float* q_norm; float* eps; float* tau; uint32_t* overflow;
     uint32_t* cand_count;       // slab pipeline: per-query append counters to zero (stride CAND_COUNT_STRIDE); may be null
     uint32_t* tile_ctr;         // one-pass pipeline: [BATCH_TILE_CTRS] tile counters of the filtering GEMM to zero; may be null
+    float* q_norm_host;         // [nq] the exact norms once more, straight into pinned host memory (fallback queries need them there); may be null
 };
 constexpr uint32_t BATCH_TILE_CTRS = 32;
 hipError_t launch_batch_prep(const PrepArgs& a, hipStream_t stream);
