@@ -226,6 +226,39 @@ int wax_hip_search_batch_submit_device(wax_hip_engine* e, const float* d_queries
                                        wax_hip_hit* d_out_hits, uint32_t out_stride, void* stream, uint64_t* out_ticket);
 int wax_hip_search_batch_collect_device(wax_hip_engine* e, uint64_t ticket, uint32_t* out_fallbacks);
 
+/* ---- rank fusion on the device ----
+ *
+ * Weighted reciprocal-rank fusion of ranked frame-id lists for nq queries at once: HybridSearch.rrfFusion(lists:k:)
+ * (HybridSearch.swift:25-52) == UnifiedSearch.rrfFusionResults (UnifiedSearch.swift:590-699) without the diagnostics.
+ * Lanes are taken in order; a lane with weight <= 0 is skipped; the entry at 0-based position p of a lane adds
+ * weight / Float(max(0, k) + p + 1) to its frame's f32 score (lane order, then position order: scores are bit-identical
+ * to the Swift loop); bestRank = the smallest p + 1 over the lanes that name the frame; sources = bit l set when lane l
+ * names it. Per query the output row holds every frame seen, best first by (score desc, bestRank asc, frameId asc),
+ * truncated / padded (frame id UInt64.max, score 0) to out_stride; d_out_counts[q] = real entries.
+ *
+ * Lane l of query q: entry p is d_ids[(q * stride + p) * pitch] (pitch 1 = a plain id array; pitch 2 with d_ids pointing at
+ * the frame_id field = a wax_hip_hit array straight out of wax_hip_search_batch_hits_device), d_counts[q] entries (NULL:
+ * stride entries); entries equal to UInt64.max (the padding of a hit list) are skipped. All pointers are device memory on
+ * the current device; the call enqueues on `stream` and returns. Limits: n_lanes <= 8, sum of the strides <= 4096,
+ * k <= 2^30. d_out_best_rank / d_out_sources / d_out_counts may be NULL. */
+#define WAX_HIP_RRF_MAX_LANES 8
+#define WAX_HIP_RRF_MAX_ENTRIES 4096
+typedef struct wax_hip_rrf_lane {
+    const uint64_t* d_ids;
+    const uint32_t* d_counts;
+    uint32_t stride;
+    uint32_t pitch;
+    float weight;
+} wax_hip_rrf_lane;
+int wax_hip_rrf_fuse_batch_device(const wax_hip_rrf_lane* lanes, uint32_t n_lanes, uint32_t nq, int32_t k,
+                                  uint64_t* d_out_ids, float* d_out_scores, uint32_t* d_out_best_rank,
+                                  uint32_t* d_out_sources, uint32_t out_stride, uint32_t* d_out_counts, void* stream);
+/* One query from host memory (what UnifiedSearch holds when the text lane comes from FTS5): uploads the lists, fuses on
+ * `device_id` (-1 = current), downloads. lists[l] has list_counts[l] ids; at most out_capacity results are written. */
+int wax_hip_rrf_fuse(const float* weights, const uint64_t* const* lists, const uint32_t* list_counts, uint32_t n_lists,
+                     int32_t k, int device_id, uint64_t* out_ids, float* out_scores, uint32_t* out_best_rank,
+                     uint32_t* out_sources, uint32_t out_capacity, uint32_t* out_count);
+
 /* ---- sharded search: per-shard top-k left in HBM for the RCCL exchange ---- */
 
 /* Declares that this engine holds rows [row_base, row_base+count) of a corpus

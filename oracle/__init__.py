@@ -341,3 +341,32 @@ def gaussian_unit_queries(nq: int, dims: int, seed: int = QUERY_SEED) -> np.ndar
     q = rng.standard_normal((nq, dims))
     q /= np.linalg.norm(q, axis=1, keepdims=True)
     return q.astype(np.float32)
+
+
+def rrf_fuse(lists, k: int = 60):
+    """HybridSearch.rrfFusion(lists:k:) (HybridSearch.swift:25-52): lists = [(weight, [frameId, ...]), ...] ->
+    (ids u64[m], scores f32[m], best_rank u32[m], sources u32[m]) sorted by (score desc, bestRank asc, id asc)."""
+    weights = np.asarray([w for w, _ in lists], dtype=np.float32)
+    parts = [np.asarray(ids, dtype=np.uint64).reshape(-1) for _, ids in lists]
+    offsets = np.zeros(len(lists) + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum([len(p) for p in parts])
+    flat = np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint64)
+    total = int(offsets[-1])
+    out_ids = np.empty(max(total, 1), dtype=np.uint64)
+    out_scores = np.empty(max(total, 1), dtype=np.float32)
+    out_rank = np.empty(max(total, 1), dtype=np.uint32)
+    out_src = np.empty(max(total, 1), dtype=np.uint32)
+    f = lib().wax_oracle_rrf_fuse
+    f.restype = ctypes.c_int64
+    f.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    flat = np.ascontiguousarray(flat)
+    m = f(len(lists), weights.ctypes.data, flat.ctypes.data if total else None, offsets.ctypes.data, int(k),
+          out_ids.ctypes.data, out_scores.ctypes.data, out_rank.ctypes.data, out_src.ctypes.data)
+    return out_ids[:m].copy(), out_scores[:m].copy(), out_rank[:m].copy(), out_src[:m].copy()
+
+
+def rrf_fuse_two(text_ids, vector_ids, k: int = 60, alpha: float = 0.5):
+    """HybridSearch.rrfFusion(textResults:vectorResults:k:alpha:) (HybridSearch.swift:8-23): alpha clamped to [0, 1]."""
+    a = np.float32(min(1.0, max(0.0, alpha)))
+    return rrf_fuse([(a, text_ids), (np.float32(1.0) - a, vector_ids)], k)

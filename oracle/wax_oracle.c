@@ -698,3 +698,57 @@ WAX_ORACLE_API void wax_oracle_tie_pattern(uint64_t row0, uint64_t n, uint32_t d
         for (uint32_t j = 0; j < dims; ++j)
             out[i * (uint64_t)dims + j] = (float)((row0 + i + j) % 256) / 255.0f;
 }
+
+/* ---------------------------------------------------------------------------
+ * Reciprocal-rank fusion: HybridSearch.rrfFusion(lists:k:) (HybridSearch.swift:25-52) ==
+ * UnifiedSearch.rrfFusionResults (UnifiedSearch.swift:590-699) without the diagnostics.
+ * Lists in order; a list with weight <= 0 is skipped (:35, :611); per entry (0-based position p):
+ * score[id] += weight / Float(max(0, k) + p + 1) in f32, in that order (:37-38, :614-616);
+ * bestRank[id] = min(bestRank[id], p + 1) (:39, :617); sources = the lists that named the id (:618-620).
+ * Result: every id seen, sorted by score descending, then bestRank ascending, then id ascending (:44-50, :661-665).
+ * ids: the lists concatenated; offsets[n_lists + 1]. Returns the number of distinct ids (all are written, the
+ * caller sizes the outputs by offsets[n_lists]). Quadratic-free: open-addressing table + qsort. */
+typedef struct { uint64_t id; float score; uint32_t best_rank; uint32_t sources; } rrf_ent;
+static int cmp_rrf(const void* a, const void* b) {
+    const rrf_ent* x = (const rrf_ent*)a; const rrf_ent* y = (const rrf_ent*)b;
+    if (x->score != y->score) return x->score > y->score ? -1 : 1;
+    if (x->best_rank != y->best_rank) return x->best_rank < y->best_rank ? -1 : 1;
+    return x->id < y->id ? -1 : (x->id > y->id ? 1 : 0);
+}
+WAX_ORACLE_API int64_t wax_oracle_rrf_fuse(uint32_t n_lists, const float* weights, const uint64_t* ids, const uint64_t* offsets,
+                                           int64_t k, uint64_t* out_ids, float* out_scores, uint32_t* out_best_rank,
+                                           uint32_t* out_sources) {
+    const uint64_t total = offsets[n_lists];
+    if (total == 0) return 0;
+    uint64_t cap = 16;
+    while (cap < 2 * total) cap *= 2;
+    rrf_ent* tab = (rrf_ent*)calloc((size_t)cap, sizeof(rrf_ent));
+    uint8_t* used = (uint8_t*)calloc((size_t)cap, 1);
+    const int64_t kc = k > 0 ? k : 0;                       /* max(0, k) */
+    uint64_t distinct = 0;
+    for (uint32_t l = 0; l < n_lists; ++l) {
+        if (!(weights[l] > 0.0f)) continue;                 /* guard list.weight > 0 */
+        for (uint64_t p = offsets[l]; p < offsets[l + 1]; ++p) {
+            const uint64_t id = ids[p];
+            const uint64_t rank = p - offsets[l] + 1;
+            const float contribution = weights[l] / (float)(kc + (int64_t)rank);
+            uint64_t h = (id * 0x9E3779B97F4A7C15ull) & (cap - 1);
+            while (used[h] && tab[h].id != id) h = (h + 1) & (cap - 1);
+            if (!used[h]) { used[h] = 1; tab[h].id = id; tab[h].score = 0.0f; tab[h].best_rank = 0xffffffffu; tab[h].sources = 0; ++distinct; }
+            tab[h].score += contribution;
+            if ((uint32_t)rank < tab[h].best_rank) tab[h].best_rank = (uint32_t)rank;
+            tab[h].sources |= 1u << (l & 31u);
+        }
+    }
+    rrf_ent* out = (rrf_ent*)malloc((size_t)(distinct ? distinct : 1) * sizeof(rrf_ent));
+    uint64_t m = 0;
+    for (uint64_t h = 0; h < cap; ++h) if (used[h]) out[m++] = tab[h];
+    qsort(out, (size_t)m, sizeof(rrf_ent), cmp_rrf);
+    for (uint64_t i = 0; i < m; ++i) {
+        out_ids[i] = out[i].id; out_scores[i] = out[i].score;
+        if (out_best_rank) out_best_rank[i] = out[i].best_rank;
+        if (out_sources) out_sources[i] = out[i].sources;
+    }
+    free(out); free(tab); free(used);
+    return (int64_t)m;
+}

@@ -242,3 +242,49 @@ def test_numa_sample_helpers():
     src = oracle.gaussian_unit_rows(0, 1000, 24)
     oracle.copy_rows(x, src, 3)
     assert np.array_equal(x, src)
+
+
+# ---- reciprocal-rank fusion (HybridSearch.swift:25-52) ----
+
+@pytest.mark.parametrize("case", REF["rrf_cases"], ids=lambda c: c["name"])
+def test_rrf_two_list_reference_cases(case):
+    ids, scores, best_rank, sources = oracle.rrf_fuse_two(case["text"], case["vector"], case["k"], case["alpha"])
+    exp = case["expect"]
+    if "count" in exp:
+        assert len(ids) == exp["count"]
+    if "idSet" in exp:
+        assert set(ids.tolist()) == set(exp["idSet"])
+    if "first" in exp:
+        assert int(ids[0]) == exp["first"]
+    assert np.all(np.diff(scores) <= 0)
+
+
+@pytest.mark.parametrize("case", REF["rrf_multi_cases"], ids=lambda c: c["name"])
+def test_rrf_multi_list_reference_cases(case):
+    lists = [(l["weight"], l["frameIds"]) for l in case["lists"]]
+    a = oracle.rrf_fuse(lists, case["k"])
+    b = oracle.rrf_fuse(lists, case["k"])
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))                       # idempotent (:5-26)
+    rev = oracle.rrf_fuse(lists[::-1], case["k"])
+    assert set(a[0].tolist()) == set(rev[0].tolist())                            # same id set under permutation (:28-39)
+
+
+def test_rrf_known_answers():
+    """Hand-computed: k = 60, lists (1.0: [1, 2]), (0.5: [2, 3]) -> 2: 1/62 + 0.5/61, 1: 1/61, 3: 0.5/62; a list with
+    weight <= 0 is skipped; ties break by bestRank then id; k < 0 behaves like 0; duplicates inside a list add twice."""
+    ids, scores, best, src = oracle.rrf_fuse([(1.0, [1, 2]), (0.5, [2, 3])], 60)
+    f = np.float32
+    assert ids.tolist() == [2, 1, 3]
+    assert scores[0] == f(f(1.0) / f(62)) + f(f(0.5) / f(61)) and scores[1] == f(1.0) / f(61) and scores[2] == f(0.5) / f(62)
+    assert best.tolist() == [1, 1, 2] and src.tolist() == [3, 1, 2]
+    ids, _, _, _ = oracle.rrf_fuse([(0.0, [9]), (-1.0, [8]), (1.0, [7])], 60)
+    assert ids.tolist() == [7]
+    # equal scores: the smaller bestRank wins, then the smaller id
+    ids, scores, best, _ = oracle.rrf_fuse([(1.0, [5, 4]), (1.0, [4, 5])], 10)
+    assert scores[0] == scores[1] and ids.tolist() == [4, 5] and best.tolist() == [1, 1]
+    a = oracle.rrf_fuse([(1.0, [3, 1, 2])], -5)
+    b = oracle.rrf_fuse([(1.0, [3, 1, 2])], 0)
+    assert np.array_equal(a[1], b[1]) and a[1][0] == np.float32(1.0)
+    ids, scores, _, _ = oracle.rrf_fuse([(1.0, [6, 6])], 1)
+    assert ids.tolist() == [6] and scores[0] == f(f(1.0) / f(2)) + f(f(1.0) / f(3))
+    assert len(oracle.rrf_fuse([], 60)[0]) == 0 and len(oracle.rrf_fuse([(1.0, [])], 60)[0]) == 0

@@ -9,8 +9,9 @@ from .vector_metric import VectorEnginePreference, VectorMetric
 from .engine import HIPVectorEngine, BufferPoolStats, clampTopK
 from . import vector_math as VectorMath
 from . import vector_serializer as VectorSerializer
+from . import hybrid_search as HybridSearch
 
 __all__ = [
     "HIPVectorEngine", "BufferPoolStats", "clampTopK", "VectorMetric", "VectorEnginePreference", "VectorMath",
-    "VectorSerializer", "WaxError", "EncodingError", "CapacityExceeded", "InvalidToc",
+    "VectorSerializer", "HybridSearch", "WaxError", "EncodingError", "CapacityExceeded", "InvalidToc",
 ]

@@ -55,6 +55,12 @@ class Stats(ctypes.Structure):
     ]
 
 
+class RrfLane(ctypes.Structure):
+    """wax_hip_rrf_lane (include/wax_hip.h)."""
+    _fields_ = [("d_ids", ctypes.c_void_p), ("d_counts", ctypes.c_void_p), ("stride", ctypes.c_uint32),
+                ("pitch", ctypes.c_uint32), ("weight", ctypes.c_float)]
+
+
 _engine_p = ctypes.c_void_p
 _f32p = ctypes.POINTER(ctypes.c_float)
 _u64p = ctypes.POINTER(ctypes.c_uint64)
@@ -64,6 +70,14 @@ _hitp = ctypes.POINTER(Hit)
 
 # name -> (restype, argtypes); must cover every function include/wax_hip.h declares
 SIGNATURES: Dict[str, tuple] = {
+    "wax_hip_rrf_fuse_batch_device": (ctypes.c_int, [ctypes.POINTER(RrfLane), ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int32,
+                                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                     ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]),
+    "wax_hip_rrf_fuse": (ctypes.c_int, [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_void_p),
+                                        ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint32, ctypes.c_int32, ctypes.c_int,
+                                        ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_float),
+                                        ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint32,
+                                        ctypes.POINTER(ctypes.c_uint32)]),
     "wax_hip_available": (ctypes.c_int, []),
     "wax_hip_device_count": (ctypes.c_int, []),
     "wax_hip_abi_version": (ctypes.c_uint32, []),

@@ -2161,6 +2161,78 @@ int wax_hip_hits_to_results(uint8_t metric, const wax_hip_hit* hits, uint32_t n,
     return hits_to_results(metric, hits, n, out_ids, out_scores, n, out_count);
 }
 
+// ---- rank fusion --------------------------------------------------------------
+
+int wax_hip_rrf_fuse_batch_device(const wax_hip_rrf_lane* lanes, uint32_t n_lanes, uint32_t nq, int32_t k,
+                                  uint64_t* d_out_ids, float* d_out_scores, uint32_t* d_out_best_rank,
+                                  uint32_t* d_out_sources, uint32_t out_stride, uint32_t* d_out_counts, void* stream) {
+    if (nq == 0) return WAX_HIP_OK;
+    if (!d_out_ids || !d_out_scores || out_stride == 0) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null output");
+    if (n_lanes > WAX_HIP_RRF_MAX_LANES || (n_lanes && !lanes)) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "at most 8 lanes");
+    if (k > (1 << 30)) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "k exceeds 2^30");
+    uint64_t total = 0;
+    for (uint32_t l = 0; l < n_lanes; ++l) {
+        if (lanes[l].stride && !lanes[l].d_ids) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "lane without ids");
+        total += lanes[l].stride;
+    }
+    if (total > WAX_HIP_RRF_MAX_ENTRIES)
+        return fail(WAX_HIP_ERR_CAPACITY, "capacity exceeded: limit " + std::to_string(WAX_HIP_RRF_MAX_ENTRIES) + ", requested " + std::to_string(total));
+    HIP_TRY(launch_rrf_fuse(lanes, n_lanes, nq, k, d_out_ids, d_out_scores, d_out_best_rank, d_out_sources, out_stride, d_out_counts,
+                            static_cast<hipStream_t>(stream)), WAX_HIP_ERR_INTERNAL, "fusion kernel launch");
+    return WAX_HIP_OK;
+}
+
+int wax_hip_rrf_fuse(const float* weights, const uint64_t* const* lists, const uint32_t* list_counts, uint32_t n_lists,
+                     int32_t k, int device_id, uint64_t* out_ids, float* out_scores, uint32_t* out_best_rank,
+                     uint32_t* out_sources, uint32_t out_capacity, uint32_t* out_count) {
+    if (out_count) *out_count = 0;
+    if (!out_count || ((!out_ids || !out_scores) && out_capacity)) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    if (n_lists > WAX_HIP_RRF_MAX_LANES || (n_lists && (!weights || !lists || !list_counts))) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "at most 8 lists");
+    uint64_t total = 0;
+    for (uint32_t l = 0; l < n_lists; ++l) {
+        if (list_counts[l] && !lists[l]) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "list without ids");
+        total += list_counts[l];
+    }
+    if (total > WAX_HIP_RRF_MAX_ENTRIES)
+        return fail(WAX_HIP_ERR_CAPACITY, "capacity exceeded: limit " + std::to_string(WAX_HIP_RRF_MAX_ENTRIES) + ", requested " + std::to_string(total));
+    if (total == 0 || out_capacity == 0) return WAX_HIP_OK;
+    if (wax_hip_device_count() <= 0) return fail(WAX_HIP_ERR_NO_DEVICE, "HIP device not available");
+    int dev = device_id;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = 0;
+    DeviceGuard g(dev);
+    const uint32_t stride_out = (uint32_t)(total < out_capacity ? total : out_capacity);
+    // one allocation: [ids of every list][out ids][out scores][out best rank][out sources][out count]
+    const size_t in_bytes = (size_t)total * 8, out_bytes = (size_t)stride_out * (8 + 4 + 4 + 4) + 8;
+    unsigned char* d = nullptr;
+    HIP_TRY(hipMalloc(&d, in_bytes + out_bytes), WAX_HIP_ERR_ALLOC, "Failed to allocate fusion buffers");
+    struct Free { void* p; ~Free() { (void)hipFree(p); } } guard{d};
+    wax_hip_rrf_lane lanes[WAX_HIP_RRF_MAX_LANES] = {};
+    size_t off = 0;
+    for (uint32_t l = 0; l < n_lists; ++l) {
+        if (list_counts[l])
+            HIP_TRY(hipMemcpy(d + off, lists[l], (size_t)list_counts[l] * 8, hipMemcpyHostToDevice), WAX_HIP_ERR_INTERNAL, "list upload");
+        lanes[l].d_ids = reinterpret_cast<const uint64_t*>(d + off); lanes[l].d_counts = nullptr;
+        lanes[l].stride = list_counts[l]; lanes[l].pitch = 1; lanes[l].weight = weights[l];
+        off += (size_t)list_counts[l] * 8;
+    }
+    uint64_t* d_ids = reinterpret_cast<uint64_t*>(d + in_bytes);
+    float* d_scores = reinterpret_cast<float*>(d_ids + stride_out);
+    uint32_t* d_rank = reinterpret_cast<uint32_t*>(d_scores + stride_out);
+    uint32_t* d_src = d_rank + stride_out;
+    uint32_t* d_cnt = d_src + stride_out;
+    int rc = wax_hip_rrf_fuse_batch_device(lanes, n_lists, 1, k, d_ids, d_scores, d_rank, d_src, stride_out, d_cnt, nullptr);
+    if (rc != WAX_HIP_OK) return rc;
+    uint32_t m = 0;
+    HIP_TRY(hipMemcpy(&m, d_cnt, sizeof(m), hipMemcpyDeviceToHost), WAX_HIP_ERR_INTERNAL, "fusion failed on device");
+    if (m > stride_out) m = stride_out;
+    HIP_TRY(hipMemcpy(out_ids, d_ids, (size_t)m * 8, hipMemcpyDeviceToHost), WAX_HIP_ERR_INTERNAL, "result download");
+    HIP_TRY(hipMemcpy(out_scores, d_scores, (size_t)m * 4, hipMemcpyDeviceToHost), WAX_HIP_ERR_INTERNAL, "result download");
+    if (out_best_rank) HIP_TRY(hipMemcpy(out_best_rank, d_rank, (size_t)m * 4, hipMemcpyDeviceToHost), WAX_HIP_ERR_INTERNAL, "result download");
+    if (out_sources) HIP_TRY(hipMemcpy(out_sources, d_src, (size_t)m * 4, hipMemcpyDeviceToHost), WAX_HIP_ERR_INTERNAL, "result download");
+    *out_count = m;
+    return WAX_HIP_OK;
+}
+
 // ---- filtered search --------------------------------------------------------
 
 int wax_hip_search_filtered(wax_hip_engine* e, const float* query, uint32_t dims, int32_t top_k, int has_allow,

@@ -195,4 +195,10 @@ hipError_t launch_allow_probe(const uint64_t* d_allow, uint64_t n_allow, const u
 hipError_t launch_allow_emit(const uint32_t* bitmap, uint32_t n_rows, const uint32_t* block_off, const uint64_t* ids,
                              uint32_t* rows_out, uint64_t* ids_out, hipStream_t st);
 
+
+// ---- rrf.hip: reciprocal-rank fusion of ranked id lists, one workgroup per query ----
+hipError_t launch_rrf_fuse(const wax_hip_rrf_lane* lanes, uint32_t n_lanes, uint32_t nq, int32_t k, uint64_t* out_ids,
+                           float* out_scores, uint32_t* out_best_rank, uint32_t* out_sources, uint32_t out_stride,
+                           uint32_t* out_counts, hipStream_t st);
+
 }  // namespace wax
