@@ -466,6 +466,35 @@ def _assert_batch_parity(metric, corpus, queries, k, got_ids, got_scores, got_co
         assert_parity(got_ids[i][:kk], got_scores[i][:kk], e_ids, x_scores[:kk], x_scores, f"{ctx} q{i}")
 
 
+@pytest.mark.parametrize("metric", [1, 2])
+def test_full_size_parity_dot_and_l2(wax, metric):
+    """North star: "cosine / dot-product". 1M x 384 with row norms spread over 0.5 .. 2 (l2: 0.5 .. 1; so dot and l2 rank differently
+    from cosine): single queries and a 256-query batch (dot: bf16 MFMA one-pass path; l2: LDS-tiled GEMM + slab
+    pipeline), every answer id for id against the f64 oracle."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n, dims, k = 1_000_000, 384, 10
+    eng = wax.HIPVectorEngine(metric=wax.VectorMetric(metric), dimensions=dims)
+    eng.reserve(n)
+    corpus = np.empty((n, dims), dtype=np.float32)
+    for lo, x in _device_corpus(torch, n, dims, dev):
+        hi = lo + x.shape[0]
+        spread = 1.5 if metric == 1 else 0.5      # l2 distances grow with the norms: keep them near 1 so that 1e-5 absolute stays meaningful
+        scale = 0.5 + spread * ((torch.arange(lo, hi, device=dev, dtype=torch.float32) * 0.6180339887) % 1.0)
+        x = (x * scale[:, None]).contiguous()
+        eng.addBatchDevice(np.arange(lo, hi, dtype=np.uint64), x)
+        corpus[lo:hi] = x.cpu().numpy()
+    queries = oracle.gaussian_unit_queries(256, dims, seed=123)
+    got = [eng.searchArrays(q, k) for q in queries[:6]]
+    _assert_batch_parity(metric, corpus, queries[:6], k, [g[0] for g in got], [g[1] for g in got], [len(g[0]) for g in got], 0,
+                         f"metric{metric} single")
+    before = eng.getTuning("batch_queries")
+    ids, scores, counts = eng.searchBatch(queries, k)
+    assert eng.getTuning("batch_queries") - before == 256          # the MFMA path answered
+    _assert_batch_parity(metric, corpus, queries, k, list(ids), list(scores), list(counts), 0, f"metric{metric} batch")
+    eng.close()
+
+
 @pytest.mark.parametrize("n,dims,nq", [(1_000_000, 384, 8), (10_000_000, 384, 3), (1_000_000, 768, 3),
                                        (6_000_000, 768, 2)])  # 6M x 768 = 4.6e9 elements: past the reference kernels' 32-bit offset wrap (CosineDistance.metal:191, 275)
 def test_full_size_parity_with_oracle(wax, n, dims, nq):
