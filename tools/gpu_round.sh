@@ -131,6 +131,15 @@ PYEOF
           --kernel-trace --output-format csv -d "$OUT/prof_gemmpmc" -o g -- python "$R/tools/batch_bench.py" --dims ${WAX_DIMS:-384} --nq ${WAX_NQ:-1024} --reps 2 > "$OUT/gemmpmc.log" 2>&1); rc=$?
       python tools/pmc_summary.py "$OUT/prof_gemmpmc" > "$OUT/gemmpmc_summary.json" 2>> "$OUT/gemmpmc.log"
       find "$OUT/prof_gemmpmc" -name "*.csv" -size +1M -delete 2>/dev/null ;;
+    gemmfetch)
+      # HBM bytes the filtering GEMMs actually fetch (FETCH_SIZE, KiB, x2 on gfx950) against the mirror's size: re-reads by the query groups
+      for cfg in "384 1000000 256" "384 1000000 1024" "768 1250000 1024"; do
+        set -- $cfg
+        (cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/prof_fetch_$1_$3" -o f -- \
+            python "$R/tools/batch_bench.py" --dims $1 --rows $2 --nq $3 --reps 2 > "$OUT/gemmfetch_$1_$3.log" 2>&1); rc=$?
+        python tools/pmc_summary.py "$OUT/prof_fetch_$1_$3" > "$OUT/gemmfetch_$1_$3.json" 2>> "$OUT/gemmfetch_$1_$3.log"
+        rm -rf "$OUT/prof_fetch_$1_$3"
+      done ;;
     gemmprobeprof)
       (cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d "$OUT/prof_probe" -o p -- python "$R/tools/gemm_probe.py" > "$OUT/gemm_probe_prof.log" 2>&1); rc=$?
       find "$OUT/prof_probe" -name "*kernel_trace.csv" -exec sh -c 'head -1 "$1" > "$2"; grep "gemm" "$1" >> "$2"' _ {} "$OUT/probe_gemm_trace.csv" \; 2>/dev/null
