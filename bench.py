@@ -279,6 +279,15 @@ def secondary_batched(torch, dev, rows, dims, nq, k, steps, warmup, label, row_b
         achieved, peak, unit = nbytes / (kern_ms * 1e-3) / 1e9, HBM_PEAK_GBPS, "GB/s"
     else:
         achieved, peak, unit = flops / (kern_ms * 1e-3) / 1e12, MFMA_BF16_PEAK_TFLOPS, "TFLOP/s"
+    traffic, traffic_source = None, None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "latest_traffic.json"))).get("batched", {})
+        ent = tj.get("configs", {}).get(f"{rows}x{dims}xq{nq}")
+        if ent:
+            traffic = ent["hbm_bytes_per_launch"]
+            traffic_source = "replayed from profiles/latest_traffic.json (" + tj.get("source", "") + "), not measured in this run"
+    except (OSError, ValueError, KeyError):
+        pass
     res = {
         "config": label,
         "value": nq * steps / el, "unit": "queries/s", "steps": steps, "warmup": warmup, "ms_per_step": el / steps * 1e3,
@@ -292,7 +301,8 @@ def secondary_batched(torch, dev, rows, dims, nq, k, steps, warmup, label, row_b
                      "kernel": "wax::batch_gemm_rega_kernel" if dims != 768 else "wax::batch_gemm_ksplit_kernel",
                      "kernel_avg_ms": kern_ms, "kernel_launches_timed": launches,
                      "algorithmic_bytes_per_launch": nbytes, "algorithmic_flops_per_launch": flops,
-                     "hbm_floor_ms": t_hbm * 1e3, "mfma_floor_ms": t_mfma * 1e3},
+                     "hbm_floor_ms": t_hbm * 1e3, "mfma_floor_ms": t_mfma * 1e3,
+                     "traffic": traffic, "traffic_source": traffic_source},
     }
     eng.close()
     return res
