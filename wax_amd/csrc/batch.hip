@@ -573,9 +573,12 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
     // with sched_group_barrier "2 DS, 2 MFMA" groups it emitted `ds_read x2; s_waitcnt lgkmcnt(0); mfma`, i.e. one
     // exposed LDS round trip per k-step and a matrix pipe ~50 % idle.)
     auto mfma_tile = [&](const unsigned char* cur) {
+        if (dbg_nomfma) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-        if (dbg_nomfma) return;
+            for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+            return;
+        }
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // first k-step: C = 0 (inline constant), no 32 v_mov per tile
         const unsigned char* b0 = cur + (lane & 31) * ROW_B + (lane >> 5) * 16;
         const unsigned char* b1 = b0 + 32 * ROW_B;
         constexpr int RING = AHEAD + 1;
@@ -593,8 +596,8 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
                 fb0[(ks + AHEAD) % RING] = *reinterpret_cast<const u32x4*>(b0 + (ks + AHEAD) * 32);
                 fb1[(ks + AHEAD) % RING] = *reinterpret_cast<const u32x4*>(b1 + (ks + AHEAD) * 32);
             }
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], __builtin_bit_cast(bf16x8, fb0[ks % RING]), acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], __builtin_bit_cast(bf16x8, fb1[ks % RING]), acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], __builtin_bit_cast(bf16x8, fb0[ks % RING]), ks == 0 ? zero16 : acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], __builtin_bit_cast(bf16x8, fb1[ks % RING]), ks == 0 ? zero16 : acc1, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (prio) __builtin_amdgcn_s_setprio(0);
@@ -821,8 +824,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_ksplit_kernel(GemmArgs a, u
     // this wave's K half of one tile: two independent accumulator chains, B fragments read AHEAD k-steps early
     auto mfma_tile = [&](const unsigned char* cur) {
         f32x16 a0, a1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // first use of a chain: C = 0
         const unsigned char* b0 = cur + (lane & 31) * ROW_B + (owner ? 0 : HALF * 2) + (lane >> 5) * 16;
         constexpr int RING = AHEAD + 1;
         u32x4 fb[RING];
@@ -833,8 +835,8 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_ksplit_kernel(GemmArgs a, u
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             if (ks + AHEAD < KS) fb[(ks + AHEAD) % RING] = *reinterpret_cast<const u32x4*>(b0 + (ks + AHEAD) * 32);
-            if (ks & 1) a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], __builtin_bit_cast(bf16x8, fb[ks % RING]), a1, 0, 0, 0);
-            else a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], __builtin_bit_cast(bf16x8, fb[ks % RING]), a0, 0, 0, 0);
+            if (ks & 1) a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], __builtin_bit_cast(bf16x8, fb[ks % RING]), ks == 1 ? zero16 : a1, 0, 0, 0);
+            else a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], __builtin_bit_cast(bf16x8, fb[ks % RING]), ks == 0 ? zero16 : a0, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (!(a.debug & 32u)) __builtin_amdgcn_s_setprio(0);
