@@ -572,10 +572,14 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
     // (Left alone, hipcc hoists all 2*KS reads above the MFMAs: 192 VGPRs at D = 384, spilling the A fragments;
     // with sched_group_barrier "2 DS, 2 MFMA" groups it emitted `ds_read x2; s_waitcnt lgkmcnt(0); mfma`, i.e. one
     // exposed LDS round trip per k-step and a matrix pipe ~50 % idle.)
-    auto mfma_tile = [&](const unsigned char* cur) {
+    // `st_dst` != nullptr: the next tile's staged segments (regs[], loaded at the top of the iteration) are written to LDS
+    // from INSIDE the K loop — piece p in front of k-step KS/2 + 2p — instead of in one burst after it: the burst was a
+    // phase of ~600 LDS cycles per tile in which no wave of the workgroup had MFMAs left to issue.
+    auto mfma_tile = [&](const unsigned char* cur, unsigned char* st_dst) {
         if (dbg_nomfma) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+            if (st_dst) store_tile(st_dst - (srow * ROW_B + sseg));
             return;
         }
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // first k-step: C = 0 (inline constant), no 32 v_mov per tile
@@ -595,6 +599,9 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
             if (ks + AHEAD < KS) {
                 fb0[(ks + AHEAD) % RING] = *reinterpret_cast<const u32x4*>(b0 + (ks + AHEAD) * 32);
                 fb1[(ks + AHEAD) % RING] = *reinterpret_cast<const u32x4*>(b1 + (ks + AHEAD) * 32);
+            }
+            if (!GLDS && ks >= KS / 2 && ((ks - KS / 2) & 1) == 0 && (ks - KS / 2) / 2 < LOADS) {
+                if (st_dst) *reinterpret_cast<u32x4*>(st_dst + ((ks - KS / 2) / 2) * 128) = regs[GLDS ? 0 : (ks - KS / 2) / 2];
             }
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], __builtin_bit_cast(bf16x8, fb0[ks % RING]), ks == 0 ? zero16 : acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], __builtin_bit_cast(bf16x8, fb1[ks % RING]), ks == 0 ? zero16 : acc1, 0, 0, 0);
@@ -704,11 +711,14 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
                 t_after = tn + blocks_per_group;
             }
         }
+        // debug bit7: the staged tile goes to LDS in one burst after the K loop (the round-1 schedule), for A/B timing
+        const bool spread = !GLDS && !(a.debug & 128u);
+        unsigned char* st_dst = (!GLDS && spread && tn < ntiles && !dbg_noload) ? nxt + srow * ROW_B + sseg : nullptr;
         if (late) {
             if (it > 0) select_tile(t_prev);
-            mfma_tile(cur);
+            mfma_tile(cur, st_dst);
         } else {
-            mfma_tile(cur);
+            mfma_tile(cur, st_dst);
             select_tile(t);
         }
         t_prev = t;
@@ -721,7 +731,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
             cur_idx = cur_idx + 1 == (uint32_t)NBUF ? 0u : cur_idx + 1;
             t += blocks_per_group;
         } else {
-            if (tn < ntiles && !dbg_noload) store_tile(nxt);
+            if (!spread && tn < ntiles && !dbg_noload) store_tile(nxt);
             if (dyn && tid == 0) {
                 claim_wait();
                 next_s[(it + 1u) & 1u] = t_after < ntiles ? 2u * blocks_per_group + claimed : t_after;
@@ -822,7 +832,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_ksplit_kernel(GemmArgs a, u
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
     // this wave's K half of one tile: two independent accumulator chains, B fragments read AHEAD k-steps early
-    auto mfma_tile = [&](const unsigned char* cur) {
+    auto mfma_tile = [&](const unsigned char* cur, unsigned char* st_dst) {   // st_dst: see batch_gemm_rega_kernel
         f32x16 a0, a1;
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // first use of a chain: C = 0
         const unsigned char* b0 = cur + (lane & 31) * ROW_B + (owner ? 0 : HALF * 2) + (lane >> 5) * 16;
@@ -835,6 +845,9 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_ksplit_kernel(GemmArgs a, u
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             if (ks + AHEAD < KS) fb[(ks + AHEAD) % RING] = *reinterpret_cast<const u32x4*>(b0 + (ks + AHEAD) * 32);
+            if (ks >= KS / 2 && ((ks - KS / 2) & 1) == 0 && (ks - KS / 2) / 2 < LOADS) {
+                if (st_dst) *reinterpret_cast<u32x4*>(st_dst + ((ks - KS / 2) / 2) * 256) = regs[(ks - KS / 2) / 2];
+            }
             if (ks & 1) a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], __builtin_bit_cast(bf16x8, fb[ks % RING]), ks == 1 ? zero16 : a1, 0, 0, 0);
             else a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], __builtin_bit_cast(bf16x8, fb[ks % RING]), ks == 0 ? zero16 : a0, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -923,14 +936,16 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_ksplit_kernel(GemmArgs a, u
         } else {
             t_after = tn + blocks_per_group;
         }
+        const bool spread = !(a.debug & 128u);                 // debug bit7: one burst after the K loop, for A/B timing
+        unsigned char* st_dst = (spread && tn < ntiles) ? nxt + srow * ROW_B + sseg : nullptr;
         if (owner) {
             if (it > 0) select_tile(t_prev, (it - 1u) & 1u);   // partial of the previous tile: parked before the last barrier
-            mfma_tile(cur);
+            mfma_tile(cur, st_dst);
         } else {
-            mfma_tile(cur);
+            mfma_tile(cur, st_dst);
             park_partial(it & 1u);
         }
-        if (tn < ntiles) store_tile(nxt);
+        if (!spread && tn < ntiles) store_tile(nxt);
         if (dyn && tid == 0) {
             claim_wait();
             next_s[(it + 1u) & 1u] = t_after < ntiles ? 2u * blocks_per_group + claimed : t_after;
