@@ -88,6 +88,12 @@ def test_sharded_engine_equals_single_engine(wax, shards, metric, dims):
         assert np.array_equal(f1[0], f2[0]) and np.array_equal(f1[1], f2[1])
         f1, f2 = one.searchFiltered(q, 20, minScore=0.1), many.searchFiltered(q, 20, minScore=0.1)
         assert np.array_equal(f1[0], f2[0])
+    # a long allow-list: every shard resolves it through its own id -> row table in HBM
+    long_allow = rng.choice(ids, 9000, replace=False)
+    before = many.getTuning("filter_device_searches")
+    f1, f2 = one.searchFiltered(queries[8], 40, frameIds=long_allow), many.searchFiltered(queries[8], 40, frameIds=long_allow)
+    assert np.array_equal(f1[0], f2[0]) and np.array_equal(f1[1], f2[1])
+    assert many.getTuning("filter_device_searches") - before == shards
     # round trip through a fresh sharded engine
     blob = many.serialize()
     again = wax.HIPVectorEngine(metric=wax.VectorMetric(metric), dimensions=dims, devices=[0] * shards)
