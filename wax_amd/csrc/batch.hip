@@ -1369,6 +1369,11 @@ static hipError_t launch_rega(const GemmArgs& a, hipStream_t st) {
         }
         return launch_rega_impl<D, true, AHEAD>(a, st);
     }
+    if constexpr (D == 384) {
+        // timing experiment (debug bits 8-9 = 1): read-ahead 2 = 224 VGPRs, which leaves room for a 64-VGPR kernel of the
+        // neighbouring batch (the finish kernel) beside the two GEMM waves of a SIMD; read-ahead 3 = 232 does not
+        if (((a.debug >> 8) & 3u) == 1u) return launch_rega_impl<D, false, 2>(a, st);
+    }
     return launch_rega_impl<D, false, AHEAD>(a, st);
 }
 
