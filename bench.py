@@ -537,14 +537,14 @@ def main():
             gc.disable()
             sec = []
             for fn in (lambda: secondary_single_query(torch, dev, 1_000_000, 384, k, max(args.steps, 100), max(args.warmup, 10), args.depth),
-                       lambda: secondary_batched(torch, dev, 1_000_000, 384, 256, k, max(args.steps, 20), max(args.warmup, 3),
+                       lambda: secondary_batched(torch, dev, 1_000_000, 384, 256, k, max(args.steps, 200), max(args.warmup, 20),
                                                  "1000000 x 384, 256 queries per step, cosine top-10, bf16 MFMA GEMM + fused top-k, 1 GPU "
                                                  "(BASELINE config 3), queries and results resident in HBM, 2 batches in flight"),
-                       lambda: secondary_batched(torch, dev, 1_000_000, 384, 1024, k, max(args.steps // 2, 10), max(args.warmup, 3),
+                       lambda: secondary_batched(torch, dev, 1_000_000, 384, 1024, k, max(args.steps // 2, 100), max(args.warmup, 20),
                                                  "1000000 x 384, 1024 queries per step, cosine top-10, bf16 MFMA GEMM + fused top-k, 1 GPU "
                                                  "(config 3 at four times the batch: the MFMA-bound shape), queries and results resident in "
                                                  "HBM, 2 batches in flight"),
-                       lambda: secondary_batched(torch, dev, 1_250_000, 768, 1024, k, max(args.steps // 2, 10), max(args.warmup, 3),
+                       lambda: secondary_batched(torch, dev, 1_250_000, 768, 1024, k, max(args.steps // 2, 60), max(args.warmup, 10),
                                                  "1250000 x 768 (one GPU's share of 10M x 768 over 8 GPUs), 1024 queries per step, cosine "
                                                  "top-10, bf16 MFMA GEMM + fused top-k (BASELINE config 5, per-GPU part), queries and "
                                                  "results resident in HBM, 2 batches in flight", row_base=3_750_000)):
