@@ -130,3 +130,28 @@ def test_rrf_batch_device_with_search_hits(wax):
     torch.cuda.synchronize()
     assert np.array_equal(o2.cpu().numpy().view(np.uint64)[:, :5], g_ids[:, :5])
     eng.close()
+
+
+def test_rrf_argument_errors(wax):
+    """The limits of include/wax_hip.h are enforced with the reference's error kinds, not by overrunning LDS."""
+    import torch
+    dev = torch.device("cuda", 0)
+    ids = torch.zeros((4, 8), dtype=torch.int64, device=dev)
+    out_i = torch.zeros((4, 8), dtype=torch.int64, device=dev)
+    out_s = torch.zeros((4, 8), dtype=torch.float32, device=dev)
+    lane = (ids.data_ptr(), 0, 8, 1, 1.0)
+    with pytest.raises(wax.WaxError):                      # nine lanes
+        wax.HybridSearch.rrfFusionBatchDevice([lane] * 9, 4, 60, out_i.data_ptr(), out_s.data_ptr(), 8)
+    with pytest.raises(wax.CapacityExceeded):              # 8 x 600 entries per query
+        wax.HybridSearch.rrfFusionBatchDevice([(ids.data_ptr(), 0, 600, 1, 1.0)] * 8, 4, 60, out_i.data_ptr(), out_s.data_ptr(), 8)
+    with pytest.raises(wax.WaxError):                      # no output
+        wax.HybridSearch.rrfFusionBatchDevice([lane], 4, 60, 0, out_s.data_ptr(), 8)
+    with pytest.raises(wax.WaxError):                      # a lane without ids
+        wax.HybridSearch.rrfFusionBatchDevice([(0, 0, 8, 1, 1.0)], 4, 60, out_i.data_ptr(), out_s.data_ptr(), 8)
+    wax.HybridSearch.rrfFusionBatchDevice([lane], 0, 60, out_i.data_ptr(), out_s.data_ptr(), 8)   # no queries: nothing to do
+    # every lane skipped (weights <= 0): all rows come back empty
+    cnt = torch.full((4,), 7, dtype=torch.int32, device=dev)
+    wax.HybridSearch.rrfFusionBatchDevice([(ids.data_ptr(), 0, 8, 1, 0.0)], 4, 60, out_i.data_ptr(), out_s.data_ptr(), 8,
+                                          d_out_counts=cnt.data_ptr())
+    torch.cuda.synchronize()
+    assert cnt.cpu().tolist() == [0, 0, 0, 0] and bool((out_i.cpu() == -1).all())
