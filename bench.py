@@ -177,8 +177,9 @@ def _bracket(torch):
     torch.cuda.synchronize()
 
 
-def secondary_single_query(torch, dev, rows, dims, k, steps, warmup, depth):
-    """BASELINE config 2: rows x dims f32, one query per step, the headline's code path at another size."""
+def secondary_single_query(torch, dev, rows, dims, k, steps, warmup, depth, label="BASELINE config 2"):
+    """BASELINE config 2 (and the 10K-row point of the north star's N matrix): rows x dims f32, one query per step, the
+    headline's code path at another size."""
     from wax_amd import HIPVectorEngine, VectorMetric
     eng = HIPVectorEngine(metric=VectorMetric.cosine, dimensions=dims)
     eng.reserve(rows)
@@ -213,7 +214,7 @@ def secondary_single_query(torch, dev, rows, dims, k, steps, warmup, depth):
     achieved = nbytes / (kern_ms * 1e-3) / 1e9
     eng.close()
     return {
-        "config": f"{rows} x {dims} f32 cosine top-{k}, one query per step, 1 GPU (BASELINE config 2)",
+        "config": f"{rows} x {dims} f32 cosine top-{k}, one query per step, 1 GPU ({label})",
         "value": steps / el, "unit": "queries/s", "steps": steps, "warmup": warmup, "ms_per_step": el / steps * 1e3,
         "dtype": "f32",
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
@@ -536,7 +537,9 @@ def main():
             gc.collect()
             gc.disable()
             sec = []
-            for fn in (lambda: secondary_single_query(torch, dev, 1_000_000, 384, k, max(args.steps, 100), max(args.warmup, 10), args.depth),
+            for fn in (lambda: secondary_single_query(torch, dev, 10_000, 384, k, max(args.steps, 2000), max(args.warmup, 100), args.depth,
+                                                      "the 10K-row point of the N matrix: launch-latency-bound, 15 MB per query"),
+                       lambda: secondary_single_query(torch, dev, 1_000_000, 384, k, max(args.steps, 100), max(args.warmup, 10), args.depth),
                        lambda: secondary_batched(torch, dev, 1_000_000, 384, 256, k, max(args.steps, 200), max(args.warmup, 20),
                                                  "1000000 x 384, 256 queries per step, cosine top-10, bf16 MFMA GEMM + fused top-k, 1 GPU "
                                                  "(BASELINE config 3), queries and results resident in HBM, 2 batches in flight"),
