@@ -325,14 +325,15 @@ int wax_hip_stats(wax_hip_engine* e, wax_hip_stats_t* out);
  * "batch_onepass" (0 = always the slab pipeline), "batch_onepass_tiles" (smallest store, in 64-row GEMM tiles, that the one-pass
  * pipeline takes; default 1024), "batch_survivors" (one-pass: floor of the expected survivors per query as a multiple of k', default 3),
  * "batch_sample_div" (one-pass: 1/this of the tiles are sampled for the thresholds, default 32, at most 512 tiles / 8 tile rounds), "batch_workspaces" (concurrent
- * batched searches per engine, default 4), "batch_dynamic" (one-pass pipeline: 1 = the filtering GEMM's workgroups claim their tiles from a counter instead of a static
+ * batched searches per engine, default 4), "batch_retry" (one-pass pipeline: 1 = an uncertified query's survivors are re-scored up to 960 deep before the exact path; default 1),
+ * "batch_dynamic" (one-pass pipeline: 1 = the filtering GEMM's workgroups claim their tiles from a counter instead of a static
  * stride, so that a workgroup delayed by another batch's kernels does not finish last; measured no faster, default 0), "share_timing" (1 = a chained scan whose predecessor is still in flight uses that scan's end-of-kernel event as its own start
  * event: one packet less between scans; 0 = every scan records its own start), "filter_device_min" (wax_hip_search_filtered: allow-lists at least this long are resolved by
  * the device-side id -> row table instead of host probes, default 4096; -1 = never),
  * "batch_slab_mb", "batch_growth", "batch_first" (slab schedule of the slab pipeline), "batch_rega" (0 LDS-tiled GEMM
  * only, 1 register-resident GEMM with register staging, 2 with LDS-DMA staging), "batch_debug" (timing experiments:
  * results are NOT valid with bits 1/2/4/8 set). get-only: "variant_count", "scan_grid", "fused_max_k", "batch_queries",
- * "batch_fallbacks", "onepass_queries", "batch_max_k", "filter_device_searches". Sharded handles: every key above is forwarded to all shards; plus
+ * "batch_fallbacks", "onepass_queries", "batch_max_k", "batch_retries", "filter_device_searches". Sharded handles: every key above is forwarded to all shards; plus
  * "exchange" (0 peer copies + merge on the first device, 1 RCCL all-gather per query) and the get-only "shards", "block_rows",
  * "rebalances", "rccl_collectives". */
 int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value);

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Randomised cross-check of the batched (bf16 MFMA, one-pass / slab) path against the single-query f32 path: random store
+size, dimension, metric, k, batch size, row_base, clustered / duplicated rows. Every checked answer must be identical
+(ids and scores); prints the plan-relevant counters so that rare planner corners (small stores, large k) are visible."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import wax_amd as wax  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--seconds", type=float, default=120.0)
+ap.add_argument("--seed", type=int, default=1)
+args = ap.parse_args()
+rng = np.random.default_rng(args.seed)
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+t_end = time.time() + args.seconds
+trials = checked = fallbacks = onepass_q = retries = 0
+while time.time() < t_end:
+    dims = int(rng.choice([128, 256, 384, 512, 768, 192]))
+    n = int(rng.integers(20_000, 400_000))
+    metric = int(rng.choice([0, 0, 1, 2]))
+    k = int(rng.choice([1, 5, 10, 30, 64, 100, 200, 300, 460]))
+    nq = int(rng.choice([16, 17, 64, 255, 256, 257, 300, 700, 1024, 1500]))
+    g = torch.Generator(device=dev)
+    g.manual_seed(int(rng.integers(1 << 30)))
+    x = torch.randn((n, dims), generator=g, device=dev, dtype=torch.float32)
+    mode = int(rng.integers(0, 4))
+    if mode == 0:
+        x = torch.nn.functional.normalize(x, dim=1)
+    elif mode == 1:                                  # clustered: 20 centres
+        c = torch.randn((20, dims), generator=g, device=dev)
+        x = torch.nn.functional.normalize(c[torch.randint(0, 20, (n,), generator=g, device=dev)] + 0.3 * x, dim=1)
+    elif mode == 2:                                  # duplicates and scaled rows
+        x = torch.nn.functional.normalize(x, dim=1)
+        x[n // 2:n // 2 + 500] = x[7]
+        x = x * (0.5 + torch.rand((n, 1), generator=g, device=dev))
+    eng = wax.HIPVectorEngine(metric=wax.VectorMetric(metric), dimensions=dims)
+    eng.reserve(n)
+    eng.addBatchDevice(np.arange(n, dtype=np.uint64) * 3 + 1, x.contiguous())
+    if rng.random() < 0.5:
+        eng.setRowBase(int(rng.integers(0, 1 << 20)))
+    q = torch.randn((nq, dims), generator=g, device=dev)
+    if mode == 1:
+        q[: nq // 2] = x[torch.randint(0, n, (nq // 2,), generator=g, device=dev)] + 0.05 * q[: nq // 2]
+    qh = q.cpu().numpy()
+    b0, f0, o0 = eng.getTuning("batch_queries"), eng.getTuning("batch_fallbacks"), eng.getTuning("onepass_queries")
+    r0 = eng.getTuning("batch_retries")
+    ids, scores, counts = eng.searchBatch(qh, k)
+    sel = rng.permutation(nq)[:12]
+    for i in sel:
+        s_ids, s_scores = eng.searchArrays(qh[i], k)
+        kk = len(s_ids)
+        ok = counts[i] == kk and np.array_equal(ids[i, :kk], s_ids) and np.array_equal(scores[i, :kk], s_scores)
+        if not ok:
+            print(json.dumps({"FAIL": True, "n": n, "dims": dims, "metric": metric, "k": k, "nq": nq, "mode": mode, "query": int(i)}), flush=True)
+            sys.exit(1)
+        checked += 1
+    trials += 1
+    fallbacks += eng.getTuning("batch_fallbacks") - f0
+    onepass_q += eng.getTuning("onepass_queries") - o0
+    retries += eng.getTuning("batch_retries") - r0
+    print(json.dumps({"n": n, "dims": dims, "metric": metric, "k": k, "nq": nq, "mode": mode,
+                      "mfma_queries": eng.getTuning("batch_queries") - b0, "onepass": eng.getTuning("onepass_queries") - o0,
+                      "fallbacks": eng.getTuning("batch_fallbacks") - f0, "retries": eng.getTuning("batch_retries") - r0}), flush=True)
+    eng.close()
+    del x, q
+print(json.dumps({"trials": trials, "answers_checked": checked, "fallbacks": fallbacks, "wide_retries": retries, "onepass_queries": onepass_q, "ok": True}))

@@ -1579,7 +1579,8 @@ __global__ __launch_bounds__(256) void rescore_kernel(RescoreArgs a) {
     const uint32_t total = a.nq * (uint32_t)a.kp;
     const bool in_range = pair < total;
     const uint32_t p = in_range ? pair : total - 1;
-    const uint32_t q = p / (uint32_t)a.kp;
+    const uint32_t qslot = p / (uint32_t)a.kp;
+    const uint32_t q = a.qlist ? a.qlist[qslot] : qslot;
     bool live;
     uint32_t grow, lrow;
     if (a.rows != nullptr) {  // listed rows (filtered search)
@@ -1587,7 +1588,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(RescoreArgs a) {
         lrow = a.rows[p];
         grow = a.row_base + lrow;
     } else {
-        const int64_t ck = a.cand[(size_t)q * a.cand_cap + (p - q * (uint32_t)a.kp)];
+        const int64_t ck = a.cand[(size_t)q * a.cand_cap + (p - qslot * (uint32_t)a.kp)];
         live = in_range && ck != KEY_PAD;
         grow = key_row(ck);
         lrow = grow - a.row_base;
@@ -1604,7 +1605,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(RescoreArgs a) {
     const float d = finish_distance_b<METRIC>(s, m, a.q_norm[q]);
     if (in_range && gl == GROUP - 1) {
         if (a.dist_out != nullptr) a.dist_out[p] = d;
-        else a.exact[p] = live ? make_key(d, grow) : KEY_PAD;
+        else a.exact[(size_t)q * (uint32_t)a.kp + (p - qslot * (uint32_t)a.kp)] = live ? make_key(d, grow) : KEY_PAD;
     }
 }
 
@@ -2123,7 +2124,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void select_segments_kernel(FinishArg
     int* counts = reinterpret_cast<int*>(lds_dyn + SCAN_WAVES * CAP);
     const int lane = lane_id();
     const int wave = (int)(threadIdx.x >> 6);
-    const uint32_t q = blockIdx.x;
+    const uint32_t q = a.qlist ? a.qlist[blockIdx.x] : blockIdx.x;
     const int kp = a.kp;
     WaveTopK<CAP> tk;
     tk.init(lds_dyn + wave * CAP, kp);
@@ -2141,7 +2142,7 @@ __global__ __launch_bounds__(1024) void finalize_big_kernel(FinishArgs a) {
     const int kp = a.kp, k = a.k;
     int64_t* keys = lds_dyn;
     int64_t* sorted = lds_dyn + kp;
-    const uint32_t q = blockIdx.x;
+    const uint32_t q = a.qlist ? a.qlist[blockIdx.x] : blockIdx.x;
     for (int t = (int)threadIdx.x; t < kp; t += 1024) {
         keys[t] = a.exact[(size_t)q * kp + t];
         sorted[t] = KEY_PAD;
@@ -2209,6 +2210,7 @@ hipError_t launch_batch_finish(const FinishArgs& a, int metric, hipStream_t st) 
     RescoreArgs r{};
     r.store = a.store; r.queries = a.queries; r.q_norm = a.q_norm; r.cand = a.sel; r.exact = a.exact;
     r.n_rows = a.n_rows; r.row_base = a.row_base; r.dims = a.dims; r.nq = a.nq; r.cand_cap = (uint32_t)a.kp; r.kp = a.kp;
+    r.qlist = a.qlist;
     hipError_t e = launch_rescore(r, metric, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(finalize_big_kernel, dim3(a.nq), dim3(1024), (size_t)2 * a.kp * sizeof(int64_t), st, a);

@@ -290,6 +290,13 @@ struct BatchCtx {
     uint64_t hits_cap = 0;
     uint64_t cert_cap = 0;
     wax_hip_hit* h_hits = nullptr;       // pinned [hits_cap]
+    // wide retry of uncertified queries (single-block one-pass batches): the finish arguments of the last block, the failed
+    // queries' numbers (pinned + device)
+    FinishArgs last_finish{};
+    int last_metric = 0;
+    bool last_finish_valid = false;
+    uint32_t* h_qlist = nullptr;         // pinned [kBatchMaxQ]
+    uint32_t* d_qlist = nullptr;         // [kBatchMaxQ]
     uint32_t* h_cert = nullptr;          // pinned [cert_cap]
     float* h_qnorm = nullptr;            // pinned [cert_cap]: exact norms (the exact-path fallback needs them on the host)
 };
@@ -384,6 +391,8 @@ struct wax_hip_engine {
     std::atomic<int64_t> batch_onepass{1};        // 0 = always the slab pipeline
     std::atomic<int64_t> batch_onepass_tiles{1024};   // smallest store (in GEMM tiles) the one-pass pipeline takes
     std::atomic<int64_t> batch_survivors{3};      // one-pass pipeline: expected survivors per query = this x k'
+    std::atomic<int64_t> batch_retry{1};          // one-pass pipeline: uncertified queries get a wide (k' = 960) finish before the exact path
+    std::atomic<uint64_t> st_batch_retries{0};
     std::atomic<int64_t> batch_dynamic{0};        // one-pass pipeline: filtering-GEMM workgroups claim their tiles from a counter
     std::atomic<int64_t> batch_sample_div{32};    // one-pass pipeline: 1 / this of the tiles are sampled (at least 256)
     std::atomic<uint64_t> st_onepass_queries{0};
@@ -835,7 +844,8 @@ void free_bctx(BatchCtx* c) {
     (void)hipFree(c->d_tau); (void)hipFree(c->d_dense); (void)hipFree(c->d_cand_count); (void)hipFree(c->d_overflow);
     (void)hipFree(c->d_cand); (void)hipFree(c->d_seg_count); (void)hipFree(c->d_exact); (void)hipFree(c->d_sel);
     (void)hipFree(c->d_tile_max); (void)hipFree(c->d_hits);
-    (void)hipHostFree(c->h_hits); (void)hipHostFree(c->h_cert); (void)hipHostFree(c->h_qnorm);
+    (void)hipHostFree(c->h_hits); (void)hipHostFree(c->h_cert); (void)hipHostFree(c->h_qnorm); (void)hipHostFree(c->h_qlist);
+    (void)hipFree(c->d_qlist);
     if (c->ev_in) (void)hipEventDestroy(c->ev_in);
     if (c->ev_g0) (void)hipEventDestroy(c->ev_g0);
     if (c->ev_g1) (void)hipEventDestroy(c->ev_g1);
@@ -860,6 +870,8 @@ int alloc_bctx(wax_hip_engine* e, BatchCtx** out) {
     A(&c->d_cand_count, (size_t)kBatchMaxQ * CAND_COUNT_STRIDE * sizeof(uint32_t));
     A(&c->d_overflow, (kBatchMaxQ + BATCH_TILE_CTRS * 32) * sizeof(uint32_t));   // + the filtering GEMM's tile counters
     A(&c->d_seg_count, (size_t)kBatchMaxSegs * kBatchMaxQ * sizeof(uint32_t));
+    A(&c->d_qlist, (size_t)kBatchMaxQ * sizeof(uint32_t));
+    if (err == hipSuccess) err = hipHostMalloc(&c->h_qlist, (size_t)kBatchMaxQ * sizeof(uint32_t), hipHostMallocDefault);
     if (err != hipSuccess) {
         free_bctx(c);
         return fail(WAX_HIP_ERR_ALLOC, std::string("Failed to allocate batch workspace: ") + hipGetErrorString(err));
@@ -989,18 +1001,24 @@ static int ensure_idhash(wax_hip_engine* e, hipStream_t st) {
 }
 
 
+// [kBatchMaxQ][kp] scratch of the re-score / large-k' selection (the workspace's stream is idle when this is called)
+int bctx_reserve_kp(BatchCtx* c, uint64_t kp) {
+    if (c->kp_cap >= kp) return WAX_HIP_OK;
+    (void)hipFree(c->d_exact); (void)hipFree(c->d_sel);
+    c->d_exact = nullptr; c->d_sel = nullptr; c->kp_cap = 0;
+    HIP_TRY(hipMalloc(&c->d_exact, (size_t)kBatchMaxQ * kp * sizeof(int64_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch re-score keys");
+    HIP_TRY(hipMalloc(&c->d_sel, (size_t)kBatchMaxQ * kp * sizeof(int64_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch selection");
+    c->kp_cap = kp;
+    return WAX_HIP_OK;
+}
+
 int bctx_reserve(BatchCtx* c, uint64_t cand_slots, uint64_t kp, uint64_t tile_rows, uint64_t n_queries, bool dense) {
     // [rows of the largest block][cand_slots] keys; capacity tracked in keys
     const uint64_t rows_blk = n_queries < kBatchMaxQ ? ((n_queries + 255ull) & ~255ull) : (uint64_t)kBatchMaxQ;
     int rc = grow_dev(&c->d_cand, &c->cand_slots, rows_blk * cand_slots, sizeof(int64_t), "Failed to allocate batch candidates");
     if (rc != WAX_HIP_OK) return rc;
-    if (c->kp_cap < kp) {
-        (void)hipFree(c->d_exact); (void)hipFree(c->d_sel);
-        c->d_exact = nullptr; c->d_sel = nullptr; c->kp_cap = 0;
-        HIP_TRY(hipMalloc(&c->d_exact, (size_t)kBatchMaxQ * kp * sizeof(int64_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch re-score keys");
-        HIP_TRY(hipMalloc(&c->d_sel, (size_t)kBatchMaxQ * kp * sizeof(int64_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch selection");
-        c->kp_cap = kp;
-    }
+    rc = bctx_reserve_kp(c, kp);
+    if (rc != WAX_HIP_OK) return rc;
     rc = grow_dev(&c->d_tile_max, &c->tile_max_rows, tile_rows, (size_t)kBatchMaxQ * sizeof(float), "Failed to allocate sample maxima");
     if (rc != WAX_HIP_OK) return rc;
     if (dense && !c->d_dense)
@@ -1210,9 +1228,12 @@ int batch_enqueue(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32
         f.kp = plan->kp; f.k = k_eff; f.sel = c->d_sel; f.exact = c->d_exact; f.out = d_out; f.out_stride = out_stride;
         f.certified = c->h_cert + cert_off;   // pinned host memory, written by the kernel: no copy launch behind the finish kernel
         HIP_TRY(launch_batch_finish(f, e->metric, st), WAX_HIP_ERR_INTERNAL, "finish kernel launch");
+        c->last_finish = f; c->last_metric = e->metric;
+        c->last_finish_valid = cert_off == 0;   // the candidate segments survive until collect only for a one-block batch
         e->st_onepass_queries += qn;
     } else {
         // ---- slab pipeline (small stores, L2, other dims): thresholds tightened between geometrically growing slabs ----
+        c->last_finish_valid = false;
         const int kp = batch_kp(k_eff, FUSED_MAX_K);
         uint64_t max_slab = (uint64_t)e->batch_slab_mb.load() * 16384ull;  // "slab_mb" MB of f32 scores per 256 queries
         if (max_slab < 2048) max_slab = 2048;
@@ -1297,6 +1318,31 @@ int batch_finish_device_locked(wax_hip_engine* e, BatchCtx* c, const float* d_qu
         }
     }
     int rc = WAX_HIP_OK;
+    // Second chance for uncertified queries without another pass over the store: their survivors (every row the GEMM
+    // admitted: approx distance <= tau) are still in the segments, so re-score up to 960 of them instead of k' = 2k + 32.
+    // With all survivors re-scored the certificate only needs tau - eps > the exact k-th — which is what dense
+    // neighbourhoods (clustered stores: more than k' rows inside the bf16 error band of the k-th) fail at k'. A query that
+    // fails again (segment overflow, a band wider than the threshold's margin, exact ties) goes to the exact path below.
+    if (c->last_finish_valid && nq <= kBatchMaxQ && e->batch_retry.load() != 0 && c->last_finish.kp < 960) {
+        uint32_t nfail = 0;
+        for (uint32_t q = 0; q < nq; ++q)
+            if (!c->h_cert[q]) c->h_qlist[nfail++] = q;
+        if (nfail > 0) {
+            FinishArgs f = c->last_finish;
+            f.kp = 960; f.qlist = c->d_qlist; f.nq = nfail;
+            rc = bctx_reserve_kp(c, 960);
+            if (rc == WAX_HIP_OK) {
+                f.sel = c->d_sel; f.exact = c->d_exact;
+                HIP_TRY(hipMemcpyAsync(c->d_qlist, c->h_qlist, nfail * sizeof(uint32_t), hipMemcpyHostToDevice, st), WAX_HIP_ERR_INTERNAL, "retry list upload");
+                HIP_TRY(launch_batch_finish(f, c->last_metric, st), WAX_HIP_ERR_INTERNAL, "wide finish launch");
+                HIP_TRY(hipStreamSynchronize(st), WAX_HIP_ERR_INTERNAL, "wide finish failed on device");
+                e->st_batch_retries += nfail;
+            } else {
+                rc = WAX_HIP_OK;   // no memory for the retry: the exact path still answers
+            }
+        }
+    }
+    c->last_finish_valid = false;
     uint32_t fallbacks = 0;
     Slot* s = nullptr;
     for (uint32_t q = 0; q < nq; ++q) {
@@ -2488,6 +2534,7 @@ int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value) {
     else if (k == "batch_onepass_tiles") { if (value < 1024) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_onepass_tiles must be >= 1024"); e->batch_onepass_tiles = value; }
     else if (k == "batch_survivors") { if (value < 2 || value > 64) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_survivors must be 2..64"); e->batch_survivors = value; }
     else if (k == "batch_dynamic") e->batch_dynamic = value != 0;
+    else if (k == "batch_retry") e->batch_retry = value != 0;
     else if (k == "share_timing") e->share_timing = value != 0;   // 0: every chained scan records its own start event (one more packet between scans)
     else if (k == "filter_device_min") { if (value < -1) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "filter_device_min must be >= -1"); e->filter_device_min = value; }
     else if (k == "batch_sample_div") { if (value < 4 || value > 4096) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_sample_div must be 4..4096"); e->batch_sample_div = value; }
@@ -2544,6 +2591,8 @@ int64_t wax_hip_get_tuning(wax_hip_engine* e, const char* key) {
     if (k == "onepass_queries") return (int64_t)e->st_onepass_queries.load();
     if (k == "share_timing") return e->share_timing.load();
     if (k == "batch_dynamic") return e->batch_dynamic.load();
+    if (k == "batch_retry") return e->batch_retry.load();
+    if (k == "batch_retries") return (int64_t)e->st_batch_retries.load();
     if (k == "filter_device_min") return e->filter_device_min.load();
     if (k == "filter_device_searches") return (int64_t)e->st_filter_device.load();
     if (k == "batch_queries") return (int64_t)e->st_batch_queries.load();

@@ -128,6 +128,7 @@ struct RescoreArgs {
     // ascending) instead of candidate keys, and plain f32 distances go to dist_out[i] instead of keys to `exact`
     const uint32_t* rows;
     float* dist_out;
+    const uint32_t* qlist;      // candidate-key mode: non-null = slot s of the launch is query qlist[s] (arrays indexed by query)
 };
 hipError_t launch_mirror(const float* src, uint32_t n_rows, uint32_t n_rows_padded, uint32_t dims, int normalize,
                          unsigned short* dst, float* norm2, unsigned int* max_norm_bits, hipStream_t stream);
@@ -168,6 +169,9 @@ struct FinishArgs {
     int64_t* exact;                                      // [nq][kp] scratch (large-kp path)
     wax_hip_hit* out; uint32_t out_stride;               // [nq][out_stride], k written per query
     uint32_t* certified;                                 // [nq]
+    // large-kp path only: non-null = process queries qlist[0 .. nq) (the "wide retry" of uncertified queries); every array
+    // above stays indexed by the query's own number
+    const uint32_t* qlist;
 };
 hipError_t launch_batch_finish(const FinishArgs& a, int metric, hipStream_t stream);
 struct TightenArgs {
