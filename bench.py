@@ -152,7 +152,7 @@ def cpu_baseline(torch, args, dev, queries):
         return done, el
 
     variants = []
-    for nthreads, budget, cap in ((1, args.cpu_baseline_seconds / 3.0, 40), (threads, args.cpu_baseline_seconds, 400)):
+    for nthreads, budget, cap in ((1, args.cpu_baseline_seconds / 3.0, 40), (threads, args.cpu_baseline_seconds, 4000)):
         done, el = timed(nthreads, budget, cap)
         qps_sample = done / el
         variants.append({
