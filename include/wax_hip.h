@@ -327,7 +327,9 @@ int wax_hip_stats(wax_hip_engine* e, wax_hip_stats_t* out);
  * "batch_sample_div" (one-pass: 1/this of the tiles are sampled for the thresholds, default 32, at most 512 tiles / 8 tile rounds), "batch_workspaces" (concurrent
  * batched searches per engine, default 4), "batch_retry" (one-pass pipeline: 1 = an uncertified query's survivors are re-scored up to 960 deep before the exact path; default 1),
  * "batch_dynamic" (one-pass pipeline: 1 = the filtering GEMM's workgroups claim their tiles from a counter instead of a static
- * stride, so that a workgroup delayed by another batch's kernels does not finish last; measured no faster, default 0), "share_timing" (1 = a chained scan whose predecessor is still in flight uses that scan's end-of-kernel event as its own start
+ * stride, so that a workgroup delayed by another batch's kernels does not finish last; measured no faster, default 0), "scan_chain" (1 = pipelined single-query scans are chained through an event so that they never overlap and a per-launch duration is one
+ * scan alone — the default, what bench.py's roofline is defined on; 0 = scans of different streams overlap: +3 .. +19 % throughput),
+ * "share_timing" (1 = a chained scan whose predecessor is still in flight uses that scan's end-of-kernel event as its own start
  * event: one packet less between scans; 0 = every scan records its own start), "filter_device_min" (wax_hip_search_filtered: allow-lists at least this long are resolved by
  * the device-side id -> row table instead of host probes, default 4096; -1 = never),
  * "batch_slab_mb", "batch_growth", "batch_first" (slab schedule of the slab pipeline), "batch_rega" (0 LDS-tiled GEMM

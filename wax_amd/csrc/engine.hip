@@ -336,6 +336,7 @@ struct wax_hip_engine {
     uint32_t tev_next = 0;
     bool chain_is_timing = false;
     std::atomic<int64_t> share_timing{1};
+    std::atomic<int64_t> scan_chain{1};          // 0 (experiments): pipelined scans of different streams may overlap each other
     std::mutex chain_mu;
 
     std::mutex slot_mu;
@@ -1754,7 +1755,7 @@ static int submit_impl(wax_hip_engine* e, const float* query, uint32_t dims, int
         // The last kernel of the chain writes the k hits straight into the slot's pinned host buffer
         // (device-visible, 16*k bytes over PCIe): no D2H copy launch; visibility at ev_done.
         rc = enqueue_scan(e, s->d_query, qn, k_eff, k_eff, s->d_partials, s, s->h_hits, s->stream,
-                          s->timed ? s->ev0 : nullptr, s->timed ? s->ev1 : nullptr, /*chain=*/true, &s->t_start, &s->t_end);
+                          s->timed ? s->ev0 : nullptr, s->timed ? s->ev1 : nullptr, /*chain=*/e->scan_chain.load() != 0, &s->t_start, &s->t_end);
         if (rc != WAX_HIP_OK) break;
         err = hipEventRecord(s->ev_done, s->stream);
         if (err != hipSuccess) { rc = fail(WAX_HIP_ERR_INTERNAL, std::string("event record: ") + hipGetErrorString(err)); break; }
@@ -2535,6 +2536,7 @@ int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value) {
     else if (k == "batch_survivors") { if (value < 2 || value > 64) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_survivors must be 2..64"); e->batch_survivors = value; }
     else if (k == "batch_dynamic") e->batch_dynamic = value != 0;
     else if (k == "batch_retry") e->batch_retry = value != 0;
+    else if (k == "scan_chain") e->scan_chain = value != 0;
     else if (k == "share_timing") e->share_timing = value != 0;   // 0: every chained scan records its own start event (one more packet between scans)
     else if (k == "filter_device_min") { if (value < -1) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "filter_device_min must be >= -1"); e->filter_device_min = value; }
     else if (k == "batch_sample_div") { if (value < 4 || value > 4096) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_sample_div must be 4..4096"); e->batch_sample_div = value; }
@@ -2589,6 +2591,7 @@ int64_t wax_hip_get_tuning(wax_hip_engine* e, const char* key) {
     if (k == "batch_workspaces") return e->bctx_max;
     if (k == "batch_max_k") return kBatchMaxK;
     if (k == "onepass_queries") return (int64_t)e->st_onepass_queries.load();
+    if (k == "scan_chain") return e->scan_chain.load();
     if (k == "share_timing") return e->share_timing.load();
     if (k == "batch_dynamic") return e->batch_dynamic.load();
     if (k == "batch_retry") return e->batch_retry.load();
