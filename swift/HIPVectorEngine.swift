@@ -12,8 +12,21 @@ import CWaxHIP
 import Foundation
 import WaxCore
 
+/// The engine handle as it crosses into `@Sendable` closures. Wax builds with Swift 6 strict concurrency
+/// (Package.swift: tools-version 6.2, `StrictConcurrency` on every target) and `BlockingIOExecutor.run` takes a
+/// `@Sendable` closure (BlockingIOExecutor.swift:19); an `OpaquePointer` is not `Sendable` (SE-0331), so capturing it
+/// there does not compile. libwaxhip is internally synchronised (its own reader/writer lock, every entry point
+/// re-entrant), which is what makes sharing the pointer sound — the same reasoning as
+/// `extension USearchIndex: @retroactive @unchecked Sendable {}` (USearchSendable.swift:6). The wrapper also owns the
+/// engine's lifetime: the actor needs no `deinit` (a nonisolated actor deinit may not touch non-Sendable state).
+final class HIPEngineHandle: @unchecked Sendable {
+    let raw: OpaquePointer
+    init(_ raw: OpaquePointer) { self.raw = raw }
+    deinit { wax_hip_engine_destroy(raw) }
+}
+
 public actor HIPVectorEngine {
-    private let handle: OpaquePointer
+    private let handle: HIPEngineHandle
     private let metric: VectorMetric
     public let dimensions: Int
     private var dirty = false
@@ -30,7 +43,7 @@ public actor HIPVectorEngine {
         }
         var h: OpaquePointer?
         try Self.check(wax_hip_engine_create(metric.toVecSimilarity().rawValue, UInt32(dimensions), device, &h))
-        self.handle = h!
+        self.handle = HIPEngineHandle(h!)
         self.metric = metric
         self.dimensions = dimensions
     }
@@ -47,15 +60,13 @@ public actor HIPVectorEngine {
         try Self.check(devices.withUnsafeBufferPointer {
             wax_hip_engine_create_sharded(metric.toVecSimilarity().rawValue, UInt32(dimensions), $0.baseAddress, Int32(devices.count), &h)
         })
-        self.handle = h!
+        self.handle = HIPEngineHandle(h!)
         self.metric = metric
         self.dimensions = dimensions
     }
 
     /// Every gfx950 device of the node (what `.auto` / `.hipPreferred` use when more than one is visible).
     public static var allDevices: [Int32] { (0..<wax_hip_device_count()).map { Int32($0) } }
-
-    deinit { wax_hip_engine_destroy(handle) }
 
     public static func load(from wax: Wax, metric: VectorMetric, dimensions: Int) async throws -> HIPVectorEngine {
         let devices = allDevices
@@ -88,7 +99,7 @@ public actor HIPVectorEngine {
             var scores = [Float](repeating: 0, count: cap)
             var got: UInt32 = 0
             try Self.check(vector.withUnsafeBufferPointer { q in
-                wax_hip_search(h, q.baseAddress, UInt32(vector.count), k32, &ids, &scores, UInt32(cap), &got)
+                wax_hip_search(h.raw, q.baseAddress, UInt32(vector.count), k32, &ids, &scores, UInt32(cap), &got)
             })
             return (0..<Int(got)).map { (frameId: ids[$0], score: scores[$0]) }
         }
@@ -97,7 +108,7 @@ public actor HIPVectorEngine {
     public func add(frameId: UInt64, vector: [Float]) async throws {
         let h = handle
         try await io.run {
-            try Self.check(vector.withUnsafeBufferPointer { wax_hip_add(h, frameId, $0.baseAddress, UInt32(vector.count)) })
+            try Self.check(vector.withUnsafeBufferPointer { wax_hip_add(h.raw, frameId, $0.baseAddress, UInt32(vector.count)) })
         }
         dirty = true
     }
@@ -115,7 +126,7 @@ public actor HIPVectorEngine {
         try await io.run {
             try Self.check(flat.withUnsafeBufferPointer { rows in
                 frameIds.withUnsafeBufferPointer { ids in
-                    wax_hip_add_batch(h, ids.baseAddress, rows.baseAddress, UInt64(frameIds.count), d)
+                    wax_hip_add_batch(h.raw, ids.baseAddress, rows.baseAddress, UInt64(frameIds.count), d)
                 }
             })
         }
@@ -145,7 +156,7 @@ public actor HIPVectorEngine {
             var scores = [Float](repeating: 0, count: nq * cap)
             var counts = [UInt32](repeating: 0, count: nq)
             try Self.check(flat.withUnsafeBufferPointer { q in
-                wax_hip_search_batch(h, q.baseAddress, UInt32(nq), d, Int32(clamping: topK), &ids, &scores, UInt32(cap), &counts)
+                wax_hip_search_batch(h.raw, q.baseAddress, UInt32(nq), d, Int32(clamping: topK), &ids, &scores, UInt32(cap), &counts)
             })
             return (0..<nq).map { i in (0..<Int(counts[i])).map { (frameId: ids[i * cap + $0], score: scores[i * cap + $0]) } }
         }
@@ -164,7 +175,7 @@ public actor HIPVectorEngine {
             var n: UInt32 = 0
             try Self.check(vector.withUnsafeBufferPointer { q in
                 (allowed ?? []).withUnsafeBufferPointer { a in
-                    wax_hip_search_filtered(h, q.baseAddress, UInt32(vector.count), Int32(clamping: topK),
+                    wax_hip_search_filtered(h.raw, q.baseAddress, UInt32(vector.count), Int32(clamping: topK),
                                             allowed == nil ? 0 : 1, a.baseAddress, UInt64(a.count),
                                             minScore == nil ? 0 : 1, minScore ?? 0, &ids, &scores, UInt32(limit), &n)
                 }
@@ -183,7 +194,7 @@ public actor HIPVectorEngine {
         let applied: UInt64 = try await io.run {
             var n: UInt64 = 0
             try Self.check(payloads.withUnsafeBytes { raw in
-                wax_hip_apply_put_embeddings(h, raw.bindMemory(to: UInt8.self).baseAddress, UInt64(raw.count), &n)
+                wax_hip_apply_put_embeddings(h.raw, raw.bindMemory(to: UInt8.self).baseAddress, UInt64(raw.count), &n)
             })
             return n
         }
@@ -193,7 +204,7 @@ public actor HIPVectorEngine {
 
     public func remove(frameId: UInt64) async throws {
         let h = handle
-        try await io.run { try Self.check(wax_hip_remove(h, frameId)) }
+        try await io.run { try Self.check(wax_hip_remove(h.raw, frameId)) }
         dirty = true
     }
 
@@ -202,7 +213,7 @@ public actor HIPVectorEngine {
         return try await io.run {
             var p: UnsafeMutablePointer<UInt8>?
             var len = 0
-            try Self.check(wax_hip_serialize(h, &p, &len))
+            try Self.check(wax_hip_serialize(h.raw, &p, &len))
             defer { wax_hip_free(p) }
             return Data(bytes: p!, count: len)   // "MV2V" encoding 2, byte-identical to MetalVectorEngine.serialize
         }
@@ -211,7 +222,7 @@ public actor HIPVectorEngine {
     public func deserialize(_ data: Data) async throws {
         let h = handle
         try await io.run {
-            try Self.check(data.withUnsafeBytes { wax_hip_deserialize(h, $0.bindMemory(to: UInt8.self).baseAddress, data.count) })
+            try Self.check(data.withUnsafeBytes { wax_hip_deserialize(h.raw, $0.bindMemory(to: UInt8.self).baseAddress, data.count) })
         }
         dirty = false
     }
@@ -219,7 +230,7 @@ public actor HIPVectorEngine {
     public func stageForCommit(into wax: Wax) async throws {
         if !dirty { return }
         let blob = try await serialize()
-        try await wax.stageVecIndexForNextCommit(bytes: blob, vectorCount: wax_hip_count(handle),
+        try await wax.stageVecIndexForNextCommit(bytes: blob, vectorCount: wax_hip_count(handle.raw),
                                                  dimension: UInt32(dimensions), similarity: metric.toVecSimilarity())
         dirty = false
     }

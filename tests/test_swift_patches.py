@@ -79,3 +79,57 @@ def test_swift_shim_matches_the_c_abi():
         assert nargs == decl[name], f"{name}: Swift passes {nargs} arguments, header declares {decl[name]}"
         calls += 1
     assert calls >= 15
+
+
+def _closure_body(text, open_brace):
+    """text[open_brace] == '{': returns (body, index after the matching '}')."""
+    depth, i = 0, open_brace
+    while True:
+        c = text[i]
+        if c == "{":
+            depth += 1
+        elif c == "}":
+            depth -= 1
+            if depth == 0:
+                return text[open_brace + 1:i], i + 1
+        i += 1
+
+
+def test_swift_shim_survives_strict_concurrency_lint():
+    """What can be checked without a Swift toolchain about Swift 6 strict concurrency (Package.swift tools-version 6.2,
+    `StrictConcurrency` on every target): `BlockingIOExecutor.run` takes a @Sendable closure
+    (BlockingIOExecutor.swift:19), so nothing non-Sendable may be captured by an `io.run { ... }` closure — in
+    particular not the engine's OpaquePointer (SE-0331) nor any Unsafe*Pointer local; the handle crosses as a
+    `final class ...: @unchecked Sendable` wrapper (the reference's own pattern, USearchSendable.swift:6), and the actor
+    has no `deinit` reading non-Sendable state."""
+    import re
+    swift = open(os.path.join(ROOT, "swift", "HIPVectorEngine.swift")).read()
+    code = re.sub(r"//[^\n]*", "", swift)
+    m = re.search(r"final class (\w+): @unchecked Sendable \{", code)
+    assert m, "the handle wrapper must be a final class marked @unchecked Sendable"
+    wrapper = m.group(1)
+    body, _ = _closure_body(code, m.end() - 1)
+    assert "let raw: OpaquePointer" in body and "deinit { wax_hip_engine_destroy(raw) }" in body
+    a = re.search(r"public actor HIPVectorEngine \{", code)
+    actor, _ = _closure_body(code, a.end() - 1)
+    assert f"private let handle: {wrapper}" in actor
+    assert "deinit" not in actor, "an actor deinit is nonisolated: it may not touch the (non-Sendable) raw pointer"
+    assert "OpaquePointer" not in re.sub(r"var h: OpaquePointer\?", "", actor), \
+        "the only OpaquePointer in the actor is the out-parameter local of the two inits"
+    # every function that hops onto the executor: its locals ahead of the closure are Sendable values
+    runs = [m.end() - 1 for m in re.finditer(r"io\.run \{", actor)]
+    assert len(runs) >= 9
+    pointer_type = re.compile(r"\b(OpaquePointer|Unsafe(Mutable)?(Raw)?(Buffer)?Pointer)\b")
+    for at in runs:
+        start = actor.rfind("func ", 0, at)
+        prologue = actor[start:at]
+        assert not pointer_type.search(prologue), f"pointer-typed local ahead of io.run: {prologue[-200:]}"
+        for decl in re.finditer(r"\b(?:let|var) (\w+) = handle\b", prologue):
+            name = decl.group(1)
+            closure, _ = _closure_body(actor, at)
+            # the wrapper is only ever dereferenced as <name>.raw, inside the closure
+            assert re.search(rf"\b{name}\.raw\b", closure), f"{name} captured but never used"
+            assert not re.search(rf"\b{name}\b(?!\.raw)", closure), f"{name} used as a raw pointer inside a @Sendable closure"
+        closure, _ = _closure_body(actor, at)
+        assert not re.search(r"\bhandle\b", closure), "actor-isolated property read from a @Sendable closure"
+        assert not re.search(r"\b(dirty|metric)\b", closure), "actor-isolated state read from a @Sendable closure"

@@ -1277,12 +1277,10 @@ uint32_t batch_w4_slack_rows() { return 64; }   // rows the w4 kernel's last DMA
 template <int D, int AH>
 static hipError_t launch_w4_ah(const GemmArgs& a, hipStream_t st) {
     constexpr size_t smem = W4Geom<D, AH>::SMEM;
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&batch_gemm_w4_kernel<D, AH>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    static std::atomic<uint64_t> configured{0};   // per device (ensure_dynamic_lds)
+    {
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&batch_gemm_w4_kernel<D, AH>), smem, configured);
         if (e != hipSuccess) return e;
-        configured = true;
     }
     uint32_t groups, pg;
     rega_geometry(a, &groups, &pg);          // the same workgroups-per-group (= survivor segments) as batch_gemm_rega_kernel
@@ -1326,12 +1324,10 @@ bool batch_gemm_segments(const GemmArgs& a, int metric, uint32_t* nseg, uint32_t
 template <int D, int AHEAD>
 static hipError_t launch_ksplit(const GemmArgs& a, hipStream_t st) {
     constexpr size_t smem = 2 * 32 * (D * 2 + 16) + 2 * 4 * (4 * 64 * 16) + 3 * 4 * 32 * 4 + 16;  // tiles, partial sums, thresholds / counters / bounds
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&batch_gemm_ksplit_kernel<D, AHEAD>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    static std::atomic<uint64_t> configured{0};   // per device (ensure_dynamic_lds)
+    {
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&batch_gemm_ksplit_kernel<D, AHEAD>), smem, configured);
         if (e != hipSuccess) return e;
-        configured = true;
     }
     uint32_t groups, per_group;
     rega_geometry(a, &groups, &per_group);
@@ -1342,12 +1338,10 @@ static hipError_t launch_ksplit(const GemmArgs& a, hipStream_t st) {
 template <int D, bool GLDS, int AHEAD>
 static hipError_t launch_rega_impl(const GemmArgs& a, hipStream_t st) {
     constexpr size_t smem = (size_t)rega_lds_tiles<D>(GLDS) * 64 * (D * 2 + 16) + 3 * 8 * 32 * 4 + 16;  // tiles, thresholds, survivor counters, bounds
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&batch_gemm_rega_kernel<D, GLDS, AHEAD>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    static std::atomic<uint64_t> configured{0};   // per device (ensure_dynamic_lds)
+    {
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&batch_gemm_rega_kernel<D, GLDS, AHEAD>), smem, configured);
         if (e != hipSuccess) return e;
-        configured = true;
     }
     uint32_t groups, per_group;
     rega_geometry(a, &groups, &per_group);
@@ -1868,12 +1862,10 @@ template <int D>
 static hipError_t launch_rega_sample(const GemmArgs& a, hipStream_t st) {
     constexpr int AHEAD = D >= 512 ? 1 : 3;
     constexpr size_t smem = (size_t)rega_lds_tiles<D>(false) * 64 * (D * 2 + 16) + 3 * 8 * 32 * 4 + 16;
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&batch_gemm_rega_kernel<D, false, AHEAD, true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    static std::atomic<uint64_t> configured{0};   // per device (ensure_dynamic_lds)
+    {
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&batch_gemm_rega_kernel<D, false, AHEAD, true>), smem, configured);
         if (e != hipSuccess) return e;
-        configured = true;
     }
     const uint32_t groups = (a.nqt * 128 + 255) / 256;
     uint32_t pg = 256 / groups;
@@ -1893,12 +1885,10 @@ hipError_t launch_batch_gemm_sample(const GemmArgs& a, int metric, hipStream_t s
         case 768: {
             constexpr int D = 768;
             constexpr size_t smem = 2 * 32 * (D * 2 + 16) + 2 * 4 * (4 * 64 * 16) + 3 * 4 * 32 * 4 + 16;
-            static bool configured = false;
-            if (!configured) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&batch_gemm_ksplit_kernel<D, 4, true>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            static std::atomic<uint64_t> configured{0};   // per device (ensure_dynamic_lds)
+            {
+                hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&batch_gemm_ksplit_kernel<D, 4, true>), smem, configured);
                 if (e != hipSuccess) return e;
-                configured = true;
             }
             const uint32_t groups = a.nqt;
             uint32_t pg = 256 / groups;

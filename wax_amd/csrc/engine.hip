@@ -1621,21 +1621,28 @@ int wax_hip_add_batch_device(wax_hip_engine* e, const uint64_t* frame_ids, const
     int rc = reserve_rows(e, e->count + n);
     if (rc != WAX_HIP_OK) return rc;
     const uint64_t first_row = e->count;
-    // host bookkeeping first (detects duplicates inside the batch, rolled back on failure)
-    e->ids.reserve(e->ids.size() + n);
-    for (uint64_t i = 0; i < n; ++i) {
-        if (e->idmap.find(frame_ids[i]) >= 0) {
-            for (uint64_t j = 0; j < i; ++j) e->idmap.erase_only(frame_ids[j]);
-            e->ids.resize((size_t)first_row);
-            return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "add_batch_device: duplicate frame id " + std::to_string(frame_ids[i]) + " inside batch");
+    // Failure-atomic: duplicates inside the batch are detected on a scratch map, the rows and ids reach HBM next, and the
+    // host bookkeeping (ids, id map, count) is committed only after both copies succeeded — a failed copy leaves the
+    // engine exactly as it was (the bytes written past `count` are invisible to every reader).
+    {
+        IdMap seen;
+        seen.reserve((size_t)n);
+        for (uint64_t i = 0; i < n; ++i) {
+            if (seen.find(frame_ids[i]) >= 0)
+                return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "add_batch_device: duplicate frame id " + std::to_string(frame_ids[i]) + " inside batch");
+            seen.put(frame_ids[i], 0);
         }
-        e->idmap.put(frame_ids[i], (uint32_t)(first_row + i));
-        e->ids.push_back(frame_ids[i]);
     }
     HIP_TRY(hipMemcpy(e->d_store + first_row * e->dims, d_rows, (size_t)n * e->dims * sizeof(float), hipMemcpyDeviceToDevice),
             WAX_HIP_ERR_INTERNAL, "vector copy");
     HIP_TRY(hipMemcpy(e->d_ids + first_row, frame_ids, (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice),
             WAX_HIP_ERR_INTERNAL, "frame id upload");
+    e->ids.reserve(e->ids.size() + n);
+    e->idmap.reserve((size_t)(first_row + n));
+    for (uint64_t i = 0; i < n; ++i) {
+        e->idmap.put(frame_ids[i], (uint32_t)(first_row + i));
+        e->ids.push_back(frame_ids[i]);
+    }
     e->count += n;
     return WAX_HIP_OK;
 }
@@ -2220,7 +2227,7 @@ int wax_hip_rrf_fuse_batch_device(const wax_hip_rrf_lane* lanes, uint32_t n_lane
     uint64_t total = 0;
     for (uint32_t l = 0; l < n_lanes; ++l) {
         if (lanes[l].stride && !lanes[l].d_ids) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "lane without ids");
-        total += lanes[l].stride;
+        if (lanes[l].weight > 0.0f) total += lanes[l].stride;   // a lane with weight <= 0 is skipped (HybridSearch.swift:31): it takes no table space
     }
     if (total > WAX_HIP_RRF_MAX_ENTRIES)
         return fail(WAX_HIP_ERR_CAPACITY, "capacity exceeded: limit " + std::to_string(WAX_HIP_RRF_MAX_ENTRIES) + ", requested " + std::to_string(total));
@@ -2235,19 +2242,20 @@ int wax_hip_rrf_fuse(const float* weights, const uint64_t* const* lists, const u
     if (out_count) *out_count = 0;
     if (!out_count || ((!out_ids || !out_scores) && out_capacity)) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null argument");
     if (n_lists > WAX_HIP_RRF_MAX_LANES || (n_lists && (!weights || !lists || !list_counts))) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "at most 8 lists");
-    uint64_t total = 0;
+    uint64_t total = 0, counted = 0;
     for (uint32_t l = 0; l < n_lists; ++l) {
         if (list_counts[l] && !lists[l]) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "list without ids");
         total += list_counts[l];
+        if (weights[l] > 0.0f) counted += list_counts[l];       // skipped lanes (weight <= 0, HybridSearch.swift:31) take no table space
     }
-    if (total > WAX_HIP_RRF_MAX_ENTRIES)
-        return fail(WAX_HIP_ERR_CAPACITY, "capacity exceeded: limit " + std::to_string(WAX_HIP_RRF_MAX_ENTRIES) + ", requested " + std::to_string(total));
-    if (total == 0 || out_capacity == 0) return WAX_HIP_OK;
+    if (counted > WAX_HIP_RRF_MAX_ENTRIES)
+        return fail(WAX_HIP_ERR_CAPACITY, "capacity exceeded: limit " + std::to_string(WAX_HIP_RRF_MAX_ENTRIES) + ", requested " + std::to_string(counted));
+    if (counted == 0 || out_capacity == 0) return WAX_HIP_OK;
     if (wax_hip_device_count() <= 0) return fail(WAX_HIP_ERR_NO_DEVICE, "HIP device not available");
     int dev = device_id;
     if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = 0;
     DeviceGuard g(dev);
-    const uint32_t stride_out = (uint32_t)(total < out_capacity ? total : out_capacity);
+    const uint32_t stride_out = (uint32_t)(counted < out_capacity ? counted : out_capacity);
     // one allocation: [ids of every list][out ids][out scores][out best rank][out sources][out count]
     const size_t in_bytes = (size_t)total * 8, out_bytes = (size_t)stride_out * (8 + 4 + 4 + 4) + 8;
     unsigned char* d = nullptr;

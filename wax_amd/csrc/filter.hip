@@ -35,15 +35,18 @@ __global__ __launch_bounds__(256) void idhash_probe_kernel(const uint64_t* __res
     if (i >= n_allow) return;
     const uint64_t id = allow[i];
     uint32_t h = (uint32_t)mix64(id) & mask;
+    // A store loaded from a segment may hold one frame id in several rows (deserialize keeps them as separate rows and the
+    // host id map resolves the id to the FIRST of them, MetalVectorEngine.swift:809-811 / firstIndex(of:)). All rows of
+    // one id sit in the same probe chain, in whatever order the build's CAS races left them: walk the chain to its end
+    // and mark the LOWEST matching row, so the device path picks the row the host path picks, on every run.
+    uint32_t best = 0xffffffffu;
     for (;;) {
         const uint32_t s = table[h];
-        if (s == 0u) return;  // not in the store: an allowed id without a vector is simply absent (UnifiedSearch.swift:1243)
-        if (ids[s - 1u] == id) {
-            atomicOr(&bitmap[(s - 1u) >> 5], 1u << ((s - 1u) & 31u));
-            return;
-        }
+        if (s == 0u) break;   // end of the chain (an allowed id without a vector is simply absent, UnifiedSearch.swift:1243)
+        if (ids[s - 1u] == id && s - 1u < best) best = s - 1u;
         h = (h + 1u) & mask;
     }
+    if (best != 0xffffffffu) atomicOr(&bitmap[best >> 5], 1u << (best & 31u));
 }
 
 constexpr int kWordsPerThread = 4;

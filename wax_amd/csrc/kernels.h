@@ -1,8 +1,26 @@
 // kernels.h — host-callable launchers for the gfx950 kernels (kernels.hip).
 #pragma once
+#include <atomic>
+
 #include "common.h"
 
 namespace wax {
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE property of a kernel: a multi-GPU handle launches the same
+// kernel from one worker thread per device, so "configured once per process" leaves every device but the first at the
+// 64 KB default and its > 64 KB launches fail. `done` (one per kernel instantiation) holds one bit per device ordinal;
+// setting the attribute twice is harmless, so concurrent first launches need no lock.
+inline hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes, std::atomic<uint64_t>& done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = 1ull << ((unsigned)dev & 63u);
+    if (dev < 64 && (done.load(std::memory_order_acquire) & bit)) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
+    if (dev < 64) done.fetch_or(bit, std::memory_order_release);
+    return hipSuccess;
+}
 
 // Arguments of one single-query scan over one shard.
 struct ScanArgs {

@@ -151,11 +151,10 @@ hipError_t launch_rrf_fuse(const wax_hip_rrf_lane* lanes, uint32_t n_lanes, uint
     a.n_lanes = n_lanes; a.nq = nq; a.out_stride = out_stride; a.k = k;
     a.out_ids = out_ids; a.out_scores = out_scores; a.out_best_rank = out_best_rank; a.out_sources = out_sources; a.out_counts = out_counts;
     constexpr size_t smem = (size_t)RRF_SLOTS * (8 + 4 + 4 + 4) + 4096 * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rrf_fuse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    static std::atomic<uint64_t> attr_set{0};   // per device (ensure_dynamic_lds)
+    {
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&rrf_fuse_kernel), smem, attr_set);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     hipLaunchKernelGGL(rrf_fuse_kernel, dim3(nq), dim3(256), smem, st, a);
     return hipGetLastError();
