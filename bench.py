@@ -10,15 +10,23 @@ is the 1.5 KB query in and the k results out (both included in `value`).
     python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         --master-port 29500 bench.py --gpus 8 --steps 200 --warmup 20
+    python bench.py --gpus 8            # ONE process: the library's own multi-GPU engine (sharded handle)
 
-Rank 0 prints ONE JSON line (contract in the task statement): `value` = whole-job queries/s,
-`roofline` = achieved HBM GB/s of the scan kernel (HIP events recorded around every scan-kernel
-launch of the timed region, on the stream the kernel runs on) against the 8 TB/s MI355X peak,
-`cpu_baseline` = the oracle's CPU scan timed on this host (rank 0, N=1 only; one thread and all threads),
-`secondary` (N=1 only) = the other single-GPU BASELINE configurations, timed after the headline with the same
-barrier/synchronise bracket, each with its own roofline block: 1M x 384 single query (config 2), 1M x 384 with
-256 queries per step (config 3: bf16 MFMA GEMM + fused top-k) and one GPU's share of config 5 (1.25M x 768,
-1024 queries per step); the batched ones go through the device-resident entry point (queries already in HBM).
+Rank 0 prints ONE JSON line (contract in the task statement):
+  `value`        whole-job queries/s of the timed region, run the way the product runs: queries software-pipelined over two
+                 streams, scans free to overlap ("scan_chain" auto: no event chain while kernels are not being timed);
+  `roofline`     achieved HBM GB/s of the scan kernel against the 8 TB/s MI355X peak. `frac` is PER LAUNCH: HIP events
+                 recorded around every scan-kernel launch, on the stream the kernel runs on, in a calibration pass of the
+                 SAME run right after the timed region (same engine, same queries, kernels chained so that a launch runs
+                 alone and its event interval is one kernel). `pipeline_frac` prices the timed region itself:
+                 bytes per launch x steps / elapsed;
+  `cpu_baseline` the oracle's CPU scan timed on this host (rank 0, N=1 only; one thread and all threads);
+  `secondary`    the other BASELINE configurations, each with the same barrier/synchronise bracket and its own roofline
+                 block. N=1: 10K / 1M x 384 single query (configs 1-2), 1M x 384 with 256 and 1024 queries per step
+                 (config 3), config 5 at full size on one GPU (10M x 768, 1024 queries per step) and its 8-GPU share
+                 (1.25M x 768), and the batched path on clustered / DeterministicEmbedder corpora (certificate fallbacks).
+                 N>1: config 5 sharded over the N GPUs (the scaling curve BASELINE.json asks for), through the launch shape
+                 in use — torchrun ranks + RCCL all-gather, or one process on the sharded handle.
 """
 from __future__ import annotations
 
@@ -38,6 +46,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md: ~2.
 CORPUS_SEED = 20260220
 QUERY_SEED = 7
 GRANULE = 65536
+SECONDARY_N1 = ["s10k", "s1m", "b1m_q256", "b1m_q1024", "c5_shard", "c5_full", "clustered_k10", "clustered_k100", "detembed"]
 
 
 def log(*a):
@@ -58,7 +67,13 @@ def parse_args():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
                    help="experiments: wax_hip_set_tuning(KEY, VALUE) on every engine the bench creates (repeatable)")
-    p.add_argument("--no-secondary", action="store_true", help="skip the secondary configurations (N=1 only)")
+    p.add_argument("--no-secondary", action="store_true", help="skip the secondary configurations")
+    p.add_argument("--secondary", default="all",
+                   help="comma-separated subset of the secondary configurations (N=1: " + ",".join(SECONDARY_N1) + "; N>1: c5); default all")
+    p.add_argument("--c5-rows", type=int, default=10_000_000, help="rows of the config-5 corpus (tests shrink it)")
+    p.add_argument("--chain-timed-region", action="store_true",
+                   help="time the kernels INSIDE the timed region (scans chained, as in rounds 1-2): the run a rocprofv3 "
+                        "--kernel-trace --stats summary is compared with — every launch of the region is one kernel alone")
     p.add_argument("--host-merge", action="store_true", help="N>1: merge gathered hits on the host instead of the device")
     p.add_argument("--exchange", choices=["rccl", "host"], default="rccl",
                    help="N>1: rccl = all-gather device buffers over RCCL (default); host = download + gloo all-gather "
@@ -75,8 +90,11 @@ def apply_tunes(eng):
         eng.setTuning(k, int(v))
 
 
+# ---------------------------------------------------------------------------
+# synthetic corpora, generated on the device that will hold them
+
 def device_rows(torch, lo, hi, dims, dev):
-    """Rows [lo, hi) of the synthetic corpus: unit-norm Gaussian, granule g seeded with CORPUS_SEED+g,
+    """Rows [lo, hi) of the primary corpus: unit-norm Gaussian, granule g seeded with CORPUS_SEED+g,
     so every GPU count sees the same global corpus."""
     g = torch.Generator(device=dev)
     r = lo
@@ -89,6 +107,60 @@ def device_rows(torch, lo, hi, dims, dev):
         a, b = r - g0, min(hi - g0, GRANULE)
         yield r, block[a:b].contiguous()
         r = g0 + b
+
+
+def clustered_rows(torch, lo, hi, dims, dev, centres=20, spread=0.3):
+    """tools/fuzz_batch.py's "20 tight clusters": normalize(centre[c_i] + 0.3 * gaussian), c_i uniform — the kind of
+    corpus a real embedding store is (topic clusters); rows of a cluster sit within a few bf16 error bands of each other."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(CORPUS_SEED + 991)
+    c = torch.randn((centres, dims), generator=g, device=dev, dtype=torch.float32)
+    r = lo
+    while r < hi:
+        gi = r // GRANULE
+        g0 = gi * GRANULE
+        g.manual_seed(CORPUS_SEED + 100_000 + gi)
+        noise = torch.randn((GRANULE, dims), generator=g, device=dev, dtype=torch.float32)
+        which = torch.randint(0, centres, (GRANULE,), generator=g, device=dev)
+        block = torch.nn.functional.normalize(c[which] + spread * noise, dim=1)
+        a, b = r - g0, min(hi - g0, GRANULE)
+        yield r, block[a:b].contiguous()
+        r = g0 + b
+
+
+def deterministic_embedder_rows(torch, lo, hi, dims, dev, prefix="doc-"):
+    """The reference's DeterministicEmbedder (RAGBenchmarkSupport.swift:114-157) on the texts "doc-<i>", vectorised:
+    seed = FNV-1a 64 of the UTF-8 text, a 64-bit LCG step per component, Float(Int64(bitPattern: state)) / Float(Int64.max),
+    then L2 normalisation. int64 arithmetic wraps exactly like Swift's &* / &+ (checked against the oracle's C restatement
+    in tests/test_host_cpu.py)."""
+    def i64(x):  # a uint64 constant as the int64 with the same bits
+        return x - (1 << 64) if x >= (1 << 63) else x
+    fnv_prime, lcg_a, lcg_c = 1099511628211, i64(6364136223846793005), i64(1442695040888963407)
+    h0 = 14695981039346656037
+    for ch in prefix.encode("utf-8"):
+        h0 = ((h0 ^ ch) * fnv_prime) & ((1 << 64) - 1)
+    step = 1 << 18
+    for r0 in range(lo, hi, step):
+        r1 = min(hi, r0 + step)
+        idx = torch.arange(r0, r1, device=dev, dtype=torch.int64)
+        h = torch.full_like(idx, i64(h0))
+        ndig = torch.ones_like(idx)
+        for p in range(1, 19):
+            ndig += (idx >= 10 ** p).to(torch.int64)
+        for pos in range(19):                      # most significant digit first, like the decimal text
+            active = pos < ndig
+            div = torch.pow(torch.tensor(10, device=dev, dtype=torch.int64), torch.clamp(ndig - 1 - pos, min=0))
+            digit = (idx // div) % 10 + 48
+            h = torch.where(active, (h ^ digit) * fnv_prime, h)
+        out = torch.empty((r1 - r0, dims), device=dev, dtype=torch.float32)
+        state = h
+        for j in range(dims):
+            state = state * lcg_a + lcg_c
+            out[:, j] = state.to(torch.float32) / float(2 ** 63)   # Float(Int64.max) rounds to 2^63
+        yield r0, torch.nn.functional.normalize(out, dim=1).contiguous()
+
+
+CORPORA = {"gaussian": device_rows, "clustered": clustered_rows, "detembed": deterministic_embedder_rows}
 
 
 def _human_rows(n):
@@ -171,71 +243,178 @@ def cpu_baseline(torch, args, dev, queries):
 
 
 # ---------------------------------------------------------------------------
-# secondary configurations (world == 1): same bracket as the headline, each with its own roofline block
+# the single-query measurement: product-mode timed region + per-launch calibration pass
+
+CALIBRATION_STEPS = 60
+
+
+def run_pipelined(submit, collect, qs, depth):
+    pending = []
+    last = None
+    for q in qs:
+        if len(pending) >= depth:
+            last = collect(pending.pop(0))
+        pending.append(submit(q))
+    while pending:
+        last = collect(pending.pop(0))
+    return last
+
+
+def measure_single_query(eng, submit, collect, queries, warmup, steps, depth, barrier, chain_timed_region=False):
+    """warm-up, then EXACTLY `steps` timed steps bracketed by barrier(); then the per-launch calibration pass.
+    Returns (elapsed_s, last_result, kernel_avg_ms, launches_timed, calibration dict)."""
+    eng.setTuning("time_kernels", 1 if chain_timed_region else 0)
+    run_pipelined(submit, collect, queries[:warmup], depth)
+    eng.setTuning("reset_stats", 1)
+    barrier()
+    t0 = time.perf_counter()
+    last = run_pipelined(submit, collect, queries[warmup:warmup + steps], depth)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if chain_timed_region:
+        st = eng.stats()
+        launches = int(st.scan_kernels_timed)
+        kern_ms = st.scan_kernel_ms_total / launches if launches else float("nan")
+        return elapsed, last, kern_ms, launches, {"steps": steps, "ms_per_step": elapsed / steps * 1e3,
+                                                  "mode": "the timed region itself (--chain-timed-region: kernels timed and chained inside it)"}
+    # calibration: the same queries again with every scan bracketed by HIP events on its own stream and chained through an
+    # event, so that a launch runs alone and its interval is one kernel (what rocprofv3's per-dispatch duration measures)
+    n_cal = min(steps, CALIBRATION_STEPS)
+    eng.setTuning("time_kernels", 1)
+    run_pipelined(submit, collect, queries[warmup:warmup + min(4, n_cal)], depth)
+    eng.setTuning("reset_stats", 1)
+    barrier()
+    t1 = time.perf_counter()
+    run_pipelined(submit, collect, queries[warmup:warmup + n_cal], depth)
+    barrier()
+    cal_el = time.perf_counter() - t1
+    st = eng.stats()
+    launches = int(st.scan_kernels_timed)
+    kern_ms = st.scan_kernel_ms_total / launches if launches else float("nan")
+    eng.setTuning("time_kernels", 0)
+    return elapsed, last, kern_ms, launches, {
+        "steps": n_cal, "ms_per_step": cal_el / n_cal * 1e3,
+        "mode": "same run, same engine, the first queries of the timed region again; \"time_kernels\" = 1: HIP events around "
+                "every scan launch on its own stream, scans chained (never two at once)"}
+
+
+def scan_roofline(bytes_per_launch, kern_ms, launches, elapsed, steps, cal, traffic=None, traffic_source=None):
+    achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if launches else float("nan")
+    pipeline = bytes_per_launch * steps / elapsed / 1e9
+    return {
+        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBPS if launches else None,
+        "pipeline_achieved": pipeline, "pipeline_frac": pipeline / HBM_PEAK_GBPS,
+        "traffic": traffic, "traffic_source": traffic_source,
+        "kernel": "wax::scan_kernel (fused scan + per-wave top-k)",
+        "kernel_avg_ms": kern_ms, "kernel_launches_timed": launches,
+        "algorithmic_bytes_per_launch": bytes_per_launch,
+        "calibration": cal,
+        "note": "frac = rows_per_gpu*dims*4 bytes per launch / mean HIP-event duration of the scan kernel, per launch, from the "
+                "calibration pass of this run (kernels chained: one at a time); pipeline_frac = the same bytes x steps / the "
+                "timed region's elapsed time (rank 0's shard), i.e. what the overlapped product pipeline sustains end to end",
+    }
+
+
+# ---------------------------------------------------------------------------
+# secondary configurations: same bracket as the headline, each with its own roofline block
 
 def _bracket(torch):
     torch.cuda.synchronize()
 
 
+def _load_engine(torch, dev, rows, dims, corpus="gaussian", devices=None, lo=0):
+    from wax_amd import HIPVectorEngine, VectorMetric
+    if devices is None:
+        eng = HIPVectorEngine(metric=VectorMetric.cosine, dimensions=dims)
+    else:
+        eng = HIPVectorEngine(metric=VectorMetric.cosine, dimensions=dims, devices=devices)
+    eng.reserve(rows)
+    for r0, x in CORPORA[corpus](torch, lo, lo + rows, dims, dev):
+        eng.addBatchDevice(np.arange(r0, r0 + x.shape[0], dtype=np.uint64), x)
+    return eng
+
+
 def secondary_single_query(torch, dev, rows, dims, k, steps, warmup, depth, label="BASELINE config 2"):
     """BASELINE config 2 (and the 10K-row point of the north star's N matrix): rows x dims f32, one query per step, the
     headline's code path at another size."""
-    from wax_amd import HIPVectorEngine, VectorMetric
-    eng = HIPVectorEngine(metric=VectorMetric.cosine, dimensions=dims)
-    eng.reserve(rows)
-    for r0, x in device_rows(torch, 0, rows, dims, dev):
-        eng.addBatchDevice(np.arange(r0, r0 + x.shape[0], dtype=np.uint64), x)
+    eng = _load_engine(torch, dev, rows, dims)
     queries = unit_queries(warmup + steps, dims)
-    eng.setTuning("time_kernels", 1)
     eng.setTuning("streams", 2)
     eng.setTuning("slots", max(depth, 2))
     apply_tunes(eng)
-
-    def run(qs):
-        pending = []
-        for q in qs:
-            if len(pending) >= depth:
-                eng.collect(pending.pop(0), k)
-            pending.append(eng.submit(q, k))
-        while pending:
-            eng.collect(pending.pop(0), k)
-
-    run(queries[:warmup])
-    eng.setTuning("reset_stats", 1)
-    _bracket(torch)
-    t0 = time.perf_counter()
-    run(queries[warmup:])
-    _bracket(torch)
-    el = time.perf_counter() - t0
-    st = eng.stats()
-    launches = int(st.scan_kernels_timed)
-    kern_ms = st.scan_kernel_ms_total / launches if launches else float("nan")
+    elapsed, _, kern_ms, launches, cal = measure_single_query(
+        eng, lambda q: eng.submit(q, k), lambda t: eng.collect(t, k), queries, warmup, steps, depth, lambda: _bracket(torch))
     nbytes = rows * dims * 4
-    achieved = nbytes / (kern_ms * 1e-3) / 1e9
+    grid = eng.getTuning("scan_grid")
     eng.close()
+    rf = scan_roofline(nbytes, kern_ms, launches, elapsed, steps, cal)
+    rf["scan_grid"] = grid
+    rf["launches_per_query"] = 1 if (eng_fused_grid(grid)) else 2
     return {
         "config": f"{rows} x {dims} f32 cosine top-{k}, one query per step, 1 GPU ({label})",
-        "value": steps / el, "unit": "queries/s", "steps": steps, "warmup": warmup, "ms_per_step": el / steps * 1e3,
-        "dtype": "f32",
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                     "kernel": "wax::scan_kernel", "kernel_avg_ms": kern_ms, "kernel_launches_timed": launches,
-                     "algorithmic_bytes_per_launch": nbytes},
+        "value": steps / elapsed, "unit": "queries/s", "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+        "dtype": "f32", "roofline": rf,
     }
 
 
-def secondary_batched(torch, dev, rows, dims, nq, k, steps, warmup, label, row_base=0):
-    """BASELINE configs 3 / 5 (one GPU's share): nq queries per step as a bf16 MFMA GEMM + fused top-k + exact f32
-    re-score. Queries and results stay in HBM (wax_hip_search_batch_submit_device / _collect_device): the timed region
-    holds no host<->device traffic except nq certificate flags per step."""
-    from wax_amd import HIPVectorEngine, VectorMetric
-    eng = HIPVectorEngine(metric=VectorMetric.cosine, dimensions=dims)
-    eng.reserve(rows)
-    for r0, x in device_rows(torch, 0, rows, dims, dev):
-        eng.addBatchDevice(np.arange(r0, r0 + x.shape[0], dtype=np.uint64), x)
+def eng_fused_grid(grid):
+    return grid <= 160   # SCAN_FUSE_MERGE_GRID: the scan kernel's last-arriving workgroup does the final merge
+
+
+def batched_roofline(rows, dims, nq, kern_ms, launches):
+    flops = 2.0 * nq * rows * dims
+    nbytes = rows * dims * 2                  # bf16 mirror, streamed once per launch
+    t_hbm, t_mfma = nbytes / (HBM_PEAK_GBPS * 1e9), flops / (MFMA_BF16_PEAK_TFLOPS * 1e12)
+    bound = "hbm" if t_hbm >= t_mfma else "mfma"
+    if bound == "hbm":
+        achieved, peak, unit = nbytes / (kern_ms * 1e-3) / 1e9, HBM_PEAK_GBPS, "GB/s"
+    else:
+        achieved, peak, unit = flops / (kern_ms * 1e-3) / 1e12, MFMA_BF16_PEAK_TFLOPS, "TFLOP/s"
+    traffic, traffic_source = None, None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "latest_traffic.json"))).get("batched", {})
+        ent = tj.get("configs", {}).get(f"{rows}x{dims}xq{nq}")
+        if ent:
+            traffic = ent["hbm_bytes_per_launch"]
+            traffic_source = "replayed from profiles/latest_traffic.json (" + tj.get("source", "") + "), not measured in this run"
+    except (OSError, ValueError, KeyError):
+        pass
+    kernel = {768: "wax::batch_gemm_ksplit_kernel", 1024: "wax::batch_gemm_ksplit_kernel", 1536: "wax::batch_gemm_ksplit_kernel"}.get(dims, "wax::batch_gemm_rega_kernel")
+    return flops, max(t_hbm, t_mfma), {
+        "bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
+        "kernel": kernel, "kernel_avg_ms": kern_ms, "kernel_launches_timed": launches,
+        "algorithmic_bytes_per_launch": nbytes, "algorithmic_flops_per_launch": flops,
+        "hbm_floor_ms": t_hbm * 1e3, "mfma_floor_ms": t_mfma * 1e3,
+        "traffic": traffic, "traffic_source": traffic_source}
+
+
+def batch_queries(torch, dev, nq, dims, corpus, eng_rows=None):
+    """Query block in HBM. gaussian / detembed corpora: unit Gaussian queries. clustered: the fuzz tool's mix — half of
+    the queries sit inside a cluster (a stored row + 0.05 gaussian, not normalised), half are plain Gaussian."""
+    q = torch.from_numpy(unit_queries(nq, dims)).to(dev)
+    if corpus == "clustered":
+        g = torch.Generator(device=dev)
+        g.manual_seed(QUERY_SEED + 5)
+        raw = torch.randn((nq, dims), generator=g, device=dev, dtype=torch.float32)
+        rows = []
+        for _, x in clustered_rows(torch, 0, GRANULE, dims, dev):
+            rows.append(x)
+        x0 = torch.cat(rows)[: nq // 2]
+        raw[: nq // 2] = x0 + 0.05 * raw[: nq // 2]
+        q = raw.contiguous()
+    return q
+
+
+def secondary_batched(torch, dev, rows, dims, nq, k, steps, warmup, label, row_base=0, corpus="gaussian"):
+    """BASELINE configs 3 / 5: nq queries per step as a bf16 MFMA GEMM + fused top-k + exact f32 re-score. Queries and
+    results stay in HBM (wax_hip_search_batch_submit_device / _collect_device): the timed region holds no host<->device
+    traffic except nq certificate flags per step."""
+    eng = _load_engine(torch, dev, rows, dims, corpus)
     eng.setRowBase(row_base)
     apply_tunes(eng)
     depth = 2                                # batches in flight, like the headline's --depth software pipeline
-    dq = torch.from_numpy(unit_queries(nq, dims)).to(dev)
+    dq = batch_queries(torch, dev, nq, dims, corpus)
     outs = [torch.empty((nq, k, 2), dtype=torch.int64, device=dev) for _ in range(depth)]
     stream = torch.cuda.current_stream(dev).cuda_stream
 
@@ -254,13 +433,14 @@ def secondary_batched(torch, dev, rows, dims, nq, k, steps, warmup, label, row_b
     eng.searchBatchHitsDevice(dq.data_ptr(), nq, k, outs[0].data_ptr(), k, stream)   # builds the bf16 mirror (untimed, like the corpus upload)
     run(warmup)
     # one blocking call per step, for reference: what a caller that cannot pipeline sees
+    nblk = max(5, steps // 4)
     _bracket(torch)
     tb = time.perf_counter()
-    for _ in range(max(10, steps // 4)):
+    for _ in range(nblk):
         eng.searchBatchHitsDevice(dq.data_ptr(), nq, k, outs[0].data_ptr(), k, stream)
     _bracket(torch)
-    blocking_ms = (time.perf_counter() - tb) / max(10, steps // 4) * 1e3
-    fb0 = eng.getTuning("batch_fallbacks")
+    blocking_ms = (time.perf_counter() - tb) / nblk * 1e3
+    fb0, rt0, mp0 = eng.getTuning("batch_fallbacks"), eng.getTuning("batch_retries"), eng.getTuning("batch_multi_passes")
     eng.setTuning("time_kernels", 1)
     apply_tunes(eng)
     eng.setTuning("reset_stats", 1)
@@ -272,38 +452,137 @@ def secondary_batched(torch, dev, rows, dims, nq, k, steps, warmup, label, row_b
     st = eng.stats()
     launches = int(st.batch_gemms_timed)
     kern_ms = st.batch_gemm_ms_total / launches if launches else float("nan")
-    flops = 2.0 * nq * rows * dims
-    nbytes = rows * dims * 2                  # bf16 mirror, streamed once per launch
-    t_hbm, t_mfma = nbytes / (HBM_PEAK_GBPS * 1e9), flops / (MFMA_BF16_PEAK_TFLOPS * 1e12)
-    bound = "hbm" if t_hbm >= t_mfma else "mfma"
-    if bound == "hbm":
-        achieved, peak, unit = nbytes / (kern_ms * 1e-3) / 1e9, HBM_PEAK_GBPS, "GB/s"
-    else:
-        achieved, peak, unit = flops / (kern_ms * 1e-3) / 1e12, MFMA_BF16_PEAK_TFLOPS, "TFLOP/s"
-    traffic, traffic_source = None, None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "latest_traffic.json"))).get("batched", {})
-        ent = tj.get("configs", {}).get(f"{rows}x{dims}xq{nq}")
-        if ent:
-            traffic = ent["hbm_bytes_per_launch"]
-            traffic_source = "replayed from profiles/latest_traffic.json (" + tj.get("source", "") + "), not measured in this run"
-    except (OSError, ValueError, KeyError):
-        pass
+    flops, floor_s, rf = batched_roofline(rows, dims, nq, kern_ms, launches)
     res = {
         "config": label,
         "value": nq * steps / el, "unit": "queries/s", "steps": steps, "warmup": warmup, "ms_per_step": el / steps * 1e3,
-        "dtype": "bf16 GEMM, exact f32 re-score", "queries_per_step": nq, "batches_in_flight": depth,
+        "dtype": "bf16 GEMM, exact f32 re-score", "queries_per_step": nq, "batches_in_flight": depth, "corpus": corpus,
         "ms_per_step_blocking_call": blocking_ms,
         "end_to_end_tflops_bf16": flops / (el / steps) / 1e12,
-        "end_to_end_frac_of_roof": max(t_hbm, t_mfma) / (el / steps),
+        "end_to_end_frac_of_roof": floor_s / (el / steps),
         "certificate_fallbacks": int(eng.getTuning("batch_fallbacks") - fb0),
+        "certificate_fallbacks_per_step": (eng.getTuning("batch_fallbacks") - fb0) / (steps + 0.0),
+        "wide_retries": int(eng.getTuning("batch_retries") - rt0),
+        "shared_exact_passes": int(eng.getTuning("batch_multi_passes") - mp0),
         "pipeline": "one-pass" if eng.getTuning("onepass_queries") > 0 else "slab",
-        "roofline": {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
-                     "kernel": "wax::batch_gemm_rega_kernel" if dims != 768 else "wax::batch_gemm_ksplit_kernel",
-                     "kernel_avg_ms": kern_ms, "kernel_launches_timed": launches,
-                     "algorithmic_bytes_per_launch": nbytes, "algorithmic_flops_per_launch": flops,
-                     "hbm_floor_ms": t_hbm * 1e3, "mfma_floor_ms": t_mfma * 1e3,
-                     "traffic": traffic, "traffic_source": traffic_source},
+        "last_result_checksum": _hits_checksum(outs[(steps - 1) % depth]),
+        "roofline": rf,
+    }
+    eng.close()
+    return res
+
+
+def _hits_checksum(hits):
+    """sha256 over the [nq][k] (key, frame id) hits of a batch: equal at every shard count / launch shape."""
+    import hashlib
+    a = hits.cpu().numpy() if hasattr(hits, "cpu") else np.asarray(hits)
+    return hashlib.sha256(np.ascontiguousarray(a, dtype=np.int64).tobytes()).hexdigest()[:16]
+
+
+def config5_sharded(torch, dist, args, rank, world, in_library, use_rccl, k=10, nq=1024, dims=768):
+    """BASELINE config 5 over the N GPUs of this run: 10M x 768 row-sharded, 1024 queries per step (bf16 MFMA GEMM + fused
+    top-k on every shard, exact re-score), per-shard [nq][k] hits exchanged and merged per query by key. Both launch shapes:
+      * torchrun ranks: every rank answers the batch on its shard (device-resident), one RCCL all-gather of nq*k hits per
+        rank, merge on every rank (wax_amd.sharded.ShardedBatchSearcher, two batches in flight);
+      * one process: the sharded handle's own device-resident submit / collect (peer copies of the hits to the first
+        device, merge there).
+    `value` = queries/s of the whole job (max over ranks of the elapsed time)."""
+    from wax_amd import sharded
+    rows = args.c5_rows
+    steps, warmup, depth = max(10, min(args.steps // 4, 40)), max(3, min(args.warmup, 6)), 2
+    same = bool(os.environ.get("WAX_BENCH_SAME_DEVICE"))
+    if in_library:
+        n_sh = args.gpus
+        devs = [0 if same else g for g in range(n_sh)]
+        dev0 = torch.device("cuda", devs[0])
+        from wax_amd import HIPVectorEngine, VectorMetric
+        eng = HIPVectorEngine(metric=VectorMetric.cosine, dimensions=dims, devices=devs)
+        eng.reserve(rows)
+        per = -(-rows // n_sh)
+        per = -(-per // 64) * 64
+        r = 0
+        while r < rows:
+            g_ = min(r // per, n_sh - 1)
+            r_hi = min(rows, (r // GRANULE + 1) * GRANULE, (g_ + 1) * per if g_ + 1 < n_sh else rows)
+            for r0, x in device_rows(torch, r, r_hi, dims, torch.device("cuda", devs[g_])):
+                eng.addBatchDevice(np.arange(r0, r0 + x.shape[0], dtype=np.uint64), x)
+            r = r_hi
+        rows_per_gpu = per
+        dev = dev0
+    else:
+        lo, hi = sharded.shard_bounds(rows, world, rank, align=64)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        eng = _load_engine(torch, dev, hi - lo, dims, lo=lo)
+        eng.setRowBase(lo)
+        rows_per_gpu = hi - lo
+    apply_tunes(eng)
+    dq = torch.from_numpy(unit_queries(nq, dims)).to(dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier(device_ids=[torch.cuda.current_device()]) if use_rccl else dist.barrier()
+        torch.cuda.synchronize()
+
+    if in_library:
+        outs = [torch.empty((nq, k, 2), dtype=torch.int64, device=dev) for _ in range(depth)]
+
+        def run(n_steps):
+            tickets = []
+            for i in range(n_steps):
+                if len(tickets) == depth:
+                    eng.searchBatchCollectDevice(tickets.pop(0))
+                tickets.append(eng.searchBatchSubmitDevice(dq.data_ptr(), nq, k, outs[i % depth].data_ptr(), k, stream))
+            for t in tickets:
+                eng.searchBatchCollectDevice(t)
+            return outs[(n_steps - 1) % depth]
+        eng.searchBatchHitsDevice(dq.data_ptr(), nq, k, outs[0].data_ptr(), k, stream)     # mirrors (untimed)
+    else:
+        searcher = sharded.ShardedBatchSearcher(eng, rank, world, k, nq, depth=depth, exchange="rccl" if use_rccl else "host")
+
+        def run(n_steps):
+            last = None
+            for _ in range(n_steps):
+                if searcher.pending() == depth:
+                    last = searcher.collect()
+                searcher.submit(dq)
+            while searcher.pending():
+                last = searcher.collect()
+            return last
+        searcher.submit(dq)
+        searcher.collect()                                                                   # mirror (untimed)
+    run(warmup)
+    eng.setTuning("time_kernels", 1)
+    eng.setTuning("reset_stats", 1)
+    barrier()
+    t0 = time.perf_counter()
+    last = run(steps)
+    barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev if use_rccl else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    st = eng.stats()
+    launches = int(st.batch_gemms_timed)
+    kern_ms = st.batch_gemm_ms_total / launches if launches else float("nan")
+    flops, floor_s, rf = batched_roofline(rows_per_gpu, dims, nq, kern_ms, launches)
+    n_gpus = args.gpus if in_library else world
+    res = {
+        "config": f"{rows} x {dims} row-sharded over {n_gpus} GPU(s) ({rows_per_gpu} rows each), {nq} queries per step, cosine top-{k}, "
+                  f"bf16 MFMA GEMM + fused top-k per shard + exact f32 re-score, per-shard hits "
+                  + ("peer-copied to the first device and merged there (ONE process, sharded handle)" if in_library else
+                     ("all-gathered over RCCL and merged on every rank" if use_rccl else "all-gathered on the host (gloo) and merged"))
+                  + " (BASELINE config 5), queries and results resident in HBM, 2 batches in flight",
+        "value": nq * steps / el, "unit": "queries/s", "steps": steps, "warmup": warmup, "ms_per_step": el / steps * 1e3,
+        "n_gpus": n_gpus, "scaling": "strong", "dtype": "bf16 GEMM, exact f32 re-score", "queries_per_step": nq,
+        "batches_in_flight": depth, "rows_per_gpu": rows_per_gpu,
+        "end_to_end_tflops_bf16": 2.0 * nq * rows * dims / (el / steps) / 1e12,
+        "end_to_end_frac_of_roof_per_gpu": floor_s / (el / steps),
+        "certificate_fallbacks": int(eng.getTuning("batch_fallbacks")),
+        "last_result_checksum": _hits_checksum(last),
+        "roofline": rf,
     }
     eng.close()
     return res
@@ -389,14 +668,12 @@ def main():
     for r0, x in device_rows(torch, probe_row, probe_row + 1, dims, dev):
         probe = x[0].cpu().numpy()
 
-    eng.setTuning("time_kernels", 1)
     apply_tunes(eng)
     if in_library and args.exchange == "rccl" and not os.environ.get("WAX_BENCH_SAME_DEVICE"):
         eng.setTuning("exchange", 1)        # one ncclAllGather per query on the library's single-process communicator
     if world == 1:
-        # two in-order streams; the library chains the scan kernels through an event so they never
-        # overlap each other (per-kernel HIP-event times stay clean) while one query's merge / result
-        # write / next query upload hide under the neighbouring scan
+        # two in-order streams: one query's merge / result write / next query upload hide under the neighbouring scan,
+        # and (product mode) neighbouring scans overlap each other's ramp and tail
         eng.setTuning("streams", 2)
         eng.setTuning("slots", max(args.depth, 2))
         searcher = None
@@ -420,17 +697,6 @@ def main():
     ids, scores = collect(submit(probe))
     assert int(ids[0]) == probe_row and abs(float(scores[0]) - 1.0) < 1e-5, (ids[:3], scores[:3])
 
-    def run(qs):
-        pending = []
-        last = None
-        for q in qs:
-            if len(pending) >= args.depth:
-                last = collect(pending.pop(0))
-            pending.append(submit(q))
-        while pending:
-            last = collect(pending.pop(0))
-        return last
-
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
@@ -446,29 +712,22 @@ def main():
     import gc
     gc.collect()
     gc.disable()
-    run(queries[:args.warmup])
-    eng.setTuning("reset_stats", 1)
-    barrier()
-    t0 = time.perf_counter()
-    last = run(queries[args.warmup:args.warmup + args.steps])
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, last, kern_ms, launches, cal = measure_single_query(eng, submit, collect, queries, args.warmup, args.steps, args.depth,
+                                                                 barrier, chain_timed_region=args.chain_timed_region)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if use_rccl else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    st = eng.stats()
     assert len(last[0]) == min(k, n)
     import hashlib
     checksum = hashlib.sha256(np.asarray(last[0], dtype=np.uint64).tobytes()
                               + np.asarray(last[1], dtype=np.float32).tobytes()).hexdigest()[:16]
-
+    exchange_mode = eng.getTuning("exchange") if in_library else 0
+    want = SECONDARY_N1 if args.secondary == "all" else [s for s in args.secondary.split(",") if s]
+    out = None
     if rank == 0:
         qps = args.steps / elapsed
-        launches = int(st.scan_kernels_timed)
-        kern_ms = (st.scan_kernel_ms_total / launches) if launches else float("nan")
         bytes_per_launch = (hi - lo) * dims * 4
-        achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if launches else float("nan")
         # HBM traffic needs a PMC pass of its own (rocprofv3 --pmc FETCH_SIZE, never combined with tracing): it cannot be
         # measured inside this run. A figure REPLAYED from the committed counter pass of this same command is reported
         # with its source; without a matching pass the field is null.
@@ -482,11 +741,12 @@ def main():
                     traffic_source = "replayed from profiles/latest_traffic.json (" + str(tj.get("source", "rocprofv3 --pmc FETCH_SIZE pass of this command")) + "), not measured in this run"
             except Exception:  # noqa: BLE001
                 traffic = None
+        n_gpus = args.gpus if in_library else world
         out = {
             "metric": f"queries/sec, {_human_rows(n)} x {dims}-dim f32 cosine top-{k} brute-force scan (single query per step)",
             "value": qps,
             "unit": "queries/s",
-            "n_gpus": args.gpus if in_library else world,
+            "n_gpus": n_gpus,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -497,65 +757,91 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{n} x {dims}-dim f32 unit-norm Gaussian corpus (seed {CORPUS_SEED}), cosine top-{k}, "
-                            f"one query per step, corpus resident in HBM and row-sharded over {args.gpus if in_library else world} GPU(s)",
+                            f"one query per step, corpus resident in HBM and row-sharded over {n_gpus} GPU(s)",
                 "rows": n, "dims": dims, "top_k": k, "rows_per_gpu": hi - lo,
                 "parallelism": (f"row-shard x{args.gpus}, ONE process: the library's multi-GPU engine (wax_hip_engine_create_sharded), "
-                                + ("single-process RCCL all-gather" if eng.getTuning("exchange") == 1 else "peer-copy gather")
+                                + ("single-process RCCL all-gather" if exchange_mode == 1 else "peer-copy gather")
                                 + " of per-shard top-k + merge on the first device") if in_library else
                                (f"row-shard x{world}" + ((" + RCCL all-gather of per-shard top-k" if use_rccl else
                                                           " + host (gloo) all-gather of per-shard top-k") if world > 1 else "")),
                 "pipeline_depth": args.depth,
+                "timed_region": "kernels timed and chained inside it (--chain-timed-region)" if args.chain_timed_region else
+                                "product mode: scans of neighbouring queries overlap; per-launch times from the calibration pass",
                 "merge": "host" if (world > 1 and (args.host_merge or not use_rccl)) else "device",
                 "exchange": ("in-library" if in_library else (("rccl all_gather" if use_rccl else "host (gloo)") if world > 1 else "none")),
                 "last_result_checksum": checksum,
             },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS if launches else None,
-                "traffic": traffic,
-                "traffic_source": traffic_source,
-                "kernel": "wax::scan_kernel (fused scan + per-wave top-k)",
-                "kernel_avg_ms": kern_ms,
-                "kernel_launches_timed": launches,
-                "algorithmic_bytes_per_launch": bytes_per_launch,
-                "note": "rows_per_gpu*dims*4 bytes per launch / mean HIP-event duration of the scan kernel over the "
-                        "timed region (rank 0's shard; scans are chained across the two pipeline streams, so they "
-                        "never overlap each other)",
-            },
+            "roofline": scan_roofline(bytes_per_launch, kern_ms, launches, elapsed, args.steps, cal, traffic, traffic_source),
         }
         if world == 1 and not in_library and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(torch, args, dev, queries)
         elif world == 1:
             out["cpu_baseline"] = None
-        if world == 1 and not in_library and not args.no_secondary:
-            # the other single-GPU BASELINE configurations, timed after the headline (its engine is released first)
-            gc.enable()
-            eng.close()
-            gc.collect()
-            gc.disable()
-            sec = []
-            for fn in (lambda: secondary_single_query(torch, dev, 10_000, 384, k, max(args.steps, 2000), max(args.warmup, 100), args.depth,
-                                                      "the 10K-row point of the N matrix: launch-latency-bound, 15 MB per query"),
-                       lambda: secondary_single_query(torch, dev, 1_000_000, 384, k, max(args.steps, 100), max(args.warmup, 10), args.depth),
-                       lambda: secondary_batched(torch, dev, 1_000_000, 384, 256, k, max(args.steps, 200), max(args.warmup, 20),
-                                                 "1000000 x 384, 256 queries per step, cosine top-10, bf16 MFMA GEMM + fused top-k, 1 GPU "
-                                                 "(BASELINE config 3), queries and results resident in HBM, 2 batches in flight"),
-                       lambda: secondary_batched(torch, dev, 1_000_000, 384, 1024, k, max(args.steps // 2, 100), max(args.warmup, 20),
-                                                 "1000000 x 384, 1024 queries per step, cosine top-10, bf16 MFMA GEMM + fused top-k, 1 GPU "
-                                                 "(config 3 at four times the batch: the MFMA-bound shape), queries and results resident in "
-                                                 "HBM, 2 batches in flight"),
-                       lambda: secondary_batched(torch, dev, 1_250_000, 768, 1024, k, max(args.steps // 2, 60), max(args.warmup, 10),
-                                                 "1250000 x 768 (one GPU's share of 10M x 768 over 8 GPUs), 1024 queries per step, cosine "
-                                                 "top-10, bf16 MFMA GEMM + fused top-k (BASELINE config 5, per-GPU part), queries and "
-                                                 "results resident in HBM, 2 batches in flight", row_base=3_750_000)):
+    if not args.no_secondary:
+        # the other BASELINE configurations, timed after the headline (its engine is released first)
+        gc.enable()
+        eng.close()
+        searcher = None
+        gc.collect()
+        gc.disable()
+        sec = []
+        if world == 1 and not in_library:
+            s, w = args.steps, args.warmup
+            table = {
+                "s10k": lambda: secondary_single_query(torch, dev, 10_000, 384, k, max(s, 2000), max(w, 100), args.depth,
+                                                       "the 10K-row point of the N matrix: launch-latency-bound, 15 MB per query"),
+                "s1m": lambda: secondary_single_query(torch, dev, 1_000_000, 384, k, max(s, 100), max(w, 10), args.depth),
+                "b1m_q256": lambda: secondary_batched(torch, dev, 1_000_000, 384, 256, k, max(s, 200), max(w, 20),
+                                                      "1000000 x 384, 256 queries per step, cosine top-10, bf16 MFMA GEMM + fused top-k, 1 GPU "
+                                                      "(BASELINE config 3), queries and results resident in HBM, 2 batches in flight"),
+                "b1m_q1024": lambda: secondary_batched(torch, dev, 1_000_000, 384, 1024, k, max(s // 2, 100), max(w, 20),
+                                                       "1000000 x 384, 1024 queries per step, cosine top-10, bf16 MFMA GEMM + fused top-k, 1 GPU "
+                                                       "(config 3 at four times the batch: the MFMA-bound shape), queries and results resident in "
+                                                       "HBM, 2 batches in flight"),
+                "c5_shard": lambda: secondary_batched(torch, dev, 1_250_000, 768, 1024, k, max(s // 2, 60), max(w, 10),
+                                                      "1250000 x 768 (one GPU's share of 10M x 768 over 8 GPUs), 1024 queries per step, cosine "
+                                                      "top-10, bf16 MFMA GEMM + fused top-k (BASELINE config 5, per-GPU part), queries and "
+                                                      "results resident in HBM, 2 batches in flight", row_base=3_750_000),
+                "c5_full": lambda: secondary_batched(torch, dev, args.c5_rows, 768, 1024, k, max(10, min(s // 8, 25)), 3,
+                                                     f"{args.c5_rows} x 768, 1024 queries per step, cosine top-10, bf16 MFMA GEMM + fused top-k, ALL "
+                                                     "rows on ONE GPU (BASELINE config 5 at full size: the N = 1 point of its 1/2/4/8-GPU scaling "
+                                                     "curve), queries and results resident in HBM, 2 batches in flight"),
+                "clustered_k10": lambda: secondary_batched(torch, dev, 1_000_000, 384, 256, 10, max(s // 2, 100), max(w, 10),
+                                                           "1000000 x 384 CLUSTERED corpus (20 tight clusters: normalize(centre + 0.3 gaussian), half "
+                                                           "of the queries inside a cluster), 256 queries per step, cosine top-10: the batched path "
+                                                           "where bf16 cannot separate neighbours — certificate fallbacks share exact passes",
+                                                           corpus="clustered"),
+                "clustered_k100": lambda: secondary_batched(torch, dev, 1_000_000, 384, 256, 100, max(s // 4, 40), max(w // 2, 5),
+                                                            "the same clustered corpus and queries at top-100 (the dense-neighbourhood regime of "
+                                                            "tools/fuzz_batch.py: the k-th neighbour has hundreds of rows inside its bf16 error band)",
+                                                            corpus="clustered"),
+                "detembed": lambda: secondary_batched(torch, dev, 1_000_000, 384, 256, 10, max(s // 2, 100), max(w, 10),
+                                                      "1000000 x 384 rows of the reference's DeterministicEmbedder (FNV-1a / LCG on \"doc-<i>\", "
+                                                      "RAGBenchmarkSupport.swift:114-157), 256 queries per step, cosine top-10", corpus="detembed"),
+            }
+            for name in want:
+                if name not in table:
+                    continue
                 try:
-                    sec.append(fn())
+                    r = table[name]()
+                    r["name"] = name
+                    sec.append(r)
                 except Exception as ex:  # noqa: BLE001 — a secondary failure must not lose the headline line
-                    sec.append({"error": f"{type(ex).__name__}: {ex}"})
+                    sec.append({"name": name, "error": f"{type(ex).__name__}: {ex}"})
+            iid = next((x for x in sec if x.get("name") == "b1m_q256" and "error" not in x), None)
+            for x in sec:
+                if iid and x.get("corpus") in ("clustered", "detembed") and "error" not in x and x.get("queries_per_step") == 256:
+                    x["ms_per_step_vs_iid_config3"] = x["ms_per_step"] / iid["ms_per_step"]
+        elif args.secondary == "all" or "c5" in want:
+            try:
+                r = config5_sharded(torch, dist, args, rank, world, in_library, use_rccl)
+                r["name"] = "c5"
+                sec.append(r)
+            except Exception as ex:  # noqa: BLE001
+                sec.append({"name": "c5", "error": f"{type(ex).__name__}: {ex}"})
+        if out is not None:
             out["secondary"] = sec
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         if use_rccl:

@@ -299,3 +299,24 @@ def test_sharded_create_validates_the_device_list(hip_lib):
     assert hip_lib.wax_hip_engine_create_sharded(0, 384, devs, 0, ctypes.byref(h)) == _abi.ERR_INVALID_ARGUMENT
     assert hip_lib.wax_hip_engine_create_sharded(0, 384, None, 2, ctypes.byref(h)) == _abi.ERR_INVALID_ARGUMENT
     assert hip_lib.wax_hip_shard_count(None) == 0
+
+
+def test_bench_deterministic_embedder_rows_match_the_oracle():
+    """bench.py's vectorised DeterministicEmbedder corpus (torch int64 arithmetic: FNV-1a over "doc-<i>", LCG, Float(Int64)
+    / Float(Int64.max), L2 normalisation) against the oracle's C restatement of RAGBenchmarkSupport.swift:114-157, text
+    by text — including every digit-count boundary."""
+    import importlib.util
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("wax_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    dims = 48
+    for lo, hi in [(0, 12), (95, 105), (999, 1002), (123456, 123459), (999_998, 1_000_003), (9_999_999, 10_000_001)]:
+        got = torch.cat([x for _, x in bench.deterministic_embedder_rows(torch, lo, hi, dims, torch.device("cpu"))]).numpy()
+        assert got.shape == (hi - lo, dims)
+        for i in range(lo, hi):
+            exp = oracle.deterministic_embed(f"doc-{i}", dims, normalize=True)
+            assert np.max(np.abs(got[i - lo] - exp)) <= 3e-7, (i, got[i - lo][:4], exp[:4])
+            raw = oracle.deterministic_embed(f"doc-{i}", dims, normalize=False)
+            assert np.allclose(got[i - lo] * np.linalg.norm(raw.astype(np.float64)), raw, atol=1e-6)

@@ -495,7 +495,7 @@ def test_full_size_parity_dot_and_l2(wax, metric):
     eng.close()
 
 
-@pytest.mark.parametrize("n,dims,nq", [(1_000_000, 384, 8), (10_000_000, 384, 3), (1_000_000, 768, 3),
+@pytest.mark.parametrize("n,dims,nq", [(1_000_000, 384, 8), (10_000_000, 384, 8), (1_000_000, 768, 3),
                                        (6_000_000, 768, 2)])  # 6M x 768 = 4.6e9 elements: past the reference kernels' 32-bit offset wrap (CosineDistance.metal:191, 275)
 def test_full_size_parity_with_oracle(wax, n, dims, nq):
     import torch
@@ -668,8 +668,8 @@ def test_batch_throughput_config3(wax):
 
 def test_batch_config5_shard_shape(wax):
     """BASELINE config 5, one GPU's share of the 8-way sharded corpus: 1.25M x 768, 1024 queries (K-split
-    register-resident GEMM), with row_base set as on rank 3 of 8. 128 of the 1024 answers (every 8th query) are
-    compared with the f64 oracle on the same rows; no certificate fallbacks on random data."""
+    register-resident GEMM), with row_base set as on rank 3 of 8. ALL 1024 answers are compared with the f64 oracle on the
+    same rows (one oracle pass for the whole batch); no certificate fallbacks on random data."""
     import time
     import torch
     n, dims, nq, k = 1_250_000, 768, 1024, 10
@@ -691,7 +691,7 @@ def test_batch_config5_shard_shape(wax):
     from wax_amd import sharded
     h_ids, h_scores, h_valid = sharded.decode_hits(wax.VectorMetric.cosine, hits)
     assert np.all(h_valid)
-    sel = np.arange(0, nq, 8)
+    sel = np.arange(0, nq)
     # keys carry GLOBAL rows (row_base + local row); frame ids are the local rows here
     assert np.array_equal((hits[:, :, 0] & 0xFFFFFFFF) - base, h_ids.astype(np.int64))
     t0 = time.perf_counter()
@@ -705,22 +705,111 @@ def test_batch_config5_shard_shape(wax):
     eng.close()
 
 
+def _oracle_batch_streaming(eng, torch, n, dims, dev, queries, kk, block_rows=1_048_576):
+    """Loads the n x dims device-generated corpus into `eng` and returns the f64 oracle's (rows, distances, counts) top-kk
+    of every query WITHOUT holding the corpus on the host: rows are downloaded a block at a time, the oracle answers the
+    whole batch on the block (oracle.search_batch: one pass for all queries) and the per-query lists are merged by
+    (distance asc, row asc) — the oracle's own order. Host memory stays at one block (3 GB at 768 dims) instead of 30 GB."""
+    nq = len(queries)
+    best_rows = np.full((nq, 0), -1, dtype=np.int64)
+    best_dist = np.full((nq, 0), np.inf, dtype=np.float32)
+    pend, pend_lo, pend_rows = [], 0, 0
+
+    def flush():
+        nonlocal best_rows, best_dist, pend, pend_lo, pend_rows
+        if not pend:
+            return
+        block = np.concatenate(pend) if len(pend) > 1 else pend[0]
+        rows, dist, counts = oracle.search_batch(0, block, queries, kk)
+        rows = np.where(np.arange(rows.shape[1])[None, :] < counts[:, None], rows + pend_lo, -1)
+        dist = np.where(rows >= 0, dist, np.inf).astype(np.float32)
+        allr = np.concatenate([best_rows, rows], axis=1)
+        alld = np.concatenate([best_dist, dist], axis=1)
+        keep_r = np.empty((nq, min(kk, allr.shape[1])), dtype=np.int64)
+        keep_d = np.empty(keep_r.shape, dtype=np.float32)
+        for i in range(nq):
+            rr = np.where(allr[i] >= 0, allr[i], np.iinfo(np.int64).max)
+            order = np.lexsort((rr, alld[i]))[:keep_r.shape[1]]
+            keep_r[i], keep_d[i] = allr[i][order], alld[i][order]
+        best_rows, best_dist = keep_r, keep_d
+        pend_lo += pend_rows
+        pend, pend_rows = [], 0
+
+    eng.reserve(n)
+    for lo, x in _device_corpus(torch, n, dims, dev):
+        eng.addBatchDevice(np.arange(lo, lo + x.shape[0], dtype=np.uint64), x)
+        pend.append(x.cpu().numpy())
+        pend_rows += x.shape[0]
+        if pend_rows >= block_rows:
+            flush()
+    flush()
+    counts = np.sum(best_rows >= 0, axis=1)
+    return best_rows, best_dist, counts
+
+
+@pytest.mark.parametrize("n,dims,nq,n_check", [(10_000_000, 768, 1024, 64), (10_000_000, 384, 256, 256)])
+def test_batched_full_size_parity_on_one_gpu(wax, n, dims, nq, n_check):
+    """BASELINE config 5 at FULL size on one GPU (10M x 768, 1024 queries: the N = 1 point of its scaling curve) and config
+    3's batch at the headline's row count (10M x 384, 256 queries): the batched bf16 MFMA path, device-resident, against the
+    f64 oracle on the same rows — 64 of the 1024 answers (every 16th query) resp. all 256, id for id and score for score —
+    plus bit-identity with the single-query path and zero certificate fallbacks on this corpus."""
+    import time
+    import torch
+    dev = torch.device("cuda", 0)
+    k = 10
+    queries = oracle.gaussian_unit_queries(nq, dims, seed=77)
+    sel = np.arange(0, nq, nq // n_check)
+    eng = wax.HIPVectorEngine(dimensions=dims)
+    t0 = time.perf_counter()
+    rows, dist, counts = _oracle_batch_streaming(eng, torch, n, dims, dev, queries[sel], k + MARGIN)
+    t_oracle = time.perf_counter() - t0
+    assert eng.count == n
+    dq = torch.from_numpy(queries).to(dev)
+    out = torch.empty((nq, k, 2), dtype=torch.int64, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    eng.searchBatchHitsDevice(dq.data_ptr(), nq, k, out.data_ptr(), k, st)          # builds the mirror
+    q0 = eng.getTuning("onepass_queries")
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        eng.searchBatchHitsDevice(dq.data_ptr(), nq, k, out.data_ptr(), k, st)
+    dt = (time.perf_counter() - t0) / reps
+    assert eng.getTuning("onepass_queries") - q0 == reps * nq                        # the one-pass MFMA pipeline served them
+    fb = eng.getTuning("batch_fallbacks")
+    print(f"\n[{n}x{dims} Q={nq}] {dt * 1e3:.2f} ms/batch (blocking call) = {nq / dt:.0f} q/s, {2 * nq * n * dims / dt / 1e12:.0f} TFLOP/s "
+          f"bf16 end to end, fallbacks {fb}; corpus build + streaming oracle for {len(sel)} queries {t_oracle:.1f} s")
+    from wax_amd import sharded
+    h_ids, h_scores, h_valid = sharded.decode_hits(wax.VectorMetric.cosine, out.cpu().numpy())
+    assert np.all(h_valid)
+    for j, i in enumerate(sel):
+        kk = min(k, int(counts[j]))
+        x_scores = oracle.scores_from_distances(0, dist[j, :counts[j]])
+        assert_parity(h_ids[i][:kk], h_scores[i][:kk], rows[j, :kk], x_scores[:kk], x_scores, f"{n}x{dims} batched q{i}")
+    for i in (0, nq // 2, nq - 1):                                                    # bit-identical to the single-query path
+        s_ids, s_scores = eng.searchArrays(queries[i], k)
+        assert np.array_equal(h_ids[i], s_ids) and np.array_equal(h_scores[i], s_scores)
+    assert fb == 0
+    eng.close()
+
+
 # ---------------------------------------------------------------------------
 # the N>1 bench path end to end on one GPU: two / three ranks share GPU 0 and exchange per-shard
 # top-k through the host (gloo) — RCCL itself refuses duplicate GPUs; everything else (shard bounds,
 # global-row keys, pipelined ShardedSearcher, merge, barriers, max-over-ranks timing) is the code the
 # driver runs with --gpus N over RCCL.
 
-def _run_bench(nproc, extra, tmp_path):
+def _run_bench(nproc, extra, tmp_path, one_process=False):
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    common = ["--rows", "300000", "--steps", "12", "--warmup", "2", "--no-cpu-baseline"] + extra
+    common = ["--rows", "300000", "--steps", "12", "--warmup", "2", "--no-cpu-baseline", "--c5-rows", "300000"] + extra
     env = dict(os.environ)
-    if nproc == 1:
-        cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common
+    if nproc == 1 or one_process:
+        if one_process:
+            env["WAX_BENCH_SAME_DEVICE"] = "1"
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(nproc)] + common
     else:
         env["WAX_BENCH_SAME_DEVICE"] = "1"
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
@@ -733,45 +822,56 @@ def _run_bench(nproc, extra, tmp_path):
 
 
 def test_bench_contract_and_shard_invariance(wax, tmp_path):
-    one = _run_bench(1, [], tmp_path)
+    one = _run_bench(1, ["--secondary", "s10k,s1m,b1m_q256,b1m_q1024,c5_shard,c5_full,clustered_k10"], tmp_path)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in one, key
     assert one["n_gpus"] == 1 and one["steps"] == 12 and one["dtype"] == "f32" and one["vs_baseline"] is None
     r = one["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["kernel_launches_timed"] == 12
+    # frac: per launch, from the calibration pass of the same run (12 chained, event-timed scans); pipeline_frac: the timed region
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["kernel_launches_timed"] == 12 and r["calibration"]["steps"] == 12
+    assert abs(r["pipeline_frac"] - 300000 * 384 * 4 * 12 / (one["ms_per_step"] * 12e-3) / 1e9 / 8000.0) < 1e-6
     assert abs(one["value"] - 12 / (one["ms_per_step"] * 12e-3)) < 1e-6 * one["value"]
     assert "300K x 384" in one["metric"] and one["config"]["parallelism"] == "row-shard x1"
     assert r["traffic"] is None and r["traffic_source"] is None      # no counter pass exists for this row count
     sec = one["secondary"]
-    assert len(sec) == 5 and all("error" not in x for x in sec), sec
+    assert [x["name"] for x in sec] == ["s10k", "s1m", "b1m_q256", "b1m_q1024", "c5_shard", "c5_full", "clustered_k10"]
+    assert all("error" not in x for x in sec), sec
     for x in sec:
         rr = x["roofline"]
-        assert x["value"] > 0 and x["ms_per_step"] > 0 and rr["kernel_launches_timed"] >= x["steps"]
+        assert x["value"] > 0 and x["ms_per_step"] > 0 and rr["kernel_launches_timed"] >= min(x["steps"], 60)
         assert rr["bound"] in ("hbm", "mfma") and 0 < rr["frac"] < 1.2 and abs(rr["frac"] - rr["achieved"] / rr["peak"]) < 1e-9
+    assert sec[0]["roofline"]["launches_per_query"] == 1            # 10K rows: the scan kernel's last workgroup merges
     assert all(x["pipeline"] == "one-pass" and x["batches_in_flight"] == 2 and x["ms_per_step_blocking_call"] > 0 for x in sec[2:])
-    assert all(x["certificate_fallbacks"] == 0 for x in sec[2:])
-    print("\n[bench secondary] " + " | ".join(f"{x['value']:.0f} q/s, {x['ms_per_step']:.3f} ms/step, frac {x['roofline']['frac']:.3f}" for x in sec))
+    assert all(x["certificate_fallbacks"] == 0 for x in sec[2:6])
+    assert sec[6]["corpus"] == "clustered" and "ms_per_step_vs_iid_config3" in sec[6]
+    print("\n[bench secondary] " + " | ".join(f"{x['name']}: {x['value']:.0f} q/s, {x['ms_per_step']:.3f} ms/step, frac {x['roofline']['frac']:.3f}" for x in sec))
+    print(f"[bench clustered k=10] fallbacks/step {sec[6]['certificate_fallbacks_per_step']:.1f}, shared exact passes {sec[6]['shared_exact_passes']}, "
+          f"{sec[6]['ms_per_step_vs_iid_config3']:.2f} x the iid batch time")
+    c5_one = sec[5]["last_result_checksum"]                          # config 5 (shrunk to 300K rows) on ONE engine
+    # the in-timed-region measurement mode (what a rocprofv3 kernel-trace summary is compared with)
+    chained = _run_bench(1, ["--no-secondary", "--chain-timed-region"], tmp_path)
+    assert chained["roofline"]["kernel_launches_timed"] == 12 and chained["config"]["last_result_checksum"] == one["config"]["last_result_checksum"]
     two = _run_bench(2, [], tmp_path)
     assert "host (gloo)" in two["config"]["parallelism"]
     # ONE process, three shards inside the library (all on GPU 0 here): same answers again
-    import os
-    import subprocess
-    import sys
-    import json
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--rows", "300000", "--steps", "12", "--warmup", "2",
-                          "--no-cpu-baseline"], env=dict(os.environ, WAX_BENCH_SAME_DEVICE="1"), capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-3000:]
-    lib3 = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
+    lib3 = _run_bench(3, [], tmp_path, one_process=True)
     assert lib3["n_gpus"] == 3 and "wax_hip_engine_create_sharded" in lib3["config"]["parallelism"]
     assert lib3["config"]["last_result_checksum"] == one["config"]["last_result_checksum"]
-    assert lib3["roofline"]["kernel_launches_timed"] == 36           # 12 steps x 3 shard scans
+    assert lib3["roofline"]["kernel_launches_timed"] == 36           # 12 calibration steps x 3 shard scans
     three = _run_bench(3, [], tmp_path)
     assert two["n_gpus"] == 2 and three["n_gpus"] == 3
     assert one["config"]["last_result_checksum"] == two["config"]["last_result_checksum"] \
         == three["config"]["last_result_checksum"]
+    # config 5 at N > 1, both launch shapes: ranks + all-gather, and one process on the sharded handle — same hits as one engine
+    for run, shape in ((two, "ranks"), (three, "ranks"), (lib3, "handle")):
+        c5 = run["secondary"]
+        assert len(c5) == 1 and c5[0]["name"] == "c5" and "error" not in c5[0], c5
+        assert c5[0]["n_gpus"] == run["n_gpus"] and c5[0]["queries_per_step"] == 1024 and c5[0]["value"] > 0
+        assert c5[0]["last_result_checksum"] == c5_one, (shape, run["n_gpus"])
+        assert ("sharded handle" in c5[0]["config"]) == (shape == "handle")
+        assert c5[0]["roofline"]["kernel_launches_timed"] >= c5[0]["steps"]
 
 
 def test_search_batch_hits_and_sharded_batch_single_rank(wax):
@@ -1698,3 +1798,73 @@ def test_concurrent_batched_searches_share_the_mirror(wax):
     ids, scores, _ = eng.searchBatch(queries, 10)
     assert ids[5, 0] == 10 ** 9 and abs(scores[5, 0] - 1.0) <= 1e-5
     eng.close()
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("dims", [64, 128, 256, 384, 512, 768, 1024, 1536])
+def test_multi_query_exact_scan_is_bit_identical(wax, dims, metric):
+    """scan_multi_kernel (the shared exact pass of the batched path's fallback, multiscan.hip) against scan_kernel:
+    with the MFMA pipelines switched off, a device-resident batch is answered by groups of queries sharing one pass
+    over the f32 store — the hits (keys = ordered distance : row, frame ids) must equal the single-query path's BIT FOR
+    BIT, at every specialised dimension and metric, for k below and above the 64-slot list limit, for group remainders,
+    ragged row counts, a non-zero row base, and against `batch_multi = 0` (one scan per query, the round-2 fallback)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n = 30_011 if dims <= 512 else 9_973
+    corpus = oracle.gaussian_unit_rows(40 + dims, n, dims)
+    if metric != 0:
+        corpus = corpus * np.linspace(0.5, 2.0, n, dtype=np.float32)[:, None]
+    corpus[17] = corpus[16]                                   # an exact tie: (distance asc, row asc) must decide
+    eng = make_engine(wax, metric, dims, corpus, np.arange(n, dtype=np.uint64) * 5 + 3)
+    eng.setRowBase(1_000_003)
+    eng.setTuning("batch_mode", 0)                            # no MFMA pipeline: the exact path answers the batch
+    group, group_big = eng.getTuning("batch_multi_group"), eng.getTuning("batch_multi_group_big")   # queries per pass: k <= 60 / k <= 192
+    assert group >= 2 and group_big >= 1
+    for nq, k in [(group * 2 + 3, 10), (1, 10), (2, 60), (group_big + 1, 100), (5, 192)]:
+        queries = oracle.gaussian_unit_queries(nq, dims, seed=dims + nq + k)
+        if nq > 2:
+            queries[2] = corpus[16]                           # aims at the tie
+        dq = torch.from_numpy(np.ascontiguousarray(queries)).to(dev)
+        out = {}
+        for multi in (1, 0):
+            eng.setTuning("batch_multi", multi)
+            p0 = eng.getTuning("batch_multi_passes")
+            o = torch.full((nq, k + 2, 2), 5, dtype=torch.int64, device=dev)
+            eng.searchBatchHitsDevice(dq.data_ptr(), nq, k, o.data_ptr(), k + 2, torch.cuda.current_stream(dev).cuda_stream)
+            out[multi] = o.cpu().numpy()
+            passes = eng.getTuning("batch_multi_passes") - p0
+            g_k = group if k <= 60 else group_big
+            assert passes == ((-(-nq // g_k)) if (multi and nq >= 2 and g_k >= 2) else 0), (dims, metric, nq, k, multi, passes)
+        assert np.array_equal(out[1], out[0]), (dims, metric, nq, k)
+        for i in range(nq):                                   # and both equal the single-query entry point
+            s_ids, s_scores = eng.searchArrays(queries[i], k)
+            hits = out[1][i]
+            assert np.array_equal(hits[:len(s_ids), 1].astype(np.uint64), s_ids), (dims, metric, nq, k, i)
+            assert np.all(hits[k:, 0] == (1 << 63) - 1)
+    eng.close()
+
+
+def test_fused_final_merge_equals_two_launch_path(wax):
+    """Small grids (<= 160 workgroups: stores up to ~20K rows) let the scan kernel's last-arriving workgroup do the final
+    merge (scan_epilogue: write-through partial lists, device-scope ticket) instead of a second launch. Same hits, bit for
+    bit, as the two-launch path ("fuse_merge" = 0) — for every k the fused kernels serve, ragged sizes, all metrics, the
+    generic-dims kernel, and many back-to-back queries on pipelined slots (the ticket must re-arm itself)."""
+    for metric, dims, n in [(0, 384, 10_000), (1, 384, 9_999), (2, 128, 5_000), (0, 768, 3_001), (0, 100, 2_000), (0, 384, 65), (0, 64, 20_000)]:
+        corpus = oracle.gaussian_unit_rows(7 + n, n, dims)
+        corpus[11] = corpus[10]
+        eng = make_engine(wax, metric, dims, corpus, np.arange(n, dtype=np.uint64) + 9)
+        queries = oracle.gaussian_unit_queries(24, dims, seed=n)
+        queries[3] = corpus[10]
+        for k in (1, 10, 64, 65, 192):
+            eng.setTuning("fuse_merge", 1)
+            pend = [eng.submit(q, k) for q in queries[:4]]          # pipelined: four slots, four tickets
+            fused = [eng.collect(t, k) for t in pend] + [eng.searchArrays(q, k) for q in queries[4:]]
+            eng.setTuning("fuse_merge", 0)
+            for q, (f_ids, f_scores) in zip(queries, fused):
+                s_ids, s_scores = eng.searchArrays(q, k)
+                assert np.array_equal(f_ids, s_ids) and np.array_equal(f_scores, s_scores), (metric, dims, n, k)
+        e_ids, e_scores, _, _ = oracle.search(metric, corpus, np.arange(n, dtype=np.uint64) + 9, queries[0], 10)
+        eng.setTuning("fuse_merge", 1)
+        g_ids, g_scores = eng.searchArrays(queries[0], 10)
+        assert_parity(g_ids, g_scores, e_ids, e_scores, None, f"fused merge m{metric} d{dims} n{n}")
+        eng.close()

@@ -211,7 +211,7 @@ def test_sharded_device_rows_and_single_device_entry_points(wax):
     with pytest.raises(wax.EncodingError):
         many.addBatchDevice(np.arange(5, dtype=np.uint64), rows[:5].contiguous())       # ids already present
     for call in (lambda: many.setRowBase(5), lambda: many.timeStreamRead(1), lambda: many.timeScanKernel(q, 10, 1),
-                 lambda: many.searchShardDevice(q, 10, rows.data_ptr()), lambda: many.searchBatchHitsDevice(rows.data_ptr(), 4, 10, rows.data_ptr(), 10)):
+                 lambda: many.searchShardDevice(q, 10, rows.data_ptr())):
         with pytest.raises(wax.EncodingError) as ei:
             call()
         assert "sharded" in str(ei.value)
@@ -221,6 +221,90 @@ def test_sharded_device_rows_and_single_device_entry_points(wax):
     with pytest.raises(wax.InvalidToc) as ei:
         wax.HIPVectorEngine(dimensions=dims, devices=[])
     assert "device list" in str(ei.value)
+    one.close(), many.close()
+
+
+@pytest.mark.parametrize("shards", [1, 2, 3, 8])
+def test_sharded_batched_device_resident_entry_points(wax, shards):
+    """wax_hip_search_batch_hits_device / _submit_device / _collect_device on a sharded handle (round 3: pooled per-shard
+    workspaces, no thread and no allocation per call): queries and hits in the first device's HBM; the answer equals ONE
+    engine's bit for bit — through the one-pass MFMA pipeline, the slab pipeline (small shards), the loop path, wider and
+    narrower strides, k above the device-merge limit, more than 1024 queries, pipelined tickets, and an empty handle."""
+    import torch
+    dev = torch.device("cuda", 0)
+    KEY_PAD = (1 << 63) - 1
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def run(eng, dq, nq, k, stride):
+        out = torch.full((nq, stride, 2), 5, dtype=torch.int64, device=dev)
+        guard = torch.full((8,), 77, dtype=torch.int64, device=dev)
+        eng.searchBatchHitsDevice(dq.data_ptr(), nq, k, out.data_ptr(), stride, stream)
+        assert torch.all(guard == 77)
+        return out.cpu().numpy()
+
+    for dims, n, nq in [(384, 160_000, 300), (384, 20_000, 200), (768, 150_000, 130), (100, 6_000, 20), (384, 90_000, 1500)]:
+        one, many = pair(wax, 0, dims, shards)
+        rows = torch.nn.functional.normalize(torch.randn((n, dims), device=dev, generator=torch.Generator(device=dev).manual_seed(n + dims)), dim=1).contiguous()
+        ids = np.arange(n, dtype=np.uint64) * 3 + 11
+        for eng in (one, many):
+            eng.reserve(n)
+            eng.addBatchDevice(ids, rows)
+        queries = oracle.gaussian_unit_queries(nq, dims, seed=shards + n % 89)
+        queries[1] = rows[4321].cpu().numpy()
+        dq = torch.from_numpy(queries).to(dev)
+        for k, stride in [(10, 10), (10, 16), (10, 4), (200, 200)]:
+            a, b = run(one, dq, nq, k, stride), run(many, dq, nq, k, stride)
+            assert np.array_equal(a, b), (shards, dims, n, nq, k, stride)
+            w = min(k, stride)
+            assert np.all(b[:, w:, 0] == KEY_PAD) and b[1, 0, 1] == 4321 * 3 + 11
+        h_one, c_one = one.searchBatchHits(queries, 10)               # host-pointer form: same path underneath
+        h_many, c_many = many.searchBatchHits(queries, 10)
+        assert np.array_equal(h_one, h_many) and np.array_equal(c_one, c_many)
+        # pipelined tickets (two in flight, as bench.py's config-5 secondary drives the handle)
+        outs = [torch.empty((nq, 10, 2), dtype=torch.int64, device=dev) for _ in range(3)]
+        tickets = []
+        for i in range(5):
+            if len(tickets) == 2:
+                many.searchBatchCollectDevice(tickets.pop(0))
+            tickets.append(many.searchBatchSubmitDevice(dq.data_ptr(), nq, 10, outs[i % 3].data_ptr(), 10, stream))
+        t = many.submit(queries[0], 10)                               # single-query tickets interleave with batch tickets
+        for bt in tickets:
+            many.searchBatchCollectDevice(bt)
+        many.collect(t, 10)
+        ref = run(one, dq, nq, 10, 10)
+        for o in outs:
+            assert np.array_equal(o.cpu().numpy(), ref)
+        one.close(), many.close()
+    empty = wax.HIPVectorEngine(dimensions=64, devices=[0] * shards)
+    dq = torch.from_numpy(oracle.gaussian_unit_queries(5, 64)).to(dev)
+    assert np.all(run(empty, dq, 5, 10, 10)[:, :, 0] == KEY_PAD)
+    empty.close()
+
+
+def test_sharded_submit_beyond_the_slot_pool_and_concurrent_filtered_search(wax):
+    """(1) A thread that pipelines more sharded submits than the handle's soft slot cap (8) without collecting gets fresh
+    slots instead of waiting for itself while holding the read lock (round-2 advisor finding). (2) Filtered search visits
+    the shards concurrently (persistent per-shard workers) and equals one engine's result, long allow-lists included."""
+    dims, n = 128, 40_000
+    corpus = oracle.gaussian_unit_rows(9, n, dims)
+    one, many = pair(wax, 0, dims, 4)
+    ids = np.arange(n, dtype=np.uint64) * 2 + 1
+    for eng in (one, many):
+        eng.reserve(n)
+        eng.addBatch(ids, corpus)
+    queries = oracle.gaussian_unit_queries(20, dims, seed=6)
+    tickets = [many.submit(q, 10) for q in queries]                   # 20 outstanding tickets, none collected yet
+    got = [many.collect(t, 10) for t in tickets]
+    for q, (g_ids, g_scores) in zip(queries, got):
+        e_ids, e_scores = one.searchArrays(q, 10)
+        assert np.array_equal(g_ids, e_ids) and np.array_equal(g_scores, e_scores)
+    rng = np.random.default_rng(3)
+    for n_allow in (5, 3000, 30_000):
+        allow = rng.choice(ids, size=n_allow, replace=False)
+        for q in queries[:3]:
+            a = one.searchFiltered(q, 10, frameIds=allow)
+            b = many.searchFiltered(q, 10, frameIds=allow)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), n_allow
     one.close(), many.close()
 
 

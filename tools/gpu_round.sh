@@ -22,6 +22,15 @@ for s in $STAGES; do
       timeout 600 python __graft_entry__.py --smoke > "$OUT/smoke.log" 2>&1; rc=$? ;;
     tests)
       timeout 600 python -m pytest tests -m gpu -q -rA --durations=15 -p no:cacheprovider --timeout 150 > "$OUT/pytest_gpu.log" 2>&1; rc=$? ;;
+    tests3)
+      timeout 1500 python -m pytest tests -m gpu -q -rf --durations=25 -p no:cacheprovider --timeout 400 > "$OUT/pytest_gpu.log" 2>&1; rc=$? ;;
+    newtests)
+      timeout 900 python -m pytest tests -m gpu -q -x -rf --durations=10 -p no:cacheprovider --timeout 400 \
+          -k "multi_query_exact or fused_final_merge or sharded_batched_device or beyond_the_slot_pool or falls_back_on_ties or adversarial" > "$OUT/pytest_new.log" 2>&1; rc=$? ;;
+    shardbench)
+      timeout 900 python tools/sharded_handle_bench.py --parts ${WAX_PARTS:-A,B,C} > "$OUT/sharded_handle_bench.jsonl" 2> "$OUT/sharded_handle_bench.err"; rc=$? ;;
+    fuzz)
+      timeout 400 python tools/fuzz_batch.py --seconds ${WAX_FUZZ_S:-120} --seed 7 > "$OUT/fuzz_batch.jsonl" 2> "$OUT/fuzz_batch.err"; rc=$? ;;
     tests_x)
       timeout 600 python -m pytest tests -m gpu -x -q -p no:cacheprovider --timeout 150 > "$OUT/pytest_gpu_x.log" 2>&1; rc=$? ;;
     filtered)

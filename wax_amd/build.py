@@ -15,7 +15,7 @@ ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libwaxhip.so")
-SOURCES = ["kernels.hip", "batch.hip", "filter.hip", "rrf.hip", "engine.hip"]
+SOURCES = ["kernels.hip", "multiscan.hip", "batch.hip", "filter.hip", "rrf.hip", "engine.hip"]
 HEADERS = ["common.h", "topk.h", "kernels.h", "sharded.inc", os.path.join(ROOT, "include", "wax_hip.h")]
 ARCH = "gfx950"
 

@@ -182,6 +182,13 @@ class IdMap {
 
 constexpr int kShardRing = 8;
 
+// A scan's stage buffer: per-workgroup partial top-k lists, followed by one cache line holding the arrival ticket of the
+// fused final merge (scan_epilogue: zero between launches — the last arriver re-arms it).
+constexpr size_t kPartialsBytes = (size_t)MAX_GRID_BLOCKS * FUSED_MAX_K * sizeof(int64_t) + 128;
+inline uint32_t* partials_ticket(int64_t* d_partials) {
+    return reinterpret_cast<uint32_t*>(d_partials + (size_t)MAX_GRID_BLOCKS * FUSED_MAX_K);
+}
+
 constexpr int kMaxStreams = 4;
 
 struct Slot {
@@ -297,6 +304,11 @@ struct BatchCtx {
     bool last_finish_valid = false;
     uint32_t* h_qlist = nullptr;         // pinned [kBatchMaxQ]
     uint32_t* d_qlist = nullptr;         // [kBatchMaxQ]
+    // shared exact pass over the uncertified queries (multiscan.hip): their norms by slot, per-(query, workgroup) partial top-k
+    float* h_fnorm = nullptr;            // pinned [kBatchMaxQ]
+    float* d_fnorm = nullptr;            // [kBatchMaxQ]
+    int64_t* d_mpart = nullptr;          // [group][grid][k]
+    uint64_t mpart_cap = 0;
     uint32_t* h_cert = nullptr;          // pinned [cert_cap]
     float* h_qnorm = nullptr;            // pinned [cert_cap]: exact norms (the exact-path fallback needs them on the host)
 };
@@ -336,7 +348,11 @@ struct wax_hip_engine {
     uint32_t tev_next = 0;
     bool chain_is_timing = false;
     std::atomic<int64_t> share_timing{1};
-    std::atomic<int64_t> scan_chain{1};          // 0 (experiments): pipelined scans of different streams may overlap each other
+    // Pipelined scans of different streams: 1 = chained through an event (they never overlap: a per-launch HIP-event
+    // duration is one scan alone), 0 = free to overlap (no idle HBM between two scans, ramp and tail of neighbouring
+    // kernels hidden: +3 .. +19 % queries/s), -1 (default) = chained exactly when the kernels are being timed
+    // ("time_kernels" = 1), so the product path is the fast one and a measurement pass still gets clean per-launch times.
+    std::atomic<int64_t> scan_chain{-1};
     std::mutex chain_mu;
 
     std::mutex slot_mu;
@@ -376,6 +392,7 @@ struct wax_hip_engine {
     std::atomic<int64_t> time_kernels{0};
     std::atomic<int64_t> force_general{0};
     std::atomic<int64_t> stream_nt{1};
+    std::atomic<int64_t> fuse_merge{1};      // 1 = grids of <= SCAN_FUSE_MERGE_GRID workgroups merge in the scan kernel's last-arriving workgroup
     std::atomic<int64_t> batch_min{1};       // fewer queries than this: always pipelined single-query scans (1..15: cost model below)
     std::atomic<int64_t> batch_mode{1};      // 0 = never use the MFMA path
     std::atomic<int64_t> batch_slab_mb{64};  // cap on slab size, in units of 16 384 rows
@@ -393,6 +410,8 @@ struct wax_hip_engine {
     std::atomic<int64_t> batch_onepass_tiles{1024};   // smallest store (in GEMM tiles) the one-pass pipeline takes
     std::atomic<int64_t> batch_survivors{3};      // one-pass pipeline: expected survivors per query = this x k'
     std::atomic<int64_t> batch_retry{1};          // one-pass pipeline: uncertified queries get a wide (k' = 960) finish before the exact path
+    std::atomic<int64_t> batch_multi{1};          // exact path of a batch: 1 = uncertified queries share passes over the f32 store (multiscan.hip), 0 = one scan each
+    std::atomic<uint64_t> st_multi_passes{0}, st_multi_queries{0};
     std::atomic<uint64_t> st_batch_retries{0};
     std::atomic<int64_t> batch_dynamic{0};        // one-pass pipeline: filtering-GEMM workgroups claim their tiles from a counter
     std::atomic<int64_t> batch_sample_div{32};    // one-pass pipeline: 1 / this of the tiles are sampled (at least 256)
@@ -478,6 +497,9 @@ int sh_submit(wax_hip_engine* e, const float* query, uint32_t dims, int32_t top_
 int sh_collect(wax_hip_engine* e, uint64_t ticket, uint64_t* out_ids, float* out_scores, uint32_t capacity, uint32_t* out_count);
 int sh_search_batch_hits(wax_hip_engine* e, const float* queries, uint32_t nq, uint32_t dims, int32_t top_k, wax_hip_hit* out_hits,
                          uint32_t stride, uint32_t* out_counts);
+int sh_batch_device(wax_hip_engine* e, const float* d_queries, uint32_t nq, uint32_t dims, int32_t top_k, wax_hip_hit* d_out_hits,
+                    uint32_t out_stride, void* stream, uint64_t* ticket);
+int sh_batch_collect_device(wax_hip_engine* e, uint64_t ticket, uint32_t* out_fallbacks);
 int sh_search_filtered(wax_hip_engine* e, const float* query, uint32_t dims, int32_t top_k, int has_allow, const uint64_t* allow,
                        uint64_t n_allow, int has_min, float min_score, uint64_t* out_ids, float* out_scores, uint32_t capacity,
                        uint32_t* out_count);
@@ -530,7 +552,8 @@ int alloc_slot(wax_hip_engine* e, Slot** out) {
     const size_t qbytes = (size_t)e->dims * sizeof(float);
     if ((err = hipMalloc(&s->d_query, qbytes)) != hipSuccess) return bail(WAX_HIP_ERR_ALLOC, "transient query buffer", err);
     if ((err = hipHostMalloc(&s->h_query, qbytes, hipHostMallocDefault)) != hipSuccess) return bail(WAX_HIP_ERR_ALLOC, "pinned query buffer", err);
-    if ((err = hipMalloc(&s->d_partials, (size_t)MAX_GRID_BLOCKS * FUSED_MAX_K * sizeof(int64_t))) != hipSuccess) return bail(WAX_HIP_ERR_ALLOC, "top-k stage buffer", err);
+    if ((err = hipMalloc(&s->d_partials, kPartialsBytes)) != hipSuccess) return bail(WAX_HIP_ERR_ALLOC, "top-k stage buffer", err);
+    if ((err = hipMemset(partials_ticket(s->d_partials), 0, 128)) != hipSuccess) return bail(WAX_HIP_ERR_ALLOC, "top-k stage buffer", err);
     if ((err = hipMalloc(&s->d_hits, (size_t)WAX_HIP_MAX_RESULTS * sizeof(wax_hip_hit))) != hipSuccess) return bail(WAX_HIP_ERR_ALLOC, "top-k results buffer", err);
     if ((err = hipHostMalloc(&s->h_hits, (size_t)WAX_HIP_MAX_RESULTS * sizeof(wax_hip_hit), hipHostMallocDefault)) != hipSuccess) return bail(WAX_HIP_ERR_ALLOC, "pinned results buffer", err);
     *out = s;
@@ -735,7 +758,10 @@ int enqueue_scan(wax_hip_engine* e, const float* d_query, float q_norm, int k_ef
             }
         }
         if (record_start) HIP_TRY(hipEventRecord(ev0, stream), WAX_HIP_ERR_INTERNAL, "event record");
-        HIP_TRY(launch_scan(a, e->metric, (int)e->variant.load(), cap, false, (int)e->grid_blocks.load(), stream, &grid),
+        // small grids: the last-arriving workgroup does the final merge itself (one launch per query instead of two)
+        bool merged = false;
+        if (e->fuse_merge.load() != 0) { a.merge_out = d_hits; a.ids = e->d_ids; a.arrive = partials_ticket(d_partials); a.kpad = kpad; }
+        HIP_TRY(launch_scan(a, e->metric, (int)e->variant.load(), cap, false, (int)e->grid_blocks.load(), stream, &grid, &merged),
                 WAX_HIP_ERR_INTERNAL, "scan kernel launch");
         if (ev1) HIP_TRY(hipEventRecord(ev1, stream), WAX_HIP_ERR_INTERNAL, "event record");
         if (chain_guard.owns_lock()) {
@@ -752,9 +778,10 @@ int enqueue_scan(wax_hip_engine* e, const float* d_query, float q_norm, int k_ef
             e->scan_done_valid = true;
             chain_guard.unlock();
         }
-        HIP_TRY(launch_merge_keys(d_partials, (uint32_t)grid * (uint32_t)k_eff, k_eff, kpad, e->d_ids, a.row_base,
-                                  a.n_rows, d_hits, cap, stream),
-                WAX_HIP_ERR_INTERNAL, "merge kernel launch");
+        if (!merged)
+            HIP_TRY(launch_merge_keys(d_partials, (uint32_t)grid * (uint32_t)k_eff, k_eff, kpad, e->d_ids, a.row_base,
+                                      a.n_rows, d_hits, cap, stream),
+                    WAX_HIP_ERR_INTERNAL, "merge kernel launch");
     } else {
         if (!general_slot) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "top_k too large for the device-resident shard path (max 192)");
         int rc = ensure_general(e, general_slot);
@@ -846,7 +873,7 @@ void free_bctx(BatchCtx* c) {
     (void)hipFree(c->d_cand); (void)hipFree(c->d_seg_count); (void)hipFree(c->d_exact); (void)hipFree(c->d_sel);
     (void)hipFree(c->d_tile_max); (void)hipFree(c->d_hits);
     (void)hipHostFree(c->h_hits); (void)hipHostFree(c->h_cert); (void)hipHostFree(c->h_qnorm); (void)hipHostFree(c->h_qlist);
-    (void)hipFree(c->d_qlist);
+    (void)hipFree(c->d_qlist); (void)hipHostFree(c->h_fnorm); (void)hipFree(c->d_fnorm); (void)hipFree(c->d_mpart);
     if (c->ev_in) (void)hipEventDestroy(c->ev_in);
     if (c->ev_g0) (void)hipEventDestroy(c->ev_g0);
     if (c->ev_g1) (void)hipEventDestroy(c->ev_g1);
@@ -872,7 +899,9 @@ int alloc_bctx(wax_hip_engine* e, BatchCtx** out) {
     A(&c->d_overflow, (kBatchMaxQ + BATCH_TILE_CTRS * 32) * sizeof(uint32_t));   // + the filtering GEMM's tile counters
     A(&c->d_seg_count, (size_t)kBatchMaxSegs * kBatchMaxQ * sizeof(uint32_t));
     A(&c->d_qlist, (size_t)kBatchMaxQ * sizeof(uint32_t));
+    A(&c->d_fnorm, (size_t)kBatchMaxQ * sizeof(float));
     if (err == hipSuccess) err = hipHostMalloc(&c->h_qlist, (size_t)kBatchMaxQ * sizeof(uint32_t), hipHostMallocDefault);
+    if (err == hipSuccess) err = hipHostMalloc(&c->h_fnorm, (size_t)kBatchMaxQ * sizeof(float), hipHostMallocDefault);
     if (err != hipSuccess) {
         free_bctx(c);
         return fail(WAX_HIP_ERR_ALLOC, std::string("Failed to allocate batch workspace: ") + hipGetErrorString(err));
@@ -1303,6 +1332,69 @@ int batch_submit_device_locked(wax_hip_engine* e, BatchCtx* c, const float* d_qu
     return WAX_HIP_OK;
 }
 
+// Exact answers for `nf` queries of a device-resident block (rows fq[i] of d_queries, norms h_norm_by_query[fq[i]]), hits
+// into rows fq[i] of d_out, on the workspace's stream; synchronised on return. Groups of scan_multi_group() queries share
+// one pass over the f32 store; what the multi-query kernel does not serve (k > 192, unspecialised dims, a single query)
+// takes one fused / general scan per query as before.
+int exact_scan_queries(wax_hip_engine* e, BatchCtx* c, const float* d_queries, const uint32_t* fq, const float* h_norm_by_query,
+                       uint32_t nf, int k_eff, wax_hip_hit* d_out, uint32_t out_stride) {
+    hipStream_t st = c->stream;
+    const uint32_t D = e->dims;
+    const uint32_t n = (uint32_t)e->count;
+    int rc = WAX_HIP_OK;
+    uint32_t done = 0;
+    const uint32_t group = (e->batch_multi.load() != 0 && nf >= 2 && e->force_general.load() == 0) ? scan_multi_group(D, k_eff) : 0u;
+    if (group >= 2) {
+        const int grid = scan_grid_for(n, D, 0, (int)e->grid_blocks.load());
+        rc = grow_dev(&c->d_mpart, &c->mpart_cap, (uint64_t)group * (uint64_t)grid * (uint64_t)k_eff, sizeof(int64_t),
+                      "Failed to allocate exact-pass partials");
+        if (rc != WAX_HIP_OK) return rc;
+        for (uint32_t base = 0; base < nf && rc == WAX_HIP_OK; base += kBatchMaxQ) {
+            const uint32_t m = nf - base < kBatchMaxQ ? nf - base : kBatchMaxQ;
+            for (uint32_t i = 0; i < m; ++i) {
+                c->h_qlist[i] = fq[base + i];
+                c->h_fnorm[i] = h_norm_by_query[fq[base + i]];
+            }
+            HIP_TRY(hipMemcpyAsync(c->d_qlist, c->h_qlist, m * sizeof(uint32_t), hipMemcpyHostToDevice, st), WAX_HIP_ERR_INTERNAL, "exact-pass list upload");
+            HIP_TRY(hipMemcpyAsync(c->d_fnorm, c->h_fnorm, m * sizeof(float), hipMemcpyHostToDevice, st), WAX_HIP_ERR_INTERNAL, "exact-pass norm upload");
+            for (uint32_t g0 = 0; g0 < m; g0 += group) {
+                ScanMultiArgs a{};
+                a.store = e->d_store; a.queries = d_queries; a.qlist = c->d_qlist + g0; a.q_norm = c->d_fnorm + g0;
+                a.partials = c->d_mpart; a.n_rows = n; a.row_base = (uint32_t)e->row_base; a.dims = D;
+                a.nq = m - g0 < group ? m - g0 : group; a.k = k_eff;
+                int used_grid = 0;
+                HIP_TRY(launch_scan_multi(a, e->metric, (int)e->grid_blocks.load(), st, &used_grid), WAX_HIP_ERR_INTERNAL, "multi-query scan launch");
+                HIP_TRY(launch_merge_keys_multi(c->d_mpart, (uint32_t)used_grid, k_eff, e->d_ids, a.row_base, n, d_out, out_stride,
+                                                c->d_qlist + g0, a.nq, st), WAX_HIP_ERR_INTERNAL, "multi-query merge launch");
+                e->st_multi_passes += 1;
+                e->st_rows += e->count;
+                e->st_bytes += e->count * (uint64_t)D * 4ull;
+            }
+            HIP_TRY(hipStreamSynchronize(st), WAX_HIP_ERR_INTERNAL, "exact pass failed on device");   // the pinned lists are reused
+            done += m;
+        }
+        e->st_multi_queries += done;
+        e->st_searches += done;
+        return rc;
+    }
+    Slot* s = nullptr;
+    for (; done < nf; ++done) {
+        const uint32_t q = fq[done];
+        if (!s) {
+            rc = acquire_slot(e, &s, /*try_only=*/false, /*holding=*/true);
+            if (rc != WAX_HIP_OK) return rc;
+        }
+        rc = enqueue_scan(e, d_queries + (uint64_t)q * D, h_norm_by_query[q], k_eff, (int)out_stride, s->d_partials, s,
+                          d_out + (uint64_t)q * out_stride, st, nullptr, nullptr, /*chain=*/false);
+        if (rc != WAX_HIP_OK) break;
+    }
+    if (s) {
+        (void)hipStreamSynchronize(st);
+        release_slot(e, s);
+    }
+    return rc;
+}
+
 // Wait for a submitted batch; queries whose certificate failed (ties, clustered data, an overflowed list) are answered
 // by the exact path in place — never an approximation.
 int batch_finish_device_locked(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32_t nq, int k_eff,
@@ -1344,23 +1436,13 @@ int batch_finish_device_locked(wax_hip_engine* e, BatchCtx* c, const float* d_qu
         }
     }
     c->last_finish_valid = false;
-    uint32_t fallbacks = 0;
-    Slot* s = nullptr;
-    for (uint32_t q = 0; q < nq; ++q) {
-        if (c->h_cert[q]) continue;
-        if (!s) {
-            rc = acquire_slot(e, &s, /*try_only=*/false, /*holding=*/true);
-            if (rc != WAX_HIP_OK) return rc;
-        }
-        rc = enqueue_scan(e, d_queries + (uint64_t)q * D, c->h_qnorm[q], k_eff, (int)out_stride, s->d_partials, s,
-                          d_out + (uint64_t)q * out_stride, st, nullptr, nullptr, /*chain=*/false);
-        if (rc != WAX_HIP_OK) break;
-        ++fallbacks;
-    }
-    if (s) {
-        (void)hipStreamSynchronize(st);
-        release_slot(e, s);
-    }
+    // Exact path for whatever is still uncertified. The queries share passes over the f32 store (up to 16 per pass,
+    // scan_multi_kernel: scan_kernel's arithmetic, bit-identical distances) instead of taking one scan each.
+    std::vector<uint32_t> failed;
+    for (uint32_t q = 0; q < nq; ++q)
+        if (!c->h_cert[q]) failed.push_back(q);
+    const uint32_t fallbacks = (uint32_t)failed.size();
+    if (fallbacks > 0) rc = exact_scan_queries(e, c, d_queries, failed.data(), c->h_qnorm, fallbacks, k_eff, d_out, out_stride);
     e->st_batch_fallbacks += fallbacks;
     if (out_fallbacks) *out_fallbacks = fallbacks;
     return rc;
@@ -1721,6 +1803,11 @@ int wax_hip_remove(wax_hip_engine* e, uint64_t frame_id) {
 static int submit_impl(wax_hip_engine* e, const float* query, uint32_t dims, int32_t top_k, uint64_t* out_ticket,
                        bool try_only);
 
+static bool chain_scans(wax_hip_engine* e) {
+    const int64_t sc = e->scan_chain.load();
+    return sc > 0 || (sc < 0 && e->time_kernels.load() != 0);
+}
+
 int wax_hip_search_submit(wax_hip_engine* e, const float* query, uint32_t dims, int32_t top_k, uint64_t* out_ticket) {
     if (e && e->sh) return sh_submit(e, query, dims, top_k, out_ticket);
     return submit_impl(e, query, dims, top_k, out_ticket, false);
@@ -1762,7 +1849,7 @@ static int submit_impl(wax_hip_engine* e, const float* query, uint32_t dims, int
         // The last kernel of the chain writes the k hits straight into the slot's pinned host buffer
         // (device-visible, 16*k bytes over PCIe): no D2H copy launch; visibility at ev_done.
         rc = enqueue_scan(e, s->d_query, qn, k_eff, k_eff, s->d_partials, s, s->h_hits, s->stream,
-                          s->timed ? s->ev0 : nullptr, s->timed ? s->ev1 : nullptr, /*chain=*/e->scan_chain.load() != 0, &s->t_start, &s->t_end);
+                          s->timed ? s->ev0 : nullptr, s->timed ? s->ev1 : nullptr, /*chain=*/chain_scans(e), &s->t_start, &s->t_end);
         if (rc != WAX_HIP_OK) break;
         err = hipEventRecord(s->ev_done, s->stream);
         if (err != hipSuccess) { rc = fail(WAX_HIP_ERR_INTERNAL, std::string("event record: ") + hipGetErrorString(err)); break; }
@@ -1999,7 +2086,8 @@ static int batch_device_impl(wax_hip_engine* e, const float* d_queries, uint32_t
                              wax_hip_hit* d_out_hits, uint32_t out_stride, void* stream, uint64_t* ticket, const char* what) {
     if (ticket) *ticket = 0;
     if (!e) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine is null");
-    if (e->sh) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, std::string(what) + " is a single-device entry point: not available on a sharded engine");
+    (void)what;
+    if (e->sh) return sh_batch_device(e, d_queries, nq, dims, top_k, d_out_hits, out_stride, stream, ticket);   // queries / hits on the handle's first device
     if (nq > 0 && (!d_queries || !d_out_hits || out_stride == 0)) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null input");
     if (nq > 0 && dims != e->dims) return fail(WAX_HIP_ERR_DIM_MISMATCH, dim_mismatch_msg(e->dims, dims));
     DeviceGuard g(e->device);
@@ -2065,19 +2153,18 @@ static int batch_device_impl(wax_hip_engine* e, const float* d_queries, uint32_t
         keep_lock = true;
         return WAX_HIP_OK;
     }
-    // loop path: one exact scan per query, back to back on the workspace's stream; the norms come from the host
+    // loop path (batches the MFMA pipelines do not take): exact scans on the workspace's stream — groups of queries
+    // share one pass over the f32 store (exact_scan_queries); the norms come from the host
     std::vector<float> hq((size_t)nq * dims);
     HIP_TRY(hipMemcpyAsync(hq.data(), d_queries, hq.size() * sizeof(float), hipMemcpyDeviceToHost, st), WAX_HIP_ERR_INTERNAL, "query download");
     HIP_TRY(hipStreamSynchronize(st), WAX_HIP_ERR_INTERNAL, "query download");
-    Slot* s = nullptr;
-    rc = acquire_slot(e, &s, /*try_only=*/false, /*holding=*/true);
-    if (rc != WAX_HIP_OK) return rc;
-    for (uint32_t q = 0; q < nq && rc == WAX_HIP_OK; ++q)
-        rc = enqueue_scan(e, d_queries + (uint64_t)q * dims, query_norm(hq.data() + (size_t)q * dims, dims), k_eff, (int)out_stride,
-                          s->d_partials, s, d_out_hits + (uint64_t)q * out_stride, st, nullptr, nullptr, /*chain=*/false);
-    hipError_t serr = hipStreamSynchronize(st);
-    release_slot(e, s);
-    if (rc == WAX_HIP_OK && serr != hipSuccess) rc = fail(WAX_HIP_ERR_INTERNAL, std::string("batch search failed on device: ") + hipGetErrorString(serr));
+    std::vector<uint32_t> all(nq);
+    std::vector<float> norms(nq);
+    for (uint32_t q = 0; q < nq; ++q) {
+        all[q] = q;
+        norms[q] = query_norm(hq.data() + (size_t)q * dims, dims);
+    }
+    rc = exact_scan_queries(e, c, d_queries, all.data(), norms.data(), nq, k_eff, d_out_hits, out_stride);
     if (rc == WAX_HIP_OK) done_ticket();
     return rc;
 }
@@ -2096,6 +2183,7 @@ int wax_hip_search_batch_submit_device(wax_hip_engine* e, const float* d_queries
 int wax_hip_search_batch_collect_device(wax_hip_engine* e, uint64_t ticket, uint32_t* out_fallbacks) {
     if (out_fallbacks) *out_fallbacks = 0;
     if (!e) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine is null");
+    if (e->sh) return sh_batch_collect_device(e, ticket, out_fallbacks);
     wax_hip_engine::BatchTicket t;
     {
         std::unique_lock<std::mutex> tg(e->bticket_mu);
@@ -2126,8 +2214,17 @@ int wax_hip_set_row_base(wax_hip_engine* e, uint64_t row_base) {
     return WAX_HIP_OK;
 }
 
+// q_norm < 0: compute it here; the sharded handle computes ||q|| once per query and hands it to every shard.
+static int search_shard_device_impl(wax_hip_engine* e, const float* query, uint32_t dims, int32_t top_k, wax_hip_hit* d_out_hits,
+                                    void* stream, float q_norm);
+
 int wax_hip_search_shard_device(wax_hip_engine* e, const float* query, uint32_t dims, int32_t top_k,
                                 wax_hip_hit* d_out_hits, void* stream) {
+    return search_shard_device_impl(e, query, dims, top_k, d_out_hits, stream, -1.0f);
+}
+
+static int search_shard_device_impl(wax_hip_engine* e, const float* query, uint32_t dims, int32_t top_k, wax_hip_hit* d_out_hits,
+                                    void* stream, float q_norm) {
     if (!e || !d_out_hits) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine/output is null");
     SHARDED_UNSUPPORTED(e, "wax_hip_search_shard_device");
     if (dims != e->dims || !query) return fail(WAX_HIP_ERR_DIM_MISMATCH, dim_mismatch_msg(e->dims, query ? dims : 0));
@@ -2153,7 +2250,8 @@ int wax_hip_search_shard_device(wax_hip_engine* e, const float* query, uint32_t 
             {
                 hipError_t err = hipMalloc(&e->ring_d_query[r], (size_t)e->dims * sizeof(float));
                 if (err == hipSuccess) err = hipHostMalloc(&e->ring_h_query[r], (size_t)e->dims * sizeof(float), hipHostMallocDefault);
-                if (err == hipSuccess) err = hipMalloc(&e->ring_d_partials[r], (size_t)MAX_GRID_BLOCKS * FUSED_MAX_K * sizeof(int64_t));
+                if (err == hipSuccess) err = hipMalloc(&e->ring_d_partials[r], kPartialsBytes);
+                if (err == hipSuccess) err = hipMemset(partials_ticket(e->ring_d_partials[r]), 0, 128);
                 if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ring_ev0[r], hipEventReleaseToDevice);
                 if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ring_ev1[r], hipEventReleaseToDevice);
                 if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ring_done[r], hipEventDisableTiming);
@@ -2169,16 +2267,16 @@ int wax_hip_search_shard_device(wax_hip_engine* e, const float* query, uint32_t 
         }
         const int k_eff = (uint64_t)kpad < e->count ? kpad : (int)e->count;
         std::memcpy(e->ring_h_query[r], query, (size_t)dims * sizeof(float));
-        const float qn = query_norm(query, dims);
+        const float qn = q_norm >= 0.0f ? q_norm : query_norm(query, dims);
         hipError_t err = hipMemcpyAsync(e->ring_d_query[r], e->ring_h_query[r], (size_t)dims * sizeof(float), hipMemcpyHostToDevice, st);
         if (err != hipSuccess) { rc = fail(WAX_HIP_ERR_INTERNAL, std::string("query upload: ") + hipGetErrorString(err)); break; }
         harvest_ring_event(e, (int)r);  // the entry's previous use has finished (waited for above)
         const bool timed = e->time_kernels.load() != 0;
-        // chain=true: scans issued on different caller streams never overlap each other, while the
-        // merge kernel and whatever the caller enqueues next (RCCL all-gather, merge, download) do
-        // overlap the following scan.
+        // chained (when kernels are timed, or "scan_chain" = 1): scans issued on different caller streams never overlap
+        // each other, while the merge kernel and whatever the caller enqueues next (RCCL all-gather, merge, download)
+        // do overlap the following scan.
         rc = enqueue_scan(e, e->ring_d_query[r], qn, k_eff, kpad, e->ring_d_partials[r], nullptr, d_out_hits, st,
-                          timed ? e->ring_ev0[r] : nullptr, timed ? e->ring_ev1[r] : nullptr, /*chain=*/true, &e->ring_t0[r], &e->ring_t1[r]);
+                          timed ? e->ring_ev0[r] : nullptr, timed ? e->ring_ev1[r] : nullptr, /*chain=*/chain_scans(e), &e->ring_t0[r], &e->ring_t1[r]);
         if (rc == WAX_HIP_OK && timed) {
             std::unique_lock<std::mutex> sg(e->st_mu);
             e->ring_ev_pending[r] = true;
@@ -2535,6 +2633,7 @@ int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value) {
     else if (k == "time_kernels") e->time_kernels = value;
     else if (k == "force_general") e->force_general = value;
     else if (k == "stream_nt") e->stream_nt = value;
+    else if (k == "fuse_merge") e->fuse_merge = value != 0;
     else if (k == "batch_min") e->batch_min = value;
     else if (k == "batch_mode") e->batch_mode = value;
     else if (k == "batch_rega") e->batch_rega = value;
@@ -2544,7 +2643,8 @@ int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value) {
     else if (k == "batch_survivors") { if (value < 2 || value > 64) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_survivors must be 2..64"); e->batch_survivors = value; }
     else if (k == "batch_dynamic") e->batch_dynamic = value != 0;
     else if (k == "batch_retry") e->batch_retry = value != 0;
-    else if (k == "scan_chain") e->scan_chain = value != 0;
+    else if (k == "batch_multi") e->batch_multi = value != 0;
+    else if (k == "scan_chain") { if (value < -1 || value > 1) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "scan_chain must be -1 (auto), 0 or 1"); e->scan_chain = value; }
     else if (k == "share_timing") e->share_timing = value != 0;   // 0: every chained scan records its own start event (one more packet between scans)
     else if (k == "filter_device_min") { if (value < -1) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "filter_device_min must be >= -1"); e->filter_device_min = value; }
     else if (k == "batch_sample_div") { if (value < 4 || value > 4096) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_sample_div must be 4..4096"); e->batch_sample_div = value; }
@@ -2586,6 +2686,7 @@ int64_t wax_hip_get_tuning(wax_hip_engine* e, const char* key) {
     if (k == "time_kernels") return e->time_kernels.load();
     if (k == "force_general") return e->force_general.load();
     if (k == "stream_nt") return e->stream_nt.load();
+    if (k == "fuse_merge") return e->fuse_merge.load();
     if (k == "batch_min") return e->batch_min.load();
     if (k == "batch_mode") return e->batch_mode.load();
     if (k == "batch_rega") return e->batch_rega.load();
@@ -2604,6 +2705,11 @@ int64_t wax_hip_get_tuning(wax_hip_engine* e, const char* key) {
     if (k == "batch_dynamic") return e->batch_dynamic.load();
     if (k == "batch_retry") return e->batch_retry.load();
     if (k == "batch_retries") return (int64_t)e->st_batch_retries.load();
+    if (k == "batch_multi") return e->batch_multi.load();
+    if (k == "batch_multi_passes") return (int64_t)e->st_multi_passes.load();
+    if (k == "batch_multi_queries") return (int64_t)e->st_multi_queries.load();
+    if (k == "batch_multi_group") return (int64_t)scan_multi_group(e->dims, 10);        // queries per shared exact pass, k <= 60 (64-slot lists)
+    if (k == "batch_multi_group_big") return (int64_t)scan_multi_group(e->dims, 192);   // ... k <= 192 (256-slot lists)
     if (k == "filter_device_min") return e->filter_device_min.load();
     if (k == "filter_device_searches") return (int64_t)e->st_filter_device.load();
     if (k == "batch_queries") return (int64_t)e->st_batch_queries.load();

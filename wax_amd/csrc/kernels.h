@@ -33,7 +33,15 @@ struct ScanArgs {
     uint32_t dims;
     int32_t k;               // min(clamp(topK), n_rows)
     float q_norm;            // ||query||_2 (f64-accumulated on the host, rounded to f32)
+    // Fused final merge (small grids: the merge launch costs more than the scan): non-null = the LAST workgroup to arrive
+    // (device-scope ticket on *arrive, which it resets to 0) reduces all per-workgroup lists and writes the kpad hits
+    // itself — one launch per query instead of two. launch_scan decides (SCAN_FUSE_MERGE_GRID) and reports it.
+    wax_hip_hit* merge_out;
+    const uint64_t* ids;     // frame ids by local row (merge_out only; may be null)
+    uint32_t* arrive;
+    int32_t kpad;
 };
+constexpr int SCAN_FUSE_MERGE_GRID = 160;   // largest grid whose last-arriving workgroup does the final merge
 
 struct ScanVariantInfo {
     int unroll;          // row groups in flight per wave iteration
@@ -50,9 +58,30 @@ bool scan_variant_info(uint32_t dims, int variant, ScanVariantInfo* out);
 // Launch the fused scan+select (write_dist=false: per-workgroup top-k keys into
 // args.partials, *out_grid workgroups) or the distance-only scan (write_dist=true).
 // cap: 128 (k <= 64) or 256 (k <= 192). grid_cap: max workgroups (0 = default).
+// *out_merged (may be null): true = the kernel wrote args.merge_out itself (args.merge_out / arrive were set and the grid is
+// small enough); false = the caller launches launch_merge_keys on args.partials as usual.
 hipError_t launch_scan(const ScanArgs& args, int metric, int variant, int cap, bool write_dist, int grid_cap,
-                       hipStream_t stream, int* out_grid);
+                       hipStream_t stream, int* out_grid, bool* out_merged = nullptr);
 int scan_grid_for(uint32_t n_rows, uint32_t dims, int variant, int grid_cap);
+
+// ---- multiscan.hip: the exact scan for a GROUP of queries in one pass over the store (fallback of the batched path) ----
+struct ScanMultiArgs {
+    const float* store;       // [n_rows][dims] f32
+    const float* queries;     // query block in HBM, row-major x dims
+    const uint32_t* qlist;    // [nq] rows of `queries` this launch answers
+    const float* q_norm;      // [nq] exact ||q|| of those queries (by slot, not by query number)
+    int64_t* partials;        // [nq][grid][k] per-(query, workgroup) sorted keys
+    uint32_t n_rows, row_base, dims, nq;
+    int32_t k;
+};
+bool scan_multi_dims(uint32_t dims);                    // dims the kernel is specialised for (= launch_scan's table)
+uint32_t scan_multi_group(uint32_t dims, int k);        // queries per launch (0: not served — k > 192 or other dims)
+hipError_t launch_scan_multi(const ScanMultiArgs& a, int metric, int grid_cap, hipStream_t stream, int* out_grid);
+// Per query b < nq: the n_lists lists of k keys at d_in + b * n_lists * k -> the k smallest as hits (frame ids attached) in
+// row (d_qlist ? d_qlist[b] : b) of d_out_base, rows out_stride hits wide and padded to it.
+hipError_t launch_merge_keys_multi(const int64_t* d_in, uint32_t n_lists, int k, const uint64_t* d_ids, uint32_t row_base,
+                                   uint32_t n_rows, wax_hip_hit* d_out_base, uint32_t out_stride, const uint32_t* d_qlist,
+                                   uint32_t nq, hipStream_t stream);
 
 // n_in sorted-or-not keys -> the k smallest, ascending, as hits (frame id looked up in d_ids
 // by local row = key_row - row_base; d_ids may be null => frame_id = global row). kpad >= k
@@ -61,9 +90,10 @@ hipError_t launch_merge_keys(const int64_t* d_in, uint32_t n_in, int k, int kpad
                              uint32_t row_base, uint32_t n_rows, wax_hip_hit* d_out, int cap, hipStream_t stream);
 // gathered shard hits (n <= 16384) -> k smallest ascending (k <= 192)
 hipError_t launch_merge_hits(const wax_hip_hit* d_in, uint32_t n, int k, wax_hip_hit* d_out, hipStream_t stream);
-// Batched form: d_in = [n_shards][nq][kin] hits (an all-gather of per-shard batch results), d_out = [nq][k].
+// Batched form: d_in = [n_shards][nq][kin] hits (an all-gather of per-shard batch results), d_out = [nq][out_stride]
+// (k merged hits per row, the rest padded; out_stride = 0 means k).
 hipError_t launch_merge_batch_hits(const wax_hip_hit* d_in, uint32_t n_shards, uint32_t nq, uint32_t kin, int k,
-                                   wax_hip_hit* d_out, hipStream_t stream);
+                                   wax_hip_hit* d_out, hipStream_t stream, uint32_t out_stride = 0);
 
 // General (any k <= 10000) selection over a distance buffer: exact k-th key by 8-pass radix
 // select on the 64-bit key, compaction, rank sort, id lookup. Work buffers are caller-owned.

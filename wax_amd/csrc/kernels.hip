@@ -71,6 +71,61 @@ __device__ inline void accumulate(const f32x4& q, const f32x4& v, f32x4& acc, f3
 
 __device__ inline float hsum(const f32x4& a) { return (a.x + a.y) + (a.z + a.w); }
 
+// Tail of the fused scan kernels: the workgroup's k best keys are in `fin` (LDS, ascending, KEY_PAD padded).
+// Ordinary launch: store them as this workgroup's partial list. Fused-merge launch (a.merge_out != nullptr): publish the
+// list write-through (8-byte agent-scope stores = `sc1`: in L2 / HBM once the wave's vmcnt drains — no release fence),
+// take a ticket; the last arriver re-reads every list with agent-scope loads (served by L2, never a stale L1 line), selects
+// the global k with the same wave lists + rank merge, attaches frame ids and writes the kpad hits
+// (cdna_hip_programming.md §6 Guideline 16, counter form; *arrive is re-armed by the last arriver).
+template <int CAP>
+__device__ inline void scan_epilogue(const ScanArgs& a, int64_t* lds, int* counts, int64_t* fin) {
+    const int k = a.k;
+    int64_t* mine = a.partials + (size_t)blockIdx.x * k;
+    if (a.merge_out == nullptr) {
+        for (int t = (int)threadIdx.x; t < k; t += SCAN_THREADS) mine[t] = fin[t];
+        return;
+    }
+    for (int t = (int)threadIdx.x; t < k; t += SCAN_THREADS)
+        __hip_atomic_store(mine + t, fin[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains before the ticket
+    __syncthreads();
+    if (threadIdx.x == 0) counts[0] = (int)__hip_atomic_fetch_add(a.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if ((unsigned)counts[0] != gridDim.x - 1u) return;
+    __syncthreads();                                     // everyone has read the ticket before counts[] is reused
+    const int lane = lane_id();
+    const int wave = (int)(threadIdx.x >> 6);
+    WaveTopK<CAP> tk;
+    tk.init(lds + wave * CAP, k);
+    const uint32_t total = gridDim.x * (uint32_t)k;
+    for (uint32_t base = 0; base < total; base += SCAN_THREADS * 4) {
+        int64_t keys[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t i = base + r * SCAN_THREADS + threadIdx.x;
+            keys[r] = (i < total) ? __hip_atomic_load(a.partials + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : KEY_PAD;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tk.push_wide(keys[r], keys[r] != KEY_PAD);
+    }
+    tk.finalize();
+    if (lane == 0) counts[wave] = tk.cnt;
+    __syncthreads();
+    block_rank_merge<SCAN_WAVES>(lds, CAP, counts, k, fin);
+    __syncthreads();
+    for (int t = (int)threadIdx.x; t < a.kpad; t += SCAN_THREADS) {
+        wax_hip_hit h;
+        h.key = (t < k) ? fin[t] : KEY_PAD;
+        h.frame_id = ID_PAD;
+        if (h.key != KEY_PAD) {
+            const uint32_t local = key_row(h.key) - a.row_base;
+            h.frame_id = (a.ids != nullptr && local < a.n_rows) ? a.ids[local] : (uint64_t)key_row(h.key);
+        }
+        a.merge_out[t] = h;
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(a.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---------------------------------------------------------------------------
 // Fused scan + select, compile-time dims.
 template <int D4, int GROUP, int METRIC, int UNROLL, bool NT, int CAP, bool WRITE_DIST>
@@ -80,7 +135,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a) {
     constexpr int RPC = RPW * UNROLL;       // rows per wave per iteration
     static_assert(D4 % GROUP == 0, "GROUP must divide D4");
 
-    __shared__ int64_t lds[WRITE_DIST ? 1 : SCAN_WAVES * CAP + SCAN_WAVES];
+    __shared__ int64_t lds[WRITE_DIST ? 1 : SCAN_WAVES * CAP + SCAN_WAVES + FUSED_MAX_K];
 
     const int lane = lane_id();
     const int wave = (int)(threadIdx.x >> 6);
@@ -136,10 +191,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a) {
 
     if (!WRITE_DIST) {
         int* counts = reinterpret_cast<int*>(lds + SCAN_WAVES * CAP);
+        int64_t* fin = lds + SCAN_WAVES * CAP + SCAN_WAVES;
         tk.finalize();
         if (lane == 0) counts[wave] = tk.cnt;
         __syncthreads();
-        block_rank_merge<SCAN_WAVES>(lds, CAP, counts, a.k, a.partials + (size_t)blockIdx.x * a.k);
+        block_rank_merge<SCAN_WAVES>(lds, CAP, counts, a.k, fin);
+        __syncthreads();
+        scan_epilogue<CAP>(a, lds, counts, fin);
     }
 }
 
@@ -149,7 +207,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a) {
 // the row; float4 loads when D % 4 == 0, scalar otherwise. Query read through L1/L2.
 template <int METRIC, int CAP, bool WRITE_DIST>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_generic_kernel(ScanArgs a) {
-    __shared__ int64_t lds[WRITE_DIST ? 1 : SCAN_WAVES * CAP + SCAN_WAVES];
+    __shared__ int64_t lds[WRITE_DIST ? 1 : SCAN_WAVES * CAP + SCAN_WAVES + FUSED_MAX_K];
     const int lane = lane_id();
     const int wave = (int)(threadIdx.x >> 6);
     const uint32_t n = a.n_rows, D = a.dims;
@@ -189,10 +247,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_generic_kernel(ScanArgs a) 
     }
     if (!WRITE_DIST) {
         int* counts = reinterpret_cast<int*>(lds + SCAN_WAVES * CAP);
+        int64_t* fin = lds + SCAN_WAVES * CAP + SCAN_WAVES;
         tk.finalize();
         if (lane == 0) counts[wave] = tk.cnt;
         __syncthreads();
-        block_rank_merge<SCAN_WAVES>(lds, CAP, counts, a.k, a.partials + (size_t)blockIdx.x * a.k);
+        block_rank_merge<SCAN_WAVES>(lds, CAP, counts, a.k, fin);
+        __syncthreads();
+        scan_epilogue<CAP>(a, lds, counts, fin);
     }
 }
 
@@ -258,7 +319,12 @@ int scan_grid_for(uint32_t n_rows, uint32_t dims, int variant, int grid_cap) {
     const uint64_t nchunks = ((uint64_t)n_rows + info.rows_per_chunk - 1) / info.rows_per_chunk;
     const uint64_t max_waves = (uint64_t)grid_cap * SCAN_WAVES;
     uint64_t waves = nchunks;
-    if (nchunks > max_waves) {
+    if (nchunks <= max_waves && nchunks >= 64) {
+        // Small stores (<= 16 K rows at 8 rows per chunk): two chunks per wave. The scan is a couple of HBM round trips
+        // either way, but half the workgroups means half the partial lists — few enough (<= SCAN_FUSE_MERGE_GRID) for the
+        // last-arriving workgroup to do the final merge itself instead of a second launch.
+        waves = (nchunks + 1) / 2;
+    } else if (nchunks > max_waves) {
         // Balance the grid-stride loop: every wave runs the same number of iterations (+-1 chunk
         // in total) instead of leaving a mostly idle last iteration (26 % idle at 1M x 384).
         const uint64_t iters = (nchunks + max_waves - 1) / max_waves;
@@ -311,13 +377,17 @@ static hipError_t launch_generic_metric(const ScanArgs& a, int cap, bool write_d
     return hipGetLastError();
 }
 
-hipError_t launch_scan(const ScanArgs& a, int metric, int variant, int cap, bool write_dist, int grid_cap,
-                       hipStream_t st, int* out_grid) {
-    if (variant < 0 || variant >= scan_variant_count(a.dims)) variant = 0;
+hipError_t launch_scan(const ScanArgs& args, int metric, int variant, int cap, bool write_dist, int grid_cap,
+                       hipStream_t st, int* out_grid, bool* out_merged) {
+    if (variant < 0 || variant >= scan_variant_count(args.dims)) variant = 0;
     const bool sweepable = (metric == M_COS && cap <= 128 && !write_dist);
     if (!sweepable) variant = 0;
-    const int grid = scan_grid_for(a.n_rows, a.dims, variant, grid_cap);
+    const int grid = scan_grid_for(args.n_rows, args.dims, variant, grid_cap);
     if (out_grid) *out_grid = grid;
+    ScanArgs a = args;
+    const bool fuse = !write_dist && a.merge_out != nullptr && a.arrive != nullptr && grid <= SCAN_FUSE_MERGE_GRID && a.kpad >= a.k;
+    if (!fuse) { a.merge_out = nullptr; a.arrive = nullptr; }
+    if (out_merged) *out_merged = fuse;
     switch (a.dims) {
         case 64: return launch_full<16, 16, 4, true>(a, metric, cap, write_dist, grid, st);
         case 128: return launch_full<32, 32, 4, true>(a, metric, cap, write_dist, grid, st);
@@ -365,8 +435,12 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_keys_kernel(const int64_t
                                                                    int k, int kpad,
                                                                    const uint64_t* __restrict__ ids,
                                                                    uint32_t row_base, uint32_t n_rows,
-                                                                   wax_hip_hit* __restrict__ out) {
+                                                                   wax_hip_hit* __restrict__ out,
+                                                                   const uint32_t* __restrict__ qlist, uint32_t out_stride) {
     __shared__ int64_t lds[MERGE_WAVES * CAP + MERGE_WAVES + 2 * FUSED_MAX_K + 1];
+    // one workgroup per query (launch_merge_keys_multi); the single-query launch has one workgroup and out_stride = 0
+    in += (size_t)blockIdx.x * n_lists * (uint32_t)k;
+    out += (size_t)(qlist ? qlist[blockIdx.x] : blockIdx.x) * out_stride;
     int* counts = reinterpret_cast<int*>(lds + MERGE_WAVES * CAP);
     int64_t* fin = lds + MERGE_WAVES * CAP + MERGE_WAVES;
     int* sel = reinterpret_cast<int*>(fin + FUSED_MAX_K);           // FUSED_MAX_K list indices
@@ -447,10 +521,23 @@ hipError_t launch_merge_keys(const int64_t* d_in, uint32_t n_in, int k, int kpad
     const uint32_t n_lists = n_in / (uint32_t)k;
     if (cap <= 128)
         hipLaunchKernelGGL((merge_keys_kernel<128>), dim3(1), dim3(MERGE_THREADS), 0, st, d_in, n_lists, k, kpad, d_ids,
-                           row_base, n_rows, d_out);
+                           row_base, n_rows, d_out, (const uint32_t*)nullptr, 0u);
     else
         hipLaunchKernelGGL((merge_keys_kernel<256>), dim3(1), dim3(MERGE_THREADS), 0, st, d_in, n_lists, k, kpad, d_ids,
-                           row_base, n_rows, d_out);
+                           row_base, n_rows, d_out, (const uint32_t*)nullptr, 0u);
+    return hipGetLastError();
+}
+
+hipError_t launch_merge_keys_multi(const int64_t* d_in, uint32_t n_lists, int k, const uint64_t* d_ids, uint32_t row_base,
+                                   uint32_t n_rows, wax_hip_hit* d_out_base, uint32_t out_stride, const uint32_t* d_qlist,
+                                   uint32_t nq, hipStream_t st) {
+    if (k > FUSED_MAX_K || k < 1 || out_stride < (uint32_t)k || nq == 0 || n_lists == 0) return hipErrorInvalidValue;
+    if (k <= 64)
+        hipLaunchKernelGGL((merge_keys_kernel<128>), dim3(nq), dim3(MERGE_THREADS), 0, st, d_in, n_lists, k, (int)out_stride, d_ids,
+                           row_base, n_rows, d_out_base, d_qlist, out_stride);
+    else
+        hipLaunchKernelGGL((merge_keys_kernel<256>), dim3(nq), dim3(MERGE_THREADS), 0, st, d_in, n_lists, k, (int)out_stride, d_ids,
+                           row_base, n_rows, d_out_base, d_qlist, out_stride);
     return hipGetLastError();
 }
 
@@ -460,7 +547,7 @@ hipError_t launch_merge_keys(const int64_t* d_in, uint32_t n_in, int k, int kpad
 // out[q * k .. + k) receives the merged top-k (nq = 1, kin = n: one flat list, the single-query exchange).
 __global__ __launch_bounds__(MERGE_THREADS) void merge_hits_kernel(const wax_hip_hit* __restrict__ in, uint32_t n_shards,
                                                                    uint32_t nq, uint32_t kin, int k,
-                                                                   wax_hip_hit* __restrict__ out_all) {
+                                                                   wax_hip_hit* __restrict__ out_all, uint32_t out_stride) {
     constexpr int CAP = 256;
     __shared__ int64_t lds[MERGE_WAVES * CAP + MERGE_WAVES + FUSED_MAX_K];
     int* counts = reinterpret_cast<int*>(lds + MERGE_WAVES * CAP);
@@ -469,7 +556,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_hits_kernel(const wax_hip
     const int wave = (int)(threadIdx.x >> 6);
     const uint32_t q = blockIdx.x;
     const uint32_t n = n_shards * kin;
-    wax_hip_hit* __restrict__ out = out_all + (size_t)q * k;
+    wax_hip_hit* __restrict__ out = out_all + (size_t)q * out_stride;   // rows out_stride hits wide, padded past k
     auto src = [&](uint32_t i) -> const wax_hip_hit* {
         const uint32_t s = i / kin, j = i - s * kin;
         return in + ((size_t)s * nq + q) * kin + j;
@@ -487,8 +574,8 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_hits_kernel(const wax_hip
     __syncthreads();
     block_rank_merge<MERGE_WAVES>(lds, CAP, counts, k, fin);
     __syncthreads();
-    for (int t = (int)threadIdx.x; t < k; t += MERGE_THREADS)
-        if (fin[t] == KEY_PAD) out[t] = wax_hip_hit{KEY_PAD, ID_PAD};
+    for (uint32_t t = threadIdx.x; t < out_stride; t += MERGE_THREADS)
+        if (t >= (uint32_t)k || fin[t] == KEY_PAD) out[t] = wax_hip_hit{KEY_PAD, ID_PAD};
     for (uint32_t i = threadIdx.x; i < n; i += MERGE_THREADS) {
         const wax_hip_hit h = *src(i);
         if (h.key == KEY_PAD) continue;
@@ -504,14 +591,16 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_hits_kernel(const wax_hip
 hipError_t launch_merge_hits(const wax_hip_hit* d_in, uint32_t n, int k, wax_hip_hit* d_out, hipStream_t st) {
     if (k > FUSED_MAX_K || k < 1 || n > 16384) return hipErrorInvalidValue;
     if (n == 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(merge_hits_kernel, dim3(1), dim3(MERGE_THREADS), 0, st, d_in, 1u, 1u, n, k, d_out);
+    hipLaunchKernelGGL(merge_hits_kernel, dim3(1), dim3(MERGE_THREADS), 0, st, d_in, 1u, 1u, n, k, d_out, (uint32_t)k);
     return hipGetLastError();
 }
 
 hipError_t launch_merge_batch_hits(const wax_hip_hit* d_in, uint32_t n_shards, uint32_t nq, uint32_t kin, int k,
-                                   wax_hip_hit* d_out, hipStream_t st) {
-    if (k > FUSED_MAX_K || k < 1 || nq == 0 || n_shards == 0 || kin == 0 || (uint64_t)n_shards * kin > 16384) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(merge_hits_kernel, dim3(nq), dim3(MERGE_THREADS), 0, st, d_in, n_shards, nq, kin, k, d_out);
+                                   wax_hip_hit* d_out, hipStream_t st, uint32_t out_stride) {
+    if (out_stride == 0) out_stride = (uint32_t)k;
+    if (k > FUSED_MAX_K || k < 1 || nq == 0 || n_shards == 0 || kin == 0 || (uint64_t)n_shards * kin > 16384 || out_stride < (uint32_t)k)
+        return hipErrorInvalidValue;
+    hipLaunchKernelGGL(merge_hits_kernel, dim3(nq), dim3(MERGE_THREADS), 0, st, d_in, n_shards, nq, kin, k, d_out, out_stride);
     return hipGetLastError();
 }
 

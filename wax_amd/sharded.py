@@ -208,3 +208,69 @@ def sharded_search_batch(engine: HIPVectorEngine, queries, topK: int, world: int
         gathered = torch.stack(parts, dim=0).numpy()
         hits = merge_batch_hits_host(gathered, kpad)
     return decode_hits(engine.metric, hits)
+
+
+class ShardedBatchSearcher:
+    """Pipelined batched search for one rank of a row-sharded corpus (BASELINE config 5's launch shape under torchrun):
+    submit() enqueues the batch on this rank's shard (wax_hip_search_batch_submit_device: returns at once), collect()
+    finishes the oldest batch — the engine's own collect (certificates, exact re-runs), then ONE all-gather of the
+    [nq][kpad] hits per rank over RCCL and a per-query merge by key on the device. With two batches in flight the
+    all-gather and merge of batch i run while the GEMM of batch i + 1 already occupies the GPU. Collectives are issued in
+    submission order on every rank. exchange="host": hits are downloaded, all-gathered through the default (gloo) group and
+    merged on the host (control path; what lets test ranks share one GPU)."""
+
+    def __init__(self, engine: HIPVectorEngine, rank: int, world: int, topK: int, nq: int, depth: int = 2,  # noqa: N803
+                 exchange: str = "rccl"):
+        import torch
+
+        self.engine, self.rank, self.world, self.topK, self.nq = engine, rank, world, topK, int(nq)
+        self.kpad = clampTopK(topK)
+        self.exchange = exchange
+        self.depth = max(1, depth)
+        self.dev = torch.device("cuda", engine.device)
+        shape = (self.nq, self.kpad, 2)
+        self.local = [torch.empty(shape, dtype=torch.int64, device=self.dev) for _ in range(self.depth)]
+        self.gathered = [torch.empty((world,) + shape, dtype=torch.int64, device=self.dev) for _ in range(self.depth)] if world > 1 else None
+        self.merged = [torch.empty(shape, dtype=torch.int64, device=self.dev) for _ in range(self.depth)]
+        self.comm_stream = torch.cuda.Stream(device=self.dev)
+        self.tickets: Deque[Tuple[int, int]] = deque()
+        self.seq = 0
+
+    def pending(self) -> int:
+        return len(self.tickets)
+
+    def submit(self, d_queries) -> None:
+        """d_queries: CUDA f32 tensor [nq, dims] on this rank's GPU; must stay untouched until the matching collect()."""
+        import torch
+
+        if len(self.tickets) >= self.depth:
+            raise RuntimeError("pipeline full: collect() first")
+        assert d_queries.is_cuda and int(d_queries.shape[0]) == self.nq
+        b = self.seq % self.depth
+        self.seq += 1
+        st = torch.cuda.current_stream(self.dev)
+        t = self.engine.searchBatchSubmitDevice(d_queries.data_ptr(), self.nq, self.topK, self.local[b].data_ptr(), self.kpad,
+                                                st.cuda_stream)
+        self.tickets.append((t, b))
+
+    def collect(self):
+        """Merged hits of the oldest batch: an int64 CUDA tensor [nq, kpad, 2] (key, frame id), complete on return
+        (exchange="host": a numpy array)."""
+        import torch
+        import torch.distributed as dist
+
+        t, b = self.tickets.popleft()
+        self.engine.searchBatchCollectDevice(t)          # this rank's hits are complete in self.local[b]
+        if self.world == 1:
+            return self.local[b]
+        if self.exchange == "rccl":
+            with torch.cuda.stream(self.comm_stream):
+                dist.all_gather_into_tensor(self.gathered[b].view(-1), self.local[b].view(-1))   # RCCL over xGMI
+                HIPVectorEngine.mergeBatchHitsDevice(self.gathered[b].data_ptr(), self.world, self.nq, self.kpad, self.kpad,
+                                                     self.merged[b].data_ptr(), self.comm_stream.cuda_stream)
+            self.comm_stream.synchronize()
+            return self.merged[b]
+        local = self.local[b].cpu()
+        parts = [torch.empty_like(local) for _ in range(self.world)]
+        dist.all_gather(parts, local)
+        return merge_batch_hits_host(torch.stack(parts, dim=0).numpy(), self.kpad)
