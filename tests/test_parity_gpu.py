@@ -1643,13 +1643,15 @@ def test_shard_scratch_ring_is_safe_beyond_its_depth(wax):
 # ---------------------------------------------------------------------------
 # one-pass batched pipeline (sampled thresholds -> one filtering GEMM -> fused finish) and the device-resident entry point
 
-@pytest.mark.parametrize("metric,dims", [(0, 384), (1, 384), (0, 128), (0, 768), (1, 768), (0, 256), (0, 512)])
+@pytest.mark.parametrize("metric,dims", [(0, 384), (1, 384), (0, 128), (0, 768), (1, 768), (0, 256), (0, 512),
+                                         (2, 384), (2, 768), (0, 1024), (1, 1536), (2, 1024), (0, 192), (2, 64)])
 def test_batch_onepass_pipeline_is_exact(wax, metric, dims):
     """Stores of >= 1024 GEMM tiles take the one-pass pipeline: every answer equals the single-query path bit for bit
     (ids, scores, counts), for k from 1 to 300 (k' = 2k + 32 up to 632: the real caller's candidateLimit range,
     UnifiedSearch.swift:1195-1200), with a row_base, with a query count that is not a multiple of 256; spot-checked
-    against the f64 oracle."""
-    n = 90_000 if dims != 768 else 50_000
+    against the f64 oracle. Round 3: L2 at every dimension and cosine / dot at the other multiples of 64 (1024, 1536, 192)
+    take the same pipeline on the LDS-tiled GEMM (sampling variant + one counted survivor list per query)."""
+    n = 90_000 if dims < 768 else (50_000 if dims == 768 else 70_000)
     corpus = oracle.gaussian_unit_rows(3, n, dims)
     if metric != 0:
         corpus = corpus * np.linspace(0.6, 1.8, n, dtype=np.float32)[:, None]
@@ -1671,7 +1673,7 @@ def test_batch_onepass_pipeline_is_exact(wax, metric, dims):
             e_ids, e_scores, _, _ = oracle.search(metric, corpus, ids, queries[i], k)
             x = oracle.search(metric, corpus, ids, queries[i], k + MARGIN)[1]
             assert_parity(b_ids[i, :k], b_scores[i, :k], e_ids, e_scores, x, f"onepass m{metric} d{dims} k{k} q{i}")
-    # the one-wave-per-SIMD GEMM (batch_rega 3; D <= 512) gives the same answers
+    # the one-wave-per-SIMD GEMM (batch_rega 3; D <= 512, cosine / dot) gives the same answers
     ref_ids, ref_scores, _ = eng.searchBatch(queries, 30)
     eng.setTuning("batch_rega", 3)
     w_ids, w_scores, _ = eng.searchBatch(queries, 30)

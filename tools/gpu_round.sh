@@ -27,6 +27,9 @@ for s in $STAGES; do
     newtests)
       timeout 900 python -m pytest tests -m gpu -q -x -rf --durations=10 -p no:cacheprovider --timeout 400 \
           -k "multi_query_exact or fused_final_merge or sharded_batched_device or beyond_the_slot_pool or falls_back_on_ties or adversarial" > "$OUT/pytest_new.log" 2>&1; rc=$? ;;
+    onepasstests)
+      timeout 900 python -m pytest tests -m gpu -q -x -rf --durations=10 -p no:cacheprovider --timeout 400 \
+          -k "onepass or batch_mfma or randomised_soak or variants_agree or edge_shapes or special_values or dot_and_l2" > "$OUT/pytest_onepass.log" 2>&1; rc=$? ;;
     shardbench)
       timeout 900 python tools/sharded_handle_bench.py --parts ${WAX_PARTS:-A,B,C} > "$OUT/sharded_handle_bench.jsonl" 2> "$OUT/sharded_handle_bench.err"; rc=$? ;;
     fuzz)

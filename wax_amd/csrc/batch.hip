@@ -156,7 +156,11 @@ __device__ inline float group_max32(float v) {
 constexpr int GM = 128, GN = 128, GK = 64;
 constexpr int LDS_STRIDE = GK + 8;  // bf16 elements per LDS row (144 bytes)
 
-template <int METRIC>
+// SAMPLE = true (one-pass pipeline on this kernel: L2, and cosine / dot at the dimensions the register-resident kernels do
+// not serve): corpus tile index i of the launch is the i-th of a.sample_tiles tiles spread evenly over the slab, and instead
+// of filtering the workgroup records, per query, the best "similarity" of the tile in a.tile_max[i][query] — the dot
+// product for cosine / dot, MINUS the distance for L2 (pick_tau_kernel turns the j-th best into the admission threshold).
+template <int METRIC, bool SAMPLE = false>
 __global__ __launch_bounds__(256) void batch_gemm_kernel(GemmArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned short As[GM * LDS_STRIDE];
     __shared__ __attribute__((aligned(16))) unsigned short Bs[GN * LDS_STRIDE];
@@ -168,7 +172,9 @@ __global__ __launch_bounds__(256) void batch_gemm_kernel(GemmArgs a) {
     const uint32_t qt = blockIdx.x % a.nqt;          // query tiles of one corpus tile are adjacent in launch order
     const uint32_t ct = blockIdx.x / a.nqt;
     const uint32_t m0 = qt * GM;
-    const uint32_t n0 = a.slab0 + ct * GN;
+    const uint32_t ntiles_all = (a.slab_rows + GN - 1) / GN;
+    const uint32_t ptile = SAMPLE ? (uint32_t)(((unsigned long long)ct * ntiles_all) / a.sample_tiles) : ct;
+    const uint32_t n0 = a.slab0 + ptile * GN;
     const uint32_t D = a.dims;
 
     // staging map: 1024 16-byte segments per operand tile, 4 per thread; 8 consecutive threads
@@ -258,6 +264,33 @@ __global__ __launch_bounds__(256) void batch_gemm_kernel(GemmArgs a) {
     const uint32_t slab_end = a.slab0 + a.slab_rows;
     uint32_t rowj[2];
     float vn2j[2];
+    if (SAMPLE) {
+        // per query: the best similarity over this workgroup's 128 rows — over j and the 32 lanes of a half-wave (DPP),
+        // then over the two wave columns through LDS
+        float* smax = reinterpret_cast<float*>(Bs);       // [2 wave columns][GM]; Bs is free after the K loop
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            rowj[j] = n0 + wn * 64 + j * 32 + (lane & 31);
+            vn2j[j] = (METRIC == BM_L2 && rowj[j] < slab_end) ? a.v_n2[rowj[j]] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float best = -__builtin_inff();
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float dot = acc[i][j][r];
+                    const float sim = (METRIC == BM_L2) ? -((qq[i][r] + vn2j[j] - 2.0f * dot) + 0.0f) : dot;
+                    best = __builtin_fmaxf(best, rowj[j] < slab_end ? sim : -__builtin_inff());   // NaN never wins (maxNum)
+                }
+                best = group_max32(best);
+                if ((lane & 31) == 31) smax[wn * GM + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)] = best;
+            }
+        __syncthreads();
+        if (tid < GM) a.tile_max[(size_t)ct * (a.nqt * 128u) + m0 + (uint32_t)tid] = __builtin_fmaxf(smax[tid], smax[GM + tid]);
+        return;
+    }
     unsigned long long pass = 0ull;  // bit j*32 + i*16 + r
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -1767,10 +1800,19 @@ hipError_t launch_finalize_batch(const int64_t* cand, uint32_t cand_cap, const u
 // row below tau when fewer than k' pass), every non-candidate's approximate distance is >= a_max, and the certificate
 // a_max - eps > exact k-th decides whether the answer is provably exact; anything else is re-run on the exact path.
 
-bool batch_onepass_dims(uint32_t dims, int metric) {
+// The register-resident filtering GEMMs (survivors into per-workgroup segments): cosine / dot at these dimensions.
+bool batch_onepass_fast(uint32_t dims, int metric) {
     return metric != BM_L2 && (dims == 128 || dims == 256 || dims == 384 || dims == 512 || dims == 768);
 }
-uint32_t batch_tile_rows(uint32_t dims) { return dims == 768 ? 32u : 64u; }
+// Everything else the MFMA path serves (L2; any other multiple of 64, e.g. 1024 / 1536) runs the same one-pass pipeline on
+// the LDS-tiled 128 x 128 kernel: survivors are appended to one counted list per query.
+bool batch_onepass_dims(uint32_t dims, int metric) {
+    return (dims % 64u) == 0 && dims >= 64 && metric >= BM_COS && metric <= BM_L2;
+}
+uint32_t batch_tile_rows(uint32_t dims, int metric) {
+    if (!batch_onepass_fast(dims, metric)) return (uint32_t)GN;
+    return dims == 768 ? 32u : 64u;
+}
 
 __global__ __launch_bounds__(256) void batch_prep_kernel(PrepArgs a) {
     constexpr uint32_t CHUNK = 1024;                     // floats staged per wave at a time
@@ -1877,6 +1919,15 @@ static hipError_t launch_rega_sample(const GemmArgs& a, hipStream_t st) {
 
 hipError_t launch_batch_gemm_sample(const GemmArgs& a, int metric, hipStream_t st) {
     if (!batch_onepass_dims(a.dims, metric) || a.tile_max == nullptr || a.sample_tiles == 0) return hipErrorInvalidValue;
+    if (!batch_onepass_fast(a.dims, metric)) {   // LDS-tiled kernel: one workgroup per (sampled tile, 128 queries)
+        const dim3 grid(a.sample_tiles * a.nqt);
+        switch (metric) {
+            case BM_COS: hipLaunchKernelGGL((batch_gemm_kernel<BM_COS, true>), grid, dim3(256), 0, st, a); break;
+            case BM_DOT: hipLaunchKernelGGL((batch_gemm_kernel<BM_DOT, true>), grid, dim3(256), 0, st, a); break;
+            default: hipLaunchKernelGGL((batch_gemm_kernel<BM_L2, true>), grid, dim3(256), 0, st, a); break;
+        }
+        return hipGetLastError();
+    }
     switch (a.dims) {
         case 128: return launch_rega_sample<128>(a, st);
         case 256: return launch_rega_sample<256>(a, st);
@@ -1916,7 +1967,7 @@ hipError_t launch_batch_gemm_sample(const GemmArgs& a, int metric, hipStream_t s
 constexpr int PICK_J = 12;
 __global__ __launch_bounds__(1024) void pick_tau_kernel(const float* __restrict__ tile_max, uint32_t sample_tiles,
                                                         uint32_t nq, uint32_t nq_pad, uint32_t rank,
-                                                        float* __restrict__ tau) {
+                                                        float* __restrict__ tau, int negated) {
     __shared__ float lists[PICK_J][32][33];                   // [position][slice][query]
     const uint32_t qi = threadIdx.x & 31u, slice = threadIdx.x >> 5;
     const uint32_t q = blockIdx.x * 32u + qi;                 // < nq_pad (tile_max rows are nq_pad wide)
@@ -1970,22 +2021,45 @@ __global__ __launch_bounds__(1024) void pick_tau_kernel(const float* __restrict_
     if ((lane & 31u) == 0u && qg < nq) {
         // fewer than `rank` finite tile maxima (NaN query / tiny sample): no threshold => +inf, the GEMM marks the query
         // for the exact path instead of admitting the whole store
-        tau[qg] = (kth > -__builtin_inff()) ? 1.0f - kth : __builtin_inff();
+        // similarities are dot products (cosine / dot: distance = 1 - sim) or, `negated` (L2), minus the distance itself
+        tau[qg] = (kth > -__builtin_inff()) ? (negated ? -kth : 1.0f - kth) : __builtin_inff();
     }
 }
 
 hipError_t launch_pick_tau(const float* tile_max, uint32_t sample_tiles, uint32_t nq, uint32_t nq_pad, uint32_t rank,
-                           float* tau, hipStream_t st) {
+                           float* tau, int metric, hipStream_t st) {
     if (rank < 1 || rank > (uint32_t)PICK_J || sample_tiles == 0 || (nq_pad % 32u) != 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(pick_tau_kernel, dim3((nq + 31) / 32), dim3(1024), 0, st, tile_max, sample_tiles, nq, nq_pad, rank, tau);
+    hipLaunchKernelGGL(pick_tau_kernel, dim3((nq + 31) / 32), dim3(1024), 0, st, tile_max, sample_tiles, nq, nq_pad, rank, tau,
+                       metric == BM_L2 ? 1 : 0);
     return hipGetLastError();
 }
 
 // Gather one query's survivors from the GEMM workgroups' segments into the wave-private lists.
 template <int CAP>
 __device__ inline bool gather_segments(WaveTopK<CAP>& tk, const int64_t* __restrict__ mine, const uint32_t* __restrict__ seg_count,
-                                       uint32_t nseg, uint32_t seg_slots, uint32_t nq_pad, uint32_t q) {
+                                       uint32_t nseg, uint32_t seg_slots, uint32_t nq_pad, uint32_t q, uint32_t count_stride) {
     bool dropped = false;
+    if (count_stride != 0u) {
+        // counted list (LDS-tiled filtering GEMM): ONE list of seg_slots keys per query, its (unclamped) length at
+        // seg_count[q * count_stride]; all threads share it
+        uint32_t c = seg_count[(size_t)q * count_stride];
+        if (c > seg_slots) {
+            dropped = true;
+            c = seg_slots;
+        }
+        constexpr uint32_t LOADS = 4;
+        for (uint32_t base = 0; base < c; base += SCAN_THREADS * LOADS) {
+            int64_t key[LOADS];
+#pragma unroll
+            for (uint32_t u = 0; u < LOADS; ++u) {
+                const uint32_t idx = base + u * SCAN_THREADS + threadIdx.x;
+                key[u] = idx < c ? mine[idx] : KEY_PAD;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < LOADS; ++u) tk.push_wide(key[u], key[u] != KEY_PAD);
+        }
+        return dropped;
+    }
     for (uint32_t sb = 0; sb < nseg; sb += SCAN_THREADS) {
         const uint32_t seg = sb + threadIdx.x;
         uint32_t c = (seg < nseg) ? seg_count[(size_t)seg * nq_pad + q] : 0u;
@@ -2024,7 +2098,7 @@ __global__ __launch_bounds__(SCAN_THREADS) __attribute__((amdgpu_waves_per_eu(8,
     const int kp = a.kp;
     WaveTopK<CAP> tk;
     tk.init(lds + wave * CAP, kp);
-    const bool dropped = gather_segments<CAP>(tk, a.cand + (size_t)q * a.cand_cap, a.seg_count, a.nseg, a.seg_slots, a.nq_pad, q);
+    const bool dropped = gather_segments<CAP>(tk, a.cand + (size_t)q * a.cand_cap, a.seg_count, a.nseg, a.seg_slots, a.nq_pad, q, a.count_stride);
     tk.finalize();
     if (lane == 0) counts[wave] = tk.cnt;
     const int any_dropped = __syncthreads_or(dropped ? 1 : 0);
@@ -2118,7 +2192,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void select_segments_kernel(FinishArg
     const int kp = a.kp;
     WaveTopK<CAP> tk;
     tk.init(lds_dyn + wave * CAP, kp);
-    const bool dropped = gather_segments<CAP>(tk, a.cand + (size_t)q * a.cand_cap, a.seg_count, a.nseg, a.seg_slots, a.nq_pad, q);
+    const bool dropped = gather_segments<CAP>(tk, a.cand + (size_t)q * a.cand_cap, a.seg_count, a.nseg, a.seg_slots, a.nq_pad, q, a.count_stride);
     tk.finalize();
     if (lane == 0) counts[wave] = tk.cnt;
     const int any_dropped = __syncthreads_or(dropped ? 1 : 0);
@@ -2171,20 +2245,30 @@ __global__ __launch_bounds__(1024) void finalize_big_kernel(FinishArgs a) {
 template <int D4, int GROUP>
 static hipError_t launch_finish_t(const FinishArgs& a, int metric, hipStream_t st) {
     if (metric == BM_COS) hipLaunchKernelGGL((batch_finish_kernel<D4, GROUP, BM_COS>), dim3(a.nq), dim3(SCAN_THREADS), 0, st, a);
-    else hipLaunchKernelGGL((batch_finish_kernel<D4, GROUP, BM_DOT>), dim3(a.nq), dim3(SCAN_THREADS), 0, st, a);
+    else if (metric == BM_DOT) hipLaunchKernelGGL((batch_finish_kernel<D4, GROUP, BM_DOT>), dim3(a.nq), dim3(SCAN_THREADS), 0, st, a);
+    else hipLaunchKernelGGL((batch_finish_kernel<D4, GROUP, BM_L2>), dim3(a.nq), dim3(SCAN_THREADS), 0, st, a);
     return hipGetLastError();
+}
+
+// Dimensions with a fused finish kernel (= a specialised scan kernel); any other multiple of 64 takes the three-launch form
+// below, whose re-score has a generic-dims kernel.
+bool batch_finish_fused_dims(uint32_t dims) {
+    return dims == 64 || dims == 128 || dims == 256 || dims == 384 || dims == 512 || dims == 768 || dims == 1024 || dims == 1536;
 }
 
 hipError_t launch_batch_finish(const FinishArgs& a, int metric, hipStream_t st) {
     if (a.nq == 0) return hipSuccess;
     if (!batch_onepass_dims(a.dims, metric) || a.k < 1 || a.k > a.kp) return hipErrorInvalidValue;
-    if (a.kp <= FUSED_MAX_K) {
+    if (a.kp <= FUSED_MAX_K && a.qlist == nullptr && batch_finish_fused_dims(a.dims)) {
         switch (a.dims) {   // (D4, GROUP) must mirror launch_scan's table: distances bit-identical to the single-query path
+            case 64: return launch_finish_t<16, 16>(a, metric, st);
             case 128: return launch_finish_t<32, 32>(a, metric, st);
             case 256: return launch_finish_t<64, 64>(a, metric, st);
             case 384: return launch_finish_t<96, 32>(a, metric, st);
             case 512: return launch_finish_t<128, 64>(a, metric, st);
             case 768: return launch_finish_t<192, 64>(a, metric, st);
+            case 1024: return launch_finish_t<256, 64>(a, metric, st);
+            case 1536: return launch_finish_t<384, 64>(a, metric, st);
             default: return hipErrorInvalidValue;
         }
     }

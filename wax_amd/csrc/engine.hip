@@ -1128,21 +1128,28 @@ double gamma_cdf_below(uint32_t j, double x) {   // P(Gamma(j, 1) < x) = P(Poiss
 }
 bool plan_onepass(wax_hip_engine* e, uint32_t n, int k_eff, uint32_t nq, OnepassPlan* p) {
     if (e->batch_onepass.load() == 0 || !batch_onepass_dims(e->dims, e->metric) || k_eff > kBatchMaxK) return false;
-    p->tile_rows = batch_tile_rows(e->dims);
+    // fast: a register-resident GEMM filters (survivors in per-workgroup segments); otherwise (L2, other multiples of 64)
+    // the LDS-tiled kernel does, appending to ONE counted list per query
+    const bool fast = batch_onepass_fast(e->dims, e->metric);
+    p->tile_rows = batch_tile_rows(e->dims, e->metric);
     p->ntiles = (n + p->tile_rows - 1) / p->tile_rows;
-    if ((int64_t)p->ntiles < e->batch_onepass_tiles.load() || p->ntiles < 1024) return false;
+    if (fast ? ((int64_t)p->ntiles < e->batch_onepass_tiles.load() || p->ntiles < 1024)
+             : ((int64_t)n < e->batch_onepass_tiles.load() * 64 || p->ntiles < 512)) return false;   // too small to sample: slab pipeline
     p->kp = batch_kp(k_eff, 960);
     const uint32_t nq_blk = nq < kBatchMaxQ ? nq : kBatchMaxQ;
     const uint32_t nq_pad = (nq_blk + 255u) & ~255u;
     const uint32_t groups = e->dims == 768 ? nq_pad / 128 : nq_pad / 256;
-    uint32_t nseg = 256 / (groups ? groups : 1);         // workgroups per query group == survivor segments per query
+    uint32_t nseg = fast ? 256 / (groups ? groups : 1) : 1u;   // workgroups per query group == survivor segments per query (1 = counted list)
     if (nseg < 1) nseg = 1;
     if (nseg > p->ntiles) nseg = p->ntiles;
+    // sampled tiles that run at once (one "round" ~ 3 us): the persistent workgroups of a query group, or — LDS-tiled kernel,
+    // one workgroup per (tile, 128 queries), ~3 resident per CU — 768 workgroups over the batch's query tiles
+    const uint32_t samp_par = fast ? nseg : std::max<uint32_t>(1u, 768u / (nq_pad / 128u));
     const double floor_e = (double)e->batch_survivors.load() * (double)p->kp;
     uint64_t s_pref = p->ntiles / (uint64_t)e->batch_sample_div.load();
     if (s_pref < 192) s_pref = 192;
     if (s_pref > 2048) s_pref = 2048;
-    if (s_pref > 8ull * nseg) s_pref = 8ull * nseg > 192 ? 8ull * nseg : 192;   // at most 8 tile rounds
+    if (s_pref > 8ull * samp_par) s_pref = 8ull * samp_par > 192 ? 8ull * samp_par : 192;   // at most 8 tile rounds
     if (s_pref > p->ntiles / 2) s_pref = p->ntiles / 2;
     const double rows = (double)p->tile_rows, nn = (double)n;
     const double need = 2.2 * (double)k_eff;             // rows that must pass: k + those inside the bf16 error band of the k-th
@@ -1167,7 +1174,7 @@ bool plan_onepass(wax_hip_engine* e, uint32_t n, int k_eff, uint32_t nq, Onepass
         if (st < (double)j + 1.0) st = (double)j + 1.0;
         const double expect = nn * (1.0 - std::pow(1.0 - (double)j / st, 1.0 / rows));
         if (expect / nn > 0.25) continue;
-        const double cost = std::ceil(st / (double)nseg) * 3.0 + expect * 0.031 * 256.0 / (double)nseg;
+        const double cost = std::ceil(st / (double)samp_par) * 3.0 + expect * 0.031 * 256.0 / (double)(fast ? nseg : 256u);
         if (p->rank == 0 || cost < best_cost) {
             best_cost = cost;
             p->rank = j;
@@ -1204,7 +1211,8 @@ int batch_enqueue(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32
     PrepArgs pa{};
     pa.queries = d_queries; pa.nq = qn; pa.nq_pad = nq_pad; pa.dims = D; pa.metric = e->metric; pa.max_norm = b.max_norm;
     pa.qb = c->d_qb; pa.q_n2 = c->d_qn2; pa.q_norm = c->d_qnorm; pa.eps = c->d_eps; pa.tau = c->d_tau; pa.overflow = c->d_overflow;
-    pa.cand_count = plan ? nullptr : c->d_cand_count;
+    const bool counted = plan != nullptr && !batch_onepass_fast(D, e->metric);   // one-pass on the LDS-tiled kernel: one counted list per query
+    pa.cand_count = (plan && !counted) ? nullptr : c->d_cand_count;
     pa.q_norm_host = c->h_qnorm + cert_off;
     const bool dynamic_tiles = plan != nullptr && e->batch_dynamic.load() != 0;
     pa.tile_ctr = dynamic_tiles ? c->d_overflow + kBatchMaxQ : nullptr;
@@ -1234,7 +1242,7 @@ int batch_enqueue(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32
             if (e->gemm_chain_ev && e->gemm_chain_ev != c->ev_g1)
                 HIP_TRY(hipStreamWaitEvent(st, e->gemm_chain_ev, 0), WAX_HIP_ERR_INTERNAL, "gemm chain wait");
         }
-        HIP_TRY(launch_pick_tau(c->d_tile_max, plan->sample_tiles, qn, nq_pad, plan->rank, c->d_tau, st), WAX_HIP_ERR_INTERNAL,
+        HIP_TRY(launch_pick_tau(c->d_tile_max, plan->sample_tiles, qn, nq_pad, plan->rank, c->d_tau, e->metric, st), WAX_HIP_ERR_INTERNAL,
                 "threshold kernel launch");
         if (timed) {
             // With several batches in flight (submit / collect) the filtering GEMMs of different workspaces would queue
@@ -1252,7 +1260,11 @@ int batch_enqueue(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32
         }
         FinishArgs f{};
         f.cand = c->d_cand; f.cand_cap = plan->seg_area; f.seg_count = c->d_seg_count; f.nq_pad = nq_pad;
-        if (!batch_gemm_segments(g, e->metric, &f.nseg, &f.seg_slots)) return fail(WAX_HIP_ERR_INTERNAL, "one-pass plan without a segment kernel");
+        if (counted) {
+            f.nseg = 1; f.seg_slots = plan->seg_area; f.seg_count = c->d_cand_count; f.count_stride = CAND_COUNT_STRIDE;
+        } else if (!batch_gemm_segments(g, e->metric, &f.nseg, &f.seg_slots)) {
+            return fail(WAX_HIP_ERR_INTERNAL, "one-pass plan without a segment kernel");
+        }
         f.tau = c->d_tau; f.overflow = c->d_overflow; f.store = e->d_store; f.queries = d_queries; f.q_norm = c->d_qnorm;
         f.eps = c->d_eps; f.ids = e->d_ids; f.n_rows = n; f.row_base = (uint32_t)e->row_base; f.dims = D; f.nq = qn;
         f.kp = plan->kp; f.k = k_eff; f.sel = c->d_sel; f.exact = c->d_exact; f.out = d_out; f.out_stride = out_stride;

@@ -185,8 +185,12 @@ hipError_t launch_batch_gemm(const GemmArgs& a, int metric, hipStream_t stream);
 // ---- one-pass batched pipeline (large stores; cosine / dot at the register-resident GEMM dims) ----
 // prep -> sampling GEMM -> pick_tau -> ONE filtering GEMM over the whole store -> finish. No host round trip, no slabs.
 bool batch_onepass_dims(uint32_t dims, int metric);
-// rows per GEMM tile of the kernel that serves `dims` (64, or 32 for the K-split kernel)
-uint32_t batch_tile_rows(uint32_t dims);
+// true: the register-resident filtering GEMMs serve (dims, metric) — survivors in per-workgroup segments; false: the
+// LDS-tiled kernel does (L2, other multiples of 64) — survivors in one counted list per query
+bool batch_onepass_fast(uint32_t dims, int metric);
+// rows per GEMM tile of the kernel that serves (dims, metric): 64, 32 for the K-split kernel, 128 for the LDS-tiled kernel
+uint32_t batch_tile_rows(uint32_t dims, int metric);
+bool batch_finish_fused_dims(uint32_t dims);
 // Queries f32 [nq][dims] in HBM -> bf16 block (cosine: normalised; rows [nq, nq_pad) zero), exact ||q|| as the
 // single-query path computes it (f64 accumulation, the host's summation order), certificate eps, and the per-batch
 // state (tau = +inf / -inf for padding, overflow = 0).
@@ -202,13 +206,14 @@ hipError_t launch_batch_prep(const PrepArgs& a, hipStream_t stream);
 hipError_t launch_batch_gemm_sample(const GemmArgs& a, int metric, hipStream_t stream);
 // tau[q] = 1 - (the rank-th largest of the sampled tiles' best similarities), rank <= 12; padding queries keep -inf.
 hipError_t launch_pick_tau(const float* tile_max, uint32_t sample_tiles, uint32_t nq, uint32_t nq_pad, uint32_t rank,
-                           float* tau, hipStream_t stream);
+                           float* tau, int metric, hipStream_t stream);
 // Per query: survivors of the filtering GEMM (per-workgroup segments) -> best kp by approximate key -> exact f32
 // re-score with the scan kernel's arithmetic -> top-k hits + exactness certificate. kp <= 192: one fused kernel;
 // larger kp (k up to 464): segment select, re-score and finalize as three launches.
 struct FinishArgs {
     const int64_t* cand; uint32_t cand_cap;              // [nq][cand_cap]: nseg segments of seg_slots keys from slot 0
     const uint32_t* seg_count; uint32_t nseg, seg_slots, nq_pad;
+    uint32_t count_stride;                               // != 0: ONE counted list of seg_slots keys per query, its length at seg_count[q * count_stride]
     const float* tau; const uint32_t* overflow;          // admission threshold the GEMM used; pre-set overflow flags
     const float* store; const float* queries; const float* q_norm; const float* eps;
     const uint64_t* ids; uint32_t n_rows, row_base, dims, nq;
