@@ -46,7 +46,8 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md: ~2.
 CORPUS_SEED = 20260220
 QUERY_SEED = 7
 GRANULE = 65536
-SECONDARY_N1 = ["s10k", "s1m", "b1m_q256", "b1m_q1024", "c5_shard", "c5_full", "clustered_k10", "clustered_k100", "detembed"]
+SECONDARY_N1 = ["s10k", "s1m", "b1m_q256", "b1m_q1024", "c5_shard", "c5_full", "clustered_k10", "clustered_k100", "dups17", "detembed"]
+DUP_ROWS, DUP_AT, DUP_OF, DUP_QUERIES = 2048, 500_000, 7, 44    # the "dups17" corpus: 2048 copies of row 7; 44 of 256 queries (17 %) aim at it
 
 
 def log(*a):
@@ -160,7 +161,22 @@ def deterministic_embedder_rows(torch, lo, hi, dims, dev, prefix="doc-"):
         yield r0, torch.nn.functional.normalize(out, dim=1).contiguous()
 
 
-CORPORA = {"gaussian": device_rows, "clustered": clustered_rows, "detembed": deterministic_embedder_rows}
+def duplicated_rows(torch, lo, hi, dims, dev):
+    """The primary corpus with rows [DUP_AT, DUP_AT + DUP_ROWS) replaced by copies of row DUP_OF: exact ties that NO
+    reduced-precision filter can order (and more of them than the widest re-score holds), so a query that aims at them can
+    only be answered by the exact f32 path — the certificate refuses by construction."""
+    src = None
+    for _, x in device_rows(torch, DUP_OF, DUP_OF + 1, dims, dev):
+        src = x[0].clone()
+    for r0, x in device_rows(torch, lo, hi, dims, dev):
+        a, b = max(r0, DUP_AT), min(r0 + x.shape[0], DUP_AT + DUP_ROWS)
+        if a < b:
+            x = x.clone()
+            x[a - r0:b - r0] = src
+        yield r0, x
+
+
+CORPORA = {"gaussian": device_rows, "clustered": clustered_rows, "detembed": deterministic_embedder_rows, "dups": duplicated_rows}
 
 
 def _human_rows(n):
@@ -403,6 +419,12 @@ def batch_queries(torch, dev, nq, dims, corpus, eng_rows=None):
         x0 = torch.cat(rows)[: nq // 2]
         raw[: nq // 2] = x0 + 0.05 * raw[: nq // 2]
         q = raw.contiguous()
+    if corpus == "dups":
+        g = torch.Generator(device=dev)
+        g.manual_seed(QUERY_SEED + 9)
+        for _, x in device_rows(torch, DUP_OF, DUP_OF + 1, dims, dev):
+            m = min(DUP_QUERIES, nq)
+            q[:m] = torch.nn.functional.normalize(x[0][None, :] + 0.02 * torch.randn((m, dims), generator=g, device=dev), dim=1)
     return q
 
 
@@ -815,6 +837,11 @@ def main():
                                                             "the same clustered corpus and queries at top-100 (the dense-neighbourhood regime of "
                                                             "tools/fuzz_batch.py: the k-th neighbour has hundreds of rows inside its bf16 error band)",
                                                             corpus="clustered"),
+                "dups17": lambda: secondary_batched(torch, dev, 1_000_000, 384, 256, 10, max(s // 2, 100), max(w, 10),
+                                                    f"1000000 x 384 with {DUP_ROWS} exact duplicates of one row, {DUP_QUERIES} of the 256 queries per step "
+                                                    "(17 %) aimed at them: ties no bf16 filter can order — those queries take the exact path, "
+                                                    "sharing passes over the f32 store (16 per pass, bit-identical to the single-query kernel); "
+                                                    "cosine top-10", corpus="dups"),
                 "detembed": lambda: secondary_batched(torch, dev, 1_000_000, 384, 256, 10, max(s // 2, 100), max(w, 10),
                                                       "1000000 x 384 rows of the reference's DeterministicEmbedder (FNV-1a / LCG on \"doc-<i>\", "
                                                       "RAGBenchmarkSupport.swift:114-157), 256 queries per step, cosine top-10", corpus="detembed"),
@@ -830,7 +857,7 @@ def main():
                     sec.append({"name": name, "error": f"{type(ex).__name__}: {ex}"})
             iid = next((x for x in sec if x.get("name") == "b1m_q256" and "error" not in x), None)
             for x in sec:
-                if iid and x.get("corpus") in ("clustered", "detembed") and "error" not in x and x.get("queries_per_step") == 256:
+                if iid and x.get("corpus") in ("clustered", "detembed", "dups") and "error" not in x and x.get("queries_per_step") == 256:
                     x["ms_per_step_vs_iid_config3"] = x["ms_per_step"] / iid["ms_per_step"]
         elif args.secondary == "all" or "c5" in want:
             try:

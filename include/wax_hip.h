@@ -123,10 +123,13 @@ int wax_hip_engine_create(uint8_t metric, uint32_t dims, int device_id, wax_hip_
  * rows after wax_hip_reserve(N) (or the first batch); when every shard is full the block size doubles (peer-copy rebalance).
  * search: per shard on its own stream, query upload + fused scan + per-shard top-k, then the k hits (16 k bytes per shard)
  * are peer-copied to the first device and merged there by key (tuning "exchange" = 1: one ncclAllGather per query on a
- * single-process RCCL communicator instead). Batched search: every shard answers the batch on its rows from its own host
- * thread, the first device merges per query. An unavailable ordinal fails with WAX_HIP_ERR_NO_DEVICE.
- * Single-device-only entry points (wax_hip_set_row_base, wax_hip_search_shard_device, wax_hip_search_batch_hits_device, the
- * two wax_hip_time_* probes) return WAX_HIP_ERR_INVALID_ARGUMENT on such a handle. */
+ * single-process RCCL communicator instead). Batched search: every shard answers the batch on its rows through the
+ * single-device submit / collect pair (one host thread drives all shards: nothing blocks between them, no thread and no
+ * allocation per call), the first device merges per query; the device-resident forms (wax_hip_search_batch_hits_device,
+ * _submit_device / _collect_device) work on the handle too — queries and hits then live in the FIRST device's HBM, the query
+ * block is peer-copied to the other shards and only nq x k hits per shard come back. An unavailable ordinal fails with
+ * WAX_HIP_ERR_NO_DEVICE. Single-device-only entry points (wax_hip_set_row_base, wax_hip_search_shard_device, the two
+ * wax_hip_time_* probes) return WAX_HIP_ERR_INVALID_ARGUMENT on such a handle. */
 int wax_hip_engine_create_sharded(uint8_t metric, uint32_t dims, const int* device_ids, int n_devices, wax_hip_engine** out);
 /* 1 for a single-device engine; shard -> (device ordinal, first global row, rows). */
 int wax_hip_shard_count(const wax_hip_engine* e);
@@ -327,15 +330,21 @@ int wax_hip_stats(wax_hip_engine* e, wax_hip_stats_t* out);
  * "batch_sample_div" (one-pass: 1/this of the tiles are sampled for the thresholds, default 32, at most 512 tiles / 8 tile rounds), "batch_workspaces" (concurrent
  * batched searches per engine, default 4), "batch_retry" (one-pass pipeline: 1 = an uncertified query's survivors are re-scored up to 960 deep before the exact path; default 1),
  * "batch_dynamic" (one-pass pipeline: 1 = the filtering GEMM's workgroups claim their tiles from a counter instead of a static
- * stride, so that a workgroup delayed by another batch's kernels does not finish last; measured no faster, default 0), "scan_chain" (1 = pipelined single-query scans are chained through an event so that they never overlap and a per-launch duration is one
- * scan alone — the default, what bench.py's roofline is defined on; 0 = scans of different streams overlap: +3 .. +19 % throughput),
+ * stride, so that a workgroup delayed by another batch's kernels does not finish last; measured no faster, default 0),
+ * "batch_multi" (exact path of a batch: 1 (default) = uncertified queries share passes over the f32 store, up to 16 per pass, with the
+ * single-query kernel's arithmetic — bit-identical results; 0 = one scan per query), "fuse_merge" (1 (default) = on grids of at most 160
+ * workgroups the scan kernel's last-arriving workgroup does the final merge: one launch per query instead of two),
+ * "scan_chain" (pipelined single-query scans of different streams: 1 = chained through an event so that they never overlap and a
+ * per-launch duration is one scan alone; 0 = free to overlap: +3 .. +19 % throughput; -1 (default) = chained exactly while "time_kernels" = 1,
+ * i.e. the product path overlaps and a measurement pass — bench.py's calibration pass — still times one kernel at a time),
  * "share_timing" (1 = a chained scan whose predecessor is still in flight uses that scan's end-of-kernel event as its own start
  * event: one packet less between scans; 0 = every scan records its own start), "filter_device_min" (wax_hip_search_filtered: allow-lists at least this long are resolved by
  * the device-side id -> row table instead of host probes, default 4096; -1 = never),
  * "batch_slab_mb", "batch_growth", "batch_first" (slab schedule of the slab pipeline), "batch_rega" (0 LDS-tiled GEMM
  * only, 1 register-resident GEMM with register staging, 2 with LDS-DMA staging), "batch_debug" (timing experiments:
  * results are NOT valid with bits 1/2/4/8 set). get-only: "variant_count", "scan_grid", "fused_max_k", "batch_queries",
- * "batch_fallbacks", "onepass_queries", "batch_max_k", "batch_retries", "filter_device_searches". Sharded handles: every key above is forwarded to all shards; plus
+ * "batch_fallbacks", "onepass_queries", "batch_max_k", "batch_retries", "batch_multi_passes", "batch_multi_queries", "batch_multi_group" /
+ * "batch_multi_group_big" (queries per shared exact pass for k <= 60 / k <= 192), "filter_device_searches". Sharded handles: every key above is forwarded to all shards; plus
  * "exchange" (0 peer copies + merge on the first device, 1 RCCL all-gather per query) and the get-only "shards", "block_rows",
  * "rebalances", "rccl_collectives". */
 int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value);

@@ -1651,7 +1651,7 @@ def test_batch_onepass_pipeline_is_exact(wax, metric, dims):
     UnifiedSearch.swift:1195-1200), with a row_base, with a query count that is not a multiple of 256; spot-checked
     against the f64 oracle. Round 3: L2 at every dimension and cosine / dot at the other multiples of 64 (1024, 1536, 192)
     take the same pipeline on the LDS-tiled GEMM (sampling variant + one counted survivor list per query)."""
-    n = 90_000 if dims < 768 else (50_000 if dims == 768 else 70_000)
+    n = 90_000 if dims < 768 else (50_000 if (dims == 768 and metric != 2) else 70_000)   # >= 1024 tiles of the serving GEMM kernel
     corpus = oracle.gaussian_unit_rows(3, n, dims)
     if metric != 0:
         corpus = corpus * np.linspace(0.6, 1.8, n, dtype=np.float32)[:, None]
@@ -1821,8 +1821,8 @@ def test_multi_query_exact_scan_is_bit_identical(wax, dims, metric):
     eng.setRowBase(1_000_003)
     eng.setTuning("batch_mode", 0)                            # no MFMA pipeline: the exact path answers the batch
     group, group_big = eng.getTuning("batch_multi_group"), eng.getTuning("batch_multi_group_big")   # queries per pass: k <= 60 / k <= 192
-    assert group >= 2 and group_big >= 1
-    for nq, k in [(group * 2 + 3, 10), (1, 10), (2, 60), (group_big + 1, 100), (5, 192)]:
+    assert group == 16 and group_big in (0, 16)               # 0: the 256-slot lists of 16 queries do not fit beside the query block (dims >= 512)
+    for nq, k in [(group * 2 + 3, 10), (1, 10), (2, 60), (group_big + 1, 100), (5, 192), (17, 30)]:
         queries = oracle.gaussian_unit_queries(nq, dims, seed=dims + nq + k)
         if nq > 2:
             queries[2] = corpus[16]                           # aims at the tie

@@ -30,6 +30,8 @@ for s in $STAGES; do
     onepasstests)
       timeout 900 python -m pytest tests -m gpu -q -x -rf --durations=10 -p no:cacheprovider --timeout 400 \
           -k "onepass or batch_mfma or randomised_soak or variants_agree or edge_shapes or special_values or dot_and_l2" > "$OUT/pytest_onepass.log" 2>&1; rc=$? ;;
+    benchsec)
+      timeout 600 python bench.py --gpus 1 --no-cpu-baseline --steps 60 --warmup 10 --secondary ${WAX_SEC:-b1m_q256,clustered_k100,dups17} > "$OUT/bench_sec.json" 2> "$OUT/bench_sec.err"; rc=$? ;;
     shardbench)
       timeout 900 python tools/sharded_handle_bench.py --parts ${WAX_PARTS:-A,B,C} > "$OUT/sharded_handle_bench.jsonl" 2> "$OUT/sharded_handle_bench.err"; rc=$? ;;
     fuzz)

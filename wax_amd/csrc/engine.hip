@@ -1357,7 +1357,7 @@ int exact_scan_queries(wax_hip_engine* e, BatchCtx* c, const float* d_queries, c
     uint32_t done = 0;
     const uint32_t group = (e->batch_multi.load() != 0 && nf >= 2 && e->force_general.load() == 0) ? scan_multi_group(D, k_eff) : 0u;
     if (group >= 2) {
-        const int grid = scan_grid_for(n, D, 0, (int)e->grid_blocks.load());
+        const int grid = scan_multi_grid(n, D, (int)e->grid_blocks.load());
         rc = grow_dev(&c->d_mpart, &c->mpart_cap, (uint64_t)group * (uint64_t)grid * (uint64_t)k_eff, sizeof(int64_t),
                       "Failed to allocate exact-pass partials");
         if (rc != WAX_HIP_OK) return rc;
@@ -1465,6 +1465,32 @@ int batch_search_device_locked(wax_hip_engine* e, BatchCtx* c, const float* d_qu
     int rc = batch_submit_device_locked(e, c, d_queries, nq, k_eff, plan, d_out, out_stride);
     if (rc != WAX_HIP_OK) return rc;
     return batch_finish_device_locked(e, c, d_queries, nq, k_eff, d_out, out_stride, out_fallbacks);
+}
+
+// "MV2V" encoding-2 segment: header + lengths, in MetalVectorEngine.deserialize's validation order and with its reasons
+// (:716-808). One copy for the single-device engine and the sharded handle.
+int validate_mv2v_segment(uint8_t metric, uint32_t engine_dims, const uint8_t* data, size_t len, uint64_t* out_n, uint64_t* out_vec_len,
+                          uint64_t* out_id_len) {
+    if (len < 36) return fail(WAX_HIP_ERR_BAD_SEGMENT, "Metal segment too small: " + std::to_string(len) + " bytes");
+    const uint8_t magic[4] = {0x4D, 0x56, 0x32, 0x56};
+    if (std::memcmp(data, magic, 4) != 0) return fail(WAX_HIP_ERR_BAD_SEGMENT, "Metal segment magic mismatch");
+    uint16_t ver; std::memcpy(&ver, data + 4, 2);
+    if (ver != 1) return fail(WAX_HIP_ERR_BAD_SEGMENT, "Unsupported Metal segment version " + std::to_string(ver));
+    if (data[6] != 2) return fail(WAX_HIP_ERR_BAD_SEGMENT, "Unsupported Metal segment encoding " + std::to_string((int)data[6]));
+    if (data[7] > 2 || data[7] != metric)
+        return fail(WAX_HIP_ERR_BAD_SEGMENT, "Metric mismatch: expected " + std::to_string((int)metric) + ", got " + std::to_string((int)data[7]));
+    uint32_t dims; std::memcpy(&dims, data + 8, 4);
+    if (dims != engine_dims) return fail(WAX_HIP_ERR_BAD_SEGMENT, "Dimension mismatch: expected " + std::to_string(engine_dims) + ", got " + std::to_string(dims));
+    uint64_t n, vec_len; std::memcpy(&n, data + 12, 8); std::memcpy(&vec_len, data + 20, 8);
+    for (int i = 0; i < 8; ++i)
+        if (data[28 + i] != 0) return fail(WAX_HIP_ERR_BAD_SEGMENT, "Metal segment reserved bytes must be zero");
+    if (n > 0xffffffffull || vec_len != n * (uint64_t)dims * 4ull) return fail(WAX_HIP_ERR_BAD_SEGMENT, "Vector data length mismatch");
+    if ((uint64_t)len < 36 + vec_len + 8) return fail(WAX_HIP_ERR_BAD_SEGMENT, "Metal segment missing frameId length");
+    uint64_t id_len; std::memcpy(&id_len, data + 36 + vec_len, 8);
+    if (id_len != n * 8ull) return fail(WAX_HIP_ERR_BAD_SEGMENT, "FrameId data length mismatch");
+    if ((uint64_t)len < 36 + vec_len + 8 + id_len) return fail(WAX_HIP_ERR_BAD_SEGMENT, "Metal segment truncated frameId data");
+    *out_n = n; *out_vec_len = vec_len; *out_id_len = id_len;
+    return WAX_HIP_OK;
 }
 
 bool device_is_gfx950(int dev) {
@@ -2565,25 +2591,9 @@ int wax_hip_serialize(wax_hip_engine* e, uint8_t** out_bytes, size_t* out_len) {
 int wax_hip_deserialize(wax_hip_engine* e, const uint8_t* data, size_t len) {
     if (!e || (!data && len)) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "null argument");
     if (e->sh) return sh_deserialize(e, data, len);
-    // Validation order and reasons: MetalVectorEngine.deserialize (:716-808)
-    if (len < 36) return fail(WAX_HIP_ERR_BAD_SEGMENT, "Metal segment too small: " + std::to_string(len) + " bytes");
-    const uint8_t magic[4] = {0x4D, 0x56, 0x32, 0x56};
-    if (std::memcmp(data, magic, 4) != 0) return fail(WAX_HIP_ERR_BAD_SEGMENT, "Metal segment magic mismatch");
-    uint16_t ver; std::memcpy(&ver, data + 4, 2);
-    if (ver != 1) return fail(WAX_HIP_ERR_BAD_SEGMENT, "Unsupported Metal segment version " + std::to_string(ver));
-    if (data[6] != 2) return fail(WAX_HIP_ERR_BAD_SEGMENT, "Unsupported Metal segment encoding " + std::to_string((int)data[6]));
-    if (data[7] > 2 || data[7] != e->metric)
-        return fail(WAX_HIP_ERR_BAD_SEGMENT, "Metric mismatch: expected " + std::to_string((int)e->metric) + ", got " + std::to_string((int)data[7]));
-    uint32_t dims; std::memcpy(&dims, data + 8, 4);
-    if (dims != e->dims) return fail(WAX_HIP_ERR_BAD_SEGMENT, "Dimension mismatch: expected " + std::to_string(e->dims) + ", got " + std::to_string(dims));
-    uint64_t n, vec_len; std::memcpy(&n, data + 12, 8); std::memcpy(&vec_len, data + 20, 8);
-    for (int i = 0; i < 8; ++i)
-        if (data[28 + i] != 0) return fail(WAX_HIP_ERR_BAD_SEGMENT, "Metal segment reserved bytes must be zero");
-    if (n > 0xffffffffull || vec_len != n * (uint64_t)dims * 4ull) return fail(WAX_HIP_ERR_BAD_SEGMENT, "Vector data length mismatch");
-    if ((uint64_t)len < 36 + vec_len + 8) return fail(WAX_HIP_ERR_BAD_SEGMENT, "Metal segment missing frameId length");
-    uint64_t id_len; std::memcpy(&id_len, data + 36 + vec_len, 8);
-    if (id_len != n * 8ull) return fail(WAX_HIP_ERR_BAD_SEGMENT, "FrameId data length mismatch");
-    if ((uint64_t)len < 36 + vec_len + 8 + id_len) return fail(WAX_HIP_ERR_BAD_SEGMENT, "Metal segment truncated frameId data");
+    uint64_t n = 0, vec_len = 0, id_len = 0;
+    { const int vrc = validate_mv2v_segment(e->metric, e->dims, data, len, &n, &vec_len, &id_len); if (vrc != WAX_HIP_OK) return vrc; }
+    const uint32_t dims = e->dims;
 
     REFUSE_IF_HOLDING(e);
     DeviceGuard g(e->device);

@@ -75,7 +75,8 @@ struct ScanMultiArgs {
     int32_t k;
 };
 bool scan_multi_dims(uint32_t dims);                    // dims the kernel is specialised for (= launch_scan's table)
-uint32_t scan_multi_group(uint32_t dims, int k);        // queries per launch (0: not served — k > 192 or other dims)
+uint32_t scan_multi_group(uint32_t dims, int k);        // queries per launch (0: not served — k > 192, other dims, lists too large for LDS)
+int scan_multi_grid(uint32_t n_rows, uint32_t dims, int grid_cap);   // workgroups launch_scan_multi will use
 hipError_t launch_scan_multi(const ScanMultiArgs& a, int metric, int grid_cap, hipStream_t stream, int* out_grid);
 // Per query b < nq: the n_lists lists of k keys at d_in + b * n_lists * k -> the k smallest as hits (frame ids attached) in
 // row (d_qlist ? d_qlist[b] : b) of d_out_base, rows out_stride hits wide and padded to it.
