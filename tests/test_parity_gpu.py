@@ -1682,7 +1682,7 @@ def test_batch_onepass_pipeline_is_exact(wax, metric, dims):
     fb = eng.getTuning("batch_fallbacks")
     print(f"\n[onepass m{metric} d{dims}] fallbacks {fb} of {7 * 301}")
     if metric == 0:
-        assert fb <= 30
+        assert fb <= (30 if dims in (128, 256, 384, 512, 768) else 80)   # (the LDS-tiled kernel samples 128-row tiles: coarser thresholds)
     # the slab pipeline gives the same answers where it applies (k <= 80)
     o_ids, o_scores, _ = eng.searchBatch(queries, 10)
     eng.setTuning("batch_onepass", 0)

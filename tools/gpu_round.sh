@@ -32,6 +32,19 @@ for s in $STAGES; do
           -k "onepass or batch_mfma or randomised_soak or variants_agree or edge_shapes or special_values or dot_and_l2" > "$OUT/pytest_onepass.log" 2>&1; rc=$? ;;
     benchsec)
       timeout 600 python bench.py --gpus 1 --no-cpu-baseline --steps 60 --warmup 10 --secondary ${WAX_SEC:-b1m_q256,clustered_k100,dups17} > "$OUT/bench_sec.json" 2> "$OUT/bench_sec.err"; rc=$? ;;
+    multiscan)
+      timeout 600 python tools/multiscan_bench.py --dims ${WAX_DIMS:-384 768} > "$OUT/multiscan_bench.jsonl" 2> "$OUT/multiscan_bench.err"; rc=$?
+      (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_ms" -o ms -- \
+          python "$R/tools/multiscan_bench.py" --dims 384 --nq 16 48 --reps 5 > "$OUT/multiscan_prof.log" 2>&1)
+      find "$OUT/prof_ms" -name "*kernel_stats.csv" -exec cp {} "$OUT/multiscan_kernel_stats.csv" \; 2>/dev/null
+      rm -rf "$OUT/prof_ms" ;;
+    multiscanpmc)
+      timeout 300 python tools/multiscan_bench.py --dims 384 --nq 2 16 --k 1 10 60 --reps 10 > "$OUT/multiscan_k.jsonl" 2> "$OUT/multiscan_k.err"
+      timeout 300 python tools/multiscan_bench.py --dims 384 --rows 4000000 --nq 16 --k 10 --reps 5 >> "$OUT/multiscan_k.jsonl" 2>> "$OUT/multiscan_k.err"
+      (cd /tmp && timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE \
+          --kernel-trace --output-format csv -d "$OUT/prof_mspmc" -o g -- python "$R/tools/multiscan_bench.py" --dims 384 --nq 16 --reps 3 > "$OUT/multiscan_pmc.log" 2>&1); rc=$?
+      python tools/pmc_summary.py "$OUT/prof_mspmc" > "$OUT/multiscan_pmc_summary.json" 2>> "$OUT/multiscan_pmc.log"
+      rm -rf "$OUT/prof_mspmc" ;;
     shardbench)
       timeout 900 python tools/sharded_handle_bench.py --parts ${WAX_PARTS:-A,B,C} > "$OUT/sharded_handle_bench.jsonl" 2> "$OUT/sharded_handle_bench.err"; rc=$? ;;
     fuzz)

@@ -1615,10 +1615,14 @@ __global__ __launch_bounds__(256) void rescore_kernel(RescoreArgs a) {
         lrow = a.rows[p];
         grow = a.row_base + lrow;
     } else {
-        const int64_t ck = a.cand[(size_t)q * a.cand_cap + (p - qslot * (uint32_t)a.kp)];
+        const int64_t ck = a.cand[(size_t)(a.by_slot ? qslot : q) * a.cand_cap + (p - qslot * (uint32_t)a.kp)];
         live = in_range && ck != KEY_PAD;
         grow = key_row(ck);
         lrow = grow - a.row_base;
+    }
+    if (a.by_slot && __ballot(live) == 0ull) {   // padded tails of a retry round's dense lists: nothing to fetch for this wave
+        if (in_range && gl == GROUP - 1) a.exact[(size_t)qslot * (uint32_t)a.kp + (p - qslot * (uint32_t)a.kp)] = KEY_PAD;
+        return;
     }
     lrow = (live && lrow < a.n_rows) ? lrow : 0;
     const f32x4* __restrict__ v4 = reinterpret_cast<const f32x4*>(a.store) + (size_t)lrow * D4 + gl;
@@ -1632,7 +1636,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(RescoreArgs a) {
     const float d = finish_distance_b<METRIC>(s, m, a.q_norm[q]);
     if (in_range && gl == GROUP - 1) {
         if (a.dist_out != nullptr) a.dist_out[p] = d;
-        else a.exact[(size_t)q * (uint32_t)a.kp + (p - qslot * (uint32_t)a.kp)] = live ? make_key(d, grow) : KEY_PAD;
+        else a.exact[(size_t)(a.by_slot ? qslot : q) * (uint32_t)a.kp + (p - qslot * (uint32_t)a.kp)] = live ? make_key(d, grow) : KEY_PAD;
     }
 }
 
@@ -1655,6 +1659,7 @@ __global__ __launch_bounds__(256) void rescore_generic_kernel(RescoreArgs a) {
         grow = key_row(ck);
         lrow = grow - a.row_base;
     }
+    // (survivor-area mode and query lists are served by the specialised kernel only: launch_rescore refuses them here)
     lrow = (live && lrow < a.n_rows) ? lrow : 0;
     const uint32_t D = a.dims;
     const float* row = a.store + (size_t)lrow * D;
@@ -1707,6 +1712,7 @@ hipError_t launch_rescore(const RescoreArgs& a, int metric, hipStream_t st) {
         case 1536: return launch_rescore_t<384, 64>(a, metric, st);
         default: break;
     }
+    if (a.qlist != nullptr || a.by_slot) return hipErrorInvalidValue;   // query lists: specialised dims only
     const uint32_t total = a.nq * (uint32_t)a.kp;
     const dim3 grid((total + 3) / 4);
     switch (metric) {
@@ -2291,5 +2297,124 @@ hipError_t launch_batch_finish(const FinishArgs& a, int metric, hipStream_t st) 
     return hipGetLastError();
 }
 
+
+// ---------------------------------------------------------------------------
+// Full retry, step 1: pack the live survivors of a query (the filled front of each of its segments) into one dense list.
+__global__ __launch_bounds__(256) void compact_survivors_kernel(CompactArgs a) {
+    __shared__ uint32_t wave_tot[4];
+    __shared__ uint32_t run_base;
+    const uint32_t slot = blockIdx.x;
+    const uint32_t q = a.qlist[slot];
+    const int64_t* __restrict__ src = a.cand + (size_t)q * a.cand_cap;
+    int64_t* __restrict__ dst = a.dense + (size_t)slot * a.dense_stride;
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    if (threadIdx.x == 0) run_base = 0u;
+    __syncthreads();
+    uint32_t total = 0;
+    if (a.count_stride != 0u) {   // one counted list: a straight copy
+        uint32_t c = a.seg_count[(size_t)q * a.count_stride];
+        c = c < a.seg_slots ? c : a.seg_slots;
+        for (uint32_t i = threadIdx.x; i < c; i += 256u) dst[i] = src[i];
+        total = c;
+    } else {
+        for (uint32_t s0 = 0; s0 < a.nseg; s0 += 256u) {
+            const uint32_t seg = s0 + threadIdx.x;
+            uint32_t c = seg < a.nseg ? a.seg_count[(size_t)seg * a.nq_pad + q] : 0u;
+            c = c < a.seg_slots ? c : a.seg_slots;
+            uint32_t inc = c;                                  // inclusive scan over the block's 256 segments
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(inc, d, 64);
+                if (lane >= d) inc += o;
+            }
+            if (lane == 63) wave_tot[wave] = inc;
+            __syncthreads();
+            uint32_t off = run_base;
+            for (int w = 0; w < wave; ++w) off += wave_tot[w];
+            off += inc - c;
+            const int64_t* sp = src + (size_t)seg * a.seg_slots;
+            for (uint32_t j = 0; j < c; ++j) dst[off + j] = sp[j];
+            __syncthreads();
+            if (threadIdx.x == 0) run_base += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+            __syncthreads();
+        }
+        total = run_base;
+    }
+    for (uint32_t i = total + threadIdx.x; i < a.dense_stride; i += 256u) dst[i] = KEY_PAD;
+    if (threadIdx.x == 0) a.live_out[slot] = total;
+}
+
+hipError_t launch_compact_survivors(const CompactArgs& a, hipStream_t st) {
+    if (a.n_slots == 0) return hipSuccess;
+    hipLaunchKernelGGL(compact_survivors_kernel, dim3(a.n_slots), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+// Full retry, step 3 (second rung of the exactness ladder): per uncertified query, the exact keys of ALL its survivors -> top-k hits +
+// certificate. One workgroup per query; the survivor area (up to 32 K keys, mostly dead) streams through the wave lists.
+__global__ __launch_bounds__(SCAN_THREADS) void full_retry_select_kernel(FullRetryArgs a) {
+    constexpr int CAP = 1024;
+    extern __shared__ __attribute__((aligned(16))) int64_t lds_dyn[];   // [SCAN_WAVES * CAP + SCAN_WAVES + 512]
+    int* counts = reinterpret_cast<int*>(lds_dyn + SCAN_WAVES * CAP);
+    int64_t* fin = lds_dyn + SCAN_WAVES * CAP + SCAN_WAVES;
+    const int lane = lane_id();
+    const int wave = (int)(threadIdx.x >> 6);
+    const uint32_t slot = blockIdx.x;
+    const uint32_t q = a.qlist[slot];
+    const int k = a.k;
+    // did any segment overflow? (then survivors were dropped and nothing can be certified)
+    bool over = false;
+    if (a.count_stride != 0u) {
+        over = a.seg_count[(size_t)q * a.count_stride] > a.seg_slots;
+    } else {
+        for (uint32_t seg = threadIdx.x; seg < a.nseg; seg += SCAN_THREADS) over |= a.seg_count[(size_t)seg * a.nq_pad + q] > a.seg_slots;
+    }
+    WaveTopK<CAP> tk;
+    tk.init(lds_dyn + wave * CAP, k);
+    const int64_t* __restrict__ mine = a.exact + (size_t)slot * a.area;
+    constexpr uint32_t LOADS = 8;
+    for (uint32_t base = 0; base < a.area; base += SCAN_THREADS * LOADS) {
+        int64_t key[LOADS];
+#pragma unroll
+        for (uint32_t u = 0; u < LOADS; ++u) {
+            const uint32_t i = base + u * SCAN_THREADS + threadIdx.x;
+            key[u] = i < a.area ? mine[i] : KEY_PAD;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < LOADS; ++u) tk.push_wide(key[u], key[u] != KEY_PAD);
+    }
+    tk.finalize();
+    if (lane == 0) counts[wave] = tk.cnt;
+    const int any_over = __syncthreads_or(over ? 1 : 0);
+    block_rank_merge<SCAN_WAVES>(lds_dyn, CAP, counts, k, fin);
+    __syncthreads();
+    int total = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_WAVES; ++w) total += counts[w];
+    for (uint32_t o = threadIdx.x; o < a.out_stride; o += SCAN_THREADS) {
+        wax_hip_hit h;
+        h.key = ((int)o < k) ? fin[o] : KEY_PAD;
+        h.frame_id = ID_PAD;
+        if (h.key != KEY_PAD) {
+            const uint32_t local = key_row(h.key) - a.row_base;
+            h.frame_id = (a.ids != nullptr && local < a.n_rows) ? a.ids[local] : (uint64_t)key_row(h.key);
+        }
+        a.out[(size_t)q * a.out_stride + o] = h;
+    }
+    if (threadIdx.x == 0) {
+        uint32_t ok = 0;
+        if (!any_over && a.overflow[q] == 0u && total >= k && fin[k - 1] != KEY_PAD)
+            ok = (a.tau[q] - a.eps[q] > key_distance(fin[k - 1])) ? 1u : 0u;   // strict: ties with a rejected row stay uncertified
+        a.certified[q] = ok;
+    }
+}
+
+hipError_t launch_full_retry_select(const FullRetryArgs& a, hipStream_t st) {
+    if (a.n_slots == 0) return hipSuccess;
+    if (a.k < 1 || a.k > 960 || a.out_stride < (uint32_t)a.k || a.area == 0) return hipErrorInvalidValue;
+    constexpr size_t smem = (size_t)(SCAN_WAVES * 1024 + SCAN_WAVES + 1024) * sizeof(int64_t);
+    hipLaunchKernelGGL(full_retry_select_kernel, dim3(a.n_slots), dim3(SCAN_THREADS), smem, st, a);
+    return hipGetLastError();
+}
 
 }  // namespace wax

@@ -309,6 +309,11 @@ struct BatchCtx {
     float* d_fnorm = nullptr;            // [kBatchMaxQ]
     int64_t* d_mpart = nullptr;          // [group][grid][k]
     uint64_t mpart_cap = 0;
+    int64_t* d_rescue = nullptr;         // full retry: [queries of a round][survivor area] dense survivor keys
+    uint64_t rescue_cap = 0;
+    int64_t* d_rescue_exact = nullptr;   // full retry: [queries of a round][largest live count] their exact keys
+    uint64_t rescue_exact_cap = 0;
+    uint32_t* h_live = nullptr;          // pinned [kBatchMaxQ]: live survivors per query of a retry round
     uint32_t* h_cert = nullptr;          // pinned [cert_cap]
     float* h_qnorm = nullptr;            // pinned [cert_cap]: exact norms (the exact-path fallback needs them on the host)
 };
@@ -873,7 +878,7 @@ void free_bctx(BatchCtx* c) {
     (void)hipFree(c->d_cand); (void)hipFree(c->d_seg_count); (void)hipFree(c->d_exact); (void)hipFree(c->d_sel);
     (void)hipFree(c->d_tile_max); (void)hipFree(c->d_hits);
     (void)hipHostFree(c->h_hits); (void)hipHostFree(c->h_cert); (void)hipHostFree(c->h_qnorm); (void)hipHostFree(c->h_qlist);
-    (void)hipFree(c->d_qlist); (void)hipHostFree(c->h_fnorm); (void)hipFree(c->d_fnorm); (void)hipFree(c->d_mpart);
+    (void)hipFree(c->d_qlist); (void)hipHostFree(c->h_fnorm); (void)hipFree(c->d_fnorm); (void)hipFree(c->d_mpart); (void)hipFree(c->d_rescue); (void)hipFree(c->d_rescue_exact); (void)hipHostFree(c->h_live);
     if (c->ev_in) (void)hipEventDestroy(c->ev_in);
     if (c->ev_g0) (void)hipEventDestroy(c->ev_g0);
     if (c->ev_g1) (void)hipEventDestroy(c->ev_g1);
@@ -902,6 +907,7 @@ int alloc_bctx(wax_hip_engine* e, BatchCtx** out) {
     A(&c->d_fnorm, (size_t)kBatchMaxQ * sizeof(float));
     if (err == hipSuccess) err = hipHostMalloc(&c->h_qlist, (size_t)kBatchMaxQ * sizeof(uint32_t), hipHostMallocDefault);
     if (err == hipSuccess) err = hipHostMalloc(&c->h_fnorm, (size_t)kBatchMaxQ * sizeof(float), hipHostMallocDefault);
+    if (err == hipSuccess) err = hipHostMalloc(&c->h_live, (size_t)kBatchMaxQ * sizeof(uint32_t), hipHostMallocDefault);
     if (err != hipSuccess) {
         free_bctx(c);
         return fail(WAX_HIP_ERR_ALLOC, std::string("Failed to allocate batch workspace: ") + hipGetErrorString(err));
@@ -1189,8 +1195,12 @@ bool plan_onepass(wax_hip_engine* e, uint32_t n, int k_eff, uint32_t nq, Onepass
     // ITS fill does: size every segment for 4 x expect spread over the group's workgroups, + 6 sigma of a Poisson fill
     // (an overflow only costs that query the exact path, but at 0.25 ms each two of them per batch doubled the batch
     // time: profiles/r02/c_onepass_diag.txt).
+    // ... and at least 128 slots per segment (8 192 for the one counted list): memory is not the constraint (32 K keys per
+    // query = 64 MB for a 256-query block), and a run of near-duplicate rows — consecutive chunks of one document — lands in
+    // the few segments whose workgroups own those tiles: 64 survivors from one 64-row tile, not the ~1 of well-mixed rows.
+    // Roomy segments are what lets the full retry (re-score every survivor) answer such queries without a pass over the store.
     const double fill = 4.0 * p->expect / (double)nseg;
-    uint64_t slots = 16;
+    uint64_t slots = fast ? 128 : 8192;
     while ((double)slots < fill + 6.0 * std::sqrt(fill) + 4.0) slots *= 2;
     const uint64_t area = slots * nseg;
     if (area > 262144) return false;
@@ -1423,28 +1433,54 @@ int batch_finish_device_locked(wax_hip_engine* e, BatchCtx* c, const float* d_qu
         }
     }
     int rc = WAX_HIP_OK;
-    // Second chance for uncertified queries without another pass over the store: their survivors (every row the GEMM
-    // admitted: approx distance <= tau) are still in the segments, so re-score up to 960 of them instead of k' = 2k + 32.
-    // With all survivors re-scored the certificate only needs tau - eps > the exact k-th — which is what dense
-    // neighbourhoods (clustered stores: more than k' rows inside the bf16 error band of the k-th) fail at k'. A query that
-    // fails again (segment overflow, a band wider than the threshold's margin, exact ties) goes to the exact path below.
-    if (c->last_finish_valid && nq <= kBatchMaxQ && e->batch_retry.load() != 0 && c->last_finish.kp < 960) {
-        uint32_t nfail = 0;
+    // Second rung of the ladder, without another pass over the store: an uncertified query's survivors — EVERY row the
+    // filtering GEMM admitted (approx distance <= tau) — are still in its segments, so all of them are re-scored exactly
+    // (rescore_kernel in survivor-area mode) and the best k selected (full_retry_select_kernel). With every survivor re-scored
+    // the certificate only needs tau - eps > the exact k-th: it no longer matters how many rows sit inside the bf16 error band
+    // of the k-th neighbour (dense neighbourhoods, runs of near-duplicates: what k' = 2k + 32 candidates cannot cover), only
+    // that no segment overflowed — which is why the planner gives every segment room for 128 survivors. A query that fails
+    // again (overflow, fewer than k survivors, a tie ACROSS the threshold) goes to the exact path below.
+    if (c->last_finish_valid && nq <= kBatchMaxQ && e->batch_retry.load() != 0 && batch_finish_fused_dims(D)) {
+        std::vector<uint32_t> failing;
         for (uint32_t q = 0; q < nq; ++q)
-            if (!c->h_cert[q]) c->h_qlist[nfail++] = q;
-        if (nfail > 0) {
-            FinishArgs f = c->last_finish;
-            f.kp = 960; f.qlist = c->d_qlist; f.nq = nfail;
-            rc = bctx_reserve_kp(c, 960);
-            if (rc == WAX_HIP_OK) {
-                f.sel = c->d_sel; f.exact = c->d_exact;
-                HIP_TRY(hipMemcpyAsync(c->d_qlist, c->h_qlist, nfail * sizeof(uint32_t), hipMemcpyHostToDevice, st), WAX_HIP_ERR_INTERNAL, "retry list upload");
-                HIP_TRY(launch_batch_finish(f, c->last_metric, st), WAX_HIP_ERR_INTERNAL, "wide finish launch");
-                HIP_TRY(hipStreamSynchronize(st), WAX_HIP_ERR_INTERNAL, "wide finish failed on device");
-                e->st_batch_retries += nfail;
-            } else {
-                rc = WAX_HIP_OK;   // no memory for the retry: the exact path still answers
-            }
+            if (!c->h_cert[q]) failing.push_back(q);
+        const FinishArgs& lf = c->last_finish;
+        const uint64_t area = lf.cand_cap;
+        const uint64_t per_round = std::max<uint64_t>(1, std::min<uint64_t>(kBatchMaxQ, (64ull << 20) / (area * sizeof(int64_t))));
+        for (size_t off = 0; off < failing.size() && rc == WAX_HIP_OK; off += per_round) {
+            const uint32_t m = (uint32_t)std::min<uint64_t>(per_round, failing.size() - off);
+            rc = grow_dev(&c->d_rescue, &c->rescue_cap, (uint64_t)m * area, sizeof(int64_t), "Failed to allocate full-retry keys");
+            if (rc != WAX_HIP_OK) { rc = WAX_HIP_OK; break; }   // no memory for the retry: the exact path still answers
+            std::memcpy(c->h_qlist, failing.data() + off, m * sizeof(uint32_t));
+            HIP_TRY(hipMemcpyAsync(c->d_qlist, c->h_qlist, m * sizeof(uint32_t), hipMemcpyHostToDevice, st), WAX_HIP_ERR_INTERNAL, "retry list upload");
+            // step 1: the live survivors of every query of the round, packed; their counts come back through pinned memory
+            CompactArgs ca{};
+            ca.cand = lf.cand; ca.cand_cap = lf.cand_cap; ca.seg_count = lf.seg_count; ca.nseg = lf.nseg; ca.seg_slots = lf.seg_slots;
+            ca.nq_pad = lf.nq_pad; ca.count_stride = lf.count_stride; ca.qlist = c->d_qlist; ca.n_slots = m;
+            ca.dense = c->d_rescue; ca.dense_stride = (uint32_t)area; ca.live_out = c->h_live;
+            HIP_TRY(launch_compact_survivors(ca, st), WAX_HIP_ERR_INTERNAL, "full-retry compaction launch");
+            HIP_TRY(hipStreamSynchronize(st), WAX_HIP_ERR_INTERNAL, "full retry failed on device");
+            uint32_t live_max = 0;
+            for (uint32_t i = 0; i < m; ++i) live_max = std::max(live_max, c->h_live[i]);
+            if (live_max == 0) continue;                      // nothing passed the filter: the exact path answers
+            const uint32_t kp = (uint32_t)std::min<uint64_t>(area, ((uint64_t)live_max + 63u) & ~63ull);
+            rc = grow_dev(&c->d_rescue_exact, &c->rescue_exact_cap, (uint64_t)m * kp, sizeof(int64_t), "Failed to allocate full-retry keys");
+            if (rc != WAX_HIP_OK) { rc = WAX_HIP_OK; break; }
+            // step 2: exact f32 distance of every survivor (scan_kernel's arithmetic)
+            RescoreArgs r{};
+            r.store = e->d_store; r.queries = d_queries; r.q_norm = c->d_qnorm; r.cand = c->d_rescue; r.exact = c->d_rescue_exact;
+            r.n_rows = lf.n_rows; r.row_base = lf.row_base; r.dims = D; r.nq = m; r.cand_cap = (uint32_t)area; r.kp = (int)kp;
+            r.qlist = c->d_qlist; r.by_slot = 1;
+            HIP_TRY(launch_rescore(r, c->last_metric, st), WAX_HIP_ERR_INTERNAL, "full-retry rescore launch");
+            // step 3: the k best + certificate
+            FullRetryArgs fr{};
+            fr.exact = c->d_rescue_exact; fr.area = kp; fr.qlist = c->d_qlist; fr.n_slots = m;
+            fr.seg_count = lf.seg_count; fr.nseg = lf.nseg; fr.seg_slots = lf.seg_slots; fr.nq_pad = lf.nq_pad; fr.count_stride = lf.count_stride;
+            fr.tau = lf.tau; fr.eps = lf.eps; fr.overflow = lf.overflow; fr.ids = lf.ids; fr.n_rows = lf.n_rows; fr.row_base = lf.row_base;
+            fr.k = lf.k; fr.out = lf.out; fr.out_stride = lf.out_stride; fr.certified = lf.certified;
+            HIP_TRY(launch_full_retry_select(fr, st), WAX_HIP_ERR_INTERNAL, "full-retry select launch");
+            HIP_TRY(hipStreamSynchronize(st), WAX_HIP_ERR_INTERNAL, "full retry failed on device");   // the pinned list is reused; flags are read below
+            e->st_batch_retries += m;
         }
     }
     c->last_finish_valid = false;

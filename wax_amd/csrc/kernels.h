@@ -178,7 +178,35 @@ struct RescoreArgs {
     const uint32_t* rows;
     float* dist_out;
     const uint32_t* qlist;      // candidate-key mode: non-null = slot s of the launch is query qlist[s] (arrays indexed by query)
+    int by_slot;                // 1 (with qlist) = `cand` and `exact` rows are indexed by the launch slot (compact buffers of a
+                                // retry round), only queries / q_norm by the query number
 };
+// Full retry, step 1: the live survivors of each listed query (segment s holds min(count_s, seg_slots) keys; count_s =
+// seg_count[s * nq_pad + q], or seg_count[q * count_stride] for the one counted list) packed into dense[slot][0 .. live),
+// the rest of the row (dense_stride keys) padded with KEY_PAD; live_out[slot] = live (pinned host memory: the host sizes the
+// re-score by the largest).
+struct CompactArgs {
+    const int64_t* cand; uint32_t cand_cap;
+    const uint32_t* seg_count; uint32_t nseg, seg_slots, nq_pad, count_stride;
+    const uint32_t* qlist; uint32_t n_slots;
+    int64_t* dense; uint32_t dense_stride;
+    uint32_t* live_out;
+};
+hipError_t launch_compact_survivors(const CompactArgs& a, hipStream_t stream);
+// Full retry, step 3 (step 2 = launch_rescore over the dense lists, by slot): exact keys of ALL survivors of each listed query
+// (`area` keys per row, KEY_PAD = dead) -> per query the k best, ascending, as hits with frame ids, and the certificate
+// "every row the filter rejected is provably worse": no segment overflowed, at least k survivors, tau - eps > the exact k-th.
+struct FullRetryArgs {
+    const int64_t* exact; uint32_t area;                 // [n_slots][area]
+    const uint32_t* qlist; uint32_t n_slots;             // launch slot -> query number
+    const uint32_t* seg_count; uint32_t nseg, seg_slots, nq_pad, count_stride;
+    const float* tau; const float* eps; const uint32_t* overflow;
+    const uint64_t* ids; uint32_t n_rows, row_base;
+    int k;
+    wax_hip_hit* out; uint32_t out_stride;               // rows indexed by query number
+    uint32_t* certified;                                 // indexed by query number
+};
+hipError_t launch_full_retry_select(const FullRetryArgs& a, hipStream_t stream);
 hipError_t launch_mirror(const float* src, uint32_t n_rows, uint32_t n_rows_padded, uint32_t dims, int normalize,
                          unsigned short* dst, float* norm2, unsigned int* max_norm_bits, hipStream_t stream);
 hipError_t launch_batch_gemm(const GemmArgs& a, int metric, hipStream_t stream);

@@ -63,28 +63,6 @@ constexpr int MS_NQ = 16;      // queries per pass (a shorter last group is padd
 constexpr int MS_U = 4;        // row-groups a wave holds in registers per chunk
 constexpr int MS_M = MS_NQ * MS_U;   // partial sums per lane per chunk: value m = u * 16 + q
 
-// Cold path: append the keys of the lanes in `same` (all of ONE query) to that query's (wave-private) list, prune when the
-// next push might not fit. Returns the (possibly tightened) threshold. Out of line on purpose (see wave_prune).
-template <int CAP>
-__device__ __attribute__((noinline)) int64_t ms_insert(int64_t* list, MsState* st, int64_t key, bool same, int k, int room) {
-    wave_lds_fence();
-    int cnt = st->cnt;
-    const unsigned long long mask = __ballot(same);
-    const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-    if (same) list[cnt + before] = key;
-    cnt += __popcll(mask);
-    int64_t tau = st->tau;
-    if (cnt > CAP - room) {
-        const PruneOut r = wave_prune<CAP, true>((lds_i64*)list, cnt, k);
-        cnt = r.cnt;
-        tau = r.tau;
-    }
-    wave_lds_fence();
-    if (lane_id() == 0) { st->cnt = cnt; st->tau = tau; }
-    wave_lds_fence();
-    return tau;
-}
-
 template <int CTRL>
 __device__ inline float ms_dpp_move(float v) {   // v of the lane the DPP pattern names (every lane has a source)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
@@ -185,9 +163,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_multi_kernel(ScanMultiArgs 
     const uint32_t gwave = blockIdx.x * SCAN_WAVES + wave;
     const uint32_t nwaves = gridDim.x * SCAN_WAVES;
 
-    for (uint32_t chunk = gwave; chunk < nchunks; chunk += nwaves) {
+    // The rows of chunk c + 1 are requested BEFORE chunk c is scored (two register sets, the loop unrolled by two): a wave
+    // computes ~4 400 VALU cycles per chunk — as long as the HBM round trip — and with two waves per SIMD nothing else would
+    // cover that latency (PMC of the first version: waves parked 60 % of their cycles, VALU busy 45 %).
+    auto load_chunk = [&](f32x4 (&v)[MS_U][LOADS], uint32_t chunk) {
         const uint32_t rbase = chunk * RPC + sub;
-        f32x4 v[MS_U][LOADS];
 #pragma unroll
         for (int u = 0; u < MS_U; ++u) {
             const uint32_t r = rbase + u * RPW;
@@ -196,19 +176,22 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_multi_kernel(ScanMultiArgs 
 #pragma unroll
             for (int j = 0; j < LOADS; ++j) v[u][j] = __builtin_nontemporal_load(p + j * GROUP);
         }
+    };
+    auto score_chunk = [&](const f32x4 (&v)[MS_U][LOADS], uint32_t chunk) {
+        const uint32_t rbase = chunk * RPC + sub;
         // ||v||^2 per row-group, scan_kernel's chain and reduction, then handed to every lane of the group
-        float nb[MS_U];
+        // (four named scalars, not an array: a `b4 ? nb[1] : nb[0]` on an array is rewritten into a load from a lane-indexed
+        // stack copy — scratch traffic in the hot loop)
+        auto row_norm = [&](const f32x4 (&vu)[LOADS]) -> float {
+            if (METRIC != MS_COS) return 0.f;
+            f32x4 nrm = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int u = 0; u < MS_U; ++u) {
-            nb[u] = 0.f;
-            if (METRIC == MS_COS) {
-                f32x4 nrm = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int j = 0; j < LOADS; ++j) nrm = __builtin_elementwise_fma(v[u][j], v[u][j], nrm);
-                const float tot = group_sum<GROUP>(ms_hsum(nrm));            // valid in the group's last lane
-                nb[u] = __shfl(tot, last_of_group, 64);
-            }
-        }
+            for (int j = 0; j < LOADS; ++j) nrm = __builtin_elementwise_fma(vu[j], vu[j], nrm);
+            const float tot = group_sum<GROUP>(ms_hsum(nrm));                // valid in the group's last lane
+            return __shfl(tot, last_of_group, 64);
+        };
+        const float nb0 = row_norm(v[0]), nb1 = row_norm(v[1]), nb2 = row_norm(v[2]), nb3 = row_norm(v[3]);
+        static_assert(MS_U == 4, "four row-groups per chunk");
         // lane-private partial sums of all 64 (row-group, query) pairs; query slices come from LDS, one query ahead
         float part[MS_M];
         f32x4 qa[LOADS], qb[LOADS];
@@ -216,7 +199,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_multi_kernel(ScanMultiArgs 
         for (int j = 0; j < LOADS; ++j) qa[j] = qs_l[j * GROUP];
 #pragma unroll
         for (int qi = 0; qi < MS_NQ; ++qi) {
-            constexpr int dummy = 0; (void)dummy;
             const int qnext = qi + 1 < MS_NQ ? qi + 1 : qi;
 #pragma unroll
             for (int j = 0; j < LOADS; ++j) qb[j] = qs_l[(size_t)qnext * D4 + j * GROUP];
@@ -249,21 +231,59 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_multi_kernel(ScanMultiArgs 
         for (int j = 0; j < OUT; ++j) {
             int u;
             float nrm;
-            if (GROUP == 16) { u = j; nrm = nb[j]; }
-            else if (GROUP == 32) { u = b4 + 2 * j; nrm = b4 ? nb[2 * j + 1] : nb[2 * j]; }
-            else { u = b4 + 2 * b5; nrm = b5 ? (b4 ? nb[3] : nb[2]) : (b4 ? nb[1] : nb[0]); }
+            if (GROUP == 16) { u = j; nrm = j == 0 ? nb0 : (j == 1 ? nb1 : (j == 2 ? nb2 : nb3)); }
+            else if (GROUP == 32) { u = b4 + 2 * j; nrm = j == 0 ? (b4 ? nb1 : nb0) : (b4 ? nb3 : nb2); }
+            else { u = b4 + 2 * b5; nrm = b5 ? (b4 ? nb3 : nb2) : (b4 ? nb1 : nb0); }
             const float d = ms_finish<METRIC>(part[j], nrm, qn_lane);
             const uint32_t r = rbase + (uint32_t)u * RPW;
             const int64_t key = make_key(d, a.row_base + r);
-            bool pass = q_live && (r < n) && (key < tau_lane);
+            const bool pass = q_live && (r < n) && (key < tau_lane);
             unsigned long long todo = __ballot(pass);
             while (todo != 0ull) {                               // rare after warm-up: one list at a time
                 const int L = (int)__builtin_ctzll(todo);
                 const int qL = __builtin_amdgcn_readlane(q_lane, L);
                 const bool same = pass && (q_lane == qL);
-                const int64_t t_new = ms_insert<CAP>(my_lists + (size_t)qL * CAP, my_state + qL, key, same, k, 4);
-                if (q_lane == qL) tau_lane = t_new;
-                todo &= ~__ballot(same);
+                // append inline (a few DS operations); only the prune of a full list runs out of line
+                lds_i64* list = (lds_i64*)(my_lists + (size_t)qL * CAP);
+                MsState* stq = my_state + qL;
+                wave_lds_fence();
+                int cnt = __builtin_amdgcn_readfirstlane(stq->cnt);
+                const unsigned long long mask = __ballot(same);
+                const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                if (same) list[cnt + before] = key;
+                cnt += __popcll(mask);
+                if (cnt > CAP - 4) {                             // the next push (<= 4 candidates per list) might not fit
+                    const PruneOut pr = wave_prune<CAP, true>(list, cnt, k);
+                    cnt = pr.cnt;
+                    if (q_lane == qL) tau_lane = pr.tau;
+                }
+                wave_lds_fence();
+                if (lane == 0) stq->cnt = cnt;
+                todo &= ~mask;
+            }
+        }
+    };
+    {
+        f32x4 va[MS_U][LOADS], vb[MS_U][LOADS];
+        // The prefetch is UNCONDITIONAL (past the end it re-requests the current chunk: L2 hits, discarded): behind a branch
+        // the compiler no longer knows how many requests are outstanding and waits vmcnt(0) for the current set — which
+        // drains the prefetch it was meant to overlap.
+        uint32_t chunk = gwave;
+        if (chunk < nchunks) {
+            load_chunk(va, chunk);
+            for (;;) {
+                uint32_t nxt = chunk + nwaves;
+                load_chunk(vb, nxt < nchunks ? nxt : chunk);
+                __builtin_amdgcn_sched_barrier(0);    // the requests go out before the first use of the current set
+                score_chunk(va, chunk);
+                chunk = nxt;
+                if (chunk >= nchunks) break;
+                nxt = chunk + nwaves;
+                load_chunk(va, nxt < nchunks ? nxt : chunk);
+                __builtin_amdgcn_sched_barrier(0);
+                score_chunk(vb, chunk);
+                chunk = nxt;
+                if (chunk >= nchunks) break;
             }
         }
     }
