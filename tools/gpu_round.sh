@@ -45,6 +45,34 @@ for s in $STAGES; do
           --kernel-trace --output-format csv -d "$OUT/prof_mspmc" -o g -- python "$R/tools/multiscan_bench.py" --dims 384 --nq 16 --reps 3 > "$OUT/multiscan_pmc.log" 2>&1); rc=$?
       python tools/pmc_summary.py "$OUT/prof_mspmc" > "$OUT/multiscan_pmc_summary.json" 2>> "$OUT/multiscan_pmc.log"
       rm -rf "$OUT/prof_mspmc" ;;
+    freerun)
+      WAX_HIP_BATCH_REGA=4 timeout 900 python -m pytest tests -q -m gpu -x -p no:cacheprovider --timeout 400 \
+          -k "onepass or batch_mfma or randomised_soak or variants_agree or edge_shapes or special_values or dot_and_l2 or adversarial or falls_back_on_ties" > "$OUT/pytest_freerun.log" 2>&1; rc=$?
+      timeout 600 python tools/batch_bench.py --nq 256 1024 --rega 1 4 1 4 > "$OUT/freerun_bench.log" 2>&1
+      timeout 300 python tools/batch_bench.py --dims 256 --nq 256 1024 --rega 1 4 1 4 --reps 3 > "$OUT/freerun_bench256.log" 2>&1
+      timeout 300 python tools/batch_bench.py --nq 256 --reps 2 --rega 4 --debug 1024 > "$OUT/freerun_clock.log" 2>&1
+      grep WAXPROF "$OUT/freerun_clock.log" | sort | uniq -c | sort -rn | head -200 > "$OUT/freerun_waxprof.txt" ;;
+    token)
+      timeout 600 python tools/batch_bench.py --nq 256 1024 --rega 4 --debug 0 2048 0 2048 > "$OUT/token_bench.log" 2>&1; rc=$?
+      timeout 300 python tools/batch_bench.py --dims 256 --nq 1024 --rega 4 --debug 0 2048 0 2048 --reps 3 > "$OUT/token_bench256.log" 2>&1
+      timeout 300 python tools/batch_bench.py --nq 256 --reps 2 --rega 4 --debug 3072 > "$OUT/token_clock.log" 2>&1
+      grep WAXPROF "$OUT/token_clock.log" | sort | uniq -c | sort -rn | head -200 > "$OUT/token_waxprof.txt" ;;
+    mfmaprobe)
+      hipcc --offload-arch=gfx950 -O3 -std=c++17 -w tools/mfma_probe.hip -o /tmp/mfma_probe > "$OUT/mfma_probe.err" 2>&1 && timeout 120 /tmp/mfma_probe > "$OUT/mfma_probe.jsonl" 2>> "$OUT/mfma_probe.err"; rc=$? ;;
+    freeprobe)
+      hipcc --offload-arch=gfx950 -O3 -std=c++17 -w tools/mfma_probe.hip -o /tmp/mfma_probe > "$OUT/mfma_probe.err" 2>&1
+      timeout 600 python tools/batch_bench.py --nq 256 1024 --rega 4 --reps 10 --debug 0 8 4096 4104 16 2048 0 > "$OUT/freeprobe_bench.log" 2>&1; rc=$?
+      timeout 120 /tmp/mfma_probe > "$OUT/mfma_probe.jsonl" 2>> "$OUT/mfma_probe.err" ;;
+    freeprobe2)
+      timeout 600 python tools/batch_bench.py --nq 1024 --rega 4 --reps 10 --debug 0 4104 4120 4136 4152 4104 > "$OUT/freeprobe2_bench.log" 2>&1; rc=$?
+      timeout 600 python tools/batch_bench.py --nq 1024 --rega 1 --reps 10 --debug 0 9 13 29 9 >> "$OUT/freeprobe2_bench.log" 2>&1 ;;
+    freeab)
+      for m in 1 4 1 4; do
+        WAX_HIP_BATCH_REGA=$m timeout 600 python bench.py --gpus 1 --no-cpu-baseline --steps 60 --warmup 10 --secondary b1m_q256,b1m_q1024,clustered_k100 > "$OUT/bench_sec_rega$m.$RANDOM.json" 2>> "$OUT/bench_sec.err"; rc=$?
+      done ;;
+    gemmclock)
+      timeout 300 python tools/batch_bench.py --nq 256 1024 --reps 2 --debug 1024 > "$OUT/gemmclock.log" 2>&1; rc=$?
+      grep WAXPROF "$OUT/gemmclock.log" | sort | uniq -c | sort -rn | head -200 > "$OUT/gemmclock_waxprof.txt" ;;
     shardbench)
       timeout 900 python tools/sharded_handle_bench.py --parts ${WAX_PARTS:-A,B,C} > "$OUT/sharded_handle_bench.jsonl" 2> "$OUT/sharded_handle_bench.err"; rc=$? ;;
     fuzz)

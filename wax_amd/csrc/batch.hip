@@ -450,7 +450,25 @@ constexpr int rega_lds_tiles(bool glds) { return (glds && 3 * 64 * (D * 2 + 16) 
 // visits `a.sample_tiles` tiles spread evenly over the slab (logical index i -> tile i * ntiles / sample_tiles) and
 // records, per query, the best similarity of each visited tile in a.tile_max[i][query] (pick_tau_kernel turns the
 // j-th best tile maximum into the query's admission threshold).
-template <int D, bool GLDS, int AHEAD, bool SAMPLE = false>
+// FREE = true ("batch_rega" = 4; register staging, THREE LDS tiles; where they fit: D <= 384): NO workgroup barrier in the tile loop.
+// The phase clock (debug bit 10, profiles/r03/i_gemm_phase_clock.txt) showed where the ~40 % of a tile period that is not
+// matrix-pipe time goes: the one barrier per tile joins eight waves whose per-tile durations differ (arbitration of the shared
+// matrix pipe and the LDS port), and every wave waits for the slowest — 13 % (late half) to 27 % (early half) of its cycles.
+// What the barrier protected is two hazards on the staged tiles, and each is covered by one LDS counter per tile buffer:
+//   RAW  stored[b]: a wave adds 1 behind its last store of a tile into buffer b (a wave's DS operations execute in order);
+//        a reader spins until the counter shows 8 x (the buffer's fill number) before its first fragment read.
+//   WAR  read[b]: a wave adds 1 behind its last fragment read of the tile in buffer b; a writer spins on it before its first
+//        store of the buffer's next fill.
+// The staging runs TWO tiles ahead (iteration t loads tile t+2 from HBM at its top and stores it from the second half of its
+// K loop into the buffer tile t-1 was read from), so the RAW wait of iteration t is on stores made during iteration t-2 — a
+// whole tile period of slack — and the WAR wait, half-way through K loop t, is on reads that ended with K loop t-1: half a
+// period of slack. Waves drift apart by that much and re-converge without anybody having waited for it.
+// Measured (profiles/r03/j_gemm_phase_clock_free_running.txt, r_bench_free_running_ab.txt): the wait falls from 13-27 % of a
+// wave's cycles to 5 %, the kernel alone gains 2-5 % (frac 0.477 -> 0.491 at Q = 256) — and the pipelined batches LOSE 1.7 %,
+// because a 150 KB workgroup keeps the neighbouring batch's finish / prep kernels off the CU. Hence a variant, not the default.
+// What the remaining gap is made of is in DESIGN.md ("the matrix roof"): with embedding-like operands the K loop ALONE
+// (tools/mfma_probe.hip) sustains 1.57 PFLOP/s on this part — the matrix clock is power-limited and data-dependent.
+template <int D, bool GLDS, int AHEAD, bool SAMPLE = false, bool PROF = false, bool FREE = false>
 __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uint32_t blocks_per_group) {
     constexpr int KS = D / 16;                       // MFMA k-steps
     constexpr int ROW_B = D * 2 + 16;                // LDS row stride (bytes)
@@ -459,7 +477,8 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
     constexpr int SEGS = TROWS * SEG_PER_ROW;        // 16-byte segments per tile
     constexpr int LOADS = SEG_PER_ROW / 8;           // per thread (8 threads per row, 64 rows)
     constexpr int BUF_B = TROWS * ROW_B;
-    constexpr int NBUF = rega_lds_tiles<D>(GLDS);
+    static_assert(!FREE || (!GLDS && !SAMPLE), "the free-running variant is the register-staged filtering kernel");
+    constexpr int NBUF = FREE ? 3 : rega_lds_tiles<D>(GLDS);
     constexpr int PRE = NBUF - 1;                    // GLDS: tiles requested ahead of the one being read
     constexpr int SLOTS_PER_ROW = ROW_B / 16;        // 16-byte slots per padded row; == 1-KB pieces per tile (64 rows)
     constexpr int PIECES = SLOTS_PER_ROW;
@@ -472,6 +491,9 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
     unsigned int* cnt_s = reinterpret_cast<unsigned int*>(tau_s + 8 * 32);     // [8][32] survivors per query (this workgroup)
     float* sim_s = reinterpret_cast<float*>(cnt_s + 8 * 32);                   // [8][32] conservative similarity bounds
     unsigned int* next_s = reinterpret_cast<unsigned int*>(sim_s + 8 * 32);    // [2] claimed tile indices (dynamic tile order)
+    unsigned int* stored_s = next_s + 4;                                       // [3] FREE: wave signals per LDS tile buffer: "my stores of its current fill are in"
+    unsigned int* read_s = next_s + 8;                                         // [3] FREE: "my reads of its current fill are done"
+    unsigned int* turn_s = next_s + 12;                                        // [4] FREE, debug bit 11: whose K loop runs next on each SIMD (pipe token)
 
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
@@ -495,6 +517,11 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
         sim_s[wave * 32 + lane] = (1.0f - tq) - 4e-7f * (1.0f + __builtin_fabsf(tq));
     }
     if (tid < 256) cnt_s[tid] = 0u;
+    if (FREE && tid < 3) {
+        stored_s[tid] = tid < 2 ? 8u : 0u;                                     // tiles 0 and 1 are staged by the prologue, behind a barrier
+        read_s[tid] = 0u;
+    }
+    if (FREE && tid >= 64 && tid < 68) turn_s[tid - 64] = 0u;
     // this workgroup's segment of every query's candidate row
     const uint32_t seg_slots = a.seg_area / blocks_per_group;
     // element offset (32-bit: rows * cand_cap < 2^23) of this lane's first query row, at this workgroup's segment;
@@ -566,7 +593,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
     // staging only): the first two tiles are the static ones, every further one is claimed from the group's counter one
     // iteration before its loads are issued — thread 0 starts the atomic at the top of an iteration and parks the
     // result in LDS at its end, next to the tile barrier, so its latency never sits on the critical path.
-    const bool dyn = !SAMPLE && !GLDS && a.tile_ctr != nullptr;
+    const bool dyn = !SAMPLE && !GLDS && !FREE && a.tile_ctr != nullptr;
     uint32_t t = bidx;
     if (dyn && tid == 0) {
         const unsigned int c0 = claim_tile_async(a.tile_ctr + group * 32u);
@@ -585,6 +612,10 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
             issue_loads(t);
             store_tile(buf0);
         }
+        if (FREE && t + blocks_per_group < ntiles) {
+            issue_loads(t + blocks_per_group);
+            store_tile(buf0 + BUF_B);
+        }
         __syncthreads();
     }
     // The two waves that share a SIMD (w and w + 4: a workgroup's waves are dealt to the SIMDs cyclically) do
@@ -593,7 +624,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
     // of a SIMD is in its VALU/LDS-only selection the other has the matrix pipe to itself, so the selection
     // (~25 % of a tile's issue slots) hides under MFMAs instead of idling the pipe for both waves at once.
     const bool late = wave >= 4 && !(a.debug & 16u);   // debug bit4: every wave in the same order
-    const bool dbg_noload = (a.debug & 1u) != 0, dbg_nomfma = (a.debug & 2u) != 0;  // timing experiments only
+    const bool dbg_noload = !FREE && (a.debug & 1u) != 0, dbg_nomfma = !FREE && (a.debug & 2u) != 0;  // timing experiments only
     const bool prio = (a.debug & 32u) == 0;            // s_setprio 1 around the MFMA stream (+2-3 % at Q = 1024); debug bit5 turns it off
     f32x16 acc0, acc1;
 #pragma unroll
@@ -608,7 +639,30 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
     // `st_dst` != nullptr: the next tile's staged segments (regs[], loaded at the top of the iteration) are written to LDS
     // from INSIDE the K loop — piece p in front of k-step KS/2 + 2p — instead of in one burst after it: the burst was a
     // phase of ~600 LDS cycles per tile in which no wave of the workgroup had MFMAs left to issue.
-    auto mfma_tile = [&](const unsigned char* cur, unsigned char* st_dst) {
+    // FREE: spin until counter `ctr` (LDS) shows `target`. Wave-uniform; bounded, so that a protocol error shows up as wrong
+    // answers in the parity tests instead of a hung GPU.
+    auto wait_count = [&](const unsigned int* ctr, unsigned int target) {
+        for (unsigned int spins = 0; spins < (1u << 22); ++spins) {
+            const unsigned int v = __hip_atomic_load((const lds_u32*)ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((unsigned int)__builtin_amdgcn_readfirstlane((int)v) >= target) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        asm volatile("" ::: "memory");
+    };
+    // FREE: one signal per wave, behind everything the wave has issued to the LDS so far (a wave's DS operations execute in
+    // order; the wait makes "issued" "done" for the reads, whose data the MFMAs have consumed anyway)
+    auto signal_count = [&](unsigned int* ctr) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add((lds_u32*)ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    // war_ctr / war_target (FREE): the buffer st_dst points into must have been read by all eight waves before the first store
+    // debug bit 11 (FREE): the two waves of a SIMD (w, w + 4) take strict turns at the matrix pipe — wave w runs K loop t as turn
+    // 2t, wave w + 4 as turn 2t + 1, the other one is in its selection meanwhile; the turn is handed over TOKEN_REL k-steps
+    // before the end of the loop to cover the hand-over latency
+    const bool token = FREE && (a.debug & 2048u) != 0;
+    const bool dbg_nostage = FREE && (a.debug & 4096u) != 0;   // debug bit 12 (FREE, timing only): no HBM loads, no staging stores, no counters
+    constexpr int TOKEN_REL = 2;
+    auto mfma_tile = [&](const unsigned char* cur, unsigned char* st_dst, const unsigned int* war_ctr = nullptr, unsigned int war_target = 0u, unsigned int my_turn = 0u) {
         if (dbg_nomfma) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
@@ -625,15 +679,19 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
             fb0[i] = *reinterpret_cast<const u32x4*>(b0 + i * 32);
             fb1[i] = *reinterpret_cast<const u32x4*>(b1 + i * 32);
         }
+        if (FREE && token) wait_count(turn_s + (wave & 3), my_turn);
         if (prio) __builtin_amdgcn_s_setprio(1);   // the SIMD's other wave is in its selection: MFMA issue first
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
+            if (FREE && ks == KS - TOKEN_REL && token && lane == 0)
+                __hip_atomic_store((lds_u32*)(turn_s + (wave & 3)), my_turn + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (ks + AHEAD < KS) {
                 fb0[(ks + AHEAD) % RING] = *reinterpret_cast<const u32x4*>(b0 + (ks + AHEAD) * 32);
                 fb1[(ks + AHEAD) % RING] = *reinterpret_cast<const u32x4*>(b1 + (ks + AHEAD) * 32);
             }
             if (!GLDS && ks >= KS / 2 && ((ks - KS / 2) & 1) == 0 && (ks - KS / 2) / 2 < LOADS) {
+                if (FREE && ks == KS / 2 && st_dst && war_ctr) wait_count(war_ctr, war_target);
                 if (st_dst) *reinterpret_cast<u32x4*>(st_dst + ((ks - KS / 2) / 2) * 128) = regs[GLDS ? 0 : (ks - KS / 2) / 2];
             }
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], __builtin_bit_cast(bf16x8, fb0[ks % RING]), ks == 0 ? zero16 : acc0, 0, 0, 0);
@@ -642,7 +700,6 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
         }
         if (prio) __builtin_amdgcn_s_setprio(0);
     };
-
     // Fused selection on the accumulators of `tile`: C[query][row], col = lane & 31 = corpus row,
     // reg r = query qo(r) = (r&3) + 8(r>>2) + 4(lane>>5).
     // Fast path, every tile: 32 compares of the accumulators (similarities) against the lane's 16 thresholds,
@@ -715,8 +772,12 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
         }
     };
 
+    constexpr bool prof = PROF;   // a separate instantiation (launch_rega, debug bit 10): the counters and the printf cost 8 VGPRs
+    unsigned long long prof_mfma = 0, prof_sel = 0, prof_bar = 0;
+    const unsigned long long prof_t0 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
     uint32_t it = 0;
-    uint32_t cur_idx = 0;                                     // GLDS: it % NBUF
+    uint32_t cur_idx = 0;                                     // GLDS / FREE: it % NBUF
+    uint32_t pre_idx3 = 2;                                    // FREE: (it + 2) % 3, the buffer this iteration stages into
     uint32_t t_prev = 0;                                      // the tile of the previous iteration (late waves select it now)
     uint32_t t_next = t + blocks_per_group;                   // register staging: the tile whose loads this iteration issues
     for (; t < ntiles; ++it) {
@@ -732,6 +793,11 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
             uint32_t pre_idx = cur_idx + PRE;
             pre_idx = pre_idx >= (uint32_t)NBUF ? pre_idx - NBUF : pre_idx;
             if (tn < ntiles) { dma_tile(tn, pre_idx * BUF_B); issued = true; }
+        } else if (FREE) {
+            cur = buf0 + cur_idx * BUF_B;
+            nxt = buf0 + pre_idx3 * BUF_B;                        // where tile it + 2 goes: the buffer tile it - 1 was read from
+            tn = dbg_nostage ? ntiles : t_next + blocks_per_group;   // the tile staged in this iteration: two ahead
+            if (tn < ntiles) issue_loads(tn);
         } else {
             cur = buf0 + ((dbg_noload ? 0u : (it & 1u)) * BUF_B);  // debug bit0: always the prologue tile
             nxt = buf0 + ((it & 1) ^ 1) * BUF_B;
@@ -745,17 +811,50 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
             }
         }
         // debug bit7: the staged tile goes to LDS in one burst after the K loop (the round-1 schedule), for A/B timing
-        const bool spread = !GLDS && !(a.debug & 128u);
+        const bool spread = !GLDS && (FREE || !(a.debug & 128u));
         unsigned char* st_dst = (!GLDS && spread && tn < ntiles && !dbg_noload) ? nxt + srow * ROW_B + sseg : nullptr;
+        // FREE: tile `it` is fill it / 3 + 1 of its buffer; the buffer being refilled was read as tile it - 1
+        const unsigned int raw_target = 8u * (it / 3u + 1u), war_target = it ? 8u * ((it - 1u) / 3u + 1u) : 0u;
+        // debug bit10: per-wave phase clock (s_memtime around the MFMA phase, the selection and the tile barrier), printed by a
+        // few workgroups at the end — where the 40 % of a tile period that is not matrix-pipe time goes. Perturbs the timing
+        // (every reading drains the wave's LDS queue): a diagnosis run, never a benchmark.
+        unsigned long long c0 = 0, c1 = 0, c2 = 0;
+        if (prof) c0 = __builtin_amdgcn_s_memtime();
         if (late) {
             if (it > 0) select_tile(t_prev);
-            mfma_tile(cur, st_dst);
+            if (prof) { c1 = __builtin_amdgcn_s_memtime(); prof_sel += c1 - c0; }
+            if (FREE) {
+                if (!dbg_nostage) wait_count(stored_s + cur_idx, raw_target);
+                if (prof) { const unsigned long long cw = __builtin_amdgcn_s_memtime(); prof_bar += cw - c1; c1 = cw; }
+                mfma_tile(cur, st_dst, it ? read_s + pre_idx3 : nullptr, war_target, 2u * it + (wave >= 4 ? 1u : 0u));
+                signal_count(read_s + cur_idx);
+                if (st_dst && lane == 0) __hip_atomic_fetch_add((lds_u32*)(stored_s + pre_idx3), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                mfma_tile(cur, st_dst);
+            }
+            if (prof) { c2 = __builtin_amdgcn_s_memtime(); prof_mfma += c2 - c1; }
         } else {
-            mfma_tile(cur, st_dst);
+            if (FREE) {
+                if (!dbg_nostage) wait_count(stored_s + cur_idx, raw_target);
+                if (prof) { const unsigned long long cw = __builtin_amdgcn_s_memtime(); prof_bar += cw - c0; c0 = cw; }
+                mfma_tile(cur, st_dst, it ? read_s + pre_idx3 : nullptr, war_target, 2u * it + (wave >= 4 ? 1u : 0u));
+                signal_count(read_s + cur_idx);
+                if (st_dst && lane == 0) __hip_atomic_fetch_add((lds_u32*)(stored_s + pre_idx3), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                mfma_tile(cur, st_dst);
+            }
+            if (prof) { c1 = __builtin_amdgcn_s_memtime(); prof_mfma += c1 - c0; }
             select_tile(t);
+            if (prof) { c2 = __builtin_amdgcn_s_memtime(); prof_sel += c2 - c1; }
         }
         t_prev = t;
-        if (GLDS) {
+        if (FREE) {
+            pre_idx3 = cur_idx;                                   // next iteration refills the buffer this one read
+            cur_idx = cur_idx + 1 == 3u ? 0u : cur_idx + 1;
+            t = t_next;
+            t_next += blocks_per_group;
+            if (prof) c2 = __builtin_amdgcn_s_memtime();
+        } else if (GLDS) {
             // tile t + 1 must have landed (every wave waits for its own pieces, the barrier joins them); with
             // three tiles in LDS the one requested in this iteration stays in flight across the barrier
             dma_wait(PRE == 2 && issued);
@@ -773,7 +872,11 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
             t = tn;
             t_next = t_after;
         }
+        if (prof) prof_bar += __builtin_amdgcn_s_memtime() - c2;
     }
+    if (prof && lane == 0 && (blockIdx.x == 0 || blockIdx.x == 101 || blockIdx.x == 255))
+        printf("WAXPROF rega D=%d blk %u wave %d tiles %u mfma %llu select %llu barrier %llu total %llu\n", D, (unsigned)blockIdx.x, wave, it,
+               prof_mfma, prof_sel, prof_bar, (unsigned long long)(__builtin_amdgcn_s_memtime() - prof_t0));
     if (late && it > 0) select_tile(t_prev);
     // unclamped counts: a count above seg_slots tells tighten_kernel that survivors were dropped (query -> exact path)
     __syncthreads();
@@ -1368,19 +1471,24 @@ static hipError_t launch_ksplit(const GemmArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
-template <int D, bool GLDS, int AHEAD>
+template <int D, bool GLDS, int AHEAD, bool PROF = false, bool FREE = false>
 static hipError_t launch_rega_impl(const GemmArgs& a, hipStream_t st) {
-    constexpr size_t smem = (size_t)rega_lds_tiles<D>(GLDS) * 64 * (D * 2 + 16) + 3 * 8 * 32 * 4 + 16;  // tiles, thresholds, survivor counters, bounds
+    // tiles, thresholds, survivor counters, bounds, claimed tile indices (+ the two counter triples of the free-running variant)
+    constexpr size_t smem = (size_t)(FREE ? 3 : rega_lds_tiles<D>(GLDS)) * 64 * (D * 2 + 16) + 3 * 8 * 32 * 4 + 16 + (FREE ? 48 : 0);   // FREE: stored[3], read[3], turn[4] behind the claimed tile indices
+    static_assert(smem <= 160 * 1024, "LDS budget of one CU");
     static std::atomic<uint64_t> configured{0};   // per device (ensure_dynamic_lds)
     {
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&batch_gemm_rega_kernel<D, GLDS, AHEAD>), smem, configured);
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&batch_gemm_rega_kernel<D, GLDS, AHEAD, false, PROF, FREE>), smem, configured);
         if (e != hipSuccess) return e;
     }
     uint32_t groups, per_group;
     rega_geometry(a, &groups, &per_group);
-    hipLaunchKernelGGL((batch_gemm_rega_kernel<D, GLDS, AHEAD>), dim3(groups * per_group), dim3(512), smem, st, a, per_group);
+    hipLaunchKernelGGL((batch_gemm_rega_kernel<D, GLDS, AHEAD, false, PROF, FREE>), dim3(groups * per_group), dim3(512), smem, st, a, per_group);
     return hipGetLastError();
 }
+
+// whether the free-running variant (three LDS tiles, no tile barrier) exists for D
+constexpr bool rega_free_dims(int d) { return 3 * 64 * (d * 2 + 16) + 3 * 8 * 32 * 4 + 64 <= 160 * 1024; }
 
 template <int D>
 static hipError_t launch_rega(const GemmArgs& a, hipStream_t st) {
@@ -1396,7 +1504,17 @@ static hipError_t launch_rega(const GemmArgs& a, hipStream_t st) {
         }
         return launch_rega_impl<D, true, AHEAD>(a, st);
     }
+    if constexpr (rega_free_dims(D)) {
+        if (a.use_rega == 4u) {
+            if constexpr (D == 384) {
+                if (a.debug & 1024u) return launch_rega_impl<D, false, AHEAD, true, true>(a, st);   // phase clock, see below
+            }
+            return launch_rega_impl<D, false, AHEAD, false, true>(a, st);
+        }
+    }
     if constexpr (D == 384) {
+        // diagnosis run: per-wave phase clock (see the kernel's main loop)
+        if (a.debug & 1024u) return launch_rega_impl<D, false, AHEAD, true>(a, st);
         // timing experiment (debug bits 8-9 = 1): read-ahead 2 = 224 VGPRs, which leaves room for a 64-VGPR kernel of the
         // neighbouring batch (the finish kernel) beside the two GEMM waves of a SIMD; read-ahead 3 = 232 does not
         if (((a.debug >> 8) & 3u) == 1u) return launch_rega_impl<D, false, 2>(a, st);
