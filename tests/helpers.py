@@ -170,9 +170,23 @@ TIE_TOL = 2e-5     # ids may permute only inside groups whose or
 
 
 def assert_parity(got_ids, got_scores, exp_ids, exp_scores, all_exp_scores=None, ctx=""):
-    """Scores within 1e-5 position by position; ids identical except inside near-tie groups
-    (neighbouring oracle scores closer than 2e-5, including the k-boundary when
-    `all_exp_scores` — oracle scores for k+margin results — is supplied)."""
+    """The parity rule of SURVEY.md §8c, as the GPU tests apply it.
+
+    1. Scores: |got - expected| <= SCORE_TOL (1e-5, the north star's tolerance) position by position — ALWAYS, whatever
+       the ids are. (The engine's f32 distances and the oracle's f64 truth differ by a few 1e-7 on unit-norm data.)
+    2. Ids: identical lists pass. Otherwise the oracle ranking is cut into NEAR-TIE GROUPS: maximal runs of neighbouring
+       oracle scores closer than TIE_TOL (2e-5 = twice the score tolerance: two rows that close can legitimately swap
+       between an f32 and an f64 evaluation). Inside a group the ids may appear in any order; as SETS every group must
+       match exactly.
+    3. The boundary group. `all_exp_scores` carries the oracle's scores for k + margin results, so a run that starts
+       inside the top k and continues PAST rank k is seen as such. For that group the engine may hold a different
+       member of the run than the oracle does (which of several rows within 2e-5 of each other makes the cut is not
+       decidable at the stated tolerance), so set equality cannot be demanded: the rule is that the engine returns as many
+       DISTINCT ids in those positions as the oracle, and rule 1 still pins each of them to the oracle's score at that
+       position within 1e-5 — an id from outside the tied run would fail rule 1. Without `all_exp_scores` the run is
+       only followed to rank k and the boundary group is held to set equality like any other (the strict form; the
+       full-size parity tests pass the margin, the exact-tie tests — duplicates, constant rows — do not need one because
+       the engine's (distance asc, row asc) order is the oracle's parity-mode order there)."""
     got_ids = [int(x) for x in got_ids]
     exp_ids = [int(x) for x in exp_ids]
     assert len(got_ids) == len(exp_ids), f"{ctx}: count {len(got_ids)} != {len(exp_ids)}"

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--dims", type=int, default=384)
     ap.add_argument("--nq", type=int, nargs="+", default=[256])
     ap.add_argument("--topk", type=int, default=10)
+    ap.add_argument("--metric", type=int, default=0, help="0 cosine, 1 dot, 2 l2")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--slab-mb", type=int, nargs="+", default=[64])
     ap.add_argument("--growth", type=int, nargs="+", default=[0], help="slab growth factors to sweep (0 = library default)")
@@ -58,7 +59,7 @@ def main():
     import wax_amd as wax
     from wax_amd import sharded
     lo, hi = sharded.shard_bounds(args.rows, world, rank, align=128)
-    eng = wax.HIPVectorEngine(dimensions=args.dims)
+    eng = wax.HIPVectorEngine(metric=args.metric, dimensions=args.dims)
     eng.reserve(max(hi - lo, 1))
     for r0, x in bench.device_rows(torch, lo, hi, args.dims, dev):
         eng.addBatchDevice(np.arange(r0, r0 + x.shape[0], dtype=np.uint64), x)
