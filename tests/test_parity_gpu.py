@@ -1115,7 +1115,7 @@ def test_filtered_search_equals_filtered_full_ranking(wax, metric, dims, device_
 
 def test_batch_submit_collect_device_pipeline(wax):
     """wax_hip_search_batch_submit_device / _collect_device: several batches in flight on the engine's workspaces give
-    the blocking call's hits bit for bit (different query sets per ticket), fallbacks are re-run at collect, writers are
+    the blocking call's hits bit for bit (different query sets per ticket), uncertified queries are settled at collect, writers are
     refused while the thread holds a batch ticket, a fifth ticket on a four-workspace engine is refused, tickets are
     single-use."""
     import torch
@@ -1139,8 +1139,11 @@ def test_batch_submit_collect_device_pipeline(wax):
         eng.searchBatchSubmitDevice(dqs[0].data_ptr(), nq, k, outs[0].data_ptr(), k, st)
     with pytest.raises(wax.WaxError):                # a writer would wait for this thread's own read lock
         eng.add(10 ** 9, corpus[0])
+    retries0 = eng.getTuning("batch_retries")
     fallbacks = [eng.searchBatchCollectDevice(t) for t in tickets]
-    assert fallbacks[1] >= 1 and fallbacks[0] == 0
+    # the duplicate-run queries cannot be certified by the first finish: they are settled at collect — by the full retry
+    # (all survivors re-scored; since round 3 that is enough for a 64-fold tie) or, failing that, by the exact path
+    assert fallbacks[0] == 0 and fallbacks[1] + (eng.getTuning("batch_retries") - retries0) >= 1
     for i in range(4):
         assert np.array_equal(outs[i].cpu().numpy(), ref[i]), i
     with pytest.raises(wax.WaxError):
