@@ -364,7 +364,16 @@ def secondary_single_query(torch, dev, rows, dims, k, steps, warmup, depth, labe
     nbytes = rows * dims * 4
     grid = eng.getTuning("scan_grid")
     eng.close()
-    rf = scan_roofline(nbytes, kern_ms, launches, elapsed, steps, cal)
+    traffic, traffic_source = None, None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "latest_traffic.json"))).get("single", {})
+        ent = tj.get("configs", {}).get(f"{rows}x{dims}")
+        if ent:
+            traffic = ent["hbm_bytes_per_launch"]
+            traffic_source = "replayed from profiles/latest_traffic.json (" + tj.get("source", "") + "), not measured in this run"
+    except (OSError, ValueError, KeyError):
+        pass
+    rf = scan_roofline(nbytes, kern_ms, launches, elapsed, steps, cal, traffic, traffic_source)
     rf["scan_grid"] = grid
     rf["launches_per_query"] = 1 if (eng_fused_grid(grid)) else 2
     return {
@@ -396,8 +405,27 @@ def batched_roofline(rows, dims, nq, kern_ms, launches):
             traffic_source = "replayed from profiles/latest_traffic.json (" + tj.get("source", "") + "), not measured in this run"
     except (OSError, ValueError, KeyError):
         pass
-    kernel = {768: "wax::batch_gemm_ksplit_kernel", 1024: "wax::batch_gemm_ksplit_kernel", 1536: "wax::batch_gemm_ksplit_kernel"}.get(dims, "wax::batch_gemm_rega_kernel")
+    kernel = ("wax::batch_gemm_ksplit_kernel" if dims == 768 else "wax::batch_gemm_rega_kernel" if dims in (128, 256, 384, 512)
+              else "wax::batch_gemm_kernel")
+    # what the kernel's K loop alone (no HBM stream, no selection) sustains on this part with embedding-like operands: the matrix
+    # clock is power-limited (tools/mfma_probe.hip; DESIGN.md "The matrix roof"). Informational: `peak` stays the nominal figure.
+    sustained = None
+    try:
+        for line in open(os.path.join(ROOT, "profiles", "r03", "q_mfma_k_loop_probe.jsonl")):
+            pj = json.loads(line)
+            if (pj.get("data") == "gaussian embedding" and pj.get("mode") == "reads+mfma" and pj.get("waves_per_simd") == 2
+                    and pj.get("ahead") == 3 and not pj.get("tile_fence")):
+                sustained = pj["tflops_bf16"]
+    except (OSError, ValueError, KeyError):
+        pass
+    extra = {}
+    if sustained:
+        extra = {"mfma_sustained_tflops_k_loop_alone": sustained,
+                 "mfma_frac_of_sustained": flops / (kern_ms * 1e-3) / 1e12 / sustained,
+                 "mfma_sustained_source": "profiles/r03/q_mfma_k_loop_probe.jsonl (tools/mfma_probe.hip: the kernel's K loop alone on all 256 CUs, "
+                                          "N(0, 1/384) bf16 operands, 2 waves per SIMD) — committed measurement, not taken in this run"}
     return flops, max(t_hbm, t_mfma), {
+        **extra,
         "bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
         "kernel": kernel, "kernel_avg_ms": kern_ms, "kernel_launches_timed": launches,
         "algorithmic_bytes_per_launch": nbytes, "algorithmic_flops_per_launch": flops,

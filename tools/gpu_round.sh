@@ -188,13 +188,28 @@ PYEOF
       find "$OUT/prof_gemmpmc" -name "*.csv" -size +1M -delete 2>/dev/null ;;
     gemmfetch)
       # HBM bytes the filtering GEMMs actually fetch (FETCH_SIZE, KiB, x2 on gfx950) against the mirror's size: re-reads by the query groups
-      for cfg in "384 1000000 256" "384 1000000 1024" "768 1250000 1024"; do
+      for cfg in "384 1000000 256" "384 1000000 1024" "768 1250000 1024" "768 10000000 1024"; do
         set -- $cfg
         (cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/prof_fetch_$1_$3" -o f -- \
             python "$R/tools/batch_bench.py" --dims $1 --rows $2 --nq $3 --reps 2 > "$OUT/gemmfetch_$1_$3.log" 2>&1); rc=$?
         python tools/pmc_summary.py "$OUT/prof_fetch_$1_$3" > "$OUT/gemmfetch_$1_$3.json" 2>> "$OUT/gemmfetch_$1_$3.log"
         rm -rf "$OUT/prof_fetch_$1_$3"
       done ;;
+    profchain)
+      # the headline with every scan of the timed region chained and timed (one kernel at a time): the run whose rocprofv3 average
+      # the per-launch `roofline.frac` of the default command (calibration pass) is compared with
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_chain" -o bench -- \
+          python "$R/bench.py" --gpus 1 --chain-timed-region --no-secondary --no-cpu-baseline > "$OUT/profchain_bench.json" 2> "$OUT/profchain.err"); rc=$?
+      find "$OUT/prof_chain" -name "*kernel_stats.csv" -exec cp {} "$OUT/chained_kernel_stats.csv" \; 2>/dev/null
+      find "$OUT/prof_chain" -name "*kernel_trace.csv" -delete 2>/dev/null ;;
+    pmc1m)
+      (cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/prof_pmc1m" -o pmc -- \
+          python "$R/bench.py" --gpus 1 --rows 1000000 --steps 40 --warmup 4 --no-cpu-baseline --no-secondary > "$OUT/pmc1m_bench.json" 2> "$OUT/pmc1m.err"); rc=$?
+      python tools/pmc_summary.py "$OUT/prof_pmc1m" > "$OUT/pmc1m_summary.json" 2>> "$OUT/pmc1m.err"
+      find "$OUT/prof_pmc1m" -name "*.csv" -size +2M -delete 2>/dev/null ;;
+    l2time)
+      timeout 300 python tools/batch_bench.py --metric 2 --nq 256 --reps 10 --onepass 0 1 0 1 > "$OUT/l2_onepass_ab.log" 2>&1; rc=$?
+      timeout 300 python tools/batch_bench.py --dims 1024 --nq 256 --reps 10 --onepass 0 1 0 1 > "$OUT/d1024_onepass_ab.log" 2>&1 ;;
     gemmprobeprof)
       (cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d "$OUT/prof_probe" -o p -- python "$R/tools/gemm_probe.py" > "$OUT/gemm_probe_prof.log" 2>&1); rc=$?
       find "$OUT/prof_probe" -name "*kernel_trace.csv" -exec sh -c 'head -1 "$1" > "$2"; grep "gemm" "$1" >> "$2"' _ {} "$OUT/probe_gemm_trace.csv" \; 2>/dev/null

@@ -297,7 +297,7 @@ struct BatchCtx {
     uint64_t hits_cap = 0;
     uint64_t cert_cap = 0;
     wax_hip_hit* h_hits = nullptr;       // pinned [hits_cap]
-    // wide retry of uncertified queries (single-block one-pass batches): the finish arguments of the last block, the failed
+    // full retry of uncertified queries (single-block one-pass batches): the finish arguments of the last block, the failed
     // queries' numbers (pinned + device)
     FinishArgs last_finish{};
     int last_metric = 0;
@@ -414,7 +414,7 @@ struct wax_hip_engine {
     std::atomic<int64_t> batch_onepass{1};        // 0 = always the slab pipeline
     std::atomic<int64_t> batch_onepass_tiles{1024};   // smallest store (in GEMM tiles) the one-pass pipeline takes
     std::atomic<int64_t> batch_survivors{3};      // one-pass pipeline: expected survivors per query = this x k'
-    std::atomic<int64_t> batch_retry{1};          // one-pass pipeline: uncertified queries get a wide (k' = 960) finish before the exact path
+    std::atomic<int64_t> batch_retry{1};          // one-pass pipeline: uncertified queries get a full retry (ALL their survivors re-scored) before the exact path
     std::atomic<int64_t> batch_multi{1};          // exact path of a batch: 1 = uncertified queries share passes over the f32 store (multiscan.hip), 0 = one scan each
     std::atomic<uint64_t> st_multi_passes{0}, st_multi_queries{0};
     std::atomic<uint64_t> st_batch_retries{0};

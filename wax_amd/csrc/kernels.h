@@ -251,8 +251,9 @@ struct FinishArgs {
     int64_t* exact;                                      // [nq][kp] scratch (large-kp path)
     wax_hip_hit* out; uint32_t out_stride;               // [nq][out_stride], k written per query
     uint32_t* certified;                                 // [nq]
-    // large-kp path only: non-null = process queries qlist[0 .. nq) (the "wide retry" of uncertified queries); every array
-    // above stays indexed by the query's own number
+    // large-kp path only: non-null = process queries qlist[0 .. nq); every array above stays indexed by the query's own number.
+    // (Round 2's "wide retry" used it; the full retry of round 3 has its own kernels — CompactArgs / FullRetryArgs — and the
+    // engine leaves this null.)
     const uint32_t* qlist;
 };
 hipError_t launch_batch_finish(const FinishArgs& a, int metric, hipStream_t stream);
