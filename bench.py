@@ -359,8 +359,10 @@ def secondary_single_query(torch, dev, rows, dims, k, steps, warmup, depth, labe
     eng.setTuning("streams", 2)
     eng.setTuning("slots", max(depth, 2))
     apply_tunes(eng)
-    elapsed, _, kern_ms, launches, cal = measure_single_query(
+    elapsed, last, kern_ms, launches, cal = measure_single_query(
         eng, lambda q: eng.submit(q, k), lambda t: eng.collect(t, k), queries, warmup, steps, depth, lambda: _bracket(torch))
+    import hashlib
+    checksum = hashlib.sha256(np.asarray(last[0], dtype=np.uint64).tobytes() + np.asarray(last[1], dtype=np.float32).tobytes()).hexdigest()[:16]
     nbytes = rows * dims * 4
     grid = eng.getTuning("scan_grid")
     eng.close()
@@ -379,7 +381,48 @@ def secondary_single_query(torch, dev, rows, dims, k, steps, warmup, depth, labe
     return {
         "config": f"{rows} x {dims} f32 cosine top-{k}, one query per step, 1 GPU ({label})",
         "value": steps / elapsed, "unit": "queries/s", "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
-        "dtype": "f32", "roofline": rf,
+        "dtype": "f32", "last_result_checksum": checksum, "roofline": rf,
+    }
+
+
+def sharded_single_query(torch, dist, args, rank, world, local_rank, use_rccl, rows, dims, k, steps, warmup, label):
+    """The N-matrix points (N in {10K, 1M} x 384) at world > 1: the headline's sharded single-query path — every rank scans
+    its row shard, per-shard top-k all-gathered (RCCL) and merged per query — at another corpus size. Same bracket as the
+    headline (barrier + synchronize on both sides, max over ranks). Called by EVERY rank (collectives inside)."""
+    from wax_amd import sharded
+    dev = torch.device("cuda", torch.cuda.current_device())
+    lo, hi = sharded.shard_bounds(rows, world, rank, align=64)
+    eng = _load_engine(torch, dev, max(hi - lo, 0), dims, lo=lo)
+    eng.setRowBase(lo)
+    apply_tunes(eng)
+    searcher = sharded.ShardedSearcher(eng, rank, world, k, depth=args.depth, n_streams=2, host_merge=args.host_merge,
+                                       exchange="rccl" if use_rccl else "host")
+    queries = unit_queries(warmup + steps, dims)
+
+    def barrier():
+        torch.cuda.synchronize()
+        dist.barrier(device_ids=[local_rank]) if use_rccl else dist.barrier()
+        torch.cuda.synchronize()
+
+    def submit(q):
+        searcher.submit(q)
+
+    elapsed, last, kern_ms, launches, cal = measure_single_query(eng, submit, lambda _: searcher.collect(), queries, warmup, steps,
+                                                                 args.depth, barrier)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if use_rccl else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    import hashlib
+    checksum = hashlib.sha256(np.asarray(last[0], dtype=np.uint64).tobytes() + np.asarray(last[1], dtype=np.float32).tobytes()).hexdigest()[:16]
+    grid = eng.getTuning("scan_grid")
+    eng.close()
+    rf = scan_roofline((hi - lo) * dims * 4, kern_ms, launches, elapsed, steps, cal)
+    rf["scan_grid"] = grid
+    return {
+        "config": f"{rows} x {dims} f32 cosine top-{k}, one query per step, row-sharded over {world} GPUs ({label})",
+        "value": steps / elapsed, "unit": "queries/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3, "dtype": "f32", "rows_per_gpu": hi - lo, "last_result_checksum": checksum,
+        "roofline": rf,
     }
 
 
@@ -887,13 +930,27 @@ def main():
             for x in sec:
                 if iid and x.get("corpus") in ("clustered", "detembed", "dups") and "error" not in x and x.get("queries_per_step") == 256:
                     x["ms_per_step_vs_iid_config3"] = x["ms_per_step"] / iid["ms_per_step"]
-        elif args.secondary == "all" or "c5" in want:
-            try:
-                r = config5_sharded(torch, dist, args, rank, world, in_library, use_rccl)
-                r["name"] = "c5"
-                sec.append(r)
-            except Exception as ex:  # noqa: BLE001
-                sec.append({"name": "c5", "error": f"{type(ex).__name__}: {ex}"})
+        else:
+            # N > 1: the rest of the north star's N matrix on the same sharded path (torchrun shape), then config 5
+            if world > 1:
+                for name, rows_, steps_, warm_, label in (
+                        ("s1m", 1_000_000, max(args.steps, 100), max(args.warmup, 10), "N matrix: 1M rows; BASELINE config 2's corpus over the node"),
+                        ("s10k", 10_000, max(args.steps, 2000), max(args.warmup, 100), "N matrix: 10K rows — exchange-latency-bound")):
+                    if args.secondary != "all" and name not in want:
+                        continue
+                    try:
+                        r = sharded_single_query(torch, dist, args, rank, world, local_rank, use_rccl, rows_, 384, k, steps_, warm_, label)
+                        r["name"] = name
+                        sec.append(r)
+                    except Exception as ex:  # noqa: BLE001
+                        sec.append({"name": name, "error": f"{type(ex).__name__}: {ex}"})
+            if args.secondary == "all" or "c5" in want:
+                try:
+                    r = config5_sharded(torch, dist, args, rank, world, in_library, use_rccl)
+                    r["name"] = "c5"
+                    sec.append(r)
+                except Exception as ex:  # noqa: BLE001
+                    sec.append({"name": "c5", "error": f"{type(ex).__name__}: {ex}"})
         if out is not None:
             out["secondary"] = sec
     if rank == 0:

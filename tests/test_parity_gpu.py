@@ -867,6 +867,12 @@ def test_bench_contract_and_shard_invariance(wax, tmp_path):
     # config 5 at N > 1, both launch shapes: ranks + all-gather, and one process on the sharded handle — same hits as one engine
     for run, shape in ((two, "ranks"), (three, "ranks"), (lib3, "handle")):
         c5 = run["secondary"]
+        if shape == "ranks":
+            # the rest of the N matrix (1M and 10K rows) on the sharded single-query path: same last answer as one engine
+            assert [x["name"] for x in c5] == ["s1m", "s10k", "c5"] and all("error" not in x for x in c5), c5
+            for x, ref in ((c5[0], sec[1]), (c5[1], sec[0])):
+                assert x["n_gpus"] == run["n_gpus"] and x["value"] > 0 and x["last_result_checksum"] == ref["last_result_checksum"], (x, ref)
+            c5 = c5[2:]
         assert len(c5) == 1 and c5[0]["name"] == "c5" and "error" not in c5[0], c5
         assert c5[0]["n_gpus"] == run["n_gpus"] and c5[0]["queries_per_step"] == 1024 and c5[0]["value"] > 0
         assert c5[0]["last_result_checksum"] == c5_one, (shape, run["n_gpus"])

@@ -195,6 +195,15 @@ PYEOF
         python tools/pmc_summary.py "$OUT/prof_fetch_$1_$3" > "$OUT/gemmfetch_$1_$3.json" 2>> "$OUT/gemmfetch_$1_$3.log"
         rm -rf "$OUT/prof_fetch_$1_$3"
       done ;;
+    profsplit)
+      # the GEMM rows of rocprofv3 --stats, one workload per run (the default command mixes five GEMM workloads in one row)
+      for w in b1m_q256 b1m_q1024 c5_shard c5_full clustered_k100; do
+        (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_split_$w" -o bench -- \
+            python "$R/bench.py" --gpus 1 --rows 1000000 --steps 20 --warmup 4 --no-cpu-baseline --secondary $w > "$OUT/profsplit_$w.json" 2> "$OUT/profsplit_$w.err"); rc=$?
+        f=$(find "$OUT/prof_split_$w" -name "*kernel_stats.csv" | head -1)
+        [ -n "$f" ] && { head -1 "$f"; grep "wax::" "$f"; } > "$OUT/kernel_stats_$w.csv"
+        rm -rf "$OUT/prof_split_$w"
+      done ;;
     profchain)
       # the headline with every scan of the timed region chained and timed (one kernel at a time): the run whose rocprofv3 average
       # the per-launch `roofline.frac` of the default command (calibration pass) is compared with
