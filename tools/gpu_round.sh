@@ -190,10 +190,10 @@ PYEOF
       # HBM bytes the filtering GEMMs actually fetch (FETCH_SIZE, KiB, x2 on gfx950) against the mirror's size: re-reads by the query groups
       for cfg in "384 1000000 256" "384 1000000 1024" "768 1250000 1024" "768 10000000 1024"; do
         set -- $cfg
-        (cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/prof_fetch_$1_$3" -o f -- \
-            python "$R/tools/batch_bench.py" --dims $1 --rows $2 --nq $3 --reps 2 > "$OUT/gemmfetch_$1_$3.log" 2>&1); rc=$?
-        python tools/pmc_summary.py "$OUT/prof_fetch_$1_$3" > "$OUT/gemmfetch_$1_$3.json" 2>> "$OUT/gemmfetch_$1_$3.log"
-        rm -rf "$OUT/prof_fetch_$1_$3"
+        (cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/prof_fetch_$1_$2_$3" -o f -- \
+            python "$R/tools/batch_bench.py" --dims $1 --rows $2 --nq $3 --reps 2 > "$OUT/gemmfetch_$1_$2_$3.log" 2>&1); rc=$?
+        python tools/pmc_summary.py "$OUT/prof_fetch_$1_$2_$3" > "$OUT/gemmfetch_$1_$2_$3.json" 2>> "$OUT/gemmfetch_$1_$2_$3.log"
+        rm -rf "$OUT/prof_fetch_$1_$2_$3"
       done ;;
     profsplit)
       # the GEMM rows of rocprofv3 --stats, one workload per run (the default command mixes five GEMM workloads in one row)
