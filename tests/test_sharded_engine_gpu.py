@@ -281,6 +281,56 @@ def test_sharded_batched_device_resident_entry_points(wax, shards):
     empty.close()
 
 
+@pytest.mark.parametrize("shards", [2, 3])
+def test_sharded_batch_resends_parts_rewritten_at_collect(wax, shards):
+    """A shard's [nq][k] part goes to the first device right behind that shard's finish kernel; queries the certificate cannot
+    prove are settled LATER, at collect (full retry of all survivors, or the exact path), rewriting rows of the part. The handle
+    must send such a part again — with retries alone (no exact-path fallback on that shard) as much as with fallbacks. Corpus:
+    200 near-duplicates (2e-4 apart: bf16 cannot order them, so the k' candidates of the first finish miss true neighbours and the
+    rows written before the retry are WRONG) in the first shard, a 3 000-fold run of exact duplicates in the last. Both are
+    settled by the full retry; with "batch_retry" = 0 both go to the exact path."""
+    import torch
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    n, dims, nq, k = 240_000, 384, 256, 10
+    rows = torch.nn.functional.normalize(torch.randn((n, dims), device=dev, generator=torch.Generator(device=dev).manual_seed(5)), dim=1).contiguous()
+    g = torch.Generator(device=dev).manual_seed(6)
+    rows[1000:1200] = torch.nn.functional.normalize(rows[999] + 2e-4 * torch.randn((200, dims), device=dev, generator=g), dim=1)   # first shard: full retry
+    rows[200_000:203_000] = rows[199_999]  # last shard: a 3 000-fold exact tie
+    ids = np.arange(n, dtype=np.uint64) + 7
+    one, many = pair(wax, 0, dims, shards)
+    for eng in (one, many):
+        eng.reserve(n)
+        eng.addBatchDevice(ids, rows)
+    queries = oracle.gaussian_unit_queries(nq, dims, seed=77)
+    queries[:6] = rows[999].cpu().numpy()
+    queries[6:10] = rows[199_999].cpu().numpy()
+    dq = torch.from_numpy(queries).to(dev)
+    a = torch.empty((nq, k, 2), dtype=torch.int64, device=dev)
+    b = torch.empty((nq, k, 2), dtype=torch.int64, device=dev)
+    one.searchBatchHitsDevice(dq.data_ptr(), nq, k, a.data_ptr(), k, stream)
+    r0, f0 = many.getTuning("batch_retries"), many.getTuning("batch_fallbacks")
+    many.searchBatchHitsDevice(dq.data_ptr(), nq, k, b.data_ptr(), k, stream)
+    assert many.getTuning("batch_retries") > r0 and many.getTuning("batch_fallbacks") == f0    # settled by full retries alone
+    assert np.array_equal(a.cpu().numpy(), b.cpu().numpy())
+    many.setTuning("batch_retry", 0)                                                            # ... and by the exact path alone
+    b.zero_()
+    many.searchBatchHitsDevice(dq.data_ptr(), nq, k, b.data_ptr(), k, stream)
+    assert many.getTuning("batch_fallbacks") > f0 and np.array_equal(a.cpu().numpy(), b.cpu().numpy())
+    many.setTuning("batch_retry", 1)
+    for i in (0, 7, 100):
+        s_ids, _ = one.searchArrays(queries[i], k)
+        assert np.array_equal(b.cpu().numpy()[i, :, 1].view(np.uint64), s_ids)
+    # ticketed form, two in flight
+    outs = [torch.empty((nq, k, 2), dtype=torch.int64, device=dev) for _ in range(2)]
+    ts = [many.searchBatchSubmitDevice(dq.data_ptr(), nq, k, outs[i].data_ptr(), k, stream) for i in range(2)]
+    for t in ts:
+        many.searchBatchCollectDevice(t)
+    for o in outs:
+        assert np.array_equal(o.cpu().numpy(), a.cpu().numpy())
+    one.close(), many.close()
+
+
 def test_sharded_submit_beyond_the_slot_pool_and_concurrent_filtered_search(wax):
     """(1) A thread that pipelines more sharded submits than the handle's soft slot cap (8) without collecting gets fresh
     slots instead of waiting for itself while holding the read lock (round-2 advisor finding). (2) Filtered search visits

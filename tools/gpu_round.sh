@@ -204,6 +204,9 @@ PYEOF
         [ -n "$f" ] && { head -1 "$f"; grep "wax::" "$f"; } > "$OUT/kernel_stats_$w.csv"
         rm -rf "$OUT/prof_split_$w"
       done ;;
+    shardtests)
+      timeout 900 python -m pytest tests/test_sharded_engine_gpu.py tests/test_parity_gpu.py -q -m gpu -x -p no:cacheprovider --timeout 400 \
+          -k "sharded or bench_contract or submit_collect_device" > "$OUT/pytest_shard.log" 2>&1; rc=$? ;;
     profchain)
       # the headline with every scan of the timed region chained and timed (one kernel at a time): the run whose rocprofv3 average
       # the per-launch `roofline.frac` of the default command (calibration pass) is compared with

@@ -1419,8 +1419,11 @@ int exact_scan_queries(wax_hip_engine* e, BatchCtx* c, const float* d_queries, c
 
 // Wait for a submitted batch; queries whose certificate failed (ties, clustered data, an overflowed list) are answered
 // by the exact path in place — never an approximation.
+// out_rewritten: queries whose rows of d_out were written HERE (full retries + exact path), i.e. after whatever the caller
+// enqueued behind the submit — the sharded handle re-sends a shard's part when it is not 0.
 int batch_finish_device_locked(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32_t nq, int k_eff,
-                               wax_hip_hit* d_out, uint32_t out_stride, uint32_t* out_fallbacks) {
+                               wax_hip_hit* d_out, uint32_t out_stride, uint32_t* out_fallbacks, uint32_t* out_rewritten = nullptr) {
+    uint32_t retried = 0;
     hipStream_t st = c->stream;
     const uint32_t D = e->dims;
     HIP_TRY(hipStreamSynchronize(st), WAX_HIP_ERR_INTERNAL, "batch search failed on device");
@@ -1481,6 +1484,7 @@ int batch_finish_device_locked(wax_hip_engine* e, BatchCtx* c, const float* d_qu
             HIP_TRY(launch_full_retry_select(fr, st), WAX_HIP_ERR_INTERNAL, "full-retry select launch");
             HIP_TRY(hipStreamSynchronize(st), WAX_HIP_ERR_INTERNAL, "full retry failed on device");   // the pinned list is reused; flags are read below
             e->st_batch_retries += m;
+            retried += m;
         }
     }
     c->last_finish_valid = false;
@@ -1493,6 +1497,7 @@ int batch_finish_device_locked(wax_hip_engine* e, BatchCtx* c, const float* d_qu
     if (fallbacks > 0) rc = exact_scan_queries(e, c, d_queries, failed.data(), c->h_qnorm, fallbacks, k_eff, d_out, out_stride);
     e->st_batch_fallbacks += fallbacks;
     if (out_fallbacks) *out_fallbacks = fallbacks;
+    if (out_rewritten) *out_rewritten = retried + fallbacks;
     return rc;
 }
 
@@ -2254,8 +2259,10 @@ int wax_hip_search_batch_submit_device(wax_hip_engine* e, const float* d_queries
     return batch_device_impl(e, d_queries, nq, dims, top_k, d_out_hits, out_stride, stream, out_ticket, "wax_hip_search_batch_submit_device");
 }
 
-int wax_hip_search_batch_collect_device(wax_hip_engine* e, uint64_t ticket, uint32_t* out_fallbacks) {
+// out_rewritten (internal; see batch_finish_device_locked): rows of the batch's output written during this call
+int batch_collect_device_impl(wax_hip_engine* e, uint64_t ticket, uint32_t* out_fallbacks, uint32_t* out_rewritten) {
     if (out_fallbacks) *out_fallbacks = 0;
+    if (out_rewritten) *out_rewritten = 0;
     if (!e) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "engine is null");
     if (e->sh) return sh_batch_collect_device(e, ticket, out_fallbacks);
     wax_hip_engine::BatchTicket t;
@@ -2268,12 +2275,16 @@ int wax_hip_search_batch_collect_device(wax_hip_engine* e, uint64_t ticket, uint
     }
     if (!t.c) return WAX_HIP_OK;   // answered at submit time
     DeviceGuard g(e->device);
-    const int rc = batch_finish_device_locked(e, t.c, t.d_queries, t.nq, t.k_eff, t.d_out, t.out_stride, out_fallbacks);
+    const int rc = batch_finish_device_locked(e, t.c, t.d_queries, t.nq, t.k_eff, t.d_out, t.out_stride, out_fallbacks, out_rewritten);
     if (rc != WAX_HIP_OK) (void)hipStreamSynchronize(t.c->stream);
     release_bctx(e, t.c);
     note_collect_id(e, t.owner);
     e->lock.unlock_shared();
     return rc;
+}
+
+int wax_hip_search_batch_collect_device(wax_hip_engine* e, uint64_t ticket, uint32_t* out_fallbacks) {
+    return batch_collect_device_impl(e, ticket, out_fallbacks, nullptr);
 }
 
 // ---- sharded search -------------------------------------------------------
