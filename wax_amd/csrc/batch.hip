@@ -1999,7 +1999,9 @@ __global__ __launch_bounds__(256) void batch_prep_kernel(PrepArgs a) {
         a.q_norm[q] = c;
         if (a.q_norm_host) a.q_norm_host[q] = c;
         a.q_n2[q] = acc;
-        // certificate bound: engine.hip batch_eps, same formula
+        // certificate bound: |approx distance - exact distance| from rounding both operands to bf16 (unit roundoff 2^-9 each =>
+        // 2^-8 (1 + 2^-10) per product, Cauchy-Schwarz over the row) plus f32 accumulation (D * 2^-24) and epilogue rounding;
+        // dot scales with ||q|| max||v||, L2 (||q||^2 + ||v||^2 - 2 q.v) carries the factor 2 and the norms' own rounding
         const double u = 0.00390625 * (1.0 + 1.0 / 1024.0) + (double)D * 5.97e-8 + 1e-6;
         float eps;
         if (a.metric == BM_COS) eps = (float)(u * 1.001 + 1e-6);

@@ -1087,19 +1087,6 @@ int bctx_reserve_host(wax_hip_engine* e, BatchCtx* c, uint64_t nq, uint64_t hits
     return WAX_HIP_OK;
 }
 
-// Rigorous bound on |approx distance - exact distance| from rounding both operands to bf16
-// (unit roundoff 2^-9 each => 2^-8 (1 + 2^-10) per product, Cauchy-Schwarz over the row) plus
-// f32 accumulation (dims * 2^-24) and epilogue rounding. The device evaluates the same formula (batch_prep_kernel);
-// L2 (slab pipeline only) adds its own term here.
-float batch_eps(uint8_t metric, float q_norm, float max_norm, uint32_t dims) {
-    const double u = 0.00390625 * (1.0 + 1.0 / 1024.0) + (double)dims * 5.97e-8 + 1e-6;
-    if (metric == WAX_HIP_METRIC_COSINE) return (float)(u * 1.001 + 1e-6);
-    const double qv = (double)q_norm * (double)max_norm;
-    if (metric == WAX_HIP_METRIC_DOT) return (float)(u * qv * 1.001 + 1e-6 * (1.0 + qv));
-    const double s = (double)q_norm * q_norm + (double)max_norm * max_norm;
-    return (float)(2.0 * u * qv * 1.001 + 4e-6 * (1.0 + s));
-}
-
 int batch_kp(int k_eff, int kp_max) {
     int kp = 2 * k_eff + 32;
     if (kp < 64) kp = 64;
@@ -2640,8 +2627,6 @@ int wax_hip_deserialize(wax_hip_engine* e, const uint8_t* data, size_t len) {
     if (e->sh) return sh_deserialize(e, data, len);
     uint64_t n = 0, vec_len = 0, id_len = 0;
     { const int vrc = validate_mv2v_segment(e->metric, e->dims, data, len, &n, &vec_len, &id_len); if (vrc != WAX_HIP_OK) return vrc; }
-    const uint32_t dims = e->dims;
-
     REFUSE_IF_HOLDING(e);
     DeviceGuard g(e->device);
     WriteGuard w(e->lock);  // withWriteLock (:717)
