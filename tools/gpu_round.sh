@@ -207,6 +207,16 @@ PYEOF
     shardtests)
       timeout 900 python -m pytest tests/test_sharded_engine_gpu.py tests/test_parity_gpu.py -q -m gpu -x -p no:cacheprovider --timeout 400 \
           -k "sharded or bench_contract or submit_collect_device" > "$OUT/pytest_shard.log" 2>&1; rc=$? ;;
+    probepmc)
+      # the K-loop probe under counters: how busy the matrix pipe is, and at what clock the chip runs meanwhile
+      hipcc --offload-arch=gfx950 -O3 -std=c++17 -w tools/mfma_probe.hip -o /tmp/mfma_probe > "$OUT/mfma_probe.err" 2>&1
+      (cd /tmp && timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 --kernel-trace --output-format csv \
+          -d "$OUT/prof_probe_pmc" -o p -- /tmp/mfma_probe > "$OUT/probe_under_pmc.jsonl" 2> "$OUT/probepmc.err"); rc=$?
+      f=$(find "$OUT/prof_probe_pmc" -name "*counter_collection.csv" | head -1)
+      [ -n "$f" ] && cp "$f" "$OUT/probe_counter_collection.csv"
+      f=$(find "$OUT/prof_probe_pmc" -name "*kernel_trace.csv" | head -1)
+      [ -n "$f" ] && cp "$f" "$OUT/probe_kernel_trace.csv"
+      rm -rf "$OUT/prof_probe_pmc" ;;
     profchain)
       # the headline with every scan of the timed region chained and timed (one kernel at a time): the run whose rocprofv3 average
       # the per-launch `roofline.frac` of the default command (calibration pass) is compared with
