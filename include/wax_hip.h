@@ -348,7 +348,8 @@ int wax_hip_stats(wax_hip_engine* e, wax_hip_stats_t* out);
  * "batch_fallbacks", "onepass_queries", "batch_max_k", "batch_retries", "batch_multi_passes", "batch_multi_queries", "batch_multi_group" /
  * "batch_multi_group_big" (queries per shared exact pass for k <= 60 / k <= 192), "filter_device_searches". Sharded handles: every key above is forwarded to all shards; plus
  * "exchange" (0 peer copies + merge on the first device, 1 RCCL all-gather per query) and the get-only "shards", "block_rows",
- * "rebalances", "rccl_collectives". */
+ * "rebalances", "rccl_collectives", "parallel_collects" (batched collects whose per-shard exactness ladders ran side by side on the
+ * handle's worker threads: chosen when the previous batch had two or more shards settle queries on the host side). */
 int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value);
 int64_t wax_hip_get_tuning(wax_hip_engine* e, const char* key);
 /* Times `iters` back-to-back launches of ONLY the scan kernel for `query`

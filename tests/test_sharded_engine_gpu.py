@@ -328,6 +328,9 @@ def test_sharded_batch_resends_parts_rewritten_at_collect(wax, shards):
         many.searchBatchCollectDevice(t)
     for o in outs:
         assert np.array_equal(o.cpu().numpy(), a.cpu().numpy())
+    # two shards settled queries on the host side in the first batch, so the later collects ran the per-shard ladders side by
+    # side on the handle's persistent workers
+    assert many.getTuning("parallel_collects") >= 2
     one.close(), many.close()
 
 
