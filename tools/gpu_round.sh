@@ -77,6 +77,8 @@ for s in $STAGES; do
       timeout 900 python tools/sharded_handle_bench.py --parts ${WAX_PARTS:-A,B,C} > "$OUT/sharded_handle_bench.jsonl" 2> "$OUT/sharded_handle_bench.err"; rc=$? ;;
     fuzz)
       timeout 400 python tools/fuzz_batch.py --seconds ${WAX_FUZZ_S:-120} --seed 7 > "$OUT/fuzz_batch.jsonl" 2> "$OUT/fuzz_batch.err"; rc=$? ;;
+    fuzzsharded)
+      timeout 500 python tools/fuzz_batch.py --seconds ${WAX_FUZZ_S:-180} --seed ${WAX_FUZZ_SEED:-11} --sharded 0.5 > "$OUT/fuzz_sharded.jsonl" 2> "$OUT/fuzz_sharded.err"; rc=$? ;;
     tests_x)
       timeout 600 python -m pytest tests -m gpu -x -q -p no:cacheprovider --timeout 150 > "$OUT/pytest_gpu_x.log" 2>&1; rc=$? ;;
     filtered)
