@@ -555,7 +555,7 @@ def secondary_batched(torch, dev, rows, dims, nq, k, steps, warmup, label, row_b
         "end_to_end_frac_of_roof": floor_s / (el / steps),
         "certificate_fallbacks": int(eng.getTuning("batch_fallbacks") - fb0),
         "certificate_fallbacks_per_step": (eng.getTuning("batch_fallbacks") - fb0) / (steps + 0.0),
-        "wide_retries": int(eng.getTuning("batch_retries") - rt0),
+        "full_retries": int(eng.getTuning("batch_retries") - rt0),
         "shared_exact_passes": int(eng.getTuning("batch_multi_passes") - mp0),
         "pipeline": "one-pass" if eng.getTuning("onepass_queries") > 0 else "slab",
         "last_result_checksum": _hits_checksum(outs[(steps - 1) % depth]),

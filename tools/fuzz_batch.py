@@ -104,4 +104,4 @@ while time.time() < t_end:
                       "fallbacks": eng.getTuning("batch_fallbacks") - f0, "retries": eng.getTuning("batch_retries") - r0}), flush=True)
     eng.close()
     del x, q
-print(json.dumps({"trials": trials, "sharded_trials": sharded_trials, "answers_checked": checked, "fallbacks": fallbacks, "wide_retries": retries, "onepass_queries": onepass_q, "ok": True}))
+print(json.dumps({"trials": trials, "sharded_trials": sharded_trials, "answers_checked": checked, "fallbacks": fallbacks, "full_retries": retries, "onepass_queries": onepass_q, "ok": True}))
