@@ -219,6 +219,20 @@ PYEOF
       f=$(find "$OUT/prof_probe_pmc" -name "*kernel_trace.csv" | head -1)
       [ -n "$f" ] && cp "$f" "$OUT/probe_kernel_trace.csv"
       rm -rf "$OUT/prof_probe_pmc" ;;
+    gridsweep)
+      # scan grid / pipeline depth under the overlapped product mode (value and pipeline_frac are what moves; frac is per launch)
+      for g in 256 384 512 768 1024; do
+        timeout 300 python bench.py --gpus 1 --no-cpu-baseline --no-secondary --steps 150 --warmup 20 --tune grid_blocks=$g >> "$OUT/gridsweep_10m.jsonl" 2>> "$OUT/gridsweep.err"
+        timeout 300 python bench.py --gpus 1 --rows 1000000 --no-cpu-baseline --no-secondary --steps 600 --warmup 50 --tune grid_blocks=$g >> "$OUT/gridsweep_1m.jsonl" 2>> "$OUT/gridsweep.err"
+      done
+      for d in 2 3 6 8; do
+        timeout 300 python bench.py --gpus 1 --rows 1000000 --no-cpu-baseline --no-secondary --steps 600 --warmup 50 --depth $d >> "$OUT/depthsweep_1m.jsonl" 2>> "$OUT/gridsweep.err"
+      done; rc=$? ;;
+    variantsuite)
+      for m in 4 3 2; do
+        WAX_HIP_BATCH_REGA=$m timeout 900 python -m pytest tests -q -m gpu -x -p no:cacheprovider --timeout 400 -k "batch or onepass or sharded or adversarial or falls_back" > "$OUT/pytest_rega$m.log" 2>&1; rc=$?
+        tail -2 "$OUT/pytest_rega$m.log"
+      done ;;
     profchain)
       # the headline with every scan of the timed region chained and timed (one kernel at a time): the run whose rocprofv3 average
       # the per-launch `roofline.frac` of the default command (calibration pass) is compared with
