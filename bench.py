@@ -46,7 +46,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md: ~2.
 CORPUS_SEED = 20260220
 QUERY_SEED = 7
 GRANULE = 65536
-SECONDARY_N1 = ["s10k", "s1m", "b1m_q256", "b1m_q1024", "c5_shard", "c5_full", "clustered_k10", "clustered_k100", "dups17", "detembed"]
+SECONDARY_N1 = ["s10k", "s1m", "s1250k", "b1m_q256", "b1m_q1024", "c5_shard", "c5_full", "clustered_k10", "clustered_k100", "dups17", "detembed"]
 DUP_ROWS, DUP_AT, DUP_OF, DUP_QUERIES = 2048, 500_000, 7, 44    # the "dups17" corpus: 2048 copies of row 7; 44 of 256 queries (17 %) aim at it
 
 
@@ -70,7 +70,7 @@ def parse_args():
                    help="experiments: wax_hip_set_tuning(KEY, VALUE) on every engine the bench creates (repeatable)")
     p.add_argument("--no-secondary", action="store_true", help="skip the secondary configurations")
     p.add_argument("--secondary", default="all",
-                   help="comma-separated subset of the secondary configurations (N=1: " + ",".join(SECONDARY_N1) + "; N>1: c5); default all")
+                   help="comma-separated subset of the secondary configurations (N=1: " + ",".join(SECONDARY_N1) + "; N>1: s1m,s10k,c5); default all")
     p.add_argument("--c5-rows", type=int, default=10_000_000, help="rows of the config-5 corpus (tests shrink it)")
     p.add_argument("--chain-timed-region", action="store_true",
                    help="time the kernels INSIDE the timed region (scans chained, as in rounds 1-2): the run a rocprofv3 "
@@ -883,7 +883,9 @@ def main():
             table = {
                 "s10k": lambda: secondary_single_query(torch, dev, 10_000, 384, k, max(s, 2000), max(w, 100), args.depth,
                                                        "the 10K-row point of the N matrix: launch-latency-bound, 15 MB per query"),
-                "s1m": lambda: secondary_single_query(torch, dev, 1_000_000, 384, k, max(s, 100), max(w, 10), args.depth),
+                "s1m": lambda: secondary_single_query(torch, dev, 1_000_000, 384, k, max(s, 600), max(w, 50), args.depth),
+                "s1250k": lambda: secondary_single_query(torch, dev, 1_250_000, 384, k, max(s, 600), max(w, 50), args.depth,
+                                                         "the headline's per-GPU shard at 8 GPUs (10M / 8 rows): what one rank of BASELINE config 4 scans per query"),
                 "b1m_q256": lambda: secondary_batched(torch, dev, 1_000_000, 384, 256, k, max(s, 200), max(w, 20),
                                                       "1000000 x 384, 256 queries per step, cosine top-10, bf16 MFMA GEMM + fused top-k, 1 GPU "
                                                       "(BASELINE config 3), queries and results resident in HBM, 2 batches in flight"),
@@ -934,7 +936,7 @@ def main():
             # N > 1: the rest of the north star's N matrix on the same sharded path (torchrun shape), then config 5
             if world > 1:
                 for name, rows_, steps_, warm_, label in (
-                        ("s1m", 1_000_000, max(args.steps, 100), max(args.warmup, 10), "N matrix: 1M rows; BASELINE config 2's corpus over the node"),
+                        ("s1m", 1_000_000, max(args.steps, 600), max(args.warmup, 50), "N matrix: 1M rows; BASELINE config 2's corpus over the node"),
                         ("s10k", 10_000, max(args.steps, 2000), max(args.warmup, 100), "N matrix: 10K rows — exchange-latency-bound")):
                     if args.secondary != "all" and name not in want:
                         continue

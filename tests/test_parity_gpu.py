@@ -822,7 +822,7 @@ def _run_bench(nproc, extra, tmp_path, one_process=False):
 
 
 def test_bench_contract_and_shard_invariance(wax, tmp_path):
-    one = _run_bench(1, ["--secondary", "s10k,s1m,b1m_q256,b1m_q1024,c5_shard,c5_full,clustered_k10"], tmp_path)
+    one = _run_bench(1, ["--secondary", "s10k,s1m,b1m_q256,b1m_q1024,c5_shard,c5_full,clustered_k10,s1250k"], tmp_path)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in one, key
@@ -836,7 +836,9 @@ def test_bench_contract_and_shard_invariance(wax, tmp_path):
     assert "300K x 384" in one["metric"] and one["config"]["parallelism"] == "row-shard x1"
     assert r["traffic"] is None and r["traffic_source"] is None      # no counter pass exists for this row count
     sec = one["secondary"]
-    assert [x["name"] for x in sec] == ["s10k", "s1m", "b1m_q256", "b1m_q1024", "c5_shard", "c5_full", "clustered_k10"]
+    assert [x["name"] for x in sec] == ["s10k", "s1m", "b1m_q256", "b1m_q1024", "c5_shard", "c5_full", "clustered_k10", "s1250k"]
+    assert "per-GPU shard at 8 GPUs" in sec[7]["config"] and sec[7]["roofline"]["algorithmic_bytes_per_launch"] == 1_250_000 * 384 * 4
+    sec = sec[:7]
     assert all("error" not in x for x in sec), sec
     for x in sec:
         rr = x["roofline"]
