@@ -40,6 +40,102 @@ def build(force: bool = False) -> str:
     return _LIB_PATH
 
 
+# ---------------------------------------------------------------------------
+# oracle/_ref: the reference's own Metal compute shaders compiled as C++ from /root/reference and run on the CPU
+# (oracle/ref_metal/). Only built where the reference checkout exists; tests that need it skip elsewhere — the committed
+# fixtures under tests/golden/metal_shader_vectors.json carry its outputs to every machine.
+REFERENCE_ROOT = os.environ.get("WAX_REFERENCE_ROOT", "/root/reference")
+_REF_LIB_PATH = os.path.join(_HERE, "_ref", "libwaxref_metal.so")
+_ref_lib = None
+
+
+def build_ref(force: bool = False) -> Optional[str]:
+    """Compile oracle/_ref/libwaxref_metal.so (recipe: oracle/ref_metal/Makefile). Returns None where the reference checkout
+    is absent (the GPU box): nothing there may depend on it."""
+    shaders = os.path.join(REFERENCE_ROOT, "Sources", "WaxVectorSearch", "Shaders", "CosineDistance.metal")
+    if not os.path.exists(shaders):
+        return _REF_LIB_PATH if os.path.exists(_REF_LIB_PATH) else None
+    if force or not os.path.exists(_REF_LIB_PATH):
+        subprocess.run(["make", "-C", os.path.join(_HERE, "ref_metal"), "-s", "-B" if force else "-s", f"REF={REFERENCE_ROOT}"], check=True)
+    return _REF_LIB_PATH
+
+
+def ref_lib():
+    """ctypes handle of the reference-shader library, or None when it is not available here."""
+    global _ref_lib
+    if _ref_lib is None:
+        path = build_ref()
+        if not path:
+            return None
+        L = ctypes.CDLL(path)
+        f32p = ctypes.POINTER(ctypes.c_float)
+        u32p = ctypes.POINTER(ctypes.c_uint32)
+        L.waxref_metal_cosine_distances.restype = ctypes.c_int
+        L.waxref_metal_cosine_distances.argtypes = [ctypes.c_int, f32p, f32p, ctypes.c_uint32, ctypes.c_uint32, f32p]
+        L.waxref_metal_topk.restype = ctypes.c_int
+        L.waxref_metal_topk.argtypes = [f32p, ctypes.c_uint32, ctypes.c_uint32, f32p, u32p, u32p]
+        _ref_lib = L
+    return _ref_lib
+
+
+def ref_metal_distances(vectors, query, simd8: Optional[bool] = None) -> np.ndarray:
+    """cosineDistanceKernelSIMD8 / SIMD4 of the reference (CosineDistance.metal:152-328) executed on the CPU, dispatched as
+    MetalVectorEngine.search does (:494-507). simd8=None: the engine's rule, D >= 384 (:24, :185)."""
+    L = ref_lib()
+    if L is None:
+        raise RuntimeError("oracle/_ref is not available here (no reference checkout, no prebuilt library)")
+    v = np.ascontiguousarray(vectors, dtype=np.float32)
+    q = np.ascontiguousarray(query, dtype=np.float32)
+    n, d = v.shape
+    out = np.empty(n, dtype=np.float32)
+    use8 = (d >= 384) if simd8 is None else bool(simd8)
+    f32p = ctypes.POINTER(ctypes.c_float)
+    rc = L.waxref_metal_cosine_distances(int(use8), v.ctypes.data_as(f32p), q.ctypes.data_as(f32p), n, d, out.ctypes.data_as(f32p))
+    assert rc == 0
+    return out
+
+
+def ref_metal_topk(dist, k: int):
+    """The GPU top-k of the reference (TopKReduction.metal kernels under the dispatch loop of MetalVectorEngine.swift:517-585).
+    Returns (indices u32[k], distances f32[k], passes), or raises NonTermination where the reference's host loop would never
+    finish (k > 128 with enough rows: see oracle/ref_metal/ref_metal.cpp)."""
+    L = ref_lib()
+    if L is None:
+        raise RuntimeError("oracle/_ref is not available here (no reference checkout, no prebuilt library)")
+    d = np.ascontiguousarray(dist, dtype=np.float32)
+    od = np.empty(k, dtype=np.float32)
+    oi = np.empty(k, dtype=np.uint32)
+    passes = ctypes.c_uint32()
+    rc = L.waxref_metal_topk(d.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), d.shape[0], k, od.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                             oi.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), ctypes.byref(passes))
+    if rc == -2:
+        raise NonTermination(f"the reference's reduction loop makes no progress for n = {d.shape[0]}, k = {k}")
+    if rc != 0:
+        raise ValueError(f"waxref_metal_topk: {rc}")
+    return oi, od, int(passes.value)
+
+
+class NonTermination(Exception):
+    pass
+
+
+def formula_rows(seed: int, n: int, dims: int) -> np.ndarray:
+    """Deterministic f32 test rows from integer arithmetic only (no RNG stream, no BLAS): identical on every machine, so the
+    reference-shader fixture stores OUTPUTS only. Values in (-1, 1) / sqrt(dims)-ish scale, never all zero."""
+    i = np.arange(n, dtype=np.int64)[:, None]
+    j = np.arange(dims, dtype=np.int64)[None, :]
+    v = ((i * 7919 + j * 104729 + (i * j) * 31 + int(seed) * 15485863) % 20011 - 10005).astype(np.float64) / 10005.0
+    return (v / np.sqrt(np.float64(max(dims, 1)))).astype(np.float32)
+
+
+def formula_unit_query(seed: int, dims: int) -> np.ndarray:
+    """Deterministic unit-norm f32 query: formula values normalised in f64 with a sequential sum."""
+    j = np.arange(dims, dtype=np.int64)
+    v = ((j * 48271 + int(seed) * 2147483 + 12345) % 10007 - 5003).astype(np.float64) / 5003.0
+    norm = np.sqrt(np.cumsum(v * v)[-1])
+    return (v / norm).astype(np.float32)
+
+
 _lib: Optional[ctypes.CDLL] = None
 
 

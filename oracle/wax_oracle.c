@@ -11,17 +11,25 @@
  * restatement of the arithmetic and of the selection order.
  *
  * Pinning status:
+ *   - PINNED, bit for bit, against OUTPUTS OF THE REFERENCE ITSELF on its GPU path: the reference's own Metal
+ *     compute shaders (CosineDistance.metal, TopKReduction.metal) are compiled unchanged as C++ from where they lie
+ *     under /root/reference (oracle/ref_metal/ -> oracle/_ref/libwaxref_metal.so; a stand-in for <metal_stdlib>,
+ *     threadgroup threads as fibers, IEEE binary32 semantics) and executed on the CPU. wax_oracle_cosine_distances_metal
+ *     returns the same 32 bits per row as cosineDistanceKernelSIMD4 / SIMD8; the selection equals topKReduceDistances /
+ *     topKReduceEntries under the engine's dispatch loop. tests/golden/metal_shader_vectors.json carries those outputs
+ *     (generator: oracle/gen_metal_golden.py) to machines without the reference checkout; tests/test_reference_shaders.py.
  *   - PINNED by the reference's own tests (tests/golden/reference_cases.json,
  *     transcribed with file:line): rank / membership on the 2-d and 4-d toy
  *     corpora, the scaled-query tolerance (1e-3), upsert-by-id, remove,
  *     the MV2V header constants and the topK clamp.
- *   - PARITY UNPINNED at the numeric USearch boundary: the reference's "CPU
- *     path" arithmetic lives in USearch 2.23.0 (Package.resolved rev
+ *   - PARITY UNPINNED at the numeric USearch boundary only: the reference's CPU
+ *     engine's arithmetic lives in USearch 2.23.0 (Package.resolved rev
  *     7306bb446be5f0f0c529ec8acdc57361cef8a8a7), which is not vendored in the
  *     checkout and cannot be built here (no Swift, no network), and no
  *     reference test pins a numeric score. USearch's published metric
  *     definitions (cos = 1 - ab/(|a||b|), ip = 1 - ab, l2sq = sum (a-b)^2)
- *     are restated in wax_oracle_distances_f64 from its documentation.
+ *     are restated in wax_oracle_distances_f64 from its documentation; the f64 truth sits within 2e-6 of the
+ *     reference's Metal kernels on unit queries (same test file), far inside the 1e-5 tolerance.
  */
 #include <math.h>
 #include <stdint.h>
