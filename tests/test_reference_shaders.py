@@ -31,6 +31,15 @@ def _inputs(c):
 
 
 @pytest.fixture(scope="module")
+def wax(hip_lib):
+    import wax_amd
+    if hip_lib.wax_hip_device_count() == 0:
+        pytest.skip("no HIP device on this host: the gpu-marked tests run on the MI355X box (pytest -m gpu)")
+    assert hip_lib.wax_hip_available() == 1, "a HIP device is visible but it is not gfx950: the HIP path needs an MI355X"
+    return wax_amd
+
+
+@pytest.fixture(scope="module")
 def golden():
     return json.load(open(os.path.join(GOLDEN, "metal_shader_vectors.json")))
 
