@@ -60,6 +60,15 @@ def main():
             idx, dist, passes = oracle.ref_metal_topk(d, k)
             case["results"].append({"k": k, "passes": passes, "indices": b64(idx), "distances": b64(dist)})
         out["topk_cases"].append(case)
+    # end to end as MetalVectorEngine.search composes it (:494-611): distance kernel -> GPU top-k -> (index, distance) pairs.
+    # Store sizes are multiples of 256 rows (every threadgroup full); k = 30 is the callers' candidateLimit for topK 10.
+    out["search_cases"] = []
+    for seed, (dims, n, k) in enumerate([(384, 2048, 30), (768, 1024, 30), (128, 1280, 10), (384, 2560, 128)], start=40):
+        x = oracle.formula_rows(seed, n, dims)
+        q = oracle.formula_unit_query(seed, dims)
+        d = oracle.ref_metal_distances(x, q)
+        idx, dist, passes = oracle.ref_metal_topk(d, k)
+        out["search_cases"].append({"seed": seed, "dims": dims, "rows": n, "k": k, "passes": passes, "indices": b64(idx), "distances": b64(dist)})
     # the host loop's fixed points (MetalVectorEngine.swift:548): no progress for k > 128
     non_term = []
     for n, k in [(1500, 129), (1500, 200), (1500, 256), (5000, 130)]:

@@ -87,6 +87,19 @@ def test_oracle_selection_equals_the_reference_gpu_reduction(golden):
             assert 2 <= r["passes"] <= 6                                   # 2-6 launches
 
 
+def test_oracle_search_equals_the_reference_pipeline_end_to_end(golden):
+    """Distance kernel -> GPU top-k, as MetalVectorEngine.search composes them, against oracle.search in its Metal-faithful mode:
+    the same rows in the same order with the same 32-bit distances (scores = 1 - d, VectorMetric.swift:32-43)."""
+    assert len(golden["search_cases"]) >= 4
+    for c in golden["search_cases"]:
+        x, q = oracle.formula_rows(c["seed"], c["rows"], c["dims"]), oracle.formula_unit_query(c["seed"], c["dims"])
+        idx, dist = _arr(c["indices"], np.uint32), _arr(c["distances"], np.float32)
+        ids = np.arange(c["rows"], dtype=np.uint64) + 500
+        o_ids, o_scores, _, _ = oracle.search(oracle.METRIC_COSINE, x, ids, q, c["k"], mode=oracle.MODE_METAL_F32)
+        assert np.array_equal(np.asarray(o_ids, dtype=np.uint64), idx.astype(np.uint64) + 500), (c["dims"], c["rows"])
+        assert np.array_equal(np.asarray(o_scores, dtype=np.float32), np.float32(1.0) - dist)
+
+
 def test_reference_reduction_loop_has_fixed_points_above_k_128(golden):
     """A property of the reference recorded while pinning it: `while currentCount > topKCount` (MetalVectorEngine.swift:548)
     makes no progress once ceil(count / 256) * k == count, which happens for every k > 128. The HIP engine serves those k on the
@@ -160,4 +173,14 @@ def test_hip_engine_against_the_reference_shader_outputs(golden, wax):
         got_ids, got_scores = eng.searchArrays(q, n)
         order = np.lexsort((np.arange(n), d_ref))
         assert_parity(got_ids, got_scores, ids[order], (np.float32(1.0) - d_ref[order]), ctx=f"dims {dims}")
+        eng.close()
+    # end to end: the reference pipeline's top-k (distance kernel + GPU reduction) against wax_hip_search on the same store
+    for c in golden["search_cases"]:
+        x, q = oracle.formula_rows(c["seed"], c["rows"], c["dims"]), oracle.formula_unit_query(c["seed"], c["dims"])
+        idx, dist = _arr(c["indices"], np.uint32), _arr(c["distances"], np.float32)
+        eng = wax.HIPVectorEngine(dimensions=c["dims"])
+        ids = np.arange(c["rows"], dtype=np.uint64) + 500
+        eng.addBatch(ids, x)
+        got_ids, got_scores = eng.searchArrays(q, c["k"])
+        assert_parity(got_ids, got_scores, idx.astype(np.uint64) + 500, np.float32(1.0) - dist, ctx=f"search {c['dims']}x{c['rows']}")
         eng.close()
