@@ -1240,14 +1240,14 @@ def test_filtered_search_long_allow_list_on_device(wax):
 def test_batch_gemm_variants_agree(wax, dims):
     """Every GEMM variant behind the batched path — LDS-tiled (batch_rega 0), register-resident with register
     staging (1), with LDS-DMA staging (2; D = 768 has the K-split kernel for both), one wave per SIMD (3) and the
-    free-running variant without a tile barrier (4; D <= 384, else it is variant 1) — gives the single-query answers bit for bit, over several slab schedules of the slab pipeline and through the one-pass pipeline."""
+    free-running variant without a tile barrier (4; D <= 384, else it is variant 1), the split barrier (5, the default) — gives the single-query answers bit for bit, over several slab schedules of the slab pipeline and through the one-pass pipeline."""
     n = 150_000
     corpus = oracle.gaussian_unit_rows(9, n, dims)
     eng = make_engine(wax, 0, dims, corpus)
     queries = oracle.gaussian_unit_queries(300, dims, seed=31)
     ref = None
     for onepass, rega, growth in [(0, 1, 8), (0, 1, 3), (0, 2, 8), (0, 2, 3), (0, 0, 8), (0, 0, 3), (0, 3, 8), (0, 3, 3), (1, 1, 8), (1, 2, 8),
-                                  (1, 3, 8), (1, 4, 8), (0, 4, 3)]:   # rega 3 = one wave per SIMD (D <= 512), LDS-DMA ring
+                                  (1, 3, 8), (1, 4, 8), (0, 4, 3), (1, 5, 8), (0, 5, 3)]:   # rega 3 = one wave per SIMD (D <= 512), LDS-DMA ring; 5 = split barrier (the default)
         eng.setTuning("batch_onepass", onepass)
         eng.setTuning("batch_rega", rega)
         eng.setTuning("batch_growth", growth)
@@ -1281,7 +1281,7 @@ def test_batch_randomised_soak(wax):
         if metric != 0:
             corpus = corpus * rng.uniform(0.5, 1.5, (n, 1)).astype(np.float32)
         eng = make_engine(wax, metric, dims, corpus)
-        eng.setTuning("batch_rega", int(rng.choice([1, 2, 3, 3, 4])))
+        eng.setTuning("batch_rega", int(rng.choice([1, 2, 3, 4, 5, 5])))
         eng.setTuning("batch_growth", int(rng.choice([3, 8, 16])))
         eng.setTuning("batch_first", int(rng.choice([512, 2048])))
         queries = oracle.gaussian_unit_queries(nq, dims, seed=500 + trial)

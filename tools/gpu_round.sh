@@ -233,6 +233,22 @@ PYEOF
         WAX_HIP_BATCH_REGA=$m timeout 900 python -m pytest tests -q -m gpu -x -p no:cacheprovider --timeout 400 -k "batch or onepass or sharded or adversarial or falls_back" > "$OUT/pytest_rega$m.log" 2>&1; rc=$?
         tail -2 "$OUT/pytest_rega$m.log"
       done ;;
+    splitab)
+      WAX_HIP_BATCH_REGA=5 timeout 900 python -m pytest tests -q -m gpu -x -p no:cacheprovider --timeout 400 \
+          -k "onepass or batch_mfma or randomised_soak or variants_agree or adversarial or falls_back_on_ties or submit_collect_device" > "$OUT/pytest_split.log" 2>&1; rc=$?
+      tail -1 "$OUT/pytest_split.log"
+      timeout 600 python tools/batch_bench.py --nq 256 1024 --rega 1 5 1 5 > "$OUT/split_bench.log" 2>&1
+      for m in 1 5 1 5; do
+        WAX_HIP_BATCH_REGA=$m timeout 600 python bench.py --gpus 1 --rows 1000000 --steps 20 --warmup 4 --no-cpu-baseline --secondary b1m_q256,b1m_q1024,clustered_k100 > "$OUT/bench_sec_rega$m.$RANDOM.json" 2>> "$OUT/bench_sec.err"
+      done ;;
+    split768)
+      timeout 900 python -m pytest tests -q -m gpu -x -p no:cacheprovider --timeout 400 \
+          -k "onepass or batch_mfma or randomised_soak or variants_agree or adversarial or falls_back_on_ties or submit_collect_device or config5_shard or sharded_batch" > "$OUT/pytest_split768.log" 2>&1; rc=$?
+      tail -1 "$OUT/pytest_split768.log"
+      timeout 600 python tools/batch_bench.py --dims 768 --rows 1250000 --nq 1024 --reps 5 --rega 1 5 1 5 > "$OUT/split768_bench.log" 2>&1
+      for m in 1 5 1 5; do
+        WAX_HIP_BATCH_REGA=$m timeout 600 python bench.py --gpus 1 --rows 1000000 --steps 20 --warmup 4 --no-cpu-baseline --secondary c5_shard,b1m_q256 > "$OUT/bench_c5_rega$m.$RANDOM.json" 2>> "$OUT/bench_sec.err"
+      done ;;
     profchain)
       # the headline with every scan of the timed region chained and timed (one kernel at a time): the run whose rocprofv3 average
       # the per-launch `roofline.frac` of the default command (calibration pass) is compared with

@@ -468,8 +468,16 @@ constexpr int rega_lds_tiles(bool glds) { return (glds && 3 * 64 * (D * 2 + 16) 
 // because a 150 KB workgroup keeps the neighbouring batch's finish / prep kernels off the CU. Hence a variant, not the default.
 // What the remaining gap is made of is in DESIGN.md ("the matrix roof"): with embedding-like operands the K loop ALONE
 // (tools/mfma_probe.hip) sustains 1.57 PFLOP/s on this part — the matrix clock is power-limited and data-dependent.
-template <int D, bool GLDS, int AHEAD, bool SAMPLE = false, bool PROF = false, bool FREE = false>
+//
+// SYNC = 2 ("batch_rega" = 5): the SPLIT barrier — the default's two LDS tiles and one-tile-ahead staging, but the per-tile
+// workgroup barrier becomes "arrive" (a wave adds 1 to an LDS counter behind its K loop) and "wait" (spin on the counter in front
+// of the next K loop): a wave's selection sits between the two, so it no longer waits for the slowest wave before selecting.
+// Everybody still finishes K loop t-1 before anybody starts K loop t (that is what covers both hazards with two tiles), so there
+// is less slack than in the free-running variant — and no extra LDS.
+template <int D, bool GLDS, int AHEAD, bool SAMPLE = false, bool PROF = false, int SYNC = 0>
 __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uint32_t blocks_per_group) {
+    constexpr bool FREE = SYNC == 1, SPLIT = SYNC == 2;
+    static_assert(!SPLIT || (!GLDS && !SAMPLE), "the split barrier is a variant of the register-staged filtering kernel");
     constexpr int KS = D / 16;                       // MFMA k-steps
     constexpr int ROW_B = D * 2 + 16;                // LDS row stride (bytes)
     constexpr int TROWS = 64;                        // corpus rows per tile
@@ -521,6 +529,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
         stored_s[tid] = tid < 2 ? 8u : 0u;                                     // tiles 0 and 1 are staged by the prologue, behind a barrier
         read_s[tid] = 0u;
     }
+    if (SPLIT && tid == 0) stored_s[0] = 0u;                                   // SPLIT: K loops finished, all waves (arrivals of the split barrier)
     if (FREE && tid >= 64 && tid < 68) turn_s[tid - 64] = 0u;
     // this workgroup's segment of every query's candidate row
     const uint32_t seg_slots = a.seg_area / blocks_per_group;
@@ -593,7 +602,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
     // staging only): the first two tiles are the static ones, every further one is claimed from the group's counter one
     // iteration before its loads are issued — thread 0 starts the atomic at the top of an iteration and parks the
     // result in LDS at its end, next to the tile barrier, so its latency never sits on the critical path.
-    const bool dyn = !SAMPLE && !GLDS && !FREE && a.tile_ctr != nullptr;
+    const bool dyn = !SAMPLE && !GLDS && !FREE && !SPLIT && a.tile_ctr != nullptr;
     uint32_t t = bidx;
     if (dyn && tid == 0) {
         const unsigned int c0 = claim_tile_async(a.tile_ctr + group * 32u);
@@ -830,7 +839,9 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
                 signal_count(read_s + cur_idx);
                 if (st_dst && lane == 0) __hip_atomic_fetch_add((lds_u32*)(stored_s + pre_idx3), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             } else {
+                if (SPLIT && it > 0) wait_count(stored_s, 8u * it);    // every wave has finished K loop it - 1: tile `it` is stored, its other buffer is free
                 mfma_tile(cur, st_dst);
+                if (SPLIT) signal_count(stored_s);
             }
             if (prof) { c2 = __builtin_amdgcn_s_memtime(); prof_mfma += c2 - c1; }
         } else {
@@ -841,7 +852,9 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
                 signal_count(read_s + cur_idx);
                 if (st_dst && lane == 0) __hip_atomic_fetch_add((lds_u32*)(stored_s + pre_idx3), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             } else {
+                if (SPLIT && it > 0) wait_count(stored_s, 8u * it);
                 mfma_tile(cur, st_dst);
+                if (SPLIT) signal_count(stored_s);
             }
             if (prof) { c1 = __builtin_amdgcn_s_memtime(); prof_mfma += c1 - c0; }
             select_tile(t);
@@ -868,7 +881,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
                 claim_wait();
                 next_s[(it + 1u) & 1u] = t_after < ntiles ? 2u * blocks_per_group + claimed : t_after;
             }
-            if (!(a.debug & 4u)) __syncthreads();  // debug bit2 (only with bit0): no per-tile barrier
+            if (!SPLIT && !(a.debug & 4u)) __syncthreads();  // debug bit2 (only with bit0): no per-tile barrier
             t = tn;
             t_next = t_after;
         }
@@ -894,7 +907,13 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
 // selection, while the helper is already issuing the next tile's MFMAs (the pair shares a SIMD, so the owner's
 // VALU/LDS work overlaps the helper's matrix work by construction).
 // Selection, segments and thresholds are those of batch_gemm_rega_kernel (one row block per tile).
-template <int D, int AHEAD, bool SAMPLE = false>
+//
+// SPLIT = true (the default for the filtering launch): the tile barrier is split as in batch_gemm_rega_kernel<..., SYNC = 2>.
+// Every wave adds 1 to `done` behind its K loop and spins on it (8 x tile number) in front of the next one — that orders the
+// tile buffers; a helper also adds 1 to its pair's `parked` counter behind its partial sums, and the owner waits for THAT before
+// its selection — so an owner selects as soon as its own partner is through, while the slowest wave of the workgroup is still
+// multiplying, instead of after everybody.
+template <int D, int AHEAD, bool SAMPLE = false, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void batch_gemm_ksplit_kernel(GemmArgs a, uint32_t blocks_per_group) {
     constexpr int HALF = D / 2;
     constexpr int KS = HALF / 16;                    // MFMA k-steps per wave
@@ -912,6 +931,8 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_ksplit_kernel(GemmArgs a, u
     unsigned int* cnt_s = reinterpret_cast<unsigned int*>(tau_s + 4 * 32);      // [4][32] survivors per query (this workgroup)
     float* sim_s = reinterpret_cast<float*>(cnt_s + 4 * 32);                    // [4][32] conservative similarity bounds
     unsigned int* next_s = reinterpret_cast<unsigned int*>(sim_s + 4 * 32);     // [2] claimed tile indices (dynamic tile order)
+    unsigned int* done_s = next_s + 4;                                          // SPLIT: K loops finished (all waves)
+    unsigned int* parked_s = next_s + 5;                                        // SPLIT: [4] partial sums parked, per pair
 
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
@@ -929,6 +950,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_ksplit_kernel(GemmArgs a, u
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) fa[ks] = __builtin_bit_cast(bf16x8, qp[ks * 2]);
     }
+    if (SPLIT && tid < 5) done_s[tid] = 0u;   // done + parked[4]
     if (owner && lane < 32) {
         const float tq = SAMPLE ? 0.f : a.tau[q0 + lane];
         tau_s[pair * 32 + lane] = tq;
@@ -1043,8 +1065,22 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_ksplit_kernel(GemmArgs a, u
         }
     };
 
+    // SPLIT: see batch_gemm_rega_kernel (bounded spin: a protocol error must show up as wrong answers, not as a hung GPU)
+    auto wait_count = [&](const unsigned int* ctr, unsigned int target) {
+        for (unsigned int spins = 0; spins < (1u << 22); ++spins) {
+            const unsigned int v = __hip_atomic_load((const lds_u32*)ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((unsigned int)__builtin_amdgcn_readfirstlane((int)v) >= target) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        asm volatile("" ::: "memory");
+    };
+    auto signal_count = [&](unsigned int* ctr) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add((lds_u32*)ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+
     // tile order: static stride, or (a.tile_ctr) claimed from the group's counter — see batch_gemm_rega_kernel
-    const bool dyn = !SAMPLE && a.tile_ctr != nullptr;
+    const bool dyn = !SAMPLE && !SPLIT && a.tile_ctr != nullptr;
     uint32_t t = bidx;
     if (dyn && tid == 0) {
         const unsigned int c0 = claim_tile_async(a.tile_ctr + group * 32u);
@@ -1074,7 +1110,23 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_ksplit_kernel(GemmArgs a, u
         }
         const bool spread = !(a.debug & 128u);                 // debug bit7: one burst after the K loop, for A/B timing
         unsigned char* st_dst = (spread && tn < ntiles) ? nxt + srow * ROW_B + sseg : nullptr;
-        if (owner) {
+        if (SPLIT) {
+            if (owner) {
+                if (it > 0) {
+                    wait_count(parked_s + pair, it);            // the partner's partial sums of tile it - 1 are in LDS
+                    select_tile(t_prev, (it - 1u) & 1u);
+                    wait_count(done_s, 8u * it);                // every wave is through K loop it - 1: tile `it` stored, its other buffer free
+                }
+                mfma_tile(cur, st_dst);
+                signal_count(done_s);
+            } else {
+                if (it > 0) wait_count(done_s, 8u * it);        // (also: the owner has read the partial buffer this tile's sums go to)
+                mfma_tile(cur, st_dst);
+                signal_count(done_s);
+                park_partial(it & 1u);
+                signal_count(parked_s + pair);
+            }
+        } else if (owner) {
             if (it > 0) select_tile(t_prev, (it - 1u) & 1u);   // partial of the previous tile: parked before the last barrier
             mfma_tile(cur, st_dst);
         } else {
@@ -1086,11 +1138,12 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_ksplit_kernel(GemmArgs a, u
             claim_wait();
             next_s[(it + 1u) & 1u] = t_after < ntiles ? 2u * blocks_per_group + claimed : t_after;
         }
-        __syncthreads();
+        if (!SPLIT) __syncthreads();
         t_prev = t;
         t = tn;
         t_next = t_after;
     }
+    if (SPLIT && owner && it > 0) wait_count(parked_s + pair, it);
     if (owner && it > 0) select_tile(t_prev, (it - 1u) & 1u);
     __syncthreads();
     if (!SAMPLE && tid < 128) a.seg_count[(size_t)bidx * (a.nqt * 128u) + group * 128u + (uint32_t)tid] = cnt_s[tid];
@@ -1457,33 +1510,34 @@ bool batch_gemm_segments(const GemmArgs& a, int metric, uint32_t* nseg, uint32_t
     return true;
 }
 
-template <int D, int AHEAD>
+template <int D, int AHEAD, bool SPLIT = true>
 static hipError_t launch_ksplit(const GemmArgs& a, hipStream_t st) {
-    constexpr size_t smem = 2 * 32 * (D * 2 + 16) + 2 * 4 * (4 * 64 * 16) + 3 * 4 * 32 * 4 + 16;  // tiles, partial sums, thresholds / counters / bounds
+    constexpr size_t smem = 2 * 32 * (D * 2 + 16) + 2 * 4 * (4 * 64 * 16) + 3 * 4 * 32 * 4 + 16 + 32;  // tiles, partial sums, thresholds / counters / bounds, split-barrier counters
     static std::atomic<uint64_t> configured{0};   // per device (ensure_dynamic_lds)
     {
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&batch_gemm_ksplit_kernel<D, AHEAD>), smem, configured);
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&batch_gemm_ksplit_kernel<D, AHEAD, false, SPLIT>), smem, configured);
         if (e != hipSuccess) return e;
     }
     uint32_t groups, per_group;
     rega_geometry(a, &groups, &per_group);
-    hipLaunchKernelGGL((batch_gemm_ksplit_kernel<D, AHEAD>), dim3(groups * per_group), dim3(512), smem, st, a, per_group);
+    hipLaunchKernelGGL((batch_gemm_ksplit_kernel<D, AHEAD, false, SPLIT>), dim3(groups * per_group), dim3(512), smem, st, a, per_group);
     return hipGetLastError();
 }
 
-template <int D, bool GLDS, int AHEAD, bool PROF = false, bool FREE = false>
+template <int D, bool GLDS, int AHEAD, bool PROF = false, int SYNC = 0>
 static hipError_t launch_rega_impl(const GemmArgs& a, hipStream_t st) {
+    constexpr bool FREE = SYNC == 1;
     // tiles, thresholds, survivor counters, bounds, claimed tile indices (+ the two counter triples of the free-running variant)
-    constexpr size_t smem = (size_t)(FREE ? 3 : rega_lds_tiles<D>(GLDS)) * 64 * (D * 2 + 16) + 3 * 8 * 32 * 4 + 16 + (FREE ? 48 : 0);   // FREE: stored[3], read[3], turn[4] behind the claimed tile indices
+    constexpr size_t smem = (size_t)(FREE ? 3 : rega_lds_tiles<D>(GLDS)) * 64 * (D * 2 + 16) + 3 * 8 * 32 * 4 + 16 + (SYNC != 0 ? 48 : 0);   // FREE / SPLIT: stored[3], read[3], turn[4] behind the claimed tile indices
     static_assert(smem <= 160 * 1024, "LDS budget of one CU");
     static std::atomic<uint64_t> configured{0};   // per device (ensure_dynamic_lds)
     {
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&batch_gemm_rega_kernel<D, GLDS, AHEAD, false, PROF, FREE>), smem, configured);
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&batch_gemm_rega_kernel<D, GLDS, AHEAD, false, PROF, SYNC>), smem, configured);
         if (e != hipSuccess) return e;
     }
     uint32_t groups, per_group;
     rega_geometry(a, &groups, &per_group);
-    hipLaunchKernelGGL((batch_gemm_rega_kernel<D, GLDS, AHEAD, false, PROF, FREE>), dim3(groups * per_group), dim3(512), smem, st, a, per_group);
+    hipLaunchKernelGGL((batch_gemm_rega_kernel<D, GLDS, AHEAD, false, PROF, SYNC>), dim3(groups * per_group), dim3(512), smem, st, a, per_group);
     return hipGetLastError();
 }
 
@@ -1507,10 +1561,16 @@ static hipError_t launch_rega(const GemmArgs& a, hipStream_t st) {
     if constexpr (rega_free_dims(D)) {
         if (a.use_rega == 4u) {
             if constexpr (D == 384) {
-                if (a.debug & 1024u) return launch_rega_impl<D, false, AHEAD, true, true>(a, st);   // phase clock, see below
+                if (a.debug & 1024u) return launch_rega_impl<D, false, AHEAD, true, 1>(a, st);   // phase clock, see below
             }
-            return launch_rega_impl<D, false, AHEAD, false, true>(a, st);
+            return launch_rega_impl<D, false, AHEAD, false, 1>(a, st);
         }
+    }
+    if (a.use_rega == 5u) {
+        if constexpr (D == 384) {
+            if (a.debug & 1024u) return launch_rega_impl<D, false, AHEAD, true, 2>(a, st);
+        }
+        return launch_rega_impl<D, false, AHEAD, false, 2>(a, st);
     }
     if constexpr (D == 384) {
         // diagnosis run: per-wave phase clock (see the kernel's main loop)
@@ -1542,7 +1602,9 @@ hipError_t launch_batch_gemm(const GemmArgs& a, int metric, hipStream_t st) {
                 switch ((a.debug >> 8) & 3u) {   // timing experiments: B-fragment read-ahead depth
                     case 1: return launch_ksplit<768, 6>(a, st);
                     case 2: return launch_ksplit<768, 8>(a, st);
-                    default: return launch_ksplit<768, 4>(a, st);
+                    default:
+                        if (a.use_rega == 1u) return launch_ksplit<768, 4, false>(a, st);   // "batch_rega" = 1: workgroup barrier per tile (rounds 1-2)
+                        return launch_ksplit<768, 4>(a, st);
                 }
             default: break;
         }

@@ -404,7 +404,7 @@ struct wax_hip_engine {
     std::atomic<int64_t> batch_growth{8};    // next slab = growth x rows seen so far
     std::atomic<int64_t> batch_first{2048};  // rows of the dense first slab (<= kBatchFirstSlab)
     std::atomic<int64_t> batch_debug{0};     // timing experiments only (GemmArgs::debug)
-    std::atomic<int64_t> batch_rega{1};      // register-resident-queries GEMM where it applies: 1 register staging, 2 LDS-DMA staging, 3 one wave per SIMD, 4 free-running (no tile barrier); 0 off
+    std::atomic<int64_t> batch_rega{5};      // register-resident-queries GEMM where it applies: 5 (default) register staging + split tile barrier, 1 register staging + workgroup barrier, 2 LDS-DMA staging, 3 one wave per SIMD, 4 free-running (three LDS tiles); 0 off
     std::atomic<uint64_t> st_batch_queries{0}, st_batch_fallbacks{0};
     BatchMirror batch;
     std::mutex bctx_mu;
@@ -1218,14 +1218,14 @@ int batch_enqueue(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32
     g.qb = c->d_qb; g.cb = b.d_cb; g.q_n2 = c->d_qn2; g.v_n2 = b.d_vn2; g.tau = c->d_tau;
     g.cand = c->d_cand; g.cand_count = c->d_cand_count; g.row_base = (uint32_t)e->row_base;
     g.dims = D; g.n_rows = n; g.nq = qn; g.nqt = nq_pad / 128;
-    g.use_rega = (uint32_t)e->batch_rega.load();  // 0 LDS-tiled kernel, 1 register staging, 2 LDS-DMA staging, 3 one wave per SIMD, 4 free-running
+    g.use_rega = (uint32_t)e->batch_rega.load();  // 0 LDS-tiled kernel, 1 register staging + workgroup barrier, 2 LDS-DMA staging, 3 one wave per SIMD, 4 free-running, 5 split barrier (default)
     g.debug = (uint32_t)e->batch_debug.load();
     g.seg_count = c->d_seg_count;
     if (plan) {
         // ---- one pass: sample -> threshold -> filter everything -> finish ----
         g.slab0 = 0; g.slab_rows = n; g.dense = nullptr; g.dense_ld = 0;
         g.cand_cap = plan->seg_area; g.seg_base = 0; g.seg_area = plan->seg_area;
-        if (g.use_rega == 0) g.use_rega = 1;
+        if (g.use_rega == 0) g.use_rega = 5;
         GemmArgs gs = g;
         gs.tile_max = c->d_tile_max; gs.sample_tiles = plan->sample_tiles;
         g.tile_ctr = pa.tile_ctr;
@@ -1574,7 +1574,7 @@ int wax_hip_engine_create(uint8_t metric, uint32_t dims, int device_id, wax_hip_
     e->dims = dims;
     if (const char* v = std::getenv("WAX_HIP_BATCH_REGA")) {  // default of the "batch_rega" tunable (A/B runs of the whole test suite)
         const long m = std::strtol(v, nullptr, 10);
-        if (m >= 0 && m <= 4) e->batch_rega = m;
+        if (m >= 0 && m <= 5) e->batch_rega = m;
     }
     int rc = resize_store(e, WAX_HIP_INITIAL_RESERVE);  // :225-229
     if (rc == WAX_HIP_OK) {
