@@ -341,7 +341,8 @@ int wax_hip_stats(wax_hip_engine* e, wax_hip_stats_t* out);
  * event: one packet less between scans; 0 = every scan records its own start), "filter_device_min" (wax_hip_search_filtered: allow-lists at least this long are resolved by
  * the device-side id -> row table instead of host probes, default 4096; -1 = never),
  * "batch_slab_mb", "batch_growth", "batch_first" (slab schedule of the slab pipeline), "batch_rega" (0 LDS-tiled GEMM
- * only; 5 (default) register-resident GEMM, register staging, split tile barrier; 1 the same with a workgroup barrier per tile; 2 LDS-DMA
+ * only; 5 (default) register-resident GEMM, register staging, split tile barrier (the 768-d kernel: below 4 096 tiles per workgroup;
+ * 6 = at every size); 1 the same with a workgroup barrier per tile; 2 LDS-DMA
  * staging; 3 one wave per SIMD; 4 free-running: no tile barrier, three LDS tiles, D <= 384 — a faster kernel alone, slower pipelined
  * because its 150 KB of LDS keep the neighbouring batch's kernels off the CU: DESIGN.md), "batch_debug" (timing experiments:
  * results are NOT valid with bits 1/2/4/8/4096 set). get-only: "variant_count", "scan_grid", "fused_max_k", "batch_queries",

@@ -1566,7 +1566,7 @@ static hipError_t launch_rega(const GemmArgs& a, hipStream_t st) {
             return launch_rega_impl<D, false, AHEAD, false, 1>(a, st);
         }
     }
-    if (a.use_rega == 5u) {
+    if (a.use_rega == 5u || a.use_rega == 6u) {   // 6: like 5, and the K-split kernel keeps the split barrier at every size
         if constexpr (D == 384) {
             if (a.debug & 1024u) return launch_rega_impl<D, false, AHEAD, true, 2>(a, st);
         }
@@ -1602,9 +1602,17 @@ hipError_t launch_batch_gemm(const GemmArgs& a, int metric, hipStream_t st) {
                 switch ((a.debug >> 8) & 3u) {   // timing experiments: B-fragment read-ahead depth
                     case 1: return launch_ksplit<768, 6>(a, st);
                     case 2: return launch_ksplit<768, 8>(a, st);
-                    default:
-                        if (a.use_rega == 1u) return launch_ksplit<768, 4, false>(a, st);   // "batch_rega" = 1: workgroup barrier per tile (rounds 1-2)
+                    default: {
+                        // The split barrier wins on short launches (1.25M rows: +1.2 % alone, +2.5 % pipelined) and LOSES 4 % on
+                        // the 16 ms launch over 10M rows (profiles/r03/zi_ksplit_split_barrier_by_size.txt) — long enough for the
+                        // power limit to set the clock, where the busier pipe buys nothing and the polling costs: workgroup barrier
+                        // from 4 096 tiles per workgroup up. ("batch_rega" = 1 forces the workgroup barrier, 6 the split one.)
+                        uint32_t groups = 1, per_group = 1;
+                        rega_geometry(a, &groups, &per_group);
+                        const uint32_t tiles_per_wg = ((a.slab_rows + 31u) / 32u + per_group - 1u) / per_group;
+                        if (a.use_rega == 1u || (a.use_rega != 6u && tiles_per_wg > 4096u)) return launch_ksplit<768, 4, false>(a, st);
                         return launch_ksplit<768, 4>(a, st);
+                    }
                 }
             default: break;
         }
