@@ -1266,6 +1266,27 @@ def test_batch_gemm_variants_agree(wax, dims):
     eng.close()
 
 
+@pytest.mark.parametrize("dims", [384, 768])
+def test_split_barrier_timeout_is_fail_safe(wax, dims):
+    """The filtering GEMMs synchronise their tiles through LDS counters with BOUNDED spins (a protocol error must not hang the GPU).
+    A wave that gives up must not produce a silent wrong answer: its workgroup reports every one of its queries as overflowed and
+    those queries are answered by the exact path. "batch_debug" bit 14 makes one wave of workgroup 1 pretend it timed out."""
+    n = 160_000
+    corpus = oracle.gaussian_unit_rows(21, n, dims)
+    eng = make_engine(wax, 0, dims, corpus)
+    queries = oracle.gaussian_unit_queries(300, dims, seed=5)
+    ref = eng.searchBatch(queries, 10)
+    f0 = eng.getTuning("batch_fallbacks")
+    eng.setTuning("batch_debug", 16384)
+    got = eng.searchBatch(queries, 10)
+    eng.setTuning("batch_debug", 0)
+    hit = eng.getTuning("batch_fallbacks") - f0
+    assert hit >= 128, hit                                   # one workgroup's queries (256 at D <= 512, 128 at D = 768) took the exact path
+    for a, b in zip(got, ref):
+        assert np.array_equal(a, b)
+    eng.close()
+
+
 def test_batch_randomised_soak(wax):
     """Seeded random sweep of the batched path: ragged corpus sizes (partial last tiles of every GEMM variant), query
     counts that are not multiples of the 128/256-query groups, k up to the MFMA limit, every staging mode and several

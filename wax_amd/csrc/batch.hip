@@ -525,6 +525,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
         sim_s[wave * 32 + lane] = (1.0f - tq) - 4e-7f * (1.0f + __builtin_fabsf(tq));
     }
     if (tid < 256) cnt_s[tid] = 0u;
+    if (SYNC != 0 && tid == 0) next_s[3] = 0u;                                 // "a wave gave up waiting" (see wait_count)
     if (FREE && tid < 3) {
         stored_s[tid] = tid < 2 ? 8u : 0u;                                     // tiles 0 and 1 are staged by the prologue, behind a barrier
         read_s[tid] = 0u;
@@ -648,14 +649,18 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
     // `st_dst` != nullptr: the next tile's staged segments (regs[], loaded at the top of the iteration) are written to LDS
     // from INSIDE the K loop — piece p in front of k-step KS/2 + 2p — instead of in one burst after it: the burst was a
     // phase of ~600 LDS cycles per tile in which no wave of the workgroup had MFMAs left to issue.
-    // FREE: spin until counter `ctr` (LDS) shows `target`. Wave-uniform; bounded, so that a protocol error shows up as wrong
-    // answers in the parity tests instead of a hung GPU.
+    // FREE / SPLIT: spin until counter `ctr` (LDS) shows `target`. Wave-uniform. Bounded (~0.3 s), so that a protocol error cannot
+    // hang the GPU — and a wave that gives up says so: the workgroup then reports every one of its queries as overflowed
+    // (count 2^30, below), which sends them to the exact path. Never a silent wrong answer.
+    bool gave_up = SYNC != 0 && (a.debug & 16384u) != 0 && blockIdx.x == 1 && wave == 3;   // debug bit 14: pretend one wave timed out (tests)
     auto wait_count = [&](const unsigned int* ctr, unsigned int target) {
+        bool ok = false;
         for (unsigned int spins = 0; spins < (1u << 22); ++spins) {
             const unsigned int v = __hip_atomic_load((const lds_u32*)ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if ((unsigned int)__builtin_amdgcn_readfirstlane((int)v) >= target) break;
+            if ((unsigned int)__builtin_amdgcn_readfirstlane((int)v) >= target) { ok = true; break; }
             __builtin_amdgcn_s_sleep(1);
         }
+        if (!ok) gave_up = true;
         asm volatile("" ::: "memory");
     };
     // FREE: one signal per wave, behind everything the wave has issued to the LDS so far (a wave's DS operations execute in
@@ -891,9 +896,13 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
         printf("WAXPROF rega D=%d blk %u wave %d tiles %u mfma %llu select %llu barrier %llu total %llu\n", D, (unsigned)blockIdx.x, wave, it,
                prof_mfma, prof_sel, prof_bar, (unsigned long long)(__builtin_amdgcn_s_memtime() - prof_t0));
     if (late && it > 0) select_tile(t_prev);
+    if (SYNC != 0 && gave_up && lane == 0) __hip_atomic_fetch_or((lds_u32*)(next_s + 3), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     // unclamped counts: a count above seg_slots tells tighten_kernel that survivors were dropped (query -> exact path)
     __syncthreads();
-    if (!SAMPLE && tid < 256) a.seg_count[(size_t)bidx * (a.nqt * 128u) + group * 256u + (uint32_t)tid] = cnt_s[tid];
+    if (!SAMPLE && tid < 256) {
+        const bool poisoned = SYNC != 0 && next_s[3] != 0u;   // a wave gave up waiting: nothing this workgroup selected can be trusted
+        a.seg_count[(size_t)bidx * (a.nqt * 128u) + group * 256u + (uint32_t)tid] = poisoned ? 0x40000000u : cnt_s[tid];
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -951,6 +960,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_ksplit_kernel(GemmArgs a, u
         for (int ks = 0; ks < KS; ++ks) fa[ks] = __builtin_bit_cast(bf16x8, qp[ks * 2]);
     }
     if (SPLIT && tid < 5) done_s[tid] = 0u;   // done + parked[4]
+    if (SPLIT && tid == 5) next_s[3] = 0u;    // "a wave gave up waiting"
     if (owner && lane < 32) {
         const float tq = SAMPLE ? 0.f : a.tau[q0 + lane];
         tau_s[pair * 32 + lane] = tq;
@@ -1065,13 +1075,16 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_ksplit_kernel(GemmArgs a, u
         }
     };
 
-    // SPLIT: see batch_gemm_rega_kernel (bounded spin: a protocol error must show up as wrong answers, not as a hung GPU)
+    // SPLIT: see batch_gemm_rega_kernel (bounded spin; a wave that gives up poisons the workgroup's counts -> exact path)
+    bool gave_up = SPLIT && (a.debug & 16384u) != 0 && blockIdx.x == 1 && wave == 3;   // debug bit 14: pretend one wave timed out (tests)
     auto wait_count = [&](const unsigned int* ctr, unsigned int target) {
+        bool ok = false;
         for (unsigned int spins = 0; spins < (1u << 22); ++spins) {
             const unsigned int v = __hip_atomic_load((const lds_u32*)ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if ((unsigned int)__builtin_amdgcn_readfirstlane((int)v) >= target) break;
+            if ((unsigned int)__builtin_amdgcn_readfirstlane((int)v) >= target) { ok = true; break; }
             __builtin_amdgcn_s_sleep(1);
         }
+        if (!ok) gave_up = true;
         asm volatile("" ::: "memory");
     };
     auto signal_count = [&](unsigned int* ctr) {
@@ -1145,7 +1158,10 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_ksplit_kernel(GemmArgs a, u
     }
     if (SPLIT && owner && it > 0) wait_count(parked_s + pair, it);
     if (owner && it > 0) select_tile(t_prev, (it - 1u) & 1u);
+    if (SPLIT && gave_up && lane == 0) __hip_atomic_fetch_or((lds_u32*)(next_s + 3), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __syncthreads();
+    if (SPLIT && next_s[3] != 0u && tid < 128) cnt_s[tid] = 0x40000000u;   // nothing this workgroup selected can be trusted -> exact path
+    if (SPLIT) __syncthreads();
     if (!SAMPLE && tid < 128) a.seg_count[(size_t)bidx * (a.nqt * 128u) + group * 128u + (uint32_t)tid] = cnt_s[tid];
 }
 
