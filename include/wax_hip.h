@@ -328,9 +328,10 @@ int wax_hip_stats(wax_hip_engine* e, wax_hip_stats_t* out);
  * "batch_onepass" (0 = always the slab pipeline), "batch_onepass_tiles" (smallest store, in 64-row GEMM tiles, that the one-pass
  * pipeline takes; default 1024), "batch_survivors" (one-pass: floor of the expected survivors per query as a multiple of k', default 3),
  * "batch_sample_div" (one-pass: 1/this of the tiles are sampled for the thresholds, default 32, at most 512 tiles / 8 tile rounds), "batch_workspaces" (concurrent
- * batched searches per engine, default 4), "batch_retry" (one-pass pipeline: 1 = an uncertified query's survivors are re-scored up to 960 deep before the exact path; default 1),
+ * batched searches per engine, default 4), "batch_retry" (one-pass pipeline: 1 = an uncertified query gets a full retry — ALL of its survivors re-scored exactly — before the exact path; default 1),
  * "batch_dynamic" (one-pass pipeline: 1 = the filtering GEMM's workgroups claim their tiles from a counter instead of a static
- * stride, so that a workgroup delayed by another batch's kernels does not finish last; measured no faster, default 0),
+ * stride, so that a workgroup delayed by another batch's kernels does not finish last; measured no faster, default 0; only the
+ * workgroup-barrier kernel ("batch_rega" = 1) implements it — the split / free-running barriers of "batch_rega" 5 / 6 / 3 ignore it),
  * "batch_multi" (exact path of a batch: 1 (default) = uncertified queries share passes over the f32 store, up to 16 per pass, with the
  * single-query kernel's arithmetic — bit-identical results; 0 = one scan per query), "fuse_merge" (1 (default) = on grids of at most 160
  * workgroups the scan kernel's last-arriving workgroup does the final merge: one launch per query instead of two),

@@ -320,3 +320,75 @@ def test_bench_deterministic_embedder_rows_match_the_oracle():
             assert np.max(np.abs(got[i - lo] - exp)) <= 3e-7, (i, got[i - lo][:4], exp[:4])
             raw = oracle.deterministic_embed(f"doc-{i}", dims, normalize=False)
             assert np.allclose(got[i - lo] * np.linalg.norm(raw.astype(np.float64)), raw, atol=1e-6)
+
+
+def _load_bench():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("wax_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+def _synthetic_full_record(bench, n_secondary, prose=1200):
+    """A record shaped like bench.py's full output with every prose field at `prose` bytes — the shape that grew to 22 KB in
+    round 3 and fell out of the driver's stdout tail."""
+    blah = "x" * prose
+    roof = {"bound": "hbm", "achieved": 6986.123456789, "peak": 8000.0, "unit": "GB/s", "frac": 0.873265432, "pipeline_achieved": 7064.9,
+            "pipeline_frac": 0.8831123, "traffic": 15360180224.0, "traffic_source": blah, "kernel": "wax::scan_kernel (fused scan + per-wave top-k)",
+            "kernel_avg_ms": 2.1987654321, "kernel_launches_timed": 60, "algorithmic_bytes_per_launch": 15360000000,
+            "calibration": {"steps": 60, "ms_per_step": 2.21, "mode": blah}, "note": blah, "mfma_sustained_source": blah}
+    sec = []
+    for i in range(n_secondary):
+        sec.append({"name": f"clustered_k100_{i}", "config": blah, "value": 1092655.338450946, "unit": "queries/s", "steps": 100, "warmup": 10,
+                    "ms_per_step": 0.23429162974935025, "dtype": "bf16 GEMM, exact f32 re-score", "queries_per_step": 256,
+                    "last_result_checksum": "0123456789abcdef", "roofline": dict(roof), "n_gpus": 8 if i % 2 else 1})
+    sec.append({"name": "broken", "error": "RuntimeError: " + blah})
+    return {
+        "metric": "queries/sec, 10M x 384-dim f32 cosine top-10 brute-force scan (single query per step)", "value": 460.4123456789,
+        "unit": "queries/s", "n_gpus": 8, "steps": 200, "warmup": 20, "ms_per_step": 2.17198765, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": blah, "workload_short": "10M x 384 f32 unit-Gaussian corpus in HBM, cosine top-10, 1 query/step", "rows": 10_000_000,
+                   "dims": 384, "top_k": 10, "rows_per_gpu": 1_250_048, "parallelism": blah, "parallelism_short": "row-shard x8 rccl all_gather",
+                   "pipeline_depth": 4, "timed_region": blah, "merge": "device", "exchange": "rccl all_gather", "rccl_ranks": 8, "shards": 8,
+                   "last_result_checksum": "fedcba9876543210"},
+        "roofline": roof,
+        "cpu_baseline": {"value": 7.93, "unit": "queries/s", "cores": 16, "kind": "port", "sample": blah,
+                         "sample_short": "95 queries over the first 1000000 rows in 12.0 s, x1000000/10000000 rows; 122 GB/s",
+                         "variants": [{"threads": 1, "value": 0.53, "sample": blah}, {"threads": 16, "value": 7.93, "sample": blah}]},
+        "secondary": sec,
+    }
+
+
+def test_bench_line_stays_inside_the_drivers_stdout_tail(tmp_path, capsys):
+    """The contract line must survive a bounded stdout tail: ONE line, < 4 KB, with every contract key, `roofline` and
+    `cpu_baseline` — whatever prose the full record carries (that goes to the detail file). Round 3's line was 22 KB."""
+    import json
+    bench = _load_bench()
+    full = _synthetic_full_record(bench, n_secondary=12)
+    assert len(json.dumps(full)) > 20_000                      # the round-3 shape
+    line = bench.compact_line(full)
+    text = json.dumps(line, separators=(",", ":"))
+    assert len(text) < bench.LINE_BUDGET == 4096, len(text)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline", "secondary"):
+        assert key in line, key
+    assert line["config"]["workload"].startswith("10M x 384") and line["config"]["rccl_ranks"] == 8 and line["config"]["checksum"] == "fedcba9876543210"
+    assert set(line["roofline"]) == {"bound", "achieved", "peak", "unit", "frac", "pipeline_frac", "kernel", "kernel_avg_ms",
+                                     "kernel_launches_timed", "algorithmic_bytes_per_launch", "traffic"}
+    assert line["roofline"]["kernel"] == "wax::scan_kernel" and abs(line["roofline"]["frac"] - 0.873265) < 1e-6
+    assert line["cpu_baseline"]["cores"] == 16 and line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value_1_thread"] == 0.53
+    assert all(set(x) <= {"name", "value", "ms_per_step", "frac", "kernel_avg_ms", "n_gpus", "ck", "blocking_ms", "error"} for x in line["secondary"])
+    assert line["secondary"][-1]["name"] == "broken" and len(line["secondary"][-1]["error"]) <= 80
+    # emit(): detail file written, stdout carries exactly one line, and that line parses and is the compact one
+    detail = tmp_path / "detail.json"
+    bench.emit(full, str(detail))
+    out = capsys.readouterr().out
+    assert out.count("\n") == 1 and len(out) < 4096 and json.loads(out)["value"] == 460.412
+    assert json.load(open(detail))["roofline"]["note"] == "x" * 1200
+    # an absurd record (60 secondaries) still yields a bounded line: the secondaries are dropped, never the headline
+    bench.emit(_synthetic_full_record(bench, n_secondary=60), str(detail))
+    out = capsys.readouterr().out
+    j = json.loads(out)
+    assert len(out) < 4096 and "secondary_dropped" in j and j["roofline"]["frac"] and j["cpu_baseline"]["cores"] == 16

@@ -815,10 +815,24 @@ def _run_bench(nproc, extra, tmp_path, one_process=False):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
                "--master-addr", "127.0.0.1", "--master-port", str(29600 + nproc),
                os.path.join(root, "bench.py"), "--gpus", str(nproc), "--exchange", "host"] + common
+    detail = os.path.join(str(tmp_path), f"bench_detail_{nproc}_{int(one_process)}_{abs(hash(tuple(extra))) % 10**8}.json")
+    cmd += ["--detail-out", detail]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
-    line = [l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1]
-    return json.loads(line)
+    # the contract: the LAST line of stdout is the one JSON line, and it fits a bounded tail (the driver keeps ~8 KB; round 3's
+    # 22 KB line was cut and the round went unrecorded)
+    last = out.stdout.strip().splitlines()[-1]
+    assert last.startswith("{") and len(last) < 4096, (len(last), last[:200])
+    line = json.loads(last)
+    full = json.load(open(detail))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline"):
+        assert key in line, key
+    assert abs(line["value"] - full["value"]) <= 1e-5 * full["value"] and line["config"]["checksum"] == full["config"]["last_result_checksum"]
+    assert abs(line["roofline"]["frac"] - full["roofline"]["frac"]) < 1e-5 and line["roofline"]["kernel"] == "wax::scan_kernel"
+    assert [x["name"] for x in line.get("secondary", [])] == [x["name"] for x in full.get("secondary", [])]
+    full["_line"] = line
+    return full
 
 
 def test_bench_contract_and_shard_invariance(wax, tmp_path):
@@ -834,6 +848,8 @@ def test_bench_contract_and_shard_invariance(wax, tmp_path):
     assert abs(r["pipeline_frac"] - 300000 * 384 * 4 * 12 / (one["ms_per_step"] * 12e-3) / 1e9 / 8000.0) < 1e-6
     assert abs(one["value"] - 12 / (one["ms_per_step"] * 12e-3)) < 1e-6 * one["value"]
     assert "300K x 384" in one["metric"] and one["config"]["parallelism"] == "row-shard x1"
+    assert one["_line"]["config"]["rccl_ranks"] == 0 and one["_line"]["config"]["parallelism"] == "row-shard x1"
+    assert "cpu_baseline" in one["_line"]
     assert r["traffic"] is None and r["traffic_source"] is None      # no counter pass exists for this row count
     sec = one["secondary"]
     assert [x["name"] for x in sec] == ["s10k", "s1m", "b1m_q256", "b1m_q1024", "c5_shard", "c5_full", "clustered_k10", "s1250k"]

@@ -51,11 +51,32 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 return LIB_PATH
             fd, tmp = tempfile.mkstemp(prefix=".libwaxhip.", suffix=".so", dir=LIB_DIR)
             os.close(fd)
-            cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-                   "-I" + os.path.join(ROOT, "include"), "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
-            if verbose:
-                print(" ".join(cmd), file=sys.stderr)
+            # one object per translation unit, compiled side by side and only when stale (a unit depends on its own source
+            # and on every header: the headers are few and shared), then one link
+            obj_dir = os.path.join(LIB_DIR, "obj")
+            os.makedirs(obj_dir, exist_ok=True)
+            hdr_t = max(os.path.getmtime(h if os.path.isabs(h) else os.path.join(CSRC, h)) for h in HEADERS)
+            flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include")]
+
+            def compile_one(src):
+                obj = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
+                path = os.path.join(CSRC, src)
+                if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), hdr_t):
+                    return obj
+                cmd = [_hipcc()] + flags + ["-c", path, "-o", obj + ".tmp"]
+                if verbose:
+                    print(" ".join(cmd), file=sys.stderr)
+                subprocess.run(cmd, check=True)
+                os.replace(obj + ".tmp", obj)
+                return obj
+
             try:
+                from concurrent.futures import ThreadPoolExecutor
+                with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 2)) as pool:
+                    objs = list(pool.map(compile_one, SOURCES))
+                cmd = [_hipcc(), f"--offload-arch={ARCH}", "-fPIC", "-shared", "-o", tmp] + objs
+                if verbose:
+                    print(" ".join(cmd), file=sys.stderr)
                 subprocess.run(cmd, check=True)
                 os.chmod(tmp, 0o755)
                 os.replace(tmp, LIB_PATH)

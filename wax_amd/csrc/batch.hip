@@ -825,7 +825,9 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
             }
         }
         // debug bit7: the staged tile goes to LDS in one burst after the K loop (the round-1 schedule), for A/B timing
-        const bool spread = !GLDS && (FREE || !(a.debug & 128u));
+        // (ignored by the split / free-running barriers: their arrival is signalled right after the K loop, so a burst
+        // stored after it would not be covered and other waves could read a half-written tile)
+        const bool spread = !GLDS && (FREE || SPLIT || !(a.debug & 128u));
         unsigned char* st_dst = (!GLDS && spread && tn < ntiles && !dbg_noload) ? nxt + srow * ROW_B + sseg : nullptr;
         // FREE: tile `it` is fill it / 3 + 1 of its buffer; the buffer being refilled was read as tile it - 1
         const unsigned int raw_target = 8u * (it / 3u + 1u), war_target = it ? 8u * ((it - 1u) / 3u + 1u) : 0u;

@@ -559,6 +559,9 @@ int alloc_slot(wax_hip_engine* e, Slot** out) {
     if ((err = hipHostMalloc(&s->h_query, qbytes, hipHostMallocDefault)) != hipSuccess) return bail(WAX_HIP_ERR_ALLOC, "pinned query buffer", err);
     if ((err = hipMalloc(&s->d_partials, kPartialsBytes)) != hipSuccess) return bail(WAX_HIP_ERR_ALLOC, "top-k stage buffer", err);
     if ((err = hipMemset(partials_ticket(s->d_partials), 0, 128)) != hipSuccess) return bail(WAX_HIP_ERR_ALLOC, "top-k stage buffer", err);
+    // hipMemset on device memory may return before the fill has run, and the slot's scans run on non-blocking streams the
+    // null stream does not order against: wait once, here, so the first fused scan can only ever see an armed (zero) ticket
+    if ((err = hipStreamSynchronize(nullptr)) != hipSuccess) return bail(WAX_HIP_ERR_ALLOC, "top-k stage buffer", err);
     if ((err = hipMalloc(&s->d_hits, (size_t)WAX_HIP_MAX_RESULTS * sizeof(wax_hip_hit))) != hipSuccess) return bail(WAX_HIP_ERR_ALLOC, "top-k results buffer", err);
     if ((err = hipHostMalloc(&s->h_hits, (size_t)WAX_HIP_MAX_RESULTS * sizeof(wax_hip_hit), hipHostMallocDefault)) != hipSuccess) return bail(WAX_HIP_ERR_ALLOC, "pinned results buffer", err);
     *out = s;
@@ -1966,6 +1969,15 @@ static int collect_impl(wax_hip_engine* e, uint64_t ticket, uint64_t* out_ids, f
         hipError_t err = hipEventSynchronize(s->ev_done);   // commandBuffer completion (:577-582); later queries on the stream keep running
         if (err != hipSuccess) {
             rc = fail(WAX_HIP_ERR_INTERNAL, std::string("search failed on device: ") + hipGetErrorString(err));
+            // a scan that died part-way leaves its fused-merge ticket half counted; no later scan on this slot could ever be
+            // "last arriver" again and callers would read stale hits with no error. Re-arm it (best effort: after a device
+            // fault the runtime usually refuses this too, and every later call on the slot then fails loudly as well).
+            std::string keep = g_last_error;
+            (void)hipStreamSynchronize(s->stream);
+            (void)hipMemsetAsync(partials_ticket(s->d_partials), 0, 128, s->stream);
+            (void)hipStreamSynchronize(s->stream);
+            (void)hipGetLastError();
+            g_last_error = keep;
         } else {
             if (s->timed) {
                 float ms = 0.f;
@@ -2148,6 +2160,25 @@ int wax_hip_search_batch(wax_hip_engine* e, const float* queries, uint32_t nq, u
 // library's own stream waits for it), and on return every result is complete. The only PCIe traffic is nq
 // certificate flags + norms (8 bytes per query) — or the query block itself when the batch has to take the loop path.
 // Shared body of the blocking and the pipelined device-resident batch search. ticket == nullptr: blocking.
+// Would wax_hip_search_batch_submit_device on this (single-device) engine finish device work before it returns? True for
+// everything but the asynchronous MFMA pipeline with a ready mirror: the loop path (dims not a multiple of 64, k beyond the
+// MFMA limits, batch_mode = 0, small nq under the cost model) ends with a stream synchronise, and a mirror (re)build is
+// synchronous too. The sharded handle asks before it decides whether ONE thread may drive every shard's submit
+// (sharded.inc: sh_batch_submit). Conservative for nq < 16 (the cost model has a side effect; a worker hop costs microseconds).
+bool batch_submit_blocks(wax_hip_engine* e, uint32_t dims, int32_t top_k, uint32_t nq, uint32_t out_stride) {
+    if (nq == 0 || e->count == 0) return false;
+    const uint64_t limit = (uint64_t)clamp_topk(top_k);
+    uint64_t k64 = limit < e->count ? limit : e->count;
+    if (k64 > out_stride) k64 = out_stride;
+    if (k64 == 0) return false;
+    OnepassPlan plan{};
+    bool onepass = false;
+    if ((int64_t)nq < e->batch_min.load() || nq < 16) return true;
+    if (!batch_mfma_applicable(e, dims, (int)k64, nq, &plan, &onepass)) return true;
+    if (e->pend_rows.load() != 0) return true;               // staged appends are flushed (and the mirror rebuilt) inside submit
+    return !(e->batch.mirror_valid.load(std::memory_order_acquire) && e->batch.mirror_cap >= e->capacity);
+}
+
 static int batch_device_impl(wax_hip_engine* e, const float* d_queries, uint32_t nq, uint32_t dims, int32_t top_k,
                              wax_hip_hit* d_out_hits, uint32_t out_stride, void* stream, uint64_t* ticket, const char* what) {
     if (ticket) *ticket = 0;
@@ -2324,6 +2355,7 @@ static int search_shard_device_impl(wax_hip_engine* e, const float* query, uint3
                 if (err == hipSuccess) err = hipHostMalloc(&e->ring_h_query[r], (size_t)e->dims * sizeof(float), hipHostMallocDefault);
                 if (err == hipSuccess) err = hipMalloc(&e->ring_d_partials[r], kPartialsBytes);
                 if (err == hipSuccess) err = hipMemset(partials_ticket(e->ring_d_partials[r]), 0, 128);
+                if (err == hipSuccess) err = hipStreamSynchronize(nullptr);   // ordered before any scan on the shard's own stream
                 if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ring_ev0[r], hipEventReleaseToDevice);
                 if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ring_ev1[r], hipEventReleaseToDevice);
                 if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ring_done[r], hipEventDisableTiming);

@@ -319,10 +319,12 @@ int scan_grid_for(uint32_t n_rows, uint32_t dims, int variant, int grid_cap) {
     const uint64_t nchunks = ((uint64_t)n_rows + info.rows_per_chunk - 1) / info.rows_per_chunk;
     const uint64_t max_waves = (uint64_t)grid_cap * SCAN_WAVES;
     uint64_t waves = nchunks;
-    if (nchunks <= max_waves && nchunks >= 64) {
+    const uint64_t halved_blocks = ((nchunks + 1) / 2 + SCAN_WAVES - 1) / SCAN_WAVES;
+    if (nchunks <= max_waves && nchunks >= 64 && halved_blocks <= (uint64_t)SCAN_FUSE_MERGE_GRID) {
         // Small stores (<= 16 K rows at 8 rows per chunk): two chunks per wave. The scan is a couple of HBM round trips
         // either way, but half the workgroups means half the partial lists — few enough (<= SCAN_FUSE_MERGE_GRID) for the
-        // last-arriving workgroup to do the final merge itself instead of a second launch.
+        // last-arriving workgroup to do the final merge itself instead of a second launch. Only where the halved grid
+        // really fits the fused merge: a mid-size store (e.g. 2048 chunks) keeps one chunk per wave and its full parallelism.
         waves = (nchunks + 1) / 2;
     } else if (nchunks > max_waves) {
         // Balance the grid-stride loop: every wave runs the same number of iterations (+-1 chunk
