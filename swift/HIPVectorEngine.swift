@@ -65,13 +65,21 @@ public actor HIPVectorEngine {
         self.dimensions = dimensions
     }
 
-    /// Every gfx950 device of the node (what `.auto` / `.hipPreferred` use when more than one is visible).
+    /// Every gfx950 device of the node: pass it as `devices:` to opt into the row-sharded engine.
     public static var allDevices: [Int32] { (0..<wax_hip_device_count()).map { Int32($0) } }
 
-    public static func load(from wax: Wax, metric: VectorMetric, dimensions: Int) async throws -> HIPVectorEngine {
-        let devices = allDevices
-        let engine = devices.count > 1 ? try HIPVectorEngine(metric: metric, dimensions: dimensions, devices: devices)
-                                       : try HIPVectorEngine(metric: metric, dimensions: dimensions)
+    /// `devices: nil` (the default) = ONE device, like every other engine in this package. Row-sharding over several GPUs is
+    /// opt-in (`devices: HIPVectorEngine.allDevices`, or an explicit list): the sharded handle has been verified on a single
+    /// GPU only (every shard on device 0), and a loader must not silently take a multi-device code path no node has run yet.
+    public static func load(from wax: Wax, metric: VectorMetric, dimensions: Int, devices: [Int32]? = nil) async throws -> HIPVectorEngine {
+        let engine: HIPVectorEngine
+        if let devices, devices.count > 1 {
+            engine = try HIPVectorEngine(metric: metric, dimensions: dimensions, devices: devices)
+        } else if let d = devices?.first {
+            engine = try HIPVectorEngine(metric: metric, dimensions: dimensions, devices: [d])
+        } else {
+            engine = try HIPVectorEngine(metric: metric, dimensions: dimensions)
+        }
         if let bytes = try await wax.readCommittedVecIndexBytes() { try await engine.deserialize(bytes) }
         for e in await wax.pendingEmbeddingMutations() { try await engine.add(frameId: e.frameId, vector: e.vector) }
         return engine

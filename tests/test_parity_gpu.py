@@ -1262,8 +1262,13 @@ def test_batch_gemm_variants_agree(wax, dims):
     eng = make_engine(wax, 0, dims, corpus)
     queries = oracle.gaussian_unit_queries(300, dims, seed=31)
     ref = None
-    for onepass, rega, growth in [(0, 1, 8), (0, 1, 3), (0, 2, 8), (0, 2, 3), (0, 0, 8), (0, 0, 3), (0, 3, 8), (0, 3, 3), (1, 1, 8), (1, 2, 8),
-                                  (1, 3, 8), (1, 4, 8), (0, 4, 3), (1, 5, 8), (0, 5, 3)]:   # rega 3 = one wave per SIMD (D <= 512), LDS-DMA ring; 5 = split barrier (the default)
+    for onepass, rega, growth, *dbg in [(0, 1, 8), (0, 1, 3), (0, 2, 8), (0, 2, 3), (0, 0, 8), (0, 0, 3), (0, 3, 8), (0, 3, 3), (1, 1, 8), (1, 2, 8),
+                                  (1, 3, 8), (1, 4, 8), (0, 4, 3), (1, 5, 8), (0, 5, 3),
+                                  # D = 768: 1 / 6 / 7 = the K-split kernel (workgroup barrier / split barrier / its size rule), every other
+                                  # value the wide kernel (whole K per wave, LDS-DMA staging) — whose build variants sit behind batch_debug
+                                  # bits 8-9: two LDS tile buffers, two accumulator chains, read-ahead 3
+                                  (1, 6, 8), (1, 7, 8), (0, 7, 3), (1, 5, 8, 256), (1, 5, 8, 512), (0, 5, 3, 768), (1, 2, 8, 256)]:
+        eng.setTuning("batch_debug", dbg[0] if dbg else 0)
         eng.setTuning("batch_onepass", onepass)
         eng.setTuning("batch_rega", rega)
         eng.setTuning("batch_growth", growth)
@@ -1278,6 +1283,7 @@ def test_batch_gemm_variants_agree(wax, dims):
                 assert np.array_equal(ids[i], s_ids) and np.array_equal(scores[i], s_scores)
         else:
             assert np.array_equal(ids, ref[0]) and np.array_equal(scores, ref[1]) and np.array_equal(counts, ref[2])
+    eng.setTuning("batch_debug", 0)
     assert eng.getTuning("batch_fallbacks") <= 80
     eng.close()
 
@@ -1291,6 +1297,8 @@ def test_split_barrier_timeout_is_fail_safe(wax, dims):
     corpus = oracle.gaussian_unit_rows(21, n, dims)
     eng = make_engine(wax, 0, dims, corpus)
     queries = oracle.gaussian_unit_queries(300, dims, seed=5)
+    if dims == 768:
+        eng.setTuning("batch_rega", 6)                       # the K-split kernel with its split barrier (the default 768-d kernel has a plain workgroup barrier)
     ref = eng.searchBatch(queries, 10)
     f0 = eng.getTuning("batch_fallbacks")
     eng.setTuning("batch_debug", 16384)
@@ -1318,7 +1326,7 @@ def test_batch_randomised_soak(wax):
         if metric != 0:
             corpus = corpus * rng.uniform(0.5, 1.5, (n, 1)).astype(np.float32)
         eng = make_engine(wax, metric, dims, corpus)
-        eng.setTuning("batch_rega", int(rng.choice([1, 2, 3, 4, 5, 5])))
+        eng.setTuning("batch_rega", int(rng.choice([1, 2, 3, 4, 5, 5, 7])))
         eng.setTuning("batch_growth", int(rng.choice([3, 8, 16])))
         eng.setTuning("batch_first", int(rng.choice([512, 2048])))
         queries = oracle.gaussian_unit_queries(nq, dims, seed=500 + trial)

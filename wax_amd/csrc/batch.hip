@@ -1168,6 +1168,230 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_ksplit_kernel(GemmArgs a, u
 }
 
 // ---------------------------------------------------------------------------
+// Register-resident-queries GEMM for D = 768, WHOLE K per wave ("wide": the default for 768 since round 4).
+//
+// The K-split kernel above is bound by the LDS port, not by the matrix pipe (profiles/r04: per 32-row tile a CU's eight waves
+// issue 192 ds_read_b128 = 768 LDS cycles, the staging stores ~620 and the partial-sum exchange ~270, against 1 536 matrix
+// cycles per SIMD): a tile staged in LDS is multiplied against only 128 queries. Here a wave keeps its 32 queries x 768 as
+// 192 VGPRs of A fragments — which fits beside ONE 16-register accumulator once nothing else needs registers:
+//   * staging is LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass — the DMA does not go through the
+//     VGPR -> LDS transfer path that limits ds_write_b128 to ~79 B/clk), NBUF tile buffers, requested NBUF - 1 tiles ahead;
+//   * one accumulator chain (a 32x32x16 MFMA accumulates back-to-back into the same registers without a stall; the other
+//     wave of the SIMD fills the pipe between them anyway);
+//   * the selection's bounds are read after the B-fragment ring has died.
+// A workgroup is 8 waves = 256 queries (as for D <= 512), tiles are 32 rows: per tile a wave issues 48 MFMAs against
+// 48 ds_read_b128 — the LDS reads per MFMA of the 384-d kernel — and a staged byte is used by twice as many queries as in
+// the K-split kernel; no partial sums cross LDS. Per tile and CU: 3 072 matrix cycles per SIMD against 1 536 LDS cycles of
+// fragment reads + 48.5 KB of DMA writes.
+// The padded tile image (row stride 2D + 16 B: conflict-free ds_read_b128) is 48.5 KB; it is cut into 49 1-KB DMA pieces
+// (lane l of piece P fetches what belongs at slot 64 P + l; a row's pad slot re-fetches its last segment; the upper half of
+// the last piece lands in the buffer's 512 B of slack). Selection, survivor segments, thresholds, seg_count layout and the
+// "late" order of waves 4-7 are those of batch_gemm_rega_kernel, so the host side and batch_finish_kernel do not know
+// which kernel ran.
+template <int D, int NBUF, int AHEAD, bool SAMPLE = false, int CHAINS = 1>
+__global__ __launch_bounds__(512, 2) void batch_gemm_wide_kernel(GemmArgs a, uint32_t blocks_per_group) {
+    constexpr int KS = D / 16;                       // MFMA k-steps
+    constexpr int ROW_B = D * 2 + 16;                // LDS row stride (bytes); (ROW_B / 4) % 64 == 4
+    constexpr int TROWS = 32;                        // corpus rows per tile
+    constexpr int SEG_PER_ROW = D * 2 / 16;          // 16-byte segments per row
+    constexpr int SLOTS_PER_ROW = ROW_B / 16;        // 16-byte slots per padded row
+    constexpr int IMG_B = TROWS * ROW_B;             // padded tile image
+    constexpr int PIECES = (IMG_B + 1023) / 1024;    // 1-KB DMA pieces per tile
+    constexpr int BUF_B = PIECES * 1024;             // buffer stride (the image + slack for the last piece)
+    constexpr int PPW = (PIECES + 7) / 8;            // pieces per wave (waves with index >= PIECES % 8 carry one less)
+    constexpr int PRE = NBUF - 1;                    // tiles requested ahead of the one being read
+    static_assert(D % 64 == 0 && (ROW_B / 4) % 64 == 4, "row stride must keep ds_read_b128 conflict-free");
+    static_assert(NBUF * BUF_B + 3 * 8 * 32 * 4 + 64 <= 160 * 1024, "LDS budget of one CU");
+    static_assert(PIECES % 8 != 0, "dma_wait assumes a ragged split (wave 0 carries one piece more)");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* tau_s = reinterpret_cast<float*>(smem + NBUF * BUF_B);              // [8][32] exact thresholds
+    unsigned int* cnt_s = reinterpret_cast<unsigned int*>(tau_s + 8 * 32);     // [8][32] survivors per query (this workgroup)
+    float* sim_s = reinterpret_cast<float*>(cnt_s + 8 * 32);                   // [8][32] conservative similarity bounds
+
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const uint32_t group = blockIdx.x / blocks_per_group;   // 256 queries per group
+    const uint32_t bidx = blockIdx.x % blocks_per_group;
+    const uint32_t q0 = group * 256 + wave * 32;             // this wave's 32 queries
+
+    // A fragments: lane l holds query (l & 31), k = 16*ks + 8*(l >> 5) .. +7
+    bf16x8 fa[KS];
+    {
+        const u32x4* qp = reinterpret_cast<const u32x4*>(a.qb + (size_t)(q0 + (lane & 31)) * D) + (lane >> 5);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) fa[ks] = __builtin_bit_cast(bf16x8, qp[ks * 2]);
+    }
+    if (!SAMPLE && lane < 32) {
+        const float tq = a.tau[q0 + lane];
+        tau_s[wave * 32 + lane] = tq;
+        sim_s[wave * 32 + lane] = (1.0f - tq) - 4e-7f * (1.0f + __builtin_fabsf(tq));   // see batch_gemm_rega_kernel
+    }
+    if (tid < 256) cnt_s[tid] = 0u;
+    const uint32_t seg_slots = a.seg_area / blocks_per_group;
+    const uint32_t seg_lane0 = (q0 + 4u * ((uint32_t)lane >> 5)) * a.cand_cap + a.seg_base + bidx * seg_slots;
+
+    const uint32_t ntiles_all = (a.slab_rows + TROWS - 1) / TROWS;
+    const uint32_t ntiles = SAMPLE ? a.sample_tiles : ntiles_all;
+    const uint32_t slab_end = a.slab0 + a.slab_rows;
+    const unsigned char* cbase = reinterpret_cast<const unsigned char*>(a.cb);
+    auto phys = [&](uint32_t tile) -> uint32_t {
+        return SAMPLE ? (uint32_t)(((unsigned long long)tile * ntiles_all) / a.sample_tiles) : tile;
+    };
+
+    // LDS-DMA map, recomputed per piece (a handful of VALU against 48 MFMAs; tables would cost 2 * PPW VGPRs):
+    // wave w moves pieces w, w + 8, ...; lane l of piece P fills slot P*64 + l of the padded image
+    const bool full_wave = (uint32_t)wave < (uint32_t)(PIECES % 8);          // wave-uniform: carries PPW pieces, the others PPW - 1
+    auto dma_tile = [&](uint32_t tile, uint32_t buf_off) {
+        const uint32_t row0 = a.slab0 + phys(tile) * TROWS;
+        // opaque per call: left to itself hipcc hoists the loop-invariant slot -> (row, column) arithmetic of all PPW pieces
+        // out of the tile loop — 3 VGPRs per piece the A fragments have no room for (they were spilled to scratch, and every
+        // reload drained the DMA queue with an s_waitcnt vmcnt(0))
+        uint32_t lane_o = (uint32_t)lane;
+        asm volatile("" : "+v"(lane_o));
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            if (i < PPW - 1 || full_wave) {
+                const uint32_t P = (uint32_t)wave + 8u * i;
+                const uint32_t slot = P * 64u + lane_o;
+                uint32_t r = slot / (uint32_t)SLOTS_PER_ROW;
+                uint32_t c = slot - r * (uint32_t)SLOTS_PER_ROW;
+                c = c < (uint32_t)SEG_PER_ROW ? c : (uint32_t)SEG_PER_ROW - 1u;   // pad slot: any valid bytes
+                r = r < (uint32_t)TROWS ? r : (uint32_t)TROWS - 1u;               // slack behind the image: any valid bytes
+                uint32_t grow = row0 + r;
+                grow = grow < a.n_rows ? grow : a.n_rows - 1;                     // clamp: masked in the selection
+                const unsigned char* src = cbase + (size_t)grow * (D * 2) + c * 16u;
+                __builtin_amdgcn_global_load_lds((global_cvoid*)src, (lds_void*)(smem + buf_off + P * 1024u), 16, 0, 0);
+            }
+        }
+    };
+    // this wave's DMA requests still allowed in flight: one whole tile, or none
+    auto dma_wait = [&](bool keep_one_tile) {
+        if (!keep_one_tile) wait_vmcnt<0>();
+        else if (full_wave) wait_vmcnt<PPW>();
+        else wait_vmcnt<PPW - 1>();
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    const bool prio = (a.debug & 32u) == 0;
+    // K loop: see batch_gemm_rega_kernel (B fragments read AHEAD k-steps early, every step pinned by a sched_barrier)
+    auto mfma_tile = [&](const unsigned char* cur) {
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const unsigned char* b0 = cur + (lane & 31) * ROW_B + (lane >> 5) * 16;
+        constexpr int RING = AHEAD + 1;
+        u32x4 fb[RING];
+        f32x16 a1;
+#pragma unroll
+        for (int i = 0; i < AHEAD && i < KS; ++i) fb[i] = *reinterpret_cast<const u32x4*>(b0 + i * 32);
+        if (prio) __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + AHEAD < KS) fb[(ks + AHEAD) % RING] = *reinterpret_cast<const u32x4*>(b0 + (ks + AHEAD) * 32);
+            if (CHAINS == 2 && (ks & 1))
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], __builtin_bit_cast(bf16x8, fb[ks % RING]), ks == 1 ? zero16 : a1, 0, 0, 0);
+            else
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], __builtin_bit_cast(bf16x8, fb[ks % RING]), ks == 0 ? zero16 : acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (prio) __builtin_amdgcn_s_setprio(0);
+        if (CHAINS == 2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += a1[r];
+        }
+    };
+    // the fused selection of batch_gemm_rega_kernel on one 32-row block
+    auto select_tile = [&](uint32_t tile) {
+        if (a.debug & 8u) return;
+        if (SAMPLE) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float m = group_max32(acc[r]);
+                if ((lane & 31) == 31)
+                    a.tile_max[(size_t)tile * (a.nqt * 128u) + q0 + (uint32_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5))] = m;
+            }
+            return;
+        }
+        const lds_f32x4* sim_w = (const lds_f32x4*)(sim_s + wave * 32 + 4 * (lane >> 5));
+        f32x4 lo[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lo[j] = sim_w[2 * j];
+        unsigned long long hit[4] = {0ull, 0ull, 0ull, 0ull};
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hit[r >> 2] |= __ballot(acc[r] >= lo[r >> 2][r & 3]);   // NaN fails
+        if ((hit[0] | hit[1] | hit[2] | hit[3]) == 0ull || (a.debug & 64u)) return;
+        const uint32_t row0 = a.slab0 + tile * TROWS + (lane & 31);
+        const bool ok0 = row0 < slab_end;
+        const lds_f32* tau_w = (const lds_f32*)(tau_s + wave * 32);
+        lds_u32* cnt_w = (lds_u32*)(cnt_s + wave * 32);
+        uint32_t seg_o = seg_lane0;                   // opaque: the 16 per-query row offsets are computed HERE (cold path), not
+        asm volatile("" : "+v"(seg_o));               // hoisted out of the tile loop into 16 VGPRs that do not exist
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (hit[g] == 0ull) continue;
+            const f32x4 tau4 = *(const lds_f32x4*)(tau_w + 8 * g + 4 * (lane >> 5));
+#pragma unroll
+            for (int r = 4 * g; r < 4 * g + 4; ++r) {
+                const int qo = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float d0 = (1.0f - acc[r]) + 0.0f;
+                if (ok0 && d0 <= tau4[r & 3]) {
+                    // opaque to hipcc on purpose: before an LDS write it can see, the compiler drains every outstanding
+                    // LDS-DMA request (s_waitcnt vmcnt(0)) — here once per tile, undoing the prefetch
+                    unsigned off;
+                    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=v"(off)
+                                 : "v"((unsigned)(size_t)(cnt_w + qo)), "v"(1u)
+                                 : "memory");
+                    const uint32_t e0 = seg_o + (uint32_t)((r & 3) + 8 * (r >> 2)) * a.cand_cap;
+                    if (off < seg_slots) a.cand[e0 + off] = make_key(d0, a.row_base + row0);
+                }
+            }
+        }
+    };
+
+    uint32_t t = bidx;
+    {
+        bool second = false;
+        if (t < ntiles) dma_tile(t, 0u);
+        if (PRE == 2 && t + blocks_per_group < ntiles) { dma_tile(t + blocks_per_group, (uint32_t)BUF_B); second = true; }
+        dma_wait(second);
+        __builtin_amdgcn_s_barrier();                         // also publishes tau_s / cnt_s / sim_s
+        asm volatile("" ::: "memory");
+    }
+    const bool late = wave >= 4 && !(a.debug & 16u);          // see batch_gemm_rega_kernel: the two waves of a SIMD work in opposite order
+    uint32_t it = 0, cur_idx = 0, t_prev = 0;
+    for (; t < ntiles; ++it) {
+        const unsigned char* cur = smem + cur_idx * BUF_B;
+        const uint32_t tn = t + PRE * blocks_per_group;
+        uint32_t pre_idx = cur_idx + PRE;
+        pre_idx = pre_idx >= (uint32_t)NBUF ? pre_idx - NBUF : pre_idx;
+        bool issued = false;
+        if (tn < ntiles) { dma_tile(tn, pre_idx * BUF_B); issued = true; }
+        if (late) {
+            if (it > 0) select_tile(t_prev);
+            mfma_tile(cur);
+        } else {
+            mfma_tile(cur);
+            select_tile(t);
+        }
+        t_prev = t;
+        // tile t + 1 must have landed (every wave waits for its own pieces, the barrier joins them); with three tiles in LDS
+        // the one requested in this iteration stays in flight across the barrier
+        dma_wait(PRE == 2 && issued);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        cur_idx = cur_idx + 1 == (uint32_t)NBUF ? 0u : cur_idx + 1;
+        t += blocks_per_group;
+    }
+    if (late && it > 0) select_tile(t_prev);
+    __syncthreads();
+    if (!SAMPLE && tid < 256) a.seg_count[(size_t)bidx * (a.nqt * 128u) + group * 256u + (uint32_t)tid] = cnt_s[tid];
+}
+
+// ---------------------------------------------------------------------------
 // Register-resident-queries GEMM, ONE wave per SIMD ("w4": batch_rega = 3; D in {128, 256, 384, 512}).
 //
 // batch_gemm_rega_kernel keeps 32 queries per wave and two waves per SIMD: every B fragment read from LDS feeds one
@@ -1503,11 +1727,16 @@ static hipError_t launch_w4(const GemmArgs& a, hipStream_t st) {
 
 // D = 1024 would need 2 x 66 KB of tiles + 32 KB of partial sums (> 160 KB of LDS): it stays on the LDS-tiled kernel.
 static bool ksplit_dims(uint32_t dims) { return dims == 768; }
+// D = 768 has two register-resident kernels. "batch_rega" 1 / 6 / 7 select the K-split kernel (1 = workgroup barrier, 6 = split
+// barrier at every size, 7 = its own size rule); every other value the wide kernel (whole K per wave, LDS-DMA staging).
+static bool ksplit_mode(uint32_t use_rega) { return use_rega == 1u || use_rega == 6u || use_rega == 7u; }
+// Queries per workgroup group of the register-resident filtering GEMM (the planner sizes survivor segments by it).
+uint32_t batch_group_queries(uint32_t dims, uint32_t use_rega) { return (ksplit_dims(dims) && ksplit_mode(use_rega)) ? 128u : 256u; }
 
 static void rega_geometry(const GemmArgs& a, uint32_t* groups, uint32_t* per_group) {
-    const bool ksplit = ksplit_dims(a.dims);                      // 128 queries / 32-row tiles per workgroup
+    const bool ksplit = batch_group_queries(a.dims, a.use_rega) == 128u;   // K-split: 128 queries per workgroup
     *groups = ksplit ? a.nqt : (a.nqt * 128 + 255) / 256;
-    const uint32_t ntiles = ksplit ? (a.slab_rows + 31) / 32 : (a.slab_rows + 63) / 64;
+    const uint32_t ntiles = ksplit_dims(a.dims) ? (a.slab_rows + 31) / 32 : (a.slab_rows + 63) / 64;   // 768: 32-row tiles (both kernels)
     uint32_t pg = 256 / *groups;                // one persistent workgroup per CU in total
     if (pg < 1) pg = 1;
     if (pg > ntiles) pg = ntiles;
@@ -1539,6 +1768,21 @@ static hipError_t launch_ksplit(const GemmArgs& a, hipStream_t st) {
     uint32_t groups, per_group;
     rega_geometry(a, &groups, &per_group);
     hipLaunchKernelGGL((batch_gemm_ksplit_kernel<D, AHEAD, false, SPLIT>), dim3(groups * per_group), dim3(512), smem, st, a, per_group);
+    return hipGetLastError();
+}
+
+template <int D, int NBUF, int AHEAD, int CHAINS = 1>
+static hipError_t launch_wide(const GemmArgs& a, hipStream_t st) {
+    constexpr size_t smem = (size_t)NBUF * (((32 * (D * 2 + 16)) + 1023) / 1024 * 1024) + 3 * 8 * 32 * 4 + 64;   // tile buffers, thresholds / counters / bounds
+    static_assert(smem <= 160 * 1024, "LDS budget of one CU");
+    static std::atomic<uint64_t> configured{0};   // per device (ensure_dynamic_lds)
+    {
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&batch_gemm_wide_kernel<D, NBUF, AHEAD, false, CHAINS>), smem, configured);
+        if (e != hipSuccess) return e;
+    }
+    uint32_t groups, per_group;
+    rega_geometry(a, &groups, &per_group);
+    hipLaunchKernelGGL((batch_gemm_wide_kernel<D, NBUF, AHEAD, false, CHAINS>), dim3(groups * per_group), dim3(512), smem, st, a, per_group);
     return hipGetLastError();
 }
 
@@ -1617,6 +1861,14 @@ hipError_t launch_batch_gemm(const GemmArgs& a, int metric, hipStream_t st) {
             case 384: return launch_rega<384>(a, st);
             case 512: return launch_rega<512>(a, st);
             case 768:
+                if (!ksplit_mode(a.use_rega)) {
+                    switch ((a.debug >> 8) & 3u) {   // timing experiments: LDS tile buffers / accumulator chains / read-ahead
+                        case 1: return launch_wide<768, 2, 2>(a, st);
+                        case 2: return launch_wide<768, 3, 2, 2>(a, st);
+                        case 3: return launch_wide<768, 3, 3>(a, st);
+                        default: return launch_wide<768, 3, 2>(a, st);
+                    }
+                }
                 switch ((a.debug >> 8) & 3u) {   // timing experiments: B-fragment read-ahead depth
                     case 1: return launch_ksplit<768, 6>(a, st);
                     case 2: return launch_ksplit<768, 8>(a, st);

@@ -1134,7 +1134,8 @@ bool plan_onepass(wax_hip_engine* e, uint32_t n, int k_eff, uint32_t nq, Onepass
     p->kp = batch_kp(k_eff, 960);
     const uint32_t nq_blk = nq < kBatchMaxQ ? nq : kBatchMaxQ;
     const uint32_t nq_pad = (nq_blk + 255u) & ~255u;
-    const uint32_t groups = e->dims == 768 ? nq_pad / 128 : nq_pad / 256;
+    const uint32_t rega_mode = e->batch_rega.load() == 0 ? 5u : (uint32_t)e->batch_rega.load();   // as batch_enqueue passes it
+    const uint32_t groups = nq_pad / batch_group_queries(e->dims, rega_mode);
     uint32_t nseg = fast ? 256 / (groups ? groups : 1) : 1u;   // workgroups per query group == survivor segments per query (1 = counted list)
     if (nseg < 1) nseg = 1;
     if (nseg > p->ntiles) nseg = p->ntiles;

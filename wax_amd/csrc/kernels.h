@@ -219,6 +219,8 @@ bool batch_onepass_dims(uint32_t dims, int metric);
 bool batch_onepass_fast(uint32_t dims, int metric);
 // rows per GEMM tile of the kernel that serves (dims, metric): 64, 32 for the K-split kernel, 128 for the LDS-tiled kernel
 uint32_t batch_tile_rows(uint32_t dims, int metric);
+// queries per workgroup group of the register-resident filtering GEMM that "batch_rega" = use_rega selects (128 or 256)
+uint32_t batch_group_queries(uint32_t dims, uint32_t use_rega);
 bool batch_finish_fused_dims(uint32_t dims);
 // Queries f32 [nq][dims] in HBM -> bf16 block (cosine: normalised; rows [nq, nq_pad) zero), exact ||q|| as the
 // single-query path computes it (f64 accumulation, the host's summation order), certificate eps, and the per-batch
