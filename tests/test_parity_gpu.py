@@ -1266,7 +1266,7 @@ def test_batch_gemm_variants_agree(wax, dims):
                                   (1, 3, 8), (1, 4, 8), (0, 4, 3), (1, 5, 8), (0, 5, 3),
                                   # D = 768: 1 / 6 / 7 = the K-split kernel (workgroup barrier / split barrier / its size rule), every other
                                   # value the wide kernel (whole K per wave, LDS-DMA staging) — whose build variants sit behind batch_debug
-                                  # bits 8-9: two LDS tile buffers, two accumulator chains, read-ahead 3
+                                  # bits 8-9: two LDS tile buffers (256), the split tile barrier (512), read-ahead 3 (768)
                                   (1, 6, 8), (1, 7, 8), (0, 7, 3), (1, 5, 8, 256), (1, 5, 8, 512), (0, 5, 3, 768), (1, 2, 8, 256)]:
         eng.setTuning("batch_debug", dbg[0] if dbg else 0)
         eng.setTuning("batch_onepass", onepass)
@@ -1288,8 +1288,8 @@ def test_batch_gemm_variants_agree(wax, dims):
     eng.close()
 
 
-@pytest.mark.parametrize("dims", [384, 768])
-def test_split_barrier_timeout_is_fail_safe(wax, dims):
+@pytest.mark.parametrize("dims,rega,dbg", [(384, 5, 0), (768, 6, 0), (768, 5, 512)])
+def test_split_barrier_timeout_is_fail_safe(wax, dims, rega, dbg):
     """The filtering GEMMs synchronise their tiles through LDS counters with BOUNDED spins (a protocol error must not hang the GPU).
     A wave that gives up must not produce a silent wrong answer: its workgroup reports every one of its queries as overflowed and
     those queries are answered by the exact path. "batch_debug" bit 14 makes one wave of workgroup 1 pretend it timed out."""
@@ -1297,11 +1297,12 @@ def test_split_barrier_timeout_is_fail_safe(wax, dims):
     corpus = oracle.gaussian_unit_rows(21, n, dims)
     eng = make_engine(wax, 0, dims, corpus)
     queries = oracle.gaussian_unit_queries(300, dims, seed=5)
-    if dims == 768:
-        eng.setTuning("batch_rega", 6)                       # the K-split kernel with its split barrier (the default 768-d kernel has a plain workgroup barrier)
+    # 768-d: the K-split kernel with its split barrier (rega 6), and the wide kernel's split-barrier build (batch_debug bit 9)
+    eng.setTuning("batch_rega", rega)
+    eng.setTuning("batch_debug", dbg)
     ref = eng.searchBatch(queries, 10)
     f0 = eng.getTuning("batch_fallbacks")
-    eng.setTuning("batch_debug", 16384)
+    eng.setTuning("batch_debug", 16384 | dbg)
     got = eng.searchBatch(queries, 10)
     eng.setTuning("batch_debug", 0)
     hit = eng.getTuning("batch_fallbacks") - f0
@@ -1926,3 +1927,54 @@ def test_fused_final_merge_equals_two_launch_path(wax):
         g_ids, g_scores = eng.searchArrays(queries[0], 10)
         assert_parity(g_ids, g_scores, e_ids, e_scores, None, f"fused merge m{metric} d{dims} n{n}")
         eng.close()
+
+
+def test_query_in_kernel_arguments_equals_uploaded_query(wax):
+    """"query_args": a single-query scan may take its query through the kernel arguments (scan_kernel_qarg: the dims floats ride
+    in the launch packet, no upload copy on the stream). Same kernel body, so the hits must be bit-identical to the uploaded-query
+    path — for both dimensions that have the kernel (384, 768), all metrics, both selection capacities (k <= 64, k <= 192),
+    ragged sizes, pipelined tickets, the two-launch merge, and on a sharded handle. Mode 1 (default) uses it only where the
+    scan grid is small (launch-latency-bound stores), mode 2 everywhere; k > 192 (general selection) and other dimensions never do."""
+    for metric, dims, n in [(0, 384, 10_000), (1, 384, 9_999), (2, 768, 3_001), (0, 768, 150_000), (0, 384, 400_000)]:
+        corpus = oracle.gaussian_unit_rows(17 + n, n, dims)
+        corpus[11] = corpus[10]
+        eng = make_engine(wax, metric, dims, corpus, np.arange(n, dtype=np.uint64) + 9)
+        queries = oracle.gaussian_unit_queries(12, dims, seed=n)
+        queries[3] = corpus[10]
+        small = eng.getTuning("scan_grid") <= 160
+        for k in (1, 10, 64, 65, 192, 500):
+            eng.setTuning("query_args", 0)
+            ref = [eng.searchArrays(q, k) for q in queries]
+            for mode in (1, 2):
+                eng.setTuning("query_args", mode)
+                before = eng.getTuning("query_args_scans")
+                pend = [eng.submit(q, k) for q in queries[:4]]
+                got = [eng.collect(t, k) for t in pend] + [eng.searchArrays(q, k) for q in queries[4:]]
+                used = eng.getTuning("query_args_scans") - before
+                assert used == (len(queries) if (k <= 192 and (mode == 2 or small)) else 0), (metric, dims, n, k, mode, used)
+                for (a_ids, a_scores), (b_ids, b_scores) in zip(ref, got):
+                    assert np.array_equal(a_ids, b_ids) and np.array_equal(a_scores, b_scores), (metric, dims, n, k, mode)
+        eng.setTuning("query_args", 2)
+        eng.setTuning("fuse_merge", 0)                                  # two launches: scan (query in its arguments) + merge
+        a = eng.searchArrays(queries[0], 10)
+        eng.setTuning("query_args", 0)
+        b = eng.searchArrays(queries[0], 10)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (metric, dims, n)
+        eng.close()
+    # other dimensions: never (no kernel), and nothing breaks
+    eng = make_engine(wax, 0, 128, oracle.gaussian_unit_rows(1, 5000, 128))
+    eng.setTuning("query_args", 2)
+    eng.searchArrays(oracle.gaussian_unit_queries(1, 128)[0], 10)
+    assert eng.getTuning("query_args_scans") == 0
+    eng.close()
+    # sharded handle: every shard's scan takes the query in its arguments; same answers as one engine
+    n, dims = 30_000, 384
+    corpus = oracle.gaussian_unit_rows(5, n, dims)
+    one = make_engine(wax, 0, dims, corpus)
+    many = wax.HIPVectorEngine(dimensions=dims, devices=[0, 0, 0])
+    many.addBatch(np.arange(n, dtype=np.uint64), corpus)
+    for q in oracle.gaussian_unit_queries(6, dims, seed=8):
+        a, b = one.searchArrays(q, 10), many.searchArrays(q, 10)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert many.getTuning("query_args_scans") == 18
+    one.close(), many.close()

@@ -1188,7 +1188,12 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_ksplit_kernel(GemmArgs a, u
 // the last piece lands in the buffer's 512 B of slack). Selection, survivor segments, thresholds, seg_count layout and the
 // "late" order of waves 4-7 are those of batch_gemm_rega_kernel, so the host side and batch_finish_kernel do not know
 // which kernel ran.
-template <int D, int NBUF, int AHEAD, bool SAMPLE = false, int CHAINS = 1>
+// SPLIT = true: the tile barrier is split as in batch_gemm_rega_kernel<..., SYNC = 2> — "arrive" (a wave adds 1 to an LDS counter
+// behind its K loop, once its own DMA pieces of the next tile have landed) and "wait" (spin on the counter in front of the next
+// K loop, BEFORE requesting the tile that will overwrite the buffer the previous K loop read): an early wave's selection sits
+// between the two instead of in front of a workgroup barrier. The counter is touched through inline assembly only: an LDS
+// access the compiler can see makes it drain the LDS-DMA queue first (s_waitcnt vmcnt(0)).
+template <int D, int NBUF, int AHEAD, bool SAMPLE = false, int CHAINS = 1, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void batch_gemm_wide_kernel(GemmArgs a, uint32_t blocks_per_group) {
     constexpr int KS = D / 16;                       // MFMA k-steps
     constexpr int ROW_B = D * 2 + 16;                // LDS row stride (bytes); (ROW_B / 4) % 64 == 4
@@ -1207,6 +1212,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_wide_kernel(GemmArgs a, uin
     float* tau_s = reinterpret_cast<float*>(smem + NBUF * BUF_B);              // [8][32] exact thresholds
     unsigned int* cnt_s = reinterpret_cast<unsigned int*>(tau_s + 8 * 32);     // [8][32] survivors per query (this workgroup)
     float* sim_s = reinterpret_cast<float*>(cnt_s + 8 * 32);                   // [8][32] conservative similarity bounds
+    unsigned int* sync_s = reinterpret_cast<unsigned int*>(sim_s + 8 * 32);    // SPLIT: [0] arrivals, [1] "a wave gave up waiting"
 
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
@@ -1228,6 +1234,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_wide_kernel(GemmArgs a, uin
         sim_s[wave * 32 + lane] = (1.0f - tq) - 4e-7f * (1.0f + __builtin_fabsf(tq));   // see batch_gemm_rega_kernel
     }
     if (tid < 256) cnt_s[tid] = 0u;
+    if (SPLIT && tid < 2) sync_s[tid] = 0u;
     const uint32_t seg_slots = a.seg_area / blocks_per_group;
     const uint32_t seg_lane0 = (q0 + 4u * ((uint32_t)lane >> 5)) * a.cand_cap + a.seg_base + bidx * seg_slots;
 
@@ -1352,6 +1359,24 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_wide_kernel(GemmArgs a, uin
         }
     };
 
+    // SPLIT: bounded spin on the arrival counter (see batch_gemm_rega_kernel: a wave that gives up poisons the workgroup's
+    // survivor counts, which sends its queries to the exact path — never a silent wrong answer)
+    bool gave_up = SPLIT && (a.debug & 16384u) != 0 && blockIdx.x == 1 && wave == 3;   // debug bit 14: pretend one wave timed out (tests)
+    const unsigned sync_addr = (unsigned)(size_t)(lds_u32*)sync_s;
+    auto wait_arrivals = [&](unsigned int target) {
+        bool ok = false;
+        for (unsigned int spins = 0; spins < (1u << 22); ++spins) {
+            unsigned int v;
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(sync_addr) : "memory");
+            if ((unsigned int)__builtin_amdgcn_readfirstlane((int)v) >= target) { ok = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (!ok) gave_up = true;
+    };
+    auto arrive = [&]() {
+        if (lane == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\tds_add_u32 %0, %1" ::"v"(sync_addr), "v"(1u) : "memory");
+    };
+
     uint32_t t = bidx;
     {
         bool second = false;
@@ -1369,26 +1394,47 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_wide_kernel(GemmArgs a, uin
         uint32_t pre_idx = cur_idx + PRE;
         pre_idx = pre_idx >= (uint32_t)NBUF ? pre_idx - NBUF : pre_idx;
         bool issued = false;
+        if (SPLIT) {
+            if (late && it > 0) select_tile(t_prev);
+            // every wave is through K loop it - 1 (the buffer tile tn goes to is free) and has its pieces of tile `it` in LDS
+            if (it > 0) wait_arrivals(8u * it);
+            if (tn < ntiles) { dma_tile(tn, pre_idx * BUF_B); issued = true; }
+            mfma_tile(cur);
+            dma_wait(PRE == 2 && issued);
+            arrive();
+            if (!late) select_tile(t);
+            t_prev = t;
+            cur_idx = cur_idx + 1 == (uint32_t)NBUF ? 0u : cur_idx + 1;
+            t += blocks_per_group;
+            continue;
+        }
         if (tn < ntiles) { dma_tile(tn, pre_idx * BUF_B); issued = true; }
+        // tile t + 1 must have landed before the barrier (every wave waits for its own pieces, the barrier joins them); with
+        // three tiles in LDS the one requested in this iteration stays in flight across it. The wait sits in FRONT of an early
+        // wave's selection: vmcnt counts the selection's survivor stores too, and a store issued just before the wait put a
+        // global-memory round trip on the barrier's critical path in ~9 of 10 tiles (some wave of the eight has a survivor).
         if (late) {
             if (it > 0) select_tile(t_prev);
             mfma_tile(cur);
+            dma_wait(PRE == 2 && issued);
         } else {
             mfma_tile(cur);
+            dma_wait(PRE == 2 && issued);
             select_tile(t);
         }
         t_prev = t;
-        // tile t + 1 must have landed (every wave waits for its own pieces, the barrier joins them); with three tiles in LDS
-        // the one requested in this iteration stays in flight across the barrier
-        dma_wait(PRE == 2 && issued);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         cur_idx = cur_idx + 1 == (uint32_t)NBUF ? 0u : cur_idx + 1;
         t += blocks_per_group;
     }
     if (late && it > 0) select_tile(t_prev);
+    if (SPLIT && gave_up && lane == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(sync_addr + 4u), "v"(1u) : "memory");
     __syncthreads();
-    if (!SAMPLE && tid < 256) a.seg_count[(size_t)bidx * (a.nqt * 128u) + group * 256u + (uint32_t)tid] = cnt_s[tid];
+    if (!SAMPLE && tid < 256) {
+        const bool poisoned = SPLIT && sync_s[1] != 0u;       // a wave gave up waiting: nothing this workgroup selected can be trusted
+        a.seg_count[(size_t)bidx * (a.nqt * 128u) + group * 256u + (uint32_t)tid] = poisoned ? 0x40000000u : cnt_s[tid];
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1771,18 +1817,18 @@ static hipError_t launch_ksplit(const GemmArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
-template <int D, int NBUF, int AHEAD, int CHAINS = 1>
+template <int D, int NBUF, int AHEAD, int CHAINS = 1, bool SPLIT = false>
 static hipError_t launch_wide(const GemmArgs& a, hipStream_t st) {
     constexpr size_t smem = (size_t)NBUF * (((32 * (D * 2 + 16)) + 1023) / 1024 * 1024) + 3 * 8 * 32 * 4 + 64;   // tile buffers, thresholds / counters / bounds
     static_assert(smem <= 160 * 1024, "LDS budget of one CU");
     static std::atomic<uint64_t> configured{0};   // per device (ensure_dynamic_lds)
     {
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&batch_gemm_wide_kernel<D, NBUF, AHEAD, false, CHAINS>), smem, configured);
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&batch_gemm_wide_kernel<D, NBUF, AHEAD, false, CHAINS, SPLIT>), smem, configured);
         if (e != hipSuccess) return e;
     }
     uint32_t groups, per_group;
     rega_geometry(a, &groups, &per_group);
-    hipLaunchKernelGGL((batch_gemm_wide_kernel<D, NBUF, AHEAD, false, CHAINS>), dim3(groups * per_group), dim3(512), smem, st, a, per_group);
+    hipLaunchKernelGGL((batch_gemm_wide_kernel<D, NBUF, AHEAD, false, CHAINS, SPLIT>), dim3(groups * per_group), dim3(512), smem, st, a, per_group);
     return hipGetLastError();
 }
 
@@ -1864,7 +1910,7 @@ hipError_t launch_batch_gemm(const GemmArgs& a, int metric, hipStream_t st) {
                 if (!ksplit_mode(a.use_rega)) {
                     switch ((a.debug >> 8) & 3u) {   // timing experiments: LDS tile buffers / accumulator chains / read-ahead
                         case 1: return launch_wide<768, 2, 2>(a, st);
-                        case 2: return launch_wide<768, 3, 2, 2>(a, st);
+                        case 2: return launch_wide<768, 3, 2, 1, true>(a, st);    // split tile barrier
                         case 3: return launch_wide<768, 3, 3>(a, st);
                         default: return launch_wide<768, 3, 2>(a, st);
                     }

@@ -397,6 +397,7 @@ struct wax_hip_engine {
     std::atomic<int64_t> time_kernels{0};
     std::atomic<int64_t> force_general{0};
     std::atomic<int64_t> stream_nt{1};
+    std::atomic<int64_t> query_args{1};      // single-query scans: 1 (default) = stores whose scan grid is small enough for the fused merge (the launch-latency-bound ones) get the query in the kernel arguments (no upload copy); 2 = every store; 0 = always upload
     std::atomic<int64_t> fuse_merge{1};      // 1 = grids of <= SCAN_FUSE_MERGE_GRID workgroups merge in the scan kernel's last-arriving workgroup
     std::atomic<int64_t> batch_min{1};       // fewer queries than this: always pipelined single-query scans (1..15: cost model below)
     std::atomic<int64_t> batch_mode{1};      // 0 = never use the MFMA path
@@ -421,6 +422,7 @@ struct wax_hip_engine {
     std::atomic<int64_t> batch_dynamic{0};        // one-pass pipeline: filtering-GEMM workgroups claim their tiles from a counter
     std::atomic<int64_t> batch_sample_div{32};    // one-pass pipeline: 1 / this of the tiles are sampled (at least 256)
     std::atomic<uint64_t> st_onepass_queries{0};
+    std::atomic<uint64_t> st_query_args{0};          // single-query scans that took their query through the kernel arguments
     // wax_hip_search_batch_submit_device tickets (guarded by bticket_mu)
     struct BatchTicket {
         BatchCtx* c = nullptr;           // null: the batch was answered at submit time (empty engine / loop path)
@@ -725,12 +727,28 @@ int reserve_rows(wax_hip_engine* e, uint64_t required) {
 struct Enqueued { int k_eff; };
 
 // The scan + select chain for one query on `stream`; leaves kpad hits in d_hits.
+// Does a scan of this engine for k_eff results take its query through the kernel arguments ("query_args")? Decided BEFORE the
+// query would be uploaded: the fused path only (the general selection reads the query through its pointer), the default kernel
+// variant, dimensions scan_kernel_qarg exists for.
+bool scan_uses_query_args(wax_hip_engine* e, int k_eff, bool has_general_slot) {
+    const int64_t mode = e->query_args.load();
+    if (mode == 0 || !scan_query_args_dims(e->dims) || k_eff > FUSED_MAX_K) return false;
+    if (e->force_general.load() && has_general_slot) return false;
+    const int variant = (int)e->variant.load();
+    if (variant > 0) return false;
+    if (mode >= 2) return true;
+    return scan_grid_for((uint32_t)e->count, e->dims, 0, (int)e->grid_blocks.load()) <= SCAN_FUSE_MERGE_GRID;
+}
+
+// d_query == nullptr: the query is `h_query` (host memory, read during this call) and travels in the kernel arguments.
 int enqueue_scan(wax_hip_engine* e, const float* d_query, float q_norm, int k_eff, int kpad, int64_t* d_partials,
                  Slot* general_slot, wax_hip_hit* d_hits, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1,
-                 bool chain = false, hipEvent_t* used_start = nullptr, hipEvent_t* used_end = nullptr) {
+                 bool chain = false, hipEvent_t* used_start = nullptr, hipEvent_t* used_end = nullptr,
+                 const float* h_query = nullptr) {
     ScanArgs a{};
     a.store = e->d_store;
     a.query = d_query;
+    a.query_host = d_query == nullptr ? h_query : nullptr;
     a.partials = d_partials;
     a.dist_out = nullptr;
     a.n_rows = (uint32_t)e->count;
@@ -1912,14 +1930,20 @@ static int submit_impl(wax_hip_engine* e, const float* query, uint32_t dims, int
         if (rc != WAX_HIP_OK) break;
         s->k_eff = k_eff;
         s->timed = e->time_kernels.load() != 0;
-        std::memcpy(s->h_query, query, (size_t)dims * sizeof(float));  // :467-468
         const float qn = query_norm(query, dims);
-        hipError_t err = hipMemcpyAsync(s->d_query, s->h_query, (size_t)dims * sizeof(float), hipMemcpyHostToDevice, s->stream);
-        if (err != hipSuccess) { rc = fail(WAX_HIP_ERR_INTERNAL, std::string("query upload: ") + hipGetErrorString(err)); break; }
+        hipError_t err = hipSuccess;
+        const bool qargs = scan_uses_query_args(e, k_eff, true);
+        if (!qargs) {
+            std::memcpy(s->h_query, query, (size_t)dims * sizeof(float));  // :467-468
+            err = hipMemcpyAsync(s->d_query, s->h_query, (size_t)dims * sizeof(float), hipMemcpyHostToDevice, s->stream);
+            if (err != hipSuccess) { rc = fail(WAX_HIP_ERR_INTERNAL, std::string("query upload: ") + hipGetErrorString(err)); break; }
+        } else {
+            e->st_query_args++;      // the query rides in the launch packet: no copy on the stream
+        }
         // The last kernel of the chain writes the k hits straight into the slot's pinned host buffer
         // (device-visible, 16*k bytes over PCIe): no D2H copy launch; visibility at ev_done.
-        rc = enqueue_scan(e, s->d_query, qn, k_eff, k_eff, s->d_partials, s, s->h_hits, s->stream,
-                          s->timed ? s->ev0 : nullptr, s->timed ? s->ev1 : nullptr, /*chain=*/chain_scans(e), &s->t_start, &s->t_end);
+        rc = enqueue_scan(e, qargs ? nullptr : s->d_query, qn, k_eff, k_eff, s->d_partials, s, s->h_hits, s->stream,
+                          s->timed ? s->ev0 : nullptr, s->timed ? s->ev1 : nullptr, /*chain=*/chain_scans(e), &s->t_start, &s->t_end, query);
         if (rc != WAX_HIP_OK) break;
         err = hipEventRecord(s->ev_done, s->stream);
         if (err != hipSuccess) { rc = fail(WAX_HIP_ERR_INTERNAL, std::string("event record: ") + hipGetErrorString(err)); break; }
@@ -2371,17 +2395,22 @@ static int search_shard_device_impl(wax_hip_engine* e, const float* query, uint3
             break;
         }
         const int k_eff = (uint64_t)kpad < e->count ? kpad : (int)e->count;
-        std::memcpy(e->ring_h_query[r], query, (size_t)dims * sizeof(float));
         const float qn = q_norm >= 0.0f ? q_norm : query_norm(query, dims);
-        hipError_t err = hipMemcpyAsync(e->ring_d_query[r], e->ring_h_query[r], (size_t)dims * sizeof(float), hipMemcpyHostToDevice, st);
-        if (err != hipSuccess) { rc = fail(WAX_HIP_ERR_INTERNAL, std::string("query upload: ") + hipGetErrorString(err)); break; }
+        const bool qargs = scan_uses_query_args(e, k_eff, false);
+        if (!qargs) {
+            std::memcpy(e->ring_h_query[r], query, (size_t)dims * sizeof(float));
+            hipError_t err = hipMemcpyAsync(e->ring_d_query[r], e->ring_h_query[r], (size_t)dims * sizeof(float), hipMemcpyHostToDevice, st);
+            if (err != hipSuccess) { rc = fail(WAX_HIP_ERR_INTERNAL, std::string("query upload: ") + hipGetErrorString(err)); break; }
+        } else {
+            e->st_query_args++;
+        }
         harvest_ring_event(e, (int)r);  // the entry's previous use has finished (waited for above)
         const bool timed = e->time_kernels.load() != 0;
         // chained (when kernels are timed, or "scan_chain" = 1): scans issued on different caller streams never overlap
         // each other, while the merge kernel and whatever the caller enqueues next (RCCL all-gather, merge, download)
         // do overlap the following scan.
-        rc = enqueue_scan(e, e->ring_d_query[r], qn, k_eff, kpad, e->ring_d_partials[r], nullptr, d_out_hits, st,
-                          timed ? e->ring_ev0[r] : nullptr, timed ? e->ring_ev1[r] : nullptr, /*chain=*/chain_scans(e), &e->ring_t0[r], &e->ring_t1[r]);
+        rc = enqueue_scan(e, qargs ? nullptr : e->ring_d_query[r], qn, k_eff, kpad, e->ring_d_partials[r], nullptr, d_out_hits, st,
+                          timed ? e->ring_ev0[r] : nullptr, timed ? e->ring_ev1[r] : nullptr, /*chain=*/chain_scans(e), &e->ring_t0[r], &e->ring_t1[r], query);
         if (rc == WAX_HIP_OK && timed) {
             std::unique_lock<std::mutex> sg(e->st_mu);
             e->ring_ev_pending[r] = true;
@@ -2721,6 +2750,7 @@ int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value) {
     else if (k == "force_general") e->force_general = value;
     else if (k == "stream_nt") e->stream_nt = value;
     else if (k == "fuse_merge") e->fuse_merge = value != 0;
+    else if (k == "query_args") { if (value < 0 || value > 2) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "query_args must be 0, 1 or 2"); e->query_args = value; }
     else if (k == "batch_min") e->batch_min = value;
     else if (k == "batch_mode") e->batch_mode = value;
     else if (k == "batch_rega") e->batch_rega = value;
@@ -2774,6 +2804,8 @@ int64_t wax_hip_get_tuning(wax_hip_engine* e, const char* key) {
     if (k == "force_general") return e->force_general.load();
     if (k == "stream_nt") return e->stream_nt.load();
     if (k == "fuse_merge") return e->fuse_merge.load();
+    if (k == "query_args") return e->query_args.load();
+    if (k == "query_args_scans") return (int64_t)e->st_query_args.load();
     if (k == "batch_min") return e->batch_min.load();
     if (k == "batch_mode") return e->batch_mode.load();
     if (k == "batch_rega") return e->batch_rega.load();

@@ -40,7 +40,20 @@ struct ScanArgs {
     const uint64_t* ids;     // frame ids by local row (merge_out only; may be null)
     uint32_t* arrive;
     int32_t kpad;
+    // Host side only (never read on the device): non-null = the query's dims floats in HOST memory, to be passed in the kernel
+    // arguments (launch_scan copies them into the launch packet's kernarg block) instead of being read through `query`.
+    // Honoured for dims 384 / 768 on the fused path; `query` may then be null.
+    const float* query_host;
 };
+// kernarg block of scan_kernel_qarg: the scan arguments followed by the query itself (16-byte aligned for float4 loads)
+template <int DIMS>
+struct alignas(16) ScanArgsQ {
+    ScanArgs a;
+    alignas(16) float q[DIMS];
+};
+static_assert(sizeof(ScanArgsQ<768>) <= 4096, "HIP kernel arguments are limited to 4 KB");
+// whether launch_scan can take the query through the kernel arguments for this shape (scan_kernel_qarg instantiations)
+inline bool scan_query_args_dims(uint32_t dims) { return dims == 384 || dims == 768; }
 constexpr int SCAN_FUSE_MERGE_GRID = 160;   // largest grid whose last-arriving workgroup does the final merge
 
 struct ScanVariantInfo {

@@ -22,6 +22,9 @@
 //     chip reads one contiguous, moving window (TLB- and DRAM-page-friendly);
 //   * every row's summation order is fixed by (GROUP, LOADS) alone, so a row's
 //     distance is bit-identical wherever it sits — on any shard, any GPU count.
+#include <cstddef>
+#include <cstring>
+
 #include "kernels.h"
 #include "topk.h"
 
@@ -129,7 +132,26 @@ __device__ inline void scan_epilogue(const ScanArgs& a, int64_t* lds, int* count
 // ---------------------------------------------------------------------------
 // Fused scan + select, compile-time dims.
 template <int D4, int GROUP, int METRIC, int UNROLL, bool NT, int CAP, bool WRITE_DIST>
+__device__ __forceinline__ void scan_body(const ScanArgs& a, const f32x4* __restrict__ q4);
+
+template <int D4, int GROUP, int METRIC, int UNROLL, bool NT, int CAP, bool WRITE_DIST>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a) {
+    scan_body<D4, GROUP, METRIC, UNROLL, NT, CAP, WRITE_DIST>(a, reinterpret_cast<const f32x4*>(a.query));
+}
+
+// The same kernel with the QUERY IN THE KERNEL ARGUMENTS (ScanArgsQ: the scan arguments followed by dims floats, <= 4 KB of
+// kernarg). A query then reaches the GPU with the launch packet itself — no upload copy in front of the scan, one packet
+// less on the stream per query — which is what a launch-latency-bound store (10K rows: the scan is ~5 us) is made of.
+// The lanes read their slice straight from the kernarg segment (a vector load per float4, like the HBM copy they replace).
+template <int D4, int GROUP, int METRIC, int UNROLL, bool NT, int CAP>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_kernel_qarg(ScanArgsQ<D4 * 4> aq) {
+    const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();   // constant -> generic address space: still plain global loads
+    const f32x4* q4 = reinterpret_cast<const f32x4*>(ka + offsetof(ScanArgsQ<D4 * 4>, q));
+    scan_body<D4, GROUP, METRIC, UNROLL, NT, CAP, false>(aq.a, q4);
+}
+
+template <int D4, int GROUP, int METRIC, int UNROLL, bool NT, int CAP, bool WRITE_DIST>
+__device__ __forceinline__ void scan_body(const ScanArgs& a, const f32x4* __restrict__ q4) {
     constexpr int LOADS = D4 / GROUP;       // float4s per lane per row
     constexpr int RPW = WAVE / GROUP;       // rows per wave-wide load
     constexpr int RPC = RPW * UNROLL;       // rows per wave per iteration
@@ -145,7 +167,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a) {
     const uint32_t n = a.n_rows;
 
     const f32x4* __restrict__ store4 = reinterpret_cast<const f32x4*>(a.store);
-    const f32x4* __restrict__ q4 = reinterpret_cast<const f32x4*>(a.query);
 
     f32x4 q[LOADS];
 #pragma unroll
@@ -350,6 +371,27 @@ static hipError_t launch_metric(const ScanArgs& a, int cap, bool write_dist, int
     return hipGetLastError();
 }
 
+// query in the kernel arguments (args.query_host != nullptr; fused path only)
+template <int D4, int GROUP, int UNROLL, bool NT, int METRIC>
+static hipError_t launch_qarg_metric(const ScanArgs& a, int cap, int grid, hipStream_t st) {
+    ScanArgsQ<D4 * 4> aq;
+    aq.a = a;
+    std::memcpy(aq.q, a.query_host, sizeof(aq.q));
+    aq.a.query = nullptr;
+    if (cap <= 128) hipLaunchKernelGGL((scan_kernel_qarg<D4, GROUP, METRIC, UNROLL, NT, 128>), dim3(grid), dim3(SCAN_THREADS), 0, st, aq);
+    else hipLaunchKernelGGL((scan_kernel_qarg<D4, GROUP, METRIC, UNROLL, NT, 256>), dim3(grid), dim3(SCAN_THREADS), 0, st, aq);
+    return hipGetLastError();
+}
+template <int D4, int GROUP, int UNROLL, bool NT>
+static hipError_t launch_qarg(const ScanArgs& a, int metric, int cap, int grid, hipStream_t st) {
+    switch (metric) {
+        case M_COS: return launch_qarg_metric<D4, GROUP, UNROLL, NT, M_COS>(a, cap, grid, st);
+        case M_DOT: return launch_qarg_metric<D4, GROUP, UNROLL, NT, M_DOT>(a, cap, grid, st);
+        case M_L2: return launch_qarg_metric<D4, GROUP, UNROLL, NT, M_L2>(a, cap, grid, st);
+    }
+    return hipErrorInvalidValue;
+}
+
 template <int D4, int GROUP, int UNROLL, bool NT>
 static hipError_t launch_full(const ScanArgs& a, int metric, int cap, bool write_dist, int grid, hipStream_t st) {
     switch (metric) {
@@ -390,6 +432,13 @@ hipError_t launch_scan(const ScanArgs& args, int metric, int variant, int cap, b
     const bool fuse = !write_dist && a.merge_out != nullptr && a.arrive != nullptr && grid <= SCAN_FUSE_MERGE_GRID && a.kpad >= a.k;
     if (!fuse) { a.merge_out = nullptr; a.arrive = nullptr; }
     if (out_merged) *out_merged = fuse;
+    // query in the kernel arguments: the BASELINE dimensions, default variant, fused path (the caller decides when — launch_scan
+    // only refuses what it has no kernel for, by falling through to the pointer form, which needs args.query)
+    if (a.query_host != nullptr && !write_dist && variant == 0) {
+        if (a.dims == 384) return launch_qarg<96, 32, 4, true>(a, metric, cap, grid, st);
+        if (a.dims == 768) return launch_qarg<192, 64, 2, true>(a, metric, cap, grid, st);
+    }
+    if (a.query == nullptr) return hipErrorInvalidValue;
     switch (a.dims) {
         case 64: return launch_full<16, 16, 4, true>(a, metric, cap, write_dist, grid, st);
         case 128: return launch_full<32, 32, 4, true>(a, metric, cap, write_dist, grid, st);
