@@ -1978,3 +1978,48 @@ def test_query_in_kernel_arguments_equals_uploaded_query(wax):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     assert many.getTuning("query_args_scans") == 18
     one.close(), many.close()
+
+
+def test_inline_full_retry_equals_host_retry_and_exact_path(wax):
+    """Dense neighbourhoods: more rows inside the bf16 error band of the k-th neighbour than the k' candidates of the first finish
+    cover, so its certificate fails with nothing dropped. Round 4: such a query is retried INSIDE the finish kernel — every
+    survivor re-scored exactly, certificate tau - eps > exact k-th — instead of from the host at collect time. The three ladders
+    ("batch_retry" 1 inline + host, 2 host only, 0 exact path only) must give the single-query answers bit for bit, and the inline
+    rung must actually take the load (clustered corpus, k = 100: most queries of a batch)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n, dims, nq = 300_000, 384, 256
+    g = torch.Generator(device=dev).manual_seed(11)
+    centres = torch.randn((20, dims), device=dev, generator=g)
+    which = torch.randint(0, 20, (n,), device=dev, generator=g)
+    rows = torch.nn.functional.normalize(centres[which] + 0.3 * torch.randn((n, dims), device=dev, generator=g), dim=1).contiguous()
+    rows[5000:5040] = rows[4999]                                     # plus a 40-fold exact tie
+    eng = wax.HIPVectorEngine(dimensions=dims)
+    eng.addBatchDevice(np.arange(n, dtype=np.uint64) + 3, rows)
+    q = torch.randn((nq, dims), device=dev, generator=g)
+    q[: nq // 2] = rows[:nq // 2] + 0.05 * q[: nq // 2]              # half of the queries inside a cluster
+    q[7] = rows[4999]
+    queries = q.cpu().numpy()
+    for k in (10, 100):
+        ref = None
+        for mode in (1, 2, 0):
+            eng.setTuning("batch_retry", mode)
+            i0, r0, f0 = eng.getTuning("batch_inline_retries"), eng.getTuning("batch_retries"), eng.getTuning("batch_fallbacks")
+            got = eng.searchBatch(queries, k)
+            inl, ret, fb = eng.getTuning("batch_inline_retries") - i0, eng.getTuning("batch_retries") - r0, eng.getTuning("batch_fallbacks") - f0
+            print(f"\n[inline retry] k {k} batch_retry {mode}: inline {inl}, retries {ret}, exact-path fallbacks {fb}")
+            assert (inl > 0) == (mode == 1 and k == 100) or (mode == 1 and inl >= 0), (k, mode, inl)
+            if mode != 1:
+                assert inl == 0
+            if mode == 0:
+                assert ret == 0
+            if ref is None:
+                ref = got
+                if k == 100:
+                    assert inl >= 20, inl                             # the rung takes the load
+                for i in (0, 7, 100, 200, 255):
+                    s_ids, s_scores = eng.searchArrays(queries[i], k)
+                    assert np.array_equal(got[0][i, :len(s_ids)], s_ids) and np.array_equal(got[1][i, :len(s_ids)], s_scores), (k, i)
+            else:
+                assert all(np.array_equal(x, y) for x, y in zip(got, ref)), (k, mode)
+    eng.close()

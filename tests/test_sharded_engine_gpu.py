@@ -309,6 +309,10 @@ def test_sharded_batch_resends_parts_rewritten_at_collect(wax, shards):
     a = torch.empty((nq, k, 2), dtype=torch.int64, device=dev)
     b = torch.empty((nq, k, 2), dtype=torch.int64, device=dev)
     one.searchBatchHitsDevice(dq.data_ptr(), nq, k, a.data_ptr(), k, stream)
+    # "batch_retry" = 2: the full retry driven from the HOST at collect time (round 3's rung; since round 4 the default, 1, first
+    # tries it inside the finish kernel, which settles the near-duplicates before the part is ever sent) — the re-send logic
+    # this test is about needs rows rewritten at collect
+    many.setTuning("batch_retry", 2)
     r0, f0 = many.getTuning("batch_retries"), many.getTuning("batch_fallbacks")
     many.searchBatchHitsDevice(dq.data_ptr(), nq, k, b.data_ptr(), k, stream)
     assert many.getTuning("batch_retries") > r0 and many.getTuning("batch_fallbacks") == f0    # settled by full retries alone
@@ -317,7 +321,7 @@ def test_sharded_batch_resends_parts_rewritten_at_collect(wax, shards):
     b.zero_()
     many.searchBatchHitsDevice(dq.data_ptr(), nq, k, b.data_ptr(), k, stream)
     assert many.getTuning("batch_fallbacks") > f0 and np.array_equal(a.cpu().numpy(), b.cpu().numpy())
-    many.setTuning("batch_retry", 1)
+    many.setTuning("batch_retry", 2)
     for i in (0, 7, 100):
         s_ids, _ = one.searchArrays(queries[i], k)
         assert np.array_equal(b.cpu().numpy()[i, :, 1].view(np.uint64), s_ids)
@@ -331,6 +335,14 @@ def test_sharded_batch_resends_parts_rewritten_at_collect(wax, shards):
     # two shards settled queries on the host side in the first batch, so the later collects ran the per-shard ladders side by
     # side on the handle's persistent workers
     assert many.getTuning("parallel_collects") >= 2
+    # the default ladder: the near-duplicate queries are certified INSIDE the finish kernel (all survivors re-scored there), the
+    # 3 000-fold tie (more survivors than one workgroup ranks) still goes to the host rungs — same hits
+    many.setTuning("batch_retry", 1)
+    i0 = many.getTuning("batch_inline_retries")
+    b.zero_()
+    many.searchBatchHitsDevice(dq.data_ptr(), nq, k, b.data_ptr(), k, stream)
+    assert np.array_equal(a.cpu().numpy(), b.cpu().numpy())
+    assert many.getTuning("batch_inline_retries") - i0 >= 6
     one.close(), many.close()
 
 

@@ -1216,7 +1216,9 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_wide_kernel(GemmArgs a, uin
 
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    // readfirstlane: tells hipcc the wave index is wave-uniform, so everything derived from it — the early / late order, and with
+    // it the survivor counters modified under that branch — stays in SGPRs
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t group = blockIdx.x / blocks_per_group;   // 256 queries per group
     const uint32_t bidx = blockIdx.x % blocks_per_group;
     const uint32_t q0 = group * 256 + wave * 32;             // this wave's 32 queries
@@ -1310,7 +1312,19 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_wide_kernel(GemmArgs a, uin
             for (int r = 0; r < 16; ++r) acc[r] += a1[r];
         }
     };
-    // the fused selection of batch_gemm_rega_kernel on one 32-row block
+    // Fused selection on one 32-row block. Hot path as in batch_gemm_rega_kernel (16 compares against conservative bounds, wave-level
+    // flags per group of four queries). The cold path differs: a wave's 32 queries are ITS OWN (no other wave of the workgroup
+    // selects for them), so the per-(workgroup, query) survivor counters live in 32 SGPRs of the wave instead of in LDS, and a
+    // survivor's slot is counter + (passing lanes below it in its half-wave) — ballot, mbcnt, s_bcnt1: no LDS atomic round trip, no
+    // threshold read. Rows are admitted on the conservative bound itself (acc >= sim_lo, a superset of `1 - acc <= tau` by less
+    // than 1e-6: rejected rows still have d > tau, which is all the certificate uses). With the eight waves joined by a barrier
+    // per tile, an LDS round trip taken by ANY wave (some wave has a survivor in ~9 of 10 tiles) was paid by all of them:
+    // 175 - 215 us of a 1 770 us launch (profiles/r04).
+    // (two 16-bit counters per SGPR — 32 full ones do not fit beside the kernel's other scalars and hipcc then keeps them in
+    // VGPRs it has to spill — saturating at 0xFFFF, which is reported as an overflow: the query takes the exact path)
+    unsigned cq[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cq[r] = 0u;
     auto select_tile = [&](uint32_t tile) {
         if (a.debug & 8u) return;
         if (SAMPLE) {
@@ -1332,29 +1346,27 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_wide_kernel(GemmArgs a, uin
         if ((hit[0] | hit[1] | hit[2] | hit[3]) == 0ull || (a.debug & 64u)) return;
         const uint32_t row0 = a.slab0 + tile * TROWS + (lane & 31);
         const bool ok0 = row0 < slab_end;
-        const lds_f32* tau_w = (const lds_f32*)(tau_s + wave * 32);
-        lds_u32* cnt_w = (lds_u32*)(cnt_s + wave * 32);
         uint32_t seg_o = seg_lane0;                   // opaque: the 16 per-query row offsets are computed HERE (cold path), not
         asm volatile("" : "+v"(seg_o));               // hoisted out of the tile loop into 16 VGPRs that do not exist
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             if (hit[g] == 0ull) continue;
-            const f32x4 tau4 = *(const lds_f32x4*)(tau_w + 8 * g + 4 * (lane >> 5));
 #pragma unroll
             for (int r = 4 * g; r < 4 * g + 4; ++r) {
-                const int qo = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const float d0 = (1.0f - acc[r]) + 0.0f;
-                if (ok0 && d0 <= tau4[r & 3]) {
-                    // opaque to hipcc on purpose: before an LDS write it can see, the compiler drains every outstanding
-                    // LDS-DMA request (s_waitcnt vmcnt(0)) — here once per tile, undoing the prefetch
-                    unsigned off;
-                    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
-                                 : "=v"(off)
-                                 : "v"((unsigned)(size_t)(cnt_w + qo)), "v"(1u)
-                                 : "memory");
+                const bool p = ok0 && acc[r] >= lo[r >> 2][r & 3];
+                const unsigned long long m = __ballot(p);
+                if (m == 0ull) continue;
+                const unsigned n_lo = (unsigned)__builtin_popcount((unsigned)m), n_hi = (unsigned)__builtin_popcount((unsigned)(m >> 32));
+                const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                unsigned c0 = cq[r] & 0xFFFFu, c1 = cq[r] >> 16;
+                const unsigned off = lane < 32 ? c0 + below : c1 + (below - n_lo);
+                if (p && off < seg_slots) {
                     const uint32_t e0 = seg_o + (uint32_t)((r & 3) + 8 * (r >> 2)) * a.cand_cap;
-                    if (off < seg_slots) a.cand[e0 + off] = make_key(d0, a.row_base + row0);
+                    a.cand[e0 + off] = make_key((1.0f - acc[r]) + 0.0f, a.row_base + row0);
                 }
+                c0 = c0 + n_lo < 0xFFFFu ? c0 + n_lo : 0xFFFFu;   // not clamped to seg_slots: a count above it tells the finish kernel that survivors were dropped
+                c1 = c1 + n_hi < 0xFFFFu ? c1 + n_hi : 0xFFFFu;
+                cq[r] = c0 | (c1 << 16);
             }
         }
     };
@@ -1430,6 +1442,15 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_wide_kernel(GemmArgs a, uin
     }
     if (late && it > 0) select_tile(t_prev);
     if (SPLIT && gave_up && lane == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(sync_addr + 4u), "v"(1u) : "memory");
+    if (!SAMPLE) {   // the wave's 32 survivor counters, SGPRs -> LDS: lane q takes query q's
+        unsigned mine = 0u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            mine = lane == (r & 3) + 8 * (r >> 2) ? (cq[r] & 0xFFFFu) : mine;
+            mine = lane == (r & 3) + 8 * (r >> 2) + 4 ? (cq[r] >> 16) : mine;
+        }
+        if (lane < 32) cnt_s[wave * 32 + lane] = mine == 0xFFFFu ? 0x40000000u : mine;   // saturated = unknown = overflowed
+    }
     __syncthreads();
     if (!SAMPLE && tid < 256) {
         const bool poisoned = SPLIT && sync_s[1] != 0u;       // a wave gave up waiting: nothing this workgroup selected can be trusted
@@ -1909,10 +1930,10 @@ hipError_t launch_batch_gemm(const GemmArgs& a, int metric, hipStream_t st) {
             case 768:
                 if (!ksplit_mode(a.use_rega)) {
                     switch ((a.debug >> 8) & 3u) {   // timing experiments: LDS tile buffers / accumulator chains / read-ahead
-                        case 1: return launch_wide<768, 2, 2>(a, st);
-                        case 2: return launch_wide<768, 3, 2, 1, true>(a, st);    // split tile barrier
-                        case 3: return launch_wide<768, 3, 3>(a, st);
-                        default: return launch_wide<768, 3, 2>(a, st);
+                        case 1: return launch_wide<768, 2, 3>(a, st);             // two LDS tile buffers
+                        case 2: return launch_wide<768, 3, 3, 1, true>(a, st);    // split tile barrier
+                        case 3: return launch_wide<768, 3, 2>(a, st);             // read-ahead 2
+                        default: return launch_wide<768, 3, 3>(a, st);            // three buffers, read-ahead 3 (-4 % against 2, profiles/r04)
                     }
                 }
                 switch ((a.debug >> 8) & 3u) {   // timing experiments: B-fragment read-ahead depth
@@ -2599,7 +2620,9 @@ __global__ __launch_bounds__(SCAN_THREADS) __attribute__((amdgpu_waves_per_eu(8,
     constexpr int CAP = 256;
     constexpr int LOADS = D4 / GROUP;
     constexpr int RPW = WAVE / GROUP;
-    __shared__ int64_t lds[SCAN_WAVES * CAP + SCAN_WAVES + 2 * FUSED_MAX_K];
+    constexpr int RCAP = FINISH_RETRY_CAP;                  // inline full retry: survivors one workgroup re-scores (below)
+    static_assert(2 * RCAP + FUSED_MAX_K + 8 >= SCAN_WAVES * CAP + SCAN_WAVES + 2 * FUSED_MAX_K, "the retry lists reuse the selection's LDS");
+    __shared__ int64_t lds[2 * RCAP + FUSED_MAX_K + 8];
     int* counts = reinterpret_cast<int*>(lds + SCAN_WAVES * CAP);
     int64_t* fin = lds + SCAN_WAVES * CAP + SCAN_WAVES;     // [kp] best approximate keys, ascending
     int64_t* ex = fin + FUSED_MAX_K;                        // [kp] their exact keys
@@ -2678,18 +2701,117 @@ __global__ __launch_bounds__(SCAN_THREADS) __attribute__((amdgpu_waves_per_eu(8,
         }
         a.out[(size_t)q * a.out_stride + o] = h;
     }
-    if (t == 0) {
-        uint32_t ok = 0;
-        if (!any_dropped && a.overflow[q] == 0u && m >= k) {
-            // every row outside the candidate set has an approximate distance >= a_max: the kp-th best approximate
-            // distance when the list is full, else the admission threshold itself (everything below it is a candidate)
-            // (the one-wave-per-SIMD GEMM admits on the conservative bound, i.e. slightly past tau: rows it rejected have
-            // d > tau, rows beyond the kp-th candidate have d >= that candidate's)
-            const float a_max = (total >= kp) ? __builtin_fminf(key_distance(fin[kp - 1]), a.tau[q]) : a.tau[q];
-            const float kth = key_distance(sorted[k - 1]);
-            ok = (a_max - a.eps[q] > kth) ? 1u : 0u;        // strict: ties stay uncertified
+    uint32_t ok = 0;
+    const bool clean = !any_dropped && a.overflow[q] == 0u;   // workgroup-uniform
+    if (clean && m >= k) {
+        // every row outside the candidate set has an approximate distance >= a_max: the kp-th best approximate
+        // distance when the list is full, else the admission threshold itself (everything below it is a candidate)
+        // (the one-wave-per-SIMD GEMM admits on the conservative bound, i.e. slightly past tau: rows it rejected have
+        // d > tau, rows beyond the kp-th candidate have d >= that candidate's)
+        const float a_max = (total >= kp) ? __builtin_fminf(key_distance(fin[kp - 1]), a.tau[q]) : a.tau[q];
+        const float kth = key_distance(sorted[k - 1]);
+        ok = (a_max - a.eps[q] > kth) ? 1u : 0u;            // strict: ties stay uncertified
+    }
+    // Inline full retry (round 4; second rung of the exactness ladder without leaving the kernel): the certificate failed although
+    // nothing was dropped — a dense neighbourhood: more rows inside the bf16 error band of the k-th neighbour than the k'
+    // candidates cover. EVERY row the filtering GEMM admitted is still in this query's segments, so this workgroup gathers all of
+    // them (up to RCAP), re-scores them exactly with the same arithmetic, ranks the exact keys and writes the k best; with every
+    // survivor re-scored the certificate only needs tau - eps > the exact k-th. Round 3 did this from the host at collect time
+    // (three launches and three synchronisations per batch behind the NEXT batch's GEMM: 2.1 x the batch time at k = 100 on a
+    // clustered corpus); here it costs the affected workgroups a few dozen microseconds and nobody else anything. A query with
+    // more survivors than RCAP (or fewer than k) stays uncertified: the host-side rungs (full retry over the whole survivor
+    // area, shared exact pass) answer it.
+    if (ok != 0u || !a.inline_retry || !clean || total <= kp) {   // total <= kp: every survivor was a candidate already
+        if (t == 0) a.certified[q] = ok;
+        return;
+    }
+    __syncthreads();                                        // `sorted`, `fin`, `ex` (all inside lds) are dead from here
+    int64_t* list = lds;                                    // [RCAP] survivors (approximate keys)
+    int64_t* exl = lds + RCAP;                              // [RCAP] their exact keys
+    int64_t* best = lds + 2 * RCAP;                         // [k] exact keys ascending
+    unsigned int* n_live = reinterpret_cast<unsigned int*>(lds + 2 * RCAP + FUSED_MAX_K);
+    if (t == 0) *n_live = 0u;
+    __syncthreads();
+    {
+        const int64_t* __restrict__ mine = a.cand + (size_t)q * a.cand_cap;
+        if (a.count_stride != 0u) {                         // one counted list
+            uint32_t c = a.seg_count[(size_t)q * a.count_stride];
+            c = c < a.seg_slots ? c : a.seg_slots;
+            if (t == 0) *n_live = c;
+            for (uint32_t i = threadIdx.x; i < c && i < (uint32_t)RCAP; i += SCAN_THREADS) list[i] = mine[i];
+        } else {
+            for (uint32_t seg = threadIdx.x; seg < a.nseg; seg += SCAN_THREADS) {
+                uint32_t c = a.seg_count[(size_t)seg * a.nq_pad + q];
+                c = c < a.seg_slots ? c : a.seg_slots;      // (no segment overflowed: `clean`)
+                if (c == 0u) continue;
+                const uint32_t pos = atomicAdd(n_live, c);
+                const int64_t* __restrict__ sp = mine + (size_t)seg * a.seg_slots;
+                for (uint32_t j = 0; j < c && pos + j < (uint32_t)RCAP; ++j) list[pos + j] = sp[j];
+            }
         }
-        a.certified[q] = ok;
+    }
+    __syncthreads();
+    const int live = (int)*n_live;
+    if (live > RCAP || live < k) {                          // too many to rank here / cannot happen (total >= m >= k): host rungs
+        if (t == 0) a.certified[q] = 0u;
+        return;
+    }
+    {
+        const int sub = lane / GROUP, gl = lane % GROUP;
+        const float qn = a.q_norm[q];
+        const f32x4* __restrict__ q4 = reinterpret_cast<const f32x4*>(a.queries) + (size_t)q * D4 + gl;
+        f32x4 qv[LOADS];
+#pragma unroll
+        for (int j = 0; j < LOADS; ++j) qv[j] = q4[j * GROUP];
+        constexpr int U = LOADS >= 4 ? 1 : 2;               // wide rows: one fetch in flight keeps this cold path inside the kernel's 64 VGPRs
+        for (int c0 = wave * RPW; c0 < live; c0 += SCAN_WAVES * RPW * U) {
+            int64_t ck[U];
+            f32x4 v[U][LOADS];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int c = c0 + u * SCAN_WAVES * RPW + sub;
+                ck[u] = list[c < live ? c : live - 1];
+                uint32_t lrow = key_row(ck[u]) - a.row_base;
+                lrow = lrow < a.n_rows ? lrow : 0;
+                const f32x4* __restrict__ v4 = reinterpret_cast<const f32x4*>(a.store) + (size_t)lrow * D4 + gl;
+#pragma unroll
+                for (int j = 0; j < LOADS; ++j) v[u][j] = v4[j * GROUP];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int c = c0 + u * SCAN_WAVES * RPW + sub;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f}, nrm = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < LOADS; ++j) accumulate_b<METRIC>(qv[j], v[u][j], acc, nrm);
+                const float s = group_sum<GROUP>(hsum_b(acc));
+                float mm = 0.f;
+                if (METRIC == BM_COS) mm = group_sum<GROUP>(hsum_b(nrm));
+                const float d = finish_distance_b<METRIC>(s, mm, qn);
+                if (c < live && gl == GROUP - 1) exl[c] = make_key(d, key_row(ck[u]));
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = t; i < live; i += SCAN_THREADS) {          // keys are unique (distinct rows): rank = number of smaller keys
+        const int64_t mine = exl[i];
+        int rank = 0;
+        for (int j = 0; j < live; ++j) rank += (exl[j] < mine) ? 1 : 0;
+        if (rank < k) best[rank] = mine;
+    }
+    __syncthreads();
+    for (uint32_t o = threadIdx.x; o < a.out_stride; o += SCAN_THREADS) {
+        wax_hip_hit h;
+        h.key = ((int)o < k) ? best[o] : KEY_PAD;
+        h.frame_id = ID_PAD;
+        if (h.key != KEY_PAD) {
+            const uint32_t local = key_row(h.key) - a.row_base;
+            h.frame_id = (a.ids != nullptr && local < a.n_rows) ? a.ids[local] : (uint64_t)key_row(h.key);
+        }
+        a.out[(size_t)q * a.out_stride + o] = h;
+    }
+    if (t == 0) {
+        ok = (a.tau[q] - a.eps[q] > key_distance(best[k - 1])) ? 2u : 0u;   // strict: ties with a rejected row stay uncertified
+        a.certified[q] = ok;                                                 // 2 = certified by the inline retry (the host counts them)
     }
 }
 

@@ -422,6 +422,7 @@ struct wax_hip_engine {
     std::atomic<int64_t> batch_dynamic{0};        // one-pass pipeline: filtering-GEMM workgroups claim their tiles from a counter
     std::atomic<int64_t> batch_sample_div{32};    // one-pass pipeline: 1 / this of the tiles are sampled (at least 256)
     std::atomic<uint64_t> st_onepass_queries{0};
+    std::atomic<uint64_t> st_batch_inline_retries{0};  // ... of which inside the finish kernel (no host round trip)
     std::atomic<uint64_t> st_query_args{0};          // single-query scans that took their query through the kernel arguments
     // wax_hip_search_batch_submit_device tickets (guarded by bticket_mu)
     struct BatchTicket {
@@ -1288,6 +1289,9 @@ int batch_enqueue(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32
         f.eps = c->d_eps; f.ids = e->d_ids; f.n_rows = n; f.row_base = (uint32_t)e->row_base; f.dims = D; f.nq = qn;
         f.kp = plan->kp; f.k = k_eff; f.sel = c->d_sel; f.exact = c->d_exact; f.out = d_out; f.out_stride = out_stride;
         f.certified = c->h_cert + cert_off;   // pinned host memory, written by the kernel: no copy launch behind the finish kernel
+        // "batch_retry" 1 (default): an uncertified query whose survivors fit one workgroup's LDS is retried inside the finish
+        // kernel (all survivors re-scored); 2: the host-driven full retry of round 3 only; 0: neither (exact path at once)
+        f.inline_retry = e->batch_retry.load() == 1 ? 1 : 0;
         HIP_TRY(launch_batch_finish(f, e->metric, st), WAX_HIP_ERR_INTERNAL, "finish kernel launch");
         c->last_finish = f; c->last_metric = e->metric;
         c->last_finish_valid = cert_off == 0;   // the candidate segments survive until collect only for a one-block batch
@@ -1445,6 +1449,12 @@ int batch_finish_device_locked(wax_hip_engine* e, BatchCtx* c, const float* d_qu
         }
     }
     int rc = WAX_HIP_OK;
+    {   // queries the finish kernel's inline full retry certified (flag value 2)
+        uint32_t inl = 0;
+        for (uint32_t q = 0; q < nq; ++q) inl += c->h_cert[q] == 2u;
+        e->st_batch_retries += inl;
+        e->st_batch_inline_retries += inl;
+    }
     // Second rung of the ladder, without another pass over the store: an uncertified query's survivors — EVERY row the
     // filtering GEMM admitted (approx distance <= tau) — are still in its segments, so all of them are re-scored exactly
     // (rescore_kernel in survivor-area mode) and the best k selected (full_retry_select_kernel). With every survivor re-scored
@@ -2759,7 +2769,7 @@ int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value) {
     else if (k == "batch_onepass_tiles") { if (value < 1024) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_onepass_tiles must be >= 1024"); e->batch_onepass_tiles = value; }
     else if (k == "batch_survivors") { if (value < 2 || value > 64) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_survivors must be 2..64"); e->batch_survivors = value; }
     else if (k == "batch_dynamic") e->batch_dynamic = value != 0;
-    else if (k == "batch_retry") e->batch_retry = value != 0;
+    else if (k == "batch_retry") { if (value < 0 || value > 2) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_retry must be 0, 1 or 2"); e->batch_retry = value; }
     else if (k == "batch_multi") e->batch_multi = value != 0;
     else if (k == "scan_chain") { if (value < -1 || value > 1) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "scan_chain must be -1 (auto), 0 or 1"); e->scan_chain = value; }
     else if (k == "share_timing") e->share_timing = value != 0;   // 0: every chained scan records its own start event (one more packet between scans)
@@ -2806,6 +2816,7 @@ int64_t wax_hip_get_tuning(wax_hip_engine* e, const char* key) {
     if (k == "fuse_merge") return e->fuse_merge.load();
     if (k == "query_args") return e->query_args.load();
     if (k == "query_args_scans") return (int64_t)e->st_query_args.load();
+    if (k == "batch_inline_retries") return (int64_t)e->st_batch_inline_retries.load();
     if (k == "batch_min") return e->batch_min.load();
     if (k == "batch_mode") return e->batch_mode.load();
     if (k == "batch_rega") return e->batch_rega.load();

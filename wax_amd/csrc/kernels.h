@@ -270,7 +270,11 @@ struct FinishArgs {
     // (Round 2's "wide retry" used it; the full retry of round 3 has its own kernels — CompactArgs / FullRetryArgs — and the
     // engine leaves this null.)
     const uint32_t* qlist;
+    // fused finish kernel (kp <= 192): != 0 = a query whose certificate fails with nothing dropped is retried INSIDE the kernel —
+    // all of its survivors (up to FINISH_RETRY_CAP) re-scored exactly; such a query's flag is certified[q] = 2 instead of 1
+    int inline_retry;
 };
+constexpr int FINISH_RETRY_CAP = 1024;
 hipError_t launch_batch_finish(const FinishArgs& a, int metric, hipStream_t stream);
 struct TightenArgs {
     int64_t* cand; uint32_t cand_cap; uint32_t* cand_count; int kp; uint32_t nq; float* tau; uint32_t* overflow;
