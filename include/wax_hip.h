@@ -329,7 +329,8 @@ int wax_hip_stats(wax_hip_engine* e, wax_hip_stats_t* out);
  * pipeline takes; default 1024), "batch_survivors" (one-pass: floor of the expected survivors per query as a multiple of k', default 3),
  * "batch_sample_div" (one-pass: 1/this of the tiles are sampled for the thresholds, default 32, at most 512 tiles / 8 tile rounds), "batch_workspaces" (concurrent
  * batched searches per engine, default 4), "batch_retry" (one-pass pipeline: an uncertified query gets a full retry — ALL of its survivors re-scored exactly — before the exact path:
- * 1 (default) = inside the finish kernel when its survivors fit one workgroup (<= 1 024), else driven from the host at collect; 2 = from the host only; 0 = never),
+ * 1 (default) = by a device-side kernel behind the finish kernel while recent batches had uncertified queries ("retry_hint" > 0: armed for 16
+ * batches by any such query, settable), and driven from the host at collect for whatever is left; 2 = from the host only; 0 = never),
  * "batch_dynamic" (one-pass pipeline: 1 = the filtering GEMM's workgroups claim their tiles from a counter instead of a static
  * stride, so that a workgroup delayed by another batch's kernels does not finish last; measured no faster, default 0; only the
  * workgroup-barrier kernel ("batch_rega" = 1) implements it — the split / free-running barriers of "batch_rega" 5 / 6 / 3 ignore it),

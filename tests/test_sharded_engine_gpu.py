@@ -309,9 +309,9 @@ def test_sharded_batch_resends_parts_rewritten_at_collect(wax, shards):
     a = torch.empty((nq, k, 2), dtype=torch.int64, device=dev)
     b = torch.empty((nq, k, 2), dtype=torch.int64, device=dev)
     one.searchBatchHitsDevice(dq.data_ptr(), nq, k, a.data_ptr(), k, stream)
-    # "batch_retry" = 2: the full retry driven from the HOST at collect time (round 3's rung; since round 4 the default, 1, first
-    # tries it inside the finish kernel, which settles the near-duplicates before the part is ever sent) — the re-send logic
-    # this test is about needs rows rewritten at collect
+    # "batch_retry" = 2: the full retry driven from the HOST at collect time (round 3's rung; since round 4 the default, 1, runs it
+    # on the device behind the finish kernel once the hint is armed, which settles such queries before the part is ever sent) —
+    # the re-send logic this test is about needs rows rewritten at collect
     many.setTuning("batch_retry", 2)
     r0, f0 = many.getTuning("batch_retries"), many.getTuning("batch_fallbacks")
     many.searchBatchHitsDevice(dq.data_ptr(), nq, k, b.data_ptr(), k, stream)
@@ -335,9 +335,10 @@ def test_sharded_batch_resends_parts_rewritten_at_collect(wax, shards):
     # two shards settled queries on the host side in the first batch, so the later collects ran the per-shard ladders side by
     # side on the handle's persistent workers
     assert many.getTuning("parallel_collects") >= 2
-    # the default ladder: the near-duplicate queries are certified INSIDE the finish kernel (all survivors re-scored there), the
-    # 3 000-fold tie (more survivors than one workgroup ranks) still goes to the host rungs — same hits
+    # the default ladder with the hint armed: the uncertified queries are settled by the device-side retry kernel behind each
+    # shard's finish kernel (all survivors re-scored there) — before the parts are sent, nothing rewritten at collect; same hits
     many.setTuning("batch_retry", 1)
+    many.setTuning("retry_hint", 16)
     i0 = many.getTuning("batch_inline_retries")
     b.zero_()
     many.searchBatchHitsDevice(dq.data_ptr(), nq, k, b.data_ptr(), k, stream)

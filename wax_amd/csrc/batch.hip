@@ -1360,7 +1360,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_wide_kernel(GemmArgs a, uin
                 const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                 unsigned c0 = cq[r] & 0xFFFFu, c1 = cq[r] >> 16;
                 const unsigned off = lane < 32 ? c0 + below : c1 + (below - n_lo);
-                if (p && off < seg_slots) {
+                if (p && off < seg_slots && !(a.debug & 8192u)) {   // debug bit 13 (timing only): everything but the store
                     const uint32_t e0 = seg_o + (uint32_t)((r & 3) + 8 * (r >> 2)) * a.cand_cap;
                     a.cand[e0 + off] = make_key((1.0f - acc[r]) + 0.0f, a.row_base + row0);
                 }
@@ -2620,9 +2620,7 @@ __global__ __launch_bounds__(SCAN_THREADS) __attribute__((amdgpu_waves_per_eu(8,
     constexpr int CAP = 256;
     constexpr int LOADS = D4 / GROUP;
     constexpr int RPW = WAVE / GROUP;
-    constexpr int RCAP = FINISH_RETRY_CAP;                  // inline full retry: survivors one workgroup re-scores (below)
-    static_assert(2 * RCAP + FUSED_MAX_K + 8 >= SCAN_WAVES * CAP + SCAN_WAVES + 2 * FUSED_MAX_K, "the retry lists reuse the selection's LDS");
-    __shared__ int64_t lds[2 * RCAP + FUSED_MAX_K + 8];
+    __shared__ int64_t lds[SCAN_WAVES * CAP + SCAN_WAVES + 2 * FUSED_MAX_K];
     int* counts = reinterpret_cast<int*>(lds + SCAN_WAVES * CAP);
     int64_t* fin = lds + SCAN_WAVES * CAP + SCAN_WAVES;     // [kp] best approximate keys, ascending
     int64_t* ex = fin + FUSED_MAX_K;                        // [kp] their exact keys
@@ -2701,105 +2699,102 @@ __global__ __launch_bounds__(SCAN_THREADS) __attribute__((amdgpu_waves_per_eu(8,
         }
         a.out[(size_t)q * a.out_stride + o] = h;
     }
-    uint32_t ok = 0;
-    const bool clean = !any_dropped && a.overflow[q] == 0u;   // workgroup-uniform
-    if (clean && m >= k) {
-        // every row outside the candidate set has an approximate distance >= a_max: the kp-th best approximate
-        // distance when the list is full, else the admission threshold itself (everything below it is a candidate)
-        // (the one-wave-per-SIMD GEMM admits on the conservative bound, i.e. slightly past tau: rows it rejected have
-        // d > tau, rows beyond the kp-th candidate have d >= that candidate's)
-        const float a_max = (total >= kp) ? __builtin_fminf(key_distance(fin[kp - 1]), a.tau[q]) : a.tau[q];
-        const float kth = key_distance(sorted[k - 1]);
-        ok = (a_max - a.eps[q] > kth) ? 1u : 0u;            // strict: ties stay uncertified
-    }
-    // Inline full retry (round 4; second rung of the exactness ladder without leaving the kernel): the certificate failed although
-    // nothing was dropped — a dense neighbourhood: more rows inside the bf16 error band of the k-th neighbour than the k'
-    // candidates cover. EVERY row the filtering GEMM admitted is still in this query's segments, so this workgroup gathers all of
-    // them (up to RCAP), re-scores them exactly with the same arithmetic, ranks the exact keys and writes the k best; with every
-    // survivor re-scored the certificate only needs tau - eps > the exact k-th. Round 3 did this from the host at collect time
-    // (three launches and three synchronisations per batch behind the NEXT batch's GEMM: 2.1 x the batch time at k = 100 on a
-    // clustered corpus); here it costs the affected workgroups a few dozen microseconds and nobody else anything. A query with
-    // more survivors than RCAP (or fewer than k) stays uncertified: the host-side rungs (full retry over the whole survivor
-    // area, shared exact pass) answer it.
-    if (ok != 0u || !a.inline_retry || !clean || total <= kp) {   // total <= kp: every survivor was a candidate already
-        if (t == 0) a.certified[q] = ok;
-        return;
-    }
-    __syncthreads();                                        // `sorted`, `fin`, `ex` (all inside lds) are dead from here
-    int64_t* list = lds;                                    // [RCAP] survivors (approximate keys)
-    int64_t* exl = lds + RCAP;                              // [RCAP] their exact keys
-    int64_t* best = lds + 2 * RCAP;                         // [k] exact keys ascending
-    unsigned int* n_live = reinterpret_cast<unsigned int*>(lds + 2 * RCAP + FUSED_MAX_K);
-    if (t == 0) *n_live = 0u;
-    __syncthreads();
-    {
-        const int64_t* __restrict__ mine = a.cand + (size_t)q * a.cand_cap;
-        if (a.count_stride != 0u) {                         // one counted list
-            uint32_t c = a.seg_count[(size_t)q * a.count_stride];
-            c = c < a.seg_slots ? c : a.seg_slots;
-            if (t == 0) *n_live = c;
-            for (uint32_t i = threadIdx.x; i < c && i < (uint32_t)RCAP; i += SCAN_THREADS) list[i] = mine[i];
-        } else {
-            for (uint32_t seg = threadIdx.x; seg < a.nseg; seg += SCAN_THREADS) {
-                uint32_t c = a.seg_count[(size_t)seg * a.nq_pad + q];
-                c = c < a.seg_slots ? c : a.seg_slots;      // (no segment overflowed: `clean`)
-                if (c == 0u) continue;
-                const uint32_t pos = atomicAdd(n_live, c);
-                const int64_t* __restrict__ sp = mine + (size_t)seg * a.seg_slots;
-                for (uint32_t j = 0; j < c && pos + j < (uint32_t)RCAP; ++j) list[pos + j] = sp[j];
-            }
+    if (t == 0) {
+        uint32_t ok = 0;
+        if (!any_dropped && a.overflow[q] == 0u && m >= k) {
+            // every row outside the candidate set has an approximate distance >= a_max: the kp-th best approximate
+            // distance when the list is full, else the admission threshold itself (everything below it is a candidate)
+            // (the one-wave-per-SIMD GEMM admits on the conservative bound, i.e. slightly past tau: rows it rejected have
+            // d > tau, rows beyond the kp-th candidate have d >= that candidate's)
+            const float a_max = (total >= kp) ? __builtin_fminf(key_distance(fin[kp - 1]), a.tau[q]) : a.tau[q];
+            const float kth = key_distance(sorted[k - 1]);
+            ok = (a_max - a.eps[q] > kth) ? 1u : 0u;        // strict: ties stay uncertified
         }
+        a.certified[q] = ok;
+        // device-side copy of the flag for batch_retry_kernel (launched behind this kernel when the engine expects failures);
+        // 2 = "retry pointless": something was dropped, or every survivor was a candidate already
+        if (a.cert_dev != nullptr) a.cert_dev[q] = ok != 0u ? 1u : ((any_dropped || a.overflow[q] != 0u || total <= kp || m < k) ? 2u : 0u);
     }
-    __syncthreads();
-    const int live = (int)*n_live;
-    if (live > RCAP || live < k) {                          // too many to rank here / cannot happen (total >= m >= k): host rungs
-        if (t == 0) a.certified[q] = 0u;
-        return;
-    }
-    {
-        const int sub = lane / GROUP, gl = lane % GROUP;
-        const float qn = a.q_norm[q];
-        const f32x4* __restrict__ q4 = reinterpret_cast<const f32x4*>(a.queries) + (size_t)q * D4 + gl;
-        f32x4 qv[LOADS];
+}
+
+// Device-side full retry (round 4; second rung of the exactness ladder without a host round trip). One 1 024-thread workgroup per
+// query, launched right behind batch_finish_kernel on the batch's stream; a workgroup whose query is certified (cert_dev != 0)
+// exits at once. Otherwise the first finish failed although nothing was dropped — a dense neighbourhood: more rows inside the bf16
+// error band of the k-th neighbour than the k' candidates cover. EVERY row the filtering GEMM admitted is still in the query's
+// segments, so all of them are re-scored exactly (scan_kernel's lane mapping and summation order: bit-identical distances), each
+// exact key goes straight into its wave's top-k list, the sixteen lists are merged by rank and the k best written; with every
+// survivor re-scored the certificate only needs tau - eps > the exact k-th. Round 3 did this from the host at collect time
+// (three launches and three synchronisations per batch, queued behind the NEXT batch's GEMM: 2.1 x the batch time at k = 100 on
+// a clustered corpus). The engine launches this kernel only while recent batches had uncertified queries ("retry hint"), so a
+// well-separated corpus never pays for the extra launch; the host-driven rung stays behind it for whatever is left.
+constexpr int RETRY_WAVES = 16;
+template <int D4, int GROUP, int METRIC>
+__global__ __launch_bounds__(RETRY_WAVES * 64) void batch_retry_kernel(FinishArgs a) {
+    constexpr int CAP = 256;
+    constexpr int LOADS = D4 / GROUP;
+    constexpr int RPW = WAVE / GROUP;
+    __shared__ int64_t lds[RETRY_WAVES * CAP + RETRY_WAVES + FUSED_MAX_K];
+    int* counts = reinterpret_cast<int*>(lds + RETRY_WAVES * CAP);
+    int64_t* best = lds + RETRY_WAVES * CAP + RETRY_WAVES;
+    const uint32_t q = blockIdx.x;
+    if (a.cert_dev[q] != 0u) return;                        // certified by the first finish, or not retryable (workgroup-uniform)
+    const int lane = lane_id();
+    const int wave = (int)(threadIdx.x >> 6);
+    const int k = a.k;
+    WaveTopK<CAP> tk;
+    tk.init(lds + wave * CAP, k);
+    const int sub = lane / GROUP, gl = lane % GROUP;
+    const float qn = a.q_norm[q];
+    const f32x4* __restrict__ q4 = reinterpret_cast<const f32x4*>(a.queries) + (size_t)q * D4 + gl;
+    f32x4 qv[LOADS];
 #pragma unroll
-        for (int j = 0; j < LOADS; ++j) qv[j] = q4[j * GROUP];
-        constexpr int U = LOADS >= 4 ? 1 : 2;               // wide rows: one fetch in flight keeps this cold path inside the kernel's 64 VGPRs
-        for (int c0 = wave * RPW; c0 < live; c0 += SCAN_WAVES * RPW * U) {
+    for (int j = 0; j < LOADS; ++j) qv[j] = q4[j * GROUP];
+    const int64_t* __restrict__ mine = a.cand + (size_t)q * a.cand_cap;
+    const uint32_t nseg = a.count_stride != 0u ? 1u : a.nseg;
+    constexpr int U = LOADS >= 4 ? 2 : 4;                   // row fetches in flight per lane group
+    uint32_t live = 0;                                      // survivors this wave re-scored
+    for (uint32_t seg = (uint32_t)wave; seg < nseg; seg += RETRY_WAVES) {
+        uint32_t c = a.count_stride != 0u ? a.seg_count[(size_t)q * a.count_stride] : a.seg_count[(size_t)seg * a.nq_pad + q];
+        c = c < a.seg_slots ? c : a.seg_slots;              // (no segment overflowed: cert_dev would be 2)
+        const int64_t* __restrict__ sp = mine + (size_t)seg * a.seg_slots;
+        live += c;
+        for (uint32_t c0 = 0; c0 < c; c0 += RPW * U) {      // wave-uniform trip count
             int64_t ck[U];
             f32x4 v[U][LOADS];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int c = c0 + u * SCAN_WAVES * RPW + sub;
-                ck[u] = list[c < live ? c : live - 1];
+                const uint32_t ci = c0 + (uint32_t)(u * RPW + sub);
+                ck[u] = sp[ci < c ? ci : c - 1];
                 uint32_t lrow = key_row(ck[u]) - a.row_base;
                 lrow = lrow < a.n_rows ? lrow : 0;
                 const f32x4* __restrict__ v4 = reinterpret_cast<const f32x4*>(a.store) + (size_t)lrow * D4 + gl;
 #pragma unroll
                 for (int j = 0; j < LOADS; ++j) v[u][j] = v4[j * GROUP];
             }
+            tk.make_room(RPW * U);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int c = c0 + u * SCAN_WAVES * RPW + sub;
+                const uint32_t ci = c0 + (uint32_t)(u * RPW + sub);
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f}, nrm = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int j = 0; j < LOADS; ++j) accumulate_b<METRIC>(qv[j], v[u][j], acc, nrm);
-                const float s = group_sum<GROUP>(hsum_b(acc));
+                const float s2 = group_sum<GROUP>(hsum_b(acc));
                 float mm = 0.f;
                 if (METRIC == BM_COS) mm = group_sum<GROUP>(hsum_b(nrm));
-                const float d = finish_distance_b<METRIC>(s, mm, qn);
-                if (c < live && gl == GROUP - 1) exl[c] = make_key(d, key_row(ck[u]));
+                const float d = finish_distance_b<METRIC>(s2, mm, qn);
+                tk.push(make_key(d, key_row(ck[u])), ci < c && gl == GROUP - 1);
             }
         }
     }
+    tk.finalize();
+    if (lane == 0) counts[wave] = tk.cnt;
     __syncthreads();
-    for (int i = t; i < live; i += SCAN_THREADS) {          // keys are unique (distinct rows): rank = number of smaller keys
-        const int64_t mine = exl[i];
-        int rank = 0;
-        for (int j = 0; j < live; ++j) rank += (exl[j] < mine) ? 1 : 0;
-        if (rank < k) best[rank] = mine;
-    }
+    block_rank_merge<RETRY_WAVES>(lds, CAP, counts, k, best);
     __syncthreads();
-    for (uint32_t o = threadIdx.x; o < a.out_stride; o += SCAN_THREADS) {
+    int total = 0;
+#pragma unroll
+    for (int w = 0; w < RETRY_WAVES; ++w) total += counts[w];
+    for (uint32_t o = threadIdx.x; o < a.out_stride; o += RETRY_WAVES * 64) {
         wax_hip_hit h;
         h.key = ((int)o < k) ? best[o] : KEY_PAD;
         h.frame_id = ID_PAD;
@@ -2809,9 +2804,36 @@ __global__ __launch_bounds__(SCAN_THREADS) __attribute__((amdgpu_waves_per_eu(8,
         }
         a.out[(size_t)q * a.out_stride + o] = h;
     }
-    if (t == 0) {
-        ok = (a.tau[q] - a.eps[q] > key_distance(best[k - 1])) ? 2u : 0u;   // strict: ties with a rejected row stay uncertified
-        a.certified[q] = ok;                                                 // 2 = certified by the inline retry (the host counts them)
+    if (threadIdx.x == 0) {
+        const bool okr = total >= k && best[k - 1] != KEY_PAD && a.tau[q] - a.eps[q] > key_distance(best[k - 1]);   // strict: ties with a rejected row stay uncertified
+        a.certified[q] = okr ? 2u : 0u;                     // 2 = certified by the device-side retry (the host counts them)
+    }
+    (void)live;
+}
+
+template <int D4, int GROUP>
+static hipError_t launch_retry_t(const FinishArgs& a, int metric, hipStream_t st) {
+    switch (metric) {
+        case BM_COS: hipLaunchKernelGGL((batch_retry_kernel<D4, GROUP, BM_COS>), dim3(a.nq), dim3(RETRY_WAVES * 64), 0, st, a); break;
+        case BM_DOT: hipLaunchKernelGGL((batch_retry_kernel<D4, GROUP, BM_DOT>), dim3(a.nq), dim3(RETRY_WAVES * 64), 0, st, a); break;
+        case BM_L2: hipLaunchKernelGGL((batch_retry_kernel<D4, GROUP, BM_L2>), dim3(a.nq), dim3(RETRY_WAVES * 64), 0, st, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// The device-side full retry behind a fused finish (same arguments; a.cert_dev must be the array that finish wrote).
+bool batch_retry_dims(uint32_t dims) { return dims == 128 || dims == 256 || dims == 384 || dims == 512 || dims == 768; }
+hipError_t launch_batch_retry(const FinishArgs& a, int metric, hipStream_t st) {
+    if (a.nq == 0) return hipSuccess;
+    if (a.cert_dev == nullptr || a.kp > FUSED_MAX_K || a.k < 1 || a.k > FUSED_MAX_K || a.qlist != nullptr) return hipErrorInvalidValue;
+    switch (a.dims) {   // (D4, GROUP) as in launch_batch_finish / launch_scan
+        case 128: return launch_retry_t<32, 32>(a, metric, st);
+        case 256: return launch_retry_t<64, 64>(a, metric, st);
+        case 384: return launch_retry_t<96, 32>(a, metric, st);
+        case 512: return launch_retry_t<128, 64>(a, metric, st);
+        case 768: return launch_retry_t<192, 64>(a, metric, st);
+        default: return hipErrorInvalidValue;
     }
 }
 

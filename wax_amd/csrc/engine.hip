@@ -315,6 +315,7 @@ struct BatchCtx {
     uint64_t rescue_exact_cap = 0;
     uint32_t* h_live = nullptr;          // pinned [kBatchMaxQ]: live survivors per query of a retry round
     uint32_t* h_cert = nullptr;          // pinned [cert_cap]
+    uint32_t* d_cert = nullptr;          // device [cert_cap]: the finish kernel's flags for the device-side retry kernel
     float* h_qnorm = nullptr;            // pinned [cert_cap]: exact norms (the exact-path fallback needs them on the host)
 };
 
@@ -422,6 +423,7 @@ struct wax_hip_engine {
     std::atomic<int64_t> batch_dynamic{0};        // one-pass pipeline: filtering-GEMM workgroups claim their tiles from a counter
     std::atomic<int64_t> batch_sample_div{32};    // one-pass pipeline: 1 / this of the tiles are sampled (at least 256)
     std::atomic<uint64_t> st_onepass_queries{0};
+    std::atomic<int> retry_hint{0};                   // > 0: batches carry the device-side retry kernel behind their finish kernel
     std::atomic<uint64_t> st_batch_inline_retries{0};  // ... of which inside the finish kernel (no host round trip)
     std::atomic<uint64_t> st_query_args{0};          // single-query scans that took their query through the kernel arguments
     // wax_hip_search_batch_submit_device tickets (guarded by bticket_mu)
@@ -899,7 +901,7 @@ void free_bctx(BatchCtx* c) {
     (void)hipFree(c->d_tau); (void)hipFree(c->d_dense); (void)hipFree(c->d_cand_count); (void)hipFree(c->d_overflow);
     (void)hipFree(c->d_cand); (void)hipFree(c->d_seg_count); (void)hipFree(c->d_exact); (void)hipFree(c->d_sel);
     (void)hipFree(c->d_tile_max); (void)hipFree(c->d_hits);
-    (void)hipHostFree(c->h_hits); (void)hipHostFree(c->h_cert); (void)hipHostFree(c->h_qnorm); (void)hipHostFree(c->h_qlist);
+    (void)hipHostFree(c->h_hits); (void)hipHostFree(c->h_cert); (void)hipFree(c->d_cert); (void)hipHostFree(c->h_qnorm); (void)hipHostFree(c->h_qlist);
     (void)hipFree(c->d_qlist); (void)hipHostFree(c->h_fnorm); (void)hipFree(c->d_fnorm); (void)hipFree(c->d_mpart); (void)hipFree(c->d_rescue); (void)hipFree(c->d_rescue_exact); (void)hipHostFree(c->h_live);
     if (c->ev_in) (void)hipEventDestroy(c->ev_in);
     if (c->ev_g0) (void)hipEventDestroy(c->ev_g0);
@@ -1084,9 +1086,10 @@ int bctx_reserve(BatchCtx* c, uint64_t cand_slots, uint64_t kp, uint64_t tile_ro
     if (c->cert_cap < n_queries) {
         uint64_t want = 1024;
         while (want < n_queries) want *= 2;
-        (void)hipHostFree(c->h_cert); (void)hipHostFree(c->h_qnorm);
-        c->h_cert = nullptr; c->h_qnorm = nullptr; c->cert_cap = 0;
+        (void)hipHostFree(c->h_cert); (void)hipHostFree(c->h_qnorm); (void)hipFree(c->d_cert);
+        c->h_cert = nullptr; c->h_qnorm = nullptr; c->d_cert = nullptr; c->cert_cap = 0;
         HIP_TRY(hipHostMalloc(&c->h_cert, want * sizeof(uint32_t), hipHostMallocDefault), WAX_HIP_ERR_ALLOC, "Failed to allocate pinned batch flags");
+        HIP_TRY(hipMalloc(&c->d_cert, want * sizeof(uint32_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch flags");
         HIP_TRY(hipHostMalloc(&c->h_qnorm, want * sizeof(float), hipHostMallocDefault), WAX_HIP_ERR_ALLOC, "Failed to allocate pinned batch norms");
         c->cert_cap = want;
     }
@@ -1289,10 +1292,14 @@ int batch_enqueue(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32
         f.eps = c->d_eps; f.ids = e->d_ids; f.n_rows = n; f.row_base = (uint32_t)e->row_base; f.dims = D; f.nq = qn;
         f.kp = plan->kp; f.k = k_eff; f.sel = c->d_sel; f.exact = c->d_exact; f.out = d_out; f.out_stride = out_stride;
         f.certified = c->h_cert + cert_off;   // pinned host memory, written by the kernel: no copy launch behind the finish kernel
-        // "batch_retry" 1 (default): an uncertified query whose survivors fit one workgroup's LDS is retried inside the finish
-        // kernel (all survivors re-scored); 2: the host-driven full retry of round 3 only; 0: neither (exact path at once)
-        f.inline_retry = e->batch_retry.load() == 1 ? 1 : 0;
+        f.cert_dev = c->d_cert + cert_off;
         HIP_TRY(launch_batch_finish(f, e->metric, st), WAX_HIP_ERR_INTERNAL, "finish kernel launch");
+        // "batch_retry" 1 (default): while recent batches had queries the first finish could not certify (`retry_hint`, set at
+        // collect), the device-side full retry rides behind the finish kernel — uncertified queries get ALL their survivors
+        // re-scored without a host round trip; certified ones cost their workgroup one flag read. A store whose batches certify
+        // never pays for the launch. 2: the host-driven full retry of round 3 only; 0: neither (exact path at once).
+        if (e->batch_retry.load() == 1 && e->retry_hint.load() > 0 && f.kp <= FUSED_MAX_K && batch_retry_dims(D) && !counted)
+            HIP_TRY(launch_batch_retry(f, e->metric, st), WAX_HIP_ERR_INTERNAL, "retry kernel launch");
         c->last_finish = f; c->last_metric = e->metric;
         c->last_finish_valid = cert_off == 0;   // the candidate segments survive until collect only for a one-block batch
         e->st_onepass_queries += qn;
@@ -1449,11 +1456,14 @@ int batch_finish_device_locked(wax_hip_engine* e, BatchCtx* c, const float* d_qu
         }
     }
     int rc = WAX_HIP_OK;
-    {   // queries the finish kernel's inline full retry certified (flag value 2)
-        uint32_t inl = 0;
-        for (uint32_t q = 0; q < nq; ++q) inl += c->h_cert[q] == 2u;
+    {   // queries the device-side full retry certified (flag value 2); and the hint that decides whether the NEXT batches carry
+        // the retry kernel: armed (for 16 batches) by any query the first finish left uncertified, counted down by clean batches
+        uint32_t inl = 0, unc = 0;
+        for (uint32_t q = 0; q < nq; ++q) { inl += c->h_cert[q] == 2u; unc += c->h_cert[q] != 1u; }
         e->st_batch_retries += inl;
         e->st_batch_inline_retries += inl;
+        if (unc > 0) e->retry_hint.store(16);
+        else if (e->retry_hint.load() > 0) e->retry_hint.fetch_sub(1);
     }
     // Second rung of the ladder, without another pass over the store: an uncertified query's survivors — EVERY row the
     // filtering GEMM admitted (approx distance <= tau) — are still in its segments, so all of them are re-scored exactly
@@ -2769,6 +2779,7 @@ int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value) {
     else if (k == "batch_onepass_tiles") { if (value < 1024) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_onepass_tiles must be >= 1024"); e->batch_onepass_tiles = value; }
     else if (k == "batch_survivors") { if (value < 2 || value > 64) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_survivors must be 2..64"); e->batch_survivors = value; }
     else if (k == "batch_dynamic") e->batch_dynamic = value != 0;
+    else if (k == "retry_hint") e->retry_hint = (int)value;   // > 0: the next batches carry the device-side retry kernel (set by collect; tests force it)
     else if (k == "batch_retry") { if (value < 0 || value > 2) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_retry must be 0, 1 or 2"); e->batch_retry = value; }
     else if (k == "batch_multi") e->batch_multi = value != 0;
     else if (k == "scan_chain") { if (value < -1 || value > 1) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "scan_chain must be -1 (auto), 0 or 1"); e->scan_chain = value; }
@@ -2817,6 +2828,7 @@ int64_t wax_hip_get_tuning(wax_hip_engine* e, const char* key) {
     if (k == "query_args") return e->query_args.load();
     if (k == "query_args_scans") return (int64_t)e->st_query_args.load();
     if (k == "batch_inline_retries") return (int64_t)e->st_batch_inline_retries.load();
+    if (k == "retry_hint") return e->retry_hint.load();
     if (k == "batch_min") return e->batch_min.load();
     if (k == "batch_mode") return e->batch_mode.load();
     if (k == "batch_rega") return e->batch_rega.load();

@@ -270,11 +270,14 @@ struct FinishArgs {
     // (Round 2's "wide retry" used it; the full retry of round 3 has its own kernels — CompactArgs / FullRetryArgs — and the
     // engine leaves this null.)
     const uint32_t* qlist;
-    // fused finish kernel (kp <= 192): != 0 = a query whose certificate fails with nothing dropped is retried INSIDE the kernel —
-    // all of its survivors (up to FINISH_RETRY_CAP) re-scored exactly; such a query's flag is certified[q] = 2 instead of 1
-    int inline_retry;
+    // fused finish kernel (kp <= 192): non-null = device-side copy of the flags for batch_retry_kernel: 1 certified, 0 = failed with
+    // every survivor still in the segments (retryable), 2 = failed and a retry is pointless (something dropped / nothing beyond k')
+    uint32_t* cert_dev;
 };
-constexpr int FINISH_RETRY_CAP = 1024;
+// Device-side full retry behind launch_batch_finish (same arguments, cert_dev written by it): per uncertified query ALL survivors are
+// re-scored exactly and the k best written; a query it certifies gets certified[q] = 2.
+bool batch_retry_dims(uint32_t dims);
+hipError_t launch_batch_retry(const FinishArgs& a, int metric, hipStream_t stream);
 hipError_t launch_batch_finish(const FinishArgs& a, int metric, hipStream_t stream);
 struct TightenArgs {
     int64_t* cand; uint32_t cand_cap; uint32_t* cand_count; int kp; uint32_t nq; float* tau; uint32_t* overflow;
