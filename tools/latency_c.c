@@ -53,8 +53,11 @@ int main(int argc, char** argv) {
         uint64_t out_ids[64], first[64];
         float out_scores[64];
         uint32_t got = 0;
-        for (int mode = 0; mode <= 2; ++mode) {
-            wax_hip_set_tuning(e, "query_args", mode);
+        /* modes 0..2 = "query_args" 0 / 1 / 2 on the automatic grid; 3, 4 = query_args 1 with at most 80 / 40 scan workgroups
+         * (fewer, fatter workgroups: fewer partial lists for the fused final merge, more rows per wave) */
+        for (int mode = 0; mode <= 4; ++mode) {
+            wax_hip_set_tuning(e, "query_args", mode <= 2 ? mode : 1);
+            wax_hip_set_tuning(e, "grid_blocks", mode == 3 ? 80 : mode == 4 ? 40 : 0);
             for (int i = 0; i < 50; ++i) wax_hip_search(e, q, (uint32_t)dims, topk, out_ids, out_scores, 64, &got);
             if (mode == 0) for (uint32_t i = 0; i < got; ++i) first[i] = out_ids[i];
             int same = 1;
@@ -68,10 +71,10 @@ int main(int argc, char** argv) {
             }
             const double mean = (now_us() - t0) / reps;
             qsort(lat, (size_t)reps, sizeof(double), cmp);
-            printf("{\"tool\": \"latency_c\", \"corpus\": \"%s\", \"rows\": %d, \"dims\": %d, \"top_k\": %d, \"query_args\": %d, "
+            printf("{\"tool\": \"latency_c\", \"corpus\": \"%s\", \"rows\": %d, \"dims\": %d, \"top_k\": %d, \"mode\": %d, \"scan_grid\": %lld, "
                    "\"scans_with_query_in_kernel_args\": %lld, \"reps\": %d, \"mean_us\": %.2f, \"median_us\": %.2f, \"p99_us\": %.2f, "
                    "\"min_us\": %.2f, \"hits\": %u, \"same_ids_as_query_args_0\": %s}\n",
-                   corpus == 0 ? "reference harness ((i + d) % 256) / 255" : "unit gaussian", n, dims, topk, mode,
+                   corpus == 0 ? "reference harness ((i + d) % 256) / 255" : "unit gaussian", n, dims, topk, mode, (long long)wax_hip_get_tuning(e, "scan_grid"),
                    (long long)(wax_hip_get_tuning(e, "query_args_scans") - before), reps, mean, lat[reps / 2], lat[(int)(reps * 0.99)],
                    lat[0], got, same ? "true" : "false");
         }

@@ -1298,7 +1298,7 @@ int batch_enqueue(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32
         // collect), the device-side full retry rides behind the finish kernel — uncertified queries get ALL their survivors
         // re-scored without a host round trip; certified ones cost their workgroup one flag read. A store whose batches certify
         // never pays for the launch. 2: the host-driven full retry of round 3 only; 0: neither (exact path at once).
-        if (e->batch_retry.load() == 1 && e->retry_hint.load() > 0 && f.kp <= FUSED_MAX_K && batch_retry_dims(D) && !counted)
+        if (e->batch_retry.load() == 1 && e->retry_hint.load() > 0 && k_eff <= FUSED_MAX_K && batch_retry_dims(D) && !counted)
             HIP_TRY(launch_batch_retry(f, e->metric, st), WAX_HIP_ERR_INTERNAL, "retry kernel launch");
         c->last_finish = f; c->last_metric = e->metric;
         c->last_finish_valid = cert_off == 0;   // the candidate segments survive until collect only for a one-block batch
