@@ -2029,3 +2029,43 @@ def test_device_side_full_retry_equals_host_retry_and_exact_path(wax):
             else:
                 assert all(np.array_equal(x, y) for x, y in zip(got, ref)), (k, mode, hint)
     eng.close()
+
+
+def test_completion_word_equals_event_completion(wax):
+    """"done_flag" (default 1): a single-query scan that merges in the kernel publishes a completion word in pinned memory behind its
+    hits and collect polls that word instead of an event recorded behind the kernel. Same hits as with events ("done_flag" = 0),
+    pipelined tickets collected in any order, slots reused thousands of times (the word is a per-slot sequence number), mixed
+    with scans that cannot use it (two-launch merge, general selection, timed kernels)."""
+    for metric, dims, n in [(0, 384, 10_000), (1, 768, 2_000), (2, 128, 5_000), (0, 100, 3_000)]:
+        corpus = oracle.gaussian_unit_rows(3 + n, n, dims)
+        eng = make_engine(wax, metric, dims, corpus, np.arange(n, dtype=np.uint64) + 5)
+        queries = oracle.gaussian_unit_queries(16, dims, seed=n)
+        fused = eng.getTuning("scan_grid") <= 160
+        eng.setTuning("done_flag", 0)
+        ref = {k: [eng.searchArrays(q, k) for q in queries] for k in (1, 10, 100, 500)}
+        eng.setTuning("done_flag", 1)
+        w0 = eng.getTuning("done_flag_waits")
+        for k in (1, 10, 100, 500):
+            pend = [(i, eng.submit(queries[i], k)) for i in range(4)]
+            got = {}
+            for i, t in reversed(pend):                                 # collected in reverse order
+                got[i] = eng.collect(t, k)
+            for i in range(4, 16):
+                got[i] = eng.searchArrays(queries[i], k)
+            for i in range(16):
+                assert np.array_equal(got[i][0], ref[k][i][0]) and np.array_equal(got[i][1], ref[k][i][1]), (metric, dims, n, k, i)
+        used = eng.getTuning("done_flag_waits") - w0
+        assert used == (3 * 16 if fused else 0), (metric, dims, n, used)   # k <= 192 on a small grid; k = 500 is the general selection
+        for _ in range(2000):                                           # the per-slot sequence numbers keep counting
+            eng.searchArrays(queries[0], 10)
+        a = eng.searchArrays(queries[1], 10)
+        assert np.array_equal(a[0], ref[10][1][0])
+        eng.setTuning("time_kernels", 1)                                # timed kernels complete through their events
+        w1 = eng.getTuning("done_flag_waits")
+        b = eng.searchArrays(queries[2], 10)
+        assert eng.getTuning("done_flag_waits") == w1 and np.array_equal(b[0], ref[10][2][0])
+        eng.setTuning("time_kernels", 0)
+        eng.setTuning("fuse_merge", 0)                                  # two launches: the merge kernel does not publish the word
+        c = eng.searchArrays(queries[3], 10)
+        assert eng.getTuning("done_flag_waits") == w1 and np.array_equal(c[0], ref[10][3][0])
+        eng.close()

@@ -636,7 +636,6 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
     const bool late = wave >= 4 && !(a.debug & 16u);   // debug bit4: every wave in the same order
     const bool dbg_noload = !FREE && (a.debug & 1u) != 0, dbg_nomfma = !FREE && (a.debug & 2u) != 0;  // timing experiments only
     const bool prio = (a.debug & 32u) == 0;            // s_setprio 1 around the MFMA stream (+2-3 % at Q = 1024); debug bit5 turns it off
-    const bool prio_hi = !late && (a.debug & 32768u) != 0;
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
@@ -695,10 +694,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
             fb1[i] = *reinterpret_cast<const u32x4*>(b1 + i * 32);
         }
         if (FREE && token) wait_count(turn_s + (wave & 3), my_turn);
-        // the SIMD's other wave is in its selection: MFMA issue first. debug bit 15: an EARLY wave (MFMAs, then selection, then the
-        // tile barrier) outranks its late partner, so its K loop ends first and its selection — cold path included — runs under the
-        // partner's remaining MFMAs instead of after them, in front of the barrier
-        if (prio) { if (prio_hi) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }
+        if (prio) __builtin_amdgcn_s_setprio(1);   // the SIMD's other wave is in its selection: MFMA issue first
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -1290,7 +1286,6 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_wide_kernel(GemmArgs a, uin
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
     const bool prio = (a.debug & 32u) == 0;
-    const bool prio_hi = (a.debug & 32768u) != 0 && wave < 4 && !(a.debug & 16u);   // an early wave outranks its late partner
     // K loop: see batch_gemm_rega_kernel (B fragments read AHEAD k-steps early, every step pinned by a sched_barrier)
     auto mfma_tile = [&](const unsigned char* cur) {
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -1300,7 +1295,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_wide_kernel(GemmArgs a, uin
         f32x16 a1;
 #pragma unroll
         for (int i = 0; i < AHEAD && i < KS; ++i) fb[i] = *reinterpret_cast<const u32x4*>(b0 + i * 32);
-        if (prio) { if (prio_hi) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }   // debug bit 15: see batch_gemm_rega_kernel
+        if (prio) __builtin_amdgcn_s_setprio(1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {

@@ -195,6 +195,9 @@ struct Slot {
     int index = 0;
     hipStream_t stream = nullptr;  // one of the engine's streams (not owned)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr;
+    uint64_t* h_done = nullptr;    // pinned: the completion word a fused scan publishes behind its hits ("done_flag")
+    uint64_t done_seq = 0;         // value the slot's current query publishes
+    bool flag_wait = false;        // this ticket completes through h_done (no event was recorded)
     hipEvent_t t_start = nullptr, t_end = nullptr;   // the events that bracket this ticket's scan kernel (not owned)
     float* d_query = nullptr;
     float* h_query = nullptr;  // pinned
@@ -398,6 +401,8 @@ struct wax_hip_engine {
     std::atomic<int64_t> time_kernels{0};
     std::atomic<int64_t> force_general{0};
     std::atomic<int64_t> stream_nt{1};
+    std::atomic<int64_t> done_flag{1};       // single-query scans that merge in the kernel publish a completion word in pinned memory; collect polls it instead of an event (0 = always an event)
+    std::atomic<uint64_t> st_flag_waits{0};
     std::atomic<int64_t> query_args{1};      // single-query scans: 1 (default) = stores whose scan grid is small enough for the fused merge (the launch-latency-bound ones) get the query in the kernel arguments (no upload copy); 2 = every store; 0 = always upload
     std::atomic<int64_t> fuse_merge{1};      // 1 = grids of <= SCAN_FUSE_MERGE_GRID workgroups merge in the scan kernel's last-arriving workgroup
     std::atomic<int64_t> batch_min{1};       // fewer queries than this: always pipelined single-query scans (1..15: cost model below)
@@ -549,7 +554,7 @@ int alloc_slot(wax_hip_engine* e, Slot** out) {
         if (s->ev1) (void)hipEventDestroy(s->ev1);
         if (s->ev_done) (void)hipEventDestroy(s->ev_done);
         (void)hipFree(s->d_query); (void)hipHostFree(s->h_query); (void)hipFree(s->d_partials);
-        (void)hipFree(s->d_hits); (void)hipHostFree(s->h_hits);
+        (void)hipFree(s->d_hits); (void)hipHostFree(s->h_hits); (void)hipHostFree(s->h_done);
         delete s;
         return fail(code, msg);
     };
@@ -569,6 +574,8 @@ int alloc_slot(wax_hip_engine* e, Slot** out) {
     if ((err = hipStreamSynchronize(nullptr)) != hipSuccess) return bail(WAX_HIP_ERR_ALLOC, "top-k stage buffer", err);
     if ((err = hipMalloc(&s->d_hits, (size_t)WAX_HIP_MAX_RESULTS * sizeof(wax_hip_hit))) != hipSuccess) return bail(WAX_HIP_ERR_ALLOC, "top-k results buffer", err);
     if ((err = hipHostMalloc(&s->h_hits, (size_t)WAX_HIP_MAX_RESULTS * sizeof(wax_hip_hit), hipHostMallocDefault)) != hipSuccess) return bail(WAX_HIP_ERR_ALLOC, "pinned results buffer", err);
+    if ((err = hipHostMalloc(&s->h_done, 64, hipHostMallocDefault)) != hipSuccess) return bail(WAX_HIP_ERR_ALLOC, "pinned completion word", err);
+    *s->h_done = 0;
     *out = s;
     return WAX_HIP_OK;
 }
@@ -576,7 +583,7 @@ int alloc_slot(wax_hip_engine* e, Slot** out) {
 void free_slot(Slot* s) {
     if (!s) return;
     (void)hipFree(s->d_query); (void)hipHostFree(s->h_query); (void)hipFree(s->d_partials);
-    (void)hipFree(s->d_hits); (void)hipHostFree(s->h_hits); (void)hipFree(s->d_dist);
+    (void)hipFree(s->d_hits); (void)hipHostFree(s->h_hits); (void)hipHostFree(s->h_done); (void)hipFree(s->d_dist);
     if (s->sw_ready) {
         (void)hipFree(s->sw.hist); (void)hipFree(s->sw.state); (void)hipFree(s->sw.counter);
         (void)hipFree(s->sw.keys_a); (void)hipFree(s->sw.keys_b);
@@ -747,11 +754,14 @@ bool scan_uses_query_args(wax_hip_engine* e, int k_eff, bool has_general_slot) {
 int enqueue_scan(wax_hip_engine* e, const float* d_query, float q_norm, int k_eff, int kpad, int64_t* d_partials,
                  Slot* general_slot, wax_hip_hit* d_hits, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1,
                  bool chain = false, hipEvent_t* used_start = nullptr, hipEvent_t* used_end = nullptr,
-                 const float* h_query = nullptr) {
+                 const float* h_query = nullptr, uint64_t* done_flag = nullptr, uint64_t done_value = 0, bool* out_flagged = nullptr) {
     ScanArgs a{};
     a.store = e->d_store;
     a.query = d_query;
     a.query_host = d_query == nullptr ? h_query : nullptr;
+    a.done_flag = done_flag;
+    a.done_value = done_value;
+    if (out_flagged) *out_flagged = false;
     a.partials = d_partials;
     a.dist_out = nullptr;
     a.n_rows = (uint32_t)e->count;
@@ -807,6 +817,7 @@ int enqueue_scan(wax_hip_engine* e, const float* d_query, float q_norm, int k_ef
             e->scan_done_valid = true;
             chain_guard.unlock();
         }
+        if (out_flagged) *out_flagged = merged && done_flag != nullptr;   // the kernel itself publishes the completion word
         if (!merged)
             HIP_TRY(launch_merge_keys(d_partials, (uint32_t)grid * (uint32_t)k_eff, k_eff, kpad, e->d_ids, a.row_base,
                                       a.n_rows, d_hits, cap, stream),
@@ -1962,11 +1973,24 @@ static int submit_impl(wax_hip_engine* e, const float* query, uint32_t dims, int
         }
         // The last kernel of the chain writes the k hits straight into the slot's pinned host buffer
         // (device-visible, 16*k bytes over PCIe): no D2H copy launch; visibility at ev_done.
+        // "done_flag" (default 1): a scan that merges in the kernel (small grids) publishes a completion word in pinned memory behind
+        // its hits and collect polls that word — no event behind the kernel. Not while kernels are timed (the timing events must have
+        // completed when collect reads them).
+        const bool want_flag = e->done_flag.load() != 0 && !s->timed;
+        s->flag_wait = false;
+        if (want_flag) s->done_seq += 1;
+        bool flagged = false;
         rc = enqueue_scan(e, qargs ? nullptr : s->d_query, qn, k_eff, k_eff, s->d_partials, s, s->h_hits, s->stream,
-                          s->timed ? s->ev0 : nullptr, s->timed ? s->ev1 : nullptr, /*chain=*/chain_scans(e), &s->t_start, &s->t_end, query);
+                          s->timed ? s->ev0 : nullptr, s->timed ? s->ev1 : nullptr, /*chain=*/chain_scans(e), &s->t_start, &s->t_end, query,
+                          want_flag ? s->h_done : nullptr, s->done_seq, &flagged);
         if (rc != WAX_HIP_OK) break;
-        err = hipEventRecord(s->ev_done, s->stream);
-        if (err != hipSuccess) { rc = fail(WAX_HIP_ERR_INTERNAL, std::string("event record: ") + hipGetErrorString(err)); break; }
+        if (flagged) {
+            s->flag_wait = true;
+            e->st_flag_waits++;
+        } else {
+            err = hipEventRecord(s->ev_done, s->stream);
+            if (err != hipSuccess) { rc = fail(WAX_HIP_ERR_INTERNAL, std::string("event record: ") + hipGetErrorString(err)); break; }
+        }
     } while (0);
     if (rc != WAX_HIP_OK) {
         if (s) { (void)hipStreamSynchronize(s->stream); release_slot(e, s); }
@@ -2011,7 +2035,25 @@ static int collect_impl(wax_hip_engine* e, uint64_t ticket, uint64_t* out_ids, f
     if (s->k_eff == 0 && out_hits)
         for (uint32_t i = 0; i < hits_cap; ++i) out_hits[i] = wax_hip_hit{KEY_PAD, ID_PAD};
     if (s->k_eff > 0) {
-        hipError_t err = hipEventSynchronize(s->ev_done);   // commandBuffer completion (:577-582); later queries on the stream keep running
+        hipError_t err = hipSuccess;
+        if (s->flag_wait) {
+            // poll the completion word the kernel's last workgroup publishes behind the hits (system-scope release). The stream is
+            // queried now and then so that a kernel that died without publishing fails loudly instead of spinning for ever.
+            const uint64_t want = s->done_seq;
+            for (uint32_t spins = 1;; ++spins) {
+                if (__atomic_load_n(s->h_done, __ATOMIC_ACQUIRE) == want) break;
+                __builtin_ia32_pause();
+                if ((spins & 0x3fffu) == 0u) {
+                    const hipError_t qs = hipStreamQuery(s->stream);
+                    if (qs == hipErrorNotReady) continue;
+                    if (__atomic_load_n(s->h_done, __ATOMIC_ACQUIRE) == want) break;
+                    err = qs == hipSuccess ? hipErrorUnknown : qs;   // the stream drained (or failed) and the word never came
+                    break;
+                }
+            }
+        } else {
+            err = hipEventSynchronize(s->ev_done);   // commandBuffer completion (:577-582); later queries on the stream keep running
+        }
         if (err != hipSuccess) {
             rc = fail(WAX_HIP_ERR_INTERNAL, std::string("search failed on device: ") + hipGetErrorString(err));
             // a scan that died part-way leaves its fused-merge ticket half counted; no later scan on this slot could ever be
@@ -2770,6 +2812,7 @@ int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value) {
     else if (k == "force_general") e->force_general = value;
     else if (k == "stream_nt") e->stream_nt = value;
     else if (k == "fuse_merge") e->fuse_merge = value != 0;
+    else if (k == "done_flag") e->done_flag = value != 0;
     else if (k == "query_args") { if (value < 0 || value > 2) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "query_args must be 0, 1 or 2"); e->query_args = value; }
     else if (k == "batch_min") e->batch_min = value;
     else if (k == "batch_mode") e->batch_mode = value;
@@ -2826,6 +2869,8 @@ int64_t wax_hip_get_tuning(wax_hip_engine* e, const char* key) {
     if (k == "stream_nt") return e->stream_nt.load();
     if (k == "fuse_merge") return e->fuse_merge.load();
     if (k == "query_args") return e->query_args.load();
+    if (k == "done_flag") return e->done_flag.load();
+    if (k == "done_flag_waits") return (int64_t)e->st_flag_waits.load();
     if (k == "query_args_scans") return (int64_t)e->st_query_args.load();
     if (k == "batch_inline_retries") return (int64_t)e->st_batch_inline_retries.load();
     if (k == "retry_hint") return e->retry_hint.load();

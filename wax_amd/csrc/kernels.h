@@ -44,6 +44,12 @@ struct ScanArgs {
     // arguments (launch_scan copies them into the launch packet's kernarg block) instead of being read through `query`.
     // Honoured for dims 384 / 768 on the fused path; `query` may then be null.
     const float* query_host;
+    // Fused final merge only: non-null = after the kpad hits are written (merge_out is then pinned host memory) the last-arriving
+    // workgroup stores done_value to *done_flag (pinned host memory) with system-scope release — the host polls this word instead
+    // of waiting on an event recorded behind the kernel (one packet and one API call less per query, and the answer is visible
+    // before the kernel has even retired). launch_scan clears it when the launch does not merge in the kernel.
+    uint64_t* done_flag;
+    uint64_t done_value;
 };
 // kernarg block of scan_kernel_qarg: the scan arguments followed by the query itself (16-byte aligned for float4 loads)
 template <int DIMS>

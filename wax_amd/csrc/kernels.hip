@@ -127,6 +127,11 @@ __device__ inline void scan_epilogue(const ScanArgs& a, int64_t* lds, int* count
         a.merge_out[t] = h;
     }
     if (threadIdx.x == 0) __hip_atomic_store(a.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.done_flag != nullptr) {
+        __threadfence_system();                              // this thread's hits have reached host memory
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(a.done_flag, a.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -430,7 +435,7 @@ hipError_t launch_scan(const ScanArgs& args, int metric, int variant, int cap, b
     if (out_grid) *out_grid = grid;
     ScanArgs a = args;
     const bool fuse = !write_dist && a.merge_out != nullptr && a.arrive != nullptr && grid <= SCAN_FUSE_MERGE_GRID && a.kpad >= a.k;
-    if (!fuse) { a.merge_out = nullptr; a.arrive = nullptr; }
+    if (!fuse) { a.merge_out = nullptr; a.arrive = nullptr; a.done_flag = nullptr; }
     if (out_merged) *out_merged = fuse;
     // query in the kernel arguments: the BASELINE dimensions, default variant, fused path (the caller decides when — launch_scan
     // only refuses what it has no kernel for, by falling through to the pointer form, which needs args.query)
