@@ -433,7 +433,7 @@ def eng_fused_grid(grid):
     return grid <= 160   # SCAN_FUSE_MERGE_GRID: the scan kernel's last-arriving workgroup does the final merge
 
 
-def batched_roofline(rows, dims, nq, kern_ms, launches):
+def batched_roofline(rows, dims, nq, kern_ms, launches, rega=5):
     flops = 2.0 * nq * rows * dims
     nbytes = rows * dims * 2                  # bf16 mirror, streamed once per launch
     t_hbm, t_mfma = nbytes / (HBM_PEAK_GBPS * 1e9), flops / (MFMA_BF16_PEAK_TFLOPS * 1e12)
@@ -451,8 +451,9 @@ def batched_roofline(rows, dims, nq, kern_ms, launches):
             traffic_source = "replayed from profiles/latest_traffic.json (" + tj.get("source", "") + "), not measured in this run"
     except (OSError, ValueError, KeyError):
         pass
-    kernel = ("wax::batch_gemm_ksplit_kernel" if dims == 768 else "wax::batch_gemm_rega_kernel" if dims in (128, 256, 384, 512)
-              else "wax::batch_gemm_kernel")
+    # D = 768: the wide kernel (whole K per wave, LDS-DMA staging) unless "batch_rega" selects the K-split one (1 / 6 / 7)
+    kernel = (("wax::batch_gemm_ksplit_kernel" if rega in (1, 6, 7) else "wax::batch_gemm_wide_kernel") if dims == 768
+              else "wax::batch_gemm_rega_kernel" if dims in (128, 256, 384, 512) else "wax::batch_gemm_kernel")
     # what the kernel's K loop alone (no HBM stream, no selection) sustains on this part with embedding-like operands: the matrix
     # clock is power-limited (tools/mfma_probe.hip; DESIGN.md "The matrix roof"). Informational: `peak` stays the nominal figure.
     sustained = None
@@ -537,6 +538,7 @@ def secondary_batched(torch, dev, rows, dims, nq, k, steps, warmup, label, row_b
     _bracket(torch)
     blocking_ms = (time.perf_counter() - tb) / nblk * 1e3
     fb0, rt0, mp0 = eng.getTuning("batch_fallbacks"), eng.getTuning("batch_retries"), eng.getTuning("batch_multi_passes")
+    ir0 = eng.getTuning("batch_inline_retries")
     eng.setTuning("time_kernels", 1)
     apply_tunes(eng)
     eng.setTuning("reset_stats", 1)
@@ -548,7 +550,7 @@ def secondary_batched(torch, dev, rows, dims, nq, k, steps, warmup, label, row_b
     st = eng.stats()
     launches = int(st.batch_gemms_timed)
     kern_ms = st.batch_gemm_ms_total / launches if launches else float("nan")
-    flops, floor_s, rf = batched_roofline(rows, dims, nq, kern_ms, launches)
+    flops, floor_s, rf = batched_roofline(rows, dims, nq, kern_ms, launches, int(eng.getTuning("batch_rega")))
     res = {
         "config": label,
         "value": nq * steps / el, "unit": "queries/s", "steps": steps, "warmup": warmup, "ms_per_step": el / steps * 1e3,
@@ -559,6 +561,7 @@ def secondary_batched(torch, dev, rows, dims, nq, k, steps, warmup, label, row_b
         "certificate_fallbacks": int(eng.getTuning("batch_fallbacks") - fb0),
         "certificate_fallbacks_per_step": (eng.getTuning("batch_fallbacks") - fb0) / (steps + 0.0),
         "full_retries": int(eng.getTuning("batch_retries") - rt0),
+        "full_retries_on_device": int(eng.getTuning("batch_inline_retries") - ir0),
         "shared_exact_passes": int(eng.getTuning("batch_multi_passes") - mp0),
         "pipeline": "one-pass" if eng.getTuning("onepass_queries") > 0 else "slab",
         "last_result_checksum": _hits_checksum(outs[(steps - 1) % depth]),
@@ -663,7 +666,7 @@ def config5_sharded(torch, dist, args, rank, world, in_library, use_rccl, k=10, 
     st = eng.stats()
     launches = int(st.batch_gemms_timed)
     kern_ms = st.batch_gemm_ms_total / launches if launches else float("nan")
-    flops, floor_s, rf = batched_roofline(rows_per_gpu, dims, nq, kern_ms, launches)
+    flops, floor_s, rf = batched_roofline(rows_per_gpu, dims, nq, kern_ms, launches, int(eng.getTuning("batch_rega")))
     n_gpus = args.gpus if in_library else world
     res = {
         "config": f"{rows} x {dims} row-sharded over {n_gpus} GPU(s) ({rows_per_gpu} rows each), {nq} queries per step, cosine top-{k}, "
