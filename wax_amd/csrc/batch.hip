@@ -1193,7 +1193,11 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_ksplit_kernel(GemmArgs a, u
 // K loop, BEFORE requesting the tile that will overwrite the buffer the previous K loop read): an early wave's selection sits
 // between the two instead of in front of a workgroup barrier. The counter is touched through inline assembly only: an LDS
 // access the compiler can see makes it drain the LDS-DMA queue first (s_waitcnt vmcnt(0)).
-template <int D, int NBUF, int AHEAD, bool SAMPLE = false, int CHAINS = 1, bool SPLIT = false>
+// SPREAD = true: the next tile's DMA pieces are issued from INSIDE the K loop — piece i in front of k-step 2 + 6 i — instead of in one
+// burst at the top of the iteration: a piece costs a wave ~15 VALU of address arithmetic plus an LDS-DMA issue (60 - 185 cycles inside
+// a phase that already carries DMA pieces, MI355X_MICROARCH.md), and at the top of an iteration BOTH waves of a SIMD are outside their
+// MFMA streams (the early one issues its burst, the late one selects), so the burst was matrix-pipe idle time.
+template <int D, int NBUF, int AHEAD, bool SAMPLE = false, int CHAINS = 1, bool SPLIT = false, bool SPREAD = false>
 __global__ __launch_bounds__(512, 2) void batch_gemm_wide_kernel(GemmArgs a, uint32_t blocks_per_group) {
     constexpr int KS = D / 16;                       // MFMA k-steps
     constexpr int ROW_B = D * 2 + 16;                // LDS row stride (bytes); (ROW_B / 4) % 64 == 4
@@ -1251,28 +1255,30 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_wide_kernel(GemmArgs a, uin
     // LDS-DMA map, recomputed per piece (a handful of VALU against 48 MFMAs; tables would cost 2 * PPW VGPRs):
     // wave w moves pieces w, w + 8, ...; lane l of piece P fills slot P*64 + l of the padded image
     const bool full_wave = (uint32_t)wave < (uint32_t)(PIECES % 8);          // wave-uniform: carries PPW pieces, the others PPW - 1
+    // piece i of this wave for the tile whose first row is row0, into the buffer at buf_off. The lane index is made opaque per
+    // piece: left to itself hipcc hoists the loop-invariant slot -> (row, column) arithmetic of all PPW pieces out of the tile loop —
+    // 3 VGPRs per piece the A fragments have no room for (they were spilled to scratch, and every reload drained the DMA queue
+    // with an s_waitcnt vmcnt(0))
+    auto dma_piece = [&](int i, uint32_t row0, uint32_t buf_off) {
+        if (i < PPW - 1 || full_wave) {
+            uint32_t lane_o = (uint32_t)lane;
+            asm volatile("" : "+v"(lane_o));
+            const uint32_t P = (uint32_t)wave + 8u * (uint32_t)i;
+            const uint32_t slot = P * 64u + lane_o;
+            uint32_t r = slot / (uint32_t)SLOTS_PER_ROW;
+            uint32_t c = slot - r * (uint32_t)SLOTS_PER_ROW;
+            c = c < (uint32_t)SEG_PER_ROW ? c : (uint32_t)SEG_PER_ROW - 1u;   // pad slot: any valid bytes
+            r = r < (uint32_t)TROWS ? r : (uint32_t)TROWS - 1u;               // slack behind the image: any valid bytes
+            uint32_t grow = row0 + r;
+            grow = grow < a.n_rows ? grow : a.n_rows - 1;                     // clamp: masked in the selection
+            const unsigned char* src = cbase + (size_t)grow * (D * 2) + c * 16u;
+            __builtin_amdgcn_global_load_lds((global_cvoid*)src, (lds_void*)(smem + buf_off + P * 1024u), 16, 0, 0);
+        }
+    };
     auto dma_tile = [&](uint32_t tile, uint32_t buf_off) {
         const uint32_t row0 = a.slab0 + phys(tile) * TROWS;
-        // opaque per call: left to itself hipcc hoists the loop-invariant slot -> (row, column) arithmetic of all PPW pieces
-        // out of the tile loop — 3 VGPRs per piece the A fragments have no room for (they were spilled to scratch, and every
-        // reload drained the DMA queue with an s_waitcnt vmcnt(0))
-        uint32_t lane_o = (uint32_t)lane;
-        asm volatile("" : "+v"(lane_o));
 #pragma unroll
-        for (int i = 0; i < PPW; ++i) {
-            if (i < PPW - 1 || full_wave) {
-                const uint32_t P = (uint32_t)wave + 8u * i;
-                const uint32_t slot = P * 64u + lane_o;
-                uint32_t r = slot / (uint32_t)SLOTS_PER_ROW;
-                uint32_t c = slot - r * (uint32_t)SLOTS_PER_ROW;
-                c = c < (uint32_t)SEG_PER_ROW ? c : (uint32_t)SEG_PER_ROW - 1u;   // pad slot: any valid bytes
-                r = r < (uint32_t)TROWS ? r : (uint32_t)TROWS - 1u;               // slack behind the image: any valid bytes
-                uint32_t grow = row0 + r;
-                grow = grow < a.n_rows ? grow : a.n_rows - 1;                     // clamp: masked in the selection
-                const unsigned char* src = cbase + (size_t)grow * (D * 2) + c * 16u;
-                __builtin_amdgcn_global_load_lds((global_cvoid*)src, (lds_void*)(smem + buf_off + P * 1024u), 16, 0, 0);
-            }
-        }
+        for (int i = 0; i < PPW; ++i) dma_piece(i, row0, buf_off);
     };
     // this wave's DMA requests still allowed in flight: one whole tile, or none
     auto dma_wait = [&](bool keep_one_tile) {
@@ -1287,7 +1293,10 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_wide_kernel(GemmArgs a, uin
 
     const bool prio = (a.debug & 32u) == 0;
     // K loop: see batch_gemm_rega_kernel (B fragments read AHEAD k-steps early, every step pinned by a sched_barrier)
-    auto mfma_tile = [&](const unsigned char* cur) {
+    // dma_on: (SPREAD) issue the pieces of the tile whose first row is dma_row0 into the buffer at dma_off from inside the loop
+    constexpr int DMA_STEP = (KS - 4) / PPW;         // k-steps between two pieces
+    static_assert(!SPREAD || (DMA_STEP >= 1 && 2 + DMA_STEP * (PPW - 1) < KS), "DMA schedule must fit the K loop");
+    auto mfma_tile = [&](const unsigned char* cur, bool dma_on = false, uint32_t dma_row0 = 0u, uint32_t dma_off = 0u) {
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const unsigned char* b0 = cur + (lane & 31) * ROW_B + (lane >> 5) * 16;
         constexpr int RING = AHEAD + 1;
@@ -1299,6 +1308,9 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_wide_kernel(GemmArgs a, uin
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
+            if (SPREAD && ks >= 2 && (ks - 2) % DMA_STEP == 0 && (ks - 2) / DMA_STEP < PPW) {
+                if (dma_on) dma_piece((ks - 2) / DMA_STEP, dma_row0, dma_off);
+            }
             if (ks + AHEAD < KS) fb[(ks + AHEAD) % RING] = *reinterpret_cast<const u32x4*>(b0 + (ks + AHEAD) * 32);
             if (CHAINS == 2 && (ks & 1))
                 a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], __builtin_bit_cast(bf16x8, fb[ks % RING]), ks == 1 ? zero16 : a1, 0, 0, 0);
@@ -1420,17 +1432,18 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_wide_kernel(GemmArgs a, uin
             t += blocks_per_group;
             continue;
         }
-        if (tn < ntiles) { dma_tile(tn, pre_idx * BUF_B); issued = true; }
+        const uint32_t dma_row0 = a.slab0 + phys(tn < ntiles ? tn : 0u) * TROWS;
+        if (tn < ntiles) { if (!SPREAD) dma_tile(tn, pre_idx * BUF_B); issued = true; }
         // tile t + 1 must have landed before the barrier (every wave waits for its own pieces, the barrier joins them); with
         // three tiles in LDS the one requested in this iteration stays in flight across it. The wait sits in FRONT of an early
         // wave's selection: vmcnt counts the selection's survivor stores too, and a store issued just before the wait put a
         // global-memory round trip on the barrier's critical path in ~9 of 10 tiles (some wave of the eight has a survivor).
         if (late) {
             if (it > 0) select_tile(t_prev);
-            mfma_tile(cur);
+            mfma_tile(cur, SPREAD && issued, dma_row0, pre_idx * BUF_B);
             dma_wait(PRE == 2 && issued);
         } else {
-            mfma_tile(cur);
+            mfma_tile(cur, SPREAD && issued, dma_row0, pre_idx * BUF_B);
             dma_wait(PRE == 2 && issued);
             select_tile(t);
         }
@@ -1838,18 +1851,19 @@ static hipError_t launch_ksplit(const GemmArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
-template <int D, int NBUF, int AHEAD, int CHAINS = 1, bool SPLIT = false>
+template <int D, int NBUF, int AHEAD, int CHAINS = 1, bool SPLIT = false, bool SPREAD = false>
 static hipError_t launch_wide(const GemmArgs& a, hipStream_t st) {
+    static_assert(!(SPLIT && SPREAD), "the split-barrier build issues its DMA at the top of the iteration");
     constexpr size_t smem = (size_t)NBUF * (((32 * (D * 2 + 16)) + 1023) / 1024 * 1024) + 3 * 8 * 32 * 4 + 64;   // tile buffers, thresholds / counters / bounds
     static_assert(smem <= 160 * 1024, "LDS budget of one CU");
     static std::atomic<uint64_t> configured{0};   // per device (ensure_dynamic_lds)
     {
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&batch_gemm_wide_kernel<D, NBUF, AHEAD, false, CHAINS, SPLIT>), smem, configured);
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&batch_gemm_wide_kernel<D, NBUF, AHEAD, false, CHAINS, SPLIT, SPREAD>), smem, configured);
         if (e != hipSuccess) return e;
     }
     uint32_t groups, per_group;
     rega_geometry(a, &groups, &per_group);
-    hipLaunchKernelGGL((batch_gemm_wide_kernel<D, NBUF, AHEAD, false, CHAINS, SPLIT>), dim3(groups * per_group), dim3(512), smem, st, a, per_group);
+    hipLaunchKernelGGL((batch_gemm_wide_kernel<D, NBUF, AHEAD, false, CHAINS, SPLIT, SPREAD>), dim3(groups * per_group), dim3(512), smem, st, a, per_group);
     return hipGetLastError();
 }
 
@@ -1932,8 +1946,8 @@ hipError_t launch_batch_gemm(const GemmArgs& a, int metric, hipStream_t st) {
                     switch ((a.debug >> 8) & 3u) {   // timing experiments: LDS tile buffers / accumulator chains / read-ahead
                         case 1: return launch_wide<768, 2, 3>(a, st);             // two LDS tile buffers
                         case 2: return launch_wide<768, 3, 3, 1, true>(a, st);    // split tile barrier
-                        case 3: return launch_wide<768, 3, 2>(a, st);             // read-ahead 2
-                        default: return launch_wide<768, 3, 3>(a, st);            // three buffers, read-ahead 3 (-4 % against 2, profiles/r04)
+                        case 3: return launch_wide<768, 3, 2, 1, false, true>(a, st);   // DMA pieces issued from inside the K loop (read-ahead 2: the piece arithmetic needs the registers)
+                        default: return launch_wide<768, 3, 3>(a, st);            // three buffers, read-ahead 3, workgroup barrier
                     }
                 }
                 switch ((a.debug >> 8) & 3u) {   // timing experiments: B-fragment read-ahead depth
@@ -2728,12 +2742,16 @@ __global__ __launch_bounds__(SCAN_THREADS) __attribute__((amdgpu_waves_per_eu(8,
 // a clustered corpus). The engine launches this kernel only while recent batches had uncertified queries ("retry hint"), so a
 // well-separated corpus never pays for the extra launch; the host-driven rung stays behind it for whatever is left.
 constexpr int RETRY_WAVES = 16;
+constexpr int RETRY_LIST = 8192;                            // survivors (rows) listed in LDS per pass
 template <int D4, int GROUP, int METRIC>
 __global__ __launch_bounds__(RETRY_WAVES * 64) void batch_retry_kernel(FinishArgs a) {
     constexpr int CAP = 256;
     constexpr int LOADS = D4 / GROUP;
     constexpr int RPW = WAVE / GROUP;
+    constexpr int NT = RETRY_WAVES * 64;
     __shared__ int64_t lds[RETRY_WAVES * CAP + RETRY_WAVES + FUSED_MAX_K];
+    __shared__ uint32_t rows_l[RETRY_LIST];                 // global rows of the survivors of the current pass
+    __shared__ uint32_t n_list, seg_next;
     int* counts = reinterpret_cast<int*>(lds + RETRY_WAVES * CAP);
     int64_t* best = lds + RETRY_WAVES * CAP + RETRY_WAVES;
     const uint32_t q = blockIdx.x;
@@ -2752,20 +2770,69 @@ __global__ __launch_bounds__(RETRY_WAVES * 64) void batch_retry_kernel(FinishArg
     const int64_t* __restrict__ mine = a.cand + (size_t)q * a.cand_cap;
     const uint32_t nseg = a.count_stride != 0u ? 1u : a.nseg;
     constexpr int U = LOADS >= 4 ? 2 : 4;                   // row fetches in flight per lane group
-    uint32_t live = 0;                                      // survivors this wave re-scored
-    for (uint32_t seg = (uint32_t)wave; seg < nseg; seg += RETRY_WAVES) {
-        uint32_t c = a.count_stride != 0u ? a.seg_count[(size_t)q * a.count_stride] : a.seg_count[(size_t)seg * a.nq_pad + q];
-        c = c < a.seg_slots ? c : a.seg_slots;              // (no segment overflowed: cert_dev would be 2)
-        const int64_t* __restrict__ sp = mine + (size_t)seg * a.seg_slots;
-        live += c;
-        for (uint32_t c0 = 0; c0 < c; c0 += RPW * U) {      // wave-uniform trip count
-            int64_t ck[U];
+    // Passes: (1) the threads list the rows of as many whole segments as fit RETRY_LIST — one thread per segment, so the
+    // dependent chain "count -> keys" runs for all segments at once instead of segment after segment; (2) the sixteen waves
+    // re-score the listed rows, U * RPW rows per wave and step with all their loads in flight. A query's survivors almost
+    // always fit one pass (the planner aims at a few hundred to a few thousand).
+    if (threadIdx.x == 0) seg_next = 0u;
+    __syncthreads();
+    for (;;) {
+        const uint32_t seg0 = seg_next;                     // first segment of this pass (workgroup-uniform)
+        if (seg0 >= nseg) break;
+        __syncthreads();
+        if (threadIdx.x == 0) n_list = 0u;
+        __syncthreads();
+        // segments seg0 .. seg0 + NT - 1, one per thread; a segment is taken only if it fits (order does not matter: keys carry rows)
+        const uint32_t seg = seg0 + threadIdx.x;
+        uint32_t c = 0u;
+        if (seg < nseg) {
+            c = a.count_stride != 0u ? a.seg_count[(size_t)q * a.count_stride] : a.seg_count[(size_t)seg * a.nq_pad + q];
+            c = c < a.seg_slots ? c : a.seg_slots;          // (no segment overflowed: cert_dev would be 2)
+        }
+        // inclusive prefix over the workgroup's segments (wave scan + wave totals through LDS)
+        uint32_t inc = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += o;
+        }
+        if (lane == 63) counts[wave] = (int)inc;
+        __syncthreads();
+        uint32_t base = 0u;
+        for (int w = 0; w < wave; ++w) base += (uint32_t)counts[w];
+        const uint32_t end = base + inc;                    // rows listed up to and including this thread's segment
+        const bool fits = seg < nseg && end <= (uint32_t)RETRY_LIST;
+        if (fits && c > 0u) {
+            const int64_t* __restrict__ sp = mine + (size_t)seg * a.seg_slots;
+            for (uint32_t j = 0; j < c; ++j) rows_l[end - c + j] = key_row(sp[j]);
+        }
+        // the pass takes the longest prefix of segments that fits; a single segment larger than the list cannot be retried here
+        const unsigned long long fm = __ballot(fits || seg >= nseg);
+        const int wave_fit = fm == ~0ull ? 64 : __builtin_ctzll(~fm);   // leading threads of this wave that fit
+        __syncthreads();                                    // counts[] read by everyone above
+        if (lane == 0) counts[wave] = wave_fit;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t taken = 0u;
+            for (int w = 0; w < RETRY_WAVES; ++w) { taken += (uint32_t)counts[w]; if (counts[w] < 64) break; }
+            seg_next = seg0 + taken;
+        }
+        if (fits) atomicMax(&n_list, end);
+        __syncthreads();
+        const uint32_t taken_to = seg_next;
+        if (taken_to == seg0) {                             // nothing fits (one huge segment): leave the query to the host rungs
+            if (threadIdx.x == 0) a.certified[q] = 0u;
+            return;
+        }
+        const uint32_t n = n_list;                          // rows of segments [seg0, taken_to): the largest prefix end that fits
+        for (uint32_t c0 = (uint32_t)wave * RPW * U; c0 < n; c0 += RETRY_WAVES * RPW * U) {   // wave-uniform trip count
+            uint32_t grow[U];
             f32x4 v[U][LOADS];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const uint32_t ci = c0 + (uint32_t)(u * RPW + sub);
-                ck[u] = sp[ci < c ? ci : c - 1];
-                uint32_t lrow = key_row(ck[u]) - a.row_base;
+                grow[u] = rows_l[ci < n ? ci : n - 1];
+                uint32_t lrow = grow[u] - a.row_base;
                 lrow = lrow < a.n_rows ? lrow : 0;
                 const f32x4* __restrict__ v4 = reinterpret_cast<const f32x4*>(a.store) + (size_t)lrow * D4 + gl;
 #pragma unroll
@@ -2782,11 +2849,12 @@ __global__ __launch_bounds__(RETRY_WAVES * 64) void batch_retry_kernel(FinishArg
                 float mm = 0.f;
                 if (METRIC == BM_COS) mm = group_sum<GROUP>(hsum_b(nrm));
                 const float d = finish_distance_b<METRIC>(s2, mm, qn);
-                tk.push(make_key(d, key_row(ck[u])), ci < c && gl == GROUP - 1);
+                tk.push(make_key(d, grow[u]), ci < n && gl == GROUP - 1);
             }
         }
     }
     tk.finalize();
+    __syncthreads();
     if (lane == 0) counts[wave] = tk.cnt;
     __syncthreads();
     block_rank_merge<RETRY_WAVES>(lds, CAP, counts, k, best);
@@ -2794,7 +2862,7 @@ __global__ __launch_bounds__(RETRY_WAVES * 64) void batch_retry_kernel(FinishArg
     int total = 0;
 #pragma unroll
     for (int w = 0; w < RETRY_WAVES; ++w) total += counts[w];
-    for (uint32_t o = threadIdx.x; o < a.out_stride; o += RETRY_WAVES * 64) {
+    for (uint32_t o = threadIdx.x; o < a.out_stride; o += NT) {
         wax_hip_hit h;
         h.key = ((int)o < k) ? best[o] : KEY_PAD;
         h.frame_id = ID_PAD;
@@ -2808,7 +2876,6 @@ __global__ __launch_bounds__(RETRY_WAVES * 64) void batch_retry_kernel(FinishArg
         const bool okr = total >= k && best[k - 1] != KEY_PAD && a.tau[q] - a.eps[q] > key_distance(best[k - 1]);   // strict: ties with a rejected row stay uncertified
         a.certified[q] = okr ? 2u : 0u;                     // 2 = certified by the device-side retry (the host counts them)
     }
-    (void)live;
 }
 
 template <int D4, int GROUP>
