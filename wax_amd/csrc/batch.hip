@@ -1193,11 +1193,10 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_ksplit_kernel(GemmArgs a, u
 // K loop, BEFORE requesting the tile that will overwrite the buffer the previous K loop read): an early wave's selection sits
 // between the two instead of in front of a workgroup barrier. The counter is touched through inline assembly only: an LDS
 // access the compiler can see makes it drain the LDS-DMA queue first (s_waitcnt vmcnt(0)).
-// SPREAD = true: the next tile's DMA pieces are issued from INSIDE the K loop — piece i in front of k-step 2 + 6 i — instead of in one
-// burst at the top of the iteration: a piece costs a wave ~15 VALU of address arithmetic plus an LDS-DMA issue (60 - 185 cycles inside
-// a phase that already carries DMA pieces, MI355X_MICROARCH.md), and at the top of an iteration BOTH waves of a SIMD are outside their
-// MFMA streams (the early one issues its burst, the late one selects), so the burst was matrix-pipe idle time.
-template <int D, int NBUF, int AHEAD, bool SAMPLE = false, int CHAINS = 1, bool SPLIT = false, bool SPREAD = false>
+// (Issuing the next tile's DMA pieces from inside the K loop instead of in one burst at the top of the iteration was built and
+// measured: 1 915 - 1 933 us against 1 807 - 1 856 us — the piece arithmetic does not fit beside 192 VGPRs of A fragments without
+// spilling, and the burst was not the idle time it looked like; profiles/HISTORY.md.)
+template <int D, int NBUF, int AHEAD, bool SAMPLE = false, int CHAINS = 1, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void batch_gemm_wide_kernel(GemmArgs a, uint32_t blocks_per_group) {
     constexpr int KS = D / 16;                       // MFMA k-steps
     constexpr int ROW_B = D * 2 + 16;                // LDS row stride (bytes); (ROW_B / 4) % 64 == 4
@@ -1293,10 +1292,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_wide_kernel(GemmArgs a, uin
 
     const bool prio = (a.debug & 32u) == 0;
     // K loop: see batch_gemm_rega_kernel (B fragments read AHEAD k-steps early, every step pinned by a sched_barrier)
-    // dma_on: (SPREAD) issue the pieces of the tile whose first row is dma_row0 into the buffer at dma_off from inside the loop
-    constexpr int DMA_STEP = (KS - 4) / PPW;         // k-steps between two pieces
-    static_assert(!SPREAD || (DMA_STEP >= 1 && 2 + DMA_STEP * (PPW - 1) < KS), "DMA schedule must fit the K loop");
-    auto mfma_tile = [&](const unsigned char* cur, bool dma_on = false, uint32_t dma_row0 = 0u, uint32_t dma_off = 0u) {
+    auto mfma_tile = [&](const unsigned char* cur) {
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const unsigned char* b0 = cur + (lane & 31) * ROW_B + (lane >> 5) * 16;
         constexpr int RING = AHEAD + 1;
@@ -1308,9 +1304,6 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_wide_kernel(GemmArgs a, uin
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            if (SPREAD && ks >= 2 && (ks - 2) % DMA_STEP == 0 && (ks - 2) / DMA_STEP < PPW) {
-                if (dma_on) dma_piece((ks - 2) / DMA_STEP, dma_row0, dma_off);
-            }
             if (ks + AHEAD < KS) fb[(ks + AHEAD) % RING] = *reinterpret_cast<const u32x4*>(b0 + (ks + AHEAD) * 32);
             if (CHAINS == 2 && (ks & 1))
                 a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], __builtin_bit_cast(bf16x8, fb[ks % RING]), ks == 1 ? zero16 : a1, 0, 0, 0);
@@ -1432,18 +1425,17 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_wide_kernel(GemmArgs a, uin
             t += blocks_per_group;
             continue;
         }
-        const uint32_t dma_row0 = a.slab0 + phys(tn < ntiles ? tn : 0u) * TROWS;
-        if (tn < ntiles) { if (!SPREAD) dma_tile(tn, pre_idx * BUF_B); issued = true; }
+        if (tn < ntiles) { dma_tile(tn, pre_idx * BUF_B); issued = true; }
         // tile t + 1 must have landed before the barrier (every wave waits for its own pieces, the barrier joins them); with
         // three tiles in LDS the one requested in this iteration stays in flight across it. The wait sits in FRONT of an early
         // wave's selection: vmcnt counts the selection's survivor stores too, and a store issued just before the wait put a
         // global-memory round trip on the barrier's critical path in ~9 of 10 tiles (some wave of the eight has a survivor).
         if (late) {
             if (it > 0) select_tile(t_prev);
-            mfma_tile(cur, SPREAD && issued, dma_row0, pre_idx * BUF_B);
+            mfma_tile(cur);
             dma_wait(PRE == 2 && issued);
         } else {
-            mfma_tile(cur, SPREAD && issued, dma_row0, pre_idx * BUF_B);
+            mfma_tile(cur);
             dma_wait(PRE == 2 && issued);
             select_tile(t);
         }
@@ -1851,19 +1843,18 @@ static hipError_t launch_ksplit(const GemmArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
-template <int D, int NBUF, int AHEAD, int CHAINS = 1, bool SPLIT = false, bool SPREAD = false>
+template <int D, int NBUF, int AHEAD, int CHAINS = 1, bool SPLIT = false>
 static hipError_t launch_wide(const GemmArgs& a, hipStream_t st) {
-    static_assert(!(SPLIT && SPREAD), "the split-barrier build issues its DMA at the top of the iteration");
     constexpr size_t smem = (size_t)NBUF * (((32 * (D * 2 + 16)) + 1023) / 1024 * 1024) + 3 * 8 * 32 * 4 + 64;   // tile buffers, thresholds / counters / bounds
     static_assert(smem <= 160 * 1024, "LDS budget of one CU");
     static std::atomic<uint64_t> configured{0};   // per device (ensure_dynamic_lds)
     {
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&batch_gemm_wide_kernel<D, NBUF, AHEAD, false, CHAINS, SPLIT, SPREAD>), smem, configured);
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&batch_gemm_wide_kernel<D, NBUF, AHEAD, false, CHAINS, SPLIT>), smem, configured);
         if (e != hipSuccess) return e;
     }
     uint32_t groups, per_group;
     rega_geometry(a, &groups, &per_group);
-    hipLaunchKernelGGL((batch_gemm_wide_kernel<D, NBUF, AHEAD, false, CHAINS, SPLIT, SPREAD>), dim3(groups * per_group), dim3(512), smem, st, a, per_group);
+    hipLaunchKernelGGL((batch_gemm_wide_kernel<D, NBUF, AHEAD, false, CHAINS, SPLIT>), dim3(groups * per_group), dim3(512), smem, st, a, per_group);
     return hipGetLastError();
 }
 
@@ -1946,7 +1937,7 @@ hipError_t launch_batch_gemm(const GemmArgs& a, int metric, hipStream_t st) {
                     switch ((a.debug >> 8) & 3u) {   // timing experiments: LDS tile buffers / accumulator chains / read-ahead
                         case 1: return launch_wide<768, 2, 3>(a, st);             // two LDS tile buffers
                         case 2: return launch_wide<768, 3, 3, 1, true>(a, st);    // split tile barrier
-                        case 3: return launch_wide<768, 3, 2, 1, false, true>(a, st);   // DMA pieces issued from inside the K loop (read-ahead 2: the piece arithmetic needs the registers)
+                        case 3: return launch_wide<768, 3, 2>(a, st);             // read-ahead 2
                         default: return launch_wide<768, 3, 3>(a, st);            // three buffers, read-ahead 3, workgroup barrier
                     }
                 }
