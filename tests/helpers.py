@@ -211,3 +211,20 @@ def assert_parity(got_ids, got_scores, exp_ids, exp_scores, all_exp_scores=None,
         else:
             assert grp_got == grp_exp, f"{ctx}: ids differ outside a tie group at rank {i}: {got_ids} vs {exp_ids}"
         i = hi + 1
+
+
+def bf16_adversarial_unit_vector(dims):
+    """A unit vector (f32) whose bf16 rounding moves its self-similarity by ~2^-7: every non-zero element is (1 + 0.99 * 2^-8) * 2^-e,
+    just below a rounding midpoint at the bottom of its binade (so rounding takes 2^-8 of it away), with the exponents chosen
+    greedily so that the squares sum to 1 — the normalisation the engine applies then changes nothing. ~20 non-zeros, rest 0."""
+    import numpy as np
+    a = 2.0 ** -8 * 0.99
+    rem, exps = (1 + a) ** -2, []
+    for e in range(1, 14):
+        c = int(rem // 4.0 ** -e)
+        c = min(c, 3 if e < 6 else 10 ** 9)
+        exps += [e] * c
+        rem -= c * 4.0 ** -e
+    x = np.zeros(dims, dtype=np.float64)
+    x[:len(exps)] = [(1 + a) * 2.0 ** -e for e in exps]
+    return (x / np.sqrt(np.sum(x * x))).astype(np.float32)

@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 import oracle
+import helpers
 from helpers import load_golden
 
 REF = load_golden("reference_cases.json")
@@ -392,3 +393,62 @@ def test_bench_line_stays_inside_the_drivers_stdout_tail(tmp_path, capsys):
     out = capsys.readouterr().out
     j = json.loads(out)
     assert len(out) < 4096 and "secondary_dropped" in j and j["roofline"]["frac"] and j["cpu_baseline"]["cores"] == 16
+
+
+def _bf16_rne(x):
+    """f32 -> bf16 (round to nearest even) -> f32, as f32_to_bf16_rne in common.h does it."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return r.astype(np.uint32).view(np.float32)
+
+
+def test_measured_bf16_certificate_bound_is_a_bound():
+    """The round-4 cosine certificate bound (batch_prep_kernel): |q~.v~ - x_q.x_v| <= ||q~ - x_q|| (1 + 2^-8) + max_rows ||v~ - x_v||
+    (+ accumulation / normalisation slack), with x the f32-normalised vectors and ~ their bf16 roundings. Checked in f64 against
+    the true error on random, clustered and adversarial inputs (rows built so that the rounding errors line up with the query —
+    the case Cauchy-Schwarz is tight for), and well below the worst case 2^-7 (the kernel uses the smaller of the two). Also shown: a
+    vector whose every element sits just below a rounding midpoint at the bottom of its binade moves its own self-similarity by more
+    than the constant rounds 1-3 took for the worst case."""
+    rng = np.random.default_rng(3)
+    dims = 384
+    worst = (2.0 ** -7) * (1 + 2.0 ** -9) + dims * 5.97e-8 + 1e-6   # bf16 keeps 8 significant bits: 2^-8 per operand, 2^-7 per product
+    old_constant = (2.0 ** -8) * (1 + 2.0 ** -10)                  # what rounds 1-3 used as "worst case": half of it
+    exceeded_old = 0
+    ratios = []
+    for kind in ("gaussian", "clustered", "aligned", "binade_edges"):
+        n = 4000
+        if kind == "gaussian":
+            rows = rng.standard_normal((n, dims))
+        elif kind == "clustered":
+            rows = rng.standard_normal((1, dims)) + 0.05 * rng.standard_normal((n, dims))
+        elif kind == "binade_edges":                      # magnitudes just above powers of two: the largest relative bf16 error
+            rows = np.sign(rng.standard_normal((n, dims))) * (2.0 ** rng.integers(-6, 0, (n, dims))) * (1 + 2.0 ** -9 * rng.uniform(0.9, 1.0, (n, dims)))
+        else:
+            rows = rng.standard_normal((n, dims))
+        rows = rows.astype(np.float32)
+        xv = (rows / np.sqrt(np.sum(rows.astype(np.float32) ** 2, axis=1, dtype=np.float32))[:, None]).astype(np.float32)   # f32 normalisation, like mirror_kernel
+        vt = _bf16_rne(xv)
+        err_v = np.sqrt(np.sum((xv.astype(np.float64) - vt.astype(np.float64)) ** 2, axis=1))
+        for _ in range(40):
+            q = rng.standard_normal(dims).astype(np.float32)
+            if kind == "aligned":                          # the query points along a row's rounding-error vector
+                i = rng.integers(0, n)
+                q = (xv[i].astype(np.float64) - vt[i].astype(np.float64) + 1e-9 * rng.standard_normal(dims)).astype(np.float32)
+            xq = (q / np.sqrt(np.sum(q * q, dtype=np.float32))).astype(np.float32)
+            qt = _bf16_rne(xq)
+            err_q = np.sqrt(np.sum((xq.astype(np.float64) - qt.astype(np.float64)) ** 2))
+            true = np.abs(vt.astype(np.float64) @ qt.astype(np.float64) - xv.astype(np.float64) @ xq.astype(np.float64))
+            bound = err_q * (1 + 1 / 256) + err_v.max() * 1.001 + 3 * dims * 5.97e-8 + 3e-6
+            assert true.max() <= min(bound, worst), (kind, true.max(), bound, worst)   # the kernel takes the smaller of the two
+            assert bound < worst, (kind, bound, worst)
+            exceeded_old += true.max() > old_constant
+            ratios.append(bound / worst)
+    assert np.mean(ratios) < 0.6                           # ~0.46 of the worst case on embedding-like data
+    # the adversarial construction really does exceed the old constant: every element just below a rounding midpoint at the bottom
+    # of its binade (so that it loses 2^-8 of itself), magnitudes chosen so that the vector has unit norm without rescaling
+    x = helpers.bf16_adversarial_unit_vector(dims)
+    xt = _bf16_rne(x)
+    err = float(np.abs(xt.astype(np.float64) @ xt.astype(np.float64) - x.astype(np.float64) @ x.astype(np.float64)))
+    en = float(np.sqrt(np.sum((x.astype(np.float64) - xt.astype(np.float64)) ** 2)))
+    assert old_constant < err <= en * (1 + 1 / 256) + en * 1.001 + 3 * dims * 5.97e-8 + 3e-6 and err <= worst
+    print(f"\n[bf16 bound] self-similarity error of an adversarial vector {err:.5f} (old constant {old_constant:.5f}, worst case {worst:.5f}, measured bound {2 * en:.5f})")

@@ -2069,3 +2069,43 @@ def test_completion_word_equals_event_completion(wax):
         c = eng.searchArrays(queries[3], 10)
         assert eng.getTuning("done_flag_waits") == w1 and np.array_equal(c[0], ref[10][3][0])
         eng.close()
+
+
+def test_certificate_bound_survives_aligned_rounding_errors(wax):
+    """bf16 keeps 8 significant bits: rounding moves an element by up to 2^-8 of itself, so a dot product of two rounded unit
+    vectors can be off by 2^-7 when the errors line up — twice the constant rounds 1-3 took for the worst case. The construction:
+    row A = a unit vector whose every element loses 2^-8 to rounding (helpers.bf16_adversarial_unit_vector); the query is A
+    itself, so its approximate similarity to A is 0.9923 instead of 1. Around it sit 300 rows at exact cosine distance
+    0.0030 - 0.0065 whose approximate distances are honest: they fill the k' candidates, A is NOT among them, and with the old
+    bound the certificate `a_max - eps > exact k-th` passed (0.0065 - 0.0039 > 0.0025) and the batch returned a neighbour instead
+    of A. The measured bound (||q~ - q|| + max ||v~ - v|| ~ 0.0077 here) refuses, the ladder answers exactly."""
+    from helpers import bf16_adversarial_unit_vector
+    dims, n = 384, 40_000
+    rng = np.random.default_rng(8)
+    corpus = oracle.gaussian_unit_rows(77, n, dims)
+    a = bf16_adversarial_unit_vector(dims)
+    corpus[1234] = a
+    # neighbours of A at controlled exact distances: normalise(A + t * u), u orthogonal to A, cos = 1 / sqrt(1 + t^2)
+    for j, dist in enumerate(np.linspace(0.0030, 0.0065, 300)):
+        u = rng.standard_normal(dims)
+        u -= (u @ a.astype(np.float64)) * a.astype(np.float64)
+        u /= np.linalg.norm(u)
+        t = np.sqrt(1.0 / (1.0 - dist) ** 2 - 1.0)
+        v = a.astype(np.float64) + t * u
+        corpus[2000 + j] = (v / np.linalg.norm(v)).astype(np.float32)
+    eng = make_engine(wax, 0, dims, corpus, np.arange(n, dtype=np.uint64) + 1)
+    queries = oracle.gaussian_unit_queries(32, dims, seed=9)
+    queries[3] = a
+    queries[17] = a
+    for onepass in (0, 1):
+        eng.setTuning("batch_onepass", onepass)
+        eng.setTuning("batch_onepass_tiles", 1024)
+        for k in (1, 5):
+            ids, scores, counts = eng.searchBatch(queries, k)
+            for i in range(len(queries)):
+                s_ids, s_scores = eng.searchArrays(queries[i], k)
+                assert np.array_equal(ids[i, :counts[i]], s_ids) and np.array_equal(scores[i, :counts[i]], s_scores), (onepass, k, i)
+            assert ids[3, 0] == 1235 and ids[17, 0] == 1235 and abs(scores[3, 0] - 1.0) < 1e-6   # A itself, not a neighbour
+    # the measured quantities: this store's worst row loses ~0.0038 to rounding (a Gaussian unit row ~0.0018)
+    assert 3.5e6 < eng.getTuning("batch_max_row_err_e9") < 4.0e6
+    eng.close()

@@ -68,14 +68,16 @@ __global__ __launch_bounds__(256) void mirror_kernel(const float* __restrict__ s
                                                      uint32_t n_rows_padded, uint32_t dims, int normalize,
                                                      unsigned short* __restrict__ dst, float* __restrict__ norm2,
                                                      unsigned int* __restrict__ max_norm_bits) {
-    __shared__ unsigned int block_max;
+    // max_norm_bits[0] = max ||v||; max_norm_bits[1] = max over the rows of ||x - bf16(x)||, x = the (scaled) f32 row that was
+    // rounded: the row-side term of the cosine certificate bound, MEASURED instead of the worst case 2^-9 ||x|| (batch_prep_kernel)
+    __shared__ unsigned int block_max, block_max_err;
     const int lane = lane_id();
     const uint32_t gwave = blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint32_t nwaves = gridDim.x * 4;
     const bool vec4 = (dims & 3u) == 0;
-    if (threadIdx.x == 0) block_max = 0u;
+    if (threadIdx.x == 0) { block_max = 0u; block_max_err = 0u; }
     __syncthreads();
-    float wave_max = 0.f;  // one global atomic per workgroup: a per-row atomicMax serialises at ~11 ns each
+    float wave_max = 0.f, wave_max_err = 0.f;  // one global atomic per workgroup: a per-row atomicMax serialises at ~11 ns each
     for (uint32_t r = gwave; r < n_rows_padded; r += nwaves) {
         unsigned short* out = dst + (size_t)r * dims;
         if (r >= n_rows) {
@@ -98,26 +100,38 @@ __global__ __launch_bounds__(256) void mirror_kernel(const float* __restrict__ s
         acc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 63));  // the total lives in lane 63
         const float n = sqrtf(acc);
         const float scale = normalize ? ((n > 1e-6f) ? 1.0f / n : 0.0f) : 1.0f;
+        float e2 = 0.f;        // ||x - bf16(x)||^2 of this row (x - bf16(x) is exact in f32: both are floats of one binade or neighbours)
+        auto rnd = [&](float x) -> unsigned short {
+            const unsigned short b = f32_to_bf16_rne(x);
+            const float d = x - __uint_as_float((unsigned int)b << 16);
+            e2 = fmaf(d, d, e2);
+            return b;
+        };
         if (vec4) {
             const f32x4* row4 = reinterpret_cast<const f32x4*>(row);
             u16x4* out4 = reinterpret_cast<u16x4*>(out);
             for (uint32_t c = lane; c < (dims >> 2); c += WAVE) {
                 const f32x4 v = row4[c];
                 u16x4 o;
-                o.x = f32_to_bf16_rne(v.x * scale); o.y = f32_to_bf16_rne(v.y * scale);
-                o.z = f32_to_bf16_rne(v.z * scale); o.w = f32_to_bf16_rne(v.w * scale);
+                o.x = rnd(v.x * scale); o.y = rnd(v.y * scale);
+                o.z = rnd(v.z * scale); o.w = rnd(v.w * scale);
                 out4[c] = o;
             }
         } else {
-            for (uint32_t c = lane; c < dims; c += WAVE) out[c] = f32_to_bf16_rne(row[c] * scale);
+            for (uint32_t c = lane; c < dims; c += WAVE) out[c] = rnd(row[c] * scale);
         }
+        e2 = group_sum<64>(e2);
+        e2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e2), 63));
+        const float err = sqrtf(e2);
         if (lane == 0) norm2[r] = acc;
         if (n == n && n > wave_max) wave_max = n;
+        if (err == err && err > wave_max_err) wave_max_err = err;   // a NaN / inf row never passes a threshold and sorts last exactly
     }
     if (max_norm_bits != nullptr) {
-        if (lane == 0) atomicMax(&block_max, __float_as_uint(wave_max));
+        if (lane == 0) { atomicMax(&block_max, __float_as_uint(wave_max)); atomicMax(&block_max_err, __float_as_uint(wave_max_err)); }
         __syncthreads();
         if (threadIdx.x == 0 && block_max != 0u) atomicMax(max_norm_bits, block_max);
+        if (threadIdx.x == 0 && block_max_err != 0u) atomicMax(max_norm_bits + 1, block_max_err);
     }
 }
 
@@ -2397,7 +2411,16 @@ __global__ __launch_bounds__(256) void batch_prep_kernel(PrepArgs a) {
     acc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 63));
     const float nf = sqrtf(acc);
     const float scale = (a.metric == BM_COS) ? ((nf > 1e-6f) ? 1.0f / nf : 0.0f) : 1.0f;
-    for (uint32_t c = lane; c < D; c += WAVE) out[c] = f32_to_bf16_rne(row[c] * scale);
+    double qe2 = 0.0;                                    // ||x - bf16(x)||^2 of the scaled query block row x (exact differences)
+    for (uint32_t c = lane; c < D; c += WAVE) {
+        const float x = row[c] * scale;
+        const unsigned short b = f32_to_bf16_rne(x);
+        const double d = (double)x - (double)__uint_as_float((unsigned int)b << 16);
+        qe2 += d * d;
+        out[c] = b;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) qe2 += __shfl_xor(qe2, o);
     const double s0 = __shfl(part, 0), s1 = __shfl(part, 1), s2 = __shfl(part, 2), s3 = __shfl(part, 3);
     if (lane == 0) {
         const double total = (s0 + s1) + (s2 + s3);
@@ -2411,20 +2434,35 @@ __global__ __launch_bounds__(256) void batch_prep_kernel(PrepArgs a) {
         a.q_norm[q] = c;
         if (a.q_norm_host) a.q_norm_host[q] = c;
         a.q_n2[q] = acc;
-        // certificate bound: |approx distance - exact distance| from rounding both operands to bf16 (unit roundoff 2^-9 each =>
-        // 2^-8 (1 + 2^-10) per product, Cauchy-Schwarz over the row) plus f32 accumulation (D * 2^-24) and epilogue rounding;
-        // dot scales with ||q|| max||v||, L2 (||q||^2 + ||v||^2 - 2 q.v) carries the factor 2 and the norms' own rounding
-        const double u = 0.00390625 * (1.0 + 1.0 / 1024.0) + (double)D * 5.97e-8 + 1e-6;
-        float eps;
-        if (a.metric == BM_COS) eps = (float)(u * 1.001 + 1e-6);
-        else {
-            const double qv = (double)c * (double)a.max_norm;
-            if (a.metric == BM_DOT) eps = (float)(u * qv * 1.001 + 1e-6 * (1.0 + qv));
-            else {
-                const double ss = (double)c * (double)c + (double)a.max_norm * (double)a.max_norm;
-                eps = (float)(2.0 * u * qv * 1.001 + 4e-6 * (1.0 + ss));
-            }
+        // Certificate bound: |approximate distance - exact distance|. With x_q, x_v the f32 vectors that were rounded (normalised for
+        // cosine) and q~, v~ their bf16 roundings: |q~.v~ - x_q.x_v| <= ||q~ - x_q|| ||v~|| + ||x_q|| ||v~ - x_v|| (Cauchy-Schwarz on the
+        // ERROR vectors). Round 4 uses the MEASURED error norms: ||q~ - x_q|| is this query's (f64 over exact differences, above),
+        // ||v~ - x_v|| is bounded by its maximum over the rows, measured when the mirror was built (a.max_row_err, + 0.1 % for its f32
+        // accumulation); ||v~|| <= max||v|| (1 + 2^-8). On top: the MFMA accumulates D products in f32 and the f32 normalisation of
+        // either side is off by at most D 2^-25 + 2^-23 relative (3 D 2^-24 of the product of the norms covers both), and the exact
+        // distance it is compared with carries ~1e-6 of its own. Typically 0.0035 for unit vectors at D = 384.
+        // The fallback when no measurement is at hand ("batch_eps_measured" = 0) is the worst case: bf16 keeps 8 significant bits,
+        // so rounding moves an element by at most 2^-8 relative and a product of two rounded elements by 2^-7 (1 + 2^-9) — 0.0078.
+        // (Rounds 1-3 used 2^-8 (1 + 2^-10) here, i.e. a unit roundoff of 2^-9 per operand: half of the true worst case. Random
+        // rounding errors are two orders of magnitude below either, which is why no test ever saw it; errors that line up with the
+        // query could have defeated it. The measured bound is rigorous AND about what the old constant was.)
+        const double qn_d = a.metric == BM_COS ? 1.0 + 1e-6 : (double)c;
+        const double vn_d = a.metric == BM_COS ? 1.0 + 1e-6 : (double)a.max_norm;
+        const double u = 0.0078125 * (1.0 + 1.0 / 512.0) + (double)D * 5.97e-8 + 1e-6;          // worst case, relative to ||q|| max||v||
+        double dot_err = u * qn_d * vn_d * 1.001;
+        if (a.max_row_err > 0.f) {
+            const double measured = sqrt(qe2) * vn_d * (1.0 + 1.0 / 256.0) + qn_d * (double)a.max_row_err * 1.001 +
+                                    3.0 * (double)D * 5.97e-8 * qn_d * vn_d;
+            if (measured < dot_err) dot_err = measured;
         }
+        float eps;
+        if (a.metric == BM_COS) eps = (float)(dot_err + 3e-6);
+        else if (a.metric == BM_DOT) eps = (float)(dot_err + 1e-6 * (1.0 + qn_d * vn_d));
+        else {   // L2: ||q||^2 + ||v||^2 - 2 q.v carries the factor 2 and the norms' own rounding
+            const double ss = (double)c * (double)c + (double)a.max_norm * (double)a.max_norm;
+            eps = (float)(2.0 * dot_err + 4e-6 * (1.0 + ss));
+        }
+        eps = nextafterf(eps, __builtin_inff());             // the double -> float conversion may have rounded down
         a.eps[q] = eps;
         a.tau[q] = __builtin_inff();
         a.overflow[q] = 0u;

@@ -260,6 +260,7 @@ struct BatchMirror {
     std::atomic<bool> mirror_valid{false};
     std::atomic<int> mirror_wanted{0};   // small batches since the last mutation that a VALID mirror would have made cheaper
     float max_norm = 0.f;
+    float max_row_err = 0.f;             // max over the rows of ||x - bf16(x)|| (x = the f32 row that was rounded): certificate bound, row side
 };
 
 constexpr uint32_t kBatchMaxQ = 1024;   // queries per GEMM pass
@@ -428,6 +429,7 @@ struct wax_hip_engine {
     std::atomic<int64_t> batch_dynamic{0};        // one-pass pipeline: filtering-GEMM workgroups claim their tiles from a counter
     std::atomic<int64_t> batch_sample_div{32};    // one-pass pipeline: 1 / this of the tiles are sampled (at least 256)
     std::atomic<uint64_t> st_onepass_queries{0};
+    std::atomic<int64_t> batch_eps_measured{1};       // cosine certificate bound from the MEASURED bf16 rounding errors (per query, max over rows) instead of the worst case
     std::atomic<int> retry_hint{0};                   // > 0: batches carry the device-side retry kernel behind their finish kernel
     std::atomic<uint64_t> st_batch_inline_retries{0};  // ... of which inside the finish kernel (no host round trip)
     std::atomic<uint64_t> st_query_args{0};          // single-query scans that took their query through the kernel arguments
@@ -881,7 +883,7 @@ int ensure_mirror(wax_hip_engine* e, hipStream_t st) {
     if (b.mirror_valid.load(std::memory_order_acquire) && b.mirror_cap >= e->capacity) return WAX_HIP_OK;
     std::unique_lock<std::mutex> g(b.mu);
     const uint32_t D = e->dims;
-    if (!b.d_maxnorm) HIP_TRY(hipMalloc(&b.d_maxnorm, sizeof(unsigned int)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch scalars");
+    if (!b.d_maxnorm) HIP_TRY(hipMalloc(&b.d_maxnorm, 2 * sizeof(unsigned int)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch scalars");
     if (b.mirror_cap < e->capacity) {
         // no batch can be reading the old mirror: a stale (smaller) mirror is only possible after a mutation, which
         // took the exclusive lock after every reader had finished
@@ -894,13 +896,14 @@ int ensure_mirror(wax_hip_engine* e, hipStream_t st) {
         b.mirror_cap = e->capacity;
     }
     if (!b.mirror_valid.load(std::memory_order_acquire)) {
-        HIP_TRY(hipMemsetAsync(b.d_maxnorm, 0, sizeof(unsigned int), st), WAX_HIP_ERR_INTERNAL, "batch memset");
+        HIP_TRY(hipMemsetAsync(b.d_maxnorm, 0, 2 * sizeof(unsigned int), st), WAX_HIP_ERR_INTERNAL, "batch memset");
         HIP_TRY(launch_mirror(e->d_store, (uint32_t)e->count, (uint32_t)e->count, D, e->metric == WAX_HIP_METRIC_COSINE ? 1 : 0,
                               b.d_cb, b.d_vn2, b.d_maxnorm, st), WAX_HIP_ERR_INTERNAL, "mirror kernel launch");
-        unsigned int bits = 0;
-        HIP_TRY(hipMemcpyAsync(&bits, b.d_maxnorm, sizeof(bits), hipMemcpyDeviceToHost, st), WAX_HIP_ERR_INTERNAL, "max norm download");
+        unsigned int bits[2] = {0u, 0u};
+        HIP_TRY(hipMemcpyAsync(bits, b.d_maxnorm, sizeof(bits), hipMemcpyDeviceToHost, st), WAX_HIP_ERR_INTERNAL, "max norm download");
         HIP_TRY(hipStreamSynchronize(st), WAX_HIP_ERR_INTERNAL, "mirror sync");
-        std::memcpy(&b.max_norm, &bits, sizeof(float));
+        std::memcpy(&b.max_norm, &bits[0], sizeof(float));
+        std::memcpy(&b.max_row_err, &bits[1], sizeof(float));
         b.mirror_valid.store(true, std::memory_order_release);
     }
     return WAX_HIP_OK;
@@ -1244,6 +1247,7 @@ int batch_enqueue(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32
     const uint32_t nq_pad = (qn + 255u) & ~255u;  // 256: the register-resident-queries GEMM works on groups of 256
     PrepArgs pa{};
     pa.queries = d_queries; pa.nq = qn; pa.nq_pad = nq_pad; pa.dims = D; pa.metric = e->metric; pa.max_norm = b.max_norm;
+    pa.max_row_err = e->batch_eps_measured.load() != 0 ? b.max_row_err : 0.f;
     pa.qb = c->d_qb; pa.q_n2 = c->d_qn2; pa.q_norm = c->d_qnorm; pa.eps = c->d_eps; pa.tau = c->d_tau; pa.overflow = c->d_overflow;
     const bool counted = plan != nullptr && !batch_onepass_fast(D, e->metric);   // one-pass on the LDS-tiled kernel: one counted list per query
     pa.cand_count = (plan && !counted) ? nullptr : c->d_cand_count;
@@ -2822,6 +2826,7 @@ int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value) {
     else if (k == "batch_onepass_tiles") { if (value < 1024) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_onepass_tiles must be >= 1024"); e->batch_onepass_tiles = value; }
     else if (k == "batch_survivors") { if (value < 2 || value > 64) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_survivors must be 2..64"); e->batch_survivors = value; }
     else if (k == "batch_dynamic") e->batch_dynamic = value != 0;
+    else if (k == "batch_eps_measured") e->batch_eps_measured = value != 0;
     else if (k == "retry_hint") e->retry_hint = (int)value;   // > 0: the next batches carry the device-side retry kernel (set by collect; tests force it)
     else if (k == "batch_retry") { if (value < 0 || value > 2) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_retry must be 0, 1 or 2"); e->batch_retry = value; }
     else if (k == "batch_multi") e->batch_multi = value != 0;
@@ -2874,6 +2879,8 @@ int64_t wax_hip_get_tuning(wax_hip_engine* e, const char* key) {
     if (k == "query_args_scans") return (int64_t)e->st_query_args.load();
     if (k == "batch_inline_retries") return (int64_t)e->st_batch_inline_retries.load();
     if (k == "retry_hint") return e->retry_hint.load();
+    if (k == "batch_eps_measured") return e->batch_eps_measured.load();
+    if (k == "batch_max_row_err_e9") return (int64_t)((double)e->batch.max_row_err * 1e9);
     if (k == "batch_min") return e->batch_min.load();
     if (k == "batch_mode") return e->batch_mode.load();
     if (k == "batch_rega") return e->batch_rega.load();

@@ -246,6 +246,7 @@ bool batch_finish_fused_dims(uint32_t dims);
 // state (tau = +inf / -inf for padding, overflow = 0).
 struct PrepArgs {
     const float* queries; uint32_t nq, nq_pad, dims; int metric; float max_norm;
+    float max_row_err;          // max over the mirror's rows of ||x - bf16(x)|| (mirror_kernel; x normalised for cosine); 0 = unknown (worst-case bound)
     unsigned short* qb; float* q_n2; float* q_norm; float* eps; float* tau; uint32_t* overflow;
     uint32_t* cand_count;       // slab pipeline: per-query append counters to zero (stride CAND_COUNT_STRIDE); may be null
     uint32_t* tile_ctr;         // one-pass pipeline: [BATCH_TILE_CTRS] tile counters of the filtering GEMM to zero; may be null
