@@ -1418,8 +1418,33 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_wide_kernel(GemmArgs a, uin
         asm volatile("" ::: "memory");
     }
     const bool late = wave >= 4 && !(a.debug & 16u);          // see batch_gemm_rega_kernel: the two waves of a SIMD work in opposite order
+    // Pace gate (advisory). With G > 1 query groups every corpus tile is wanted G times, by the G workgroups that share a `bidx` —
+    // they sit on the same XCD (block -> XCD is blockIdx % 8 and G * blocks_per_group = 256), so the second to G-th reader hit in its
+    // L2 as long as the groups stay within a few tiles of each other. Over a launch of milliseconds they do not (different survivor
+    // loads): config 5 whole fetched 1.13 - 1.64 x the mirror (FETCH_SIZE, profiles/r04). Every GATE_EVERY tiles wave 0 adds its
+    // progress to a word shared by the G workgroups of its bidx and, if it is more than GATE_WINDOW tiles ahead of their average,
+    // sleeps until they catch up — the other seven waves wait for it at the tile barrier. Bounded and advisory: a timeout (a group
+    // that started late behind another kernel) just proceeds; a workgroup that leaves the loop credits the word so that nobody
+    // waits for it.
+    constexpr uint32_t GATE_EVERY = 8u, GATE_WINDOW = 6u;
+    const uint32_t ngroups = gridDim.x / blocks_per_group;
+    const bool gate = !SAMPLE && a.progress != nullptr && ngroups > 1u && (blocks_per_group & 7u) == 0u && ngroups * blocks_per_group <= 256u && !(a.debug & 4096u);
+    const uint32_t* gate_word = gate ? a.progress + (bidx & 7u) * 32u + (bidx >> 3) : a.progress;   // one word per bidx, one 128-byte line per XCD
     uint32_t it = 0, cur_idx = 0, t_prev = 0;
     for (; t < ntiles; ++it) {
+        if (gate && wave == 0 && (it & (GATE_EVERY - 1u)) == 0u && it > 0u) {
+            // (returning atomics: the value comes from wherever agent-scope atomics execute, never from a stale cache line)
+            unsigned int add = GATE_EVERY;
+            for (uint32_t spins = 0; spins < 1024u; ++spins) {
+                unsigned int total = 0u;
+                if (lane == 0) total = __hip_atomic_fetch_add(const_cast<uint32_t*>(gate_word), add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add;
+                total = (unsigned int)__builtin_amdgcn_readfirstlane((int)total);
+                add = 0u;
+                // ahead of the average by more than the window?  G * it - total > G * WINDOW   (total counts tiles of all G groups)
+                if ((int)(ngroups * it - total) <= (int)(ngroups * GATE_WINDOW)) break;
+                __builtin_amdgcn_s_sleep(32);
+            }
+        }
         const unsigned char* cur = smem + cur_idx * BUF_B;
         const uint32_t tn = t + PRE * blocks_per_group;
         uint32_t pre_idx = cur_idx + PRE;
@@ -1460,6 +1485,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_wide_kernel(GemmArgs a, uin
         t += blocks_per_group;
     }
     if (late && it > 0) select_tile(t_prev);
+    if (gate && tid == 0) __hip_atomic_fetch_add(const_cast<uint32_t*>(gate_word), 1u << 24, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // done: nobody waits for this group
     if (SPLIT && gave_up && lane == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(sync_addr + 4u), "v"(1u) : "memory");
     if (!SAMPLE) {   // the wave's 32 survivor counters, SGPRs -> LDS: lane q takes query q's
         unsigned mine = 0u;

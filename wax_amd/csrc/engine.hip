@@ -1253,7 +1253,10 @@ int batch_enqueue(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32
     pa.cand_count = (plan && !counted) ? nullptr : c->d_cand_count;
     pa.q_norm_host = c->h_qnorm + cert_off;
     const bool dynamic_tiles = plan != nullptr && e->batch_dynamic.load() != 0;
-    pa.tile_ctr = dynamic_tiles ? c->d_overflow + kBatchMaxQ : nullptr;
+    // the words behind the overflow flags: tile counters of the dynamic tile order, or the progress words of the wide 768-d kernel's
+    // pace gate (never both: the wide kernel walks its tiles statically) — zeroed by the prep kernel
+    const bool pace_gate = plan != nullptr && D == 768 && nq_pad > 256 && batch_group_queries(D, e->batch_rega.load() == 0 ? 5u : (uint32_t)e->batch_rega.load()) == 256u;
+    pa.tile_ctr = (dynamic_tiles || pace_gate) ? c->d_overflow + kBatchMaxQ : nullptr;
     HIP_TRY(launch_batch_prep(pa, st), WAX_HIP_ERR_INTERNAL, "batch prep launch");
     GemmArgs g{};
     g.qb = c->d_qb; g.cb = b.d_cb; g.q_n2 = c->d_qn2; g.v_n2 = b.d_vn2; g.tau = c->d_tau;
@@ -1269,7 +1272,8 @@ int batch_enqueue(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32
         if (g.use_rega == 0) g.use_rega = 5;
         GemmArgs gs = g;
         gs.tile_max = c->d_tile_max; gs.sample_tiles = plan->sample_tiles;
-        g.tile_ctr = pa.tile_ctr;
+        g.tile_ctr = dynamic_tiles ? pa.tile_ctr : nullptr;
+        g.progress = pace_gate ? pa.tile_ctr : nullptr;
         HIP_TRY(launch_batch_gemm_sample(gs, e->metric, st), WAX_HIP_ERR_INTERNAL, "sampling gemm launch");
         const bool timed = e->time_kernels.load() != 0;
         std::unique_lock<std::mutex> cg(e->gemm_chain_mu, std::defer_lock);

@@ -180,6 +180,10 @@ struct GemmArgs {
     // tile = 2 * workgroups-per-group + old counter value). A workgroup that is delayed — by another batch's kernels
     // sharing the GPU — then simply claims fewer tiles instead of finishing last.
     uint32_t* tile_ctr;
+    // Wide 768-d kernel, more than one query group: non-null = [256] progress words (zeroed before the launch; one 128-byte line per
+    // XCD) for the advisory pace gate that keeps the groups walking the corpus within a few tiles of each other, so that a tile
+    // fetched for one group is still in the XCD's L2 when the others read it.
+    uint32_t* progress;
 };
 // Geometry the register-resident kernel will use for these arguments (false: the LDS-tiled kernel runs instead,
 // appending through cand_count).
