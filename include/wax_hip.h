@@ -343,17 +343,29 @@ int wax_hip_stats(wax_hip_engine* e, wax_hip_stats_t* out);
  * "share_timing" (1 = a chained scan whose predecessor is still in flight uses that scan's end-of-kernel event as its own start
  * event: one packet less between scans; 0 = every scan records its own start), "filter_device_min" (wax_hip_search_filtered: allow-lists at least this long are resolved by
  * the device-side id -> row table instead of host probes, default 4096; -1 = never),
+ * "query_args" (single-query scans, dims 384 / 768: 1 (default) = a store whose scan grid is small enough for the fused merge — the
+ * launch-latency-bound ones — gets the query in the kernel arguments instead of an upload copy in front of the scan; 2 = every store; 0 = never),
+ * "done_flag" (1 (default) = a scan that merges in the kernel publishes a completion word in pinned memory behind its hits and
+ * wax_hip_search_collect polls that word instead of an event recorded behind the kernel; 0 = always an event; never while "time_kernels" = 1),
+ * "batch_eps_measured" (1 (default) = the certificate bound of the batched path uses the measured bf16 rounding errors — per query, and
+ * the maximum over the rows taken when the mirror is built; 0 = the worst case 2^-7 per product),
  * "batch_slab_mb", "batch_growth", "batch_first" (slab schedule of the slab pipeline), "batch_rega" (0 LDS-tiled GEMM
- * only; 5 (default) register-resident GEMM, register staging, split tile barrier (the 768-d kernel: below 4 096 tiles per workgroup;
- * 6 = at every size); 1 the same with a workgroup barrier per tile; 2 LDS-DMA
+ * only; 5 (default) register-resident GEMM, register staging, split tile barrier; D = 768: the wide kernel — whole K per wave, LDS-DMA
+ * staging, 256 queries per workgroup — unless 1 / 6 / 7 select the K-split kernel (workgroup barrier / split barrier at every size /
+ * split barrier below 4 096 tiles per workgroup); 1 the same with a workgroup barrier per tile; 2 LDS-DMA
  * staging; 3 one wave per SIMD; 4 free-running: no tile barrier, three LDS tiles, D <= 384 — a faster kernel alone, slower pipelined
  * because its 150 KB of LDS keep the neighbouring batch's kernels off the CU: DESIGN.md), "batch_debug" (timing experiments:
- * results are NOT valid with bits 1/2/4/8/4096 set). get-only: "variant_count", "scan_grid", "fused_max_k", "batch_queries",
+ * results are NOT valid with bits 1/2/4/8/64/8192 set; bit 12 (4096) switches the wide 768-d kernel's pace gate off, bits 8-9 select its
+ * build variants: all valid). get-only: "variant_count", "scan_grid", "fused_max_k", "batch_queries", "query_args_scans", "done_flag_waits",
+ * "batch_inline_retries" (queries certified by the device-side retry kernel), "batch_max_row_err_e9",
  * "batch_fallbacks", "onepass_queries", "batch_max_k", "batch_retries", "batch_multi_passes", "batch_multi_queries", "batch_multi_group" /
  * "batch_multi_group_big" (queries per shared exact pass for k <= 60 / k <= 192), "filter_device_searches". Sharded handles: every key above is forwarded to all shards; plus
- * "exchange" (0 peer copies + merge on the first device, 1 RCCL all-gather per query) and the get-only "shards", "block_rows",
- * "rebalances", "rccl_collectives", "parallel_collects" (batched collects whose per-shard exactness ladders ran side by side on the
- * handle's worker threads: chosen when the previous batch had two or more shards settle queries on the host side). */
+ * "exchange" (0 peer copies + merge on the first device, 1 RCCL all-gather per query), "gather" (0 = per-shard hits gathered on the
+ * first device; 2 = through the host, merged by key there: what a handle falls back to when a device pair lacks peer access) and the
+ * get-only "shards", "block_rows", "rebalances", "rccl_collectives", "rccl_ranks" (ncclCommCount of the in-library communicator),
+ * "peer_pairs" / "peer_enabled" (device pairs that need / have peer access), "parallel_submits" (batches whose per-shard submits ran on
+ * the handle's workers because a submit would have blocked), "parallel_collects" (batched collects whose per-shard exactness ladders
+ * ran side by side on the handle's worker threads: chosen when the previous batch had two or more shards settle queries on the host side). */
 int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value);
 int64_t wax_hip_get_tuning(wax_hip_engine* e, const char* key);
 /* Times `iters` back-to-back launches of ONLY the scan kernel for `query`
