@@ -2110,38 +2110,3 @@ def test_certificate_bound_survives_aligned_rounding_errors(wax):
     assert 3.5e6 < eng.getTuning("batch_max_row_err_e9") < 4.0e6
     eng.close()
 
-
-def test_light_sampling_kernel_gives_the_same_answers(wax):
-    """"batch_sample_lite" = 1: the one-pass pipeline's thresholds come from the light sampling kernel (one wave per workgroup, <= 48
-    VGPRs, no LDS: it runs beside the previous batch's filtering GEMM) instead of the SAMPLE instantiation of the GEMM kernel.
-    Thresholds only steer how many rows survive the filter; the answers must be the single-query path's bit for bit either way —
-    for every dimension the kernel serves, cosine and dot, ragged stores, k from 1 to 100, several batches in flight."""
-    import torch
-    dev = torch.device("cuda", 0)
-    st = torch.cuda.current_stream(dev).cuda_stream
-    for metric, dims, n, nq in [(0, 384, 200_000, 256), (1, 384, 131_075, 300), (0, 128, 150_000, 64), (0, 256, 140_000, 256), (0, 512, 100_003, 129)]:
-        corpus = oracle.gaussian_unit_rows(50 + dims, n, dims)
-        if metric == 1:
-            corpus = corpus * np.random.default_rng(dims).uniform(0.5, 1.5, (n, 1)).astype(np.float32)
-        eng = make_engine(wax, metric, dims, corpus)
-        queries = oracle.gaussian_unit_queries(nq, dims, seed=dims + metric)
-        eng.setTuning("batch_onepass_tiles", 1024)
-        for k in (1, 10, 100):
-            eng.setTuning("batch_sample_lite", 0)
-            ref = eng.searchBatch(queries, k)
-            o0 = eng.getTuning("onepass_queries")
-            eng.setTuning("batch_sample_lite", 1)
-            got = eng.searchBatch(queries, k)
-            assert eng.getTuning("onepass_queries") - o0 == nq, (metric, dims, n, k)            # the one-pass pipeline took it
-            assert all(np.array_equal(x, y) for x, y in zip(got, ref)), (metric, dims, n, k)
-            for i in (0, nq // 2, nq - 1):
-                s_ids, s_scores = eng.searchArrays(queries[i], k)
-                assert np.array_equal(got[0][i, :len(s_ids)], s_ids) and np.array_equal(got[1][i, :len(s_ids)], s_scores), (metric, dims, n, k, i)
-        # two batches in flight with the light sampler
-        dq = torch.from_numpy(queries).to(dev)
-        outs = [torch.empty((nq, 10, 2), dtype=torch.int64, device=dev) for _ in range(2)]
-        ts = [eng.searchBatchSubmitDevice(dq.data_ptr(), nq, 10, outs[i].data_ptr(), 10, st) for i in range(2)]
-        for t in ts:
-            eng.searchBatchCollectDevice(t)
-        assert np.array_equal(outs[0].cpu().numpy(), outs[1].cpu().numpy())
-        eng.close()

@@ -2519,70 +2519,6 @@ static hipError_t launch_rega_sample(const GemmArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
-// ---------------------------------------------------------------------------
-// Light sampling kernel (round 4; cosine / dot, D in {128, 256, 384, 512}): the same per-(tile, query) maxima as the SAMPLE
-// instantiations of the GEMM kernels, from a kernel small enough to run BESIDE a filtering GEMM instead of behind it.
-// With two batches in flight, batch i + 1's prep -> sampling -> threshold chain is enqueued while batch i's filtering GEMM runs; that
-// GEMM is one persistent workgroup per CU holding 100 KB of LDS and 2 x 232 of a SIMD's 512 VGPRs, so the sampling GEMM (a workgroup
-// of the same shape) could not start before it ended: ~30 us between two batches' GEMMs at Q = 256 (prep, at 32 VGPRs, already runs
-// beside it). This kernel is one wave per workgroup, no LDS, at most 48 VGPRs — exactly what a SIMD has left — and one task per
-// wave: a half tile (32 corpus rows) x 32 queries, the K loop fed straight from global memory (query block: L2; rows: the 2 KB
-// lines of 32 consecutive rows), double-buffered in registers. It is a poor GEMM and does not need to be a good one: sampling is 1 / 32
-// of the filtering work and it has the whole filtering launch to finish in; the matrix pipe has ~45 % to spare.
-// Output: tile_max[2 i + h][query] for half h of sampled tile i (pick_tau_kernel then ranks 2 S half-tile maxima; the statistics are those
-// of S tiles of 64 rows: the same sampled rows, and two top rows that share a tile but not a half now count separately).
-template <int D>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(10, 10))) void batch_sample_lite_kernel(GemmArgs a) {
-    constexpr int KS = D / 16;
-    const int lane = (int)threadIdx.x;
-    const uint32_t nqb = a.nqt * 4u;                          // 32-query blocks
-    const uint32_t task = blockIdx.x;
-    const uint32_t half_tile = task / nqb;                    // 0 .. 2 * sample_tiles - 1
-    const uint32_t q0 = (task - half_tile * nqb) * 32u;
-    const uint32_t ntiles_all = (a.slab_rows + 63u) / 64u;
-    const uint32_t tile = (uint32_t)(((unsigned long long)(half_tile >> 1) * ntiles_all) / a.sample_tiles);   // as the GEMM kernels' phys()
-    uint32_t row = a.slab0 + tile * 64u + (half_tile & 1u) * 32u + (uint32_t)(lane & 31);
-    row = row < a.n_rows ? row : a.n_rows - 1;                // clamp: a duplicate of the last row cannot raise a maximum
-    const u32x4* qp = reinterpret_cast<const u32x4*>(a.qb + (size_t)(q0 + (uint32_t)(lane & 31)) * D) + (lane >> 5);
-    const u32x4* bp = reinterpret_cast<const u32x4*>(a.cb + (size_t)row * D) + (lane >> 5);
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    u32x4 fa[2], fb[2];
-    fa[0] = qp[0];
-    fb[0] = bp[0];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        if (ks + 1 < KS) {
-            fa[(ks + 1) & 1] = qp[(ks + 1) * 2];
-            fb[(ks + 1) & 1] = bp[(ks + 1) * 2];
-        }
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[ks & 1]), __builtin_bit_cast(bf16x8, fb[ks & 1]), acc, 0, 0, 0);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float m = group_max32(acc[r]);
-        if ((lane & 31) == 31)
-            a.tile_max[(size_t)half_tile * (a.nqt * 128u) + q0 + (uint32_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5))] = m;
-    }
-}
-
-bool batch_sample_lite_dims(uint32_t dims, int metric) {
-    return metric != BM_L2 && (dims == 128 || dims == 256 || dims == 384 || dims == 512);
-}
-// Writes 2 * a.sample_tiles rows of tile_max (half tiles): the caller ranks that many.
-hipError_t launch_batch_sample_lite(const GemmArgs& a, int metric, hipStream_t st) {
-    if (!batch_sample_lite_dims(a.dims, metric) || a.tile_max == nullptr || a.sample_tiles == 0) return hipErrorInvalidValue;
-    const dim3 grid(2u * a.sample_tiles * a.nqt * 4u);
-    switch (a.dims) {
-        case 128: hipLaunchKernelGGL((batch_sample_lite_kernel<128>), grid, dim3(64), 0, st, a); break;
-        case 256: hipLaunchKernelGGL((batch_sample_lite_kernel<256>), grid, dim3(64), 0, st, a); break;
-        case 384: hipLaunchKernelGGL((batch_sample_lite_kernel<384>), grid, dim3(64), 0, st, a); break;
-        default: hipLaunchKernelGGL((batch_sample_lite_kernel<512>), grid, dim3(64), 0, st, a); break;
-    }
-    return hipGetLastError();
-}
-
 hipError_t launch_batch_gemm_sample(const GemmArgs& a, int metric, hipStream_t st) {
     if (!batch_onepass_dims(a.dims, metric) || a.tile_max == nullptr || a.sample_tiles == 0) return hipErrorInvalidValue;
     if (!batch_onepass_fast(a.dims, metric)) {   // LDS-tiled kernel: one workgroup per (sampled tile, 128 queries)

@@ -429,7 +429,6 @@ struct wax_hip_engine {
     std::atomic<int64_t> batch_dynamic{0};        // one-pass pipeline: filtering-GEMM workgroups claim their tiles from a counter
     std::atomic<int64_t> batch_sample_div{32};    // one-pass pipeline: 1 / this of the tiles are sampled (at least 256)
     std::atomic<uint64_t> st_onepass_queries{0};
-    std::atomic<int64_t> batch_sample_lite{0};        // one-pass pipeline: 1 = thresholds sampled by the light kernel that fits beside a filtering GEMM
     std::atomic<int64_t> batch_eps_measured{1};       // cosine certificate bound from the MEASURED bf16 rounding errors (per query, max over rows) instead of the worst case
     std::atomic<int> retry_hint{0};                   // > 0: batches carry the device-side retry kernel behind their finish kernel
     std::atomic<uint64_t> st_batch_inline_retries{0};  // ... of which inside the finish kernel (no host round trip)
@@ -1275,12 +1274,7 @@ int batch_enqueue(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32
         gs.tile_max = c->d_tile_max; gs.sample_tiles = plan->sample_tiles;
         g.tile_ctr = dynamic_tiles ? pa.tile_ctr : nullptr;
         g.progress = pace_gate ? pa.tile_ctr : nullptr;
-        // "batch_sample_lite" 1: the sampling runs in the light kernel that fits beside the previous batch's filtering GEMM (half tiles:
-        // twice as many maxima to rank)
-        const bool lite = e->batch_sample_lite.load() != 0 && batch_sample_lite_dims(D, e->metric) && !counted;
-        const uint32_t sampled = lite ? 2u * plan->sample_tiles : plan->sample_tiles;
-        if (lite) HIP_TRY(launch_batch_sample_lite(gs, e->metric, st), WAX_HIP_ERR_INTERNAL, "sampling kernel launch");
-        else HIP_TRY(launch_batch_gemm_sample(gs, e->metric, st), WAX_HIP_ERR_INTERNAL, "sampling gemm launch");
+        HIP_TRY(launch_batch_gemm_sample(gs, e->metric, st), WAX_HIP_ERR_INTERNAL, "sampling gemm launch");
         const bool timed = e->time_kernels.load() != 0;
         std::unique_lock<std::mutex> cg(e->gemm_chain_mu, std::defer_lock);
         if (timed) {
@@ -1290,7 +1284,7 @@ int batch_enqueue(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32
             if (e->gemm_chain_ev && e->gemm_chain_ev != c->ev_g1)
                 HIP_TRY(hipStreamWaitEvent(st, e->gemm_chain_ev, 0), WAX_HIP_ERR_INTERNAL, "gemm chain wait");
         }
-        HIP_TRY(launch_pick_tau(c->d_tile_max, sampled, qn, nq_pad, plan->rank, c->d_tau, e->metric, st), WAX_HIP_ERR_INTERNAL,
+        HIP_TRY(launch_pick_tau(c->d_tile_max, plan->sample_tiles, qn, nq_pad, plan->rank, c->d_tau, e->metric, st), WAX_HIP_ERR_INTERNAL,
                 "threshold kernel launch");
         if (timed) {
             // With several batches in flight (submit / collect) the filtering GEMMs of different workspaces would queue
@@ -1388,7 +1382,7 @@ int batch_submit_device_locked(wax_hip_engine* e, BatchCtx* c, const float* d_qu
     hipStream_t st = c->stream;
     const uint32_t D = e->dims;
     int rc = bctx_reserve(c, plan ? plan->seg_area : kBatchCandCap, plan ? (uint64_t)plan->kp : (uint64_t)FUSED_MAX_K,
-                          plan ? 2 * plan->sample_tiles : 0, nq, plan == nullptr);   // (the light sampling kernel writes half-tile maxima)
+                          plan ? plan->sample_tiles : 0, nq, plan == nullptr);
     if (rc != WAX_HIP_OK) return rc;
     for (uint32_t q0 = 0; q0 < nq; q0 += kBatchMaxQ) {
         const uint32_t qn = (nq - q0 < kBatchMaxQ) ? nq - q0 : kBatchMaxQ;
@@ -2837,7 +2831,6 @@ int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value) {
     else if (k == "batch_survivors") { if (value < 2 || value > 64) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_survivors must be 2..64"); e->batch_survivors = value; }
     else if (k == "batch_dynamic") e->batch_dynamic = value != 0;
     else if (k == "batch_eps_measured") e->batch_eps_measured = value != 0;
-    else if (k == "batch_sample_lite") e->batch_sample_lite = value != 0;
     else if (k == "retry_hint") e->retry_hint = (int)value;   // > 0: the next batches carry the device-side retry kernel (set by collect; tests force it)
     else if (k == "batch_retry") { if (value < 0 || value > 2) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_retry must be 0, 1 or 2"); e->batch_retry = value; }
     else if (k == "batch_multi") e->batch_multi = value != 0;
@@ -2891,7 +2884,6 @@ int64_t wax_hip_get_tuning(wax_hip_engine* e, const char* key) {
     if (k == "batch_inline_retries") return (int64_t)e->st_batch_inline_retries.load();
     if (k == "retry_hint") return e->retry_hint.load();
     if (k == "batch_eps_measured") return e->batch_eps_measured.load();
-    if (k == "batch_sample_lite") return e->batch_sample_lite.load();
     if (k == "batch_max_row_err_e9") return (int64_t)((double)e->batch.max_row_err * 1e9);
     if (k == "batch_min") return e->batch_min.load();
     if (k == "batch_mode") return e->batch_mode.load();

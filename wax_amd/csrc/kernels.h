@@ -259,10 +259,6 @@ struct PrepArgs {
 constexpr uint32_t BATCH_TILE_CTRS = 32;
 hipError_t launch_batch_prep(const PrepArgs& a, hipStream_t stream);
 hipError_t launch_batch_gemm_sample(const GemmArgs& a, int metric, hipStream_t stream);
-// The light sampling kernel (one wave per workgroup, <= 48 VGPRs, no LDS: runs beside a filtering GEMM). Writes 2 * sample_tiles rows
-// of tile_max (32-row half tiles): rank that many.
-bool batch_sample_lite_dims(uint32_t dims, int metric);
-hipError_t launch_batch_sample_lite(const GemmArgs& a, int metric, hipStream_t stream);
 // tau[q] = 1 - (the rank-th largest of the sampled tiles' best similarities), rank <= 12; padding queries keep -inf.
 hipError_t launch_pick_tau(const float* tile_max, uint32_t sample_tiles, uint32_t nq, uint32_t nq_pad, uint32_t rank,
                            float* tau, int metric, hipStream_t stream);
