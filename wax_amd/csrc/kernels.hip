@@ -80,6 +80,12 @@ __device__ inline float hsum(const f32x4& a) { return (a.x + a.y) + (a.z + a.w);
 // take a ticket; the last arriver re-reads every list with agent-scope loads (served by L2, never a stale L1 line), selects
 // the global k with the same wave lists + rank merge, attaches frame ids and writes the kpad hits
 // (cdna_hip_programming.md §6 Guideline 16, counter form; *arrive is re-armed by the last arriver).
+// Why not an acq_rel ticket: at agent scope a release on this part writes back the XCD's whole L2 (buffer_wbl2 sc1) and an acquire
+// invalidates it — microseconds on a kernel whose point is to be a few microseconds. What is ordered here is exactly what must be:
+// the k keys are stored write-through with agent-scope atomics (they are in memory when vmcnt reaches 0, which every storing wave
+// waits for before the workgroup barrier in front of the ticket), the ticket itself is an agent-scope RMW, and the last arriver reads
+// the lists with agent-scope atomic loads that cannot be served from a stale line. Every access that takes part in the hand-over is
+// an atomic of agent scope; only the fence instructions a release / acquire pair would add around them are left out.
 template <int CAP>
 __device__ inline void scan_epilogue(const ScanArgs& a, int64_t* lds, int* counts, int64_t* fin) {
     const int k = a.k;
