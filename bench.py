@@ -75,6 +75,10 @@ def parse_args():
     p.add_argument("--chain-timed-region", action="store_true",
                    help="time the kernels INSIDE the timed region (scans chained, as in rounds 1-2): the run a rocprofv3 "
                         "--kernel-trace --stats summary is compared with — every launch of the region is one kernel alone")
+    p.add_argument("--traffic", choices=["auto", "live", "replay", "off"], default="auto",
+                   help="roofline.traffic of the headline kernel: live = a rocprofv3 --pmc FETCH_SIZE child pass inside this run (N = 1); "
+                        "replay = the committed pass in profiles/latest_traffic.json; auto = live where rocprofv3 is on PATH, else replay")
+    p.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     p.add_argument("--detail-out", default=None, metavar="PATH",
                    help="where the verbose record goes (default bench_detail.json next to bench.py); stdout carries ONE compact line")
     p.add_argument("--host-merge", action="store_true", help="N>1: merge gathered hits on the host instead of the device")
@@ -317,6 +321,78 @@ def measure_single_query(eng, submit, collect, queries, warmup, steps, depth, ba
                 "every scan launch on its own stream, scans chained (never two at once)"}
 
 
+TRAFFIC_CHILD_WARM, TRAFFIC_CHILD_LAUNCHES = 2, 6
+
+
+def traffic_child(torch, dev, rows, dims, k):
+    """`--traffic-child` (run under rocprofv3 --pmc by live_traffic): the headline corpus, a few blocking single-query scans, nothing else."""
+    eng = _load_engine(torch, dev, rows, dims)
+    apply_tunes(eng)
+    torch.cuda.synchronize()
+    for q in unit_queries(TRAFFIC_CHILD_WARM + TRAFFIC_CHILD_LAUNCHES, dims):
+        eng.searchArrays(q, k)
+    eng.close()
+
+
+def live_traffic(rows, dims, k, timeout_s=300):
+    """HBM bytes per launch of the headline scan kernel, measured IN this run: a counters-only child pass
+    (`rocprofv3 --pmc FETCH_SIZE --kernel-trace`, no other tracing: MI355X_MICROARCH.md's HBM recipe) over the same corpus
+    and kernel, TRAFFIC_CHILD_LAUNCHES launches after TRAFFIC_CHILD_WARM warm-ups. bytes = FETCH_SIZE (KiB) * 1024 * 2 (the guide's
+    gfx950 correction: the counter sees a 128-B request of a wide coalesced stream as 64 B). Returns (bytes or None, source text)."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    if any(v.startswith(("ROCPROF", "ROCP_")) for v in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this run is itself under rocprofv3: no nested counter pass"
+    tmp = tempfile.mkdtemp(prefix="wax_pmc_", dir="/tmp")
+    cmd = [exe, "--pmc", "FETCH_SIZE", "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "t", "--",
+           sys.executable, os.path.abspath(__file__), "--traffic-child", "--rows", str(rows), "--dims", str(dims), "--topk", str(k)]
+    for t in TUNES:
+        cmd += ["--tune", t]
+    env = dict(os.environ, TMPDIR="/tmp")
+    for v in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(v, None)
+    t0 = time.perf_counter()
+    try:
+        with open(os.path.join(tmp, "child.log"), "w") as lf:
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=lf, stderr=subprocess.STDOUT, start_new_session=True)
+            try:
+                rc = proc.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, signal.SIGKILL)      # exactly the process group started above
+                proc.wait()
+                return None, f"counter pass timed out after {timeout_s} s"
+        vals = []
+        for path in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+            with open(path) as f:
+                for r in csv.DictReader(f):
+                    if "scan_kernel" in (r.get("Kernel_Name") or "") and r.get("Counter_Name") == "FETCH_SIZE":
+                        vals.append((int(r.get("Dispatch_Id") or 0), float(r["Counter_Value"])))
+        vals = [v for _, v in sorted(vals)][TRAFFIC_CHILD_WARM:]
+        if rc != 0 or not vals:
+            tail = ""
+            try:
+                tail = open(os.path.join(tmp, "child.log")).read()[-300:].replace("\n", " | ")
+            except OSError:
+                pass
+            return None, f"counter pass failed (rc {rc}, {len(vals)} launches seen): {tail}"
+        mean_kib = sum(vals) / len(vals)
+        return mean_kib * 1024.0 * 2.0, (f"measured in this run: rocprofv3 --pmc FETCH_SIZE --kernel-trace child pass (counters only) over the same "
+                                         f"corpus, {len(vals)} launches after {TRAFFIC_CHILD_WARM} warm-ups, {time.perf_counter() - t0:.0f} s; "
+                                         f"bytes = FETCH_SIZE[KiB] * 1024 * 2 (gfx950 correction); min/max over launches "
+                                         f"{min(vals) * 2048:.6g} / {max(vals) * 2048:.6g}")
+    except Exception as ex:  # noqa: BLE001 - the bench line must not die on its optional leg
+        return None, f"counter pass raised {type(ex).__name__}: {ex}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def scan_roofline(bytes_per_launch, kern_ms, launches, elapsed, steps, cal, traffic=None, traffic_source=None):
     achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if launches else float("nan")
     pipeline = bytes_per_launch * steps / elapsed / 1e9
@@ -368,6 +444,7 @@ def secondary_single_query(torch, dev, rows, dims, k, steps, warmup, depth, labe
     checksum = hashlib.sha256(np.asarray(last[0], dtype=np.uint64).tobytes() + np.asarray(last[1], dtype=np.float32).tobytes()).hexdigest()[:16]
     nbytes = rows * dims * 4
     grid = eng.getTuning("scan_grid")
+    merged = eng.getTuning("merged_scans")
     eng.close()
     traffic, traffic_source = None, None
     try:
@@ -380,7 +457,7 @@ def secondary_single_query(torch, dev, rows, dims, k, steps, warmup, depth, labe
         pass
     rf = scan_roofline(nbytes, kern_ms, launches, elapsed, steps, cal, traffic, traffic_source)
     rf["scan_grid"] = grid
-    rf["launches_per_query"] = 1 if (eng_fused_grid(grid)) else 2
+    rf["launches_per_query"] = 1 if merged > 0 else 2     # 1: the scan kernel's last-arriving workgroup did the final merge
     return {
         "config": f"{rows} x {dims} f32 cosine top-{k}, one query per step, 1 GPU ({label})",
         "value": steps / elapsed, "unit": "queries/s", "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
@@ -427,10 +504,6 @@ def sharded_single_query(torch, dist, args, rank, world, local_rank, use_rccl, r
         "ms_per_step": elapsed / steps * 1e3, "dtype": "f32", "rows_per_gpu": hi - lo, "last_result_checksum": checksum,
         "roofline": rf,
     }
-
-
-def eng_fused_grid(grid):
-    return grid <= 160   # SCAN_FUSE_MERGE_GRID: the scan kernel's last-arriving workgroup does the final merge
 
 
 def batched_roofline(rows, dims, nq, kern_ms, launches, rega=5):
@@ -725,6 +798,8 @@ def compact_line(full):
         r = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "pipeline_frac", "kernel_avg_ms", "kernel_launches_timed",
                        "algorithmic_bytes_per_launch", "traffic"))
         r["kernel"] = str(rf.get("kernel", "")).split(" ")[0]
+        if rf.get("traffic") is not None:
+            r["traffic_from"] = "live-pmc" if str(rf.get("traffic_source", "")).startswith("measured in this run") else "replayed-pmc"
         line["roofline"] = r
     cb = full.get("cpu_baseline")
     if cb is not None:
@@ -819,6 +894,9 @@ def main():
         raise SystemExit("no gfx950 device visible: bench.py measures the HIP path only")
 
     n, dims, k = args.rows, args.dims, args.topk
+    if args.traffic_child:
+        traffic_child(torch, dev, n, dims, k)
+        return
     lo, hi = sharded.shard_bounds(n, world, rank, align=64)
     t_build = time.perf_counter()
     if in_library:
@@ -918,17 +996,26 @@ def main():
     if rank == 0:
         qps = args.steps / elapsed
         bytes_per_launch = (hi - lo) * dims * 4
-        # HBM traffic needs a PMC pass of its own (rocprofv3 --pmc FETCH_SIZE, never combined with tracing): it cannot be
-        # measured inside this run. A figure REPLAYED from the committed counter pass of this same command is reported
-        # with its source; without a matching pass the field is null.
+        # HBM traffic needs a PMC pass of its own (rocprofv3 --pmc FETCH_SIZE, never combined with tracing): at N = 1 a child process
+        # does that pass inside this run (live_traffic). Where it cannot (N > 1, no rocprofv3, a failed pass) the figure is REPLAYED
+        # from the committed counter pass of this same command and says so; without a matching pass the field is null.
         traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
-        if os.path.exists(tpath):
+        live_note = None
+        if args.traffic in ("auto", "live") and world == 1 and not in_library:
+            traffic, live_note = live_traffic(n, dims, k)
+            if traffic is not None:
+                traffic_source = live_note
+            else:
+                log(f"[bench] live traffic pass unavailable: {live_note}")
+        if traffic is None and args.traffic in ("auto", "replay") and os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 if tj.get("rows_per_launch") == hi - lo and tj.get("dims") == dims:
                     traffic = tj.get("hbm_bytes_per_launch")
                     traffic_source = "replayed from profiles/latest_traffic.json (" + str(tj.get("source", "rocprofv3 --pmc FETCH_SIZE pass of this command")) + "), not measured in this run"
+                    if live_note:
+                        traffic_source += "; live pass: " + live_note
             except Exception:  # noqa: BLE001
                 traffic = None
         n_gpus = args.gpus if in_library else world

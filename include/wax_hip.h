@@ -343,8 +343,11 @@ int wax_hip_stats(wax_hip_engine* e, wax_hip_stats_t* out);
  * "share_timing" (1 = a chained scan whose predecessor is still in flight uses that scan's end-of-kernel event as its own start
  * event: one packet less between scans; 0 = every scan records its own start), "filter_device_min" (wax_hip_search_filtered: allow-lists at least this long are resolved by
  * the device-side id -> row table instead of host probes, default 4096; -1 = never),
- * "query_args" (single-query scans, dims 384 / 768: 1 (default) = a store whose scan grid is small enough for the fused merge — the
- * launch-latency-bound ones — gets the query in the kernel arguments instead of an upload copy in front of the scan; 2 = every store; 0 = never),
+ * "merge_kway" (1 (default) = top_k <= 32: the scan kernel's last-arriving workgroup merges the per-workgroup lists by their heads — k
+ * rounds of a workgroup-wide minimum, whatever the number of lists — which lets every default grid (<= 512 workgroups) of a store of up to
+ * 2 GiB of rows finish in ONE launch; 0 = small grids (<= 160 workgroups) stream the lists through the wave lists, larger ones use the merge kernel),
+ * "query_args" (single-query scans, dims 384 / 768: 1 (default) = a store whose scan merges in its own kernel — the launch-latency-bound
+ * ones — gets the query in the kernel arguments instead of an upload copy in front of the scan; 2 = every store; 0 = never),
  * "done_flag" (1 (default) = a scan that merges in the kernel publishes a completion word in pinned memory behind its hits and
  * wax_hip_search_collect polls that word instead of an event recorded behind the kernel; 0 = always an event; never while "time_kernels" = 1),
  * "batch_eps_measured" (1 (default) = the certificate bound of the batched path uses the measured bf16 rounding errors — per query, and
@@ -356,7 +359,8 @@ int wax_hip_stats(wax_hip_engine* e, wax_hip_stats_t* out);
  * staging; 3 one wave per SIMD; 4 free-running: no tile barrier, three LDS tiles, D <= 384 — a faster kernel alone, slower pipelined
  * because its 150 KB of LDS keep the neighbouring batch's kernels off the CU: DESIGN.md), "batch_debug" (timing experiments:
  * results are NOT valid with bits 1/2/4/8/64/8192 set; bit 12 (4096) switches the wide 768-d kernel's pace gate off, bits 8-9 select its
- * build variants: all valid). get-only: "variant_count", "scan_grid", "fused_max_k", "batch_queries", "query_args_scans", "done_flag_waits",
+ * build variants: all valid). get-only: "variant_count", "scan_grid", "fused_max_k", "batch_queries", "query_args_scans", "merged_scans" (single-query scans that
+ * merged in their own kernel), "done_flag_waits",
  * "batch_inline_retries" (queries certified by the device-side retry kernel), "batch_max_row_err_e9",
  * "batch_fallbacks", "onepass_queries", "batch_max_k", "batch_retries", "batch_multi_passes", "batch_multi_queries", "batch_multi_group" /
  * "batch_multi_group_big" (queries per shared exact pass for k <= 60 / k <= 192), "filter_device_searches". Sharded handles: every key above is forwarded to all shards; plus

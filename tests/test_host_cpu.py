@@ -377,7 +377,8 @@ def test_bench_line_stays_inside_the_drivers_stdout_tail(tmp_path, capsys):
         assert key in line, key
     assert line["config"]["workload"].startswith("10M x 384") and line["config"]["rccl_ranks"] == 8 and line["config"]["checksum"] == "fedcba9876543210"
     assert set(line["roofline"]) == {"bound", "achieved", "peak", "unit", "frac", "pipeline_frac", "kernel", "kernel_avg_ms",
-                                     "kernel_launches_timed", "algorithmic_bytes_per_launch", "traffic"}
+                                     "kernel_launches_timed", "algorithmic_bytes_per_launch", "traffic", "traffic_from"}
+    assert line["roofline"]["traffic_from"] in ("live-pmc", "replayed-pmc")
     assert line["roofline"]["kernel"] == "wax::scan_kernel" and abs(line["roofline"]["frac"] - 0.873265) < 1e-6
     assert line["cpu_baseline"]["cores"] == 16 and line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value_1_thread"] == 0.53
     assert all(set(x) <= {"name", "value", "ms_per_step", "frac", "kernel_avg_ms", "n_gpus", "ck", "blocking_ms", "error"} for x in line["secondary"])

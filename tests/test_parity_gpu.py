@@ -519,6 +519,8 @@ def test_full_size_parity_with_oracle(wax, n, dims, nq):
     k = 10
     queries = oracle.gaussian_unit_queries(nq, dims)
     got = [eng.searchArrays(q, k) for q in queries]
+    # k <= 32: the scan merges in its own kernel (one packet, completion word) up to 2 GiB of rows; beyond, a separate merge kernel
+    assert (eng.getTuning("done_flag_waits") == nq) == (n * dims * 4 <= 2 << 30), (n, dims, eng.getTuning("done_flag_waits"))
     # the whole top-10 of every query, id for id and score for score, against the f64 oracle on the same rows
     _assert_batch_parity(0, corpus, queries, k, [g[0] for g in got], [g[1] for g in got], [len(g[0]) for g in got], 0,
                          f"{n}x{dims}")
@@ -850,7 +852,10 @@ def test_bench_contract_and_shard_invariance(wax, tmp_path):
     assert "300K x 384" in one["metric"] and one["config"]["parallelism"] == "row-shard x1"
     assert one["_line"]["config"]["rccl_ranks"] == 0 and one["_line"]["config"]["parallelism"] == "row-shard x1"
     assert "cpu_baseline" in one["_line"]
-    assert r["traffic"] is None and r["traffic_source"] is None      # no counter pass exists for this row count
+    # roofline.traffic: measured in the run itself by a counters-only rocprofv3 child pass over the same corpus (bench.live_traffic)
+    assert r["traffic_source"].startswith("measured in this run"), r["traffic_source"]
+    assert 0.95 < r["traffic"] / (300000 * 384 * 4) < 1.3, r["traffic"]
+    assert one["_line"]["roofline"]["traffic_from"] == "live-pmc" and one["_line"]["roofline"]["traffic"] > 0
     sec = one["secondary"]
     assert [x["name"] for x in sec] == ["s10k", "s1m", "b1m_q256", "b1m_q1024", "c5_shard", "c5_full", "clustered_k10", "s1250k"]
     assert "per-GPU shard at 8 GPUs" in sec[7]["config"] and sec[7]["roofline"]["algorithmic_bytes_per_launch"] == 1_250_000 * 384 * 4
@@ -861,6 +866,7 @@ def test_bench_contract_and_shard_invariance(wax, tmp_path):
         assert x["value"] > 0 and x["ms_per_step"] > 0 and rr["kernel_launches_timed"] >= min(x["steps"], 60)
         assert rr["bound"] in ("hbm", "mfma") and 0 < rr["frac"] < 1.2 and abs(rr["frac"] - rr["achieved"] / rr["peak"]) < 1e-9
     assert sec[0]["roofline"]["launches_per_query"] == 1            # 10K rows: the scan kernel's last workgroup merges
+    assert sec[1]["roofline"]["launches_per_query"] == 1            # ... and so does the 1M-row store's (top-10: the k-way merge of the list heads)
     assert all(x["pipeline"] == "one-pass" and x["batches_in_flight"] == 2 and x["ms_per_step_blocking_call"] > 0 for x in sec[2:])
     assert all(x["certificate_fallbacks"] == 0 for x in sec[2:6])
     assert sec[6]["corpus"] == "clustered" and "ms_per_step_vs_iid_config3" in sec[6]
@@ -869,7 +875,8 @@ def test_bench_contract_and_shard_invariance(wax, tmp_path):
           f"{sec[6]['ms_per_step_vs_iid_config3']:.2f} x the iid batch time")
     c5_one = sec[5]["last_result_checksum"]                          # config 5 (shrunk to 300K rows) on ONE engine
     # the in-timed-region measurement mode (what a rocprofv3 kernel-trace summary is compared with)
-    chained = _run_bench(1, ["--no-secondary", "--chain-timed-region"], tmp_path)
+    chained = _run_bench(1, ["--no-secondary", "--chain-timed-region", "--traffic", "replay"], tmp_path)
+    assert chained["roofline"]["traffic"] is None                    # no committed counter pass exists for this row count
     assert chained["roofline"]["kernel_launches_timed"] == 12 and chained["config"]["last_result_checksum"] == one["config"]["last_result_checksum"]
     two = _run_bench(2, [], tmp_path)
     assert "host (gloo)" in two["config"]["parallelism"]
@@ -1903,21 +1910,36 @@ def test_multi_query_exact_scan_is_bit_identical(wax, dims, metric):
     eng.close()
 
 
+def _merges_in_kernel(grid, k, n, dims):
+    """kernels.h scan_merges_in_kernel: any k <= 192 on grids <= 160 (wave-list merge); k <= 32 on every default grid (<= 512:
+    the k-way merge of the lists' heads) for stores of up to 2 GiB of rows."""
+    return grid <= 160 or (k <= 32 and grid <= 512 and n * dims * 4 <= 2 << 30)
+
+
 def test_fused_final_merge_equals_two_launch_path(wax):
     """Small grids (<= 160 workgroups: stores up to ~20K rows) let the scan kernel's last-arriving workgroup do the final
     merge (scan_epilogue: write-through partial lists, device-scope ticket) instead of a second launch. Same hits, bit for
     bit, as the two-launch path ("fuse_merge" = 0) — for every k the fused kernels serve, ragged sizes, all metrics, the
-    generic-dims kernel, and many back-to-back queries on pipelined slots (the ticket must re-arm itself)."""
-    for metric, dims, n in [(0, 384, 10_000), (1, 384, 9_999), (2, 128, 5_000), (0, 768, 3_001), (0, 100, 2_000), (0, 384, 65), (0, 64, 20_000)]:
+    generic-dims kernel, and many back-to-back queries on pipelined slots (the ticket must re-arm itself). For k <= 32 the last
+    arriver merges the lists' heads (kway_merge: one or two lists per thread), which serves every default grid (<= 512), so
+    larger stores take the same path; there k > 32 stays on two launches and both settings run the same kernels."""
+    for metric, dims, n in [(0, 384, 10_000), (1, 384, 9_999), (2, 128, 5_000), (0, 768, 3_001), (0, 100, 2_000), (0, 384, 65), (0, 64, 20_000),
+                            (0, 384, 45_001), (2, 768, 70_000), (1, 384, 400_000), (0, 100, 150_000)]:   # grids of 257 .. 512: two lists per thread (k <= 32)
         corpus = oracle.gaussian_unit_rows(7 + n, n, dims)
         corpus[11] = corpus[10]
         eng = make_engine(wax, metric, dims, corpus, np.arange(n, dtype=np.uint64) + 9)
         queries = oracle.gaussian_unit_queries(24, dims, seed=n)
         queries[3] = corpus[10]
-        for k in (1, 10, 64, 65, 192):
+        for k in (1, 3, 4, 5, 10, 24, 32, 33, 64, 65, 192):
             eng.setTuning("fuse_merge", 1)
             pend = [eng.submit(q, k) for q in queries[:4]]          # pipelined: four slots, four tickets
             fused = [eng.collect(t, k) for t in pend] + [eng.searchArrays(q, k) for q in queries[4:]]
+            if k <= 32:                                             # k <= 32 merges the lists' heads ("merge_kway"); the wave-list merge must agree
+                eng.setTuning("merge_kway", 0)
+                for q, (f_ids, f_scores) in zip(queries[:8], fused):
+                    w_ids, w_scores = eng.searchArrays(q, k)
+                    assert np.array_equal(f_ids, w_ids) and np.array_equal(f_scores, w_scores), ("kway", metric, dims, n, k)
+                eng.setTuning("merge_kway", 1)
             eng.setTuning("fuse_merge", 0)
             for q, (f_ids, f_scores) in zip(queries, fused):
                 s_ids, s_scores = eng.searchArrays(q, k)
@@ -1941,8 +1963,9 @@ def test_query_in_kernel_arguments_equals_uploaded_query(wax):
         eng = make_engine(wax, metric, dims, corpus, np.arange(n, dtype=np.uint64) + 9)
         queries = oracle.gaussian_unit_queries(12, dims, seed=n)
         queries[3] = corpus[10]
-        small = eng.getTuning("scan_grid") <= 160
+        grid = eng.getTuning("scan_grid")
         for k in (1, 10, 64, 65, 192, 500):
+            small = _merges_in_kernel(grid, k, n, dims)                 # mode 1: where the scan is the query's only packet
             eng.setTuning("query_args", 0)
             ref = [eng.searchArrays(q, k) for q in queries]
             for mode in (1, 2):
@@ -2036,11 +2059,11 @@ def test_completion_word_equals_event_completion(wax):
     hits and collect polls that word instead of an event recorded behind the kernel. Same hits as with events ("done_flag" = 0),
     pipelined tickets collected in any order, slots reused thousands of times (the word is a per-slot sequence number), mixed
     with scans that cannot use it (two-launch merge, general selection, timed kernels)."""
-    for metric, dims, n in [(0, 384, 10_000), (1, 768, 2_000), (2, 128, 5_000), (0, 100, 3_000)]:
+    for metric, dims, n in [(0, 384, 10_000), (1, 768, 2_000), (2, 128, 5_000), (0, 100, 3_000), (0, 384, 120_000)]:
         corpus = oracle.gaussian_unit_rows(3 + n, n, dims)
         eng = make_engine(wax, metric, dims, corpus, np.arange(n, dtype=np.uint64) + 5)
         queries = oracle.gaussian_unit_queries(16, dims, seed=n)
-        fused = eng.getTuning("scan_grid") <= 160
+        grid = eng.getTuning("scan_grid")
         eng.setTuning("done_flag", 0)
         ref = {k: [eng.searchArrays(q, k) for q in queries] for k in (1, 10, 100, 500)}
         eng.setTuning("done_flag", 1)
@@ -2055,7 +2078,7 @@ def test_completion_word_equals_event_completion(wax):
             for i in range(16):
                 assert np.array_equal(got[i][0], ref[k][i][0]) and np.array_equal(got[i][1], ref[k][i][1]), (metric, dims, n, k, i)
         used = eng.getTuning("done_flag_waits") - w0
-        assert used == (3 * 16 if fused else 0), (metric, dims, n, used)   # k <= 192 on a small grid; k = 500 is the general selection
+        assert used == 16 * sum(_merges_in_kernel(grid, k, n, dims) for k in (1, 10, 100)), (metric, dims, n, used)   # k = 500 is the general selection
         for _ in range(2000):                                           # the per-slot sequence numbers keep counting
             eng.searchArrays(queries[0], 10)
         a = eng.searchArrays(queries[1], 10)

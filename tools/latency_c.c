@@ -54,10 +54,12 @@ int main(int argc, char** argv) {
         float out_scores[64];
         uint32_t got = 0;
         /* modes 0..2 = "query_args" 0 / 1 / 2 on the automatic grid; 3 = query_args 1 with at most 80 scan workgroups (fewer, fatter
-         * workgroups: fewer partial lists for the fused final merge, more rows per wave); 4 = query_args 1, "done_flag" 0 */
-        for (int mode = 0; mode <= 4; ++mode) {
+         * workgroups: fewer partial lists for the fused final merge, more rows per wave); 4 = query_args 1, "done_flag" 0;
+         * 5 = query_args 1, "merge_kway" 0 (the last workgroup streams the partial lists through its wave lists instead of merging their heads) */
+        for (int mode = 0; mode <= 5; ++mode) {
             wax_hip_set_tuning(e, "query_args", mode <= 2 ? mode : 1);
             wax_hip_set_tuning(e, "grid_blocks", mode == 3 ? 80 : 0);
+            wax_hip_set_tuning(e, "merge_kway", mode == 5 ? 0 : 1);
             wax_hip_set_tuning(e, "done_flag", mode == 4 ? 0 : 1);   /* mode 4: query_args 1 with an event behind the kernel instead of the completion word */
             for (int i = 0; i < 50; ++i) wax_hip_search(e, q, (uint32_t)dims, topk, out_ids, out_scores, 64, &got);
             if (mode == 0) for (uint32_t i = 0; i < got; ++i) first[i] = out_ids[i];

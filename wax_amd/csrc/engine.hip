@@ -402,6 +402,7 @@ struct wax_hip_engine {
     std::atomic<int64_t> time_kernels{0};
     std::atomic<int64_t> force_general{0};
     std::atomic<int64_t> stream_nt{1};
+    std::atomic<int64_t> merge_kway{1};      // fused final merge, k <= 32: 1 (default) = k-way merge of the per-workgroup lists' heads; 0 = stream them through the wave lists
     std::atomic<int64_t> done_flag{1};       // single-query scans that merge in the kernel publish a completion word in pinned memory; collect polls it instead of an event (0 = always an event)
     std::atomic<uint64_t> st_flag_waits{0};
     std::atomic<int64_t> query_args{1};      // single-query scans: 1 (default) = stores whose scan grid is small enough for the fused merge (the launch-latency-bound ones) get the query in the kernel arguments (no upload copy); 2 = every store; 0 = always upload
@@ -432,6 +433,7 @@ struct wax_hip_engine {
     std::atomic<int64_t> batch_eps_measured{1};       // cosine certificate bound from the MEASURED bf16 rounding errors (per query, max over rows) instead of the worst case
     std::atomic<int> retry_hint{0};                   // > 0: batches carry the device-side retry kernel behind their finish kernel
     std::atomic<uint64_t> st_batch_inline_retries{0};  // ... of which inside the finish kernel (no host round trip)
+    std::atomic<uint64_t> st_merged_scans{0};        // single-query scans whose last-arriving workgroup did the final merge (one launch per query)
     std::atomic<uint64_t> st_query_args{0};          // single-query scans that took their query through the kernel arguments
     // wax_hip_search_batch_submit_device tickets (guarded by bticket_mu)
     struct BatchTicket {
@@ -749,7 +751,10 @@ bool scan_uses_query_args(wax_hip_engine* e, int k_eff, bool has_general_slot) {
     const int variant = (int)e->variant.load();
     if (variant > 0) return false;
     if (mode >= 2) return true;
-    return scan_grid_for((uint32_t)e->count, e->dims, 0, (int)e->grid_blocks.load()) <= SCAN_FUSE_MERGE_GRID;
+    const int grid = scan_grid_for((uint32_t)e->count, e->dims, 0, (int)e->grid_blocks.load());
+    if (grid <= SCAN_FUSE_MERGE_GRID) return true;
+    // larger stores: where the scan is the query's only packet (it merges in its own kernel: k <= SCAN_KWAY_MAX_K, <= 2 GiB of rows)
+    return e->fuse_merge.load() != 0 && scan_merges_in_kernel(grid, k_eff, e->merge_kway.load() != 0, (uint32_t)e->count, e->dims);
 }
 
 // d_query == nullptr: the query is `h_query` (host memory, read during this call) and travels in the kernel arguments.
@@ -763,6 +768,7 @@ int enqueue_scan(wax_hip_engine* e, const float* d_query, float q_norm, int k_ef
     a.query_host = d_query == nullptr ? h_query : nullptr;
     a.done_flag = done_flag;
     a.done_value = done_value;
+    a.no_kway = e->merge_kway.load() != 0 ? 0 : 1;
     if (out_flagged) *out_flagged = false;
     a.partials = d_partials;
     a.dist_out = nullptr;
@@ -819,6 +825,7 @@ int enqueue_scan(wax_hip_engine* e, const float* d_query, float q_norm, int k_ef
             e->scan_done_valid = true;
             chain_guard.unlock();
         }
+        if (merged) e->st_merged_scans++;
         if (out_flagged) *out_flagged = merged && done_flag != nullptr;   // the kernel itself publishes the completion word
         if (!merged)
             HIP_TRY(launch_merge_keys(d_partials, (uint32_t)grid * (uint32_t)k_eff, k_eff, kpad, e->d_ids, a.row_base,
@@ -2821,6 +2828,7 @@ int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value) {
     else if (k == "stream_nt") e->stream_nt = value;
     else if (k == "fuse_merge") e->fuse_merge = value != 0;
     else if (k == "done_flag") e->done_flag = value != 0;
+    else if (k == "merge_kway") e->merge_kway = value != 0;
     else if (k == "query_args") { if (value < 0 || value > 2) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "query_args must be 0, 1 or 2"); e->query_args = value; }
     else if (k == "batch_min") e->batch_min = value;
     else if (k == "batch_mode") e->batch_mode = value;
@@ -2879,8 +2887,10 @@ int64_t wax_hip_get_tuning(wax_hip_engine* e, const char* key) {
     if (k == "fuse_merge") return e->fuse_merge.load();
     if (k == "query_args") return e->query_args.load();
     if (k == "done_flag") return e->done_flag.load();
+    if (k == "merge_kway") return e->merge_kway.load();
     if (k == "done_flag_waits") return (int64_t)e->st_flag_waits.load();
     if (k == "query_args_scans") return (int64_t)e->st_query_args.load();
+    if (k == "merged_scans") return (int64_t)e->st_merged_scans.load();
     if (k == "batch_inline_retries") return (int64_t)e->st_batch_inline_retries.load();
     if (k == "retry_hint") return e->retry_hint.load();
     if (k == "batch_eps_measured") return e->batch_eps_measured.load();

@@ -50,6 +50,7 @@ struct ScanArgs {
     // before the kernel has even retired). launch_scan clears it when the launch does not merge in the kernel.
     uint64_t* done_flag;
     uint64_t done_value;
+    int32_t no_kway;         // fused final merge: != 0 = always the wave-list merge (A/B; default 0 = the k-way merge of the list heads for k <= 32)
 };
 // kernarg block of scan_kernel_qarg: the scan arguments followed by the query itself (16-byte aligned for float4 loads)
 template <int DIMS>
@@ -60,7 +61,21 @@ struct alignas(16) ScanArgsQ {
 static_assert(sizeof(ScanArgsQ<768>) <= 4096, "HIP kernel arguments are limited to 4 KB");
 // whether launch_scan can take the query through the kernel arguments for this shape (scan_kernel_qarg instantiations)
 inline bool scan_query_args_dims(uint32_t dims) { return dims == 384 || dims == 768; }
-constexpr int SCAN_FUSE_MERGE_GRID = 160;   // largest grid whose last-arriving workgroup does the final merge
+constexpr int SCAN_FUSE_MERGE_GRID = 160;   // largest grid whose last-arriving workgroup does the final merge (any k <= FUSED_MAX_K)
+// k <= SCAN_KWAY_MAX_K: the last arriver merges the lists' HEADS (k rounds of a workgroup-wide minimum; cost independent of the number
+// of lists), so every grid the engine launches by default (<= 512 workgroups = two lists per thread) can merge in the scan kernel:
+// one launch per query. Measured (profiles/r04/m_*): a blocking call gets 12 - 14 us shorter at every store size (20K rows 38 -> 25 us,
+// 100K 55 -> 43, 1M 250 -> 237), while a PIPELINED stream of queries on a large store loses the overlap of the small merge kernel
+// with the next scan (the last arriver's tail, ~7 us at 505 workgroups, is serial): 10M x 384 2.162 -> 2.166 ms per query. So the
+// larger grids merge in the kernel only up to SCAN_KWAY_MAX_BYTES of rows (a scan of <= ~0.3 ms, where 12 us is >= 4 %).
+constexpr int SCAN_KWAY_MAX_K = 32;
+constexpr int SCAN_KWAY_MERGE_GRID = 512;
+constexpr uint64_t SCAN_KWAY_MAX_BYTES = 2ull << 30;
+// will a scan of `grid` workgroups over n_rows x dims floats for top-`k` merge in its own last-arriving workgroup? (kway = "merge_kway")
+inline bool scan_merges_in_kernel(int grid, int k, bool kway, uint32_t n_rows, uint32_t dims) {
+    return grid <= SCAN_FUSE_MERGE_GRID || (kway && k <= SCAN_KWAY_MAX_K && grid <= SCAN_KWAY_MERGE_GRID &&
+                                            (uint64_t)n_rows * dims * sizeof(float) <= SCAN_KWAY_MAX_BYTES);
+}
 
 struct ScanVariantInfo {
     int unroll;          // row groups in flight per wave iteration

@@ -86,6 +86,85 @@ __device__ inline float hsum(const f32x4& a) { return (a.x + a.y) + (a.z + a.w);
 // waits for before the workgroup barrier in front of the ticket), the ticket itself is an agent-scope RMW, and the last arriver reads
 // the lists with agent-scope atomic loads that cannot be served from a stale line. Every access that takes part in the hand-over is
 // an atomic of agent scope; only the fence instructions a release / acquire pair would add around them are left out.
+// ---- last arriver, small k: a k-way merge of the per-workgroup lists instead of streaming them through the wave lists -----------
+// The lists are sorted, so the global best key is the smallest of the lists' HEADS. Thread t owns lists t, t + 256, ... (LISTS of
+// them: 1 for the small grids, 2 up to SCAN_KWAY_MERGE_GRID) and keeps the next four keys of each in registers; k rounds of
+// {workgroup-wide minimum of the heads by DPP + one LDS exchange, the owner of the minimum emits it and advances that list} produce
+// the k best in order. A round is a few hundred cycles and one barrier whatever the number of lists; the wave-list path (157 lists,
+// k = 10: eight 64-key pushes with two rank-sort prunes per wave, a final prune, a rank merge) took ~10 of the ~20 us a 10K-row
+// query spends in this kernel, and grows with the grid. Keys are unique (distinct rows) except KEY_PAD, which nobody "wins".
+template <int CTRL>
+__device__ inline int64_t dpp_min_i64(int64_t v) {
+    const int lo = __builtin_amdgcn_update_dpp((int)(uint32_t)v, (int)(uint32_t)v, CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(v >> 32), (int)(v >> 32), CTRL, 0xF, 0xF, false);
+    const int64_t o = (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+    return o < v ? o : v;
+}
+__device__ inline int64_t readlane_i64(int64_t v, int l) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), l);
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+template <int LISTS>
+__device__ __attribute__((noinline)) void kway_merge(const int64_t* partials, int nlists, int k, int64_t* fin, int64_t* xch) {
+    const int t = (int)threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    int64_t h[LISTS][4];
+    int taken[LISTS];
+#pragma unroll
+    for (int j = 0; j < LISTS; ++j) {
+        const int64_t* lst = partials + (size_t)(t + j * SCAN_THREADS) * k;
+        taken[j] = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            h[j][i] = (t + j * SCAN_THREADS < nlists && i < k) ? __hip_atomic_load(lst + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : KEY_PAD;
+    }
+    for (int r = 0; r < k; ++r) {
+        int64_t head[LISTS];
+#pragma unroll
+        for (int j = 0; j < LISTS; ++j) {
+            const int sel = taken[j] & 3;
+            head[j] = sel == 0 ? h[j][0] : sel == 1 ? h[j][1] : sel == 2 ? h[j][2] : h[j][3];
+        }
+        int64_t mine = head[0];
+#pragma unroll
+        for (int j = 1; j < LISTS; ++j) mine = head[j] < mine ? head[j] : mine;
+        int64_t v = mine;
+        v = dpp_min_i64<0xB1>(v);       // quad_perm [1,0,3,2]
+        v = dpp_min_i64<0x4E>(v);       // quad_perm [2,3,0,1]
+        v = dpp_min_i64<0x141>(v);      // row_half_mirror
+        v = dpp_min_i64<0x140>(v);      // row_mirror: every lane holds its row's (16 lanes) minimum
+        int64_t w = readlane_i64(v, 0);
+        const int64_t w1 = readlane_i64(v, 16), w2 = readlane_i64(v, 32), w3 = readlane_i64(v, 48);
+        w = w1 < w ? w1 : w; w = w2 < w ? w2 : w; w = w3 < w ? w3 : w;
+        int64_t* slot = xch + (r & 1) * SCAN_WAVES;            // two sets of slots: one barrier per round
+        if (lane == 0) slot[wave] = w;
+        __syncthreads();
+        int64_t best = slot[0];
+#pragma unroll
+        for (int i = 1; i < SCAN_WAVES; ++i) best = slot[i] < best ? slot[i] : best;
+        if (best == KEY_PAD) {                                  // every list is exhausted: pad the rest
+            if (t == 0) fin[r] = KEY_PAD;
+            continue;
+        }
+        if (mine == best) {
+            fin[r] = best;
+#pragma unroll
+            for (int j = 0; j < LISTS; ++j) {
+                if (head[j] != best) continue;
+                ++taken[j];
+                if ((taken[j] & 3) == 0) {                       // the next four keys of this list (a run of neighbours in one workgroup's rows)
+                    const int64_t* lst = partials + (size_t)(t + j * SCAN_THREADS) * k + taken[j];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        h[j][i] = (taken[j] + i < k) ? __hip_atomic_load(lst + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : KEY_PAD;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
 template <int CAP>
 __device__ inline void scan_epilogue(const ScanArgs& a, int64_t* lds, int* counts, int64_t* fin) {
     const int k = a.k;
@@ -102,26 +181,33 @@ __device__ inline void scan_epilogue(const ScanArgs& a, int64_t* lds, int* count
     __syncthreads();
     if ((unsigned)counts[0] != gridDim.x - 1u) return;
     __syncthreads();                                     // everyone has read the ticket before counts[] is reused
-    const int lane = lane_id();
-    const int wave = (int)(threadIdx.x >> 6);
-    WaveTopK<CAP> tk;
-    tk.init(lds + wave * CAP, k);
-    const uint32_t total = gridDim.x * (uint32_t)k;
-    for (uint32_t base = 0; base < total; base += SCAN_THREADS * 4) {
-        int64_t keys[4];
+    static_assert(SCAN_KWAY_MERGE_GRID <= 2 * SCAN_THREADS, "two lists per thread");
+    if (k <= SCAN_KWAY_MAX_K && gridDim.x <= (unsigned)SCAN_KWAY_MERGE_GRID && !a.no_kway) {
+        // (the wave lists at the start of `lds` are free: 8 exchange slots)
+        if (gridDim.x <= (unsigned)SCAN_THREADS) kway_merge<1>(a.partials, (int)gridDim.x, k, fin, lds);
+        else kway_merge<2>(a.partials, (int)gridDim.x, k, fin, lds);
+    } else {
+        const int lane = lane_id();
+        const int wave = (int)(threadIdx.x >> 6);
+        WaveTopK<CAP> tk;
+        tk.init(lds + wave * CAP, k);
+        const uint32_t total = gridDim.x * (uint32_t)k;
+        for (uint32_t base = 0; base < total; base += SCAN_THREADS * 4) {
+            int64_t keys[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const uint32_t i = base + r * SCAN_THREADS + threadIdx.x;
-            keys[r] = (i < total) ? __hip_atomic_load(a.partials + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : KEY_PAD;
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t i = base + r * SCAN_THREADS + threadIdx.x;
+                keys[r] = (i < total) ? __hip_atomic_load(a.partials + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : KEY_PAD;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tk.push_wide(keys[r], keys[r] != KEY_PAD);
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) tk.push_wide(keys[r], keys[r] != KEY_PAD);
+        tk.finalize();
+        if (lane == 0) counts[wave] = tk.cnt;
+        __syncthreads();
+        block_rank_merge<SCAN_WAVES>(lds, CAP, counts, k, fin);
+        __syncthreads();
     }
-    tk.finalize();
-    if (lane == 0) counts[wave] = tk.cnt;
-    __syncthreads();
-    block_rank_merge<SCAN_WAVES>(lds, CAP, counts, k, fin);
-    __syncthreads();
     for (int t = (int)threadIdx.x; t < a.kpad; t += SCAN_THREADS) {
         wax_hip_hit h;
         h.key = (t < k) ? fin[t] : KEY_PAD;
@@ -440,7 +526,8 @@ hipError_t launch_scan(const ScanArgs& args, int metric, int variant, int cap, b
     const int grid = scan_grid_for(args.n_rows, args.dims, variant, grid_cap);
     if (out_grid) *out_grid = grid;
     ScanArgs a = args;
-    const bool fuse = !write_dist && a.merge_out != nullptr && a.arrive != nullptr && grid <= SCAN_FUSE_MERGE_GRID && a.kpad >= a.k;
+    const bool fuse = !write_dist && a.merge_out != nullptr && a.arrive != nullptr && scan_merges_in_kernel(grid, a.k, a.no_kway == 0, a.n_rows, a.dims) && a.kpad >= a.k;
+    const bool small = grid <= SCAN_FUSE_MERGE_GRID;   // a store that lives in the L2s (see below)
     if (!fuse) { a.merge_out = nullptr; a.arrive = nullptr; a.done_flag = nullptr; }
     if (out_merged) *out_merged = fuse;
     // query in the kernel arguments: the BASELINE dimensions, default variant, fused path (the caller decides when — launch_scan
@@ -449,8 +536,8 @@ hipError_t launch_scan(const ScanArgs& args, int metric, int variant, int cap, b
     // rows every query: block -> XCD and block -> rows are both fixed), so its rows are read with ordinary loads — the streaming
     // (non-temporal) loads of the large-store kernels would send every query back to HBM for them.
     if (a.query_host != nullptr && !write_dist && variant == 0) {
-        if (a.dims == 384) return fuse ? launch_qarg<96, 32, 4, false>(a, metric, cap, grid, st) : launch_qarg<96, 32, 4, true>(a, metric, cap, grid, st);
-        if (a.dims == 768) return fuse ? launch_qarg<192, 64, 2, false>(a, metric, cap, grid, st) : launch_qarg<192, 64, 2, true>(a, metric, cap, grid, st);
+        if (a.dims == 384) return (fuse && small) ? launch_qarg<96, 32, 4, false>(a, metric, cap, grid, st) : launch_qarg<96, 32, 4, true>(a, metric, cap, grid, st);
+        if (a.dims == 768) return (fuse && small) ? launch_qarg<192, 64, 2, false>(a, metric, cap, grid, st) : launch_qarg<192, 64, 2, true>(a, metric, cap, grid, st);
     }
     if (a.query == nullptr) return hipErrorInvalidValue;
     switch (a.dims) {
