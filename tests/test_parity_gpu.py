@@ -2025,15 +2025,18 @@ def test_device_side_full_retry_equals_host_retry_and_exact_path(wax):
     queries = q.cpu().numpy()
     for k in (10, 100):
         ref = None
-        for mode, hint in ((1, 0), (1, None), (2, 0), (0, 0), (1, 16)):
+        # (the last entry re-scores EVERY survivor on the device, "batch_debug" bit 16, instead of only those the first finish's
+        # exact k-th cannot exclude: same answers, same certificates)
+        for mode, hint, dbg in ((1, 0, 0), (1, None, 0), (2, 0, 0), (0, 0, 0), (1, 16, 0), (1, 16, 65536)):
             eng.setTuning("batch_retry", mode)
+            eng.setTuning("batch_debug", dbg)
             if hint is not None:
                 eng.setTuning("retry_hint", hint)
             h0 = eng.getTuning("retry_hint")
             i0, r0, f0 = eng.getTuning("batch_inline_retries"), eng.getTuning("batch_retries"), eng.getTuning("batch_fallbacks")
             got = eng.searchBatch(queries, k)
             inl, ret, fb = eng.getTuning("batch_inline_retries") - i0, eng.getTuning("batch_retries") - r0, eng.getTuning("batch_fallbacks") - f0
-            print(f"\n[device retry] k {k} batch_retry {mode} hint {h0}: on the device {inl}, retries {ret}, exact-path fallbacks {fb}")
+            print(f"\n[device retry] k {k} batch_retry {mode} hint {h0} debug {dbg}: on the device {inl}, retries {ret}, exact-path fallbacks {fb}")
             if mode != 1 or h0 == 0:
                 assert inl == 0, (k, mode, h0, inl)                   # the kernel is not even launched
             if mode == 0:
@@ -2050,7 +2053,8 @@ def test_device_side_full_retry_equals_host_retry_and_exact_path(wax):
                     s_ids, s_scores = eng.searchArrays(queries[i], k)
                     assert np.array_equal(got[0][i, :len(s_ids)], s_ids) and np.array_equal(got[1][i, :len(s_ids)], s_scores), (k, i)
             else:
-                assert all(np.array_equal(x, y) for x, y in zip(got, ref)), (k, mode, hint)
+                assert all(np.array_equal(x, y) for x, y in zip(got, ref)), (k, mode, hint, dbg)
+        eng.setTuning("batch_debug", 0)
     eng.close()
 
 

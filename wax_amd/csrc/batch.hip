@@ -2824,6 +2824,14 @@ __global__ __launch_bounds__(RETRY_WAVES * 64) void batch_retry_kernel(FinishArg
     for (int j = 0; j < LOADS; ++j) qv[j] = q4[j * GROUP];
     const int64_t* __restrict__ mine = a.cand + (size_t)q * a.cand_cap;
     const uint32_t nseg = a.count_stride != 0u ? 1u : a.nseg;
+    // Which survivors can still matter: the first finish left its exact k-th distance in the hit row (m >= k here: cert_dev would be 2
+    // otherwise). A survivor whose APPROXIMATE distance is beyond it by more than eps has an exact distance beyond it too (the
+    // certificate's own inequality, `approx - eps > kth`, and in the same float form), and the final k-th can only be smaller — so
+    // only the others are listed and re-scored. At k = 100 on the clustered corpus that is a few hundred rows of 1.5 KB per query
+    // instead of every survivor (~2 600).
+    const int64_t kth_key = a.out[(size_t)q * a.out_stride + (size_t)(k - 1)].key;
+    const bool prune = kth_key != KEY_PAD && a.retry_all == 0u;
+    const float kth0 = key_distance(kth_key), eps_q = a.eps[q];
     constexpr int U = LOADS >= 4 ? 2 : 4;                   // row fetches in flight per lane group
     // Passes: (1) the threads list the rows of as many whole segments as fit RETRY_LIST — one thread per segment, so the
     // dependent chain "count -> keys" runs for all segments at once instead of segment after segment; (2) the sixteen waves
@@ -2859,7 +2867,11 @@ __global__ __launch_bounds__(RETRY_WAVES * 64) void batch_retry_kernel(FinishArg
         const bool fits = seg < nseg && end <= (uint32_t)RETRY_LIST;
         if (fits && c > 0u) {
             const int64_t* __restrict__ sp = mine + (size_t)seg * a.seg_slots;
-            for (uint32_t j = 0; j < c; ++j) rows_l[end - c + j] = key_row(sp[j]);
+            for (uint32_t j = 0; j < c; ++j) {
+                const int64_t key = sp[j];
+                if (prune && key_distance(key) - eps_q > kth0) continue;
+                rows_l[atomicAdd(&n_list, 1u)] = key_row(key);   // (order does not matter: the exact keys are unique and selected by value)
+            }
         }
         // the pass takes the longest prefix of segments that fits; a single segment larger than the list cannot be retried here
         const unsigned long long fm = __ballot(fits || seg >= nseg);
@@ -2872,7 +2884,6 @@ __global__ __launch_bounds__(RETRY_WAVES * 64) void batch_retry_kernel(FinishArg
             for (int w = 0; w < RETRY_WAVES; ++w) { taken += (uint32_t)counts[w]; if (counts[w] < 64) break; }
             seg_next = seg0 + taken;
         }
-        if (fits) atomicMax(&n_list, end);
         __syncthreads();
         const uint32_t taken_to = seg_next;
         if (taken_to == seg0) {                             // nothing fits (one huge segment): leave the query to the host rungs

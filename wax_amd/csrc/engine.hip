@@ -1319,6 +1319,7 @@ int batch_enqueue(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32
         f.kp = plan->kp; f.k = k_eff; f.sel = c->d_sel; f.exact = c->d_exact; f.out = d_out; f.out_stride = out_stride;
         f.certified = c->h_cert + cert_off;   // pinned host memory, written by the kernel: no copy launch behind the finish kernel
         f.cert_dev = c->d_cert + cert_off;
+        f.retry_all = (e->batch_debug.load() & 65536) != 0 ? 1u : 0u;
         HIP_TRY(launch_batch_finish(f, e->metric, st), WAX_HIP_ERR_INTERNAL, "finish kernel launch");
         // "batch_retry" 1 (default): while recent batches had queries the first finish could not certify (`retry_hint`, set at
         // collect), the device-side full retry rides behind the finish kernel — uncertified queries get ALL their survivors

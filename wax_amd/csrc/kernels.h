@@ -299,6 +299,7 @@ struct FinishArgs {
     // fused finish kernel (kp <= 192): non-null = device-side copy of the flags for batch_retry_kernel: 1 certified, 0 = failed with
     // every survivor still in the segments (retryable), 2 = failed and a retry is pointless (something dropped / nothing beyond k')
     uint32_t* cert_dev;
+    uint32_t retry_all;                                  // batch_retry_kernel: != 0 = re-score EVERY survivor (A/B: "batch_debug" bit 16); 0 = only those the first finish's k-th cannot exclude
 };
 // Device-side full retry behind launch_batch_finish (same arguments, cert_dev written by it): per uncertified query ALL survivors are
 // re-scored exactly and the k best written; a query it certifies gets certified[q] = 2.
