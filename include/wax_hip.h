@@ -352,13 +352,15 @@ int wax_hip_stats(wax_hip_engine* e, wax_hip_stats_t* out);
  * wax_hip_search_collect polls that word instead of an event recorded behind the kernel; 0 = always an event; never while "time_kernels" = 1),
  * "batch_eps_measured" (1 (default) = the certificate bound of the batched path uses the measured bf16 rounding errors — per query, and
  * the maximum over the rows taken when the mirror is built; 0 = the worst case 2^-7 per product),
+ * "batch_kp_fused" (1 (default) = top_k 81 .. 128 on the one-pass pipeline re-scores k' = 192 candidates in the fused finish kernel — the
+ * device-side retry behind it settles what that leaves uncertified; 0 = k' = 2k + 32 through the three-launch finish),
  * "batch_slab_mb", "batch_growth", "batch_first" (slab schedule of the slab pipeline), "batch_rega" (0 LDS-tiled GEMM
  * only; 5 (default) register-resident GEMM, register staging, split tile barrier; D = 768: the wide kernel — whole K per wave, LDS-DMA
  * staging, 256 queries per workgroup — unless 1 / 6 / 7 select the K-split kernel (workgroup barrier / split barrier at every size /
  * split barrier below 4 096 tiles per workgroup); 1 the same with a workgroup barrier per tile; 2 LDS-DMA
  * staging; 3 one wave per SIMD; 4 free-running: no tile barrier, three LDS tiles, D <= 384 — a faster kernel alone, slower pipelined
  * because its 150 KB of LDS keep the neighbouring batch's kernels off the CU: DESIGN.md), "batch_debug" (timing experiments:
- * results are NOT valid with bits 1/2/4/8/64/8192 set; bit 12 (4096) switches the wide 768-d kernel's pace gate off, bits 8-9 select its
+ * results are NOT valid with bits 1/2/4/8/64/8192 set; bit 16 (65536) makes the device-side retry re-score every survivor instead of only those the first finish cannot exclude (valid); bit 12 (4096) switches the wide 768-d kernel's pace gate off, bits 8-9 select its
  * build variants: all valid). get-only: "variant_count", "scan_grid", "fused_max_k", "batch_queries", "query_args_scans", "merged_scans" (single-query scans that
  * merged in their own kernel), "done_flag_waits",
  * "batch_inline_retries" (queries certified by the device-side retry kernel), "batch_max_row_err_e9",

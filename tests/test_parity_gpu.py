@@ -2055,6 +2055,12 @@ def test_device_side_full_retry_equals_host_retry_and_exact_path(wax):
             else:
                 assert all(np.array_equal(x, y) for x, y in zip(got, ref)), (k, mode, hint, dbg)
         eng.setTuning("batch_debug", 0)
+        # k = 100: k' is capped at 192 (fused finish kernel) because the device retry stands behind it; k' = 2k + 32 = 232 (the
+        # three-launch finish) must give the same answers
+        eng.setTuning("batch_kp_fused", 0)
+        got = eng.searchBatch(queries, k)
+        assert all(np.array_equal(x, y) for x, y in zip(got, ref)), (k, "batch_kp_fused 0")
+        eng.setTuning("batch_kp_fused", 1)
     eng.close()
 
 

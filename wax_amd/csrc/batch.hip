@@ -793,6 +793,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uin
                         off = __hip_atomic_fetch_add(cnt_w + qo, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                     const uint32_t e0 = seg_lane0 + (uint32_t)((r & 3) + 8 * (r >> 2)) * a.cand_cap;
+                    if (a.debug & 8192u) continue;           // debug bit13: count, do not store (timing experiments: what do the stores cost the tile pipeline?)
                     if (p0 && off < seg_slots) a.cand[e0 + off++] = make_key(d0, a.row_base + row0);
                     if (p1 && off < seg_slots) a.cand[e0 + off] = make_key(d1, a.row_base + row1);
                 }

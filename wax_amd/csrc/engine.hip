@@ -423,6 +423,7 @@ struct wax_hip_engine {
     std::atomic<int64_t> batch_onepass{1};        // 0 = always the slab pipeline
     std::atomic<int64_t> batch_onepass_tiles{1024};   // smallest store (in GEMM tiles) the one-pass pipeline takes
     std::atomic<int64_t> batch_survivors{3};      // one-pass pipeline: expected survivors per query = this x k'
+    std::atomic<int64_t> batch_kp_fused{1};       // one-pass pipeline, k in 81 .. 128: 1 = k' capped at 192 (fused finish kernel + device retry); 0 = k' = 2k + 32 (three-launch finish)
     std::atomic<int64_t> batch_retry{1};          // one-pass pipeline: uncertified queries get a full retry (ALL their survivors re-scored) before the exact path
     std::atomic<int64_t> batch_multi{1};          // exact path of a batch: 1 = uncertified queries share passes over the f32 store (multiscan.hip), 0 = one scan each
     std::atomic<uint64_t> st_multi_passes{0}, st_multi_queries{0};
@@ -1175,6 +1176,11 @@ bool plan_onepass(wax_hip_engine* e, uint32_t n, int k_eff, uint32_t nq, Onepass
     if (fast ? ((int64_t)p->ntiles < e->batch_onepass_tiles.load() || p->ntiles < 1024)
              : ((int64_t)n < e->batch_onepass_tiles.load() * 64 || p->ntiles < 512)) return false;   // too small to sample: slab pipeline
     p->kp = batch_kp(k_eff, 960);
+    // k in 81 .. 128: k' = 2k + 32 would need the three-launch finish (select 120-190 us + re-score + finalize at 256 queries on a dense
+    // corpus) where the fused finish kernel takes ~58 us. With the device-side retry behind it — which re-scores exactly the survivors the
+    // first finish's k-th cannot exclude, whatever k' was — k' = 192 (>= 64 candidates beyond k) loses nothing but a few more retried queries.
+    if (e->batch_kp_fused.load() != 0 && p->kp > FUSED_MAX_K && k_eff <= 128 && e->batch_retry.load() == 1 && batch_retry_dims(e->dims))
+        p->kp = FUSED_MAX_K;
     const uint32_t nq_blk = nq < kBatchMaxQ ? nq : kBatchMaxQ;
     const uint32_t nq_pad = (nq_blk + 255u) & ~255u;
     const uint32_t rega_mode = e->batch_rega.load() == 0 ? 5u : (uint32_t)e->batch_rega.load();   // as batch_enqueue passes it
@@ -2837,6 +2843,7 @@ int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value) {
     else if (k == "batch_debug") e->batch_debug = value;
     else if (k == "batch_onepass") e->batch_onepass = value;
     else if (k == "batch_onepass_tiles") { if (value < 1024) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_onepass_tiles must be >= 1024"); e->batch_onepass_tiles = value; }
+    else if (k == "batch_kp_fused") e->batch_kp_fused = value != 0;
     else if (k == "batch_survivors") { if (value < 2 || value > 64) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_survivors must be 2..64"); e->batch_survivors = value; }
     else if (k == "batch_dynamic") e->batch_dynamic = value != 0;
     else if (k == "batch_eps_measured") e->batch_eps_measured = value != 0;
@@ -2904,6 +2911,7 @@ int64_t wax_hip_get_tuning(wax_hip_engine* e, const char* key) {
     if (k == "batch_first") return e->batch_first.load();
     if (k == "batch_onepass") return e->batch_onepass.load();
     if (k == "batch_onepass_tiles") return e->batch_onepass_tiles.load();
+    if (k == "batch_kp_fused") return e->batch_kp_fused.load();
     if (k == "batch_survivors") return e->batch_survivors.load();
     if (k == "batch_sample_div") return e->batch_sample_div.load();
     if (k == "batch_workspaces") return e->bctx_max;
