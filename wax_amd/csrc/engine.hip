@@ -402,6 +402,7 @@ struct wax_hip_engine {
     std::atomic<int64_t> time_kernels{0};
     std::atomic<int64_t> force_general{0};
     std::atomic<int64_t> stream_nt{1};
+    std::atomic<int64_t> scan_plain_mb{-1};  // single-query scans with the query in their arguments: stores up to this many MB read their rows with ordinary loads (-1 = grids <= 160 workgroups)
     std::atomic<int64_t> merge_kway{1};      // fused final merge, k <= 32: 1 (default) = k-way merge of the per-workgroup lists' heads; 0 = stream them through the wave lists
     std::atomic<int64_t> done_flag{1};       // single-query scans that merge in the kernel publish a completion word in pinned memory; collect polls it instead of an event (0 = always an event)
     std::atomic<uint64_t> st_flag_waits{0};
@@ -770,6 +771,13 @@ int enqueue_scan(wax_hip_engine* e, const float* d_query, float q_norm, int k_ef
     a.done_flag = done_flag;
     a.done_value = done_value;
     a.no_kway = e->merge_kway.load() != 0 ? 0 : 1;
+    {
+        // ordinary (cacheable) instead of non-temporal row loads: "scan_plain_mb" -1 (default) = stores whose grid fits the wave-list
+        // fused merge (<= 160 workgroups, ~30 MB: they live in the L2s); N >= 0 = stores of at most N MB
+        const int64_t mb = e->scan_plain_mb.load();
+        a.plain_loads = mb < 0 ? (scan_grid_for((uint32_t)e->count, e->dims, 0, (int)e->grid_blocks.load()) <= SCAN_FUSE_MERGE_GRID)
+                               : ((uint64_t)e->count * e->dims * sizeof(float) <= (uint64_t)mb << 20);
+    }
     if (out_flagged) *out_flagged = false;
     a.partials = d_partials;
     a.dist_out = nullptr;
@@ -2836,6 +2844,7 @@ int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value) {
     else if (k == "fuse_merge") e->fuse_merge = value != 0;
     else if (k == "done_flag") e->done_flag = value != 0;
     else if (k == "merge_kway") e->merge_kway = value != 0;
+    else if (k == "scan_plain_mb") e->scan_plain_mb = value;
     else if (k == "query_args") { if (value < 0 || value > 2) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "query_args must be 0, 1 or 2"); e->query_args = value; }
     else if (k == "batch_min") e->batch_min = value;
     else if (k == "batch_mode") e->batch_mode = value;
@@ -2896,6 +2905,7 @@ int64_t wax_hip_get_tuning(wax_hip_engine* e, const char* key) {
     if (k == "query_args") return e->query_args.load();
     if (k == "done_flag") return e->done_flag.load();
     if (k == "merge_kway") return e->merge_kway.load();
+    if (k == "scan_plain_mb") return e->scan_plain_mb.load();
     if (k == "done_flag_waits") return (int64_t)e->st_flag_waits.load();
     if (k == "query_args_scans") return (int64_t)e->st_query_args.load();
     if (k == "merged_scans") return (int64_t)e->st_merged_scans.load();

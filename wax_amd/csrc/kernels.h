@@ -50,6 +50,7 @@ struct ScanArgs {
     // before the kernel has even retired). launch_scan clears it when the launch does not merge in the kernel.
     uint64_t* done_flag;
     uint64_t done_value;
+    int32_t plain_loads;     // query-in-arguments kernels: != 0 = ordinary row loads (the store is expected to stay cached between queries), 0 = non-temporal
     int32_t no_kway;         // fused final merge: != 0 = always the wave-list merge (A/B; default 0 = the k-way merge of the list heads for k <= 32)
 };
 // kernarg block of scan_kernel_qarg: the scan arguments followed by the query itself (16-byte aligned for float4 loads)

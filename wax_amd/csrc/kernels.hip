@@ -527,7 +527,7 @@ hipError_t launch_scan(const ScanArgs& args, int metric, int variant, int cap, b
     if (out_grid) *out_grid = grid;
     ScanArgs a = args;
     const bool fuse = !write_dist && a.merge_out != nullptr && a.arrive != nullptr && scan_merges_in_kernel(grid, a.k, a.no_kway == 0, a.n_rows, a.dims) && a.kpad >= a.k;
-    const bool small = grid <= SCAN_FUSE_MERGE_GRID;   // a store that lives in the L2s (see below)
+    const bool small = a.plain_loads != 0;             // a store that lives in the caches between queries (see below; the caller decides)
     if (!fuse) { a.merge_out = nullptr; a.arrive = nullptr; a.done_flag = nullptr; }
     if (out_merged) *out_merged = fuse;
     // query in the kernel arguments: the BASELINE dimensions, default variant, fused path (the caller decides when — launch_scan
