@@ -79,6 +79,7 @@ def parse_args():
                    help="roofline.traffic of the headline kernel: live = a rocprofv3 --pmc FETCH_SIZE child pass inside this run (N = 1); "
                         "replay = the committed pass in profiles/latest_traffic.json; auto = live where rocprofv3 is on PATH, else replay")
     p.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
+    p.add_argument("--traffic-child-batch", default=None, help=argparse.SUPPRESS)   # "nq:corpus:row_base": the batched form of the child
     p.add_argument("--detail-out", default=None, metavar="PATH",
                    help="where the verbose record goes (default bench_detail.json next to bench.py); stdout carries ONE compact line")
     p.add_argument("--host-merge", action="store_true", help="N>1: merge gathered hits on the host instead of the device")
@@ -334,7 +335,26 @@ def traffic_child(torch, dev, rows, dims, k):
     eng.close()
 
 
-def live_traffic(rows, dims, k, timeout_s=300):
+def traffic_child_batch(torch, dev, rows, dims, k, spec):
+    """`--traffic-child --traffic-child-batch nq:corpus:row_base`: the batched workload, a mirror build + one warm batch + three counted ones."""
+    nq, corpus, row_base = spec.split(":")
+    nq = int(nq)
+    eng = _load_engine(torch, dev, rows, dims, corpus)
+    eng.setRowBase(int(row_base))
+    apply_tunes(eng)
+    dq = batch_queries(torch, dev, nq, dims, corpus)
+    out = torch.empty((nq, k, 2), dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    for _ in range(2 + 3):
+        eng.searchBatchHitsDevice(dq.data_ptr(), nq, k, out.data_ptr(), k, stream)
+    torch.cuda.synchronize()
+    eng.close()
+
+
+TRAFFIC_MODE = "replay"      # set by main(): what secondary_batched may do for its roofline.traffic
+
+
+def live_traffic(rows, dims, k, timeout_s=300, batch=None):
     """HBM bytes per launch of the headline scan kernel, measured IN this run: a counters-only child pass
     (`rocprofv3 --pmc FETCH_SIZE --kernel-trace`, no other tracing: MI355X_MICROARCH.md's HBM recipe) over the same corpus
     and kernel, TRAFFIC_CHILD_LAUNCHES launches after TRAFFIC_CHILD_WARM warm-ups. bytes = FETCH_SIZE (KiB) * 1024 * 2 (the guide's
@@ -353,6 +373,8 @@ def live_traffic(rows, dims, k, timeout_s=300):
     tmp = tempfile.mkdtemp(prefix="wax_pmc_", dir="/tmp")
     cmd = [exe, "--pmc", "FETCH_SIZE", "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "t", "--",
            sys.executable, os.path.abspath(__file__), "--traffic-child", "--rows", str(rows), "--dims", str(dims), "--topk", str(k)]
+    if batch is not None:
+        cmd += ["--traffic-child-batch", batch]
     for t in TUNES:
         cmd += ["--tune", t]
     env = dict(os.environ, TMPDIR="/tmp")
@@ -368,13 +390,23 @@ def live_traffic(rows, dims, k, timeout_s=300):
                 os.killpg(proc.pid, signal.SIGKILL)      # exactly the process group started above
                 proc.wait()
                 return None, f"counter pass timed out after {timeout_s} s"
-        vals = []
+        vals, by_name = [], {}
         for path in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
             with open(path) as f:
                 for r in csv.DictReader(f):
-                    if "scan_kernel" in (r.get("Kernel_Name") or "") and r.get("Counter_Name") == "FETCH_SIZE":
+                    name = r.get("Kernel_Name") or ""
+                    if r.get("Counter_Name") != "FETCH_SIZE":
+                        continue
+                    if batch is None and "scan_kernel" in name:
                         vals.append((int(r.get("Dispatch_Id") or 0), float(r["Counter_Value"])))
-        vals = [v for _, v in sorted(vals)][TRAFFIC_CHILD_WARM:]
+                    elif batch is not None and "batch_gemm" in name:
+                        by_name.setdefault(name, []).append((int(r.get("Dispatch_Id") or 0), float(r["Counter_Value"])))
+        warm = TRAFFIC_CHILD_WARM
+        if batch is not None and by_name:
+            # the filtering GEMM is the instantiation that streams the whole mirror (the sampling launch reads a few hundred tiles);
+            # its first two launches (mirror build call, warm batch) are dropped
+            vals = max(by_name.values(), key=lambda v: sum(x for _, x in v) / len(v))
+        vals = [v for _, v in sorted(vals)][warm:]
         if rc != 0 or not vals:
             tail = ""
             try:
@@ -384,7 +416,7 @@ def live_traffic(rows, dims, k, timeout_s=300):
             return None, f"counter pass failed (rc {rc}, {len(vals)} launches seen): {tail}"
         mean_kib = sum(vals) / len(vals)
         return mean_kib * 1024.0 * 2.0, (f"measured in this run: rocprofv3 --pmc FETCH_SIZE --kernel-trace child pass (counters only) over the same "
-                                         f"corpus, {len(vals)} launches after {TRAFFIC_CHILD_WARM} warm-ups, {time.perf_counter() - t0:.0f} s; "
+                                         f"corpus{' and query block' if batch else ''}, {len(vals)} launches after {TRAFFIC_CHILD_WARM} warm-ups, {time.perf_counter() - t0:.0f} s; "
                                          f"bytes = FETCH_SIZE[KiB] * 1024 * 2 (gfx950 correction); min/max over launches "
                                          f"{min(vals) * 2048:.6g} / {max(vals) * 2048:.6g}")
     except Exception as ex:  # noqa: BLE001 - the bench line must not die on its optional leg
@@ -447,10 +479,15 @@ def secondary_single_query(torch, dev, rows, dims, k, steps, warmup, depth, labe
     merged = eng.getTuning("merged_scans")
     eng.close()
     traffic, traffic_source = None, None
+    if TRAFFIC_MODE in ("auto", "live"):
+        traffic, traffic_source = live_traffic(rows, dims, k)      # (a store that lives in the L2s reads far less than its size from HBM)
+        if traffic is None:
+            log(f"[bench] live traffic pass unavailable ({rows}x{dims}): {traffic_source}")
+            traffic_source = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "latest_traffic.json"))).get("single", {})
         ent = tj.get("configs", {}).get(f"{rows}x{dims}")
-        if ent:
+        if ent and traffic is None and TRAFFIC_MODE in ("auto", "replay"):
             traffic = ent["hbm_bytes_per_launch"]
             traffic_source = "replayed from profiles/latest_traffic.json (" + tj.get("source", "") + "), not measured in this run"
     except (OSError, ValueError, KeyError):
@@ -506,7 +543,7 @@ def sharded_single_query(torch, dist, args, rank, world, local_rank, use_rccl, r
     }
 
 
-def batched_roofline(rows, dims, nq, kern_ms, launches, rega=5):
+def batched_roofline(rows, dims, nq, kern_ms, launches, rega=5, live=None):
     flops = 2.0 * nq * rows * dims
     nbytes = rows * dims * 2                  # bf16 mirror, streamed once per launch
     t_hbm, t_mfma = nbytes / (HBM_PEAK_GBPS * 1e9), flops / (MFMA_BF16_PEAK_TFLOPS * 1e12)
@@ -516,10 +553,16 @@ def batched_roofline(rows, dims, nq, kern_ms, launches, rega=5):
     else:
         achieved, peak, unit = flops / (kern_ms * 1e-3) / 1e12, MFMA_BF16_PEAK_TFLOPS, "TFLOP/s"
     traffic, traffic_source = None, None
+    live_note = None
+    if live is not None and TRAFFIC_MODE in ("auto", "live"):
+        traffic, live_note = live_traffic(rows, dims, live["k"], batch=f"{nq}:{live['corpus']}:{live['row_base']}")
+        traffic_source = live_note if traffic is not None else None
+        if traffic is None:
+            log(f"[bench] live traffic pass unavailable ({rows}x{dims}xq{nq}): {live_note}")
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "latest_traffic.json"))).get("batched", {})
         ent = tj.get("configs", {}).get(f"{rows}x{dims}xq{nq}")
-        if ent:
+        if ent and traffic is None and TRAFFIC_MODE in ("auto", "replay"):
             traffic = ent["hbm_bytes_per_launch"]
             traffic_source = "replayed from profiles/latest_traffic.json (" + tj.get("source", "") + "), not measured in this run"
     except (OSError, ValueError, KeyError):
@@ -624,6 +667,7 @@ def secondary_batched(torch, dev, rows, dims, nq, k, steps, warmup, label, row_b
     launches = int(st.batch_gemms_timed)
     kern_ms = st.batch_gemm_ms_total / launches if launches else float("nan")
     flops, floor_s, rf = batched_roofline(rows, dims, nq, kern_ms, launches, int(eng.getTuning("batch_rega")))
+    want_live = True                          # roofline.traffic of the filtering GEMM is measured below (child counter pass)
     res = {
         "config": label,
         "value": nq * steps / el, "unit": "queries/s", "steps": steps, "warmup": warmup, "ms_per_step": el / steps * 1e3,
@@ -640,7 +684,13 @@ def secondary_batched(torch, dev, rows, dims, nq, k, steps, warmup, label, row_b
         "last_result_checksum": _hits_checksum(outs[(steps - 1) % depth]),
         "roofline": rf,
     }
+    rega = int(eng.getTuning("batch_rega"))
     eng.close()
+    if want_live and TRAFFIC_MODE in ("auto", "live"):
+        # HBM bytes per launch of the filtering GEMM, measured now (the engine above is released first): a counters-only child pass
+        del dq, outs
+        torch.cuda.empty_cache()
+        _, _, res["roofline"] = batched_roofline(rows, dims, nq, kern_ms, launches, rega, live={"k": k, "corpus": corpus, "row_base": row_base})
     return res
 
 
@@ -895,8 +945,13 @@ def main():
 
     n, dims, k = args.rows, args.dims, args.topk
     if args.traffic_child:
-        traffic_child(torch, dev, n, dims, k)
+        if args.traffic_child_batch:
+            traffic_child_batch(torch, dev, n, dims, k, args.traffic_child_batch)
+        else:
+            traffic_child(torch, dev, n, dims, k)
         return
+    global TRAFFIC_MODE
+    TRAFFIC_MODE = args.traffic if (world == 1 and not in_library) else ("replay" if args.traffic in ("auto", "replay") else "off")
     lo, hi = sharded.shard_bounds(n, world, rank, align=64)
     t_build = time.perf_counter()
     if in_library:

@@ -865,6 +865,12 @@ def test_bench_contract_and_shard_invariance(wax, tmp_path):
         rr = x["roofline"]
         assert x["value"] > 0 and x["ms_per_step"] > 0 and rr["kernel_launches_timed"] >= min(x["steps"], 60)
         assert rr["bound"] in ("hbm", "mfma") and 0 < rr["frac"] < 1.2 and abs(rr["frac"] - rr["achieved"] / rr["peak"]) < 1e-9
+    # every BASELINE secondary measures its own roofline.traffic the same way (a counters-only child pass over the same workload)
+    for x in sec:
+        rr = x["roofline"]
+        assert str(rr["traffic_source"]).startswith("measured in this run"), (x["name"], rr["traffic_source"])
+        if x["name"] != "s10k":                                     # (a 15 MB store lives in the L2s: far fewer bytes than its size)
+            assert 0.9 < rr["traffic"] / rr["algorithmic_bytes_per_launch"] < 1.5, (x["name"], rr["traffic"], rr["algorithmic_bytes_per_launch"])
     assert sec[0]["roofline"]["launches_per_query"] == 1            # 10K rows: the scan kernel's last workgroup merges
     assert sec[1]["roofline"]["launches_per_query"] == 1            # ... and so does the 1M-row store's (top-10: the k-way merge of the list heads)
     assert all(x["pipeline"] == "one-pass" and x["batches_in_flight"] == 2 and x["ms_per_step_blocking_call"] > 0 for x in sec[2:])

@@ -773,7 +773,8 @@ int enqueue_scan(wax_hip_engine* e, const float* d_query, float q_norm, int k_ef
     a.no_kway = e->merge_kway.load() != 0 ? 0 : 1;
     {
         // ordinary (cacheable) instead of non-temporal row loads: "scan_plain_mb" -1 (default) = stores whose grid fits the wave-list
-        // fused merge (<= 160 workgroups, ~30 MB: they live in the L2s); N >= 0 = stores of at most N MB
+        // fused merge (<= 160 workgroups, ~30 MB); N >= 0 = stores of at most N MB. (Measured: no difference up to 230 MB, slower beyond —
+        // FETCH_SIZE shows even a 15 MB store is fetched whole on every query: the per-XCD L2s do not keep it across kernel boundaries.)
         const int64_t mb = e->scan_plain_mb.load();
         a.plain_loads = mb < 0 ? (scan_grid_for((uint32_t)e->count, e->dims, 0, (int)e->grid_blocks.load()) <= SCAN_FUSE_MERGE_GRID)
                                : ((uint64_t)e->count * e->dims * sizeof(float) <= (uint64_t)mb << 20);

@@ -532,9 +532,9 @@ hipError_t launch_scan(const ScanArgs& args, int metric, int variant, int cap, b
     if (out_merged) *out_merged = fuse;
     // query in the kernel arguments: the BASELINE dimensions, default variant, fused path (the caller decides when — launch_scan
     // only refuses what it has no kernel for, by falling through to the pointer form, which needs args.query)
-    // A grid small enough for the fused merge is a store of at most a few tens of MB: it fits the L2s (each XCD sees the same
-    // rows every query: block -> XCD and block -> rows are both fixed), so its rows are read with ordinary loads — the streaming
-    // (non-temporal) loads of the large-store kernels would send every query back to HBM for them.
+    // Small stores (a.plain_loads: the caller's rule) read their rows with ordinary loads instead of the streaming (non-temporal)
+    // loads of the large-store kernels. Measured equal on this part (the L2s do not keep a store across kernel boundaries:
+    // profiles/HISTORY.md), never slower for stores of up to 230 MB.
     if (a.query_host != nullptr && !write_dist && variant == 0) {
         if (a.dims == 384) return (fuse && small) ? launch_qarg<96, 32, 4, false>(a, metric, cap, grid, st) : launch_qarg<96, 32, 4, true>(a, metric, cap, grid, st);
         if (a.dims == 768) return (fuse && small) ? launch_qarg<192, 64, 2, false>(a, metric, cap, grid, st) : launch_qarg<192, 64, 2, true>(a, metric, cap, grid, st);
