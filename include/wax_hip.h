@@ -346,8 +346,8 @@ int wax_hip_stats(wax_hip_engine* e, wax_hip_stats_t* out);
  * "merge_kway" (1 (default) = top_k <= 32: the scan kernel's last-arriving workgroup merges the per-workgroup lists by their heads — k
  * rounds of a workgroup-wide minimum, whatever the number of lists — which lets every default grid (<= 512 workgroups) of a store of up to
  * 2 GiB of rows finish in ONE launch; 0 = small grids (<= 160 workgroups) stream the lists through the wave lists, larger ones use the merge kernel),
- * "scan_plain_mb" (query-in-arguments scans: stores of at most this many MB read their rows with ordinary instead of non-temporal loads; -1
- * (default) = grids of at most 160 workgroups; measured equal to non-temporal loads up to 230 MB of rows and slower beyond — the L2s do not keep a store across kernels),
+ * "scan_plain_mb" (query-in-arguments scans: stores of at most this many MB read their rows with ordinary instead of non-temporal loads;
+ * default 32: 0.7 - 0.9 us per query faster up to ~30 MB, equal from 60 to 230 MB, slower beyond; -1 = grids of at most 160 workgroups),
  * "query_args" (single-query scans, dims 384 / 768: 1 (default) = a store whose scan merges in its own kernel — the launch-latency-bound
  * ones — gets the query in the kernel arguments instead of an upload copy in front of the scan; 2 = every store; 0 = never),
  * "done_flag" (1 (default) = a scan that merges in the kernel publishes a completion word in pinned memory behind its hits and

@@ -57,8 +57,9 @@ int main(int argc, char** argv) {
          * workgroups: fewer partial lists for the fused final merge, more rows per wave); 4 = query_args 1, "done_flag" 0;
          * 5 = query_args 1, "merge_kway" 0 (the last workgroup streams the partial lists through its wave lists instead of merging their heads) */
         /* 6 = query_args 1 with ordinary (cacheable) row loads whatever the store size ("scan_plain_mb" = 1 << 20) */
-        for (int mode = 0; mode <= 6; ++mode) {
-            wax_hip_set_tuning(e, "scan_plain_mb", mode == 6 ? (1 << 20) : -1);
+        /* 7 = query_args 1 with non-temporal row loads whatever the store size ("scan_plain_mb" = 0) */
+        for (int mode = 0; mode <= 7; ++mode) {
+            wax_hip_set_tuning(e, "scan_plain_mb", mode == 6 ? (1 << 20) : mode == 7 ? 0 : -1);
             wax_hip_set_tuning(e, "query_args", mode <= 2 ? mode : 1);
             wax_hip_set_tuning(e, "grid_blocks", mode == 3 ? 80 : 0);
             wax_hip_set_tuning(e, "merge_kway", mode == 5 ? 0 : 1);

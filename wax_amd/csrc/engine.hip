@@ -402,7 +402,7 @@ struct wax_hip_engine {
     std::atomic<int64_t> time_kernels{0};
     std::atomic<int64_t> force_general{0};
     std::atomic<int64_t> stream_nt{1};
-    std::atomic<int64_t> scan_plain_mb{-1};  // single-query scans with the query in their arguments: stores up to this many MB read their rows with ordinary loads (-1 = grids <= 160 workgroups)
+    std::atomic<int64_t> scan_plain_mb{32};  // single-query scans with the query in their arguments: stores up to this many MB read their rows with ordinary loads (-1 = grids <= 160 workgroups)
     std::atomic<int64_t> merge_kway{1};      // fused final merge, k <= 32: 1 (default) = k-way merge of the per-workgroup lists' heads; 0 = stream them through the wave lists
     std::atomic<int64_t> done_flag{1};       // single-query scans that merge in the kernel publish a completion word in pinned memory; collect polls it instead of an event (0 = always an event)
     std::atomic<uint64_t> st_flag_waits{0};
@@ -772,9 +772,10 @@ int enqueue_scan(wax_hip_engine* e, const float* d_query, float q_norm, int k_ef
     a.done_value = done_value;
     a.no_kway = e->merge_kway.load() != 0 ? 0 : 1;
     {
-        // ordinary (cacheable) instead of non-temporal row loads: "scan_plain_mb" -1 (default) = stores whose grid fits the wave-list
-        // fused merge (<= 160 workgroups, ~30 MB); N >= 0 = stores of at most N MB. (Measured: no difference up to 230 MB, slower beyond —
-        // FETCH_SIZE shows even a 15 MB store is fetched whole on every query: the per-XCD L2s do not keep it across kernel boundaries.)
+        // ordinary (cacheable) instead of non-temporal row loads: "scan_plain_mb" = stores of at most N MB (default 32); -1 = stores whose
+        // grid fits the wave-list fused merge (<= 160 workgroups). Measured on one box (profiles/r04/n_latency_small_stores_*): ordinary loads
+        // are 0.7-0.9 us per query faster at 5K / 10K / 20K rows x 384 (7.7 / 15 / 31 MB), equal from 60 to 230 MB, 10 % slower beyond.
+        // (FETCH_SIZE still shows the whole store crossing the L2 -> fabric boundary on every query: the gain is on the memory side.)
         const int64_t mb = e->scan_plain_mb.load();
         a.plain_loads = mb < 0 ? (scan_grid_for((uint32_t)e->count, e->dims, 0, (int)e->grid_blocks.load()) <= SCAN_FUSE_MERGE_GRID)
                                : ((uint64_t)e->count * e->dims * sizeof(float) <= (uint64_t)mb << 20);

@@ -533,8 +533,8 @@ hipError_t launch_scan(const ScanArgs& args, int metric, int variant, int cap, b
     // query in the kernel arguments: the BASELINE dimensions, default variant, fused path (the caller decides when — launch_scan
     // only refuses what it has no kernel for, by falling through to the pointer form, which needs args.query)
     // Small stores (a.plain_loads: the caller's rule) read their rows with ordinary loads instead of the streaming (non-temporal)
-    // loads of the large-store kernels. Measured equal on this part (the L2s do not keep a store across kernel boundaries:
-    // profiles/HISTORY.md), never slower for stores of up to 230 MB.
+    // loads of the large-store kernels: 0.7 - 0.9 us per query faster up to ~30 MB of rows, equal to 230 MB, slower beyond
+    // (profiles/HISTORY.md).
     if (a.query_host != nullptr && !write_dist && variant == 0) {
         if (a.dims == 384) return (fuse && small) ? launch_qarg<96, 32, 4, false>(a, metric, cap, grid, st) : launch_qarg<96, 32, 4, true>(a, metric, cap, grid, st);
         if (a.dims == 768) return (fuse && small) ? launch_qarg<192, 64, 2, false>(a, metric, cap, grid, st) : launch_qarg<192, 64, 2, true>(a, metric, cap, grid, st);
