@@ -61,7 +61,7 @@ int main(int argc, char** argv) {
         for (int mode = 0; mode <= 7; ++mode) {
             wax_hip_set_tuning(e, "scan_plain_mb", mode == 6 ? (1 << 20) : mode == 7 ? 0 : -1);
             wax_hip_set_tuning(e, "query_args", mode <= 2 ? mode : 1);
-            wax_hip_set_tuning(e, "grid_blocks", mode == 3 ? 80 : 0);
+            wax_hip_set_tuning(e, "grid_blocks", mode == 3 ? (getenv("WAX_LAT_GRID") ? atoi(getenv("WAX_LAT_GRID")) : 80) : 0);   /* WAX_LAT_GRID: mode 3's grid cap */
             wax_hip_set_tuning(e, "merge_kway", mode == 5 ? 0 : 1);
             wax_hip_set_tuning(e, "done_flag", mode == 4 ? 0 : 1);   /* mode 4: query_args 1 with an event behind the kernel instead of the completion word */
             for (int i = 0; i < 50; ++i) wax_hip_search(e, q, (uint32_t)dims, topk, out_ids, out_scores, 64, &got);

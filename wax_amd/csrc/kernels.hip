@@ -437,16 +437,15 @@ int scan_grid_for(uint32_t n_rows, uint32_t dims, int variant, int grid_cap) {
     const uint64_t nchunks = ((uint64_t)n_rows + info.rows_per_chunk - 1) / info.rows_per_chunk;
     const uint64_t max_waves = (uint64_t)grid_cap * SCAN_WAVES;
     uint64_t waves = nchunks;
-    const uint64_t halved_blocks = ((nchunks + 1) / 2 + SCAN_WAVES - 1) / SCAN_WAVES;
-    const uint64_t full_blocks = (nchunks + SCAN_WAVES - 1) / SCAN_WAVES;
-    if (nchunks <= max_waves && nchunks >= 64 && halved_blocks <= (uint64_t)SCAN_FUSE_MERGE_GRID && full_blocks > (uint64_t)SCAN_FUSE_MERGE_GRID) {
-        // Small stores (<= 16 K rows at 8 rows per chunk): two chunks per wave. The scan is a couple of HBM round trips
-        // either way, but half the workgroups means half the partial lists — few enough (<= SCAN_FUSE_MERGE_GRID) for the
-        // last-arriving workgroup to do the final merge itself instead of a second launch. Only where the halved grid
-        // really fits the fused merge: a mid-size store (e.g. 2048 chunks) keeps one chunk per wave and its full parallelism.
-        // And only where one chunk per wave would NOT fit it: ~157 workgroups is the best grid from 2.5K to 10K rows (5K rows: 157
-        // workgroups 19.8 us per blocking call against 79 at 21.0; 10K rows: 157 at 21.6 against 313 at 23.3 — session r04_s22).
-        waves = (nchunks + 1) / 2;
+    const uint64_t small_waves = (uint64_t)SCAN_FUSE_MERGE_GRID * SCAN_WAVES;   // 640 waves = 160 workgroups
+    if (nchunks >= 64 && nchunks <= 4 * small_waves && (uint64_t)grid_cap >= (uint64_t)SCAN_FUSE_MERGE_GRID) {
+        // Small stores (<= 20 K rows at 8 rows per chunk): as many chunks per wave (1 .. 4) as keep the grid at <= 160 workgroups —
+        // few enough partial lists for the last-arriving workgroup to do the final merge itself for every k the fused kernels serve,
+        // and the best grid measured at every such size: blocking call, 384-d, top-10 (sessions r04_s22 / s23) —
+        //    5K rows: 157 workgroups 19.8 us, 79 (two chunks per wave) 21.0     10K: 157 (two chunks) 21.6, 313 (one) 23.3
+        //   20K rows: 157 (four chunks) 24.2, 313 (two) 25.6                     40K: 157 30.8, 417 (default rule) 29.6: the rule ends here
+        const uint64_t iters = (nchunks + small_waves - 1) / small_waves;
+        waves = (nchunks + iters - 1) / iters;
     } else if (nchunks > max_waves) {
         // Balance the grid-stride loop: every wave runs the same number of iterations (+-1 chunk
         // in total) instead of leaving a mostly idle last iteration (26 % idle at 1M x 384).
