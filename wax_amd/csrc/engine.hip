@@ -7,6 +7,7 @@
 // travel through pinned staging, every search runs on a pooled scratch slot with its own HIP
 // stream (the analogue of the transient buffer pool, :84-117), and there is no CPU fallback.
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -1215,12 +1216,22 @@ bool plan_onepass(wax_hip_engine* e, uint32_t n, int k_eff, uint32_t nq, Onepass
     // k forces j close to S — and a cost in microseconds: sampling rounds + cold-path survivors (profiles/r02).
     double best_cost = 0.0;
     p->rank = 0;
-    for (uint32_t j = 5; j <= kPickJ; ++j) {
-        double lo = 0.0, hi = (double)j;                  // x_j: P(Gamma(j) < x_j) = 1e-6
-        for (int it = 0; it < 40; ++it) {
-            const double mid = 0.5 * (lo + hi);
-            if (gamma_cdf_below(j, mid) > 1e-6) hi = mid; else lo = mid;
+    // x_j: P(Gamma(j) < x_j) = 1e-6 — constants (40 bisection steps of a 70-term series each, for eight ranks: ~35 us of host
+    // time that used to sit in front of the first launch of EVERY batch; a blocking call paid it in full). Computed once.
+    static const std::array<double, kPickJ + 1> kGammaX = [] {
+        std::array<double, kPickJ + 1> x{};
+        for (uint32_t j = 5; j <= kPickJ; ++j) {
+            double lo = 0.0, hi = (double)j;
+            for (int it = 0; it < 40; ++it) {
+                const double mid = 0.5 * (lo + hi);
+                if (gamma_cdf_below(j, mid) > 1e-6) hi = mid; else lo = mid;
+            }
+            x[j] = lo;
         }
+        return x;
+    }();
+    for (uint32_t j = 5; j <= kPickJ; ++j) {
+        const double lo = kGammaX[j];
         double e_need = need * (double)j / lo;
         if (e_need < floor_e) e_need = floor_e;
         if (e_need / nn > 0.25) continue;                 // a quarter of the store as candidates: not a filter any more
