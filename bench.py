@@ -354,13 +354,34 @@ def traffic_child_batch(torch, dev, rows, dims, k, spec):
 TRAFFIC_MODE = "replay"      # set by main(): what secondary_batched may do for its roofline.traffic
 
 
+def fetch_size_per_launch(out_dir, batched):
+    """FETCH_SIZE [KiB] of the counted launches in a rocprofv3 `--pmc FETCH_SIZE --output-format csv` directory, in dispatch order,
+    warm-ups dropped. Single-query child: the scan kernel's launches. Batched child: the `batch_gemm_*` instantiation with the largest
+    mean — the filtering GEMM streams the whole mirror, the sampling launch of the same template reads a few hundred tiles."""
+    import csv
+    import glob
+    vals, by_name = [], {}
+    for path in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                name = r.get("Kernel_Name") or ""
+                if r.get("Counter_Name") != "FETCH_SIZE":
+                    continue
+                ent = (int(r.get("Dispatch_Id") or 0), float(r["Counter_Value"]))
+                if not batched and "scan_kernel" in name:
+                    vals.append(ent)
+                elif batched and "batch_gemm" in name:
+                    by_name.setdefault(name, []).append(ent)
+    if batched and by_name:
+        vals = max(by_name.values(), key=lambda v: sum(x for _, x in v) / len(v))
+    return [v for _, v in sorted(vals)][TRAFFIC_CHILD_WARM:]
+
+
 def live_traffic(rows, dims, k, timeout_s=300, batch=None):
     """HBM bytes per launch of the headline scan kernel, measured IN this run: a counters-only child pass
     (`rocprofv3 --pmc FETCH_SIZE --kernel-trace`, no other tracing: MI355X_MICROARCH.md's HBM recipe) over the same corpus
     and kernel, TRAFFIC_CHILD_LAUNCHES launches after TRAFFIC_CHILD_WARM warm-ups. bytes = FETCH_SIZE (KiB) * 1024 * 2 (the guide's
     gfx950 correction: the counter sees a 128-B request of a wide coalesced stream as 64 B). Returns (bytes or None, source text)."""
-    import csv
-    import glob
     import shutil
     import signal
     import subprocess
@@ -390,23 +411,7 @@ def live_traffic(rows, dims, k, timeout_s=300, batch=None):
                 os.killpg(proc.pid, signal.SIGKILL)      # exactly the process group started above
                 proc.wait()
                 return None, f"counter pass timed out after {timeout_s} s"
-        vals, by_name = [], {}
-        for path in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
-            with open(path) as f:
-                for r in csv.DictReader(f):
-                    name = r.get("Kernel_Name") or ""
-                    if r.get("Counter_Name") != "FETCH_SIZE":
-                        continue
-                    if batch is None and "scan_kernel" in name:
-                        vals.append((int(r.get("Dispatch_Id") or 0), float(r["Counter_Value"])))
-                    elif batch is not None and "batch_gemm" in name:
-                        by_name.setdefault(name, []).append((int(r.get("Dispatch_Id") or 0), float(r["Counter_Value"])))
-        warm = TRAFFIC_CHILD_WARM
-        if batch is not None and by_name:
-            # the filtering GEMM is the instantiation that streams the whole mirror (the sampling launch reads a few hundred tiles);
-            # its first two launches (mirror build call, warm batch) are dropped
-            vals = max(by_name.values(), key=lambda v: sum(x for _, x in v) / len(v))
-        vals = [v for _, v in sorted(vals)][warm:]
+        vals = fetch_size_per_launch(tmp, batch is not None)
         if rc != 0 or not vals:
             tail = ""
             try:

@@ -453,3 +453,34 @@ def test_measured_bf16_certificate_bound_is_a_bound():
     en = float(np.sqrt(np.sum((x.astype(np.float64) - xt.astype(np.float64)) ** 2)))
     assert old_constant < err <= en * (1 + 1 / 256) + en * 1.001 + 3 * dims * 5.97e-8 + 3e-6 and err <= worst
     print(f"\n[bf16 bound] self-similarity error of an adversarial vector {err:.5f} (old constant {old_constant:.5f}, worst case {worst:.5f}, measured bound {2 * en:.5f})")
+
+
+def test_bench_reads_fetch_size_per_launch_from_a_counter_pass(tmp_path):
+    """bench.live_traffic's reader: a rocprofv3 `--pmc FETCH_SIZE --output-format csv` directory -> FETCH_SIZE of the counted launches,
+    in dispatch order, the two warm-ups dropped. Single-query pass: the scan kernel (either form), other kernels and counters ignored.
+    Batched pass: of the `batch_gemm_*` instantiations, the one that streams the mirror (largest mean), not the sampling launch."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("wax_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    d = tmp_path / "node" / "123"
+    d.mkdir(parents=True)
+    head = "Correlation_Id,Dispatch_Id,Agent_Id,Kernel_Name,Counter_Name,Counter_Value\n"
+    rows = []
+    for i in range(8):                                    # dispatches written out of order on purpose
+        rows.append(f'{i},{20 - i},1,"void wax::scan_kernel<96, 32, 0, 4, true, 128, false>(wax::ScanArgs)",FETCH_SIZE,{7500000 + (20 - i)}\n')
+        rows.append(f'{i},{20 - i},1,"void wax::scan_kernel<96, 32, 0, 4, true, 128, false>(wax::ScanArgs)",SQ_WAVES,5\n')
+        rows.append(f'{i},{40 + i},1,"void wax::merge_keys_kernel<128>(long const*)",FETCH_SIZE,3\n')
+    (d / "t_counter_collection.csv").write_text(head + "".join(rows))
+    got = bench.fetch_size_per_launch(str(tmp_path), False)
+    assert got == [7500000.0 + x for x in range(15, 21)]  # dispatch ids 13, 14 were the warm-ups
+    assert sum(got) / len(got) * 2048 == (7500000 + 17.5) * 2048
+    rows = []
+    for i in range(5):
+        rows.append(f'{i},{2 * i},1,"void wax::batch_gemm_rega_kernel<384, false, 3, true, false, 0>(wax::GemmArgs, unsigned int)",FETCH_SIZE,{9000 + i}\n')
+        rows.append(f'{i},{2 * i + 1},1,"void wax::batch_gemm_rega_kernel<384, false, 3, false, false, 2>(wax::GemmArgs, unsigned int)",FETCH_SIZE,{375000 + i}\n')
+    (d / "t_counter_collection.csv").write_text(head + "".join(rows))
+    assert bench.fetch_size_per_launch(str(tmp_path), True) == [375002.0, 375003.0, 375004.0]
+    assert bench.fetch_size_per_launch(str(tmp_path), False) == []     # no scan kernel in a batched pass
