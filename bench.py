@@ -377,7 +377,29 @@ def fetch_size_per_launch(out_dir, batched):
     return [v for _, v in sorted(vals)][TRAFFIC_CHILD_WARM:]
 
 
-def live_traffic(rows, dims, k, timeout_s=300, batch=None):
+# The counter passes are an optional leg of a run that must finish within minutes whatever the box does: each child has its own limit, all
+# of them together a budget, and the first pass that times out switches the rest of the run to the replayed figures.
+LIVE_CHILD_LIMIT_S, LIVE_TOTAL_BUDGET_S = 150.0, 300.0
+LIVE_STATE = {"disabled": None, "spent_s": 0.0, "passes": 0}
+
+
+def live_allowed():
+    """None if another counter pass may start, else the reason why not."""
+    if LIVE_STATE["disabled"]:
+        return "counter passes disabled for the rest of this run: " + LIVE_STATE["disabled"]
+    if LIVE_STATE["spent_s"] >= LIVE_TOTAL_BUDGET_S:
+        return f"counter-pass budget of {LIVE_TOTAL_BUDGET_S:.0f} s spent ({LIVE_STATE['passes']} passes, {LIVE_STATE['spent_s']:.0f} s)"
+    return None
+
+
+def live_account(seconds, timed_out=False):
+    LIVE_STATE["spent_s"] += seconds
+    LIVE_STATE["passes"] += 1
+    if timed_out:
+        LIVE_STATE["disabled"] = f"a pass hit its {LIVE_CHILD_LIMIT_S:.0f} s limit"
+
+
+def live_traffic(rows, dims, k, timeout_s=None, batch=None):
     """HBM bytes per launch of the headline scan kernel, measured IN this run: a counters-only child pass
     (`rocprofv3 --pmc FETCH_SIZE --kernel-trace`, no other tracing: MI355X_MICROARCH.md's HBM recipe) over the same corpus
     and kernel, TRAFFIC_CHILD_LAUNCHES launches after TRAFFIC_CHILD_WARM warm-ups. bytes = FETCH_SIZE (KiB) * 1024 * 2 (the guide's
@@ -391,6 +413,11 @@ def live_traffic(rows, dims, k, timeout_s=300, batch=None):
         return None, "rocprofv3 not found"
     if any(v.startswith(("ROCPROF", "ROCP_")) for v in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
         return None, "this run is itself under rocprofv3: no nested counter pass"
+    why_not = live_allowed()
+    if why_not:
+        return None, why_not
+    if timeout_s is None:
+        timeout_s = min(LIVE_CHILD_LIMIT_S, max(30.0, LIVE_TOTAL_BUDGET_S - LIVE_STATE["spent_s"]))
     tmp = tempfile.mkdtemp(prefix="wax_pmc_", dir="/tmp")
     cmd = [exe, "--pmc", "FETCH_SIZE", "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "t", "--",
            sys.executable, os.path.abspath(__file__), "--traffic-child", "--rows", str(rows), "--dims", str(dims), "--topk", str(k)]
@@ -410,7 +437,9 @@ def live_traffic(rows, dims, k, timeout_s=300, batch=None):
             except subprocess.TimeoutExpired:
                 os.killpg(proc.pid, signal.SIGKILL)      # exactly the process group started above
                 proc.wait()
-                return None, f"counter pass timed out after {timeout_s} s"
+                live_account(time.perf_counter() - t0, timed_out=True)
+                return None, f"counter pass timed out after {timeout_s:.0f} s"
+        live_account(time.perf_counter() - t0)
         vals = fetch_size_per_launch(tmp, batch is not None)
         if rc != 0 or not vals:
             tail = ""

@@ -484,3 +484,30 @@ def test_bench_reads_fetch_size_per_launch_from_a_counter_pass(tmp_path):
     (d / "t_counter_collection.csv").write_text(head + "".join(rows))
     assert bench.fetch_size_per_launch(str(tmp_path), True) == [375002.0, 375003.0, 375004.0]
     assert bench.fetch_size_per_launch(str(tmp_path), False) == []     # no scan kernel in a batched pass
+
+
+def test_bench_counter_passes_are_bounded():
+    """bench.py's live counter passes are an optional leg of a run that must finish within minutes: a pass that hits its limit
+    disables the rest, and all passes together have a budget; after either, live_traffic returns at once with the reason (the
+    caller falls back to the replayed figure)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("wax_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.live_allowed() is None
+    for _ in range(5):
+        bench.live_account(12.0)
+    assert bench.live_allowed() is None and bench.LIVE_STATE["passes"] == 5
+    bench.live_account(bench.LIVE_TOTAL_BUDGET_S)                       # budget spent
+    assert "budget" in bench.live_allowed()
+    bench.LIVE_STATE.update(disabled=None, spent_s=0.0, passes=0)
+    bench.live_account(bench.LIVE_CHILD_LIMIT_S, timed_out=True)        # one pass hung: no more passes in this run
+    why = bench.live_allowed()
+    assert why and "disabled" in why
+    import shutil
+    if shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3"):
+        got, note = bench.live_traffic(1000, 384, 10)                   # returns at once, nothing is launched
+        assert got is None and "disabled" in note
+
