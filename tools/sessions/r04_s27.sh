@@ -1,6 +1,8 @@
 #!/bin/bash
 # round 4, GPU session 27: survivors parked in LDS and flushed after the tile loop (new build, 252 VGPRs) against the committed build (230),
 # alternating in one session; then the GEMM variants / parity tests on the new build
+# (a record of the experiment: it needs the experimental kernel — since removed, profiles/HISTORY.md — built as wax_amd/lib/libwaxhip.so and
+# the committed build saved beside it as wax_amd/lib/libwaxhip_head.so.keep)
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/r04_s27
