@@ -343,7 +343,7 @@ int wax_hip_stats(wax_hip_engine* e, wax_hip_stats_t* out);
  * "share_timing" (1 = a chained scan whose predecessor is still in flight uses that scan's end-of-kernel event as its own start
  * event: one packet less between scans; 0 = every scan records its own start), "filter_device_min" (wax_hip_search_filtered: allow-lists at least this long are resolved by
  * the device-side id -> row table instead of host probes, default 4096; -1 = never),
- * "merge_kway" (1 (default) = top_k <= 32: the scan kernel's last-arriving workgroup merges the per-workgroup lists by their heads — k
+ * "merge_kway" (1 (default) = top_k <= 64: the scan kernel's last-arriving workgroup merges the per-workgroup lists by their heads — k
  * rounds of a workgroup-wide minimum, whatever the number of lists — which lets every default grid (<= 512 workgroups) of a store of up to
  * 2 GiB of rows finish in ONE launch; 0 = small grids (<= 160 workgroups) stream the lists through the wave lists, larger ones use the merge kernel),
  * "scan_plain_mb" (query-in-arguments scans: stores of at most this many MB read their rows with ordinary instead of non-temporal loads;

@@ -519,7 +519,7 @@ def test_full_size_parity_with_oracle(wax, n, dims, nq):
     k = 10
     queries = oracle.gaussian_unit_queries(nq, dims)
     got = [eng.searchArrays(q, k) for q in queries]
-    # k <= 32: the scan merges in its own kernel (one packet, completion word) up to 2 GiB of rows; beyond, a separate merge kernel
+    # k <= 64: the scan merges in its own kernel (one packet, completion word) up to 2 GiB of rows; beyond, a separate merge kernel
     assert (eng.getTuning("done_flag_waits") == nq) == (n * dims * 4 <= 2 << 30), (n, dims, eng.getTuning("done_flag_waits"))
     # the whole top-10 of every query, id for id and score for score, against the f64 oracle on the same rows
     _assert_batch_parity(0, corpus, queries, k, [g[0] for g in got], [g[1] for g in got], [len(g[0]) for g in got], 0,
@@ -1917,30 +1917,30 @@ def test_multi_query_exact_scan_is_bit_identical(wax, dims, metric):
 
 
 def _merges_in_kernel(grid, k, n, dims):
-    """kernels.h scan_merges_in_kernel: any k <= 192 on grids <= 160 (wave-list merge); k <= 32 on every default grid (<= 512:
+    """kernels.h scan_merges_in_kernel: any k <= 192 on grids <= 160 (wave-list merge); k <= 64 on every default grid (<= 512:
     the k-way merge of the lists' heads) for stores of up to 2 GiB of rows."""
-    return grid <= 160 or (k <= 32 and grid <= 512 and n * dims * 4 <= 2 << 30)
+    return grid <= 160 or (k <= 64 and grid <= 512 and n * dims * 4 <= 2 << 30)
 
 
 def test_fused_final_merge_equals_two_launch_path(wax):
     """Small grids (<= 160 workgroups: stores up to ~20K rows) let the scan kernel's last-arriving workgroup do the final
     merge (scan_epilogue: write-through partial lists, device-scope ticket) instead of a second launch. Same hits, bit for
     bit, as the two-launch path ("fuse_merge" = 0) — for every k the fused kernels serve, ragged sizes, all metrics, the
-    generic-dims kernel, and many back-to-back queries on pipelined slots (the ticket must re-arm itself). For k <= 32 the last
+    generic-dims kernel, and many back-to-back queries on pipelined slots (the ticket must re-arm itself). For k <= 64 the last
     arriver merges the lists' heads (kway_merge: one or two lists per thread), which serves every default grid (<= 512), so
-    larger stores take the same path; there k > 32 stays on two launches and both settings run the same kernels."""
+    larger stores take the same path; there k > 64 stays on two launches and both settings run the same kernels."""
     for metric, dims, n in [(0, 384, 10_000), (1, 384, 9_999), (2, 128, 5_000), (0, 768, 3_001), (0, 100, 2_000), (0, 384, 65), (0, 64, 20_000),
-                            (0, 384, 45_001), (2, 768, 70_000), (1, 384, 400_000), (0, 100, 150_000)]:   # grids of 257 .. 512: two lists per thread (k <= 32)
+                            (0, 384, 45_001), (2, 768, 70_000), (1, 384, 400_000), (0, 100, 150_000)]:   # grids of 257 .. 512: two lists per thread (k <= 64)
         corpus = oracle.gaussian_unit_rows(7 + n, n, dims)
         corpus[11] = corpus[10]
         eng = make_engine(wax, metric, dims, corpus, np.arange(n, dtype=np.uint64) + 9)
         queries = oracle.gaussian_unit_queries(24, dims, seed=n)
         queries[3] = corpus[10]
-        for k in (1, 3, 4, 5, 10, 24, 32, 33, 64, 65, 192):
+        for k in (1, 3, 4, 5, 10, 24, 32, 33, 47, 64, 65, 192):
             eng.setTuning("fuse_merge", 1)
             pend = [eng.submit(q, k) for q in queries[:4]]          # pipelined: four slots, four tickets
             fused = [eng.collect(t, k) for t in pend] + [eng.searchArrays(q, k) for q in queries[4:]]
-            if k <= 32:                                             # k <= 32 merges the lists' heads ("merge_kway"); the wave-list merge must agree
+            if k <= 64:                                             # k <= 64 merges the lists' heads ("merge_kway"); the wave-list merge must agree
                 eng.setTuning("merge_kway", 0)
                 for q, (f_ids, f_scores) in zip(queries[:8], fused):
                     w_ids, w_scores = eng.searchArrays(q, k)

@@ -32,7 +32,7 @@ int main(int argc, char** argv) {
     float* q = malloc((size_t)dims * sizeof(float));
     double* lat = malloc((size_t)reps * sizeof(double));
     for (int corpus = 0; corpus < 2; ++corpus) {
-        const int topk = corpus == 0 ? 24 : 10;
+        const int topk = corpus == 0 ? 24 : (argc > 4 ? atoi(argv[4]) : 10);   /* argv[4]: top_k of the unit-gaussian part (<= 64) */
         unsigned long long seed = 12345;
         for (int i = 0; i < n; ++i) {
             ids[i] = (uint64_t)i;

@@ -404,7 +404,7 @@ struct wax_hip_engine {
     std::atomic<int64_t> force_general{0};
     std::atomic<int64_t> stream_nt{1};
     std::atomic<int64_t> scan_plain_mb{32};  // single-query scans with the query in their arguments: stores up to this many MB read their rows with ordinary loads (-1 = grids <= 160 workgroups)
-    std::atomic<int64_t> merge_kway{1};      // fused final merge, k <= 32: 1 (default) = k-way merge of the per-workgroup lists' heads; 0 = stream them through the wave lists
+    std::atomic<int64_t> merge_kway{1};      // fused final merge, k <= 64: 1 (default) = k-way merge of the per-workgroup lists' heads; 0 = stream them through the wave lists
     std::atomic<int64_t> done_flag{1};       // single-query scans that merge in the kernel publish a completion word in pinned memory; collect polls it instead of an event (0 = always an event)
     std::atomic<uint64_t> st_flag_waits{0};
     std::atomic<int64_t> query_args{1};      // single-query scans: 1 (default) = stores whose scan grid is small enough for the fused merge (the launch-latency-bound ones) get the query in the kernel arguments (no upload copy); 2 = every store; 0 = always upload

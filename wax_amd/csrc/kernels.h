@@ -51,7 +51,7 @@ struct ScanArgs {
     uint64_t* done_flag;
     uint64_t done_value;
     int32_t plain_loads;     // query-in-arguments kernels: != 0 = ordinary row loads (the store is expected to stay cached between queries), 0 = non-temporal
-    int32_t no_kway;         // fused final merge: != 0 = always the wave-list merge (A/B; default 0 = the k-way merge of the list heads for k <= 32)
+    int32_t no_kway;         // fused final merge: != 0 = always the wave-list merge (A/B; default 0 = the k-way merge of the list heads for k <= SCAN_KWAY_MAX_K)
 };
 // kernarg block of scan_kernel_qarg: the scan arguments followed by the query itself (16-byte aligned for float4 loads)
 template <int DIMS>
@@ -69,7 +69,7 @@ constexpr int SCAN_FUSE_MERGE_GRID = 160;   // largest grid whose last-arriving 
 // 100K 55 -> 43, 1M 250 -> 237), while a PIPELINED stream of queries on a large store loses the overlap of the small merge kernel
 // with the next scan (the last arriver's tail, ~7 us at 505 workgroups, is serial): 10M x 384 2.162 -> 2.166 ms per query. So the
 // larger grids merge in the kernel only up to SCAN_KWAY_MAX_BYTES of rows (a scan of <= ~0.3 ms, where 12 us is >= 4 %).
-constexpr int SCAN_KWAY_MAX_K = 32;
+constexpr int SCAN_KWAY_MAX_K = 64;
 constexpr int SCAN_KWAY_MERGE_GRID = 512;
 constexpr uint64_t SCAN_KWAY_MAX_BYTES = 2ull << 30;
 // will a scan of `grid` workgroups over n_rows x dims floats for top-`k` merge in its own last-arriving workgroup? (kway = "merge_kway")
