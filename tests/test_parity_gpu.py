@@ -1280,7 +1280,10 @@ def test_batch_gemm_variants_agree(wax, dims):
                                   # D = 768: 1 / 6 / 7 = the K-split kernel (workgroup barrier / split barrier / its size rule), every other
                                   # value the wide kernel (whole K per wave, LDS-DMA staging) — whose build variants sit behind batch_debug
                                   # bits 8-9: two LDS tile buffers (256), the split tile barrier (512), read-ahead 3 (768)
-                                  (1, 6, 8), (1, 7, 8), (0, 7, 3), (1, 5, 8, 256), (1, 5, 8, 512), (0, 5, 3, 768), (1, 2, 8, 256)]:
+                                  (1, 6, 8), (1, 7, 8), (0, 7, 3), (1, 5, 8, 256), (1, 5, 8, 512), (0, 5, 3, 768), (1, 2, 8, 256),
+                                  # round 5 (D = 384 / 768): the ping-pong kernel — 8 = late-half DMA + primed fragment rings (bits 8-9:
+                                  # read-ahead / ring variants), 9 = one barrier per tile, 10 = plain ping-pong
+                                  (1, 8, 8), (0, 8, 3), (1, 8, 8, 256), (1, 8, 8, 512), (1, 9, 8), (1, 10, 8), (0, 10, 3)]:
         eng.setTuning("batch_debug", dbg[0] if dbg else 0)
         eng.setTuning("batch_onepass", onepass)
         eng.setTuning("batch_rega", rega)

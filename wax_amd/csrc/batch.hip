@@ -1505,6 +1505,360 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_wide_kernel(GemmArgs a, uin
 }
 
 // ---------------------------------------------------------------------------
+// Register-resident-queries GEMM, PING-PONG schedule (round 5; D * TROWS = 24 576: 768-d x 32 rows, 384-d x 64 rows, ...).
+//
+// Same data path as batch_gemm_wide_kernel — 32 queries x D per wave as MFMA A fragments, corpus tiles by LDS-DMA into a ring of
+// NBUF padded tile images, one ds_read_b128 per MFMA, SGPR survivor counters — with two differences that the round-4 counters
+// asked for (matrix pipe 55 % busy, waves parked 48 %, no bank conflicts, traffic 1.00 x):
+//
+//  1. NOTHING in the tile loop is an LDS access the compiler can see. hipcc's waitcnt pass cannot tell which LDS bytes a pending
+//     global_load_lds will write, so in front of the first B-fragment read of every tile it emitted `s_waitcnt vmcnt(0)` — the wide
+//     kernel issued tile t + 2's DMA and then WAITED FOR IT TO LAND (an L2 / HBM round trip per tile, on every wave) before its
+//     first MFMA: the three-buffer ring never had anything in flight across a tile (rocm 7.2 ISA of the round-4 build:
+//     `s_waitcnt vmcnt(0) lgkmcnt(0)` ahead of MFMA 0 of the K loop). Here the B fragments and the selection's bounds are read by
+//     inline-asm ds_read_b128 with hand-counted lgkmcnt waits (LDS operations return in order: "at most N younger ones outstanding"
+//     implies that read f has landed, whatever else is queued), and the only vmcnt waits are the counted ones below.
+//  2. The two waves of a SIMD are HALF A TILE PERIOD apart (PING): waves 0-3 multiply tile t (48 MFMAs back to back, s_setprio 1)
+//     while waves 4-7 select tile t - 1 and request their pieces of tile t + PRE; an s_barrier; then waves 4-7 multiply tile t while
+//     waves 0-3 request their pieces, wait for tile t + 1 and select tile t; an s_barrier. A SIMD's matrix pipe always has exactly
+//     one wave feeding it, and everything that is not an MFMA (DMA address arithmetic, the selection with its cold path and global
+//     stores, the waits) runs in the shadow of the partner's MFMAs instead of at the tile boundary where BOTH waves used to do it
+//     with the pipe idle. Two barriers per tile, but no wave ever arrives at one with matrix work pending behind it.
+//     Hazards: tile t + PRE goes to the buffer tile t - 1 was read from; its last reader (a late wave's K loop of period t - 1)
+//     ended before the barrier that opens period t, and both halves request after that barrier. A wave waits for its OWN pieces of
+//     tile t + 1 (counted vmcnt: the PRE - 1 younger tiles stay in flight; survivor stores are older than those and complete first)
+//     before the barrier that ends period t; readers start behind that barrier.
+// PING = false keeps one barrier per tile and the early / late order of the wide kernel (A/B of item 1 alone).
+template <int D, int TROWS, int NBUF, int AHEAD, bool SAMPLE = false, int MODE = 2>
+__global__ __launch_bounds__(512, 2) void batch_gemm_pp_kernel(GemmArgs a, uint32_t blocks_per_group) {
+    constexpr bool PING = MODE >= 1;                 // two barriers per tile, the halves half a period apart
+    constexpr bool LATE_DMA = MODE >= 2;             // only waves 4-7 request tiles; the late half's fragment ring is primed ahead of the MID barrier
+    constexpr bool EARLY_HEAD = MODE == 2;           // ... and the early half's ahead of the END barrier (its ring is then live around the loop)
+    constexpr int KS = D / 16;                       // MFMA k-steps
+    constexpr int RB = TROWS / 32;                   // 32-row blocks per tile = accumulators per wave
+    constexpr int NF = KS * RB;                      // B fragments (= MFMAs) per wave and tile; fragment f = (k-step f / RB, block f % RB)
+    constexpr int ROW_B = D * 2 + 16;                // LDS row stride (bytes); (ROW_B / 4) % 64 == 4
+    constexpr int SEG_PER_ROW = D * 2 / 16;          // 16-byte segments per row
+    constexpr int SLOTS_PER_ROW = ROW_B / 16;        // 16-byte slots per padded row
+    constexpr int IMG_B = TROWS * ROW_B;             // padded tile image
+    constexpr int PIECES = (IMG_B + 1023) / 1024;    // 1-KB DMA pieces per tile
+    constexpr int BUF_B = PIECES * 1024;             // buffer stride (the image + slack for the last piece)
+    constexpr int PRE = NBUF - 1;                    // tiles requested ahead of the one being read
+    constexpr int RING = AHEAD + 1;
+    static_assert(TROWS % 32 == 0 && RB >= 1 && RB <= 4, "tile = 1..4 MFMA row blocks");
+    static_assert(D % 64 == 0 && (ROW_B / 4) % 64 == 4, "row stride must keep ds_read_b128 conflict-free");
+    static_assert(NBUF >= 3, "a tile is requested at least two periods before it is read");
+    static_assert(NBUF * BUF_B + 2 * 8 * 32 * 4 + 64 <= 160 * 1024, "LDS budget of one CU");
+    static_assert((RB - 1) * 32 * ROW_B + (KS - 1) * 32 < 65536, "ds_read offset field");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned int* cnt_s = reinterpret_cast<unsigned int*>(smem + NBUF * BUF_B);    // [8][32] survivors per query (this workgroup; written once, at the end)
+    float* sim_s = reinterpret_cast<float*>(cnt_s + 8 * 32);                       // [8][32] conservative similarity bounds
+
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: the early / late split and the survivor counters stay scalar
+    const uint32_t group = blockIdx.x / blocks_per_group;        // 256 queries per group
+    const uint32_t bidx = blockIdx.x % blocks_per_group;
+    const uint32_t q0 = group * 256 + wave * 32;                 // this wave's 32 queries
+
+    // A fragments: lane l holds query (l & 31), k = 16*ks + 8*(l >> 5) .. +7
+    bf16x8 fa[KS];
+    {
+        const u32x4* qp = reinterpret_cast<const u32x4*>(a.qb + (size_t)(q0 + (lane & 31)) * D) + (lane >> 5);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) fa[ks] = __builtin_bit_cast(bf16x8, qp[ks * 2]);
+        // The fragments are "used" HERE, so hipcc waits for their loads here — before the first DMA request. Left alone it places
+        // that wait in front of the first MFMA of the tile loop, where the only count it can prove is vmcnt(0): every wave then
+        // drains its whole DMA queue (the tile it requested a moment ago included) at the top of every K loop.
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(fa[ks]));
+    }
+    if (!SAMPLE && lane < 32) {
+        const float tq = a.tau[q0 + lane];
+        sim_s[wave * 32 + lane] = (1.0f - tq) - 4e-7f * (1.0f + __builtin_fabsf(tq));   // see batch_gemm_rega_kernel
+    }
+    const uint32_t seg_slots = a.seg_area / blocks_per_group;
+    const uint32_t seg_lane0 = (q0 + 4u * ((uint32_t)lane >> 5)) * a.cand_cap + a.seg_base + bidx * seg_slots;
+
+    const uint32_t ntiles_all = (a.slab_rows + TROWS - 1) / TROWS;
+    const uint32_t ntiles = SAMPLE ? a.sample_tiles : ntiles_all;
+    const uint32_t slab_end = a.slab0 + a.slab_rows;
+    const unsigned char* cbase = reinterpret_cast<const unsigned char*>(a.cb);
+    auto phys = [&](uint32_t tile) -> uint32_t {
+        return SAMPLE ? (uint32_t)(((unsigned long long)tile * ntiles_all) / a.sample_tiles) : tile;
+    };
+
+    // LDS-DMA map (as in batch_gemm_wide_kernel): wave w moves pieces w, w + 8, ...; lane l of piece P fills slot P*64 + l of
+    // the padded image; the arithmetic is redone per piece behind an opaque lane index so that it is not hoisted into VGPRs
+    // LATE_DMA: the four late waves carry all of it (pieces w - 4, w, w + 4, ...)
+    constexpr int DW = LATE_DMA ? 4 : 8;                                       // waves that request
+    constexpr int PPWD = (PIECES + DW - 1) / DW;                               // pieces per requesting wave
+    constexpr int FULLD = PIECES % DW == 0 ? DW : PIECES % DW;                 // requesting waves below this index carry PPWD pieces
+    const int dwave = LATE_DMA ? wave - 4 : wave;
+    const bool full_wave = dwave >= 0 && dwave < FULLD;
+    auto dma_piece = [&](int i, uint32_t row0, uint32_t buf_off) {
+        if (i < PPWD - 1 || full_wave) {
+            uint32_t lane_o = (uint32_t)lane;
+            asm volatile("" : "+v"(lane_o));
+            const uint32_t P = (uint32_t)dwave + (uint32_t)DW * (uint32_t)i;
+            const uint32_t slot = P * 64u + lane_o;
+            uint32_t r = slot / (uint32_t)SLOTS_PER_ROW;
+            uint32_t c = slot - r * (uint32_t)SLOTS_PER_ROW;
+            c = c < (uint32_t)SEG_PER_ROW ? c : (uint32_t)SEG_PER_ROW - 1u;   // pad slot: any valid bytes
+            r = r < (uint32_t)TROWS ? r : (uint32_t)TROWS - 1u;               // slack behind the image: any valid bytes
+            uint32_t grow = row0 + r;
+            grow = grow < a.n_rows ? grow : a.n_rows - 1;                     // clamp: masked in the selection
+            const unsigned char* src = cbase + (size_t)grow * (D * 2) + c * 16u;
+            __builtin_amdgcn_global_load_lds((global_cvoid*)src, (lds_void*)(smem + buf_off + P * 1024u), 16, 0, 0);
+        }
+    };
+    auto dma_tile = [&](uint32_t tile, uint32_t buf_off) {
+        const uint32_t row0 = a.slab0 + phys(tile) * TROWS;
+#pragma unroll
+        for (int i = 0; i < PPWD; ++i) dma_piece(i, row0, buf_off);
+    };
+    // this wave's DMA requests still allowed in flight: PRE - 1 whole tiles, or none
+    auto dma_wait = [&](bool keep) {
+        if (!keep) wait_vmcnt<0>();
+        else if (full_wave) wait_vmcnt<(PRE - 1) * PPWD>();
+        else wait_vmcnt<(PRE - 1) * (PPWD - 1)>();
+    };
+
+    f32x16 acc[RB];
+    u32x4 fb[RING];                                  // B-fragment ring (kernel scope: LATE_DMA fills its head ahead of a barrier)
+    const bool prio = (a.debug & 32u) == 0;
+    const uint32_t smem_lds = (uint32_t)(size_t)(lds_void*)smem;
+    const uint32_t lane_boff = (uint32_t)(lane & 31) * (uint32_t)ROW_B + (uint32_t)(lane >> 5) * 16u;
+    // K loop. Fragment f + AHEAD is requested before MFMA f; the wait in front of MFMA f leaves at most min(AHEAD, NF - 1 - f)
+    // younger reads outstanding. Every step is pinned (sched_barrier) — hipcc otherwise hoists an MFMA over the asm wait it depends on.
+    auto mfma_head = [&](uint32_t baddr) {           // request fragments 0 .. AHEAD - 1
+        static_for<0, (AHEAD < NF ? AHEAD : NF)>([&](auto F) {
+            constexpr int f = decltype(F)::value;
+            u32x4(&fbr)[RING] = fb;                  // (asm operands alone do not make a generic lambda capture)
+            const uint32_t ba = baddr;
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fbr[f % RING]) : "v"(ba), "n"((f % RB) * 32 * ROW_B + (f / RB) * 32));
+        });
+    };
+    auto mfma_body = [&](uint32_t baddr) {
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (prio) __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, NF>([&](auto F) {
+            constexpr int f = decltype(F)::value;
+            constexpr int g = f + AHEAD;
+            u32x4(&fbr)[RING] = fb;
+            const uint32_t ba = baddr;
+            if constexpr (g < NF)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fbr[g % RING]) : "v"(ba), "n"((g % RB) * 32 * ROW_B + (g / RB) * 32));
+            constexpr int younger = (NF - 1 - f) < AHEAD ? (NF - 1 - f) : AHEAD;
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(younger) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int ks = f / RB, rb = f % RB;
+            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], __builtin_bit_cast(bf16x8, fbr[f % RING]), ks == 0 ? zero16 : acc[rb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if (prio) __builtin_amdgcn_s_setprio(0);
+    };
+    auto mfma_tile = [&](uint32_t baddr) {
+        mfma_head(baddr);
+        mfma_body(baddr);
+    };
+    // Fused selection, see batch_gemm_wide_kernel (hot test against conservative bounds, wave-level flags per four queries; cold
+    // path with the wave's 32 per-query survivor counters in SGPRs, two saturating 16-bit counters each). The bounds are read by
+    // inline asm (point 1 above).
+    unsigned cq[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cq[r] = 0u;
+    const uint32_t sim_addr = (uint32_t)(size_t)(lds_void*)sim_s + (uint32_t)(wave * 32 + 4 * (lane >> 5)) * 4u;
+    auto select_tile = [&](uint32_t tile) {
+        if (a.debug & 8u) return;
+        if (SAMPLE) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[0][r];
+#pragma unroll
+                for (int b = 1; b < RB; ++b) v = __builtin_fmaxf(v, acc[b][r]);   // rows past the store are clamped copies of its last row
+                const float m = group_max32(v);
+                if ((lane & 31) == 31)
+                    a.tile_max[(size_t)tile * (a.nqt * 128u) + q0 + (uint32_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5))] = m;
+            }
+            return;
+        }
+        f32x4 lo[4];
+        static_for<0, 4>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            f32x4(&lor)[4] = lo;
+            const uint32_t sa = sim_addr;
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(lor[j]) : "v"(sa), "n"(j * 32));
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        unsigned long long hit[RB][4];
+        unsigned long long any = 0ull;
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) hit[b][g] = 0ull;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hit[b][r >> 2] |= __ballot(acc[b][r] >= lo[r >> 2][r & 3]);   // NaN fails
+#pragma unroll
+            for (int g = 0; g < 4; ++g) any |= hit[b][g];
+        }
+        if (any == 0ull || (a.debug & 64u)) return;
+        uint32_t seg_o = seg_lane0;                   // opaque: the per-query row offsets are computed HERE (cold path)
+        asm volatile("" : "+v"(seg_o));
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+            const uint32_t row0 = a.slab0 + tile * TROWS + (uint32_t)(b * 32) + (uint32_t)(lane & 31);
+            const bool ok0 = row0 < slab_end;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (hit[b][g] == 0ull) continue;
+#pragma unroll
+                for (int r = 4 * g; r < 4 * g + 4; ++r) {
+                    const bool p = ok0 && acc[b][r] >= lo[r >> 2][r & 3];
+                    const unsigned long long m = __ballot(p);
+                    if (m == 0ull) continue;
+                    const unsigned n_lo = (unsigned)__builtin_popcount((unsigned)m), n_hi = (unsigned)__builtin_popcount((unsigned)(m >> 32));
+                    const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    unsigned c0 = cq[r] & 0xFFFFu, c1 = cq[r] >> 16;
+                    const unsigned off = lane < 32 ? c0 + below : c1 + (below - n_lo);
+                    if (p && off < seg_slots) {
+                        const uint32_t e0 = seg_o + (uint32_t)((r & 3) + 8 * (r >> 2)) * a.cand_cap;
+                        a.cand[e0 + off] = make_key((1.0f - acc[b][r]) + 0.0f, a.row_base + row0);
+                    }
+                    c0 = c0 + n_lo < 0xFFFFu ? c0 + n_lo : 0xFFFFu;   // not clamped to seg_slots: a count above it tells the finish kernel that survivors were dropped
+                    c1 = c1 + n_hi < 0xFFFFu ? c1 + n_hi : 0xFFFFu;
+                    cq[r] = c0 | (c1 << 16);
+                }
+            }
+        }
+    };
+
+    uint32_t t = bidx;
+    {   // prologue: the first PRE tiles of this workgroup
+        bool all = true;
+#pragma unroll
+        for (int i = 0; i < PRE; ++i) {
+            const uint32_t ti = t + (uint32_t)i * blocks_per_group;
+            if (ti < ntiles) { if (!LATE_DMA || wave >= 4) dma_tile(ti, (uint32_t)(i * BUF_B)); } else all = false;
+        }
+        if (!LATE_DMA || wave >= 4) dma_wait(all);
+        __builtin_amdgcn_s_barrier();                         // also publishes sim_s
+        asm volatile("" ::: "memory");
+    }
+    const bool late = wave >= 4 && (PING || !(a.debug & 16u));   // debug bit 4 (timing only, MODE 0): every wave in the early order
+    // Pace gate (advisory; see batch_gemm_wide_kernel): with G > 1 query groups the G workgroups of a bidx are kept within a few
+    // tiles of each other so that a tile fetched for one is still in the XCD's L2 when the others want it. Wave 0 runs it in its
+    // side phase (PING), in the shadow of the late half's MFMAs.
+    constexpr uint32_t GATE_EVERY = 8u, GATE_WINDOW = 6u;
+    const uint32_t ngroups = gridDim.x / blocks_per_group;
+    const bool gate = !SAMPLE && a.progress != nullptr && ngroups > 1u && (blocks_per_group & 7u) == 0u && ngroups * blocks_per_group <= 256u && !(a.debug & 4096u);
+    const uint32_t* gate_word = gate ? a.progress + (bidx & 7u) * 32u + (bidx >> 3) : a.progress;   // one word per bidx, one 128-byte line per XCD
+    auto pace = [&](uint32_t it) {
+        if (gate && wave == 0 && (it & (GATE_EVERY - 1u)) == 0u && it > 0u) {
+            unsigned int add = GATE_EVERY;
+            for (uint32_t spins = 0; spins < 1024u; ++spins) {
+                unsigned int total = 0u;
+                if (lane == 0) total = __hip_atomic_fetch_add(const_cast<uint32_t*>(gate_word), add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add;
+                total = (unsigned int)__builtin_amdgcn_readfirstlane((int)total);
+                add = 0u;
+                if ((int)(ngroups * it - total) <= (int)(ngroups * GATE_WINDOW)) break;
+                __builtin_amdgcn_s_sleep(32);
+            }
+        }
+    };
+    uint32_t it = 0, cur_idx = 0, t_prev = 0;
+    if (EARLY_HEAD && !late && t < ntiles) {                  // tile t is published by the prologue's barrier
+        mfma_head(smem_lds + lane_boff);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    for (; t < ntiles; ++it) {
+        const uint32_t baddr = smem_lds + cur_idx * (uint32_t)BUF_B + lane_boff;
+        const uint32_t tn = t + PRE * blocks_per_group;
+        uint32_t pre_idx = cur_idx + PRE;
+        pre_idx = pre_idx >= (uint32_t)NBUF ? pre_idx - NBUF : pre_idx;
+        const bool issued = tn < ntiles;
+        if (LATE_DMA) {
+            // period t. Phase A: the early half multiplies tile t; the late half selects tile t - 1, requests tile t + PRE, waits for
+            // tile t + 1 (so that the MID barrier publishes it) and requests the head of its own K loop. Phase B: the late half
+            // multiplies tile t; the early half selects tile t and requests the head of K loop t + 1 ahead of the END barrier.
+            if (!late) {
+                if (!EARLY_HEAD) mfma_head(baddr);
+                mfma_body(baddr);
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                pace(it);
+                select_tile(t);
+                if (EARLY_HEAD && t + blocks_per_group < ntiles) {
+                    uint32_t nxt_idx = cur_idx + 1 == (uint32_t)NBUF ? 0u : cur_idx + 1;
+                    mfma_head(smem_lds + nxt_idx * (uint32_t)BUF_B + lane_boff);
+                    // landed before anything the compiler may do with these registers around the loop edge (the wave would sit at
+                    // the barrier meanwhile anyway)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+            } else {
+                if (it > 0) select_tile(t_prev);
+                if (issued) dma_tile(tn, pre_idx * BUF_B);
+                dma_wait(issued);
+                mfma_head(baddr);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                mfma_body(baddr);
+            }
+        } else if (PING) {
+            if (!late) {
+                mfma_tile(baddr);
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                pace(it);                                     // (its returning atomic drains this wave's DMA queue: tile t + 1, long landed)
+                if (issued) dma_tile(tn, pre_idx * BUF_B);
+                dma_wait(issued);
+                select_tile(t);
+            } else {
+                if (it > 0) select_tile(t_prev);
+                if (issued) dma_tile(tn, pre_idx * BUF_B);
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                mfma_tile(baddr);
+                dma_wait(issued);
+            }
+        } else {
+            pace(it);
+            if (issued) dma_tile(tn, pre_idx * BUF_B);
+            if (late) {
+                if (it > 0) select_tile(t_prev);
+                mfma_tile(baddr);
+                dma_wait(issued);
+            } else {
+                mfma_tile(baddr);
+                dma_wait(issued);
+                select_tile(t);
+            }
+        }
+        t_prev = t;
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        cur_idx = cur_idx + 1 == (uint32_t)NBUF ? 0u : cur_idx + 1;
+        t += blocks_per_group;
+    }
+    if (late && it > 0) select_tile(t_prev);
+    if (gate && tid == 0) __hip_atomic_fetch_add(const_cast<uint32_t*>(gate_word), 1u << 24, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // done: nobody waits for this group
+    if (!SAMPLE) {   // the wave's 32 survivor counters, SGPRs -> LDS: lane q takes query q's
+        unsigned mine = 0u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            mine = lane == (r & 3) + 8 * (r >> 2) ? (cq[r] & 0xFFFFu) : mine;
+            mine = lane == (r & 3) + 8 * (r >> 2) + 4 ? (cq[r] >> 16) : mine;
+        }
+        if (lane < 32) cnt_s[wave * 32 + lane] = mine == 0xFFFFu ? 0x40000000u : mine;   // saturated = unknown = overflowed
+    }
+    __syncthreads();
+    if (!SAMPLE && tid < 256) a.seg_count[(size_t)bidx * (a.nqt * 128u) + group * 256u + (uint32_t)tid] = cnt_s[tid];
+}
+
+// ---------------------------------------------------------------------------
 // Register-resident-queries GEMM, ONE wave per SIMD ("w4": batch_rega = 3; D in {128, 256, 384, 512}).
 //
 // batch_gemm_rega_kernel keeps 32 queries per wave and two waves per SIMD: every B fragment read from LDS feeds one
@@ -1899,6 +2253,21 @@ static hipError_t launch_wide(const GemmArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
+template <int D, int TROWS, int NBUF, int AHEAD, int MODE>
+static hipError_t launch_pp(const GemmArgs& a, hipStream_t st) {
+    constexpr size_t smem = (size_t)NBUF * (((TROWS * (D * 2 + 16)) + 1023) / 1024 * 1024) + 2 * 8 * 32 * 4 + 64;   // tile buffers, counters, bounds
+    static_assert(smem <= 160 * 1024, "LDS budget of one CU");
+    static std::atomic<uint64_t> configured{0};   // per device (ensure_dynamic_lds)
+    {
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&batch_gemm_pp_kernel<D, TROWS, NBUF, AHEAD, false, MODE>), smem, configured);
+        if (e != hipSuccess) return e;
+    }
+    uint32_t groups, per_group;
+    rega_geometry(a, &groups, &per_group);
+    hipLaunchKernelGGL((batch_gemm_pp_kernel<D, TROWS, NBUF, AHEAD, false, MODE>), dim3(groups * per_group), dim3(512), smem, st, a, per_group);
+    return hipGetLastError();
+}
+
 template <int D, bool GLDS, int AHEAD, bool PROF = false, int SYNC = 0>
 static hipError_t launch_rega_impl(const GemmArgs& a, hipStream_t st) {
     constexpr bool FREE = SYNC == 1;
@@ -1966,6 +2335,19 @@ hipError_t launch_batch_gemm(const GemmArgs& a, int metric, hipStream_t st) {
                 case 256: return launch_w4<256>(a, st);
                 case 512: return launch_w4<512>(a, st);
                 default: return launch_w4<384>(a, st);
+            }
+        }
+        if (a.use_rega >= 8u && a.use_rega <= 10u) {   // round 5: 8 = ping-pong, late-half DMA, prefetched heads; 9 = asm-read fix alone; 10 = plain ping-pong
+            const uint32_t v = (a.debug >> 8) & 3u;   // timing experiments: read-ahead depth
+            if (a.dims == 768) {
+                if (a.use_rega == 8u) return v == 1u ? launch_pp<768, 32, 3, 4, 3>(a, st) : v == 2u ? launch_pp<768, 32, 3, 2, 3>(a, st) : launch_pp<768, 32, 3, 3, 3>(a, st);
+                if (a.use_rega == 10u) return launch_pp<768, 32, 3, 3, 1>(a, st);
+                return launch_pp<768, 32, 3, 3, 0>(a, st);
+            }
+            if (a.dims == 384) {
+                if (a.use_rega == 8u) return v == 1u ? launch_pp<384, 64, 3, 6, 2>(a, st) : v == 2u ? launch_pp<384, 64, 3, 3, 3>(a, st) : launch_pp<384, 64, 3, 3, 2>(a, st);
+                if (a.use_rega == 10u) return launch_pp<384, 64, 3, 3, 1>(a, st);
+                return launch_pp<384, 64, 3, 3, 0>(a, st);
             }
         }
         switch (a.dims) {
