@@ -2004,6 +2004,7 @@ def test_query_in_kernel_arguments_equals_uploaded_query(wax):
     corpus = oracle.gaussian_unit_rows(5, n, dims)
     one = make_engine(wax, 0, dims, corpus)
     many = wax.HIPVectorEngine(dimensions=dims, devices=[0, 0, 0])
+    many.setTuning("shard_min_mb", 0)                          # spread these 46 MB over the three shards (the default keeps them on one)
     many.addBatch(np.arange(n, dtype=np.uint64), corpus)
     for q in oracle.gaussian_unit_queries(6, dims, seed=8):
         a, b = one.searchArrays(q, 10), many.searchArrays(q, 10)

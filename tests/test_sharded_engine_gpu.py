@@ -15,6 +15,10 @@ from helpers import assert_parity
 
 pytestmark = pytest.mark.gpu
 
+# These tests are about the multi-shard machinery on stores of a few thousand rows: switch the small-store rule off for
+# the handles they create (read at handle creation; test_small_store_rule_* set it back per handle through "shard_min_mb").
+os.environ["WAX_HIP_SHARD_MIN_MB"] = "0"
+
 
 @pytest.fixture(scope="module")
 def wax(hip_lib):
@@ -527,4 +531,114 @@ def test_sharded_engine_over_distinct_devices(wax, hip_lib):
     many.setTuning("exchange", 0)
     assert all(np.array_equal(x, y) for x, y in zip(one.searchBatch(qs, 10), many.searchBatch(qs, 10)))
     assert one.serialize() == many.serialize()
+    one.close(), many.close()
+
+
+def test_small_store_rule_keeps_a_small_store_on_one_device(wax):
+    """Round 5: a store below "shard_min_mb" (default 64 MB of rows per shard block) is NOT spread over the devices — eight
+    launches and a gather for 2 MB of scan each cost 12 x the single engine's latency at 10K rows (round-4 rehearsal). It lives on
+    the first shard, a search is that engine's search behind one ticket lookup (within 1.5 x its latency), and when the store
+    outgrows the block the next shard starts to fill: same answers throughout."""
+    import time
+    dims, shards = 384, 8
+    one = wax.HIPVectorEngine(dimensions=dims)
+    many = wax.HIPVectorEngine(dimensions=dims, devices=[0] * shards)
+    many.setTuning("shard_min_mb", 64)
+    assert many.getTuning("shard_min_mb") == 64
+    n0 = 10_000
+    corpus = oracle.gaussian_unit_rows(3, 60_000, dims)
+    ids = np.arange(60_000, dtype=np.uint64) * 5 + 1
+    for eng in (one, many):
+        eng.reserve(n0)
+        eng.addBatch(ids[:n0], corpus[:n0])
+    block = many.getTuning("block_rows")
+    assert block * dims * 4 >= 64 << 20 and (block - 64) * dims * 4 < 64 << 20
+    assert [many.shardInfo(g)[2] for g in range(shards)] == [n0] + [0] * (shards - 1)
+    queries = oracle.gaussian_unit_queries(400, dims, seed=77)
+    s0 = many.getTuning("single_shard_searches")
+    for q in queries[:8]:
+        for k in (1, 10, 64, 65, 200):
+            same_search(one, many, q, k)
+    assert many.getTuning("single_shard_searches") - s0 == 40 and many.getTuning("ticket_searches") == 0
+
+    def lat(eng):
+        for q in queries[:50]:
+            eng.searchArrays(q, 10)
+        best = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for q in queries:
+                eng.searchArrays(q, 10)
+            best = min(best, (time.perf_counter() - t0) / len(queries))
+        return best
+    a, b = lat(one), lat(many)
+    assert b <= 1.5 * a + 5e-6, (a, b)
+    # batched search and filtered search on a handle whose other shards are empty
+    b1, b2 = one.searchBatch(queries[:64], 10), many.searchBatch(queries[:64], 10)
+    assert all(np.array_equal(x, y) for x, y in zip(b1, b2))
+    f1, f2 = one.searchFiltered(queries[0], 20, frameIds=ids[:500]), many.searchFiltered(queries[0], 20, frameIds=ids[:500])
+    assert np.array_equal(f1[0], f2[0]) and np.array_equal(f1[1], f2[1])
+    # growth past one block: the second shard starts to fill, searches fan out, answers stay the single engine's
+    for eng in (one, many):
+        eng.addBatch(ids[n0:], corpus[n0:])
+    counts = [many.shardInfo(g)[2] for g in range(shards)]
+    assert counts[0] == block and counts[1] == 60_000 - block and sum(counts[2:]) == 0, counts
+    t0 = many.getTuning("ticket_searches")
+    for q in queries[8:14]:
+        for k in (10, 100):
+            same_search(one, many, q, k)
+    assert many.getTuning("ticket_searches") - t0 == 12
+    assert one.serialize() == many.serialize()
+    one.close(), many.close()
+
+
+@pytest.mark.parametrize("shards", [2, 5])
+def test_ticket_path_equals_device_gather(wax, shards):
+    """Round 5 default for single queries on a sharded handle: per-shard tickets submitted side by side by the persistent
+    workers + a host merge by key ("ticket_path" = 1) against the round-2 device gather (0): identical ids and scores for every k
+    class (k-way merge in the scan kernel, wave lists, general selection beyond 192), pipelined tickets, concurrent callers."""
+    dims, n = 384, 40_000
+    one, many = pair(wax, 0, dims, shards)
+    corpus = oracle.gaussian_unit_rows(9, n, dims)
+    corpus[1000:1040] = corpus[999]                                  # a 41-fold exact tie inside the first shard
+    corpus[n // shards - 3:n // shards + 3] = corpus[7]              # and a 7-fold one across the first shard boundary
+    ids = np.arange(n, dtype=np.uint64) + 11
+    for eng in (one, many):
+        eng.reserve(n)
+        eng.addBatch(ids, corpus)
+    queries = np.concatenate([oracle.gaussian_unit_queries(10, dims, seed=5), corpus[[7, 999]]])
+    got = {}
+    for mode in (1, 0):
+        many.setTuning("ticket_path", mode)
+        res = []
+        for q in queries:
+            for k in (1, 10, 64, 65, 192, 193, 700):
+                a, b = one.searchArrays(q, k), many.searchArrays(q, k)
+                assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (mode, k)
+                res.append(b)
+        # six tickets in flight from one thread
+        tickets = [many.submit(q, 10) for q in queries[:6]]
+        for t, q in zip(tickets, queries[:6]):
+            r = many.collect(t, 10)
+            e = one.searchArrays(q, 10)
+            assert np.array_equal(r[0], e[0]) and np.array_equal(r[1], e[1])
+        got[mode] = res
+    assert many.getTuning("ticket_searches") > 0
+    many.setTuning("ticket_path", 1)
+    errors = []
+
+    def worker(seed):
+        try:
+            rng = np.random.default_rng(seed)
+            for _ in range(40):
+                q = queries[rng.integers(len(queries))]
+                k = int(rng.choice([1, 10, 100, 300]))
+                a, b = one.searchArrays(q, k), many.searchArrays(q, k)
+                assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        except Exception as ex:  # noqa: BLE001
+            errors.append(ex)
+    ts = [threading.Thread(target=worker, args=(s,)) for s in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors[:1]
     one.close(), many.close()

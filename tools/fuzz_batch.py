@@ -5,6 +5,8 @@ size, dimension, metric, k, batch size, row_base, clustered / duplicated rows. E
 --sharded P: with probability P a trial ALSO loads the rows into a sharded handle (2-5 shards, all on GPU 0) and demands that
 its batched answer (host buffers, and two device-resident tickets in flight) equals the single engine's hit for hit."""
 import argparse
+import os
+os.environ.setdefault("WAX_HIP_SHARD_MIN_MB", "0")   # sharded handles of the fuzz spread their (small) stores over every shard
 import json
 import os
 import sys

@@ -1,0 +1,24 @@
+#!/bin/bash
+# round 5, GPU session 4: pp kernel MODE 4 (rega 11: early half multiplies first, requests behind its K loop) against MODE 0 (rega 9)
+# and the round-4 kernels (rega 5); read-ahead variants (debug 256 = deeper, 512 = 2); sharded handle: new tests + fan-out bench part A
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/r05_s4
+mkdir -p "$OUT"; cd "$R"; export TMPDIR=/tmp
+timeout 300 python -m pytest tests/test_parity_gpu.py -m gpu -q -x -p no:cacheprovider --timeout 300 -k "variants_agree" > "$OUT/pytest_variants.log" 2>&1
+echo "pytest rc $?" >> "$OUT/pytest_variants.log"; tail -3 "$OUT/pytest_variants.log"
+timeout 600 python tools/batch_bench.py --rows 1250000 --dims 768 --nq 1024 --reps 5 --rega 5 9 11 5 9 11 > "$OUT/bench768.jsonl" 2> "$OUT/bench768.err"
+timeout 600 python tools/batch_bench.py --rows 1250000 --dims 768 --nq 1024 --reps 5 --rega 9 11 --debug 256 512 16 32 >> "$OUT/bench768.jsonl" 2>> "$OUT/bench768.err"
+timeout 600 python tools/batch_bench.py --rows 1000000 --dims 384 --nq 256 1024 --reps 5 --rega 5 9 11 5 9 11 > "$OUT/bench384.jsonl" 2> "$OUT/bench384.err"
+timeout 600 python tools/batch_bench.py --rows 1000000 --dims 384 --nq 256 1024 --reps 5 --rega 11 --debug 256 >> "$OUT/bench384.jsonl" 2>> "$OUT/bench384.err"
+python - "$OUT/bench768.jsonl" "$OUT/bench384.jsonl" <<'PY' | tee "$OUT/summary.txt"
+import json, sys
+for f in sys.argv[1:]:
+    for l in open(f):
+        try: d = json.loads(l)
+        except Exception: continue
+        print(d["dims"], d["rows"], "nq", d["nq"], "rega", d["rega"], "dbg", d["debug"], "gemm_us %.1f" % d["gemm_kernel_us"], "dev_call_ms %.4f" % d["ms_device_call"], "fb", d["fallbacks_rank0"], d["result_checksum"])
+PY
+timeout 900 python -m pytest tests/test_sharded_engine_gpu.py -m gpu -q -x -p no:cacheprovider --timeout 300 > "$OUT/pytest_sharded.log" 2>&1
+echo "pytest rc $?" >> "$OUT/pytest_sharded.log"; tail -15 "$OUT/pytest_sharded.log"
+timeout 300 python tools/sharded_handle_bench.py --parts A > "$OUT/fanout_A.jsonl" 2> "$OUT/fanout_A.err"; cat "$OUT/fanout_A.jsonl"; tail -3 "$OUT/fanout_A.err"

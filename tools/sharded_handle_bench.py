@@ -34,8 +34,10 @@ torch.cuda.set_device(0)
 G = args.shards
 
 
-def load(rows, dims, devices=None):
+def load(rows, dims, devices=None, pre=()):
     eng = wax.HIPVectorEngine(dimensions=dims) if devices is None else wax.HIPVectorEngine(dimensions=dims, devices=devices)
+    for k, v in pre:                     # handle-level settings that must be in place before the layout is chosen
+        eng.setTuning(k, v)
     eng.reserve(rows)
     for r0, x in bench.device_rows(torch, 0, rows, dims, dev):
         eng.addBatchDevice(np.arange(r0, r0 + x.shape[0], dtype=np.uint64), x)
@@ -92,15 +94,26 @@ parts = args.parts.split(",")
 if "A" in parts:
     dims, per = 384, 2000
     queries = bench.unit_queries(2000, dims)
-    one, many = load(per * G, dims), load(per * G, dims, [0] * G)
-    for e in (one, many):
-        e.setTuning("streams", 2)
-        e.setTuning("slots", 4)
-    for depth in (1, 4):
-        a, b = time_single(one, queries, 10, depth, 2000), time_single(many, queries, 10, depth, 2000)
-        print(json.dumps({"part": "A", "what": f"tiny corpus ({per} rows x {G} shards), single query, depth {depth}", "one_engine_us": a * 1e6,
-                          "sharded_handle_us": b * 1e6, "fanout_us_per_query": (b - a) * 1e6, "per_shard_us": (b - a) * 1e6 / G}), flush=True)
-    one.close(), many.close()
+    one = load(per * G, dims)
+    one.setTuning("streams", 2)
+    one.setTuning("slots", 4)
+    # the fan-out proper (small-store rule off: the 24 MB store IS spread over the G shards), round-4 device gather against the
+    # round-5 per-shard tickets submitted side by side; and the default (rule on: the store stays on the first shard)
+    for label, pre, post in (("spread, device gather (round 4)", (("shard_min_mb", 0),), (("ticket_path", 0),)),
+                             ("spread, per-shard tickets (round 5)", (("shard_min_mb", 0),), (("ticket_path", 1),)),
+                             ("default (small-store rule: one shard holds it)", (), ())):
+        many = load(per * G, dims, [0] * G, pre)
+        many.setTuning("streams", 2)
+        many.setTuning("slots", 4)
+        for k, v in post:
+            many.setTuning(k, v)
+        for depth in (1, 4):
+            a, b = time_single(one, queries, 10, depth, 2000), time_single(many, queries, 10, depth, 2000)
+            print(json.dumps({"part": "A", "what": f"tiny corpus ({per} rows x {G} shards), single query, depth {depth}: {label}", "one_engine_us": a * 1e6,
+                              "sharded_handle_us": b * 1e6, "fanout_us_per_query": (b - a) * 1e6, "per_shard_us": (b - a) * 1e6 / G,
+                              "rows_per_shard": [many.shardInfo(g)[2] for g in range(G)]}), flush=True)
+        many.close()
+    one.close()
 if "B" in parts:
     dims, n = 384, args.rows
     queries = bench.unit_queries(300, dims)

@@ -1531,9 +1531,10 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_wide_kernel(GemmArgs a, uin
 // PING = false keeps one barrier per tile and the early / late order of the wide kernel (A/B of item 1 alone).
 template <int D, int TROWS, int NBUF, int AHEAD, bool SAMPLE = false, int MODE = 2>
 __global__ __launch_bounds__(512, 2) void batch_gemm_pp_kernel(GemmArgs a, uint32_t blocks_per_group) {
-    constexpr bool PING = MODE >= 1;                 // two barriers per tile, the halves half a period apart
-    constexpr bool LATE_DMA = MODE >= 2;             // only waves 4-7 request tiles; the late half's fragment ring is primed ahead of the MID barrier
+    constexpr bool PING = MODE >= 1 && MODE <= 3;    // two barriers per tile, the halves half a period apart
+    constexpr bool LATE_DMA = MODE == 2 || MODE == 3;   // only waves 4-7 request tiles; the late half's fragment ring is primed ahead of the MID barrier
     constexpr bool EARLY_HEAD = MODE == 2;           // ... and the early half's ahead of the END barrier (its ring is then live around the loop)
+    constexpr bool EARLY_DMA_AFTER = MODE == 4;      // one barrier per tile; the early half multiplies FIRST and requests tile t + PRE behind its K loop
     constexpr int KS = D / 16;                       // MFMA k-steps
     constexpr int RB = TROWS / 32;                   // 32-row blocks per tile = accumulators per wave
     constexpr int NF = KS * RB;                      // B fragments (= MFMAs) per wave and tile; fragment f = (k-step f / RB, block f % RB)
@@ -1613,6 +1614,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_pp_kernel(GemmArgs a, uint3
         }
     };
     auto dma_tile = [&](uint32_t tile, uint32_t buf_off) {
+        if (a.debug & 1u) return;                    // timing only: no corpus stream (the K loop reads whatever is in LDS)
         const uint32_t row0 = a.slab0 + phys(tile) * TROWS;
 #pragma unroll
         for (int i = 0; i < PPWD; ++i) dma_piece(i, row0, buf_off);
@@ -1641,6 +1643,12 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_pp_kernel(GemmArgs a, uint3
     };
     auto mfma_body = [&](uint32_t baddr) {
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (a.debug & 2u) {                          // timing only: no K loop (the ring's head is retired, the accumulators defined)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int b = 0; b < RB; ++b) acc[b] = zero16;
+            return;
+        }
         if (prio) __builtin_amdgcn_s_setprio(1);
         __builtin_amdgcn_sched_barrier(0);
         static_for<0, NF>([&](auto F) {
@@ -1823,6 +1831,22 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_pp_kernel(GemmArgs a, uint3
                 asm volatile("" ::: "memory");
                 mfma_tile(baddr);
                 dma_wait(issued);
+            }
+        } else if (EARLY_DMA_AFTER) {
+            // Behind the barrier the early half goes straight into its K loop (the matrix pipe is busy at once) while the late half
+            // selects tile t - 1 and requests its pieces of tile t + PRE in the shadow of those MFMAs; the early half requests its
+            // pieces, waits and selects behind its K loop, in the shadow of the late half's.
+            if (late) {
+                if (it > 0) select_tile(t_prev);
+                if (issued) dma_tile(tn, pre_idx * BUF_B);
+                mfma_tile(baddr);
+                dma_wait(issued);
+            } else {
+                mfma_tile(baddr);
+                pace(it);
+                if (issued) dma_tile(tn, pre_idx * BUF_B);
+                dma_wait(issued);
+                select_tile(t);
             }
         } else {
             pace(it);
@@ -2337,16 +2361,18 @@ hipError_t launch_batch_gemm(const GemmArgs& a, int metric, hipStream_t st) {
                 default: return launch_w4<384>(a, st);
             }
         }
-        if (a.use_rega >= 8u && a.use_rega <= 10u) {   // round 5: 8 = ping-pong, late-half DMA, prefetched heads; 9 = asm-read fix alone; 10 = plain ping-pong
+        if (a.use_rega >= 8u && a.use_rega <= 11u) {   // round 5: 8 = ping-pong, late-half DMA, prefetched heads; 9 = asm-read fix alone; 10 = plain ping-pong
             const uint32_t v = (a.debug >> 8) & 3u;   // timing experiments: read-ahead depth
             if (a.dims == 768) {
                 if (a.use_rega == 8u) return v == 1u ? launch_pp<768, 32, 3, 4, 3>(a, st) : v == 2u ? launch_pp<768, 32, 3, 2, 3>(a, st) : launch_pp<768, 32, 3, 3, 3>(a, st);
                 if (a.use_rega == 10u) return launch_pp<768, 32, 3, 3, 1>(a, st);
-                return launch_pp<768, 32, 3, 3, 0>(a, st);
+                if (a.use_rega == 11u) return v == 1u ? launch_pp<768, 32, 3, 4, 4>(a, st) : v == 2u ? launch_pp<768, 32, 3, 2, 4>(a, st) : launch_pp<768, 32, 3, 3, 4>(a, st);
+                return v == 1u ? launch_pp<768, 32, 3, 4, 0>(a, st) : v == 2u ? launch_pp<768, 32, 3, 2, 0>(a, st) : launch_pp<768, 32, 3, 3, 0>(a, st);
             }
             if (a.dims == 384) {
                 if (a.use_rega == 8u) return v == 1u ? launch_pp<384, 64, 3, 6, 2>(a, st) : v == 2u ? launch_pp<384, 64, 3, 3, 3>(a, st) : launch_pp<384, 64, 3, 3, 2>(a, st);
                 if (a.use_rega == 10u) return launch_pp<384, 64, 3, 3, 1>(a, st);
+                if (a.use_rega == 11u) return v == 1u ? launch_pp<384, 64, 3, 6, 4>(a, st) : launch_pp<384, 64, 3, 3, 4>(a, st);
                 return launch_pp<384, 64, 3, 3, 0>(a, st);
             }
         }
