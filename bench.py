@@ -536,6 +536,68 @@ def secondary_single_query(torch, dev, rows, dims, k, steps, warmup, depth, labe
     }
 
 
+def _load_handle(torch, devs, rows, dims):
+    """A sharded handle (one process, the library's multi-GPU engine) holding `rows` rows of the bench corpus: the library
+    chooses the block layout (even spread, but never less than "shard_min_mb" of rows per block: a small store stays on the
+    first device); every granule is generated on the device whose shard takes it."""
+    from wax_amd import HIPVectorEngine, VectorMetric
+    eng = HIPVectorEngine(metric=VectorMetric.cosine, dimensions=dims, devices=devs)
+    eng.reserve(rows)
+    per = int(eng.getTuning("block_rows"))
+    r = 0
+    while r < rows:
+        g_ = min(r // per, len(devs) - 1)
+        gdev = torch.device("cuda", devs[g_])
+        r_hi = min(rows, (r // GRANULE + 1) * GRANULE, (g_ + 1) * per if g_ + 1 < len(devs) else rows)
+        for r0, x in device_rows(torch, r, r_hi, dims, gdev):
+            eng.addBatchDevice(np.arange(r0, r0 + x.shape[0], dtype=np.uint64), x)
+        r = r_hi
+    for d_ in set(devs):
+        torch.cuda.synchronize(d_)
+    return eng
+
+
+def handle_exchange(eng, args, n_devices):
+    """One-process shape: which exchange the handle uses, and the loud check that RCCL really spans the devices."""
+    if args.exchange == "rccl" and not os.environ.get("WAX_BENCH_SAME_DEVICE"):
+        eng.setTuning("exchange", 1)        # one ncclAllGather per query on the library's single-process communicator
+        ranks = int(eng.getTuning("rccl_ranks"))
+        if ranks != n_devices:
+            raise SystemExit(f"[bench] --exchange rccl over {n_devices} devices, but the library's communicator has {ranks} ranks")
+        return 1, ranks
+    return 0, 0
+
+
+def handle_single_query(torch, args, devs, rows, dims, k, steps, warmup, label):
+    """The N-matrix points (N in {10K, 1M} x 384) in the ONE-PROCESS shape (`python bench.py --gpus N`): the same sharded handle
+    as the headline at another corpus size. A store below the small-store threshold is not spread (rows_per_gpu shows it)."""
+    eng = _load_handle(torch, devs, rows, dims)
+    apply_tunes(eng)
+    exchange_mode, rccl_ranks = handle_exchange(eng, args, len(devs))
+    eng.setTuning("streams", 2)
+    eng.setTuning("slots", max(args.depth, 2))
+    queries = unit_queries(warmup + steps, dims)
+    per_gpu = [int(eng.shardInfo(g)[2]) for g in range(len(devs))]
+    elapsed, last, kern_ms, launches, cal = measure_single_query(
+        eng, lambda q: eng.submit(q, k), lambda t: eng.collect(t, k), queries, warmup, steps, args.depth, lambda: _bracket(torch))
+    import hashlib
+    checksum = hashlib.sha256(np.asarray(last[0], dtype=np.uint64).tobytes() + np.asarray(last[1], dtype=np.float32).tobytes()).hexdigest()[:16]
+    grid = eng.getTuning("scan_grid")
+    tickets, single = int(eng.getTuning("ticket_searches")), int(eng.getTuning("single_shard_searches"))
+    eng.close()
+    rf = scan_roofline(max(per_gpu) * dims * 4, kern_ms, launches, elapsed, steps, cal)
+    rf["scan_grid"] = grid
+    return {
+        "config": f"{rows} x {dims} f32 cosine top-{k}, one query per step, ONE process, sharded handle over {len(devs)} device(s), "
+                  f"rows per device {per_gpu} ({label})",
+        "value": steps / elapsed, "unit": "queries/s", "n_gpus": len(devs), "steps": steps, "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3, "dtype": "f32", "rows_per_gpu": per_gpu, "last_result_checksum": checksum,
+        "exchange": "rccl" if exchange_mode == 1 else ("one device" if single else "per-shard tickets, host merge"),
+        "rccl_ranks": rccl_ranks, "ticket_searches": tickets, "single_shard_searches": single,
+        "roofline": rf,
+    }
+
+
 def sharded_single_query(torch, dist, args, rank, world, local_rank, use_rccl, rows, dims, k, steps, warmup, label):
     """The N-matrix points (N in {10K, 1M} x 384) at world > 1: the headline's sharded single-query path — every rank scans
     its row shard, per-shard top-k all-gathered (RCCL) and merged per query — at another corpus size. Same bracket as the
@@ -751,18 +813,8 @@ def config5_sharded(torch, dist, args, rank, world, in_library, use_rccl, k=10, 
         n_sh = args.gpus
         devs = [0 if same else g for g in range(n_sh)]
         dev0 = torch.device("cuda", devs[0])
-        from wax_amd import HIPVectorEngine, VectorMetric
-        eng = HIPVectorEngine(metric=VectorMetric.cosine, dimensions=dims, devices=devs)
-        eng.reserve(rows)
-        per = -(-rows // n_sh)
-        per = -(-per // 64) * 64
-        r = 0
-        while r < rows:
-            g_ = min(r // per, n_sh - 1)
-            r_hi = min(rows, (r // GRANULE + 1) * GRANULE, (g_ + 1) * per if g_ + 1 < n_sh else rows)
-            for r0, x in device_rows(torch, r, r_hi, dims, torch.device("cuda", devs[g_])):
-                eng.addBatchDevice(np.arange(r0, r0 + x.shape[0], dtype=np.uint64), x)
-            r = r_hi
+        eng = _load_handle(torch, devs, rows, dims)
+        per = max(int(eng.shardInfo(g)[2]) for g in range(n_sh))
         rows_per_gpu = per
         dev = dev0
     else:
@@ -907,6 +959,10 @@ def compact_line(full):
         e["ck"] = x.get("last_result_checksum")          # equal at every N / launch shape for the same workload
         if x.get("n_gpus", 1) != 1:
             e["n_gpus"] = x["n_gpus"]
+            if "rows_per_gpu" in x:
+                e["rows_per_gpu"] = x["rows_per_gpu"]
+            if x.get("rccl_ranks"):
+                e["rccl_ranks"] = x["rccl_ranks"]
         if "ms_per_step_blocking_call" in x:
             e["blocking_ms"] = _r(x["ms_per_step_blocking_call"], 4)
         sec.append(e)
@@ -991,21 +1047,9 @@ def main():
     if in_library:
         same = bool(os.environ.get("WAX_BENCH_SAME_DEVICE"))          # testing only: every shard on GPU 0
         devs = [0 if same else g for g in range(args.gpus)]
-        eng = HIPVectorEngine(metric=VectorMetric.cosine, dimensions=dims, devices=devs)
-        eng.reserve(n)                                                 # block layout: ceil(n / N) rows per shard
-        per = -(-n // args.gpus)
-        per = -(-per // 64) * 64
-        r = 0
-        while r < n:                                                   # every granule is generated on the device that will hold it
-            g_ = min(r // per, args.gpus - 1)
-            gdev = torch.device("cuda", devs[g_])
-            r_hi = min(n, (r // GRANULE + 1) * GRANULE, (g_ + 1) * per if g_ + 1 < args.gpus else n)
-            for r0, x in device_rows(torch, r, r_hi, dims, gdev):
-                eng.addBatchDevice(np.arange(r0, r0 + x.shape[0], dtype=np.uint64), x)
-            r = r_hi
-        for d_ in set(devs):
-            torch.cuda.synchronize(d_)
-        lo, hi = 0, -(-n // args.gpus)                                  # rows per launch of ONE shard's scan kernel (roofline)
+        eng = _load_handle(torch, devs, n, dims)                       # block layout chosen by the library (ceil(n / N) rows per shard at this size)
+        shard_rows = [int(eng.shardInfo(g)[2]) for g in range(args.gpus)]
+        lo, hi = 0, max(shard_rows)                                     # rows per launch of ONE shard's scan kernel (roofline)
     else:
         eng = HIPVectorEngine(metric=VectorMetric.cosine, dimensions=dims)
         eng.reserve(max(hi - lo, 1))
@@ -1026,8 +1070,10 @@ def main():
         probe = x[0].cpu().numpy()
 
     apply_tunes(eng)
-    if in_library and args.exchange == "rccl" and not os.environ.get("WAX_BENCH_SAME_DEVICE"):
-        eng.setTuning("exchange", 1)        # one ncclAllGather per query on the library's single-process communicator
+    if in_library:
+        handle_exchange(eng, args, args.gpus)   # --exchange rccl: one ncclAllGather per query on the library's communicator, N ranks or no run
+    elif world > 1 and use_rccl and dist.get_world_size() != world:
+        raise SystemExit(f"[bench] --exchange rccl: the process group has {dist.get_world_size()} ranks, expected {world}")
     if world == 1:
         # two in-order streams: one query's merge / result write / next query upload hide under the neighbouring scan,
         # and (product mode) neighbouring scans overlap each other's ramp and tail
@@ -1129,15 +1175,15 @@ def main():
                 "workload": f"{n} x {dims}-dim f32 unit-norm Gaussian corpus (seed {CORPUS_SEED}), cosine top-{k}, "
                             f"one query per step, corpus resident in HBM and row-sharded over {n_gpus} GPU(s)",
                 "workload_short": f"{_human_rows(n)} x {dims} f32 unit-Gaussian corpus in HBM, cosine top-{k}, 1 query/step",
-                "rows": n, "dims": dims, "top_k": k, "rows_per_gpu": hi - lo,
+                "rows": n, "dims": dims, "top_k": k, "rows_per_gpu": (shard_rows if in_library else hi - lo),
                 # how many ranks the collective library actually joined (torchrun shape: dist world size after the all_reduce
                 # probe; one-process shape: the library's ncclCommCount when its RCCL exchange is on, else 1 = peer copies)
                 "rccl_ranks": rccl_ranks, "shards": n_gpus,
-                "parallelism_short": (f"row-shard x{n_gpus} one-process " + ("rccl" if exchange_mode == 1 else "peer-copy")) if in_library
+                "parallelism_short": (f"row-shard x{n_gpus} one-process " + ("rccl" if exchange_mode == 1 else "tickets+host-merge")) if in_library
                                      else (f"row-shard x{world}" + ((" rccl all_gather" if use_rccl else " gloo all_gather") if world > 1 else "")),
                 "parallelism": (f"row-shard x{args.gpus}, ONE process: the library's multi-GPU engine (wax_hip_engine_create_sharded), "
-                                + ("single-process RCCL all-gather" if exchange_mode == 1 else "peer-copy gather")
-                                + " of per-shard top-k + merge on the first device") if in_library else
+                                + ("single-process RCCL all-gather of per-shard top-k + merge on the first device" if exchange_mode == 1 else
+                                   "per-shard tickets submitted side by side (one launch per shard, hits straight to pinned memory) + host merge by key")) if in_library else
                                (f"row-shard x{world}" + ((" + RCCL all-gather of per-shard top-k" if use_rccl else
                                                           " + host (gloo) all-gather of per-shard top-k") if world > 1 else "")),
                 "pipeline_depth": args.depth,
@@ -1227,6 +1273,22 @@ def main():
                         r = sharded_single_query(torch, dist, args, rank, world, local_rank, use_rccl, rows_, 384, k, steps_, warm_, label)
                         r["name"] = name
                         sec.append(r)
+                    except Exception as ex:  # noqa: BLE001
+                        sec.append({"name": name, "error": f"{type(ex).__name__}: {ex}"})
+            if in_library:
+                same_dev = bool(os.environ.get("WAX_BENCH_SAME_DEVICE"))
+                devs_ = [0 if same_dev else g for g in range(args.gpus)]
+                for name, rows_, steps_, warm_, label in (
+                        ("s1m", 1_000_000, max(args.steps, 600), max(args.warmup, 50), "N matrix: 1M rows; BASELINE config 2's corpus over the node"),
+                        ("s10k", 10_000, max(args.steps, 2000), max(args.warmup, 100), "N matrix: 10K rows — a 15 MB store is not spread (small-store rule)")):
+                    if args.secondary != "all" and name not in want:
+                        continue
+                    try:
+                        r = handle_single_query(torch, args, devs_, rows_, 384, k, steps_, warm_, label)
+                        r["name"] = name
+                        sec.append(r)
+                    except SystemExit:
+                        raise
                     except Exception as ex:  # noqa: BLE001
                         sec.append({"name": name, "error": f"{type(ex).__name__}: {ex}"})
             if args.secondary == "all" or "c5" in want:

@@ -898,12 +898,18 @@ def test_bench_contract_and_shard_invariance(wax, tmp_path):
     # config 5 at N > 1, both launch shapes: ranks + all-gather, and one process on the sharded handle — same hits as one engine
     for run, shape in ((two, "ranks"), (three, "ranks"), (lib3, "handle")):
         c5 = run["secondary"]
-        if shape == "ranks":
-            # the rest of the N matrix (1M and 10K rows) on the sharded single-query path: same last answer as one engine
-            assert [x["name"] for x in c5] == ["s1m", "s10k", "c5"] and all("error" not in x for x in c5), c5
-            for x, ref in ((c5[0], sec[1]), (c5[1], sec[0])):
-                assert x["n_gpus"] == run["n_gpus"] and x["value"] > 0 and x["last_result_checksum"] == ref["last_result_checksum"], (x, ref)
-            c5 = c5[2:]
+        # the rest of the N matrix (1M and 10K rows) on the sharded single-query path, in BOTH launch shapes (round 5: also the
+        # one-process shape a driver is most likely to run): same last answer as one engine
+        assert [x["name"] for x in c5] == ["s1m", "s10k", "c5"] and all("error" not in x for x in c5), c5
+        for x, ref in ((c5[0], sec[1]), (c5[1], sec[0])):
+            assert x["n_gpus"] == run["n_gpus"] and x["value"] > 0 and x["last_result_checksum"] == ref["last_result_checksum"], (x, ref)
+        if shape == "handle":
+            assert c5[0]["rows_per_gpu"] == [333376, 333376, 333248] and c5[0]["ticket_searches"] > 0, c5[0]       # 1M rows: spread
+            assert c5[1]["rows_per_gpu"] == [10000, 0, 0] and c5[1]["single_shard_searches"] > 0, c5[1]             # 15 MB: one device
+            assert [e_["name"] for e_ in run["_line"]["secondary"]] == ["s1m", "s10k", "c5"]
+            assert run["_line"]["secondary"][1]["rows_per_gpu"] == [10000, 0, 0]
+            assert run["config"]["rows_per_gpu"] == [100032, 100032, 99936]
+        c5 = c5[2:]
         assert len(c5) == 1 and c5[0]["name"] == "c5" and "error" not in c5[0], c5
         assert c5[0]["n_gpus"] == run["n_gpus"] and c5[0]["queries_per_step"] == 1024 and c5[0]["value"] > 0
         assert c5[0]["last_result_checksum"] == c5_one, (shape, run["n_gpus"])

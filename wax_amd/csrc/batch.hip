@@ -1535,6 +1535,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_pp_kernel(GemmArgs a, uint3
     constexpr bool LATE_DMA = MODE == 2 || MODE == 3;   // only waves 4-7 request tiles; the late half's fragment ring is primed ahead of the MID barrier
     constexpr bool EARLY_HEAD = MODE == 2;           // ... and the early half's ahead of the END barrier (its ring is then live around the loop)
     constexpr bool EARLY_DMA_AFTER = MODE == 4;      // one barrier per tile; the early half multiplies FIRST and requests tile t + PRE behind its K loop
+    constexpr bool SPLIT = MODE == 5;                // one SPLIT barrier per tile (arrive behind the K loop, wait in front of the next): selection between the two
     constexpr int KS = D / 16;                       // MFMA k-steps
     constexpr int RB = TROWS / 32;                   // 32-row blocks per tile = accumulators per wave
     constexpr int NF = KS * RB;                      // B fragments (= MFMAs) per wave and tile; fragment f = (k-step f / RB, block f % RB)
@@ -1554,6 +1555,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_pp_kernel(GemmArgs a, uint3
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned int* cnt_s = reinterpret_cast<unsigned int*>(smem + NBUF * BUF_B);    // [8][32] survivors per query (this workgroup; written once, at the end)
     float* sim_s = reinterpret_cast<float*>(cnt_s + 8 * 32);                       // [8][32] conservative similarity bounds
+    unsigned int* sync_s = reinterpret_cast<unsigned int*>(sim_s + 8 * 32);        // SPLIT: [0] arrivals, [1] "a wave gave up waiting"
 
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
@@ -1578,6 +1580,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_pp_kernel(GemmArgs a, uint3
         const float tq = a.tau[q0 + lane];
         sim_s[wave * 32 + lane] = (1.0f - tq) - 4e-7f * (1.0f + __builtin_fabsf(tq));   // see batch_gemm_rega_kernel
     }
+    if (SPLIT && tid < 2) sync_s[tid] = 0u;
     const uint32_t seg_slots = a.seg_area / blocks_per_group;
     const uint32_t seg_lane0 = (q0 + 4u * ((uint32_t)lane >> 5)) * a.cand_cap + a.seg_base + bidx * seg_slots;
 
@@ -1613,11 +1616,51 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_pp_kernel(GemmArgs a, uint3
             __builtin_amdgcn_global_load_lds((global_cvoid*)src, (lds_void*)(smem + buf_off + P * 1024u), 16, 0, 0);
         }
     };
+    // Filtering launch: no clamps. A pad slot fetches the first 16 bytes of the next row, the slack behind the image the row after the
+    // tile, a tile that runs past the store whatever the mirror holds there — all of it inside the mirror's allocation (capacity + 64
+    // slack rows, ensure_mirror) and none of it ever used (pad bytes are never read as fragments, rows >= slab_end are masked by the
+    // selection; a garbage row only pollutes its own output column). Then slot -> global offset is 16 * (slot - slot / SLOTS_PER_ROW)
+    // from a uniform tile base: a multiply, a shift, a subtract and a shift per piece (the general form above costs ~14 VALU plus
+    // the spilled-SGPR traffic of its clamps).
+    constexpr uint32_t DIV_SHIFT = 18, DIV_MAGIC = ((1u << DIV_SHIFT) + SLOTS_PER_ROW - 1) / SLOTS_PER_ROW;
+    static_assert((uint64_t)(PIECES * 64) * (DIV_MAGIC * (uint64_t)SLOTS_PER_ROW - (1u << DIV_SHIFT)) < (1u << DIV_SHIFT),
+                  "magic division must be exact for every slot of a tile");
+    // Where the A fragments leave room (D <= 512) the per-piece offsets are computed once and stay in VGPRs: a request is then ONE
+    // instruction (saddr form: uniform tile base + the lane's 32-bit offset).
+    constexpr bool CACHE_OFF = !SAMPLE && D <= 512;
+    uint32_t doff[CACHE_OFF ? PPWD : 1];
+    if (CACHE_OFF) {
+#pragma unroll
+        for (int i = 0; i < PPWD; ++i) {
+            const uint32_t slot = ((uint32_t)(dwave < 0 ? 0 : dwave) + (uint32_t)DW * (uint32_t)i) * 64u + (uint32_t)lane;
+            doff[i] = (slot - ((slot * DIV_MAGIC) >> DIV_SHIFT)) * 16u;
+        }
+    }
     auto dma_tile = [&](uint32_t tile, uint32_t buf_off) {
         if (a.debug & 1u) return;                    // timing only: no corpus stream (the K loop reads whatever is in LDS)
-        const uint32_t row0 = a.slab0 + phys(tile) * TROWS;
+        if (SAMPLE) {
+            const uint32_t row0 = a.slab0 + phys(tile) * TROWS;
 #pragma unroll
-        for (int i = 0; i < PPWD; ++i) dma_piece(i, row0, buf_off);
+            for (int i = 0; i < PPWD; ++i) dma_piece(i, row0, buf_off);
+            return;
+        }
+        const unsigned char* tbase = cbase + (size_t)(a.slab0 + tile * TROWS) * (D * 2);   // wave-uniform
+#pragma unroll
+        for (int i = 0; i < PPWD; ++i) {
+            if (i < PPWD - 1 || full_wave) {
+                const uint32_t P = (uint32_t)dwave + (uint32_t)DW * (uint32_t)i;
+                uint32_t off;
+                if constexpr (CACHE_OFF) {
+                    off = doff[i];
+                } else {
+                    uint32_t lane_o = (uint32_t)lane;
+                    asm volatile("" : "+v"(lane_o));  // (recomputed per piece: no per-piece VGPRs live around the tile loop)
+                    const uint32_t slot = P * 64u + lane_o;
+                    off = (slot - ((slot * DIV_MAGIC) >> DIV_SHIFT)) * 16u;
+                }
+                __builtin_amdgcn_global_load_lds((global_cvoid*)(tbase + off), (lds_void*)(smem + buf_off + P * 1024u), 16, 0, 0);
+            }
+        }
     };
     // this wave's DMA requests still allowed in flight: PRE - 1 whole tiles, or none
     auto dma_wait = [&](bool keep) {
@@ -1776,6 +1819,23 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_pp_kernel(GemmArgs a, uint3
             }
         }
     };
+    // SPLIT: bounded spin on the arrival counter (a wave that gives up poisons the workgroup's survivor counts, which sends its
+    // queries to the exact path — never a silent wrong answer). The counter is touched through inline assembly only.
+    bool gave_up = SPLIT && (a.debug & 16384u) != 0 && blockIdx.x == 1 && wave == 3;   // debug bit 14: pretend one wave timed out (tests)
+    const unsigned sync_addr = (unsigned)(size_t)(lds_u32*)sync_s;
+    auto wait_arrivals = [&](unsigned int target) {
+        bool ok = false;
+        for (unsigned int spins = 0; spins < (1u << 22); ++spins) {
+            unsigned int v;
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(sync_addr) : "memory");
+            if ((unsigned int)__builtin_amdgcn_readfirstlane((int)v) >= target) { ok = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (!ok) gave_up = true;
+    };
+    auto arrive = [&]() {
+        if (lane == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\tds_add_u32 %0, %1" ::"v"(sync_addr), "v"(1u) : "memory");
+    };
     uint32_t it = 0, cur_idx = 0, t_prev = 0;
     if (EARLY_HEAD && !late && t < ntiles) {                  // tile t is published by the prologue's barrier
         mfma_head(smem_lds + lane_boff);
@@ -1832,6 +1892,20 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_pp_kernel(GemmArgs a, uint3
                 mfma_tile(baddr);
                 dma_wait(issued);
             }
+        } else if (SPLIT) {
+            if (late && it > 0) select_tile(t_prev);
+            // every wave is through K loop it - 1 (the buffer tile tn goes to is free) and has its pieces of tile `it` in LDS
+            if (it > 0) wait_arrivals(8u * it);
+            pace(it);
+            if (issued) dma_tile(tn, pre_idx * BUF_B);
+            mfma_tile(baddr);
+            dma_wait(issued);
+            arrive();
+            if (!late) select_tile(t);
+            t_prev = t;
+            cur_idx = cur_idx + 1 == (uint32_t)NBUF ? 0u : cur_idx + 1;
+            t += blocks_per_group;
+            continue;
         } else if (EARLY_DMA_AFTER) {
             // Behind the barrier the early half goes straight into its K loop (the matrix pipe is busy at once) while the late half
             // selects tile t - 1 and requests its pieces of tile t + PRE in the shadow of those MFMAs; the early half requests its
@@ -1869,6 +1943,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_pp_kernel(GemmArgs a, uint3
     }
     if (late && it > 0) select_tile(t_prev);
     if (gate && tid == 0) __hip_atomic_fetch_add(const_cast<uint32_t*>(gate_word), 1u << 24, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // done: nobody waits for this group
+    if (SPLIT && gave_up && lane == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(sync_addr + 4u), "v"(1u) : "memory");
     if (!SAMPLE) {   // the wave's 32 survivor counters, SGPRs -> LDS: lane q takes query q's
         unsigned mine = 0u;
 #pragma unroll
@@ -1879,7 +1954,10 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_pp_kernel(GemmArgs a, uint3
         if (lane < 32) cnt_s[wave * 32 + lane] = mine == 0xFFFFu ? 0x40000000u : mine;   // saturated = unknown = overflowed
     }
     __syncthreads();
-    if (!SAMPLE && tid < 256) a.seg_count[(size_t)bidx * (a.nqt * 128u) + group * 256u + (uint32_t)tid] = cnt_s[tid];
+    if (!SAMPLE && tid < 256) {
+        const bool poisoned = SPLIT && sync_s[1] != 0u;       // a wave gave up waiting: nothing this workgroup selected can be trusted
+        a.seg_count[(size_t)bidx * (a.nqt * 128u) + group * 256u + (uint32_t)tid] = poisoned ? 0x40000000u : cnt_s[tid];
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -2361,18 +2439,20 @@ hipError_t launch_batch_gemm(const GemmArgs& a, int metric, hipStream_t st) {
                 default: return launch_w4<384>(a, st);
             }
         }
-        if (a.use_rega >= 8u && a.use_rega <= 11u) {   // round 5: 8 = ping-pong, late-half DMA, prefetched heads; 9 = asm-read fix alone; 10 = plain ping-pong
+        if (a.use_rega >= 8u && a.use_rega <= 12u) {   // round 5: 8 = ping-pong, late-half DMA, prefetched heads; 9 = asm-read fix alone; 10 = plain ping-pong
             const uint32_t v = (a.debug >> 8) & 3u;   // timing experiments: read-ahead depth
             if (a.dims == 768) {
                 if (a.use_rega == 8u) return v == 1u ? launch_pp<768, 32, 3, 4, 3>(a, st) : v == 2u ? launch_pp<768, 32, 3, 2, 3>(a, st) : launch_pp<768, 32, 3, 3, 3>(a, st);
                 if (a.use_rega == 10u) return launch_pp<768, 32, 3, 3, 1>(a, st);
-                if (a.use_rega == 11u) return v == 1u ? launch_pp<768, 32, 3, 4, 4>(a, st) : v == 2u ? launch_pp<768, 32, 3, 2, 4>(a, st) : launch_pp<768, 32, 3, 3, 4>(a, st);
-                return v == 1u ? launch_pp<768, 32, 3, 4, 0>(a, st) : v == 2u ? launch_pp<768, 32, 3, 2, 0>(a, st) : launch_pp<768, 32, 3, 3, 0>(a, st);
+                if (a.use_rega == 11u) return launch_pp<768, 32, 3, 3, 4>(a, st);
+                if (a.use_rega == 12u) return launch_pp<768, 32, 3, 3, 5>(a, st);
+                return v == 2u ? launch_pp<768, 32, 3, 2, 0>(a, st) : launch_pp<768, 32, 3, 3, 0>(a, st);
             }
             if (a.dims == 384) {
                 if (a.use_rega == 8u) return v == 1u ? launch_pp<384, 64, 3, 6, 2>(a, st) : v == 2u ? launch_pp<384, 64, 3, 3, 3>(a, st) : launch_pp<384, 64, 3, 3, 2>(a, st);
                 if (a.use_rega == 10u) return launch_pp<384, 64, 3, 3, 1>(a, st);
-                if (a.use_rega == 11u) return v == 1u ? launch_pp<384, 64, 3, 6, 4>(a, st) : launch_pp<384, 64, 3, 3, 4>(a, st);
+                if (a.use_rega == 11u) return launch_pp<384, 64, 3, 3, 4>(a, st);
+                if (a.use_rega == 12u) return v == 1u ? launch_pp<384, 64, 3, 6, 5>(a, st) : launch_pp<384, 64, 3, 3, 5>(a, st);
                 return launch_pp<384, 64, 3, 3, 0>(a, st);
             }
         }

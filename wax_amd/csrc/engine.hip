@@ -1670,7 +1670,7 @@ int wax_hip_engine_create(uint8_t metric, uint32_t dims, int device_id, wax_hip_
     e->dims = dims;
     if (const char* v = std::getenv("WAX_HIP_BATCH_REGA")) {  // default of the "batch_rega" tunable (A/B runs of the whole test suite)
         const long m = std::strtol(v, nullptr, 10);
-        if (m >= 0 && m <= 11) e->batch_rega = m;
+        if (m >= 0 && m <= 12) e->batch_rega = m;
     }
     int rc = resize_store(e, WAX_HIP_INITIAL_RESERVE);  // :225-229
     if (rc == WAX_HIP_OK) {
