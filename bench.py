@@ -663,9 +663,8 @@ def batched_roofline(rows, dims, nq, kern_ms, launches, rega=5, live=None):
             traffic_source = "replayed from profiles/latest_traffic.json (" + tj.get("source", "") + "), not measured in this run"
     except (OSError, ValueError, KeyError):
         pass
-    # D = 768: the wide kernel (whole K per wave, LDS-DMA staging) unless "batch_rega" selects the K-split one (1 / 6 / 7)
-    kernel = (("wax::batch_gemm_ksplit_kernel" if rega in (1, 6, 7) else "wax::batch_gemm_wide_kernel") if dims == 768
-              else "wax::batch_gemm_rega_kernel" if dims in (128, 256, 384, 512) else "wax::batch_gemm_kernel")
+    # the register-resident-queries GEMM where it exists ("batch_rega" 0 = the LDS-tiled kernel everywhere)
+    kernel = "wax::batch_gemm_rq_kernel" if (dims in (128, 256, 384, 512, 768) and rega != 0) else "wax::batch_gemm_kernel"
     # what the kernel's K loop alone (no HBM stream, no selection) sustains on this part with embedding-like operands: the matrix
     # clock is power-limited (tools/mfma_probe.hip; DESIGN.md "The matrix roof"). Informational: `peak` stays the nominal figure.
     sustained = None

@@ -317,63 +317,52 @@ void wax_hip_free(void* p);
 /* ---- observability / tuning --------------------------------------------- */
 
 int wax_hip_stats(wax_hip_engine* e, wax_hip_stats_t* out);
-/* Tunables (all optional): "grid_blocks" (0 = auto), "variant" (scan kernel
- * variant index, -1 = auto), "time_kernels" (1 = bracket the scan kernel with
- * HIP events on its own stream and report last_scan_kernel_ms),
- * "slots" (scratch-slot pool size), "force_general" (1 = use the
- * distance-buffer + radix-select path even for small k), "stream_nt",
- * "reset_stats" (any value: zero the counters), "streams" (1..4 in-order streams the slots rotate over),
- * "batch_mode" (0 = never use the MFMA batched path), "batch_min" (smallest batch that may use it, default 1; below 16 queries a cost model picks
- * the cheaper of one GEMM pass over the bf16 mirror and nq f32 scans),
- * "batch_onepass" (0 = always the slab pipeline), "batch_onepass_tiles" (smallest store, in 64-row GEMM tiles, that the one-pass
- * pipeline takes; default 1024), "batch_survivors" (one-pass: floor of the expected survivors per query as a multiple of k', default 3),
- * "batch_sample_div" (one-pass: 1/this of the tiles are sampled for the thresholds, default 32, at most 512 tiles / 8 tile rounds), "batch_workspaces" (concurrent
- * batched searches per engine, default 4), "batch_retry" (one-pass pipeline: an uncertified query gets a full retry — ALL of its survivors re-scored exactly — before the exact path:
- * 1 (default) = by a device-side kernel behind the finish kernel while recent batches had uncertified queries ("retry_hint" > 0: armed for 16
- * batches by any such query, settable), and driven from the host at collect for whatever is left; 2 = from the host only; 0 = never),
- * "batch_dynamic" (one-pass pipeline: 1 = the filtering GEMM's workgroups claim their tiles from a counter instead of a static
- * stride, so that a workgroup delayed by another batch's kernels does not finish last; measured no faster, default 0; only the
- * workgroup-barrier kernel ("batch_rega" = 1) implements it — the split / free-running barriers of "batch_rega" 5 / 6 / 3 ignore it),
- * "batch_multi" (exact path of a batch: 1 (default) = uncertified queries share passes over the f32 store, up to 16 per pass, with the
- * single-query kernel's arithmetic — bit-identical results; 0 = one scan per query), "fuse_merge" (1 (default) = on grids of at most 160
- * workgroups the scan kernel's last-arriving workgroup does the final merge: one launch per query instead of two),
- * "scan_chain" (pipelined single-query scans of different streams: 1 = chained through an event so that they never overlap and a
- * per-launch duration is one scan alone; 0 = free to overlap: +3 .. +19 % throughput; -1 (default) = chained exactly while "time_kernels" = 1,
- * i.e. the product path overlaps and a measurement pass — bench.py's calibration pass — still times one kernel at a time),
- * "share_timing" (1 = a chained scan whose predecessor is still in flight uses that scan's end-of-kernel event as its own start
- * event: one packet less between scans; 0 = every scan records its own start), "filter_device_min" (wax_hip_search_filtered: allow-lists at least this long are resolved by
- * the device-side id -> row table instead of host probes, default 4096; -1 = never),
- * "merge_kway" (1 (default) = top_k <= 64: the scan kernel's last-arriving workgroup merges the per-workgroup lists by their heads — k
- * rounds of a workgroup-wide minimum, whatever the number of lists — which lets every default grid (<= 512 workgroups) of a store of up to
- * 2 GiB of rows finish in ONE launch; 0 = small grids (<= 160 workgroups) stream the lists through the wave lists, larger ones use the merge kernel),
- * "scan_plain_mb" (query-in-arguments scans: stores of at most this many MB read their rows with ordinary instead of non-temporal loads;
- * default 32: 0.7 - 0.9 us per query faster up to ~30 MB, equal from 60 to 230 MB, slower beyond; -1 = grids of at most 160 workgroups),
- * "query_args" (single-query scans, dims 384 / 768: 1 (default) = a store whose scan merges in its own kernel — the launch-latency-bound
- * ones — gets the query in the kernel arguments instead of an upload copy in front of the scan; 2 = every store; 0 = never),
- * "done_flag" (1 (default) = a scan that merges in the kernel publishes a completion word in pinned memory behind its hits and
- * wax_hip_search_collect polls that word instead of an event recorded behind the kernel; 0 = always an event; never while "time_kernels" = 1),
- * "batch_eps_measured" (1 (default) = the certificate bound of the batched path uses the measured bf16 rounding errors — per query, and
- * the maximum over the rows taken when the mirror is built; 0 = the worst case 2^-7 per product),
- * "batch_kp_fused" (1 (default) = top_k 81 .. 128 on the one-pass pipeline re-scores k' = 192 candidates in the fused finish kernel — the
- * device-side retry behind it settles what that leaves uncertified; 0 = k' = 2k + 32 through the three-launch finish),
- * "batch_slab_mb", "batch_growth", "batch_first" (slab schedule of the slab pipeline), "batch_rega" (0 LDS-tiled GEMM
- * only; 5 (default) register-resident GEMM, register staging, split tile barrier; D = 768: the wide kernel — whole K per wave, LDS-DMA
- * staging, 256 queries per workgroup — unless 1 / 6 / 7 select the K-split kernel (workgroup barrier / split barrier at every size /
- * split barrier below 4 096 tiles per workgroup); 1 the same with a workgroup barrier per tile; 2 LDS-DMA
- * staging; 3 one wave per SIMD; 4 free-running: no tile barrier, three LDS tiles, D <= 384 — a faster kernel alone, slower pipelined
- * because its 150 KB of LDS keep the neighbouring batch's kernels off the CU: DESIGN.md), "batch_debug" (timing experiments:
- * results are NOT valid with bits 1/2/4/8/64/8192 set; bit 16 (65536) makes the device-side retry re-score every survivor instead of only those the first finish cannot exclude (valid); bit 12 (4096) switches the wide 768-d kernel's pace gate off, bits 8-9 select its
- * build variants: all valid). get-only: "variant_count", "scan_grid", "fused_max_k", "batch_queries", "query_args_scans", "merged_scans" (single-query scans that
- * merged in their own kernel), "done_flag_waits",
- * "batch_inline_retries" (queries certified by the device-side retry kernel), "batch_max_row_err_e9",
- * "batch_fallbacks", "onepass_queries", "batch_max_k", "batch_retries", "batch_multi_passes", "batch_multi_queries", "batch_multi_group" /
- * "batch_multi_group_big" (queries per shared exact pass for k <= 60 / k <= 192), "filter_device_searches". Sharded handles: every key above is forwarded to all shards; plus
- * "exchange" (0 peer copies + merge on the first device, 1 RCCL all-gather per query), "gather" (0 = per-shard hits gathered on the
- * first device; 2 = through the host, merged by key there: what a handle falls back to when a device pair lacks peer access) and the
- * get-only "shards", "block_rows", "rebalances", "rccl_collectives", "rccl_ranks" (ncclCommCount of the in-library communicator),
- * "peer_pairs" / "peer_enabled" (device pairs that need / have peer access), "parallel_submits" (batches whose per-shard submits ran on
- * the handle's workers because a submit would have blocked), "parallel_collects" (batched collects whose per-shard exactness ladders
- * ran side by side on the handle's worker threads: chosen when the previous batch had two or more shards settle queries on the host side). */
+/* Tunables (all optional). No key can change an answer: every setting selects between paths that return the same hits.
+ *
+ * single-query scan
+ *   "grid_blocks" (0 = auto), "variant" (scan kernel variant index, -1 = auto), "stream_nt", "force_general" (1 = the distance-buffer +
+ *   radix-select path even for small k), "slots" (scratch-slot pool size), "streams" (1..4 in-order streams the slots rotate over),
+ *   "time_kernels" (1 = bracket the kernels with HIP events on their own stream: wax_hip_stats), "reset_stats" (any value: zero the counters),
+ *   "fuse_merge" (1 (default) = on grids of at most 160 workgroups the scan kernel's last-arriving workgroup does the final merge),
+ *   "merge_kway" (1 (default) = top_k <= 64: that workgroup merges the per-workgroup lists by their heads, which lets every default
+ *   grid of a store of up to 2 GiB of rows finish in ONE launch; 0 = the round-3 rule),
+ *   "query_args" (dims 384 / 768: 1 (default) = a scan that merges in its own kernel takes the query in its kernel arguments; 2 = every
+ *   store; 0 = never), "scan_plain_mb" (such scans read stores of at most this many MB with ordinary instead of non-temporal loads, default 32),
+ *   "done_flag" (1 (default) = such a scan publishes a completion word in coherent pinned memory behind its hits and collect polls it
+ *   instead of an event; never while "time_kernels" = 1),
+ *   "scan_chain" (pipelined scans of different streams: 1 = chained through an event so that a per-launch duration is one scan alone;
+ *   0 = free to overlap; -1 (default) = chained exactly while "time_kernels" = 1), "share_timing" (1 = a chained scan reuses its
+ *   predecessor's end event as its start event),
+ *   "filter_device_min" (wax_hip_search_filtered: allow-lists at least this long are resolved by the id -> row table in HBM, default 4096; -1 = never).
+ * batched queries (bf16 MFMA GEMM + fused selection + exact re-score; exact answers whatever the setting)
+ *   "batch_mode" (0 = never use the MFMA path), "batch_min" (smallest batch that may use it, default 1; below 16 queries a cost model
+ *   picks between one GEMM pass over the bf16 mirror and nq f32 scans), "batch_workspaces" (concurrent batched searches per engine, default 4),
+ *   "batch_rega" (5 (default) = the register-resident-queries GEMM with the split tile barrier; 1 = the same with a workgroup barrier
+ *   per tile; 0 = the LDS-tiled GEMM only), "batch_onepass" (0 = always the slab pipeline), "batch_onepass_tiles" (smallest store, in
+ *   GEMM tiles, that the one-pass pipeline takes; default 1024), "batch_survivors" (floor of the expected survivors per query as a
+ *   multiple of k', default 3), "batch_sample_div" (1 / this of the tiles are sampled for the thresholds, default 32),
+ *   "batch_retry" (an uncertified query gets ALL of its survivors re-scored before the exact path: 1 (default) = by a device-side
+ *   kernel while "retry_hint" > 0 — armed for 16 batches by any such query, settable 0..1024 — and from the host for what is left;
+ *   2 = from the host only; 0 = never), "batch_kp_fused" (1 (default) = top_k 81 .. 128 re-scores k' = 192 candidates in the fused finish kernel),
+ *   "batch_multi" (1 (default) = uncertified queries share passes over the f32 store, up to 16 per pass, bit-identical to the
+ *   single-query kernel), "batch_eps_measured" (1 (default) = the certificate bound uses the measured bf16 rounding errors; 0 = the
+ *   worst case 2^-7 per product), "batch_slab_mb" / "batch_growth" / "batch_first" (slab schedule of the slab pipeline),
+ *   "batch_debug" (test / diagnosis bits: 4096 = no pace gate in the 768-d filtering GEMM, 16384 = one wave of workgroup 1 pretends its
+ *   split-barrier wait timed out (its workgroup's queries take the exact path), 65536 = the device-side retry re-scores every
+ *   survivor; any other bit is refused).
+ * get-only
+ *   "variant_count", "scan_grid", "fused_max_k", "batch_queries", "query_args_scans", "merged_scans", "done_flag_waits",
+ *   "batch_inline_retries", "batch_max_row_err_e9", "batch_fallbacks", "onepass_queries", "batch_max_k", "batch_retries",
+ *   "batch_multi_passes", "batch_multi_queries", "batch_multi_group" / "batch_multi_group_big", "filter_device_searches".
+ * sharded handles: every key above is forwarded to all shards; plus
+ *   "ticket_path" (single queries: 1 (default) = every shard that holds rows answers through its own ticket — one launch per shard,
+ *   submitted side by side by the handle's worker threads, hits straight to pinned memory — and the host merges G x k keys;
+ *   0 = the device gather below), "exchange" (device gather: 0 = peer copies + merge on the first device, 1 = one RCCL all-gather per
+ *   query; 1 implies the device gather), "gather" (0 = device; 2 = through the host: what a handle falls back to when a device pair
+ *   lacks peer access), "shard_min_mb" (a shard's block holds at least this many MB of rows, default 64: a store below it lives on
+ *   the first device only; 0 = spread from the first row; env WAX_HIP_SHARD_MIN_MB sets the default),
+ *   get-only "shards", "block_rows", "rebalances", "rccl_collectives", "rccl_ranks" (ncclCommCount of the in-library communicator),
+ *   "peer_pairs" / "peer_enabled", "ticket_searches" / "single_shard_searches", "parallel_submits", "parallel_collects". */
 int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value);
 int64_t wax_hip_get_tuning(wax_hip_engine* e, const char* key);
 /* Times `iters` back-to-back launches of ONLY the scan kernel for `query`

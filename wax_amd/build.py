@@ -57,6 +57,24 @@ def build(force: bool = False, verbose: bool = False) -> str:
             os.makedirs(obj_dir, exist_ok=True)
             hdr_t = max(os.path.getmtime(h if os.path.isabs(h) else os.path.join(CSRC, h)) for h in HEADERS)
             flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include")]
+            # the object cache is valid for ONE (compiler, flags) pair: a stamp file names it, anything else rebuilds every unit
+            try:
+                ver = subprocess.run([_hipcc(), "--version"], capture_output=True, text=True, check=False).stdout
+            except OSError:
+                ver = ""
+            import hashlib
+            stamp = hashlib.sha256((ver + "\n" + " ".join(flags)).encode()).hexdigest()
+            stamp_path = os.path.join(obj_dir, ".stamp")
+            try:
+                stale = open(stamp_path).read().strip() != stamp
+            except OSError:
+                stale = True
+            if stale:
+                for f_ in os.listdir(obj_dir):
+                    if f_.endswith(".o"):
+                        os.unlink(os.path.join(obj_dir, f_))
+                with open(stamp_path, "w") as sf:
+                    sf.write(stamp)
 
             def compile_one(src):
                 obj = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")

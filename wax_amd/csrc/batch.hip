@@ -13,10 +13,9 @@
 //                        epilogue: an approx distance survives only if it beats its query's running threshold
 //                        tau_q (the k'-th best approx distance over the slabs seen so far). The Q x N score matrix
 //                        is never written: after the first 2K rows ~k' * slab/rows_so_far survivors per query per
-//                        slab. Three kernels:
-//     batch_gemm_rega_kernel    D in {128, 256, 384, 512}, cosine / dot: queries resident in VGPRs as A fragments,
-//                               survivors into per-workgroup segments (no global atomics)
-//     batch_gemm_ksplit_kernel  D = 768: the same with K split over the two waves of a SIMD
+//                        slab. Two kernels:
+//     batch_gemm_rq_kernel      D in {128, 256, 384, 512, 768}, cosine / dot: queries resident in VGPRs as A fragments,
+//                               corpus tiles by LDS-DMA, survivors into per-workgroup segments (no global atomics)
 //     batch_gemm_kernel         everything else (D % 64 == 0, L2, the dense first slab): LDS-tiled 128 x 128
 //   tighten_kernel       per query: best list + survivors -> best k' (sorted), tau_q tightened (between slabs)
 //   rescore_kernel       exact f32 distance of every candidate, SAME lane mapping / summation order
@@ -414,1128 +413,59 @@ __global__ __launch_bounds__(256) void batch_gemm_kernel(GemmArgs a) {
 
 typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
 typedef __attribute__((address_space(3))) unsigned int lds_u32;
-
 typedef __attribute__((address_space(3))) float lds_f32;
 typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
-
-// ---------------------------------------------------------------------------
-// Register-resident-queries GEMM (cosine / dot, D in {128, 256, 384, 512}; every slab after the first).
-//
-// The query block is tiny and reused against every corpus row, so it never goes through LDS: each of
-// the 8 waves of a workgroup keeps its 32 queries x D as MFMA A-fragments in VGPRs for the whole launch
-// (96 VGPRs at D = 384). Only the corpus streams: persistent workgroups walk 64-row tiles (contiguous
-// 48 KB in the bf16 mirror), double-buffered in LDS with one barrier per tile; all 8 waves read the
-// same B fragments (ds_read_b128, rows padded by 16 B => conflict-free), so per tile a SIMD issues
-// 2 waves x 48 MFMAs against 384 KB of LDS reads (50 % of the LDS pipe). At Q = 256 one pass over the
-// corpus is HBM-bound (48 KB per 3072 MFMA cycles per CU = 9.6 TB/s at MFMA peak).
-// Epilogue per tile: 32 compares against the lane's 16 thresholds. A survivor takes a slot in THIS workgroup's
-// segment of its query's candidate row (slot index from an LDS counter, a plain 8-byte global store) — no
-// global atomics: with ~50 K survivors per slab funnelled through 256 counters in 8 cache lines, device-scope
-// atomics cost ~0.9 us per thousand survivors (a 16 K-row slab took 120 us, profiles/r01/y_growth_trace_tail.csv).
-//
-// Staging, GLDS = false: global -> VGPRs (issued at the top of an iteration) -> ds_write at its end, two LDS tiles.
-// Staging, GLDS = true: LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass). The DMA writes
-// 64 lanes x 16 B contiguously, so the padded tile image (row stride D*2 + 16) is cut into 1-KB pieces and each lane
-// FETCHES whatever belongs at its slot (the pad slot of a row re-fetches the row's last segment). With three
-// tiles in LDS (D <= 384) a tile is requested two iterations before it is read: the wait at the end of an
-// iteration is a counted vmcnt that leaves the newest tile in flight across the (raw) barrier.
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void global_cvoid;
 
 template <int N>
 __device__ inline void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// Claim the next tile of a group: a returning global atomic whose result is NOT waited for here. (HIP's atomicAdd is
-// rewritten by the compiler's atomic optimizer into bcnt + atomic + `s_waitcnt vmcnt(0)` + readfirstlane on the spot,
-// which also drains the tile loads issued just before it — the whole prefetch.) The caller executes
-// `s_waitcnt vmcnt(0)` (claim_wait) before reading the value; the compiler's own counted waits only ever over-wait
-// because of the extra request in flight.
-__device__ __forceinline__ unsigned int claim_tile_async(uint32_t* ctr) {
-    unsigned int old;
-    asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(old) : "v"(ctr), "v"(1u) : "memory");
-    return old;
-}
-__device__ __forceinline__ void claim_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-template <int D>
-constexpr int rega_lds_tiles(bool glds) { return (glds && 3 * 64 * (D * 2 + 16) + 3088 <= 160 * 1024) ? 3 : 2; }
-
-// SAMPLE = true (one-pass pipeline, threshold estimation): instead of filtering against a threshold, the workgroup
-// visits `a.sample_tiles` tiles spread evenly over the slab (logical index i -> tile i * ntiles / sample_tiles) and
-// records, per query, the best similarity of each visited tile in a.tile_max[i][query] (pick_tau_kernel turns the
-// j-th best tile maximum into the query's admission threshold).
-// FREE = true ("batch_rega" = 4; register staging, THREE LDS tiles; where they fit: D <= 384): NO workgroup barrier in the tile loop.
-// The phase clock (debug bit 10, profiles/r03/i_gemm_phase_clock.txt) showed where the ~40 % of a tile period that is not
-// matrix-pipe time goes: the one barrier per tile joins eight waves whose per-tile durations differ (arbitration of the shared
-// matrix pipe and the LDS port), and every wave waits for the slowest — 13 % (late half) to 27 % (early half) of its cycles.
-// What the barrier protected is two hazards on the staged tiles, and each is covered by one LDS counter per tile buffer:
-//   RAW  stored[b]: a wave adds 1 behind its last store of a tile into buffer b (a wave's DS operations execute in order);
-//        a reader spins until the counter shows 8 x (the buffer's fill number) before its first fragment read.
-//   WAR  read[b]: a wave adds 1 behind its last fragment read of the tile in buffer b; a writer spins on it before its first
-//        store of the buffer's next fill.
-// The staging runs TWO tiles ahead (iteration t loads tile t+2 from HBM at its top and stores it from the second half of its
-// K loop into the buffer tile t-1 was read from), so the RAW wait of iteration t is on stores made during iteration t-2 — a
-// whole tile period of slack — and the WAR wait, half-way through K loop t, is on reads that ended with K loop t-1: half a
-// period of slack. Waves drift apart by that much and re-converge without anybody having waited for it.
-// Measured (profiles/r03/j_gemm_phase_clock_free_running.txt, r_bench_free_running_ab.txt): the wait falls from 13-27 % of a
-// wave's cycles to 5 %, the kernel alone gains 2-5 % (frac 0.477 -> 0.491 at Q = 256) — and the pipelined batches LOSE 1.7 %,
-// because a 150 KB workgroup keeps the neighbouring batch's finish / prep kernels off the CU. Hence a variant, not the default.
-// What the remaining gap is made of is in DESIGN.md ("the matrix roof"): with embedding-like operands the K loop ALONE
-// (tools/mfma_probe.hip) sustains 1.57 PFLOP/s on this part — the matrix clock is power-limited and data-dependent.
-//
-// SYNC = 2 ("batch_rega" = 5): the SPLIT barrier — the default's two LDS tiles and one-tile-ahead staging, but the per-tile
-// workgroup barrier becomes "arrive" (a wave adds 1 to an LDS counter behind its K loop) and "wait" (spin on the counter in front
-// of the next K loop): a wave's selection sits between the two, so it no longer waits for the slowest wave before selecting.
-// Everybody still finishes K loop t-1 before anybody starts K loop t (that is what covers both hazards with two tiles), so there
-// is less slack than in the free-running variant — and no extra LDS.
-template <int D, bool GLDS, int AHEAD, bool SAMPLE = false, bool PROF = false, int SYNC = 0>
-__global__ __launch_bounds__(512, 2) void batch_gemm_rega_kernel(GemmArgs a, uint32_t blocks_per_group) {
-    constexpr bool FREE = SYNC == 1, SPLIT = SYNC == 2;
-    static_assert(!SPLIT || (!GLDS && !SAMPLE), "the split barrier is a variant of the register-staged filtering kernel");
-    constexpr int KS = D / 16;                       // MFMA k-steps
-    constexpr int ROW_B = D * 2 + 16;                // LDS row stride (bytes)
-    constexpr int TROWS = 64;                        // corpus rows per tile
-    constexpr int SEG_PER_ROW = D * 2 / 16;
-    constexpr int SEGS = TROWS * SEG_PER_ROW;        // 16-byte segments per tile
-    constexpr int LOADS = SEG_PER_ROW / 8;           // per thread (8 threads per row, 64 rows)
-    constexpr int BUF_B = TROWS * ROW_B;
-    static_assert(!FREE || (!GLDS && !SAMPLE), "the free-running variant is the register-staged filtering kernel");
-    constexpr int NBUF = FREE ? 3 : rega_lds_tiles<D>(GLDS);
-    constexpr int PRE = NBUF - 1;                    // GLDS: tiles requested ahead of the one being read
-    constexpr int SLOTS_PER_ROW = ROW_B / 16;        // 16-byte slots per padded row; == 1-KB pieces per tile (64 rows)
-    constexpr int PIECES = SLOTS_PER_ROW;
-    constexpr int PPW = (PIECES + 7) / 8;            // pieces per wave (waves with index >= PIECES % 8 carry one less)
-    static_assert(SEGS == 512 * LOADS && D % 64 == 0, "tile must split evenly over 512 threads");
-    static_assert(BUF_B == PIECES * 1024, "a padded tile is a whole number of 1-KB DMA pieces");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* buf0 = smem;
-    float* tau_s = reinterpret_cast<float*>(smem + NBUF * BUF_B);              // [8][32] exact thresholds
-    unsigned int* cnt_s = reinterpret_cast<unsigned int*>(tau_s + 8 * 32);     // [8][32] survivors per query (this workgroup)
-    float* sim_s = reinterpret_cast<float*>(cnt_s + 8 * 32);                   // [8][32] conservative similarity bounds
-    unsigned int* next_s = reinterpret_cast<unsigned int*>(sim_s + 8 * 32);    // [2] claimed tile indices (dynamic tile order)
-    unsigned int* stored_s = next_s + 4;                                       // [3] FREE: wave signals per LDS tile buffer: "my stores of its current fill are in"
-    unsigned int* read_s = next_s + 8;                                         // [3] FREE: "my reads of its current fill are done"
-    unsigned int* turn_s = next_s + 12;                                        // [4] FREE, debug bit 11: whose K loop runs next on each SIMD (pipe token)
-
-    const int tid = (int)threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const uint32_t group = blockIdx.x / blocks_per_group;   // 256 queries per group
-    const uint32_t bidx = blockIdx.x % blocks_per_group;
-    const uint32_t q0 = group * 256 + wave * 32;             // this wave's 32 queries
-
-    // A fragments: lane l holds query (l & 31), k = 16*ks + 8*(l >> 5) .. +7
-    bf16x8 fa[KS];
-    {
-        const u32x4* qp = reinterpret_cast<const u32x4*>(a.qb + (size_t)(q0 + (lane & 31)) * D) + (lane >> 5);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) fa[ks] = __builtin_bit_cast(bf16x8, qp[ks * 2]);
-    }
-    if (!SAMPLE && lane < 32) {
-        const float tq = a.tau[q0 + lane];
-        tau_s[wave * 32 + lane] = tq;
-        // fl(1 - acc) <= tq implies acc >= (1 - tq) - 2^-23 (|1 - tq| + |tq|); 4e-7 (1 + |tq|) covers it with slack.
-        // tq = +inf (no threshold yet) gives -inf: everything is flagged; tq = -inf (padding query) gives NaN: nothing is.
-        sim_s[wave * 32 + lane] = (1.0f - tq) - 4e-7f * (1.0f + __builtin_fabsf(tq));
-    }
-    if (tid < 256) cnt_s[tid] = 0u;
-    if (SYNC != 0 && tid == 0) next_s[3] = 0u;                                 // "a wave gave up waiting" (see wait_count)
-    if (FREE && tid < 3) {
-        stored_s[tid] = tid < 2 ? 8u : 0u;                                     // tiles 0 and 1 are staged by the prologue, behind a barrier
-        read_s[tid] = 0u;
-    }
-    if (SPLIT && tid == 0) stored_s[0] = 0u;                                   // SPLIT: K loops finished, all waves (arrivals of the split barrier)
-    if (FREE && tid >= 64 && tid < 68) turn_s[tid - 64] = 0u;
-    // this workgroup's segment of every query's candidate row
-    const uint32_t seg_slots = a.seg_area / blocks_per_group;
-    // element offset (32-bit: rows * cand_cap < 2^23) of this lane's first query row, at this workgroup's segment;
-    // kept as ONE VGPR + per-query scalar multiples — 16 hoisted 64-bit row pointers would spill
-    const uint32_t seg_lane0 = (q0 + 4u * ((uint32_t)lane >> 5)) * a.cand_cap + a.seg_base + bidx * seg_slots;
-
-    const uint32_t ntiles_all = (a.slab_rows + TROWS - 1) / TROWS;
-    const uint32_t ntiles = SAMPLE ? a.sample_tiles : ntiles_all;   // loop range (logical tiles)
-    const uint32_t slab_end = a.slab0 + a.slab_rows;
-    const unsigned char* cbase = reinterpret_cast<const unsigned char*>(a.cb);
-    // logical -> physical tile (identity unless sampling)
-    auto phys = [&](uint32_t tile) -> uint32_t {
-        return SAMPLE ? (uint32_t)(((unsigned long long)tile * ntiles_all) / a.sample_tiles) : tile;
-    };
-
-    // register staging map: 8 threads per tile row; a thread moves the 16-byte segments (tid & 7) + 8*p of its
-    // row, so every global / LDS address is one per-tile base plus a compile-time offset (no address arrays).
-    const uint32_t srow = (uint32_t)tid >> 3;
-    const uint32_t sseg = ((uint32_t)tid & 7u) * 16u;
-    u32x4 regs[GLDS ? 1 : LOADS];
-    auto issue_loads = [&](uint32_t tile) {
-        uint32_t grow = a.slab0 + phys(tile) * TROWS + srow;
-        grow = grow < a.n_rows ? grow : a.n_rows - 1;        // clamp: masked in the epilogue
-        const unsigned char* src = cbase + (size_t)grow * (D * 2) + sseg;
-#pragma unroll
-        for (int p = 0; p < (GLDS ? 0 : LOADS); ++p) regs[p] = *reinterpret_cast<const u32x4*>(src + p * 128);
-    };
-    auto store_tile = [&](unsigned char* buf) {
-        unsigned char* dst = buf + srow * ROW_B + sseg;
-#pragma unroll
-        for (int p = 0; p < (GLDS ? 0 : LOADS); ++p) *reinterpret_cast<u32x4*>(dst + p * 128) = regs[p];
-    };
-    // LDS-DMA map: wave w moves pieces w, w + 8, ...; lane l of piece P fills slot P*64 + l of the padded image
-    uint32_t prow[PPW], pcol[PPW];
-    int my_pieces = 0;
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-        const uint32_t P = (uint32_t)wave + 8u * i;
-        const uint32_t slot = P * 64u + (uint32_t)lane;
-        const uint32_t r = slot / SLOTS_PER_ROW;
-        uint32_t c = slot - r * SLOTS_PER_ROW;
-        c = c < (uint32_t)SEG_PER_ROW ? c : (uint32_t)SEG_PER_ROW - 1u;   // pad slot: any valid bytes
-        prow[i] = r;
-        pcol[i] = c * 16u;
-        if (P < (uint32_t)PIECES) ++my_pieces;
-    }
-    const bool full_wave = my_pieces == PPW;                 // wave-uniform
-    auto dma_tile = [&](uint32_t tile, uint32_t buf_off) {
-        const uint32_t row0 = a.slab0 + phys(tile) * TROWS;
-#pragma unroll
-        for (int i = 0; i < PPW; ++i) {
-            const uint32_t P = (uint32_t)wave + 8u * i;
-            if (i < PPW - 1 || full_wave) {
-                uint32_t grow = row0 + prow[i];
-                grow = grow < a.n_rows ? grow : a.n_rows - 1;
-                const unsigned char* src = cbase + (size_t)grow * (D * 2) + pcol[i];
-                __builtin_amdgcn_global_load_lds((global_cvoid*)src, (lds_void*)(smem + buf_off + P * 1024u), 16, 0, 0);
-            }
-        }
-    };
-    // this wave's DMA requests still allowed in flight: `keep_tiles` whole tiles (0 or 1)
-    auto dma_wait = [&](bool keep_one_tile) {
-        if (!keep_one_tile) wait_vmcnt<0>();
-        else if (full_wave) wait_vmcnt<PPW>();
-        else wait_vmcnt<PPW - 1>();
-    };
-
-    // Tile order. Static: bidx, bidx + W, bidx + 2W, ... (W = workgroups per group). Dynamic (a.tile_ctr, register
-    // staging only): the first two tiles are the static ones, every further one is claimed from the group's counter one
-    // iteration before its loads are issued — thread 0 starts the atomic at the top of an iteration and parks the
-    // result in LDS at its end, next to the tile barrier, so its latency never sits on the critical path.
-    const bool dyn = !SAMPLE && !GLDS && !FREE && !SPLIT && a.tile_ctr != nullptr;
-    uint32_t t = bidx;
-    if (dyn && tid == 0) {
-        const unsigned int c0 = claim_tile_async(a.tile_ctr + group * 32u);
-        claim_wait();
-        next_s[0] = 2u * blocks_per_group + c0;
-    }
-    if (GLDS) {
-        bool second = false;
-        if (t < ntiles) dma_tile(t, 0u);
-        if (PRE == 2 && t + blocks_per_group < ntiles) { dma_tile(t + blocks_per_group, (uint32_t)BUF_B); second = true; }
-        dma_wait(second);
-        __builtin_amdgcn_s_barrier();                         // also publishes tau_s / cnt_s
-        asm volatile("" ::: "memory");
-    } else {
-        if (t < ntiles) {
-            issue_loads(t);
-            store_tile(buf0);
-        }
-        if (FREE && t + blocks_per_group < ntiles) {
-            issue_loads(t + blocks_per_group);
-            store_tile(buf0 + BUF_B);
-        }
-        __syncthreads();
-    }
-    // The two waves that share a SIMD (w and w + 4: a workgroup's waves are dealt to the SIMDs cyclically) do
-    // the same work per tile in OPPOSITE order. Waves 0-3 run MFMAs(t) then select(t); waves 4-7 run
-    // select(t - 1) — on accumulators carried over from the previous iteration — then MFMAs(t). While one wave
-    // of a SIMD is in its VALU/LDS-only selection the other has the matrix pipe to itself, so the selection
-    // (~25 % of a tile's issue slots) hides under MFMAs instead of idling the pipe for both waves at once.
-    const bool late = wave >= 4 && !(a.debug & 16u);   // debug bit4: every wave in the same order
-    const bool dbg_noload = !FREE && (a.debug & 1u) != 0, dbg_nomfma = !FREE && (a.debug & 2u) != 0;  // timing experiments only
-    const bool prio = (a.debug & 32u) == 0;            // s_setprio 1 around the MFMA stream (+2-3 % at Q = 1024); debug bit5 turns it off
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-
-    // K loop, software-pipelined in the source: the B fragments of k-step ks + AHEAD are read (2 ds_read_b128)
-    // before the two MFMAs of k-step ks issue, and a sched_barrier pins every step, so the wait in front of an
-    // MFMA is a counted lgkmcnt(2 * AHEAD) on reads issued AHEAD steps earlier — never on the reads just issued.
-    // (Left alone, hipcc hoists all 2*KS reads above the MFMAs: 192 VGPRs at D = 384, spilling the A fragments;
-    // with sched_group_barrier "2 DS, 2 MFMA" groups it emitted `ds_read x2; s_waitcnt lgkmcnt(0); mfma`, i.e. one
-    // exposed LDS round trip per k-step and a matrix pipe ~50 % idle.)
-    // `st_dst` != nullptr: the next tile's staged segments (regs[], loaded at the top of the iteration) are written to LDS
-    // from INSIDE the K loop — piece p in front of k-step KS/2 + 2p — instead of in one burst after it: the burst was a
-    // phase of ~600 LDS cycles per tile in which no wave of the workgroup had MFMAs left to issue.
-    // FREE / SPLIT: spin until counter `ctr` (LDS) shows `target`. Wave-uniform. Bounded (~0.3 s), so that a protocol error cannot
-    // hang the GPU — and a wave that gives up says so: the workgroup then reports every one of its queries as overflowed
-    // (count 2^30, below), which sends them to the exact path. Never a silent wrong answer.
-    bool gave_up = SYNC != 0 && (a.debug & 16384u) != 0 && blockIdx.x == 1 && wave == 3;   // debug bit 14: pretend one wave timed out (tests)
-    auto wait_count = [&](const unsigned int* ctr, unsigned int target) {
-        bool ok = false;
-        for (unsigned int spins = 0; spins < (1u << 22); ++spins) {
-            const unsigned int v = __hip_atomic_load((const lds_u32*)ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if ((unsigned int)__builtin_amdgcn_readfirstlane((int)v) >= target) { ok = true; break; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        if (!ok) gave_up = true;
-        asm volatile("" ::: "memory");
-    };
-    // FREE: one signal per wave, behind everything the wave has issued to the LDS so far (a wave's DS operations execute in
-    // order; the wait makes "issued" "done" for the reads, whose data the MFMAs have consumed anyway)
-    auto signal_count = [&](unsigned int* ctr) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add((lds_u32*)ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-    // war_ctr / war_target (FREE): the buffer st_dst points into must have been read by all eight waves before the first store
-    // debug bit 11 (FREE): the two waves of a SIMD (w, w + 4) take strict turns at the matrix pipe — wave w runs K loop t as turn
-    // 2t, wave w + 4 as turn 2t + 1, the other one is in its selection meanwhile; the turn is handed over TOKEN_REL k-steps
-    // before the end of the loop to cover the hand-over latency
-    const bool token = FREE && (a.debug & 2048u) != 0;
-    const bool dbg_nostage = FREE && (a.debug & 4096u) != 0;   // debug bit 12 (FREE, timing only): no HBM loads, no staging stores, no counters
-    constexpr int TOKEN_REL = 2;
-    auto mfma_tile = [&](const unsigned char* cur, unsigned char* st_dst, const unsigned int* war_ctr = nullptr, unsigned int war_target = 0u, unsigned int my_turn = 0u) {
-        if (dbg_nomfma) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-            if (st_dst) store_tile(st_dst - (srow * ROW_B + sseg));
-            return;
-        }
-        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // first k-step: C = 0 (inline constant), no 32 v_mov per tile
-        const unsigned char* b0 = cur + (lane & 31) * ROW_B + (lane >> 5) * 16;
-        const unsigned char* b1 = b0 + 32 * ROW_B;
-        constexpr int RING = AHEAD + 1;
-        u32x4 fb0[RING], fb1[RING];
-#pragma unroll
-        for (int i = 0; i < AHEAD && i < KS; ++i) {
-            fb0[i] = *reinterpret_cast<const u32x4*>(b0 + i * 32);
-            fb1[i] = *reinterpret_cast<const u32x4*>(b1 + i * 32);
-        }
-        if (FREE && token) wait_count(turn_s + (wave & 3), my_turn);
-        if (prio) __builtin_amdgcn_s_setprio(1);   // the SIMD's other wave is in its selection: MFMA issue first
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            if (FREE && ks == KS - TOKEN_REL && token && lane == 0)
-                __hip_atomic_store((lds_u32*)(turn_s + (wave & 3)), my_turn + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (ks + AHEAD < KS) {
-                fb0[(ks + AHEAD) % RING] = *reinterpret_cast<const u32x4*>(b0 + (ks + AHEAD) * 32);
-                fb1[(ks + AHEAD) % RING] = *reinterpret_cast<const u32x4*>(b1 + (ks + AHEAD) * 32);
-            }
-            if (!GLDS && ks >= KS / 2 && ((ks - KS / 2) & 1) == 0 && (ks - KS / 2) / 2 < LOADS) {
-                if (FREE && ks == KS / 2 && st_dst && war_ctr) wait_count(war_ctr, war_target);
-                if (st_dst) *reinterpret_cast<u32x4*>(st_dst + ((ks - KS / 2) / 2) * 128) = regs[GLDS ? 0 : (ks - KS / 2) / 2];
-            }
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], __builtin_bit_cast(bf16x8, fb0[ks % RING]), ks == 0 ? zero16 : acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], __builtin_bit_cast(bf16x8, fb1[ks % RING]), ks == 0 ? zero16 : acc1, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (prio) __builtin_amdgcn_s_setprio(0);
-    };
-    // Fused selection on the accumulators of `tile`: C[query][row], col = lane & 31 = corpus row,
-    // reg r = query qo(r) = (r&3) + 8(r>>2) + 4(lane>>5).
-    // Fast path, every tile: 32 compares of the accumulators (similarities) against the lane's 16 thresholds,
-    // OR-ed into four wave-level flags (one per group of four queries) — no branches, one LDS round trip. (Reading each threshold from LDS next to
-    // its compare cost 16 exposed LDS round trips per tile, ~25 % of the kernel: profiles/r01/ae_gemm_probe.txt.)
-    // sim_s[q] = (1 - tau) - 4e-7 (1 + |tau|) is a conservative similarity bound: whatever passes
-    // the exact test `1 - acc <= tau` below also passes `acc >= sim_lo`, so the mask is a superset.
-    // Slow path (a wave-tile holds ~0.8 survivors at Q = 256, k' = 64): groups of four queries are re-examined
-    // only if some lane flagged them; the group re-tests exactly (`1 - acc <= tau`, tau from LDS) and a survivor
-    // takes a slot in this workgroup's segment of the query's candidate row.
-    auto select_tile = [&](uint32_t tile) {
-        if (a.debug & 8u) return;
-        if (SAMPLE) {
-            // best similarity of this tile per query: rows sit in lanes (lane & 31) of both accumulators; a clamped
-            // row past the end of the store duplicates the last row and cannot raise a maximum. NaN never wins (maxNum).
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float m = group_max32(__builtin_fmaxf(acc0[r], acc1[r]));
-                if ((lane & 31) == 31)
-                    a.tile_max[(size_t)tile * (a.nqt * 128u) + q0 + (uint32_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5))] = m;
-            }
-            return;
-        }
-        // the lane's 16 bounds are four aligned float4 in LDS (queries 8j + 4(lane>>5) .. +3 for r = 4j .. 4j+3):
-        // one batch of ds_read_b128 and ONE wait per tile; they are live only here, after the B-fragment ring died
-        const lds_f32x4* sim_w = (const lds_f32x4*)(sim_s + wave * 32 + 4 * (lane >> 5));
-        f32x4 lo[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) lo[j] = sim_w[2 * j];
-        // wave-level flags per group of four queries: v_cmp into an SGPR pair + s_or_b64 (1 VALU + 1 SALU per element)
-        unsigned long long hit[4] = {0ull, 0ull, 0ull, 0ull};
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            hit[r >> 2] |= __ballot(acc0[r] >= lo[r >> 2][r & 3]) | __ballot(acc1[r] >= lo[r >> 2][r & 3]);   // NaN fails
-        if ((hit[0] | hit[1] | hit[2] | hit[3]) == 0ull || (a.debug & 64u)) return;   // debug bit6: hot test only (timing experiments)
-        const uint32_t row0 = a.slab0 + tile * TROWS + (lane & 31);
-        const uint32_t row1 = row0 + 32;
-        const bool ok0 = row0 < slab_end, ok1 = row1 < slab_end;
-        const lds_f32* tau_w = (const lds_f32*)(tau_s + wave * 32);
-        lds_u32* cnt_w = (lds_u32*)(cnt_s + wave * 32);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            if (hit[g] == 0ull) continue;
-            const f32x4 tau4 = *(const lds_f32x4*)(tau_w + 8 * g + 4 * (lane >> 5));   // exact thresholds of the group
-#pragma unroll
-            for (int r = 4 * g; r < 4 * g + 4; ++r) {
-                const int qo = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const float tqr = tau4[r & 3];
-                const float d0 = (1.0f - acc0[r]) + 0.0f, d1 = (1.0f - acc1[r]) + 0.0f;
-                const bool p0 = ok0 && d0 <= tqr, p1 = ok1 && d1 <= tqr;
-                if (p0 || p1) {
-                    // slot in this workgroup's segment of the query's row: one LDS atomic, plain global stores
-                    const unsigned n = (p0 ? 1u : 0u) + (p1 ? 1u : 0u);
-                    unsigned off;
-                    if (GLDS) {
-                        // opaque to hipcc on purpose: before an LDS write it can see, the compiler drains every
-                        // outstanding LDS-DMA request (s_waitcnt vmcnt(0)) — here once per tile, undoing the prefetch
-                        asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
-                                     : "=v"(off)
-                                     : "v"((unsigned)(size_t)(cnt_w + qo)), "v"(n)
-                                     : "memory");
-                    } else {
-                        off = __hip_atomic_fetch_add(cnt_w + qo, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                    const uint32_t e0 = seg_lane0 + (uint32_t)((r & 3) + 8 * (r >> 2)) * a.cand_cap;
-                    if (a.debug & 8192u) continue;           // debug bit13: count, do not store (timing experiments: what do the stores cost the tile pipeline?)
-                    if (p0 && off < seg_slots) a.cand[e0 + off++] = make_key(d0, a.row_base + row0);
-                    if (p1 && off < seg_slots) a.cand[e0 + off] = make_key(d1, a.row_base + row1);
-                }
-            }
-        }
-    };
-
-    constexpr bool prof = PROF;   // a separate instantiation (launch_rega, debug bit 10): the counters and the printf cost 8 VGPRs
-    unsigned long long prof_mfma = 0, prof_sel = 0, prof_bar = 0;
-    const unsigned long long prof_t0 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
-    uint32_t it = 0;
-    uint32_t cur_idx = 0;                                     // GLDS / FREE: it % NBUF
-    uint32_t pre_idx3 = 2;                                    // FREE: (it + 2) % 3, the buffer this iteration stages into
-    uint32_t t_prev = 0;                                      // the tile of the previous iteration (late waves select it now)
-    uint32_t t_next = t + blocks_per_group;                   // register staging: the tile whose loads this iteration issues
-    for (; t < ntiles; ++it) {
-        unsigned char* cur;
-        unsigned char* nxt = buf0;
-        uint32_t tn;
-        uint32_t t_after = 0;                                 // register staging: the tile after t_next
-        unsigned int claimed = 0;
-        bool issued = false;
-        if (GLDS) {
-            cur = buf0 + cur_idx * BUF_B;
-            tn = t + PRE * blocks_per_group;
-            uint32_t pre_idx = cur_idx + PRE;
-            pre_idx = pre_idx >= (uint32_t)NBUF ? pre_idx - NBUF : pre_idx;
-            if (tn < ntiles) { dma_tile(tn, pre_idx * BUF_B); issued = true; }
-        } else if (FREE) {
-            cur = buf0 + cur_idx * BUF_B;
-            nxt = buf0 + pre_idx3 * BUF_B;                        // where tile it + 2 goes: the buffer tile it - 1 was read from
-            tn = dbg_nostage ? ntiles : t_next + blocks_per_group;   // the tile staged in this iteration: two ahead
-            if (tn < ntiles) issue_loads(tn);
-        } else {
-            cur = buf0 + ((dbg_noload ? 0u : (it & 1u)) * BUF_B);  // debug bit0: always the prologue tile
-            nxt = buf0 + ((it & 1) ^ 1) * BUF_B;
-            tn = t_next;
-            if (tn < ntiles && !dbg_noload) issue_loads(tn);
-            if (dyn) {
-                t_after = next_s[it & 1u];
-                if (tid == 0 && t_after < ntiles) claimed = claim_tile_async(a.tile_ctr + group * 32u);   // read at the end of the iteration
-            } else {
-                t_after = tn + blocks_per_group;
-            }
-        }
-        // debug bit7: the staged tile goes to LDS in one burst after the K loop (the round-1 schedule), for A/B timing
-        // (ignored by the split / free-running barriers: their arrival is signalled right after the K loop, so a burst
-        // stored after it would not be covered and other waves could read a half-written tile)
-        const bool spread = !GLDS && (FREE || SPLIT || !(a.debug & 128u));
-        unsigned char* st_dst = (!GLDS && spread && tn < ntiles && !dbg_noload) ? nxt + srow * ROW_B + sseg : nullptr;
-        // FREE: tile `it` is fill it / 3 + 1 of its buffer; the buffer being refilled was read as tile it - 1
-        const unsigned int raw_target = 8u * (it / 3u + 1u), war_target = it ? 8u * ((it - 1u) / 3u + 1u) : 0u;
-        // debug bit10: per-wave phase clock (s_memtime around the MFMA phase, the selection and the tile barrier), printed by a
-        // few workgroups at the end — where the 40 % of a tile period that is not matrix-pipe time goes. Perturbs the timing
-        // (every reading drains the wave's LDS queue): a diagnosis run, never a benchmark.
-        unsigned long long c0 = 0, c1 = 0, c2 = 0;
-        if (prof) c0 = __builtin_amdgcn_s_memtime();
-        if (late) {
-            if (it > 0) select_tile(t_prev);
-            if (prof) { c1 = __builtin_amdgcn_s_memtime(); prof_sel += c1 - c0; }
-            if (FREE) {
-                if (!dbg_nostage) wait_count(stored_s + cur_idx, raw_target);
-                if (prof) { const unsigned long long cw = __builtin_amdgcn_s_memtime(); prof_bar += cw - c1; c1 = cw; }
-                mfma_tile(cur, st_dst, it ? read_s + pre_idx3 : nullptr, war_target, 2u * it + (wave >= 4 ? 1u : 0u));
-                signal_count(read_s + cur_idx);
-                if (st_dst && lane == 0) __hip_atomic_fetch_add((lds_u32*)(stored_s + pre_idx3), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            } else {
-                if (SPLIT && it > 0) wait_count(stored_s, 8u * it);    // every wave has finished K loop it - 1: tile `it` is stored, its other buffer is free
-                mfma_tile(cur, st_dst);
-                if (SPLIT) signal_count(stored_s);
-            }
-            if (prof) { c2 = __builtin_amdgcn_s_memtime(); prof_mfma += c2 - c1; }
-        } else {
-            if (FREE) {
-                if (!dbg_nostage) wait_count(stored_s + cur_idx, raw_target);
-                if (prof) { const unsigned long long cw = __builtin_amdgcn_s_memtime(); prof_bar += cw - c0; c0 = cw; }
-                mfma_tile(cur, st_dst, it ? read_s + pre_idx3 : nullptr, war_target, 2u * it + (wave >= 4 ? 1u : 0u));
-                signal_count(read_s + cur_idx);
-                if (st_dst && lane == 0) __hip_atomic_fetch_add((lds_u32*)(stored_s + pre_idx3), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            } else {
-                if (SPLIT && it > 0) wait_count(stored_s, 8u * it);
-                mfma_tile(cur, st_dst);
-                if (SPLIT) signal_count(stored_s);
-            }
-            if (prof) { c1 = __builtin_amdgcn_s_memtime(); prof_mfma += c1 - c0; }
-            select_tile(t);
-            if (prof) { c2 = __builtin_amdgcn_s_memtime(); prof_sel += c2 - c1; }
-        }
-        t_prev = t;
-        if (FREE) {
-            pre_idx3 = cur_idx;                                   // next iteration refills the buffer this one read
-            cur_idx = cur_idx + 1 == 3u ? 0u : cur_idx + 1;
-            t = t_next;
-            t_next += blocks_per_group;
-            if (prof) c2 = __builtin_amdgcn_s_memtime();
-        } else if (GLDS) {
-            // tile t + 1 must have landed (every wave waits for its own pieces, the barrier joins them); with
-            // three tiles in LDS the one requested in this iteration stays in flight across the barrier
-            dma_wait(PRE == 2 && issued);
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            cur_idx = cur_idx + 1 == (uint32_t)NBUF ? 0u : cur_idx + 1;
-            t += blocks_per_group;
-        } else {
-            if (!spread && tn < ntiles && !dbg_noload) store_tile(nxt);
-            if (dyn && tid == 0) {
-                claim_wait();
-                next_s[(it + 1u) & 1u] = t_after < ntiles ? 2u * blocks_per_group + claimed : t_after;
-            }
-            if (!SPLIT && !(a.debug & 4u)) __syncthreads();  // debug bit2 (only with bit0): no per-tile barrier
-            t = tn;
-            t_next = t_after;
-        }
-        if (prof) prof_bar += __builtin_amdgcn_s_memtime() - c2;
-    }
-    if (prof && lane == 0 && (blockIdx.x == 0 || blockIdx.x == 101 || blockIdx.x == 255))
-        printf("WAXPROF rega D=%d blk %u wave %d tiles %u mfma %llu select %llu barrier %llu total %llu\n", D, (unsigned)blockIdx.x, wave, it,
-               prof_mfma, prof_sel, prof_bar, (unsigned long long)(__builtin_amdgcn_s_memtime() - prof_t0));
-    if (late && it > 0) select_tile(t_prev);
-    if (SYNC != 0 && gave_up && lane == 0) __hip_atomic_fetch_or((lds_u32*)(next_s + 3), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    // unclamped counts: a count above seg_slots tells tighten_kernel that survivors were dropped (query -> exact path)
-    __syncthreads();
-    if (!SAMPLE && tid < 256) {
-        const bool poisoned = SYNC != 0 && next_s[3] != 0u;   // a wave gave up waiting: nothing this workgroup selected can be trusted
-        a.seg_count[(size_t)bidx * (a.nqt * 128u) + group * 256u + (uint32_t)tid] = poisoned ? 0x40000000u : cnt_s[tid];
-    }
-}
-
 // ---------------------------------------------------------------------------
-// Register-resident-queries GEMM for D = 768: 32 queries x D of A fragments do not fit beside the
-// accumulators in 256 VGPRs, so the K dimension is split over the two waves that share a SIMD. Wave p (owner) and
-// wave p + 4 (helper), p = 0..3, hold the same 32 queries; the owner keeps k in [0, D/2), the helper [D/2, D)
-// (96 VGPRs each at D = 768). A workgroup therefore covers 128 queries; tiles are 32 corpus rows (48 KB at D = 768),
-// double-buffered in LDS with one barrier per tile. Per tile every wave runs D/32 MFMAs on two independent
-// accumulators; the helper then parks its partial sums in LDS (4 ds_write_b128, buffers alternate by tile parity),
-// and at the top of the NEXT iteration — after the tile barrier — the owner adds them to its own and runs the
-// selection, while the helper is already issuing the next tile's MFMAs (the pair shares a SIMD, so the owner's
-// VALU/LDS work overlaps the helper's matrix work by construction).
-// Selection, segments and thresholds are those of batch_gemm_rega_kernel (one row block per tile).
+// Register-resident-queries GEMM ("rq"): cosine / dot at D in {128, 256, 384, 512, 768}; the filtering launch of the one-pass
+// pipeline, its sampling launch (SAMPLE), and every slab after the first of the slab pipeline.
 //
-// SPLIT = true (the default for the filtering launch): the tile barrier is split as in batch_gemm_rega_kernel<..., SYNC = 2>.
-// Every wave adds 1 to `done` behind its K loop and spins on it (8 x tile number) in front of the next one — that orders the
-// tile buffers; a helper also adds 1 to its pair's `parked` counter behind its partial sums, and the owner waits for THAT before
-// its selection — so an owner selects as soon as its own partner is through, while the slowest wave of the workgroup is still
-// multiplying, instead of after everybody.
-template <int D, int AHEAD, bool SAMPLE = false, bool SPLIT = false>
-__global__ __launch_bounds__(512, 2) void batch_gemm_ksplit_kernel(GemmArgs a, uint32_t blocks_per_group) {
-    constexpr int HALF = D / 2;
-    constexpr int KS = HALF / 16;                    // MFMA k-steps per wave
-    constexpr int ROW_B = D * 2 + 16;                // LDS row stride (bytes); (ROW_B / 4) % 64 == 4 => conflict-free b128 reads
-    constexpr int TROWS = 32;                        // corpus rows per tile
-    constexpr int THREADS_PER_ROW = 512 / TROWS;     // 16
-    constexpr int LOADS = D * 2 / 16 / THREADS_PER_ROW;
-    constexpr int BUF_B = TROWS * ROW_B;
-    constexpr int PART_B = 4 * 64 * 16;              // one wave's partial sums: 16 floats per lane
-    static_assert(D % 256 == 0 && LOADS * THREADS_PER_ROW * 16 == D * 2, "row must split evenly over 16 threads");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* buf0 = smem;
-    unsigned char* part0 = smem + 2 * BUF_B;                                    // [2 parities][4 pairs][4][64] float4
-    float* tau_s = reinterpret_cast<float*>(part0 + 2 * 4 * PART_B);            // [4][32] exact thresholds
-    unsigned int* cnt_s = reinterpret_cast<unsigned int*>(tau_s + 4 * 32);      // [4][32] survivors per query (this workgroup)
-    float* sim_s = reinterpret_cast<float*>(cnt_s + 4 * 32);                    // [4][32] conservative similarity bounds
-    unsigned int* next_s = reinterpret_cast<unsigned int*>(sim_s + 4 * 32);     // [2] claimed tile indices (dynamic tile order)
-    unsigned int* done_s = next_s + 4;                                          // SPLIT: K loops finished (all waves)
-    unsigned int* parked_s = next_s + 5;                                        // SPLIT: [4] partial sums parked, per pair
-
-    const int tid = (int)threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int pair = wave & 3;
-    const bool owner = wave < 4;
-    const uint32_t group = blockIdx.x / blocks_per_group;   // 128 queries per group
-    const uint32_t bidx = blockIdx.x % blocks_per_group;
-    const uint32_t q0 = group * 128 + pair * 32;             // this pair's 32 queries
-
-    // A fragments: lane l holds query (l & 31), k = khalf*HALF + 16*ks + 8*(l >> 5) .. +7
-    bf16x8 fa[KS];
-    {
-        const u32x4* qp = reinterpret_cast<const u32x4*>(a.qb + (size_t)(q0 + (lane & 31)) * D + (owner ? 0 : HALF)) + (lane >> 5);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) fa[ks] = __builtin_bit_cast(bf16x8, qp[ks * 2]);
-    }
-    if (SPLIT && tid < 5) done_s[tid] = 0u;   // done + parked[4]
-    if (SPLIT && tid == 5) next_s[3] = 0u;    // "a wave gave up waiting"
-    if (owner && lane < 32) {
-        const float tq = SAMPLE ? 0.f : a.tau[q0 + lane];
-        tau_s[pair * 32 + lane] = tq;
-        sim_s[pair * 32 + lane] = (1.0f - tq) - 4e-7f * (1.0f + __builtin_fabsf(tq));   // see batch_gemm_rega_kernel
-        cnt_s[pair * 32 + lane] = 0u;
-    }
-    const uint32_t seg_slots = a.seg_area / blocks_per_group;
-    const uint32_t seg_lane0 = (q0 + 4u * ((uint32_t)lane >> 5)) * a.cand_cap + a.seg_base + bidx * seg_slots;
-
-    const uint32_t ntiles_all = (a.slab_rows + TROWS - 1) / TROWS;
-    const uint32_t ntiles = SAMPLE ? a.sample_tiles : ntiles_all;
-    const uint32_t slab_end = a.slab0 + a.slab_rows;
-    const unsigned char* cbase = reinterpret_cast<const unsigned char*>(a.cb);
-    auto phys = [&](uint32_t tile) -> uint32_t {
-        return SAMPLE ? (uint32_t)(((unsigned long long)tile * ntiles_all) / a.sample_tiles) : tile;
-    };
-
-    // staging: 16 threads per tile row, a thread moves the 16-byte segments (tid & 15) + 16*p of its row
-    const uint32_t srow = (uint32_t)tid >> 4;
-    const uint32_t sseg = ((uint32_t)tid & 15u) * 16u;
-    u32x4 regs[LOADS];
-    auto issue_loads = [&](uint32_t tile) {
-        uint32_t grow = a.slab0 + phys(tile) * TROWS + srow;
-        grow = grow < a.n_rows ? grow : a.n_rows - 1;        // clamp: masked in the selection
-        const unsigned char* src = cbase + (size_t)grow * (D * 2) + sseg;
-#pragma unroll
-        for (int p = 0; p < LOADS; ++p) regs[p] = *reinterpret_cast<const u32x4*>(src + p * 256);
-    };
-    auto store_tile = [&](unsigned char* buf) {
-        unsigned char* dst = buf + srow * ROW_B + sseg;
-#pragma unroll
-        for (int p = 0; p < LOADS; ++p) *reinterpret_cast<u32x4*>(dst + p * 256) = regs[p];
-    };
-
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-
-    // this wave's K half of one tile: two independent accumulator chains, B fragments read AHEAD k-steps early
-    auto mfma_tile = [&](const unsigned char* cur, unsigned char* st_dst) {   // st_dst: see batch_gemm_rega_kernel
-        f32x16 a0, a1;
-        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // first use of a chain: C = 0
-        const unsigned char* b0 = cur + (lane & 31) * ROW_B + (owner ? 0 : HALF * 2) + (lane >> 5) * 16;
-        constexpr int RING = AHEAD + 1;
-        u32x4 fb[RING];
-#pragma unroll
-        for (int i = 0; i < AHEAD && i < KS; ++i) fb[i] = *reinterpret_cast<const u32x4*>(b0 + i * 32);
-        if (!(a.debug & 32u)) __builtin_amdgcn_s_setprio(1);   // the pair's other wave is selecting: MFMA issue first (+3 %)
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            if (ks + AHEAD < KS) fb[(ks + AHEAD) % RING] = *reinterpret_cast<const u32x4*>(b0 + (ks + AHEAD) * 32);
-            if (ks >= KS / 2 && ((ks - KS / 2) & 1) == 0 && (ks - KS / 2) / 2 < LOADS) {
-                if (st_dst) *reinterpret_cast<u32x4*>(st_dst + ((ks - KS / 2) / 2) * 256) = regs[(ks - KS / 2) / 2];
-            }
-            if (ks & 1) a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], __builtin_bit_cast(bf16x8, fb[ks % RING]), ks == 1 ? zero16 : a1, 0, 0, 0);
-            else a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], __builtin_bit_cast(bf16x8, fb[ks % RING]), ks == 0 ? zero16 : a0, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (!(a.debug & 32u)) __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = a0[r] + a1[r];
-    };
-    auto park_partial = [&](uint32_t parity) {      // helper: 16 floats per lane, [j][lane] float4
-        f32x4* dst = reinterpret_cast<f32x4*>(part0 + (parity * 4 + pair) * PART_B) + lane;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dst[j * 64] = f32x4{acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]};
-    };
-    // owner: add the helper's half, then the fused selection of batch_gemm_rega_kernel on one 32-row block
-    auto select_tile = [&](uint32_t tile, uint32_t parity) {
-        const f32x4* src = reinterpret_cast<const f32x4*>(part0 + (parity * 4 + pair) * PART_B) + lane;
-        const lds_f32x4* sim_w = (const lds_f32x4*)(sim_s + pair * 32 + 4 * (lane >> 5));
-        f32x4 lo[4], hp[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { hp[j] = src[j * 64]; lo[j] = sim_w[2 * j]; }
-        if (a.debug & 8u) return;
-        unsigned long long hit[4] = {0ull, 0ull, 0ull, 0ull};
-        float full[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            full[r] = acc[r] + hp[r >> 2][r & 3];
-            hit[r >> 2] |= __ballot(full[r] >= lo[r >> 2][r & 3]);   // NaN fails
-        }
-        if (SAMPLE) {   // per-query best similarity of this 32-row tile (see batch_gemm_rega_kernel)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float m = group_max32(full[r]);
-                if ((lane & 31) == 31)
-                    a.tile_max[(size_t)tile * (a.nqt * 128u) + q0 + (uint32_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5))] = m;
-            }
-            return;
-        }
-        if ((hit[0] | hit[1] | hit[2] | hit[3]) == 0ull || (a.debug & 64u)) return;   // debug bit6: hot test only (timing experiments)
-        const uint32_t row0 = a.slab0 + tile * TROWS + (lane & 31);
-        const bool ok0 = row0 < slab_end;
-        const lds_f32* tau_w = (const lds_f32*)(tau_s + pair * 32);
-        lds_u32* cnt_w = (lds_u32*)(cnt_s + pair * 32);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            if (hit[g] == 0ull) continue;
-            const f32x4 tau4 = *(const lds_f32x4*)(tau_w + 8 * g + 4 * (lane >> 5));
-#pragma unroll
-            for (int r = 4 * g; r < 4 * g + 4; ++r) {
-                const int qo = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const float d0 = (1.0f - full[r]) + 0.0f;
-                if (ok0 && d0 <= tau4[r & 3]) {
-                    const unsigned off = __hip_atomic_fetch_add(cnt_w + qo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    const uint32_t e0 = seg_lane0 + (uint32_t)((r & 3) + 8 * (r >> 2)) * a.cand_cap;
-                    if (off < seg_slots) a.cand[e0 + off] = make_key(d0, a.row_base + row0);
-                }
-            }
-        }
-    };
-
-    // SPLIT: see batch_gemm_rega_kernel (bounded spin; a wave that gives up poisons the workgroup's counts -> exact path)
-    bool gave_up = SPLIT && (a.debug & 16384u) != 0 && blockIdx.x == 1 && wave == 3;   // debug bit 14: pretend one wave timed out (tests)
-    auto wait_count = [&](const unsigned int* ctr, unsigned int target) {
-        bool ok = false;
-        for (unsigned int spins = 0; spins < (1u << 22); ++spins) {
-            const unsigned int v = __hip_atomic_load((const lds_u32*)ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if ((unsigned int)__builtin_amdgcn_readfirstlane((int)v) >= target) { ok = true; break; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        if (!ok) gave_up = true;
-        asm volatile("" ::: "memory");
-    };
-    auto signal_count = [&](unsigned int* ctr) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add((lds_u32*)ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-
-    // tile order: static stride, or (a.tile_ctr) claimed from the group's counter — see batch_gemm_rega_kernel
-    const bool dyn = !SAMPLE && !SPLIT && a.tile_ctr != nullptr;
-    uint32_t t = bidx;
-    if (dyn && tid == 0) {
-        const unsigned int c0 = claim_tile_async(a.tile_ctr + group * 32u);
-        claim_wait();
-        next_s[0] = 2u * blocks_per_group + c0;
-    }
-    if (t < ntiles) {
-        issue_loads(t);
-        store_tile(buf0);
-    }
-    __syncthreads();
-    uint32_t it = 0;
-    uint32_t t_prev = 0;
-    uint32_t t_next = t + blocks_per_group;
-    for (; t < ntiles; ++it) {
-        unsigned char* cur = buf0 + (it & 1u) * BUF_B;
-        unsigned char* nxt = buf0 + ((it & 1u) ^ 1u) * BUF_B;
-        const uint32_t tn = t_next;
-        if (tn < ntiles) issue_loads(tn);
-        uint32_t t_after;
-        unsigned int claimed = 0;
-        if (dyn) {
-            t_after = next_s[it & 1u];
-            if (tid == 0 && t_after < ntiles) claimed = claim_tile_async(a.tile_ctr + group * 32u);   // read at the end of the iteration
-        } else {
-            t_after = tn + blocks_per_group;
-        }
-        const bool spread = !(a.debug & 128u);                 // debug bit7: one burst after the K loop, for A/B timing
-        unsigned char* st_dst = (spread && tn < ntiles) ? nxt + srow * ROW_B + sseg : nullptr;
-        if (SPLIT) {
-            if (owner) {
-                if (it > 0) {
-                    wait_count(parked_s + pair, it);            // the partner's partial sums of tile it - 1 are in LDS
-                    select_tile(t_prev, (it - 1u) & 1u);
-                    wait_count(done_s, 8u * it);                // every wave is through K loop it - 1: tile `it` stored, its other buffer free
-                }
-                mfma_tile(cur, st_dst);
-                signal_count(done_s);
-            } else {
-                if (it > 0) wait_count(done_s, 8u * it);        // (also: the owner has read the partial buffer this tile's sums go to)
-                mfma_tile(cur, st_dst);
-                signal_count(done_s);
-                park_partial(it & 1u);
-                signal_count(parked_s + pair);
-            }
-        } else if (owner) {
-            if (it > 0) select_tile(t_prev, (it - 1u) & 1u);   // partial of the previous tile: parked before the last barrier
-            mfma_tile(cur, st_dst);
-        } else {
-            mfma_tile(cur, st_dst);
-            park_partial(it & 1u);
-        }
-        if (!spread && tn < ntiles) store_tile(nxt);
-        if (dyn && tid == 0) {
-            claim_wait();
-            next_s[(it + 1u) & 1u] = t_after < ntiles ? 2u * blocks_per_group + claimed : t_after;
-        }
-        if (!SPLIT) __syncthreads();
-        t_prev = t;
-        t = tn;
-        t_next = t_after;
-    }
-    if (SPLIT && owner && it > 0) wait_count(parked_s + pair, it);
-    if (owner && it > 0) select_tile(t_prev, (it - 1u) & 1u);
-    if (SPLIT && gave_up && lane == 0) __hip_atomic_fetch_or((lds_u32*)(next_s + 3), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __syncthreads();
-    if (SPLIT && next_s[3] != 0u && tid < 128) cnt_s[tid] = 0x40000000u;   // nothing this workgroup selected can be trusted -> exact path
-    if (SPLIT) __syncthreads();
-    if (!SAMPLE && tid < 128) a.seg_count[(size_t)bidx * (a.nqt * 128u) + group * 128u + (uint32_t)tid] = cnt_s[tid];
-}
-
-// ---------------------------------------------------------------------------
-// Register-resident-queries GEMM for D = 768, WHOLE K per wave ("wide": the default for 768 since round 4).
+// The query block is tiny and reused against every corpus row, so it never goes through LDS: each of a workgroup's 8 waves keeps
+// its 32 queries x D as MFMA A fragments in VGPRs for the whole launch (D / 4 registers: 192 at D = 768). Only the corpus
+// streams: persistent workgroups (one per CU; 256 queries per group of workgroups) walk TROWS-row tiles of the bf16 mirror through
+// a ring of NBUF padded tile images in LDS (row stride 2 D + 16 bytes: conflict-free ds_read_b128), filled by LDS-DMA
+// (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass). All 8 waves read the same B fragments: one ds_read_b128 per MFMA,
+// RB = TROWS / 32 accumulators per wave, KS * RB MFMAs (v_mfma_f32_32x32x16_bf16) per wave and tile. The selection is fused:
+// per tile 16 RB compares against conservative per-query bounds; a survivor takes a slot in THIS workgroup's segment of its
+// query's candidate row (plain 8-byte store, no global atomics); the wave's 32 per-query survivor counters live in SGPRs.
 //
-// The K-split kernel above is bound by the LDS port, not by the matrix pipe (profiles/r04: per 32-row tile a CU's eight waves
-// issue 192 ds_read_b128 = 768 LDS cycles, the staging stores ~620 and the partial-sum exchange ~270, against 1 536 matrix
-// cycles per SIMD): a tile staged in LDS is multiplied against only 128 queries. Here a wave keeps its 32 queries x 768 as
-// 192 VGPRs of A fragments — which fits beside ONE 16-register accumulator once nothing else needs registers:
-//   * staging is LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass — the DMA does not go through the
-//     VGPR -> LDS transfer path that limits ds_write_b128 to ~79 B/clk), NBUF tile buffers, requested NBUF - 1 tiles ahead;
-//   * one accumulator chain (a 32x32x16 MFMA accumulates back-to-back into the same registers without a stall; the other
-//     wave of the SIMD fills the pipe between them anyway);
-//   * the selection's bounds are read after the B-fragment ring has died.
-// A workgroup is 8 waves = 256 queries (as for D <= 512), tiles are 32 rows: per tile a wave issues 48 MFMAs against
-// 48 ds_read_b128 — the LDS reads per MFMA of the 384-d kernel — and a staged byte is used by twice as many queries as in
-// the K-split kernel; no partial sums cross LDS. Per tile and CU: 3 072 matrix cycles per SIMD against 1 536 LDS cycles of
-// fragment reads + 48.5 KB of DMA writes.
-// The padded tile image (row stride 2D + 16 B: conflict-free ds_read_b128) is 48.5 KB; it is cut into 49 1-KB DMA pieces
-// (lane l of piece P fetches what belongs at slot 64 P + l; a row's pad slot re-fetches its last segment; the upper half of
-// the last piece lands in the buffer's 512 B of slack). Selection, survivor segments, thresholds, seg_count layout and the
-// "late" order of waves 4-7 are those of batch_gemm_rega_kernel, so the host side and batch_finish_kernel do not know
-// which kernel ran.
-// SPLIT = true: the tile barrier is split as in batch_gemm_rega_kernel<..., SYNC = 2> — "arrive" (a wave adds 1 to an LDS counter
-// behind its K loop, once its own DMA pieces of the next tile have landed) and "wait" (spin on the counter in front of the next
-// K loop, BEFORE requesting the tile that will overwrite the buffer the previous K loop read): an early wave's selection sits
-// between the two instead of in front of a workgroup barrier. The counter is touched through inline assembly only: an LDS
-// access the compiler can see makes it drain the LDS-DMA queue first (s_waitcnt vmcnt(0)).
-// (Issuing the next tile's DMA pieces from inside the K loop instead of in one burst at the top of the iteration was built and
-// measured: 1 915 - 1 933 us against 1 807 - 1 856 us — the piece arithmetic does not fit beside 192 VGPRs of A fragments without
-// spilling, and the burst was not the idle time it looked like; profiles/HISTORY.md.)
-template <int D, int NBUF, int AHEAD, bool SAMPLE = false, int CHAINS = 1, bool SPLIT = false>
-__global__ __launch_bounds__(512, 2) void batch_gemm_wide_kernel(GemmArgs a, uint32_t blocks_per_group) {
-    constexpr int KS = D / 16;                       // MFMA k-steps
-    constexpr int ROW_B = D * 2 + 16;                // LDS row stride (bytes); (ROW_B / 4) % 64 == 4
-    constexpr int TROWS = 32;                        // corpus rows per tile
-    constexpr int SEG_PER_ROW = D * 2 / 16;          // 16-byte segments per row
-    constexpr int SLOTS_PER_ROW = ROW_B / 16;        // 16-byte slots per padded row
-    constexpr int IMG_B = TROWS * ROW_B;             // padded tile image
-    constexpr int PIECES = (IMG_B + 1023) / 1024;    // 1-KB DMA pieces per tile
-    constexpr int BUF_B = PIECES * 1024;             // buffer stride (the image + slack for the last piece)
-    constexpr int PPW = (PIECES + 7) / 8;            // pieces per wave (waves with index >= PIECES % 8 carry one less)
-    constexpr int PRE = NBUF - 1;                    // tiles requested ahead of the one being read
-    static_assert(D % 64 == 0 && (ROW_B / 4) % 64 == 4, "row stride must keep ds_read_b128 conflict-free");
-    static_assert(NBUF * BUF_B + 3 * 8 * 32 * 4 + 64 <= 160 * 1024, "LDS budget of one CU");
-    static_assert(PIECES % 8 != 0, "dma_wait assumes a ragged split (wave 0 carries one piece more)");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* tau_s = reinterpret_cast<float*>(smem + NBUF * BUF_B);              // [8][32] exact thresholds
-    unsigned int* cnt_s = reinterpret_cast<unsigned int*>(tau_s + 8 * 32);     // [8][32] survivors per query (this workgroup)
-    float* sim_s = reinterpret_cast<float*>(cnt_s + 8 * 32);                   // [8][32] conservative similarity bounds
-    unsigned int* sync_s = reinterpret_cast<unsigned int*>(sim_s + 8 * 32);    // SPLIT: [0] arrivals, [1] "a wave gave up waiting"
-
-    const int tid = (int)threadIdx.x;
-    const int lane = tid & 63;
-    // readfirstlane: tells hipcc the wave index is wave-uniform, so everything derived from it — the early / late order, and with
-    // it the survivor counters modified under that branch — stays in SGPRs
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t group = blockIdx.x / blocks_per_group;   // 256 queries per group
-    const uint32_t bidx = blockIdx.x % blocks_per_group;
-    const uint32_t q0 = group * 256 + wave * 32;             // this wave's 32 queries
-
-    // A fragments: lane l holds query (l & 31), k = 16*ks + 8*(l >> 5) .. +7
-    bf16x8 fa[KS];
-    {
-        const u32x4* qp = reinterpret_cast<const u32x4*>(a.qb + (size_t)(q0 + (lane & 31)) * D) + (lane >> 5);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) fa[ks] = __builtin_bit_cast(bf16x8, qp[ks * 2]);
-    }
-    if (!SAMPLE && lane < 32) {
-        const float tq = a.tau[q0 + lane];
-        tau_s[wave * 32 + lane] = tq;
-        sim_s[wave * 32 + lane] = (1.0f - tq) - 4e-7f * (1.0f + __builtin_fabsf(tq));   // see batch_gemm_rega_kernel
-    }
-    if (tid < 256) cnt_s[tid] = 0u;
-    if (SPLIT && tid < 2) sync_s[tid] = 0u;
-    const uint32_t seg_slots = a.seg_area / blocks_per_group;
-    const uint32_t seg_lane0 = (q0 + 4u * ((uint32_t)lane >> 5)) * a.cand_cap + a.seg_base + bidx * seg_slots;
-
-    const uint32_t ntiles_all = (a.slab_rows + TROWS - 1) / TROWS;
-    const uint32_t ntiles = SAMPLE ? a.sample_tiles : ntiles_all;
-    const uint32_t slab_end = a.slab0 + a.slab_rows;
-    const unsigned char* cbase = reinterpret_cast<const unsigned char*>(a.cb);
-    auto phys = [&](uint32_t tile) -> uint32_t {
-        return SAMPLE ? (uint32_t)(((unsigned long long)tile * ntiles_all) / a.sample_tiles) : tile;
-    };
-
-    // LDS-DMA map, recomputed per piece (a handful of VALU against 48 MFMAs; tables would cost 2 * PPW VGPRs):
-    // wave w moves pieces w, w + 8, ...; lane l of piece P fills slot P*64 + l of the padded image
-    const bool full_wave = (uint32_t)wave < (uint32_t)(PIECES % 8);          // wave-uniform: carries PPW pieces, the others PPW - 1
-    // piece i of this wave for the tile whose first row is row0, into the buffer at buf_off. The lane index is made opaque per
-    // piece: left to itself hipcc hoists the loop-invariant slot -> (row, column) arithmetic of all PPW pieces out of the tile loop —
-    // 3 VGPRs per piece the A fragments have no room for (they were spilled to scratch, and every reload drained the DMA queue
-    // with an s_waitcnt vmcnt(0))
-    auto dma_piece = [&](int i, uint32_t row0, uint32_t buf_off) {
-        if (i < PPW - 1 || full_wave) {
-            uint32_t lane_o = (uint32_t)lane;
-            asm volatile("" : "+v"(lane_o));
-            const uint32_t P = (uint32_t)wave + 8u * (uint32_t)i;
-            const uint32_t slot = P * 64u + lane_o;
-            uint32_t r = slot / (uint32_t)SLOTS_PER_ROW;
-            uint32_t c = slot - r * (uint32_t)SLOTS_PER_ROW;
-            c = c < (uint32_t)SEG_PER_ROW ? c : (uint32_t)SEG_PER_ROW - 1u;   // pad slot: any valid bytes
-            r = r < (uint32_t)TROWS ? r : (uint32_t)TROWS - 1u;               // slack behind the image: any valid bytes
-            uint32_t grow = row0 + r;
-            grow = grow < a.n_rows ? grow : a.n_rows - 1;                     // clamp: masked in the selection
-            const unsigned char* src = cbase + (size_t)grow * (D * 2) + c * 16u;
-            __builtin_amdgcn_global_load_lds((global_cvoid*)src, (lds_void*)(smem + buf_off + P * 1024u), 16, 0, 0);
-        }
-    };
-    auto dma_tile = [&](uint32_t tile, uint32_t buf_off) {
-        const uint32_t row0 = a.slab0 + phys(tile) * TROWS;
-#pragma unroll
-        for (int i = 0; i < PPW; ++i) dma_piece(i, row0, buf_off);
-    };
-    // this wave's DMA requests still allowed in flight: one whole tile, or none
-    auto dma_wait = [&](bool keep_one_tile) {
-        if (!keep_one_tile) wait_vmcnt<0>();
-        else if (full_wave) wait_vmcnt<PPW>();
-        else wait_vmcnt<PPW - 1>();
-    };
-
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-
-    const bool prio = (a.debug & 32u) == 0;
-    // K loop: see batch_gemm_rega_kernel (B fragments read AHEAD k-steps early, every step pinned by a sched_barrier)
-    auto mfma_tile = [&](const unsigned char* cur) {
-        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const unsigned char* b0 = cur + (lane & 31) * ROW_B + (lane >> 5) * 16;
-        constexpr int RING = AHEAD + 1;
-        u32x4 fb[RING];
-        f32x16 a1;
-#pragma unroll
-        for (int i = 0; i < AHEAD && i < KS; ++i) fb[i] = *reinterpret_cast<const u32x4*>(b0 + i * 32);
-        if (prio) __builtin_amdgcn_s_setprio(1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            if (ks + AHEAD < KS) fb[(ks + AHEAD) % RING] = *reinterpret_cast<const u32x4*>(b0 + (ks + AHEAD) * 32);
-            if (CHAINS == 2 && (ks & 1))
-                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], __builtin_bit_cast(bf16x8, fb[ks % RING]), ks == 1 ? zero16 : a1, 0, 0, 0);
-            else
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], __builtin_bit_cast(bf16x8, fb[ks % RING]), ks == 0 ? zero16 : acc, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (prio) __builtin_amdgcn_s_setprio(0);
-        if (CHAINS == 2) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] += a1[r];
-        }
-    };
-    // Fused selection on one 32-row block. Hot path as in batch_gemm_rega_kernel (16 compares against conservative bounds, wave-level
-    // flags per group of four queries). The cold path differs: a wave's 32 queries are ITS OWN (no other wave of the workgroup
-    // selects for them), so the per-(workgroup, query) survivor counters live in 32 SGPRs of the wave instead of in LDS, and a
-    // survivor's slot is counter + (passing lanes below it in its half-wave) — ballot, mbcnt, s_bcnt1: no LDS atomic round trip, no
-    // threshold read. Rows are admitted on the conservative bound itself (acc >= sim_lo, a superset of `1 - acc <= tau` by less
-    // than 1e-6: rejected rows still have d > tau, which is all the certificate uses). With the eight waves joined by a barrier
-    // per tile, an LDS round trip taken by ANY wave (some wave has a survivor in ~9 of 10 tiles) was paid by all of them:
-    // 175 - 215 us of a 1 770 us launch (profiles/r04).
-    // (two 16-bit counters per SGPR — 32 full ones do not fit beside the kernel's other scalars and hipcc then keeps them in
-    // VGPRs it has to spill — saturating at 0xFFFF, which is reported as an overflow: the query takes the exact path)
-    unsigned cq[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) cq[r] = 0u;
-    auto select_tile = [&](uint32_t tile) {
-        if (a.debug & 8u) return;
-        if (SAMPLE) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float m = group_max32(acc[r]);
-                if ((lane & 31) == 31)
-                    a.tile_max[(size_t)tile * (a.nqt * 128u) + q0 + (uint32_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5))] = m;
-            }
-            return;
-        }
-        const lds_f32x4* sim_w = (const lds_f32x4*)(sim_s + wave * 32 + 4 * (lane >> 5));
-        f32x4 lo[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) lo[j] = sim_w[2 * j];
-        unsigned long long hit[4] = {0ull, 0ull, 0ull, 0ull};
-#pragma unroll
-        for (int r = 0; r < 16; ++r) hit[r >> 2] |= __ballot(acc[r] >= lo[r >> 2][r & 3]);   // NaN fails
-        if ((hit[0] | hit[1] | hit[2] | hit[3]) == 0ull || (a.debug & 64u)) return;
-        const uint32_t row0 = a.slab0 + tile * TROWS + (lane & 31);
-        const bool ok0 = row0 < slab_end;
-        uint32_t seg_o = seg_lane0;                   // opaque: the 16 per-query row offsets are computed HERE (cold path), not
-        asm volatile("" : "+v"(seg_o));               // hoisted out of the tile loop into 16 VGPRs that do not exist
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            if (hit[g] == 0ull) continue;
-#pragma unroll
-            for (int r = 4 * g; r < 4 * g + 4; ++r) {
-                const bool p = ok0 && acc[r] >= lo[r >> 2][r & 3];
-                const unsigned long long m = __ballot(p);
-                if (m == 0ull) continue;
-                const unsigned n_lo = (unsigned)__builtin_popcount((unsigned)m), n_hi = (unsigned)__builtin_popcount((unsigned)(m >> 32));
-                const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                unsigned c0 = cq[r] & 0xFFFFu, c1 = cq[r] >> 16;
-                const unsigned off = lane < 32 ? c0 + below : c1 + (below - n_lo);
-                if (p && off < seg_slots && !(a.debug & 8192u)) {   // debug bit 13 (timing only): everything but the store
-                    const uint32_t e0 = seg_o + (uint32_t)((r & 3) + 8 * (r >> 2)) * a.cand_cap;
-                    a.cand[e0 + off] = make_key((1.0f - acc[r]) + 0.0f, a.row_base + row0);
-                }
-                c0 = c0 + n_lo < 0xFFFFu ? c0 + n_lo : 0xFFFFu;   // not clamped to seg_slots: a count above it tells the finish kernel that survivors were dropped
-                c1 = c1 + n_hi < 0xFFFFu ? c1 + n_hi : 0xFFFFu;
-                cq[r] = c0 | (c1 << 16);
-            }
-        }
-    };
-
-    // SPLIT: bounded spin on the arrival counter (see batch_gemm_rega_kernel: a wave that gives up poisons the workgroup's
-    // survivor counts, which sends its queries to the exact path — never a silent wrong answer)
-    bool gave_up = SPLIT && (a.debug & 16384u) != 0 && blockIdx.x == 1 && wave == 3;   // debug bit 14: pretend one wave timed out (tests)
-    const unsigned sync_addr = (unsigned)(size_t)(lds_u32*)sync_s;
-    auto wait_arrivals = [&](unsigned int target) {
-        bool ok = false;
-        for (unsigned int spins = 0; spins < (1u << 22); ++spins) {
-            unsigned int v;
-            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(sync_addr) : "memory");
-            if ((unsigned int)__builtin_amdgcn_readfirstlane((int)v) >= target) { ok = true; break; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        if (!ok) gave_up = true;
-    };
-    auto arrive = [&]() {
-        if (lane == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\tds_add_u32 %0, %1" ::"v"(sync_addr), "v"(1u) : "memory");
-    };
-
-    uint32_t t = bidx;
-    {
-        bool second = false;
-        if (t < ntiles) dma_tile(t, 0u);
-        if (PRE == 2 && t + blocks_per_group < ntiles) { dma_tile(t + blocks_per_group, (uint32_t)BUF_B); second = true; }
-        dma_wait(second);
-        __builtin_amdgcn_s_barrier();                         // also publishes tau_s / cnt_s / sim_s
-        asm volatile("" ::: "memory");
-    }
-    const bool late = wave >= 4 && !(a.debug & 16u);          // see batch_gemm_rega_kernel: the two waves of a SIMD work in opposite order
-    // Pace gate (advisory). With G > 1 query groups every corpus tile is wanted G times, by the G workgroups that share a `bidx` —
-    // they sit on the same XCD (block -> XCD is blockIdx % 8 and G * blocks_per_group = 256), so the second to G-th reader hit in its
-    // L2 as long as the groups stay within a few tiles of each other. Over a launch of milliseconds they do not (different survivor
-    // loads): config 5 whole fetched 1.13 - 1.64 x the mirror (FETCH_SIZE, profiles/r04). Every GATE_EVERY tiles wave 0 adds its
-    // progress to a word shared by the G workgroups of its bidx and, if it is more than GATE_WINDOW tiles ahead of their average,
-    // sleeps until they catch up — the other seven waves wait for it at the tile barrier. Bounded and advisory: a timeout (a group
-    // that started late behind another kernel) just proceeds; a workgroup that leaves the loop credits the word so that nobody
-    // waits for it.
-    constexpr uint32_t GATE_EVERY = 8u, GATE_WINDOW = 6u;
-    const uint32_t ngroups = gridDim.x / blocks_per_group;
-    const bool gate = !SAMPLE && a.progress != nullptr && ngroups > 1u && (blocks_per_group & 7u) == 0u && ngroups * blocks_per_group <= 256u && !(a.debug & 4096u);
-    const uint32_t* gate_word = gate ? a.progress + (bidx & 7u) * 32u + (bidx >> 3) : a.progress;   // one word per bidx, one 128-byte line per XCD
-    uint32_t it = 0, cur_idx = 0, t_prev = 0;
-    for (; t < ntiles; ++it) {
-        if (gate && wave == 0 && (it & (GATE_EVERY - 1u)) == 0u && it > 0u) {
-            // (returning atomics: the value comes from wherever agent-scope atomics execute, never from a stale cache line)
-            unsigned int add = GATE_EVERY;
-            for (uint32_t spins = 0; spins < 1024u; ++spins) {
-                unsigned int total = 0u;
-                if (lane == 0) total = __hip_atomic_fetch_add(const_cast<uint32_t*>(gate_word), add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add;
-                total = (unsigned int)__builtin_amdgcn_readfirstlane((int)total);
-                add = 0u;
-                // ahead of the average by more than the window?  G * it - total > G * WINDOW   (total counts tiles of all G groups)
-                if ((int)(ngroups * it - total) <= (int)(ngroups * GATE_WINDOW)) break;
-                __builtin_amdgcn_s_sleep(32);
-            }
-        }
-        const unsigned char* cur = smem + cur_idx * BUF_B;
-        const uint32_t tn = t + PRE * blocks_per_group;
-        uint32_t pre_idx = cur_idx + PRE;
-        pre_idx = pre_idx >= (uint32_t)NBUF ? pre_idx - NBUF : pre_idx;
-        bool issued = false;
-        if (SPLIT) {
-            if (late && it > 0) select_tile(t_prev);
-            // every wave is through K loop it - 1 (the buffer tile tn goes to is free) and has its pieces of tile `it` in LDS
-            if (it > 0) wait_arrivals(8u * it);
-            if (tn < ntiles) { dma_tile(tn, pre_idx * BUF_B); issued = true; }
-            mfma_tile(cur);
-            dma_wait(PRE == 2 && issued);
-            arrive();
-            if (!late) select_tile(t);
-            t_prev = t;
-            cur_idx = cur_idx + 1 == (uint32_t)NBUF ? 0u : cur_idx + 1;
-            t += blocks_per_group;
-            continue;
-        }
-        if (tn < ntiles) { dma_tile(tn, pre_idx * BUF_B); issued = true; }
-        // tile t + 1 must have landed before the barrier (every wave waits for its own pieces, the barrier joins them); with
-        // three tiles in LDS the one requested in this iteration stays in flight across it. The wait sits in FRONT of an early
-        // wave's selection: vmcnt counts the selection's survivor stores too, and a store issued just before the wait put a
-        // global-memory round trip on the barrier's critical path in ~9 of 10 tiles (some wave of the eight has a survivor).
-        if (late) {
-            if (it > 0) select_tile(t_prev);
-            mfma_tile(cur);
-            dma_wait(PRE == 2 && issued);
-        } else {
-            mfma_tile(cur);
-            dma_wait(PRE == 2 && issued);
-            select_tile(t);
-        }
-        t_prev = t;
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        cur_idx = cur_idx + 1 == (uint32_t)NBUF ? 0u : cur_idx + 1;
-        t += blocks_per_group;
-    }
-    if (late && it > 0) select_tile(t_prev);
-    if (gate && tid == 0) __hip_atomic_fetch_add(const_cast<uint32_t*>(gate_word), 1u << 24, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // done: nobody waits for this group
-    if (SPLIT && gave_up && lane == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(sync_addr + 4u), "v"(1u) : "memory");
-    if (!SAMPLE) {   // the wave's 32 survivor counters, SGPRs -> LDS: lane q takes query q's
-        unsigned mine = 0u;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            mine = lane == (r & 3) + 8 * (r >> 2) ? (cq[r] & 0xFFFFu) : mine;
-            mine = lane == (r & 3) + 8 * (r >> 2) + 4 ? (cq[r] >> 16) : mine;
-        }
-        if (lane < 32) cnt_s[wave * 32 + lane] = mine == 0xFFFFu ? 0x40000000u : mine;   // saturated = unknown = overflowed
-    }
-    __syncthreads();
-    if (!SAMPLE && tid < 256) {
-        const bool poisoned = SPLIT && sync_s[1] != 0u;       // a wave gave up waiting: nothing this workgroup selected can be trusted
-        a.seg_count[(size_t)bidx * (a.nqt * 128u) + group * 256u + (uint32_t)tid] = poisoned ? 0x40000000u : cnt_s[tid];
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Register-resident-queries GEMM, PING-PONG schedule (round 5; D * TROWS = 24 576: 768-d x 32 rows, 384-d x 64 rows, ...).
+// What round 5 changed (one kernel instead of four; D = 768 from 0.40 - 0.45 to 0.49 - 0.52 of the dense bf16 peak, same answers):
+//  1. NOTHING in the tile loop is an LDS access the compiler can see, and the A fragments are "used" before the first DMA request.
+//     hipcc's waitcnt pass cannot tell which LDS bytes a pending global_load_lds will write, nor count the requests of a loop it has
+//     not unrolled: the round-4 768-d kernel carried `s_waitcnt vmcnt(0) lgkmcnt(0)` in front of MFMA 0 of EVERY tile — it requested
+//     tile t + 2 and then waited for it to land before its first MFMA; the three-buffer ring never had anything in flight across
+//     a tile. Here B fragments and bounds are read by inline-asm ds_read_b128 with hand-counted lgkmcnt waits (LDS operations
+//     return in order: "at most N younger ones outstanding" implies that read f has landed, whatever else is queued), and the only
+//     vmcnt waits in the loop are the counted ones of dma_wait. (-6.5 % at D = 768.)
+//  2. A DMA request is four VALU instructions, or one. The padded image is cut into 1-KB pieces; lane l of piece P fills slot
+//     64 P + l. Slot -> global offset is 16 (slot - slot / SLOTS_PER_ROW) from a wave-uniform tile base (saddr form), with no clamps:
+//     a pad slot fetches the first bytes of the next row, the slack behind the image the row after the tile, a tile that runs past
+//     the store whatever the mirror holds there — all inside the mirror's allocation (capacity + 64 slack rows) and never used
+//     (rows >= slab_end are masked by the selection; a garbage row only pollutes its own output column). Where registers allow
+//     (D <= 512) the per-piece offsets stay in VGPRs. The round-4 form cost ~14 VALU + spilled-SGPR traffic per piece, 49 pieces per
+//     tile: -7 % at D = 768; with it the LDS-DMA kernel also overtook the register-staged one at D = 384.
+//  3. SPLIT (filtering launches): the tile barrier is "arrive" (a wave adds 1 to an LDS counter behind its K loop, once its own DMA
+//     pieces of the next tile have landed) and "wait" (spin on the counter in front of the next K loop, BEFORE requesting the tile
+//     that overwrites the buffer the previous K loop read): an early wave's selection sits between the two. (-1.5 ... -2.5 %.)
+//     The spin is bounded; a wave that gives up poisons its workgroup's survivor counts, which sends those queries to the exact
+//     path — never a silent wrong answer.
+// Measured and NOT kept (profiles/HISTORY.md, round 5): putting the two waves of a SIMD half a tile period apart ("ping-pong":
+// two barriers per tile, one wave multiplies while its partner requests and selects; also with all requests on the late half and
+// with fragment rings primed ahead of the barriers) — equal or slower at both dimensions: under any schedule the chip delivers the
+// same matrix rate at this power, what counts is the instructions and bytes per MFMA; deeper / shallower read-ahead: no change.
+// The two waves of a SIMD still work in opposite order (waves 0-3: K loop, then select; waves 4-7: select the previous tile, then K
+// loop), which is worth 11 %.
 //
-// Same data path as batch_gemm_wide_kernel — 32 queries x D per wave as MFMA A fragments, corpus tiles by LDS-DMA into a ring of
-// NBUF padded tile images, one ds_read_b128 per MFMA, SGPR survivor counters — with two differences that the round-4 counters
-// asked for (matrix pipe 55 % busy, waves parked 48 %, no bank conflicts, traffic 1.00 x):
-//
-//  1. NOTHING in the tile loop is an LDS access the compiler can see. hipcc's waitcnt pass cannot tell which LDS bytes a pending
-//     global_load_lds will write, so in front of the first B-fragment read of every tile it emitted `s_waitcnt vmcnt(0)` — the wide
-//     kernel issued tile t + 2's DMA and then WAITED FOR IT TO LAND (an L2 / HBM round trip per tile, on every wave) before its
-//     first MFMA: the three-buffer ring never had anything in flight across a tile (rocm 7.2 ISA of the round-4 build:
-//     `s_waitcnt vmcnt(0) lgkmcnt(0)` ahead of MFMA 0 of the K loop). Here the B fragments and the selection's bounds are read by
-//     inline-asm ds_read_b128 with hand-counted lgkmcnt waits (LDS operations return in order: "at most N younger ones outstanding"
-//     implies that read f has landed, whatever else is queued), and the only vmcnt waits are the counted ones below.
-//  2. The two waves of a SIMD are HALF A TILE PERIOD apart (PING): waves 0-3 multiply tile t (48 MFMAs back to back, s_setprio 1)
-//     while waves 4-7 select tile t - 1 and request their pieces of tile t + PRE; an s_barrier; then waves 4-7 multiply tile t while
-//     waves 0-3 request their pieces, wait for tile t + 1 and select tile t; an s_barrier. A SIMD's matrix pipe always has exactly
-//     one wave feeding it, and everything that is not an MFMA (DMA address arithmetic, the selection with its cold path and global
-//     stores, the waits) runs in the shadow of the partner's MFMAs instead of at the tile boundary where BOTH waves used to do it
-//     with the pipe idle. Two barriers per tile, but no wave ever arrives at one with matrix work pending behind it.
-//     Hazards: tile t + PRE goes to the buffer tile t - 1 was read from; its last reader (a late wave's K loop of period t - 1)
-//     ended before the barrier that opens period t, and both halves request after that barrier. A wave waits for its OWN pieces of
-//     tile t + 1 (counted vmcnt: the PRE - 1 younger tiles stay in flight; survivor stores are older than those and complete first)
-//     before the barrier that ends period t; readers start behind that barrier.
-// PING = false keeps one barrier per tile and the early / late order of the wide kernel (A/B of item 1 alone).
-template <int D, int TROWS, int NBUF, int AHEAD, bool SAMPLE = false, int MODE = 2>
-__global__ __launch_bounds__(512, 2) void batch_gemm_pp_kernel(GemmArgs a, uint32_t blocks_per_group) {
-    constexpr bool PING = MODE >= 1 && MODE <= 3;    // two barriers per tile, the halves half a period apart
-    constexpr bool LATE_DMA = MODE == 2 || MODE == 3;   // only waves 4-7 request tiles; the late half's fragment ring is primed ahead of the MID barrier
-    constexpr bool EARLY_HEAD = MODE == 2;           // ... and the early half's ahead of the END barrier (its ring is then live around the loop)
-    constexpr bool EARLY_DMA_AFTER = MODE == 4;      // one barrier per tile; the early half multiplies FIRST and requests tile t + PRE behind its K loop
-    constexpr bool SPLIT = MODE == 5;                // one SPLIT barrier per tile (arrive behind the K loop, wait in front of the next): selection between the two
+// SAMPLE = true (one-pass pipeline, threshold estimation): instead of filtering, the workgroup visits `a.sample_tiles` tiles spread
+// evenly over the slab (logical index i -> tile i * ntiles / sample_tiles) and records, per query, the best similarity of each
+// visited tile in a.tile_max[i][query] (pick_tau_kernel turns the j-th best tile maximum into the query's admission threshold).
+template <int D, int TROWS, int NBUF, int AHEAD, bool SAMPLE, bool SPLIT>
+__global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint32_t blocks_per_group) {
     constexpr int KS = D / 16;                       // MFMA k-steps
     constexpr int RB = TROWS / 32;                   // 32-row blocks per tile = accumulators per wave
     constexpr int NF = KS * RB;                      // B fragments (= MFMAs) per wave and tile; fragment f = (k-step f / RB, block f % RB)
@@ -1545,11 +475,14 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_pp_kernel(GemmArgs a, uint3
     constexpr int IMG_B = TROWS * ROW_B;             // padded tile image
     constexpr int PIECES = (IMG_B + 1023) / 1024;    // 1-KB DMA pieces per tile
     constexpr int BUF_B = PIECES * 1024;             // buffer stride (the image + slack for the last piece)
+    constexpr int PPW = (PIECES + 7) / 8;            // pieces per wave
+    constexpr int FULL_WAVES = PIECES % 8 == 0 ? 8 : PIECES % 8;   // waves below this index carry PPW pieces, the others PPW - 1
     constexpr int PRE = NBUF - 1;                    // tiles requested ahead of the one being read
     constexpr int RING = AHEAD + 1;
+    static_assert(!(SAMPLE && SPLIT), "the sampling launch keeps the workgroup barrier");
     static_assert(TROWS % 32 == 0 && RB >= 1 && RB <= 4, "tile = 1..4 MFMA row blocks");
     static_assert(D % 64 == 0 && (ROW_B / 4) % 64 == 4, "row stride must keep ds_read_b128 conflict-free");
-    static_assert(NBUF >= 3, "a tile is requested at least two periods before it is read");
+    static_assert(NBUF >= 2, "one tile is read while the next lands");
     static_assert(NBUF * BUF_B + 2 * 8 * 32 * 4 + 64 <= 160 * 1024, "LDS budget of one CU");
     static_assert((RB - 1) * 32 * ROW_B + (KS - 1) * 32 < 65536, "ds_read offset field");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1577,8 +510,10 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_pp_kernel(GemmArgs a, uint3
         for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(fa[ks]));
     }
     if (!SAMPLE && lane < 32) {
+        // conservative bound for the hot test: rows with acc >= sim_lo are admitted (a superset of `1 - acc <= tau` by less than
+        // 1e-6: rejected rows still have d > tau, which is all the certificate uses)
         const float tq = a.tau[q0 + lane];
-        sim_s[wave * 32 + lane] = (1.0f - tq) - 4e-7f * (1.0f + __builtin_fabsf(tq));   // see batch_gemm_rega_kernel
+        sim_s[wave * 32 + lane] = (1.0f - tq) - 4e-7f * (1.0f + __builtin_fabsf(tq));
     }
     if (SPLIT && tid < 2) sync_s[tid] = 0u;
     const uint32_t seg_slots = a.seg_area / blocks_per_group;
@@ -1588,111 +523,80 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_pp_kernel(GemmArgs a, uint3
     const uint32_t ntiles = SAMPLE ? a.sample_tiles : ntiles_all;
     const uint32_t slab_end = a.slab0 + a.slab_rows;
     const unsigned char* cbase = reinterpret_cast<const unsigned char*>(a.cb);
-    auto phys = [&](uint32_t tile) -> uint32_t {
-        return SAMPLE ? (uint32_t)(((unsigned long long)tile * ntiles_all) / a.sample_tiles) : tile;
-    };
 
-    // LDS-DMA map (as in batch_gemm_wide_kernel): wave w moves pieces w, w + 8, ...; lane l of piece P fills slot P*64 + l of
-    // the padded image; the arithmetic is redone per piece behind an opaque lane index so that it is not hoisted into VGPRs
-    // LATE_DMA: the four late waves carry all of it (pieces w - 4, w, w + 4, ...)
-    constexpr int DW = LATE_DMA ? 4 : 8;                                       // waves that request
-    constexpr int PPWD = (PIECES + DW - 1) / DW;                               // pieces per requesting wave
-    constexpr int FULLD = PIECES % DW == 0 ? DW : PIECES % DW;                 // requesting waves below this index carry PPWD pieces
-    const int dwave = LATE_DMA ? wave - 4 : wave;
-    const bool full_wave = dwave >= 0 && dwave < FULLD;
-    auto dma_piece = [&](int i, uint32_t row0, uint32_t buf_off) {
-        if (i < PPWD - 1 || full_wave) {
-            uint32_t lane_o = (uint32_t)lane;
-            asm volatile("" : "+v"(lane_o));
-            const uint32_t P = (uint32_t)dwave + (uint32_t)DW * (uint32_t)i;
-            const uint32_t slot = P * 64u + lane_o;
-            uint32_t r = slot / (uint32_t)SLOTS_PER_ROW;
-            uint32_t c = slot - r * (uint32_t)SLOTS_PER_ROW;
-            c = c < (uint32_t)SEG_PER_ROW ? c : (uint32_t)SEG_PER_ROW - 1u;   // pad slot: any valid bytes
-            r = r < (uint32_t)TROWS ? r : (uint32_t)TROWS - 1u;               // slack behind the image: any valid bytes
-            uint32_t grow = row0 + r;
-            grow = grow < a.n_rows ? grow : a.n_rows - 1;                     // clamp: masked in the selection
-            const unsigned char* src = cbase + (size_t)grow * (D * 2) + c * 16u;
-            __builtin_amdgcn_global_load_lds((global_cvoid*)src, (lds_void*)(smem + buf_off + P * 1024u), 16, 0, 0);
-        }
-    };
-    // Filtering launch: no clamps. A pad slot fetches the first 16 bytes of the next row, the slack behind the image the row after the
-    // tile, a tile that runs past the store whatever the mirror holds there — all of it inside the mirror's allocation (capacity + 64
-    // slack rows, ensure_mirror) and none of it ever used (pad bytes are never read as fragments, rows >= slab_end are masked by the
-    // selection; a garbage row only pollutes its own output column). Then slot -> global offset is 16 * (slot - slot / SLOTS_PER_ROW)
-    // from a uniform tile base: a multiply, a shift, a subtract and a shift per piece (the general form above costs ~14 VALU plus
-    // the spilled-SGPR traffic of its clamps).
+    // LDS-DMA map: wave w moves pieces w, w + 8, ...; lane l of piece P fills slot P*64 + l of the padded image (point 2 above)
+    const bool full_wave = wave < FULL_WAVES;
     constexpr uint32_t DIV_SHIFT = 18, DIV_MAGIC = ((1u << DIV_SHIFT) + SLOTS_PER_ROW - 1) / SLOTS_PER_ROW;
     static_assert((uint64_t)(PIECES * 64) * (DIV_MAGIC * (uint64_t)SLOTS_PER_ROW - (1u << DIV_SHIFT)) < (1u << DIV_SHIFT),
                   "magic division must be exact for every slot of a tile");
-    // Where the A fragments leave room (D <= 512) the per-piece offsets are computed once and stay in VGPRs: a request is then ONE
-    // instruction (saddr form: uniform tile base + the lane's 32-bit offset).
-    constexpr bool CACHE_OFF = !SAMPLE && D <= 512;
-    uint32_t doff[CACHE_OFF ? PPWD : 1];
+    constexpr bool CACHE_OFF = !SAMPLE && D <= 512;  // per-piece offsets in VGPRs: a request is ONE instruction
+    uint32_t doff[CACHE_OFF ? PPW : 1];
     if (CACHE_OFF) {
 #pragma unroll
-        for (int i = 0; i < PPWD; ++i) {
-            const uint32_t slot = ((uint32_t)(dwave < 0 ? 0 : dwave) + (uint32_t)DW * (uint32_t)i) * 64u + (uint32_t)lane;
+        for (int i = 0; i < PPW; ++i) {
+            const uint32_t slot = ((uint32_t)wave + 8u * (uint32_t)i) * 64u + (uint32_t)lane;
             doff[i] = (slot - ((slot * DIV_MAGIC) >> DIV_SHIFT)) * 16u;
         }
     }
     auto dma_tile = [&](uint32_t tile, uint32_t buf_off) {
-        if (a.debug & 1u) return;                    // timing only: no corpus stream (the K loop reads whatever is in LDS)
-        if (SAMPLE) {
-            const uint32_t row0 = a.slab0 + phys(tile) * TROWS;
 #pragma unroll
-            for (int i = 0; i < PPWD; ++i) dma_piece(i, row0, buf_off);
-            return;
-        }
-        const unsigned char* tbase = cbase + (size_t)(a.slab0 + tile * TROWS) * (D * 2);   // wave-uniform
-#pragma unroll
-        for (int i = 0; i < PPWD; ++i) {
-            if (i < PPWD - 1 || full_wave) {
-                const uint32_t P = (uint32_t)dwave + (uint32_t)DW * (uint32_t)i;
-                uint32_t off;
-                if constexpr (CACHE_OFF) {
-                    off = doff[i];
-                } else {
+        for (int i = 0; i < PPW; ++i) {
+            if (i < PPW - 1 || full_wave) {
+                const uint32_t P = (uint32_t)wave + 8u * (uint32_t)i;
+                if constexpr (SAMPLE) {
+                    // scattered tiles, the last of which may run past the store: rows are clamped to its last row (a duplicate of a
+                    // real row cannot raise a tile maximum), pad and slack slots to valid bytes
+                    const uint32_t row0 = a.slab0 + (uint32_t)(((unsigned long long)tile * ntiles_all) / a.sample_tiles) * TROWS;
                     uint32_t lane_o = (uint32_t)lane;
-                    asm volatile("" : "+v"(lane_o));  // (recomputed per piece: no per-piece VGPRs live around the tile loop)
+                    asm volatile("" : "+v"(lane_o));      // (recomputed per piece: no per-piece VGPRs live around the tile loop)
                     const uint32_t slot = P * 64u + lane_o;
-                    off = (slot - ((slot * DIV_MAGIC) >> DIV_SHIFT)) * 16u;
+                    uint32_t r = slot / (uint32_t)SLOTS_PER_ROW;
+                    uint32_t c = slot - r * (uint32_t)SLOTS_PER_ROW;
+                    c = c < (uint32_t)SEG_PER_ROW ? c : (uint32_t)SEG_PER_ROW - 1u;
+                    r = r < (uint32_t)TROWS ? r : (uint32_t)TROWS - 1u;
+                    uint32_t grow = row0 + r;
+                    grow = grow < a.n_rows ? grow : a.n_rows - 1;
+                    const unsigned char* src = cbase + (size_t)grow * (D * 2) + c * 16u;
+                    __builtin_amdgcn_global_load_lds((global_cvoid*)src, (lds_void*)(smem + buf_off + P * 1024u), 16, 0, 0);
+                } else {
+                    const unsigned char* tbase = cbase + (size_t)(a.slab0 + tile * TROWS) * (D * 2);   // wave-uniform
+                    uint32_t off;
+                    if constexpr (CACHE_OFF) {
+                        off = doff[i];
+                    } else {
+                        uint32_t lane_o = (uint32_t)lane;
+                        asm volatile("" : "+v"(lane_o));
+                        const uint32_t slot = P * 64u + lane_o;
+                        off = (slot - ((slot * DIV_MAGIC) >> DIV_SHIFT)) * 16u;
+                    }
+                    __builtin_amdgcn_global_load_lds((global_cvoid*)(tbase + off), (lds_void*)(smem + buf_off + P * 1024u), 16, 0, 0);
                 }
-                __builtin_amdgcn_global_load_lds((global_cvoid*)(tbase + off), (lds_void*)(smem + buf_off + P * 1024u), 16, 0, 0);
             }
         }
     };
     // this wave's DMA requests still allowed in flight: PRE - 1 whole tiles, or none
     auto dma_wait = [&](bool keep) {
         if (!keep) wait_vmcnt<0>();
-        else if (full_wave) wait_vmcnt<(PRE - 1) * PPWD>();
-        else wait_vmcnt<(PRE - 1) * (PPWD - 1)>();
+        else if (full_wave) wait_vmcnt<(PRE - 1) * PPW>();
+        else wait_vmcnt<(PRE - 1) * (PPW - 1)>();
     };
 
     f32x16 acc[RB];
-    u32x4 fb[RING];                                  // B-fragment ring (kernel scope: LATE_DMA fills its head ahead of a barrier)
-    const bool prio = (a.debug & 32u) == 0;
     const uint32_t smem_lds = (uint32_t)(size_t)(lds_void*)smem;
     const uint32_t lane_boff = (uint32_t)(lane & 31) * (uint32_t)ROW_B + (uint32_t)(lane >> 5) * 16u;
     // K loop. Fragment f + AHEAD is requested before MFMA f; the wait in front of MFMA f leaves at most min(AHEAD, NF - 1 - f)
-    // younger reads outstanding. Every step is pinned (sched_barrier) — hipcc otherwise hoists an MFMA over the asm wait it depends on.
-    auto mfma_head = [&](uint32_t baddr) {           // request fragments 0 .. AHEAD - 1
+    // younger reads outstanding. Every step is pinned (sched_barrier) — hipcc otherwise hoists an MFMA over the asm wait it depends
+    // on. s_setprio 1 lets the multiplying wave win issue arbitration against its selecting partner.
+    auto mfma_tile = [&](uint32_t baddr) {
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        u32x4 fb[RING];
         static_for<0, (AHEAD < NF ? AHEAD : NF)>([&](auto F) {
             constexpr int f = decltype(F)::value;
             u32x4(&fbr)[RING] = fb;                  // (asm operands alone do not make a generic lambda capture)
             const uint32_t ba = baddr;
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fbr[f % RING]) : "v"(ba), "n"((f % RB) * 32 * ROW_B + (f / RB) * 32));
         });
-    };
-    auto mfma_body = [&](uint32_t baddr) {
-        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (a.debug & 2u) {                          // timing only: no K loop (the ring's head is retired, the accumulators defined)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int b = 0; b < RB; ++b) acc[b] = zero16;
-            return;
-        }
-        if (prio) __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(1);
         __builtin_amdgcn_sched_barrier(0);
         static_for<0, NF>([&](auto F) {
             constexpr int f = decltype(F)::value;
@@ -1708,27 +612,26 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_pp_kernel(GemmArgs a, uint3
             acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], __builtin_bit_cast(bf16x8, fbr[f % RING]), ks == 0 ? zero16 : acc[rb], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         });
-        if (prio) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(0);
     };
-    auto mfma_tile = [&](uint32_t baddr) {
-        mfma_head(baddr);
-        mfma_body(baddr);
-    };
-    // Fused selection, see batch_gemm_wide_kernel (hot test against conservative bounds, wave-level flags per four queries; cold
-    // path with the wave's 32 per-query survivor counters in SGPRs, two saturating 16-bit counters each). The bounds are read by
-    // inline asm (point 1 above).
+    // Fused selection on one tile. C/D layout of the 32x32 MFMA: column = lane & 31 (corpus row of the block), row =
+    // (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (query of the wave). Hot path: 16 RB compares against the bounds (one LDS round trip:
+    // four aligned float4 per lane), OR-ed into wave-level flags per group of four queries; nothing set (the common case) = done.
+    // Cold path: a wave's 32 queries are ITS OWN (no other wave of the workgroup selects for them), so the per-(workgroup, query)
+    // survivor counters are 16 SGPRs of the wave (two saturating 16-bit counters each; 0xFFFF is reported as an overflow: the query
+    // takes the exact path) and a survivor's slot is counter + (passing lanes below it in its half-wave): ballot, mbcnt, s_bcnt1 —
+    // no LDS atomic, no threshold read.
     unsigned cq[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) cq[r] = 0u;
     const uint32_t sim_addr = (uint32_t)(size_t)(lds_void*)sim_s + (uint32_t)(wave * 32 + 4 * (lane >> 5)) * 4u;
     auto select_tile = [&](uint32_t tile) {
-        if (a.debug & 8u) return;
         if (SAMPLE) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float v = acc[0][r];
 #pragma unroll
-                for (int b = 1; b < RB; ++b) v = __builtin_fmaxf(v, acc[b][r]);   // rows past the store are clamped copies of its last row
+                for (int b = 1; b < RB; ++b) v = __builtin_fmaxf(v, acc[b][r]);
                 const float m = group_max32(v);
                 if ((lane & 31) == 31)
                     a.tile_max[(size_t)tile * (a.nqt * 128u) + q0 + (uint32_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5))] = m;
@@ -1755,9 +658,9 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_pp_kernel(GemmArgs a, uint3
 #pragma unroll
             for (int g = 0; g < 4; ++g) any |= hit[b][g];
         }
-        if (any == 0ull || (a.debug & 64u)) return;
-        uint32_t seg_o = seg_lane0;                   // opaque: the per-query row offsets are computed HERE (cold path)
-        asm volatile("" : "+v"(seg_o));
+        if (any == 0ull) return;
+        uint32_t seg_o = seg_lane0;                   // opaque: the per-query row offsets are computed HERE (cold path), not
+        asm volatile("" : "+v"(seg_o));               // hoisted out of the tile loop into VGPRs that do not exist
 #pragma unroll
         for (int b = 0; b < RB; ++b) {
             const uint32_t row0 = a.slab0 + tile * TROWS + (uint32_t)(b * 32) + (uint32_t)(lane & 31);
@@ -1792,36 +695,42 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_pp_kernel(GemmArgs a, uint3
 #pragma unroll
         for (int i = 0; i < PRE; ++i) {
             const uint32_t ti = t + (uint32_t)i * blocks_per_group;
-            if (ti < ntiles) { if (!LATE_DMA || wave >= 4) dma_tile(ti, (uint32_t)(i * BUF_B)); } else all = false;
+            if (ti < ntiles) dma_tile(ti, (uint32_t)(i * BUF_B)); else all = false;
         }
-        if (!LATE_DMA || wave >= 4) dma_wait(all);
-        __builtin_amdgcn_s_barrier();                         // also publishes sim_s
+        dma_wait(all);
+        __builtin_amdgcn_s_barrier();                         // also publishes sim_s / sync_s
         asm volatile("" ::: "memory");
     }
-    const bool late = wave >= 4 && (PING || !(a.debug & 16u));   // debug bit 4 (timing only, MODE 0): every wave in the early order
-    // Pace gate (advisory; see batch_gemm_wide_kernel): with G > 1 query groups the G workgroups of a bidx are kept within a few
-    // tiles of each other so that a tile fetched for one is still in the XCD's L2 when the others want it. Wave 0 runs it in its
-    // side phase (PING), in the shadow of the late half's MFMAs.
+    const bool late = wave >= 4;
+    // Pace gate (advisory). With G > 1 query groups every corpus tile is wanted G times, by the G workgroups that share a `bidx` —
+    // they sit on the same XCD (block -> XCD is blockIdx % 8 and G * blocks_per_group = 256), so the second to G-th reader hit in its
+    // L2 as long as the groups stay within a few tiles of each other. Over a launch of milliseconds they do not (different survivor
+    // loads): config 5 whole fetched 1.13 - 1.64 x the mirror (FETCH_SIZE, profiles/r04). Every GATE_EVERY tiles wave 0 adds its
+    // progress to a word shared by the G workgroups of its bidx and, if it is more than GATE_WINDOW tiles ahead of their average,
+    // sleeps until they catch up — the other seven waves wait for it at the tile barrier. Bounded and advisory: a timeout (a group
+    // that started late behind another kernel) just proceeds; a workgroup that leaves the loop credits the word so that nobody
+    // waits for it. ("batch_debug" bit 12 switches it off.)
     constexpr uint32_t GATE_EVERY = 8u, GATE_WINDOW = 6u;
     const uint32_t ngroups = gridDim.x / blocks_per_group;
     const bool gate = !SAMPLE && a.progress != nullptr && ngroups > 1u && (blocks_per_group & 7u) == 0u && ngroups * blocks_per_group <= 256u && !(a.debug & 4096u);
     const uint32_t* gate_word = gate ? a.progress + (bidx & 7u) * 32u + (bidx >> 3) : a.progress;   // one word per bidx, one 128-byte line per XCD
     auto pace = [&](uint32_t it) {
         if (gate && wave == 0 && (it & (GATE_EVERY - 1u)) == 0u && it > 0u) {
+            // (returning atomics: the value comes from wherever agent-scope atomics execute, never from a stale cache line)
             unsigned int add = GATE_EVERY;
             for (uint32_t spins = 0; spins < 1024u; ++spins) {
                 unsigned int total = 0u;
                 if (lane == 0) total = __hip_atomic_fetch_add(const_cast<uint32_t*>(gate_word), add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add;
                 total = (unsigned int)__builtin_amdgcn_readfirstlane((int)total);
                 add = 0u;
+                // ahead of the average by more than the window?  G * it - total > G * WINDOW   (total counts tiles of all G groups)
                 if ((int)(ngroups * it - total) <= (int)(ngroups * GATE_WINDOW)) break;
                 __builtin_amdgcn_s_sleep(32);
             }
         }
     };
-    // SPLIT: bounded spin on the arrival counter (a wave that gives up poisons the workgroup's survivor counts, which sends its
-    // queries to the exact path — never a silent wrong answer). The counter is touched through inline assembly only.
-    bool gave_up = SPLIT && (a.debug & 16384u) != 0 && blockIdx.x == 1 && wave == 3;   // debug bit 14: pretend one wave timed out (tests)
+    // SPLIT: bounded spin on the arrival counter. The counter is touched through inline assembly only (point 1 above).
+    bool gave_up = SPLIT && (a.debug & 16384u) != 0 && blockIdx.x == 1 && wave == 3;   // "batch_debug" bit 14: pretend one wave timed out (tests)
     const unsigned sync_addr = (unsigned)(size_t)(lds_u32*)sync_s;
     auto wait_arrivals = [&](unsigned int target) {
         bool ok = false;
@@ -1837,107 +746,29 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_pp_kernel(GemmArgs a, uint3
         if (lane == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\tds_add_u32 %0, %1" ::"v"(sync_addr), "v"(1u) : "memory");
     };
     uint32_t it = 0, cur_idx = 0, t_prev = 0;
-    if (EARLY_HEAD && !late && t < ntiles) {                  // tile t is published by the prologue's barrier
-        mfma_head(smem_lds + lane_boff);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
     for (; t < ntiles; ++it) {
         const uint32_t baddr = smem_lds + cur_idx * (uint32_t)BUF_B + lane_boff;
         const uint32_t tn = t + PRE * blocks_per_group;
         uint32_t pre_idx = cur_idx + PRE;
         pre_idx = pre_idx >= (uint32_t)NBUF ? pre_idx - NBUF : pre_idx;
         const bool issued = tn < ntiles;
-        if (LATE_DMA) {
-            // period t. Phase A: the early half multiplies tile t; the late half selects tile t - 1, requests tile t + PRE, waits for
-            // tile t + 1 (so that the MID barrier publishes it) and requests the head of its own K loop. Phase B: the late half
-            // multiplies tile t; the early half selects tile t and requests the head of K loop t + 1 ahead of the END barrier.
-            if (!late) {
-                if (!EARLY_HEAD) mfma_head(baddr);
-                mfma_body(baddr);
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                pace(it);
-                select_tile(t);
-                if (EARLY_HEAD && t + blocks_per_group < ntiles) {
-                    uint32_t nxt_idx = cur_idx + 1 == (uint32_t)NBUF ? 0u : cur_idx + 1;
-                    mfma_head(smem_lds + nxt_idx * (uint32_t)BUF_B + lane_boff);
-                    // landed before anything the compiler may do with these registers around the loop edge (the wave would sit at
-                    // the barrier meanwhile anyway)
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                }
-            } else {
-                if (it > 0) select_tile(t_prev);
-                if (issued) dma_tile(tn, pre_idx * BUF_B);
-                dma_wait(issued);
-                mfma_head(baddr);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                mfma_body(baddr);
-            }
-        } else if (PING) {
-            if (!late) {
-                mfma_tile(baddr);
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                pace(it);                                     // (its returning atomic drains this wave's DMA queue: tile t + 1, long landed)
-                if (issued) dma_tile(tn, pre_idx * BUF_B);
-                dma_wait(issued);
-                select_tile(t);
-            } else {
-                if (it > 0) select_tile(t_prev);
-                if (issued) dma_tile(tn, pre_idx * BUF_B);
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                mfma_tile(baddr);
-                dma_wait(issued);
-            }
-        } else if (SPLIT) {
-            if (late && it > 0) select_tile(t_prev);
-            // every wave is through K loop it - 1 (the buffer tile tn goes to is free) and has its pieces of tile `it` in LDS
-            if (it > 0) wait_arrivals(8u * it);
-            pace(it);
-            if (issued) dma_tile(tn, pre_idx * BUF_B);
-            mfma_tile(baddr);
-            dma_wait(issued);
-            arrive();
-            if (!late) select_tile(t);
-            t_prev = t;
-            cur_idx = cur_idx + 1 == (uint32_t)NBUF ? 0u : cur_idx + 1;
-            t += blocks_per_group;
-            continue;
-        } else if (EARLY_DMA_AFTER) {
-            // Behind the barrier the early half goes straight into its K loop (the matrix pipe is busy at once) while the late half
-            // selects tile t - 1 and requests its pieces of tile t + PRE in the shadow of those MFMAs; the early half requests its
-            // pieces, waits and selects behind its K loop, in the shadow of the late half's.
-            if (late) {
-                if (it > 0) select_tile(t_prev);
-                if (issued) dma_tile(tn, pre_idx * BUF_B);
-                mfma_tile(baddr);
-                dma_wait(issued);
-            } else {
-                mfma_tile(baddr);
-                pace(it);
-                if (issued) dma_tile(tn, pre_idx * BUF_B);
-                dma_wait(issued);
-                select_tile(t);
-            }
-        } else {
-            pace(it);
-            if (issued) dma_tile(tn, pre_idx * BUF_B);
-            if (late) {
-                if (it > 0) select_tile(t_prev);
-                mfma_tile(baddr);
-                dma_wait(issued);
-            } else {
-                mfma_tile(baddr);
-                dma_wait(issued);
-                select_tile(t);
-            }
-        }
+        if (late && it > 0) select_tile(t_prev);
+        // every wave is through K loop it - 1 (the buffer tile tn goes to is free) and has its pieces of tile `it` in LDS
+        if (SPLIT && it > 0) wait_arrivals(8u * it);
+        pace(it);
+        if (issued) dma_tile(tn, pre_idx * BUF_B);
+        mfma_tile(baddr);
+        // tile t + 1 must have landed before the others read it (every wave waits for its own pieces, the barrier / the arrival
+        // counter joins them); the PRE - 1 younger tiles stay in flight. The wait sits in FRONT of an early wave's selection:
+        // vmcnt counts the selection's survivor stores too (they are older than the requests that stay in flight and complete first)
+        dma_wait(issued);
+        if (SPLIT) arrive();
+        if (!late) select_tile(t);
         t_prev = t;
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
+        if (!SPLIT) {
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
         cur_idx = cur_idx + 1 == (uint32_t)NBUF ? 0u : cur_idx + 1;
         t += blocks_per_group;
     }
@@ -1960,531 +791,79 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_pp_kernel(GemmArgs a, uint3
     }
 }
 
-// ---------------------------------------------------------------------------
-// Register-resident-queries GEMM, ONE wave per SIMD ("w4": batch_rega = 3; D in {128, 256, 384, 512}).
-//
-// batch_gemm_rega_kernel keeps 32 queries per wave and two waves per SIMD: every B fragment read from LDS feeds one
-// MFMA, the two waves of a SIMD split the matrix pipe, only ONE 48 KB tile per CU is in flight from HBM (which caps
-// the stream near 6 TB/s: bytes in flight / latency), and its counters say the pipe is busy 48 % of the time with
-// the waves parked on LDS / barriers for most of the rest (profiles/r01/ay_*). Here a workgroup is 4 waves — one per
-// SIMD, 512 registers each — and a wave keeps 64 queries (two A-fragment sets, 192 VGPRs at D = 384):
-//   * every B fragment feeds TWO MFMAs (both query sets): half the LDS reads per flop;
-//   * a k-step is 1 ds_read_b128 + 2 MFMAs on two independent accumulators, ~2 other instructions per MFMA issue
-//     slot, far below the ~5 a wave can hide behind a 32-cycle MFMA;
-//   * tiles are 32 rows (24.5 KB at D = 384) in a ring of NBUF LDS buffers filled by LDS-DMA
-//     (global_load_lds_dwordx4: no staging registers, no ds_write pass), requested PRE = NBUF - 2 tiles ahead
-//     (D = 384: 6 buffers, 4 tiles = 98 KB per CU in flight) with counted vmcnt waits and a raw s_barrier per tile,
-//     so the requests stay in flight across barriers;
-//   * the threshold test costs no compare against a per-query value: the accumulators start at -(sim_lo_q) instead
-//     of 0 (the first MFMA of a tile takes its C operand from 32 loop-invariant registers), so "passes its query's
-//     threshold" is the SIGN of the accumulator. The selection of tile t-1 (second accumulator set) is spread over
-//     the k-steps of tile t: one quad of accumulators at a time — v_max3, v_max, v_cmp, branch — in the shadow of
-//     the MFMAs; only a quad with a hit (~1 per tile at ~500 survivors per query) leaves the stream for ~40
-//     instructions (exact re-test d = 1 - (acc + sim_lo) <= tau, slot from an LDS counter, 8-byte store).
-// The padded tile image (row stride 2D + 16 bytes) is cut into 1-KB DMA pieces; lane l of piece P fetches whatever
-// belongs at slot 64 P + l (a row's pad slot re-fetches its last segment); the last piece may run past the 32 rows
-// into the rows that follow — the mirror is allocated with slack rows for that, and rows past the slab are masked by
-// the selection. Survivor segments, thresholds and the exact test are those of batch_gemm_rega_kernel, so the host
-// side and batch_finish_kernel do not know which of the two ran. A query whose threshold is not finite (no usable
-// sample) is marked as overflowed (count 2^30) and answered by the exact path.
-template <int D, int AH = 3>
-struct W4Geom {
-    static constexpr int KS = D / 16;                                   // MFMA k-steps
-    static constexpr int ROW_B = D * 2 + 16;                            // LDS row stride (bytes): conflict-free ds_read_b128
-    static constexpr int TROWS = 32;
-    static constexpr int PIECES = (TROWS * ROW_B + 1023) / 1024;        // 1-KB DMA pieces per tile
-    static constexpr int BUF_B = PIECES * 1024;
-    static constexpr int NBUF_RAW = (160 * 1024 - 3 * 256 * 4) / BUF_B;
-    static constexpr int NBUF = NBUF_RAW > 8 ? 8 : NBUF_RAW;
-    static constexpr int PRE = NBUF - 2;                                // tiles requested ahead of the one being read
-    static constexpr size_t SMEM = (size_t)NBUF * BUF_B + 256 * 4;
-    static constexpr int AHEAD = AH, RING = AHEAD + 1;                  // B-fragment read-ahead (k-steps)
-    static constexpr int UNITS = 8;                                     // selection units per tile: 2 accumulators x 4 quads
-    static_assert(NBUF >= 4, "need at least two tiles in flight");
-};
-
-// Per-wave state of batch_gemm_w4_kernel shared by its (compile-time unrolled) helper functions. Everything is
-// loop-invariant; after inlining it lives in registers.
-template <int D, int AH>
-struct W4Ctx {
-    bf16x8 fa0[W4Geom<D, AH>::KS], fa1[W4Geom<D, AH>::KS];     // A fragments of the wave's two query sets
-    int64_t* cand;
-    uint32_t cand_cap, row_base, slab0, slab_end, seg_slots, seg_w0;
-    f32x16 nl0, nl1;             // accumulator start values: -(conservative similarity bound) of the register's query, per set
-    uint32_t debug;              // timing experiments (GemmArgs::debug)
-    int cnt_v;                   // lane l: survivors of the wave's query l so far (this workgroup's segment fill)
-    int lane;
-};
-
-// One quad of accumulators of a finished tile: a clear sign bit => some (query, row) reached its threshold.
-// Hot part: 3 integer ANDs, one compare, one branch. Cold part (one copy per unit; ~1 visit per wave and tile): with one
-// wave per SIMD nothing hides a memory round trip, so it makes none: admission is the sign test itself (the conservative
-// bound: a superset of "d <= tau"; every row it rejects has d > tau, which is what the certificate needs), the start
-// value comes from the registers, and the slot in the query's segment comes from a per-wave counter kept in a VGPR
-// (lane l = the wave's query l; only this wave ever appends to its 64 queries' segments of this workgroup), advanced
-// with readlane + lane-compare adds in a scalar loop over the hit lanes. The only memory operation is the 8-byte store.
-template <int D, int AH, int U>
-__device__ __forceinline__ void w4_select_unit(W4Ctx<D, AH>& c, const f32x16 (&P)[2], uint32_t tile) {
-    constexpr int set = U >> 2, qd = U & 3;
-    const float v0 = P[set][4 * qd], v1 = P[set][4 * qd + 1], v2 = P[set][4 * qd + 2], v3 = P[set][4 * qd + 3];
-    const int all_neg = __float_as_int(v0) & __float_as_int(v1) & __float_as_int(v2) & __float_as_int(v3);
-    if (__ballot(all_neg >= 0) == 0ull) return;           // every sign bit set: nothing reached its threshold
-    if (c.debug & 16u) return;                            // timing experiments: hot test only
-    const uint32_t row = c.slab0 + tile * (uint32_t)W4Geom<D, AH>::TROWS + (uint32_t)(c.lane & 31);
-    unsigned hits = (v0 >= 0.0f ? 1u : 0u) | (v1 >= 0.0f ? 2u : 0u) | (v2 >= 0.0f ? 4u : 0u) | (v3 >= 0.0f ? 8u : 0u);   // NaN fails
-    hits = row < c.slab_end ? hits : 0u;                  // rows past the slab (clamped / slack rows of the last tile)
-    const f32x16& nl = set ? c.nl1 : c.nl0;
-    const float n0 = nl[4 * qd], n1 = nl[4 * qd + 1], n2 = nl[4 * qd + 2], n3 = nl[4 * qd + 3];
-    // register 4 qd + j of set s belongs to the wave's query 32 s + j + 8 qd + 4 (lane >> 5)
-    const uint32_t qq0 = 32u * (uint32_t)set + 8u * (uint32_t)qd + 4u * ((uint32_t)c.lane >> 5);
-    for (;;) {
-        const bool has = hits != 0u;
-        unsigned long long todo = __ballot(has);
-        if (todo == 0ull) break;
-        const unsigned j = has ? (unsigned)__builtin_ctz(hits) : 0u;   // the lane's lowest pending register
-        hits &= hits - 1u;
-        const float v = j == 0u ? v0 : (j == 1u ? v1 : (j == 2u ? v2 : v3));
-        const float ng = j == 0u ? n0 : (j == 1u ? n1 : (j == 2u ? n2 : n3));
-        const int qq = (int)(qq0 + j);
-        const float d = (1.0f - (v - ng)) + 0.0f;           // v = sim - sim_lo, ng = -sim_lo
-        int slot = 0;
-        do {                                                // scalar loop over the hit lanes (usually one)
-            const int L = (int)__builtin_ctzll(todo);
-            todo &= todo - 1ull;
-            const int qL = __builtin_amdgcn_readlane(qq, L);
-            const int cL = __builtin_amdgcn_readlane(c.cnt_v, qL);
-            c.cnt_v += (c.lane == qL) ? 1 : 0;              // (no v_writelane builtin in this toolchain: compare + add)
-            slot = (c.lane == L) ? cL : slot;
-        } while (todo != 0ull);
-        if (has && (uint32_t)slot < c.seg_slots && !(c.debug & 32u))   // debug bit5: no survivor store
-            c.cand[c.seg_w0 + (uint32_t)qq * c.cand_cap + (uint32_t)slot] = make_key(d, c.row_base + row);
-    }
-}
-
-template <int D, int AH, int U0, int U1>
-__device__ __forceinline__ void w4_select_units(W4Ctx<D, AH>& c, const f32x16 (&P)[2], uint32_t tile) {
-    if constexpr (U0 < U1) {
-        w4_select_unit<D, AH, U0>(c, P, tile);
-        w4_select_units<D, AH, U0 + 1, U1>(c, P, tile);
-    }
-}
-
-// k-steps KSI .. KS-1 of one tile: read-ahead of B fragment KSI + AHEAD (inline asm), counted wait for fragment KSI,
-// two MFMAs, then the selection units of the previous tile that are scheduled after this k-step.
-// The B-fragment reads are inline asm with hand-counted waits: with branches inside the k-loop hipcc falls back to
-// `s_waitcnt lgkmcnt(0)` in front of every MFMA pair (one exposed LDS round trip per k-step). LDS operations return
-// in order, so "at most N younger operations outstanding" implies that read KSI has landed whatever else (the cold
-// path's reads, scalar loads) is in the queue: extra operations only make a counted wait stricter.
-template <int D, int AH, int KSI>
-__device__ __forceinline__ void w4_ksteps(W4Ctx<D, AH>& c, f32x16 (&cur)[2], const f32x16 (&prev)[2], uint32_t prev_tile,
-                                          uint32_t baddr, u32x4 (&fb)[W4Geom<D, AH>::RING]) {
-    using G = W4Geom<D, AH>;
-    if constexpr (KSI < G::KS) {
-        if constexpr (KSI + G::AHEAD < G::KS)
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[(KSI + G::AHEAD) % G::RING]) : "v"(baddr), "n"((KSI + G::AHEAD) * 32));
-        constexpr int younger = (G::KS - 1 - KSI) < G::AHEAD ? (G::KS - 1 - KSI) : G::AHEAD;
-        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(younger) : "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        const bf16x8 B = __builtin_bit_cast(bf16x8, fb[KSI % G::RING]);
-        if constexpr (KSI == 0) {   // C operand = the per-query start values: no accumulator initialisation pass
-            cur[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c.fa0[0], B, c.nl0, 0, 0, 0);
-            cur[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c.fa1[0], B, c.nl1, 0, 0, 0);
-        } else {
-            cur[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c.fa0[KSI], B, cur[0], 0, 0, 0);
-            cur[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c.fa1[KSI], B, cur[1], 0, 0, 0);
-        }
-        // selection units spread evenly over the k-steps: unit u runs after k-step floor(u * KS / UNITS)
-        constexpr int u0 = (KSI * G::UNITS + G::KS - 1) / G::KS;            // first u with floor(u KS / UNITS) >= KSI
-        constexpr int u1 = ((KSI + 1) * G::UNITS + G::KS - 1) / G::KS;      // first u with floor(u KS / UNITS) >= KSI + 1
-        if (!(c.debug & 8u)) w4_select_units<D, AH, u0, (u1 < G::UNITS ? u1 : G::UNITS)>(c, prev, prev_tile);   // debug bit3: no selection
-        __builtin_amdgcn_sched_barrier(0);
-        w4_ksteps<D, AH, KSI + 1>(c, cur, prev, prev_tile, baddr, fb);
-    }
-}
-
-template <int D, int AH, int I>
-__device__ __forceinline__ void w4_prefetch_b(uint32_t baddr, u32x4 (&fb)[W4Geom<D, AH>::RING]) {
-    using G = W4Geom<D, AH>;
-    if constexpr (I < G::AHEAD && I < G::KS) {
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[I]) : "v"(baddr), "n"(I * 32));
-        w4_prefetch_b<D, AH, I + 1>(baddr, fb);
-    }
-}
-
-// MFMAs of one tile into `cur`, with the selection of the PREVIOUS tile (`prev`) interleaved between the k-steps.
-template <int D, int AH>
-__device__ __forceinline__ void w4_tile_step(W4Ctx<D, AH>& c, f32x16 (&cur)[2], const f32x16 (&prev)[2], uint32_t prev_tile,
-                                             uint32_t baddr) {
-    u32x4 fb[W4Geom<D, AH>::RING];
-    w4_prefetch_b<D, AH, 0>(baddr, fb);
-    __builtin_amdgcn_sched_barrier(0);
-    w4_ksteps<D, AH, 0>(c, cur, prev, prev_tile, baddr, fb);
-}
-
-template <int D, int AH>
-__global__ __launch_bounds__(256, 1) void batch_gemm_w4_kernel(GemmArgs a, uint32_t blocks_per_group) {
-    using G = W4Geom<D, AH>;
-    constexpr int KS = G::KS;
-    constexpr int ROW_B = G::ROW_B, TROWS = G::TROWS, PIECES = G::PIECES, BUF_B = G::BUF_B, NBUF = G::NBUF, PRE = G::PRE;
-    constexpr int SPR = ROW_B / 16;                  // 16-byte slots per padded row
-    constexpr int PPW = (PIECES + 3) / 4;            // pieces per wave (waves with index >= PIECES % 4 carry one less, if PIECES % 4)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* neg_s = reinterpret_cast<float*>(smem + NBUF * BUF_B);          // [256] -(conservative similarity bound) (set-up only)
-
-    const int tid = (int)threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const uint32_t group = blockIdx.x / blocks_per_group;    // 256 queries per group
-    const uint32_t bidx = blockIdx.x % blocks_per_group;
-    const uint32_t q0 = group * 256 + wave * 64;              // this wave's 64 queries
-
-    W4Ctx<D, AH> c;
-    // A fragments: set s, lane l holds query 32 s + (l & 31), k = 16 ks + 8 (l >> 5) .. +7
-    {
-        const u32x4* qp0 = reinterpret_cast<const u32x4*>(a.qb + (size_t)(q0 + (lane & 31)) * D) + (lane >> 5);
-        const u32x4* qp1 = reinterpret_cast<const u32x4*>(a.qb + (size_t)(q0 + 32 + (lane & 31)) * D) + (lane >> 5);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            c.fa0[ks] = __builtin_bit_cast(bf16x8, qp0[ks * 2]);
-            c.fa1[ks] = __builtin_bit_cast(bf16x8, qp1[ks * 2]);
-        }
-    }
-    {
-        const float tq = a.tau[q0 + lane];
-        const bool usable = (tq == tq) && (tq < __builtin_inff());        // -inf (padding query) is usable: it admits nothing
-        c.cnt_v = usable ? 0 : 0x40000000;                                 // lane l counts the wave's query l
-        // fl(1 - sim) <= tq implies sim >= (1 - tq) - 2^-23 (|1 - tq| + |tq|); 4e-7 (1 + |tq|) covers it and the rounding of
-        // (acc + sim_lo) with slack. tq = -inf gives NaN: nothing is flagged.
-        const float sim_lo = (1.0f - tq) - 4e-7f * (1.0f + __builtin_fabsf(tq));
-        neg_s[wave * 64 + lane] = usable ? -sim_lo : __builtin_nanf("");
-    }
-    __syncthreads();     // the only compiler-visible LDS writes of the kernel: all before the first DMA request
-    c.cand = a.cand; c.cand_cap = a.cand_cap; c.row_base = a.row_base; c.slab0 = a.slab0;
-    c.slab_end = a.slab0 + a.slab_rows;
-    c.seg_slots = a.seg_area / blocks_per_group;
-    c.seg_w0 = q0 * a.cand_cap + a.seg_base + bidx * c.seg_slots;   // element offset of the wave's first query row, this workgroup's segment
-    c.lane = lane;
-    c.debug = a.debug;
-    // the lane's 32 accumulator start values: register r of set s belongs to query 32 s + (r&3) + 8 (r>>2) + 4 (lane>>5)
-    {
-        const float* nw = neg_s + wave * 64 + 4 * (lane >> 5);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            c.nl0[r] = nw[(r & 3) + 8 * (r >> 2)];
-            c.nl1[r] = nw[32 + (r & 3) + 8 * (r >> 2)];
-        }
-    }
-
-    const uint32_t ntiles = (a.slab_rows + TROWS - 1) / TROWS;
-    const unsigned char* cbase = reinterpret_cast<const unsigned char*>(a.cb) + (size_t)a.slab0 * (D * 2);
-
-    // LDS-DMA map: wave w moves pieces w, w + 4, ...; lane l of piece P fills slot 64 P + l of the padded image.
-    // Source offset of that slot inside the tile's contiguous rows (loop-invariant: one register per piece).
-    uint32_t poff[PPW];
-    int my_pieces = 0;
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-        const uint32_t P = (uint32_t)wave + 4u * i;
-        const uint32_t slot = P * 64u + (uint32_t)lane;
-        const uint32_t r = slot / SPR;
-        uint32_t cc = slot - r * SPR;
-        cc = cc < (uint32_t)(SPR - 1) ? cc : (uint32_t)(SPR - 2);         // pad slot: re-fetch the row's last segment
-        poff[i] = r * (uint32_t)(D * 2) + cc * 16u;                       // r may reach a few rows past the tile (last piece): slack rows
-        if (P < (uint32_t)PIECES) ++my_pieces;
-    }
-    const bool full_wave = my_pieces == PPW;                  // wave-uniform
-    auto dma_tile = [&](uint32_t tile, uint32_t buf_idx) {
-        const unsigned char* src0 = cbase + (size_t)tile * (TROWS * D * 2);
-#pragma unroll
-        for (int i = 0; i < PPW; ++i) {
-            const uint32_t P = (uint32_t)wave + 4u * i;
-            if (i < PPW - 1 || full_wave)
-                __builtin_amdgcn_global_load_lds((global_cvoid*)(src0 + poff[i]), (lds_void*)(smem + buf_idx * BUF_B + P * 1024u), 16, 0, 0);
-        }
-    };
-    // wait until this wave's DMA requests of all but the newest PRE - 1 tiles have landed (steady state), or all of them
-    auto dma_wait_keep = [&](bool steady) {
-        if (!steady) wait_vmcnt<0>();
-        else if (full_wave) wait_vmcnt<(PRE - 1) * PPW>();
-        else wait_vmcnt<(PRE - 1) * (PPW - 1)>();
-    };
-
-    const uint32_t lane_boff = (uint32_t)(lane & 31) * (uint32_t)ROW_B + (uint32_t)(lane >> 5) * 16u;
-    const uint32_t smem_lds = (uint32_t)(size_t)(lds_void*)smem;
-    // timing experiments (results are garbage): bit0 no DMA after the prologue, bit1 no MFMA tile work, bit2 no per-tile
-    // barrier, bit3 no selection
-    const bool dbg_nodma = (a.debug & 1u) != 0, dbg_nomfma = (a.debug & 2u) != 0, dbg_nobar = (a.debug & 4u) != 0;
-
-    f32x16 accA[2], accB[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { accA[i][r] = -1.0f; accB[i][r] = -1.0f; }   // "no hit": nothing to select before the first tile
-
-    // The A fragments are ordinary loads: make them land BEFORE the first DMA request (beside a DMA in flight hipcc waits
-    // vmcnt(0) for an ordinary load's first use, which would drain the prologue's prefetch). Loads return in order.
-    asm volatile("" ::"v"(c.fa0[KS - 1]), "v"(c.fa1[KS - 1]));
-    // prologue: request the first PRE tiles, wait for the first
-    uint32_t t = bidx;
-    {
-        uint32_t tt = t;
-        int issued = 0;
-#pragma unroll
-        for (int i = 0; i < PRE; ++i, tt += blocks_per_group)
-            if (tt < ntiles) { dma_tile(tt, (uint32_t)i); ++issued; }
-        dma_wait_keep(issued == PRE);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    }
-    uint32_t cur_idx = 0;                                      // ring position of tile t
-    while (t < ntiles) {
-#pragma unroll
-        for (int par = 0; par < 2; ++par) {
-            const uint32_t tp = t + (uint32_t)PRE * blocks_per_group;
-            uint32_t pre_idx = cur_idx + (uint32_t)PRE;
-            pre_idx = pre_idx >= (uint32_t)NBUF ? pre_idx - (uint32_t)NBUF : pre_idx;
-            const bool issued = tp < ntiles && !dbg_nodma;
-            if (issued) dma_tile(tp, pre_idx);
-            const uint32_t baddr = smem_lds + cur_idx * (uint32_t)BUF_B + lane_boff;
-            if (!dbg_nomfma) {
-                if (par == 0) w4_tile_step<D, AH>(c, accA, accB, t - blocks_per_group, baddr);   // first iteration: accB is all -1, its tile index is never used
-                else w4_tile_step<D, AH>(c, accB, accA, t - blocks_per_group, baddr);
-            }
-            // tile t + 1 must have landed (every wave waits for its own pieces, the barrier joins them); the younger
-            // requests stay in flight across the barrier
-            dma_wait_keep(issued);
-            if (!dbg_nobar) __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            cur_idx = cur_idx + 1 == (uint32_t)NBUF ? 0u : cur_idx + 1;
-            const uint32_t tn = t + blocks_per_group;
-            if (tn >= ntiles) {
-                if (par == 0) w4_select_units<D, AH, 0, G::UNITS>(c, accA, t);
-                else w4_select_units<D, AH, 0, G::UNITS>(c, accB, t);
-                t = tn;
-                break;
-            }
-            t = tn;
-        }
-    }
-    // unclamped counts: a count above seg_slots tells the consumer that survivors were dropped (query -> exact path)
-    a.seg_count[(size_t)bidx * (a.nqt * 128u) + q0 + (uint32_t)lane] = (uint32_t)c.cnt_v;
-}
-
-static void rega_geometry(const GemmArgs& a, uint32_t* groups, uint32_t* per_group);
-static bool w4_dims(uint32_t dims) { return dims == 128 || dims == 256 || dims == 384 || dims == 512; }
-uint32_t batch_w4_slack_rows() { return 64; }   // rows the w4 kernel's last DMA piece may read past the end of the store
-
-template <int D, int AH>
-static hipError_t launch_w4_ah(const GemmArgs& a, hipStream_t st) {
-    constexpr size_t smem = W4Geom<D, AH>::SMEM;
-    static std::atomic<uint64_t> configured{0};   // per device (ensure_dynamic_lds)
-    {
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&batch_gemm_w4_kernel<D, AH>), smem, configured);
-        if (e != hipSuccess) return e;
-    }
-    uint32_t groups, pg;
-    rega_geometry(a, &groups, &pg);          // the same workgroups-per-group (= survivor segments) as batch_gemm_rega_kernel
-    hipLaunchKernelGGL((batch_gemm_w4_kernel<D, AH>), dim3(groups * pg), dim3(256), smem, st, a, pg);
-    return hipGetLastError();
-}
-
+// Per-dimension geometry of the rq kernel: rows per tile (what the one-pass planner calls a tile), LDS tile buffers, read-ahead.
+// D * TROWS is 16 - 32 K elements (32 - 64 MFMAs per wave and tile); three buffers where they fit beside the neighbouring batch's
+// small kernels (a workgroup of ~100 KB leaves them a third of the CU's LDS; 150 KB does not: measured in round 3 and again in
+// round 5 at D = 384, where two buffers lose nothing), except at D = 768 where a 32-row tile is already 48.5 KB and the third
+// buffer is what lets a request stay in flight across a tile.
+template <int D> struct RqGeom;
+template <> struct RqGeom<128> { static constexpr int TROWS = 128, NBUF = 3, AHEAD = 3; };
+template <> struct RqGeom<256> { static constexpr int TROWS = 64, NBUF = 3, AHEAD = 3; };
+template <> struct RqGeom<384> { static constexpr int TROWS = 64, NBUF = 2, AHEAD = 3; };
+template <> struct RqGeom<512> { static constexpr int TROWS = 64, NBUF = 2, AHEAD = 3; };
+template <> struct RqGeom<768> { static constexpr int TROWS = 32, NBUF = 3, AHEAD = 3; };
+static bool rq_dims(uint32_t dims) { return dims == 128 || dims == 256 || dims == 384 || dims == 512 || dims == 768; }
+static uint32_t rq_tile_rows(uint32_t dims) { return dims == 128 ? 128u : dims == 768 ? 32u : 64u; }
 template <int D>
-static hipError_t launch_w4(const GemmArgs& a, hipStream_t st) {
-    // read-ahead 3 and 6 k-steps measure the same (profiles/r02/i_w4_ahead.txt): the kernel is issue-bound, not LDS-latency-bound
-    return launch_w4_ah<D, 3>(a, st);
+constexpr size_t rq_smem() {
+    return (size_t)RqGeom<D>::NBUF * (((RqGeom<D>::TROWS * (D * 2 + 16)) + 1023) / 1024 * 1024) + 2 * 8 * 32 * 4 + 64;   // tile buffers, counters, bounds, split-barrier words
 }
 
-// D = 1024 would need 2 x 66 KB of tiles + 32 KB of partial sums (> 160 KB of LDS): it stays on the LDS-tiled kernel.
-static bool ksplit_dims(uint32_t dims) { return dims == 768; }
-// D = 768 has two register-resident kernels. "batch_rega" 1 / 6 / 7 select the K-split kernel (1 = workgroup barrier, 6 = split
-// barrier at every size, 7 = its own size rule); every other value the wide kernel (whole K per wave, LDS-DMA staging).
-static bool ksplit_mode(uint32_t use_rega) { return use_rega == 1u || use_rega == 6u || use_rega == 7u; }
-// Queries per workgroup group of the register-resident filtering GEMM (the planner sizes survivor segments by it).
-uint32_t batch_group_queries(uint32_t dims, uint32_t use_rega) { return (ksplit_dims(dims) && ksplit_mode(use_rega)) ? 128u : 256u; }
-
-static void rega_geometry(const GemmArgs& a, uint32_t* groups, uint32_t* per_group) {
-    const bool ksplit = batch_group_queries(a.dims, a.use_rega) == 128u;   // K-split: 128 queries per workgroup
-    *groups = ksplit ? a.nqt : (a.nqt * 128 + 255) / 256;
-    const uint32_t ntiles = ksplit_dims(a.dims) ? (a.slab_rows + 31) / 32 : (a.slab_rows + 63) / 64;   // 768: 32-row tiles (both kernels)
+static void rq_geometry(const GemmArgs& a, uint32_t* groups, uint32_t* per_group) {
+    *groups = (a.nqt * 128 + 255) / 256;        // 256 queries per group of workgroups
+    const uint32_t tr = rq_tile_rows(a.dims);
+    const uint32_t ntiles = (a.slab_rows + tr - 1) / tr;
     uint32_t pg = 256 / *groups;                // one persistent workgroup per CU in total
     if (pg < 1) pg = 1;
     if (pg > ntiles) pg = ntiles;
     *per_group = pg;
 }
 
-static bool rega_eligible(const GemmArgs& a, int metric) {
-    return a.dense == nullptr && a.use_rega && metric != BM_L2 &&
-           (a.dims == 128 || a.dims == 256 || a.dims == 384 || a.dims == 512 || ksplit_dims(a.dims));
+static bool rq_eligible(const GemmArgs& a, int metric) {
+    return a.dense == nullptr && a.use_rega && metric != BM_L2 && rq_dims(a.dims);
 }
 
 bool batch_gemm_segments(const GemmArgs& a, int metric, uint32_t* nseg, uint32_t* seg_slots) {
-    if (!rega_eligible(a, metric)) return false;
+    if (!rq_eligible(a, metric)) return false;
     uint32_t groups, per_group;
-    rega_geometry(a, &groups, &per_group);
+    rq_geometry(a, &groups, &per_group);
     *nseg = per_group;
     *seg_slots = a.seg_area / per_group;
     return true;
 }
 
-template <int D, int AHEAD, bool SPLIT = true>
-static hipError_t launch_ksplit(const GemmArgs& a, hipStream_t st) {
-    constexpr size_t smem = 2 * 32 * (D * 2 + 16) + 2 * 4 * (4 * 64 * 16) + 3 * 4 * 32 * 4 + 16 + 32;  // tiles, partial sums, thresholds / counters / bounds, split-barrier counters
-    static std::atomic<uint64_t> configured{0};   // per device (ensure_dynamic_lds)
-    {
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&batch_gemm_ksplit_kernel<D, AHEAD, false, SPLIT>), smem, configured);
-        if (e != hipSuccess) return e;
-    }
-    uint32_t groups, per_group;
-    rega_geometry(a, &groups, &per_group);
-    hipLaunchKernelGGL((batch_gemm_ksplit_kernel<D, AHEAD, false, SPLIT>), dim3(groups * per_group), dim3(512), smem, st, a, per_group);
-    return hipGetLastError();
-}
-
-template <int D, int NBUF, int AHEAD, int CHAINS = 1, bool SPLIT = false>
-static hipError_t launch_wide(const GemmArgs& a, hipStream_t st) {
-    constexpr size_t smem = (size_t)NBUF * (((32 * (D * 2 + 16)) + 1023) / 1024 * 1024) + 3 * 8 * 32 * 4 + 64;   // tile buffers, thresholds / counters / bounds
+template <int D, bool SAMPLE, bool SPLIT>
+static hipError_t launch_rq(const GemmArgs& a, uint32_t groups, uint32_t per_group, hipStream_t st) {
+    using G = RqGeom<D>;
+    constexpr size_t smem = rq_smem<D>();
     static_assert(smem <= 160 * 1024, "LDS budget of one CU");
     static std::atomic<uint64_t> configured{0};   // per device (ensure_dynamic_lds)
     {
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&batch_gemm_wide_kernel<D, NBUF, AHEAD, false, CHAINS, SPLIT>), smem, configured);
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&batch_gemm_rq_kernel<D, G::TROWS, G::NBUF, G::AHEAD, SAMPLE, SPLIT>), smem, configured);
         if (e != hipSuccess) return e;
     }
-    uint32_t groups, per_group;
-    rega_geometry(a, &groups, &per_group);
-    hipLaunchKernelGGL((batch_gemm_wide_kernel<D, NBUF, AHEAD, false, CHAINS, SPLIT>), dim3(groups * per_group), dim3(512), smem, st, a, per_group);
+    hipLaunchKernelGGL((batch_gemm_rq_kernel<D, G::TROWS, G::NBUF, G::AHEAD, SAMPLE, SPLIT>), dim3(groups * per_group), dim3(512), smem, st, a, per_group);
     return hipGetLastError();
 }
-
-template <int D, int TROWS, int NBUF, int AHEAD, int MODE>
-static hipError_t launch_pp(const GemmArgs& a, hipStream_t st) {
-    constexpr size_t smem = (size_t)NBUF * (((TROWS * (D * 2 + 16)) + 1023) / 1024 * 1024) + 2 * 8 * 32 * 4 + 64;   // tile buffers, counters, bounds
-    static_assert(smem <= 160 * 1024, "LDS budget of one CU");
-    static std::atomic<uint64_t> configured{0};   // per device (ensure_dynamic_lds)
-    {
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&batch_gemm_pp_kernel<D, TROWS, NBUF, AHEAD, false, MODE>), smem, configured);
-        if (e != hipSuccess) return e;
-    }
-    uint32_t groups, per_group;
-    rega_geometry(a, &groups, &per_group);
-    hipLaunchKernelGGL((batch_gemm_pp_kernel<D, TROWS, NBUF, AHEAD, false, MODE>), dim3(groups * per_group), dim3(512), smem, st, a, per_group);
-    return hipGetLastError();
-}
-
-template <int D, bool GLDS, int AHEAD, bool PROF = false, int SYNC = 0>
-static hipError_t launch_rega_impl(const GemmArgs& a, hipStream_t st) {
-    constexpr bool FREE = SYNC == 1;
-    // tiles, thresholds, survivor counters, bounds, claimed tile indices (+ the two counter triples of the free-running variant)
-    constexpr size_t smem = (size_t)(FREE ? 3 : rega_lds_tiles<D>(GLDS)) * 64 * (D * 2 + 16) + 3 * 8 * 32 * 4 + 16 + (SYNC != 0 ? 48 : 0);   // FREE / SPLIT: stored[3], read[3], turn[4] behind the claimed tile indices
-    static_assert(smem <= 160 * 1024, "LDS budget of one CU");
-    static std::atomic<uint64_t> configured{0};   // per device (ensure_dynamic_lds)
-    {
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&batch_gemm_rega_kernel<D, GLDS, AHEAD, false, PROF, SYNC>), smem, configured);
-        if (e != hipSuccess) return e;
-    }
-    uint32_t groups, per_group;
-    rega_geometry(a, &groups, &per_group);
-    hipLaunchKernelGGL((batch_gemm_rega_kernel<D, GLDS, AHEAD, false, PROF, SYNC>), dim3(groups * per_group), dim3(512), smem, st, a, per_group);
-    return hipGetLastError();
-}
-
-// whether the free-running variant (three LDS tiles, no tile barrier) exists for D
-constexpr bool rega_free_dims(int d) { return 3 * 64 * (d * 2 + 16) + 3 * 8 * 32 * 4 + 64 <= 160 * 1024; }
 
 template <int D>
-static hipError_t launch_rega(const GemmArgs& a, hipStream_t st) {
-    // B-fragment read-ahead: as deep as the 256-VGPR budget allows next to the D/4 VGPRs of A fragments
-    constexpr int AHEAD = D >= 512 ? 1 : 3;
-    if (a.use_rega == 2u) {
-        if constexpr (D < 512) {
-            switch ((a.debug >> 8) & 3u) {   // timing experiments: read-ahead depth
-                case 1: return launch_rega_impl<D, true, 2>(a, st);
-                case 2: return launch_rega_impl<D, true, 4>(a, st);
-                default: break;
-            }
-        }
-        return launch_rega_impl<D, true, AHEAD>(a, st);
-    }
-    if constexpr (rega_free_dims(D)) {
-        if (a.use_rega == 4u) {
-            if constexpr (D == 384) {
-                if (a.debug & 1024u) return launch_rega_impl<D, false, AHEAD, true, 1>(a, st);   // phase clock, see below
-            }
-            return launch_rega_impl<D, false, AHEAD, false, 1>(a, st);
-        }
-    }
-    if (a.use_rega == 5u || a.use_rega == 6u) {   // 6: like 5, and the K-split kernel keeps the split barrier at every size
-        if constexpr (D == 384) {
-            if (a.debug & 1024u) return launch_rega_impl<D, false, AHEAD, true, 2>(a, st);
-        }
-        return launch_rega_impl<D, false, AHEAD, false, 2>(a, st);
-    }
-    if constexpr (D == 384) {
-        // diagnosis run: per-wave phase clock (see the kernel's main loop)
-        if (a.debug & 1024u) return launch_rega_impl<D, false, AHEAD, true>(a, st);
-        // timing experiment (debug bits 8-9 = 1): read-ahead 2 = 224 VGPRs, which leaves room for a 64-VGPR kernel of the
-        // neighbouring batch (the finish kernel) beside the two GEMM waves of a SIMD; read-ahead 3 = 232 does not
-        if (((a.debug >> 8) & 3u) == 1u) return launch_rega_impl<D, false, 2>(a, st);
-    }
-    return launch_rega_impl<D, false, AHEAD>(a, st);
+static hipError_t launch_rq_filter(const GemmArgs& a, hipStream_t st) {
+    uint32_t groups, per_group;
+    rq_geometry(a, &groups, &per_group);
+    // "batch_rega" 1: a workgroup barrier per tile instead of the split one (A/B, and the variant the fail-safe test compares with)
+    if (a.use_rega == 1u) return launch_rq<D, false, false>(a, groups, per_group, st);
+    return launch_rq<D, false, true>(a, groups, per_group, st);
 }
 
 hipError_t launch_batch_gemm(const GemmArgs& a, int metric, hipStream_t st) {
     // fast path: queries resident in registers (needs the query block padded to a multiple of 256 rows)
-    if (rega_eligible(a, metric)) {
-        if (a.use_rega == 3u && w4_dims(a.dims)) {   // one wave per SIMD, 64 queries per wave (same segments / geometry)
-            switch (a.dims) {
-                case 128: return launch_w4<128>(a, st);
-                case 256: return launch_w4<256>(a, st);
-                case 512: return launch_w4<512>(a, st);
-                default: return launch_w4<384>(a, st);
-            }
-        }
-        if (a.use_rega >= 8u && a.use_rega <= 12u) {   // round 5: 8 = ping-pong, late-half DMA, prefetched heads; 9 = asm-read fix alone; 10 = plain ping-pong
-            const uint32_t v = (a.debug >> 8) & 3u;   // timing experiments: read-ahead depth
-            if (a.dims == 768) {
-                if (a.use_rega == 8u) return v == 1u ? launch_pp<768, 32, 3, 4, 3>(a, st) : v == 2u ? launch_pp<768, 32, 3, 2, 3>(a, st) : launch_pp<768, 32, 3, 3, 3>(a, st);
-                if (a.use_rega == 10u) return launch_pp<768, 32, 3, 3, 1>(a, st);
-                if (a.use_rega == 11u) return launch_pp<768, 32, 3, 3, 4>(a, st);
-                if (a.use_rega == 12u) return launch_pp<768, 32, 3, 3, 5>(a, st);
-                return v == 2u ? launch_pp<768, 32, 3, 2, 0>(a, st) : launch_pp<768, 32, 3, 3, 0>(a, st);
-            }
-            if (a.dims == 384) {
-                if (a.use_rega == 8u) return v == 1u ? launch_pp<384, 64, 3, 6, 2>(a, st) : v == 2u ? launch_pp<384, 64, 3, 3, 3>(a, st) : launch_pp<384, 64, 3, 3, 2>(a, st);
-                if (a.use_rega == 10u) return launch_pp<384, 64, 3, 3, 1>(a, st);
-                if (a.use_rega == 11u) return launch_pp<384, 64, 3, 3, 4>(a, st);
-                if (a.use_rega == 12u) return v == 1u ? launch_pp<384, 64, 3, 6, 5>(a, st) : launch_pp<384, 64, 3, 3, 5>(a, st);
-                return launch_pp<384, 64, 3, 3, 0>(a, st);
-            }
-        }
+    if (rq_eligible(a, metric)) {
         switch (a.dims) {
-            case 128: return launch_rega<128>(a, st);
-            case 256: return launch_rega<256>(a, st);
-            case 384: return launch_rega<384>(a, st);
-            case 512: return launch_rega<512>(a, st);
-            case 768:
-                if (!ksplit_mode(a.use_rega)) {
-                    switch ((a.debug >> 8) & 3u) {   // timing experiments: LDS tile buffers / accumulator chains / read-ahead
-                        case 1: return launch_wide<768, 2, 3>(a, st);             // two LDS tile buffers
-                        case 2: return launch_wide<768, 3, 3, 1, true>(a, st);    // split tile barrier
-                        case 3: return launch_wide<768, 3, 2>(a, st);             // read-ahead 2
-                        default: return launch_wide<768, 3, 3>(a, st);            // three buffers, read-ahead 3, workgroup barrier
-                    }
-                }
-                switch ((a.debug >> 8) & 3u) {   // timing experiments: B-fragment read-ahead depth
-                    case 1: return launch_ksplit<768, 6>(a, st);
-                    case 2: return launch_ksplit<768, 8>(a, st);
-                    default: {
-                        // The split barrier wins on short launches (1.25M rows: +1.2 % alone, +2.5 % pipelined) and LOSES 4 % on
-                        // the 16 ms launch over 10M rows (profiles/r03/zi_ksplit_split_barrier_by_size.txt) — long enough for the
-                        // power limit to set the clock, where the busier pipe buys nothing and the polling costs: workgroup barrier
-                        // from 4 096 tiles per workgroup up. ("batch_rega" = 1 forces the workgroup barrier, 6 the split one.)
-                        uint32_t groups = 1, per_group = 1;
-                        rega_geometry(a, &groups, &per_group);
-                        const uint32_t tiles_per_wg = ((a.slab_rows + 31u) / 32u + per_group - 1u) / per_group;
-                        if (a.use_rega == 1u || (a.use_rega != 6u && tiles_per_wg > 4096u)) return launch_ksplit<768, 4, false>(a, st);
-                        return launch_ksplit<768, 4>(a, st);
-                    }
-                }
+            case 128: return launch_rq_filter<128>(a, st);
+            case 256: return launch_rq_filter<256>(a, st);
+            case 384: return launch_rq_filter<384>(a, st);
+            case 512: return launch_rq_filter<512>(a, st);
+            case 768: return launch_rq_filter<768>(a, st);
             default: break;
         }
     }
@@ -2857,7 +1236,7 @@ hipError_t launch_finalize_batch(const int64_t* cand, uint32_t cand_cap, const u
 //                          across its whole range): per (tile, query) the best similarity of the tile
 //   pick_tau_kernel        tau_q = 1 - (rank-th best tile maximum): at least `rank` sampled rows pass it, and about
 //                          rank * tiles / sampled_tiles rows of the whole store (~8 k', see batch_onepass_plan)
-//   filtering GEMM         batch_gemm_rega_kernel / batch_gemm_ksplit_kernel over ALL tiles with that fixed tau;
+//   filtering GEMM         batch_gemm_rq_kernel (or the LDS-tiled batch_gemm_kernel) over ALL tiles with that fixed tau;
 //                          survivors into per-workgroup segments
 //   batch_finish_kernel    per query: survivors -> best k' (approximate keys) -> exact f32 re-score (scan_kernel's
 //                          arithmetic) -> top-k + certificate, one launch
@@ -2865,10 +1244,8 @@ hipError_t launch_finalize_batch(const int64_t* cand, uint32_t cand_cap, const u
 // row below tau when fewer than k' pass), every non-candidate's approximate distance is >= a_max, and the certificate
 // a_max - eps > exact k-th decides whether the answer is provably exact; anything else is re-run on the exact path.
 
-// The register-resident filtering GEMMs (survivors into per-workgroup segments): cosine / dot at these dimensions.
-bool batch_onepass_fast(uint32_t dims, int metric) {
-    return metric != BM_L2 && (dims == 128 || dims == 256 || dims == 384 || dims == 512 || dims == 768);
-}
+// The register-resident filtering GEMM (survivors into per-workgroup segments): cosine / dot at these dimensions.
+bool batch_onepass_fast(uint32_t dims, int metric) { return metric != BM_L2 && rq_dims(dims); }
 // Everything else the MFMA path serves (L2; any other multiple of 64, e.g. 1024 / 1536) runs the same one-pass pipeline on
 // the LDS-tiled 128 x 128 kernel: survivors are appended to one counted list per query.
 bool batch_onepass_dims(uint32_t dims, int metric) {
@@ -2876,7 +1253,7 @@ bool batch_onepass_dims(uint32_t dims, int metric) {
 }
 uint32_t batch_tile_rows(uint32_t dims, int metric) {
     if (!batch_onepass_fast(dims, metric)) return (uint32_t)GN;
-    return dims == 768 ? 32u : 64u;
+    return rq_tile_rows(dims);
 }
 
 __global__ __launch_bounds__(256) void batch_prep_kernel(PrepArgs a) {
@@ -2886,7 +1263,7 @@ __global__ __launch_bounds__(256) void batch_prep_kernel(PrepArgs a) {
     const int wave = (int)(threadIdx.x >> 6);
     const uint32_t q = blockIdx.x * 4 + (uint32_t)wave;
     if (q >= a.nq_pad) return;
-    if (q == 0 && a.tile_ctr) for (uint32_t i = lane; i < BATCH_TILE_CTRS * 32u; i += WAVE) a.tile_ctr[i] = 0u;   // one counter per 128-byte line
+    if (q == 0 && a.progress) for (uint32_t i = lane; i < BATCH_PROGRESS_WORDS; i += WAVE) a.progress[i] = 0u;   // the pace gate's words (one 128-byte line per XCD)
     const uint32_t D = a.dims;
     unsigned short* out = a.qb + (size_t)q * D;
     if (q >= a.nq) {                                     // padding query: admits nothing, matches nothing
@@ -2992,20 +1369,12 @@ hipError_t launch_batch_prep(const PrepArgs& a, hipStream_t st) {
 }
 
 template <int D>
-static hipError_t launch_rega_sample(const GemmArgs& a, hipStream_t st) {
-    constexpr int AHEAD = D >= 512 ? 1 : 3;
-    constexpr size_t smem = (size_t)rega_lds_tiles<D>(false) * 64 * (D * 2 + 16) + 3 * 8 * 32 * 4 + 16;
-    static std::atomic<uint64_t> configured{0};   // per device (ensure_dynamic_lds)
-    {
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&batch_gemm_rega_kernel<D, false, AHEAD, true>), smem, configured);
-        if (e != hipSuccess) return e;
-    }
+static hipError_t launch_rq_sample(const GemmArgs& a, hipStream_t st) {
     const uint32_t groups = (a.nqt * 128 + 255) / 256;
     uint32_t pg = 256 / groups;
     if (pg < 1) pg = 1;
     if (pg > a.sample_tiles) pg = a.sample_tiles;
-    hipLaunchKernelGGL((batch_gemm_rega_kernel<D, false, AHEAD, true>), dim3(groups * pg), dim3(512), smem, st, a, pg);
-    return hipGetLastError();
+    return launch_rq<D, true, false>(a, groups, pg, st);
 }
 
 hipError_t launch_batch_gemm_sample(const GemmArgs& a, int metric, hipStream_t st) {
@@ -3020,25 +1389,11 @@ hipError_t launch_batch_gemm_sample(const GemmArgs& a, int metric, hipStream_t s
         return hipGetLastError();
     }
     switch (a.dims) {
-        case 128: return launch_rega_sample<128>(a, st);
-        case 256: return launch_rega_sample<256>(a, st);
-        case 384: return launch_rega_sample<384>(a, st);
-        case 512: return launch_rega_sample<512>(a, st);
-        case 768: {
-            constexpr int D = 768;
-            constexpr size_t smem = 2 * 32 * (D * 2 + 16) + 2 * 4 * (4 * 64 * 16) + 3 * 4 * 32 * 4 + 16;
-            static std::atomic<uint64_t> configured{0};   // per device (ensure_dynamic_lds)
-            {
-                hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&batch_gemm_ksplit_kernel<D, 4, true>), smem, configured);
-                if (e != hipSuccess) return e;
-            }
-            const uint32_t groups = a.nqt;
-            uint32_t pg = 256 / groups;
-            if (pg < 1) pg = 1;
-            if (pg > a.sample_tiles) pg = a.sample_tiles;
-            hipLaunchKernelGGL((batch_gemm_ksplit_kernel<D, 4, true>), dim3(groups * pg), dim3(512), smem, st, a, pg);
-            return hipGetLastError();
-        }
+        case 128: return launch_rq_sample<128>(a, st);
+        case 256: return launch_rq_sample<256>(a, st);
+        case 384: return launch_rq_sample<384>(a, st);
+        case 512: return launch_rq_sample<512>(a, st);
+        case 768: return launch_rq_sample<768>(a, st);
         default: break;
     }
     return hipErrorInvalidValue;

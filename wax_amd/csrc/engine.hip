@@ -197,6 +197,7 @@ struct Slot {
     hipStream_t stream = nullptr;  // one of the engine's streams (not owned)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr;
     uint64_t* h_done = nullptr;    // pinned: the completion word a fused scan publishes behind its hits ("done_flag")
+    bool coherent = false;         // h_hits / h_done are coherent host memory (a condition of the completion-word path)
     uint64_t done_seq = 0;         // value the slot's current query publishes
     bool flag_wait = false;        // this ticket completes through h_done (no event was recorded)
     hipEvent_t t_start = nullptr, t_end = nullptr;   // the events that bracket this ticket's scan kernel (not owned)
@@ -414,8 +415,8 @@ struct wax_hip_engine {
     std::atomic<int64_t> batch_slab_mb{64};  // cap on slab size, in units of 16 384 rows
     std::atomic<int64_t> batch_growth{8};    // next slab = growth x rows seen so far
     std::atomic<int64_t> batch_first{2048};  // rows of the dense first slab (<= kBatchFirstSlab)
-    std::atomic<int64_t> batch_debug{0};     // timing experiments only (GemmArgs::debug)
-    std::atomic<int64_t> batch_rega{5};      // register-resident-queries GEMM where it applies: 5 (default) register staging + split tile barrier, 1 register staging + workgroup barrier, 2 LDS-DMA staging, 3 one wave per SIMD, 4 free-running (three LDS tiles); 0 off
+    std::atomic<int64_t> batch_debug{0};     // test / diagnosis bits, none of which can change an answer: 4096 = no pace gate, 16384 = one wave of workgroup 1 pretends its split-barrier wait timed out, 65536 = the device-side retry re-scores every survivor
+    std::atomic<int64_t> batch_rega{5};      // register-resident-queries GEMM where it applies: 5 (default) split tile barrier, 1 workgroup barrier per tile; 0 = the LDS-tiled kernel instead
     std::atomic<uint64_t> st_batch_queries{0}, st_batch_fallbacks{0};
     BatchMirror batch;
     std::mutex bctx_mu;
@@ -430,7 +431,6 @@ struct wax_hip_engine {
     std::atomic<int64_t> batch_multi{1};          // exact path of a batch: 1 = uncertified queries share passes over the f32 store (multiscan.hip), 0 = one scan each
     std::atomic<uint64_t> st_multi_passes{0}, st_multi_queries{0};
     std::atomic<uint64_t> st_batch_retries{0};
-    std::atomic<int64_t> batch_dynamic{0};        // one-pass pipeline: filtering-GEMM workgroups claim their tiles from a counter
     std::atomic<int64_t> batch_sample_div{32};    // one-pass pipeline: 1 / this of the tiles are sampled (at least 256)
     std::atomic<uint64_t> st_onepass_queries{0};
     std::atomic<int64_t> batch_eps_measured{1};       // cosine certificate bound from the MEASURED bf16 rounding errors (per query, max over rows) instead of the worst case
@@ -477,6 +477,16 @@ struct wax_hip_engine {
 };
 
 namespace {
+
+inline void cpu_relax() {   // a spin-wait hint, per architecture
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#else
+    std::this_thread::yield();
+#endif
+}
 
 constexpr uint64_t kBounceBytes = 64ull << 20;
 
@@ -580,8 +590,21 @@ int alloc_slot(wax_hip_engine* e, Slot** out) {
     // null stream does not order against: wait once, here, so the first fused scan can only ever see an armed (zero) ticket
     if ((err = hipStreamSynchronize(nullptr)) != hipSuccess) return bail(WAX_HIP_ERR_ALLOC, "top-k stage buffer", err);
     if ((err = hipMalloc(&s->d_hits, (size_t)WAX_HIP_MAX_RESULTS * sizeof(wax_hip_hit))) != hipSuccess) return bail(WAX_HIP_ERR_ALLOC, "top-k results buffer", err);
-    if ((err = hipHostMalloc(&s->h_hits, (size_t)WAX_HIP_MAX_RESULTS * sizeof(wax_hip_hit), hipHostMallocDefault)) != hipSuccess) return bail(WAX_HIP_ERR_ALLOC, "pinned results buffer", err);
-    if ((err = hipHostMalloc(&s->h_done, 64, hipHostMallocDefault)) != hipSuccess) return bail(WAX_HIP_ERR_ALLOC, "pinned completion word", err);
+    // The completion-word protocol ("done_flag") needs the kernel's writes — hits, then the word — visible to the host IN ORDER while
+    // the kernel is still running: coherent (fine-grained) host memory, asked for explicitly (the default is coherent on this stack
+    // today, but HIP_HOST_COHERENT=0 or another platform changes that silently). Where a coherent allocation is refused the slot falls
+    // back to default pinned memory and never takes the completion-word path (collect waits on the event behind the kernel).
+    s->coherent = true;
+    if ((err = hipHostMalloc(&s->h_hits, (size_t)WAX_HIP_MAX_RESULTS * sizeof(wax_hip_hit), hipHostMallocCoherent)) != hipSuccess) {
+        (void)hipGetLastError();
+        s->coherent = false;
+        if ((err = hipHostMalloc(&s->h_hits, (size_t)WAX_HIP_MAX_RESULTS * sizeof(wax_hip_hit), hipHostMallocDefault)) != hipSuccess) return bail(WAX_HIP_ERR_ALLOC, "pinned results buffer", err);
+    }
+    if ((err = hipHostMalloc(&s->h_done, 64, s->coherent ? hipHostMallocCoherent : hipHostMallocDefault)) != hipSuccess) {
+        (void)hipGetLastError();
+        s->coherent = false;
+        if ((err = hipHostMalloc(&s->h_done, 64, hipHostMallocDefault)) != hipSuccess) return bail(WAX_HIP_ERR_ALLOC, "pinned completion word", err);
+    }
     *s->h_done = 0;
     *out = s;
     return WAX_HIP_OK;
@@ -958,7 +981,7 @@ int alloc_bctx(wax_hip_engine* e, BatchCtx** out) {
     A(&c->d_eps, kBatchMaxQ * sizeof(float));
     A(&c->d_tau, kBatchMaxQ * sizeof(float));
     A(&c->d_cand_count, (size_t)kBatchMaxQ * CAND_COUNT_STRIDE * sizeof(uint32_t));
-    A(&c->d_overflow, (kBatchMaxQ + BATCH_TILE_CTRS * 32) * sizeof(uint32_t));   // + the filtering GEMM's tile counters
+    A(&c->d_overflow, (kBatchMaxQ + BATCH_PROGRESS_WORDS) * sizeof(uint32_t));   // + the filtering GEMM's pace-gate words
     A(&c->d_seg_count, (size_t)kBatchMaxSegs * kBatchMaxQ * sizeof(uint32_t));
     A(&c->d_qlist, (size_t)kBatchMaxQ * sizeof(uint32_t));
     A(&c->d_fnorm, (size_t)kBatchMaxQ * sizeof(float));
@@ -1194,8 +1217,7 @@ bool plan_onepass(wax_hip_engine* e, uint32_t n, int k_eff, uint32_t nq, Onepass
         p->kp = FUSED_MAX_K;
     const uint32_t nq_blk = nq < kBatchMaxQ ? nq : kBatchMaxQ;
     const uint32_t nq_pad = (nq_blk + 255u) & ~255u;
-    const uint32_t rega_mode = e->batch_rega.load() == 0 ? 5u : (uint32_t)e->batch_rega.load();   // as batch_enqueue passes it
-    const uint32_t groups = nq_pad / batch_group_queries(e->dims, rega_mode);
+    const uint32_t groups = nq_pad / BATCH_GROUP_QUERIES;
     uint32_t nseg = fast ? 256 / (groups ? groups : 1) : 1u;   // workgroups per query group == survivor segments per query (1 = counted list)
     if (nseg < 1) nseg = 1;
     if (nseg > p->ntiles) nseg = p->ntiles;
@@ -1286,17 +1308,15 @@ int batch_enqueue(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32
     const bool counted = plan != nullptr && !batch_onepass_fast(D, e->metric);   // one-pass on the LDS-tiled kernel: one counted list per query
     pa.cand_count = (plan && !counted) ? nullptr : c->d_cand_count;
     pa.q_norm_host = c->h_qnorm + cert_off;
-    const bool dynamic_tiles = plan != nullptr && e->batch_dynamic.load() != 0;
-    // the words behind the overflow flags: tile counters of the dynamic tile order, or the progress words of the wide 768-d kernel's
-    // pace gate (never both: the wide kernel walks its tiles statically) — zeroed by the prep kernel
-    const bool pace_gate = plan != nullptr && D == 768 && nq_pad > 256 && batch_group_queries(D, e->batch_rega.load() == 0 ? 5u : (uint32_t)e->batch_rega.load()) == 256u;
-    pa.tile_ctr = (dynamic_tiles || pace_gate) ? c->d_overflow + kBatchMaxQ : nullptr;
+    // the words behind the overflow flags: the progress words of the 768-d filtering GEMM's pace gate — zeroed by the prep kernel
+    const bool pace_gate = plan != nullptr && D == 768 && nq_pad > 256;
+    pa.progress = pace_gate ? c->d_overflow + kBatchMaxQ : nullptr;
     HIP_TRY(launch_batch_prep(pa, st), WAX_HIP_ERR_INTERNAL, "batch prep launch");
     GemmArgs g{};
     g.qb = c->d_qb; g.cb = b.d_cb; g.q_n2 = c->d_qn2; g.v_n2 = b.d_vn2; g.tau = c->d_tau;
     g.cand = c->d_cand; g.cand_count = c->d_cand_count; g.row_base = (uint32_t)e->row_base;
     g.dims = D; g.n_rows = n; g.nq = qn; g.nqt = nq_pad / 128;
-    g.use_rega = (uint32_t)e->batch_rega.load();  // 0 LDS-tiled kernel, 1 register staging + workgroup barrier, 2 LDS-DMA staging, 3 one wave per SIMD, 4 free-running, 5 split barrier (default)
+    g.use_rega = (uint32_t)e->batch_rega.load();  // 0 LDS-tiled kernel, 1 workgroup barrier per tile, 5 split barrier (default)
     g.debug = (uint32_t)e->batch_debug.load();
     g.seg_count = c->d_seg_count;
     if (plan) {
@@ -1306,8 +1326,7 @@ int batch_enqueue(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32
         if (g.use_rega == 0) g.use_rega = 5;
         GemmArgs gs = g;
         gs.tile_max = c->d_tile_max; gs.sample_tiles = plan->sample_tiles;
-        g.tile_ctr = dynamic_tiles ? pa.tile_ctr : nullptr;
-        g.progress = pace_gate ? pa.tile_ctr : nullptr;
+        g.progress = pa.progress;
         HIP_TRY(launch_batch_gemm_sample(gs, e->metric, st), WAX_HIP_ERR_INTERNAL, "sampling gemm launch");
         const bool timed = e->time_kernels.load() != 0;
         std::unique_lock<std::mutex> cg(e->gemm_chain_mu, std::defer_lock);
@@ -1517,7 +1536,10 @@ int batch_finish_device_locked(wax_hip_engine* e, BatchCtx* c, const float* d_qu
         e->st_batch_retries += inl;
         e->st_batch_inline_retries += inl;
         if (unc > 0) e->retry_hint.store(16);
-        else if (e->retry_hint.load() > 0) e->retry_hint.fetch_sub(1);
+        else {   // count a clean batch down, never below zero (concurrent collects race on this word)
+            int cur = e->retry_hint.load();
+            while (cur > 0 && !e->retry_hint.compare_exchange_weak(cur, cur - 1)) {}
+        }
     }
     // Second rung of the ladder, without another pass over the store: an uncertified query's survivors — EVERY row the
     // filtering GEMM admitted (approx distance <= tau) — are still in its segments, so all of them are re-scored exactly
@@ -1670,7 +1692,7 @@ int wax_hip_engine_create(uint8_t metric, uint32_t dims, int device_id, wax_hip_
     e->dims = dims;
     if (const char* v = std::getenv("WAX_HIP_BATCH_REGA")) {  // default of the "batch_rega" tunable (A/B runs of the whole test suite)
         const long m = std::strtol(v, nullptr, 10);
-        if (m >= 0 && m <= 12) e->batch_rega = m;
+        if (m == 0 || m == 1 || m == 5) e->batch_rega = m;
     }
     int rc = resize_store(e, WAX_HIP_INITIAL_RESERVE);  // :225-229
     if (rc == WAX_HIP_OK) {
@@ -2019,7 +2041,7 @@ static int submit_impl(wax_hip_engine* e, const float* query, uint32_t dims, int
         // "done_flag" (default 1): a scan that merges in the kernel (small grids) publishes a completion word in pinned memory behind
         // its hits and collect polls that word — no event behind the kernel. Not while kernels are timed (the timing events must have
         // completed when collect reads them).
-        const bool want_flag = e->done_flag.load() != 0 && !s->timed;
+        const bool want_flag = e->done_flag.load() != 0 && !s->timed && s->coherent;
         s->flag_wait = false;
         if (want_flag) s->done_seq += 1;
         bool flagged = false;
@@ -2082,11 +2104,23 @@ static int collect_impl(wax_hip_engine* e, uint64_t ticket, uint64_t* out_ids, f
         if (s->flag_wait) {
             // poll the completion word the kernel's last workgroup publishes behind the hits (system-scope release). The stream is
             // queried now and then so that a kernel that died without publishing fails loudly instead of spinning for ever.
+            // Spin for a bounded time (the scans this path serves take 10 - 300 us), then give the core away between polls: many
+            // collecting threads behind a busy stream must not each burn a core.
             const uint64_t want = s->done_seq;
+            const auto t_spin = std::chrono::steady_clock::now();
+            bool polite = false;
             for (uint32_t spins = 1;; ++spins) {
                 if (__atomic_load_n(s->h_done, __ATOMIC_ACQUIRE) == want) break;
-                __builtin_ia32_pause();
-                if ((spins & 0x3fffu) == 0u) {
+                if (!polite) {
+                    cpu_relax();
+                    if ((spins & 0x3ffu) == 0u &&
+                        std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_spin).count() > 400)
+                        polite = true;
+                } else {
+                    std::this_thread::yield();
+                    if ((spins & 0xffu) == 0u) std::this_thread::sleep_for(std::chrono::microseconds(50));
+                }
+                if ((spins & 0x3fffu) == 0u || (polite && (spins & 0x3fu) == 0u)) {
                     const hipError_t qs = hipStreamQuery(s->stream);
                     if (qs == hipErrorNotReady) continue;
                     if (__atomic_load_n(s->h_done, __ATOMIC_ACQUIRE) == want) break;
@@ -2861,15 +2895,17 @@ int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value) {
     else if (k == "query_args") { if (value < 0 || value > 2) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "query_args must be 0, 1 or 2"); e->query_args = value; }
     else if (k == "batch_min") e->batch_min = value;
     else if (k == "batch_mode") e->batch_mode = value;
-    else if (k == "batch_rega") e->batch_rega = value;
-    else if (k == "batch_debug") e->batch_debug = value;
+    else if (k == "batch_rega") { if (value != 0 && value != 1 && value != 5) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_rega must be 0, 1 or 5"); e->batch_rega = value; }
+    else if (k == "batch_debug") { if (value & ~(int64_t)(4096 | 16384 | 65536)) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_debug: bits 4096, 16384, 65536 only"); e->batch_debug = value; }
     else if (k == "batch_onepass") e->batch_onepass = value;
     else if (k == "batch_onepass_tiles") { if (value < 1024) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_onepass_tiles must be >= 1024"); e->batch_onepass_tiles = value; }
     else if (k == "batch_kp_fused") e->batch_kp_fused = value != 0;
     else if (k == "batch_survivors") { if (value < 2 || value > 64) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_survivors must be 2..64"); e->batch_survivors = value; }
-    else if (k == "batch_dynamic") e->batch_dynamic = value != 0;
     else if (k == "batch_eps_measured") e->batch_eps_measured = value != 0;
-    else if (k == "retry_hint") e->retry_hint = (int)value;   // > 0: the next batches carry the device-side retry kernel (set by collect; tests force it)
+    else if (k == "retry_hint") {   // > 0: the next `value` clean batches still carry the device-side retry kernel (set by collect; tests force it)
+        if (value < 0 || value > 1024) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "retry_hint must be 0..1024");
+        e->retry_hint = (int)value;
+    }
     else if (k == "batch_retry") { if (value < 0 || value > 2) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_retry must be 0, 1 or 2"); e->batch_retry = value; }
     else if (k == "batch_multi") e->batch_multi = value != 0;
     else if (k == "scan_chain") { if (value < -1 || value > 1) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "scan_chain must be -1 (auto), 0 or 1"); e->scan_chain = value; }
@@ -2942,7 +2978,6 @@ int64_t wax_hip_get_tuning(wax_hip_engine* e, const char* key) {
     if (k == "onepass_queries") return (int64_t)e->st_onepass_queries.load();
     if (k == "scan_chain") return e->scan_chain.load();
     if (k == "share_timing") return e->share_timing.load();
-    if (k == "batch_dynamic") return e->batch_dynamic.load();
     if (k == "batch_retry") return e->batch_retry.load();
     if (k == "batch_retries") return (int64_t)e->st_batch_retries.load();
     if (k == "batch_multi") return e->batch_multi.load();

@@ -178,8 +178,8 @@ struct GemmArgs {
     uint32_t slab_rows;
     uint32_t nq;
     uint32_t nqt;               // nq_pad / 128
-    uint32_t debug;             // timing experiments: bit0 skip corpus loads, bit1 skip MFMAs (results are garbage)
-    uint32_t use_rega;          // != 0: queries padded to 256 rows => register-resident-queries kernel allowed (1 register staging, 2 LDS-DMA staging)
+    uint32_t debug;             // "batch_debug": bit 12 no pace gate, bit 14 one wave of workgroup 1 pretends its split-barrier wait timed out (tests)
+    uint32_t use_rega;          // != 0: queries padded to 256 rows => register-resident-queries kernel allowed (1 = a workgroup barrier per tile instead of the split one)
     // Register-resident kernel only: survivors go to per-(workgroup, query) segments, no global atomics.
     // Query q's row of `cand` holds [0, seg_base) the best list and, from seg_base, `nseg` segments of `seg_slots`
     // keys; workgroup b of a 256-query group writes its survivors for q into segment b and its (unclamped) count
@@ -191,12 +191,7 @@ struct GemmArgs {
     // `sample_tiles` tiles spread evenly over the slab, tile_max[sample_tiles][nq_pad].
     float* tile_max;
     uint32_t sample_tiles;
-    // One-pass pipeline, filtering launch: non-null = a workgroup's first two tiles are its static ones (bidx,
-    // bidx + workgroups-per-group) and every further tile is claimed from tile_ctr[group] (zeroed before the launch;
-    // tile = 2 * workgroups-per-group + old counter value). A workgroup that is delayed — by another batch's kernels
-    // sharing the GPU — then simply claims fewer tiles instead of finishing last.
-    uint32_t* tile_ctr;
-    // Wide 768-d kernel, more than one query group: non-null = [256] progress words (zeroed before the launch; one 128-byte line per
+    // rq kernel, more than one query group (D = 768): non-null = [256] progress words (zeroed before the launch; one 128-byte line per
     // XCD) for the advisory pace gate that keeps the groups walking the corpus within a few tiles of each other, so that a tile
     // fetched for one group is still in the XCD's L2 when the others read it.
     uint32_t* progress;
@@ -258,8 +253,7 @@ bool batch_onepass_dims(uint32_t dims, int metric);
 bool batch_onepass_fast(uint32_t dims, int metric);
 // rows per GEMM tile of the kernel that serves (dims, metric): 64, 32 for the K-split kernel, 128 for the LDS-tiled kernel
 uint32_t batch_tile_rows(uint32_t dims, int metric);
-// queries per workgroup group of the register-resident filtering GEMM that "batch_rega" = use_rega selects (128 or 256)
-uint32_t batch_group_queries(uint32_t dims, uint32_t use_rega);
+constexpr uint32_t BATCH_GROUP_QUERIES = 256;   // queries per group of workgroups of the register-resident filtering GEMM
 bool batch_finish_fused_dims(uint32_t dims);
 // Queries f32 [nq][dims] in HBM -> bf16 block (cosine: normalised; rows [nq, nq_pad) zero), exact ||q|| as the
 // single-query path computes it (f64 accumulation, the host's summation order), certificate eps, and the per-batch
@@ -269,10 +263,10 @@ struct PrepArgs {
     float max_row_err;          // max over the mirror's rows of ||x - bf16(x)|| (mirror_kernel; x normalised for cosine); 0 = unknown (worst-case bound)
     unsigned short* qb; float* q_n2; float* q_norm; float* eps; float* tau; uint32_t* overflow;
     uint32_t* cand_count;       // slab pipeline: per-query append counters to zero (stride CAND_COUNT_STRIDE); may be null
-    uint32_t* tile_ctr;         // one-pass pipeline: [BATCH_TILE_CTRS] tile counters of the filtering GEMM to zero; may be null
+    uint32_t* progress;         // one-pass pipeline: [BATCH_PROGRESS_WORDS] pace-gate words of the filtering GEMM to zero; may be null
     float* q_norm_host;         // [nq] the exact norms once more, straight into pinned host memory (fallback queries need them there); may be null
 };
-constexpr uint32_t BATCH_TILE_CTRS = 32;
+constexpr uint32_t BATCH_PROGRESS_WORDS = 256;
 hipError_t launch_batch_prep(const PrepArgs& a, hipStream_t stream);
 hipError_t launch_batch_gemm_sample(const GemmArgs& a, int metric, hipStream_t stream);
 // tau[q] = 1 - (the rank-th largest of the sampled tiles' best similarities), rank <= 12; padding queries keep -inf.
