@@ -808,6 +808,7 @@ def _run_bench(nproc, extra, tmp_path, one_process=False):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     common = ["--rows", "300000", "--steps", "12", "--warmup", "2", "--no-cpu-baseline", "--c5-rows", "300000"] + extra
     env = dict(os.environ)
+    env.pop("WAX_HIP_SHARD_MIN_MB", None)          # the bench runs with the library's defaults
     if nproc == 1 or one_process:
         if one_process:
             env["WAX_BENCH_SAME_DEVICE"] = "1"
@@ -1956,6 +1957,91 @@ def test_fused_final_merge_equals_two_launch_path(wax):
         g_ids, g_scores = eng.searchArrays(queries[0], 10)
         assert_parity(g_ids, g_scores, e_ids, e_scores, None, f"fused merge m{metric} d{dims} n{n}")
         eng.close()
+
+
+def test_fused_merge_hand_over_litmus_under_l2_pressure(wax):
+    """Litmus for the fused final merge's hand-over (kernels.hip::scan_epilogue): every workgroup publishes its k keys with
+    relaxed agent-scope (write-through) stores, drains them (`s_waitcnt vmcnt(0)`), takes a relaxed agent-scope ticket; the last
+    arriver reads the other lists with agent-scope loads. That is an argument about what gfx950 does with sc1 stores and L2-resident
+    atomics, not a release / acquire pair the language guarantees — so this test hammers it where a violation would show: hundreds of
+    thousands of one-launch scans on grids of 157 / 313 / 505 workgroups (wave-list merge, one and two lists per thread of the k-way
+    merge), from four host threads with four tickets each in flight (slots and tickets re-armed back to back), while a co-running
+    copy kernel streams 1 GB through every XCD's L2 and HBM channel. Every answer is compared, id for id and score for score,
+    with the two-launch path's ("fuse_merge" = 0: partial lists cross a kernel boundary). A stale partial list would surface as a
+    missing or duplicated neighbour in some top-k; a lost ticket as a collect that never returns (the per-test timeout)."""
+    import threading
+    import time
+    import torch
+    dev = torch.device("cuda", 0)
+    dims = 384
+    stores = []
+    for n in (10_000, 20_000, 120_000):                       # 157 (two chunks per wave), 313, 505 workgroups at D = 384
+        corpus = oracle.gaussian_unit_rows(31 + n, n, dims)
+        eng = make_engine(wax, 0, dims, corpus, np.arange(n, dtype=np.uint64) + 5)
+        eng.setTuning("slots", 16)
+        eng.setTuning("streams", 4)
+        queries = oracle.gaussian_unit_queries(48, dims, seed=n)
+        ref = {}
+        eng.setTuning("fuse_merge", 0)
+        for k in (10, 30, 100):
+            ref[k] = [eng.searchArrays(q, k) for q in queries]
+        eng.setTuning("fuse_merge", 1)
+        assert eng.getTuning("scan_grid") in (157, 313, 505), eng.getTuning("scan_grid")
+        stores.append((eng, queries, ref))
+    stop = threading.Event()
+    side = torch.cuda.Stream(device=dev)
+    a = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+    b = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+
+    def thrash():                                             # 2 x 256 MB per copy pair: no line of any L2 survives it
+        with torch.cuda.stream(side):
+            while not stop.is_set():
+                for _ in range(8):
+                    b.copy_(a, non_blocking=True)
+                    a.copy_(b, non_blocking=True)
+                side.synchronize()
+    errors, done = [], [0] * 4
+
+    def worker(w, deadline):
+        rng = np.random.default_rng(1000 + w)
+        try:
+            while time.perf_counter() < deadline and not errors:
+                eng, queries, ref = stores[int(rng.integers(len(stores)))]
+                k = int(rng.choice([10, 10, 30, 100]))
+                order = rng.integers(len(queries), size=64)
+                pend = []
+                for qi in order:
+                    if len(pend) == 4:
+                        t, j = pend.pop(0)
+                        ids, scores = eng.collect(t, k)
+                        if not (np.array_equal(ids, ref[k][j][0]) and np.array_equal(scores, ref[k][j][1])):
+                            errors.append((w, k, int(j), ids[:5].tolist(), ref[k][j][0][:5].tolist()))
+                            return
+                        done[w] += 1
+                    pend.append((eng.submit(queries[qi], k), qi))
+                for t, j in pend:
+                    ids, scores = eng.collect(t, k)
+                    if not (np.array_equal(ids, ref[k][j][0]) and np.array_equal(scores, ref[k][j][1])):
+                        errors.append((w, k, int(j), ids[:5].tolist(), ref[k][j][0][:5].tolist()))
+                        return
+                    done[w] += 1
+        except Exception as ex:  # noqa: BLE001
+            errors.append((w, repr(ex)))
+    th = threading.Thread(target=thrash)
+    th.start()
+    deadline = time.perf_counter() + 12.0
+    ws = [threading.Thread(target=worker, args=(w, deadline)) for w in range(4)]
+    [t.start() for t in ws]
+    [t.join() for t in ws]
+    stop.set()
+    th.join()
+    torch.cuda.synchronize()
+    merged = sum(int(e.getTuning("merged_scans")) for e, _, _ in stores)
+    print(f"\n[litmus] {sum(done)} one-launch scans checked against the two-launch path under L2 / HBM pressure ({merged} merged in their own kernel)")
+    assert not errors, errors[:2]
+    assert sum(done) >= 20_000 and merged >= sum(done)
+    for e, _, _ in stores:
+        e.close()
 
 
 def test_query_in_kernel_arguments_equals_uploaded_query(wax):

@@ -15,9 +15,20 @@ from helpers import assert_parity
 
 pytestmark = pytest.mark.gpu
 
-# These tests are about the multi-shard machinery on stores of a few thousand rows: switch the small-store rule off for
-# the handles they create (read at handle creation; test_small_store_rule_* set it back per handle through "shard_min_mb").
-os.environ["WAX_HIP_SHARD_MIN_MB"] = "0"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _spread_small_stores():
+    """These tests are about the multi-shard machinery on stores of a few thousand rows: the small-store rule is switched off for
+    the handles they create (the variable is read at handle creation; test_small_store_rule_* set the rule back per handle
+    through "shard_min_mb") — and restored afterwards, so that nothing else in the session (bench.py subprocesses) inherits it."""
+    old = os.environ.get("WAX_HIP_SHARD_MIN_MB")
+    os.environ["WAX_HIP_SHARD_MIN_MB"] = "0"
+    yield
+    if old is None:
+        os.environ.pop("WAX_HIP_SHARD_MIN_MB", None)
+    else:
+        os.environ["WAX_HIP_SHARD_MIN_MB"] = old
 
 
 @pytest.fixture(scope="module")

@@ -1207,8 +1207,9 @@ bool plan_onepass(wax_hip_engine* e, uint32_t n, int k_eff, uint32_t nq, Onepass
     const bool fast = batch_onepass_fast(e->dims, e->metric);
     p->tile_rows = batch_tile_rows(e->dims, e->metric);
     p->ntiles = (n + p->tile_rows - 1) / p->tile_rows;
-    if (fast ? ((int64_t)p->ntiles < e->batch_onepass_tiles.load() || p->ntiles < 1024)
-             : ((int64_t)n < e->batch_onepass_tiles.load() * 64 || p->ntiles < 512)) return false;   // too small to sample: slab pipeline
+    // too small to sample: slab pipeline ("batch_onepass_tiles" counts units of min(tile rows, 64) rows: 32 at D = 768, 64 elsewhere)
+    const uint32_t unit = fast ? std::min<uint32_t>(p->tile_rows, 64u) : 64u;
+    if ((int64_t)n < e->batch_onepass_tiles.load() * (int64_t)unit || (fast ? n < 1024u * unit : p->ntiles < 512)) return false;
     p->kp = batch_kp(k_eff, 960);
     // k in 81 .. 128: k' = 2k + 32 would need the three-launch finish (select 120-190 us + re-score + finalize at 256 queries on a dense
     // corpus) where the fused finish kernel takes ~58 us. With the device-side retry behind it — which re-scores exactly the survivors the
