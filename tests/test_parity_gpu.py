@@ -1964,8 +1964,8 @@ def test_fused_merge_hand_over_litmus_under_l2_pressure(wax):
     relaxed agent-scope (write-through) stores, drains them (`s_waitcnt vmcnt(0)`), takes a relaxed agent-scope ticket; the last
     arriver reads the other lists with agent-scope loads. That is an argument about what gfx950 does with sc1 stores and L2-resident
     atomics, not a release / acquire pair the language guarantees — so this test hammers it where a violation would show: hundreds of
-    thousands of one-launch scans on grids of 157 / 313 / 505 workgroups (wave-list merge, one and two lists per thread of the k-way
-    merge), from four host threads with four tickets each in flight (slots and tickets re-armed back to back), while a co-running
+    thousands of one-launch scans on grids of 157 / 417 / 469 workgroups (one and two lists per thread of the k-way merge, the
+    wave-list merge at k = 100), from four host threads with four tickets each in flight (slots and tickets re-armed back to back), while a co-running
     copy kernel streams 1 GB through every XCD's L2 and HBM channel. Every answer is compared, id for id and score for score,
     with the two-launch path's ("fuse_merge" = 0: partial lists cross a kernel boundary). A stale partial list would surface as a
     missing or duplicated neighbour in some top-k; a lost ticket as a collect that never returns (the per-test timeout)."""
@@ -1975,7 +1975,7 @@ def test_fused_merge_hand_over_litmus_under_l2_pressure(wax):
     dev = torch.device("cuda", 0)
     dims = 384
     stores = []
-    for n in (10_000, 20_000, 120_000):                       # 157 (two chunks per wave), 313, 505 workgroups at D = 384
+    for n in (10_000, 40_000, 120_000):                       # 157 workgroups (two chunks per wave; one list per thread), 417 and 469 (two lists per thread)
         corpus = oracle.gaussian_unit_rows(31 + n, n, dims)
         eng = make_engine(wax, 0, dims, corpus, np.arange(n, dtype=np.uint64) + 5)
         eng.setTuning("slots", 16)
@@ -1986,7 +1986,7 @@ def test_fused_merge_hand_over_litmus_under_l2_pressure(wax):
         for k in (10, 30, 100):
             ref[k] = [eng.searchArrays(q, k) for q in queries]
         eng.setTuning("fuse_merge", 1)
-        assert eng.getTuning("scan_grid") in (157, 313, 505), eng.getTuning("scan_grid")
+        assert (eng.getTuning("scan_grid") <= 160) == (n == 10_000) and eng.getTuning("scan_grid") <= 512, eng.getTuning("scan_grid")
         stores.append((eng, queries, ref))
     stop = threading.Event()
     side = torch.cuda.Stream(device=dev)
@@ -2039,7 +2039,7 @@ def test_fused_merge_hand_over_litmus_under_l2_pressure(wax):
     merged = sum(int(e.getTuning("merged_scans")) for e, _, _ in stores)
     print(f"\n[litmus] {sum(done)} one-launch scans checked against the two-launch path under L2 / HBM pressure ({merged} merged in their own kernel)")
     assert not errors, errors[:2]
-    assert sum(done) >= 20_000 and merged >= sum(done)
+    assert sum(done) >= 20_000 and merged >= sum(done) // 2     # (k = 100 on the two larger grids takes two launches: same comparison, different path)
     for e, _, _ in stores:
         e.close()
 

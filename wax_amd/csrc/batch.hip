@@ -464,7 +464,7 @@ __device__ inline void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N
 // SAMPLE = true (one-pass pipeline, threshold estimation): instead of filtering, the workgroup visits `a.sample_tiles` tiles spread
 // evenly over the slab (logical index i -> tile i * ntiles / sample_tiles) and records, per query, the best similarity of each
 // visited tile in a.tile_max[i][query] (pick_tau_kernel turns the j-th best tile maximum into the query's admission threshold).
-template <int D, int TROWS, int NBUF, int AHEAD, bool SAMPLE, bool SPLIT>
+template <int D, int TROWS, int NBUF, int AHEAD, bool SAMPLE, bool SPLIT, bool NT = false>
 __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint32_t blocks_per_group) {
     constexpr int KS = D / 16;                       // MFMA k-steps
     constexpr int RB = TROWS / 32;                   // 32-row blocks per tile = accumulators per wave
@@ -569,7 +569,8 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
                         const uint32_t slot = P * 64u + lane_o;
                         off = (slot - ((slot * DIV_MAGIC) >> DIV_SHIFT)) * 16u;
                     }
-                    __builtin_amdgcn_global_load_lds((global_cvoid*)(tbase + off), (lds_void*)(smem + buf_off + P * 1024u), 16, 0, 0);
+                    // NT (one query group: every tile is read exactly once): non-temporal requests
+                    __builtin_amdgcn_global_load_lds((global_cvoid*)(tbase + off), (lds_void*)(smem + buf_off + P * 1024u), 16, 0, NT ? 2 : 0);
                 }
             }
         }
@@ -832,17 +833,17 @@ bool batch_gemm_segments(const GemmArgs& a, int metric, uint32_t* nseg, uint32_t
     return true;
 }
 
-template <int D, bool SAMPLE, bool SPLIT>
+template <int D, bool SAMPLE, bool SPLIT, bool NT = false>
 static hipError_t launch_rq(const GemmArgs& a, uint32_t groups, uint32_t per_group, hipStream_t st) {
     using G = RqGeom<D>;
     constexpr size_t smem = rq_smem<D>();
     static_assert(smem <= 160 * 1024, "LDS budget of one CU");
     static std::atomic<uint64_t> configured{0};   // per device (ensure_dynamic_lds)
     {
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&batch_gemm_rq_kernel<D, G::TROWS, G::NBUF, G::AHEAD, SAMPLE, SPLIT>), smem, configured);
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&batch_gemm_rq_kernel<D, G::TROWS, G::NBUF, G::AHEAD, SAMPLE, SPLIT, NT>), smem, configured);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((batch_gemm_rq_kernel<D, G::TROWS, G::NBUF, G::AHEAD, SAMPLE, SPLIT>), dim3(groups * per_group), dim3(512), smem, st, a, per_group);
+    hipLaunchKernelGGL((batch_gemm_rq_kernel<D, G::TROWS, G::NBUF, G::AHEAD, SAMPLE, SPLIT, NT>), dim3(groups * per_group), dim3(512), smem, st, a, per_group);
     return hipGetLastError();
 }
 
@@ -852,6 +853,9 @@ static hipError_t launch_rq_filter(const GemmArgs& a, hipStream_t st) {
     rq_geometry(a, &groups, &per_group);
     // "batch_rega" 1: a workgroup barrier per tile instead of the split one (A/B, and the variant the fail-safe test compares with)
     if (a.use_rega == 1u) return launch_rq<D, false, false>(a, groups, per_group, st);
+    // one query group: every tile is requested exactly once, by one workgroup -> non-temporal requests (-1 ... -3 % at Q = 256; with
+    // G > 1 groups sharing tiles through their XCD's L2 the same hint costs 3 - 5 %: profiles/r05/e_nontemporal_tile_requests.txt)
+    if (groups == 1) return launch_rq<D, false, true, true>(a, groups, per_group, st);
     return launch_rq<D, false, true>(a, groups, per_group, st);
 }
 
