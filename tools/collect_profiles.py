@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Copy the summaries of a tools/sessions/r04_final.sh run (gpurun_out/<tag>/) into profiles/<round>/ under stable names and refresh
+"""Copy the summaries of a tools/sessions/r0N_final.sh run (gpurun_out/<tag>/) into profiles/<round>/ under stable names and refresh
 profiles/latest_traffic.json (the counters-only FETCH_SIZE passes bench.py replays as `roofline.traffic`).
-    python tools/collect_profiles.py gpurun_out/r04_final profiles/r04"""
+    python tools/collect_profiles.py gpurun_out/r05_final profiles/r05"""
 import csv
 import json
 import os
@@ -26,8 +26,12 @@ cp("headline_chained.out", "z_bench_headline_chained_under_rocprof.json")
 cp("default_cmd_kernel_stats.csv", "z_default_cmd_kernel_stats.csv")
 cp("default_cmd.out", "z_bench_n1_under_rocprof.json")
 cp("scale_rehearsal.txt", "z_scale_matrix_rehearsal_one_gpu.txt")
-cp("sq_768_wide.json", "z_pmc_sq_counters_768_wide_final_build.json")
-cp("sq2_768_wide.json", "z_pmc_sq2_counters_768_wide_final_build.json")
+for a, b in (("sq_768", "z_pmc_sq_counters_768_rq_final_build.json"), ("sq2_768", "z_pmc_sq2_counters_768_rq_final_build.json"),
+             ("sq_384", "z_pmc_sq_counters_384_rq_final_build.json"), ("sq_768_wide", "z_pmc_sq_counters_768_wide_final_build.json"),
+             ("sq2_768_wide", "z_pmc_sq2_counters_768_wide_final_build.json")):
+    cp(a + ".json", b)
+for a in ("one_process_2_shards.json", "one_process_n1.json", "pytest_gpu.log", "fuzz.txt", "latency_c.jsonl", "smoke.log"):
+    cp(a, "z_" + a)
 
 # one rocprofv3 row per GEMM workload
 rows = []
@@ -80,15 +84,15 @@ if h:
     out["fetch"]["headline 10M x 384 scan"] = h
 b = t.setdefault("batched", {}).setdefault("configs", {})
 for name, key in (("fetch_768_shard", "1250000x768xq1024"), ("fetch_768_full", "10000000x768xq1024")):
-    e = fetch(name, lambda k: "batch_gemm_wide" in k)
+    e = fetch(name, lambda k: "batch_gemm_rq" in k or "batch_gemm_wide" in k)
     if e:
         b[key] = {"hbm_bytes_per_launch": e["hbm_bytes_per_launch"], "launches": e["launches"], "kernel": e["kernel"]}
         out["fetch"][key] = e
-e = fetch("fetch_384_q256", lambda k: "batch_gemm_rega" in k and ", true," not in k.split("<")[1][:22])
+e = fetch("fetch_384_q256", lambda k: ("batch_gemm_rq" in k or "batch_gemm_rega" in k))
 if e:
     out["fetch"]["1M x 384 (Q = 256 and 1 024 launches averaged)"] = e
 t["batched"]["source"] = (f"profiles/{rnd}/z_pmc_fetch_size.json (rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python tools/batch_bench.py --dims D --rows N --nq Q --reps 2; "
-                          "counters-only passes; the 768-d entries are the round-4 wide kernel, the 1M x 384 entries round 3's: profiles/r03/v_gemm_fetch_size.txt)")
+                          "counters-only passes; the instantiation of the filtering GEMM with the largest mean)")
 json.dump(t, open(tpath, "w"), indent=1)
 out["correction"] = t.get("correction")
 json.dump(out, open(os.path.join(dst, "z_pmc_fetch_size.json"), "w"), indent=1)

@@ -24,9 +24,6 @@ for s in $STAGES; do
       timeout 600 python -m pytest tests -m gpu -q -rA --durations=15 -p no:cacheprovider --timeout 150 > "$OUT/pytest_gpu.log" 2>&1; rc=$? ;;
     tests3)
       timeout 1500 python -m pytest tests -m gpu -q -rf --durations=25 -p no:cacheprovider --timeout 400 > "$OUT/pytest_gpu.log" 2>&1; rc=$? ;;
-    newtests)
-      timeout 900 python -m pytest tests -m gpu -q -x -rf --durations=10 -p no:cacheprovider --timeout 400 \
-          -k "multi_query_exact or fused_final_merge or sharded_batched_device or beyond_the_slot_pool or falls_back_on_ties or adversarial" > "$OUT/pytest_new.log" 2>&1; rc=$? ;;
     onepasstests)
       timeout 900 python -m pytest tests -m gpu -q -x -rf --durations=10 -p no:cacheprovider --timeout 400 \
           -k "onepass or batch_mfma or randomised_soak or variants_agree or edge_shapes or special_values or dot_and_l2" > "$OUT/pytest_onepass.log" 2>&1; rc=$? ;;
@@ -45,42 +42,14 @@ for s in $STAGES; do
           --kernel-trace --output-format csv -d "$OUT/prof_mspmc" -o g -- python "$R/tools/multiscan_bench.py" --dims 384 --nq 16 --reps 3 > "$OUT/multiscan_pmc.log" 2>&1); rc=$?
       python tools/pmc_summary.py "$OUT/prof_mspmc" > "$OUT/multiscan_pmc_summary.json" 2>> "$OUT/multiscan_pmc.log"
       rm -rf "$OUT/prof_mspmc" ;;
-    freerun)
-      WAX_HIP_BATCH_REGA=4 timeout 900 python -m pytest tests -q -m gpu -x -p no:cacheprovider --timeout 400 \
-          -k "onepass or batch_mfma or randomised_soak or variants_agree or edge_shapes or special_values or dot_and_l2 or adversarial or falls_back_on_ties" > "$OUT/pytest_freerun.log" 2>&1; rc=$?
-      timeout 600 python tools/batch_bench.py --nq 256 1024 --rega 1 4 1 4 > "$OUT/freerun_bench.log" 2>&1
-      timeout 300 python tools/batch_bench.py --dims 256 --nq 256 1024 --rega 1 4 1 4 --reps 3 > "$OUT/freerun_bench256.log" 2>&1
-      timeout 300 python tools/batch_bench.py --nq 256 --reps 2 --rega 4 --debug 1024 > "$OUT/freerun_clock.log" 2>&1
-      grep WAXPROF "$OUT/freerun_clock.log" | sort | uniq -c | sort -rn | head -200 > "$OUT/freerun_waxprof.txt" ;;
-    token)
-      timeout 600 python tools/batch_bench.py --nq 256 1024 --rega 4 --debug 0 2048 0 2048 > "$OUT/token_bench.log" 2>&1; rc=$?
-      timeout 300 python tools/batch_bench.py --dims 256 --nq 1024 --rega 4 --debug 0 2048 0 2048 --reps 3 > "$OUT/token_bench256.log" 2>&1
-      timeout 300 python tools/batch_bench.py --nq 256 --reps 2 --rega 4 --debug 3072 > "$OUT/token_clock.log" 2>&1
-      grep WAXPROF "$OUT/token_clock.log" | sort | uniq -c | sort -rn | head -200 > "$OUT/token_waxprof.txt" ;;
     mfmaprobe)
       hipcc --offload-arch=gfx950 -O3 -std=c++17 -w tools/mfma_probe.hip -o /tmp/mfma_probe > "$OUT/mfma_probe.err" 2>&1 && timeout 120 /tmp/mfma_probe > "$OUT/mfma_probe.jsonl" 2>> "$OUT/mfma_probe.err"; rc=$? ;;
-    freeprobe)
-      hipcc --offload-arch=gfx950 -O3 -std=c++17 -w tools/mfma_probe.hip -o /tmp/mfma_probe > "$OUT/mfma_probe.err" 2>&1
-      timeout 600 python tools/batch_bench.py --nq 256 1024 --rega 4 --reps 10 --debug 0 8 4096 4104 16 2048 0 > "$OUT/freeprobe_bench.log" 2>&1; rc=$?
-      timeout 120 /tmp/mfma_probe > "$OUT/mfma_probe.jsonl" 2>> "$OUT/mfma_probe.err" ;;
-    freeprobe2)
-      timeout 600 python tools/batch_bench.py --nq 1024 --rega 4 --reps 10 --debug 0 4104 4120 4136 4152 4104 > "$OUT/freeprobe2_bench.log" 2>&1; rc=$?
-      timeout 600 python tools/batch_bench.py --nq 1024 --rega 1 --reps 10 --debug 0 9 13 29 9 >> "$OUT/freeprobe2_bench.log" 2>&1 ;;
-    freeab)
-      for m in 1 4 1 4; do
-        WAX_HIP_BATCH_REGA=$m timeout 600 python bench.py --gpus 1 --no-cpu-baseline --steps 60 --warmup 10 --secondary b1m_q256,b1m_q1024,clustered_k100 > "$OUT/bench_sec_rega$m.$RANDOM.json" 2>> "$OUT/bench_sec.err"; rc=$?
-      done ;;
-    gemmclock)
-      timeout 300 python tools/batch_bench.py --nq 256 1024 --reps 2 --debug 1024 > "$OUT/gemmclock.log" 2>&1; rc=$?
-      grep WAXPROF "$OUT/gemmclock.log" | sort | uniq -c | sort -rn | head -200 > "$OUT/gemmclock_waxprof.txt" ;;
     shardbench)
       timeout 900 python tools/sharded_handle_bench.py --parts ${WAX_PARTS:-A,B,C} > "$OUT/sharded_handle_bench.jsonl" 2> "$OUT/sharded_handle_bench.err"; rc=$? ;;
     fuzz)
       timeout 400 python tools/fuzz_batch.py --seconds ${WAX_FUZZ_S:-120} --seed 7 > "$OUT/fuzz_batch.jsonl" 2> "$OUT/fuzz_batch.err"; rc=$? ;;
     fuzzsharded)
       timeout 500 python tools/fuzz_batch.py --seconds ${WAX_FUZZ_S:-180} --seed ${WAX_FUZZ_SEED:-11} --sharded 0.5 > "$OUT/fuzz_sharded.jsonl" 2> "$OUT/fuzz_sharded.err"; rc=$? ;;
-    tests_x)
-      timeout 600 python -m pytest tests -m gpu -x -q -p no:cacheprovider --timeout 150 > "$OUT/pytest_gpu_x.log" 2>&1; rc=$? ;;
     filtered)
       timeout 300 python tools/filtered_bench.py > "$OUT/filtered_bench.json" 2> "$OUT/filtered_bench.err"; rc=$? ;;
     cpusweep)
@@ -100,31 +69,6 @@ for s in $STAGES; do
       find "$OUT/prof_pmc" -name "*.csv" -size +2M -delete 2>/dev/null ;;
     batch)
       timeout 900 python tools/batch_bench.py --nq 64 256 1024 > "$OUT/batch_bench.log" 2>&1; rc=$? ;;
-    growth)
-      timeout 600 python tools/batch_bench.py --nq 256 1024 --growth 3 4 6 8 10 12 > "$OUT/growth_bench.log" 2>&1; rc=$? ;;
-    tests_glds)
-      WAX_HIP_BATCH_REGA=2 timeout 900 python -m pytest tests -q -m gpu -x -k "batch" > "$OUT/pytest_gpu_glds.log" 2>&1; rc=$? ;;
-    glds)
-      timeout 600 python tools/batch_bench.py --nq 256 1024 --growth 8 --rega 1 2 1 2 > "$OUT/glds_bench.log" 2>&1; rc=$? ;;
-    ahead)
-      timeout 600 python tools/batch_bench.py --nq 256 1024 --growth 8 --rega 1 2 1 2 --debug 0 512 > "$OUT/ahead_bench.log" 2>&1; rc=$?
-      (cd /tmp && WAX_HIP_BATCH_REGA=2 timeout 600 rocprofv3 --kernel-trace --output-format csv -d "$OUT/prof_ahead" -o g -- \
-          python "$R/tools/batch_bench.py" --nq 256 --reps 2 --rega 1 2 --debug 0 256 512 > "$OUT/aheadprof.log" 2>&1)
-      f=$(find "$OUT/prof_ahead" -name "*kernel_trace.csv" | head -1)
-      [ -n "$f" ] && grep "rega_kernel" "$f" | python "$R/tools/trace_durations.py" > "$OUT/ahead_rega_durations.txt" 2>/dev/null
-      find "$OUT/prof_ahead" -name "*kernel_trace.csv" -delete 2>/dev/null ;;
-    trace768)
-      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d "$OUT/prof_768" -o g -- \
-          python "$R/tools/batch_bench.py" --rows 1000000 --dims 768 --nq ${WAX_NQ:-1024} --reps 2 > "$OUT/trace768.log" 2>&1); rc=$?
-      f=$(find "$OUT/prof_768" -name "*kernel_trace.csv" | head -1)
-      [ -n "$f" ] && python "$R/tools/trace_tail.py" "$f" 40 > "$OUT/trace768_tail.csv" 2>/dev/null
-      find "$OUT/prof_768" -name "*kernel_trace.csv" -delete 2>/dev/null ;;
-    firstslab)
-      timeout 600 python tools/batch_bench.py --nq 256 1024 --first 512 1024 2048 --growth 8 12 16 > "$OUT/firstslab_bench.log" 2>&1; rc=$?
-      timeout 300 python tools/batch_bench.py --rows 1000000 --dims 768 --nq 1024 --reps 3 --first 1024 2048 --growth 8 12 > "$OUT/firstslab768_bench.log" 2>&1 ;;
-    setprio)
-      timeout 600 python tools/batch_bench.py --nq 256 1024 --debug 0 32 0 32 > "$OUT/setprio_bench.log" 2>&1; rc=$?
-      timeout 300 python tools/batch_bench.py --rows 1000000 --dims 768 --nq 1024 --reps 3 --debug 0 32 0 32 > "$OUT/setprio768_bench.log" 2>&1 ;;
     trace1m)
       (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d "$OUT/prof_1m" -o g -- \
           python "$R/bench.py" --gpus 1 --rows ${WAX_ROWS:-1000000} --steps 60 --warmup 10 --no-cpu-baseline > "$OUT/trace1m_bench.json" 2> "$OUT/trace1m.err"); rc=$?
@@ -135,16 +79,6 @@ for s in $STAGES; do
       timeout 300 python tools/reference_harness_bench.py > "$OUT/reference_harness.json" 2> "$OUT/reference_harness.err"; rc=$? ;;
     hosttrace)
       WAX_HIP_BATCH_TRACE=1 timeout 300 python tools/batch_bench.py --nq 256 1024 --reps 3 > "$OUT/hosttrace.log" 2>&1; rc=$? ;;
-    pingpong)
-      timeout 600 python tools/batch_bench.py --nq 256 1024 --growth 8 --debug 0 16 0 16 > "$OUT/pingpong_bench.log" 2>&1; rc=$? ;;
-    growthprof)
-      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d "$OUT/prof_growth" -o g -- \
-          python "$R/tools/batch_bench.py" --nq ${WAX_NQ:-256} --reps 2 --growth ${WAX_GROWTH:-8} > "$OUT/growthprof.log" 2>&1); rc=$?
-      f=$(find "$OUT/prof_growth" -name "*kernel_trace.csv" | head -1)
-      [ -n "$f" ] && python "$R/tools/trace_tail.py" "$f" 40 > "$OUT/growth_trace_tail.csv" 2>/dev/null
-      find "$OUT/prof_growth" -name "*kernel_trace.csv" -delete 2>/dev/null ;;
-    batch768)
-      timeout 300 python tools/batch_bench.py --rows 1000000 --dims 768 --nq 256 1024 --reps 3 --growth ${WAX_GROWTHS:-0} > "$OUT/batch768_bench.log" 2>&1; rc=$? ;;
     profdefault)
       (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_default" -o bench -- \
           python "$R/bench.py" --gpus 1 > "$OUT/profdefault_bench.json" 2> "$OUT/profdefault.err"); rc=$?
@@ -197,28 +131,9 @@ PYEOF
         python tools/pmc_summary.py "$OUT/prof_fetch_$1_$2_$3" > "$OUT/gemmfetch_$1_$2_$3.json" 2>> "$OUT/gemmfetch_$1_$2_$3.log"
         rm -rf "$OUT/prof_fetch_$1_$2_$3"
       done ;;
-    profsplit)
-      # the GEMM rows of rocprofv3 --stats, one workload per run (the default command mixes five GEMM workloads in one row)
-      for w in b1m_q256 b1m_q1024 c5_shard c5_full clustered_k100; do
-        (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_split_$w" -o bench -- \
-            python "$R/bench.py" --gpus 1 --rows 1000000 --steps 20 --warmup 4 --no-cpu-baseline --secondary $w > "$OUT/profsplit_$w.json" 2> "$OUT/profsplit_$w.err"); rc=$?
-        f=$(find "$OUT/prof_split_$w" -name "*kernel_stats.csv" | head -1)
-        [ -n "$f" ] && { head -1 "$f"; grep "wax::" "$f"; } > "$OUT/kernel_stats_$w.csv"
-        rm -rf "$OUT/prof_split_$w"
-      done ;;
     shardtests)
       timeout 900 python -m pytest tests/test_sharded_engine_gpu.py tests/test_parity_gpu.py -q -m gpu -x -p no:cacheprovider --timeout 400 \
           -k "sharded or bench_contract or submit_collect_device" > "$OUT/pytest_shard.log" 2>&1; rc=$? ;;
-    probepmc)
-      # the K-loop probe under counters: how busy the matrix pipe is, and at what clock the chip runs meanwhile
-      hipcc --offload-arch=gfx950 -O3 -std=c++17 -w tools/mfma_probe.hip -o /tmp/mfma_probe > "$OUT/mfma_probe.err" 2>&1
-      (cd /tmp && timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 --kernel-trace --output-format csv \
-          -d "$OUT/prof_probe_pmc" -o p -- /tmp/mfma_probe > "$OUT/probe_under_pmc.jsonl" 2> "$OUT/probepmc.err"); rc=$?
-      f=$(find "$OUT/prof_probe_pmc" -name "*counter_collection.csv" | head -1)
-      [ -n "$f" ] && cp "$f" "$OUT/probe_counter_collection.csv"
-      f=$(find "$OUT/prof_probe_pmc" -name "*kernel_trace.csv" | head -1)
-      [ -n "$f" ] && cp "$f" "$OUT/probe_kernel_trace.csv"
-      rm -rf "$OUT/prof_probe_pmc" ;;
     gridsweep)
       # scan grid / pipeline depth under the overlapped product mode (value and pipeline_frac are what moves; frac is per launch)
       for g in 256 384 512 768 1024; do
@@ -228,27 +143,6 @@ PYEOF
       for d in 2 3 6 8; do
         timeout 300 python bench.py --gpus 1 --rows 1000000 --no-cpu-baseline --no-secondary --steps 600 --warmup 50 --depth $d >> "$OUT/depthsweep_1m.jsonl" 2>> "$OUT/gridsweep.err"
       done; rc=$? ;;
-    variantsuite)
-      for m in 4 3 2; do
-        WAX_HIP_BATCH_REGA=$m timeout 900 python -m pytest tests -q -m gpu -x -p no:cacheprovider --timeout 400 -k "batch or onepass or sharded or adversarial or falls_back" > "$OUT/pytest_rega$m.log" 2>&1; rc=$?
-        tail -2 "$OUT/pytest_rega$m.log"
-      done ;;
-    splitab)
-      WAX_HIP_BATCH_REGA=5 timeout 900 python -m pytest tests -q -m gpu -x -p no:cacheprovider --timeout 400 \
-          -k "onepass or batch_mfma or randomised_soak or variants_agree or adversarial or falls_back_on_ties or submit_collect_device" > "$OUT/pytest_split.log" 2>&1; rc=$?
-      tail -1 "$OUT/pytest_split.log"
-      timeout 600 python tools/batch_bench.py --nq 256 1024 --rega 1 5 1 5 > "$OUT/split_bench.log" 2>&1
-      for m in 1 5 1 5; do
-        WAX_HIP_BATCH_REGA=$m timeout 600 python bench.py --gpus 1 --rows 1000000 --steps 20 --warmup 4 --no-cpu-baseline --secondary b1m_q256,b1m_q1024,clustered_k100 > "$OUT/bench_sec_rega$m.$RANDOM.json" 2>> "$OUT/bench_sec.err"
-      done ;;
-    split768)
-      timeout 900 python -m pytest tests -q -m gpu -x -p no:cacheprovider --timeout 400 \
-          -k "onepass or batch_mfma or randomised_soak or variants_agree or adversarial or falls_back_on_ties or submit_collect_device or config5_shard or sharded_batch" > "$OUT/pytest_split768.log" 2>&1; rc=$?
-      tail -1 "$OUT/pytest_split768.log"
-      timeout 600 python tools/batch_bench.py --dims 768 --rows 1250000 --nq 1024 --reps 5 --rega 1 5 1 5 > "$OUT/split768_bench.log" 2>&1
-      for m in 1 5 1 5; do
-        WAX_HIP_BATCH_REGA=$m timeout 600 python bench.py --gpus 1 --rows 1000000 --steps 20 --warmup 4 --no-cpu-baseline --secondary c5_shard,b1m_q256 > "$OUT/bench_c5_rega$m.$RANDOM.json" 2>> "$OUT/bench_sec.err"
-      done ;;
     profchain)
       # the headline with every scan of the timed region chained and timed (one kernel at a time): the run whose rocprofv3 average
       # the per-launch `roofline.frac` of the default command (calibration pass) is compared with
@@ -261,57 +155,6 @@ PYEOF
           python "$R/bench.py" --gpus 1 --rows 1000000 --steps 40 --warmup 4 --no-cpu-baseline --no-secondary > "$OUT/pmc1m_bench.json" 2> "$OUT/pmc1m.err"); rc=$?
       python tools/pmc_summary.py "$OUT/prof_pmc1m" > "$OUT/pmc1m_summary.json" 2>> "$OUT/pmc1m.err"
       find "$OUT/prof_pmc1m" -name "*.csv" -size +2M -delete 2>/dev/null ;;
-    l2time)
-      timeout 300 python tools/batch_bench.py --metric 2 --nq 256 --reps 10 --onepass 0 1 0 1 > "$OUT/l2_onepass_ab.log" 2>&1; rc=$?
-      timeout 300 python tools/batch_bench.py --dims 1024 --nq 256 --reps 10 --onepass 0 1 0 1 > "$OUT/d1024_onepass_ab.log" 2>&1 ;;
-    gemmprobeprof)
-      (cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d "$OUT/prof_probe" -o p -- python "$R/tools/gemm_probe.py" > "$OUT/gemm_probe_prof.log" 2>&1); rc=$?
-      find "$OUT/prof_probe" -name "*kernel_trace.csv" -exec sh -c 'head -1 "$1" > "$2"; grep "gemm" "$1" >> "$2"' _ {} "$OUT/probe_gemm_trace.csv" \; 2>/dev/null
-      find "$OUT/prof_probe" -name "*kernel_trace.csv" -delete 2>/dev/null ;;
-    gemmprobe)
-      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d "$OUT/prof_probe" -o g -- \
-          python "$R/tools/gemm_probe.py" > "$OUT/gemm_probe.log" 2>&1); rc=$?
-      f=$(find "$OUT/prof_probe" -name "*kernel_trace.csv" | head -1)
-      [ -n "$f" ] && grep "rega_kernel" "$f" | python "$R/tools/trace_durations.py" > "$OUT/gemm_probe_durations.txt" 2>/dev/null
-      find "$OUT/prof_probe" -name "*kernel_trace.csv" -delete 2>/dev/null ;;
-    onepass)
-      timeout 600 python tools/batch_bench.py --nq 256 1024 --onepass 1 0 > "$OUT/onepass_bench.log" 2>&1; rc=$?
-      timeout 300 python tools/batch_bench.py --rows 1250000 --dims 768 --nq 1024 --reps 3 --onepass 1 0 > "$OUT/onepass768_bench.log" 2>&1 ;;
-    regaablate)
-      # ablation of the filtering GEMM (one-pass pipeline) by debug bits: 1 no corpus loads after the prologue, 2 no MFMA work,
-      # 4 no per-tile barrier (with 1), 8 no selection, 16 both waves of a SIMD in the same order. gemm_kernel_us is the number to read.
-      timeout 900 python tools/batch_bench.py --nq 256 --reps 4 --rega 1 2 --debug 0 8 9 10 11 15 16 > "$OUT/rega_ablate.log" 2>&1; rc=$?
-      timeout 600 python tools/batch_bench.py --nq 1024 --reps 3 --rega 1 --debug 0 8 9 10 11 > "$OUT/rega_ablate_q1024.log" 2>&1 ;;
-    pipetrace)
-      for timed in 1 0; do
-        (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/prof_pipe$timed" -o p -- \
-            python "$R/tools/pipeline_trace.py" --timed $timed > "$OUT/pipe_timed$timed.log" 2>&1)
-        f=$(find "$OUT/prof_pipe$timed" -name "*kernel_trace.csv" | head -1)
-        [ -n "$f" ] && python "$R/tools/trace_timeline.py" "$f" 36 > "$OUT/pipe_timeline_timed$timed.csv" 2>/dev/null
-        rm -rf "$OUT/prof_pipe$timed"
-      done
-      python tools/pipeline_trace.py --timed 0 > "$OUT/pipe_untimed_noprof.log" 2>&1
-      python tools/pipeline_trace.py --timed 1 > "$OUT/pipe_timed_noprof.log" 2>&1; rc=$? ;;
-    selablate)
-      # selection cost split (filtering GEMM, one-pass): debug 8 = no selection, 64 = hot test only, 0 = full; survivor targets 8 / 4 / 2
-      timeout 900 python tools/batch_bench.py --nq 256 1024 --reps 20 --rega 1 --debug 0 64 8 --survivors 8 > "$OUT/sel_ablate.log" 2>&1; rc=$?
-      timeout 600 python tools/batch_bench.py --nq 256 1024 --reps 20 --rega 1 --survivors 4 2 > "$OUT/sel_survivors.log" 2>&1
-      timeout 600 python tools/batch_bench.py --rows 1250000 --dims 768 --nq 1024 --reps 10 --debug 0 64 8 > "$OUT/sel_ablate768.log" 2>&1 ;;
-    w4)
-      timeout 600 python tools/batch_bench.py --nq 256 1024 --rega 1 3 1 3 > "$OUT/w4_bench.log" 2>&1; rc=$?
-      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_w4" -o w4 -- \
-          python "$R/tools/batch_bench.py" --nq 256 1024 --reps 3 --rega 3 > "$OUT/w4prof.log" 2>&1)
-      find "$OUT/prof_w4" -name "*kernel_stats.csv" -exec cp {} "$OUT/w4_kernel_stats.csv" \; 2>/dev/null
-      f=$(find "$OUT/prof_w4" -name "*kernel_trace.csv" | head -1)
-      [ -n "$f" ] && python "$R/tools/trace_tail.py" "$f" 40 > "$OUT/w4_trace_tail.csv" 2>/dev/null
-      find "$OUT/prof_w4" -name "*kernel_trace.csv" -delete 2>/dev/null ;;
-    w4ablate)
-      # ablation of batch_gemm_w4_kernel by debug bits (1 no DMA after the prologue, 2 no MFMA work, 4 no tile barrier, 8 no selection)
-      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d "$OUT/prof_w4a" -o w4a -- \
-          python "$R/tools/batch_bench.py" --nq ${WAX_NQ:-256} --reps 2 --rega 3 --debug ${WAX_DEBUGS:-0 8 1 9 2 3 4 12 0} > "$OUT/w4ablate.log" 2>&1); rc=$?
-      f=$(find "$OUT/prof_w4a" -name "*kernel_trace.csv" | head -1)
-      [ -n "$f" ] && python "$R/tools/trace_durations.py" "$f" w4_kernel > "$OUT/w4ablate_durations.txt" 2>/dev/null
-      find "$OUT/prof_w4a" -name "*kernel_trace.csv" -delete 2>/dev/null ;;
     onepassprof)
       (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_onepass" -o op -- \
           python "$R/tools/batch_bench.py" --nq ${WAX_NQ:-256} --reps 3 > "$OUT/onepassprof.log" 2>&1); rc=$?
