@@ -653,3 +653,45 @@ def test_ticket_path_equals_device_gather(wax, shards):
     [t.join() for t in ts]
     assert not errors, errors[:1]
     one.close(), many.close()
+
+
+def test_pace_gate_does_not_wait_for_workgroups_that_are_not_running(wax):
+    """The 768-d filtering GEMM's pace gate keeps the G query groups that want the same tile within a few tiles of each other
+    (L2 sharing). It must only ever wait for workgroups that are ON a CU: with several persistent GEMMs sharing one GPU — four shards
+    on device 0 here, two batches in flight in production — the G workgroups of a tile column start far apart, and the round-4
+    form (average over all G, 1 ms spin bound) made the early ones sleep through every check: 157 ms instead of 16 per batch in the
+    8-shard rehearsal of config 5 (profiles/r05/z_fanout_ABC.jsonl against g_pace_gate_running_workgroups_only.txt). Same answers
+    either way; this test is about the time."""
+    import time
+    import torch
+    dev = torch.device("cuda", 0)
+    dims, n, nq, shards = 768, 400_000, 1024, 4
+    g = torch.Generator(device=dev).manual_seed(3)
+    rows = torch.nn.functional.normalize(torch.randn((n, dims), device=dev, generator=g), dim=1).contiguous()
+    one = wax.HIPVectorEngine(dimensions=dims)
+    many = wax.HIPVectorEngine(dimensions=dims, devices=[0] * shards)
+    ids = np.arange(n, dtype=np.uint64)
+    for eng in (one, many):
+        eng.reserve(n)
+        eng.addBatchDevice(ids, rows)
+    assert [many.shardInfo(i)[2] for i in range(shards)] == [100_032] * 3 + [n - 3 * 100_032]
+    dq = torch.nn.functional.normalize(torch.randn((nq, dims), device=dev, generator=g), dim=1).contiguous()
+    st = torch.cuda.current_stream(dev).cuda_stream
+    outs = {}
+
+    def batch_ms(eng, tag):
+        out = torch.empty((nq, 10, 2), dtype=torch.int64, device=dev)
+        for _ in range(2):
+            eng.searchBatchHitsDevice(dq.data_ptr(), nq, 10, out.data_ptr(), 10, st)      # mirrors, warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            eng.searchBatchHitsDevice(dq.data_ptr(), nq, 10, out.data_ptr(), 10, st)
+        torch.cuda.synchronize()
+        outs[tag] = out.cpu().numpy()
+        return (time.perf_counter() - t0) / 5 * 1e3
+    a, b = batch_ms(one, "one"), batch_ms(many, "many")
+    print(f"\n[pace gate] one engine {a:.3f} ms per batch, four shards on one GPU {b:.3f} ms")
+    assert np.array_equal(outs["one"], outs["many"])
+    assert b < 3.0 * a + 1.0, (a, b)                            # (1.1 - 1.4 x measured; the round-4 gate: > 8 x)
+    one.close(), many.close()

@@ -707,25 +707,33 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
     // they sit on the same XCD (block -> XCD is blockIdx % 8 and G * blocks_per_group = 256), so the second to G-th reader hit in its
     // L2 as long as the groups stay within a few tiles of each other. Over a launch of milliseconds they do not (different survivor
     // loads): config 5 whole fetched 1.13 - 1.64 x the mirror (FETCH_SIZE, profiles/r04). Every GATE_EVERY tiles wave 0 adds its
-    // progress to a word shared by the G workgroups of its bidx and, if it is more than GATE_WINDOW tiles ahead of their average,
-    // sleeps until they catch up — the other seven waves wait for it at the tile barrier. Bounded and advisory: a timeout (a group
-    // that started late behind another kernel) just proceeds; a workgroup that leaves the loop credits the word so that nobody
-    // waits for it. ("batch_debug" bit 12 switches it off.)
+    // progress to a word shared by the G workgroups of its bidx and, if it is more than GATE_WINDOW tiles ahead of the average of
+    // those that are RUNNING, sleeps until they catch up — the other seven waves wait for it at the tile hand-over.
+    // The word is {workgroups running: bits 24+, sum of their progress: bits 0-23}: a workgroup enters itself when it starts and takes
+    // itself (and what it had added) out when it leaves, so nobody ever waits for a workgroup that is not on a CU — round 5: when
+    // several persistent GEMMs share the GPU (two batches in flight; eight shards on one device) the G workgroups of a bidx start far
+    // apart, and the round-4 form (average over all G, a 1 ms spin bound) made the early ones sleep through every check: the
+    // 8-shards-on-one-GPU rehearsal of config 5 took 157 ms instead of 16. Bounded (64 polls, ~70 us) and advisory: a timeout just
+    // proceeds. ("batch_debug" bit 12 switches the gate off.)
     constexpr uint32_t GATE_EVERY = 8u, GATE_WINDOW = 6u;
     const uint32_t ngroups = gridDim.x / blocks_per_group;
     const bool gate = !SAMPLE && a.progress != nullptr && ngroups > 1u && (blocks_per_group & 7u) == 0u && ngroups * blocks_per_group <= 256u && !(a.debug & 4096u);
-    const uint32_t* gate_word = gate ? a.progress + (bidx & 7u) * 32u + (bidx >> 3) : a.progress;   // one word per bidx, one 128-byte line per XCD
+    uint32_t* gate_word = gate ? a.progress + (bidx & 7u) * 32u + (bidx >> 3) : a.progress;   // one word per bidx, one 128-byte line per XCD
+    uint32_t gate_added = 0u;                                 // (wave 0) what this workgroup has added to the progress sum
+    if (gate && tid == 0) __hip_atomic_fetch_add(gate_word, 1u << 24, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // running
     auto pace = [&](uint32_t it) {
         if (gate && wave == 0 && (it & (GATE_EVERY - 1u)) == 0u && it > 0u) {
             // (returning atomics: the value comes from wherever agent-scope atomics execute, never from a stale cache line)
             unsigned int add = GATE_EVERY;
-            for (uint32_t spins = 0; spins < 1024u; ++spins) {
-                unsigned int total = 0u;
-                if (lane == 0) total = __hip_atomic_fetch_add(const_cast<uint32_t*>(gate_word), add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add;
-                total = (unsigned int)__builtin_amdgcn_readfirstlane((int)total);
+            gate_added += GATE_EVERY;
+            for (uint32_t spins = 0; spins < 64u; ++spins) {
+                unsigned int word = 0u;
+                if (lane == 0) word = __hip_atomic_fetch_add(gate_word, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add;
+                word = (unsigned int)__builtin_amdgcn_readfirstlane((int)word);
                 add = 0u;
-                // ahead of the average by more than the window?  G * it - total > G * WINDOW   (total counts tiles of all G groups)
-                if ((int)(ngroups * it - total) <= (int)(ngroups * GATE_WINDOW)) break;
+                const uint32_t running = word >> 24, sum = word & 0xFFFFFFu;
+                // ahead of the running workgroups' average by more than the window?  running * it - sum > running * WINDOW
+                if ((int)(running * it - sum) <= (int)(running * GATE_WINDOW)) break;
                 __builtin_amdgcn_s_sleep(32);
             }
         }
@@ -774,7 +782,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
         t += blocks_per_group;
     }
     if (late && it > 0) select_tile(t_prev);
-    if (gate && tid == 0) __hip_atomic_fetch_add(const_cast<uint32_t*>(gate_word), 1u << 24, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // done: nobody waits for this group
+    if (gate && tid == 0) __hip_atomic_fetch_add(gate_word, 0u - gate_added - (1u << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // leaving: out of the count and the sum
     if (SPLIT && gave_up && lane == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(sync_addr + 4u), "v"(1u) : "memory");
     if (!SAMPLE) {   // the wave's 32 survivor counters, SGPRs -> LDS: lane q takes query q's
         unsigned mine = 0u;
