@@ -445,7 +445,7 @@ __device__ inline void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N
 //  2. A DMA request is four VALU instructions, or one. The padded image is cut into 1-KB pieces; lane l of piece P fills slot
 //     64 P + l. Slot -> global offset is 16 (slot - slot / SLOTS_PER_ROW) from a wave-uniform tile base (saddr form), with no clamps:
 //     a pad slot fetches the first bytes of the next row, the slack behind the image the row after the tile, a tile that runs past
-//     the store whatever the mirror holds there — all inside the mirror's allocation (capacity + 64 slack rows) and never used
+//     the store whatever the mirror holds there — all inside the mirror's allocation (capacity + BATCH_MIRROR_SLACK_ROWS) and never used
 //     (rows >= slab_end are masked by the selection; a garbage row only pollutes its own output column). Where registers allow
 //     (D <= 512) the per-piece offsets stay in VGPRs. The round-4 form cost ~14 VALU + spilled-SGPR traffic per piece, 49 pieces per
 //     tile: -7 % at D = 768; with it the LDS-DMA kernel also overtook the register-staged one at D = 384.
@@ -481,6 +481,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
     constexpr int RING = AHEAD + 1;
     static_assert(!(SAMPLE && SPLIT), "the sampling launch keeps the workgroup barrier");
     static_assert(TROWS % 32 == 0 && RB >= 1 && RB <= 4, "tile = 1..4 MFMA row blocks");
+    static_assert(TROWS + 2 <= (int)BATCH_MIRROR_SLACK_ROWS, "the un-clamped requests of the last tile stay inside the mirror's slack rows");
     static_assert(D % 64 == 0 && (ROW_B / 4) % 64 == 4, "row stride must keep ds_read_b128 conflict-free");
     static_assert(NBUF >= 2, "one tile is read while the next lands");
     static_assert(NBUF * BUF_B + 2 * 8 * 32 * 4 + 64 <= 160 * 1024, "LDS budget of one CU");

@@ -931,9 +931,10 @@ int ensure_mirror(wax_hip_engine* e, hipStream_t st) {
         // took the exclusive lock after every reader had finished
         (void)hipFree(b.d_cb); (void)hipFree(b.d_vn2);
         b.d_cb = nullptr; b.d_vn2 = nullptr; b.mirror_cap = 0; b.mirror_valid = false;
-        // + slack rows: the one-wave-per-SIMD GEMM's last DMA piece of a tile reads a few rows past it (never used: masked)
-        HIP_TRY(hipMalloc(&b.d_cb, ((size_t)e->capacity + 64) * D * sizeof(unsigned short)), WAX_HIP_ERR_ALLOC, "Failed to allocate bf16 mirror");
-        HIP_TRY(hipMemsetAsync(b.d_cb + (size_t)e->capacity * D, 0, (size_t)64 * D * sizeof(unsigned short), st), WAX_HIP_ERR_INTERNAL, "mirror slack clear");
+        // + slack rows: the filtering GEMM requests whole tiles without clamps — its last tile may run up to (tile rows - 1) rows
+        // past the store, plus one row for the pad slots and the slack behind the tile image (never used: masked by the selection)
+        HIP_TRY(hipMalloc(&b.d_cb, ((size_t)e->capacity + BATCH_MIRROR_SLACK_ROWS) * D * sizeof(unsigned short)), WAX_HIP_ERR_ALLOC, "Failed to allocate bf16 mirror");
+        HIP_TRY(hipMemsetAsync(b.d_cb + (size_t)e->capacity * D, 0, (size_t)BATCH_MIRROR_SLACK_ROWS * D * sizeof(unsigned short), st), WAX_HIP_ERR_INTERNAL, "mirror slack clear");
         HIP_TRY(hipMalloc(&b.d_vn2, (size_t)e->capacity * sizeof(float)), WAX_HIP_ERR_ALLOC, "Failed to allocate row norms");
         b.mirror_cap = e->capacity;
     }

@@ -253,6 +253,7 @@ bool batch_onepass_dims(uint32_t dims, int metric);
 bool batch_onepass_fast(uint32_t dims, int metric);
 // rows per GEMM tile of the kernel that serves (dims, metric): 64, 32 for the K-split kernel, 128 for the LDS-tiled kernel
 uint32_t batch_tile_rows(uint32_t dims, int metric);
+constexpr uint32_t BATCH_MIRROR_SLACK_ROWS = 160;   // rows allocated behind the bf16 mirror: >= the largest GEMM tile (128 rows) + its over-reads
 constexpr uint32_t BATCH_GROUP_QUERIES = 256;   // queries per group of workgroups of the register-resident filtering GEMM
 bool batch_finish_fused_dims(uint32_t dims);
 // Queries f32 [nq][dims] in HBM -> bf16 block (cosine: normalised; rows [nq, nq_pad) zero), exact ||q|| as the
