@@ -64,7 +64,9 @@ def parse_args():
     p.add_argument("--topk", type=int, default=10)
     p.add_argument("--depth", type=int, default=4, help="queries in flight (software pipeline)")
     p.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
-    p.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
+    p.add_argument("--cpu-sample-rows", type=int, default=0,
+                   help="rows of the corpus the CPU baseline scans; 0 (default) = ALL rows when the host has the memory (3 x the store "
+                        "free), else the first 1M rows scaled")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
                    help="experiments: wax_hip_set_tuning(KEY, VALUE) on every engine the bench creates (repeatable)")
@@ -219,6 +221,24 @@ def usable_host_threads(omp_max):
     return max(1, n)
 
 
+def host_memory_free_bytes():
+    """What this process may still allocate on the host: MemAvailable, capped by the cgroup's memory.max minus its current use."""
+    free = 0
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                free = int(line.split()[1]) * 1024
+    except (OSError, ValueError):
+        return 0
+    try:
+        lim = open("/sys/fs/cgroup/memory.max").read().strip()
+        if lim != "max":
+            free = min(free, int(lim) - int(open("/sys/fs/cgroup/memory.current").read().strip()))
+    except (OSError, ValueError):
+        pass
+    return max(0, free)
+
+
 def cpu_baseline(torch, args, dev, queries):
     """The oracle's CPU scan (C restatement of the reference's arithmetic: a3 + a5) on a bounded sample of the same
     corpus, timed on this host as BASELINE.md §3 prescribes: (i) one thread, (ii) all host threads (static row
@@ -227,7 +247,9 @@ def cpu_baseline(torch, args, dev, queries):
     number; never the thing measured. Wax's actual CPU engine (USearch HNSW through Swift) cannot run here."""
     import oracle
     oracle.build()
-    n_s = min(args.cpu_sample_rows, args.rows)
+    n_s = min(args.cpu_sample_rows, args.rows) if args.cpu_sample_rows > 0 else min(1_000_000, args.rows)
+    if args.cpu_sample_rows <= 0 and host_memory_free_bytes() >= 3 * args.rows * args.dims * 4:
+        n_s = args.rows                      # the whole workload on the host: no scaling (10M x 384: 15.4 GB; ~100 queries in the budget)
     threads = usable_host_threads(oracle.max_threads())
     sample = oracle.numa_sample(n_s, args.dims, threads)
     for lo, x in device_rows(torch, 0, n_s, args.dims, dev):
@@ -247,21 +269,23 @@ def cpu_baseline(torch, args, dev, queries):
         return done, el
 
     variants = []
-    for nthreads, budget, cap in ((1, args.cpu_baseline_seconds / 3.0, 40), (threads, args.cpu_baseline_seconds, 4000)):
+    for nthreads, budget, cap in ((1, args.cpu_baseline_seconds / 3.0, 40), (threads, args.cpu_baseline_seconds, 4000)):   # (a query that overruns its budget still completes)
         done, el = timed(nthreads, budget, cap)
         qps_sample = done / el
         variants.append({
             "threads": nthreads, "value": qps_sample * n_s / args.rows, "unit": "queries/s",
             "sample_qps": qps_sample, "sample_gbps": n_s * args.dims * 4 * qps_sample / 1e9,
-            "sample": f"{done} queries over the first {n_s} rows in {el:.1f} s",
+            "sample": (f"{done} queries over all {n_s} rows in {el:.1f} s" if n_s == args.rows else
+                       f"{done} queries over the first {n_s} rows in {el:.1f} s"),
         })
     best = variants[-1]
     return {
         "value": best["value"], "unit": "queries/s", "cores": threads, "kind": "port",
-        "sample_short": f"{best['sample']}, x{n_s}/{args.rows} rows; {best['sample_gbps']:.0f} GB/s",
+        "sample_short": (f"{best['sample']}; {best['sample_gbps']:.0f} GB/s" if n_s == args.rows else
+                         f"{best['sample']}, x{n_s}/{args.rows} rows; {best['sample_gbps']:.0f} GB/s"),
         "sample": f"{best['sample']} of the same corpus on {threads} threads ({best['sample_qps']:.2f} q/s on the sample = "
-                  f"{best['sample_gbps']:.1f} GB/s), scaled by {n_s}/{args.rows} rows to the full workload; "
-                  f"metric-specialised FMA inner loop, NUMA first-touch by the scanning threads",
+                  f"{best['sample_gbps']:.1f} GB/s)" + ("" if n_s == args.rows else f", scaled by {n_s}/{args.rows} rows to the full workload")
+                  + "; metric-specialised FMA inner loop, NUMA first-touch by the scanning threads",
         "variants": variants,
     }
 
