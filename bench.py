@@ -622,18 +622,27 @@ def handle_single_query(torch, args, devs, rows, dims, k, steps, warmup, label):
     }
 
 
+SMALL_STORE_BYTES = 64 << 20     # = the library's "shard_min_mb" default: a store below it is not spread over GPUs
+
+
+def small_store(rows, dims, world):
+    """The small-store rule in the one-rank-per-GPU launch shape: below SMALL_STORE_BYTES the whole store lives on rank 0's GPU and
+    rank 0 answers alone (no exchange); the other ranks hold an empty engine and only meet the barriers. Sharding a 15 MB store over
+    N GPUs buys N launches and a collective per query for 2 MB of scan each (round-4 rehearsal: 7 882 q/s at 2 ranks against 94 843 at 1)."""
+    return world > 1 and rows * dims * 4 < SMALL_STORE_BYTES
+
+
 def sharded_single_query(torch, dist, args, rank, world, local_rank, use_rccl, rows, dims, k, steps, warmup, label):
     """The N-matrix points (N in {10K, 1M} x 384) at world > 1: the headline's sharded single-query path — every rank scans
     its row shard, per-shard top-k all-gathered (RCCL) and merged per query — at another corpus size. Same bracket as the
     headline (barrier + synchronize on both sides, max over ranks). Called by EVERY rank (collectives inside)."""
     from wax_amd import sharded
     dev = torch.device("cuda", torch.cuda.current_device())
-    lo, hi = sharded.shard_bounds(rows, world, rank, align=64)
+    solo = small_store(rows, dims, world)
+    lo, hi = ((0, rows) if rank == 0 else (0, 0)) if solo else sharded.shard_bounds(rows, world, rank, align=64)
     eng = _load_engine(torch, dev, max(hi - lo, 0), dims, lo=lo)
     eng.setRowBase(lo)
     apply_tunes(eng)
-    searcher = sharded.ShardedSearcher(eng, rank, world, k, depth=args.depth, n_streams=2, host_merge=args.host_merge,
-                                       exchange="rccl" if use_rccl else "host")
     queries = unit_queries(warmup + steps, dims)
 
     def barrier():
@@ -641,11 +650,20 @@ def sharded_single_query(torch, dist, args, rank, world, local_rank, use_rccl, r
         dist.barrier(device_ids=[local_rank]) if use_rccl else dist.barrier()
         torch.cuda.synchronize()
 
-    def submit(q):
-        searcher.submit(q)
+    if solo:
+        eng.setTuning("streams", 2)
+        eng.setTuning("slots", max(args.depth, 2))
+        elapsed, last, kern_ms, launches, cal = measure_single_query(eng, lambda q: eng.submit(q, k), lambda t: eng.collect(t, k), queries,
+                                                                     warmup, steps, args.depth, barrier)
+    else:
+        searcher = sharded.ShardedSearcher(eng, rank, world, k, depth=args.depth, n_streams=2, host_merge=args.host_merge,
+                                           exchange="rccl" if use_rccl else "host")
 
-    elapsed, last, kern_ms, launches, cal = measure_single_query(eng, submit, lambda _: searcher.collect(), queries, warmup, steps,
-                                                                 args.depth, barrier)
+        def submit(q):
+            searcher.submit(q)
+
+        elapsed, last, kern_ms, launches, cal = measure_single_query(eng, submit, lambda _: searcher.collect(), queries, warmup, steps,
+                                                                     args.depth, barrier)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev if use_rccl else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -653,12 +671,15 @@ def sharded_single_query(torch, dist, args, rank, world, local_rank, use_rccl, r
     checksum = hashlib.sha256(np.asarray(last[0], dtype=np.uint64).tobytes() + np.asarray(last[1], dtype=np.float32).tobytes()).hexdigest()[:16]
     grid = eng.getTuning("scan_grid")
     eng.close()
-    rf = scan_roofline((hi - lo) * dims * 4, kern_ms, launches, elapsed, steps, cal)
+    rf = scan_roofline(max(hi - lo, 1) * dims * 4, kern_ms, launches, elapsed, steps, cal)
     rf["scan_grid"] = grid
     return {
-        "config": f"{rows} x {dims} f32 cosine top-{k}, one query per step, row-sharded over {world} GPUs ({label})",
+        "config": (f"{rows} x {dims} f32 cosine top-{k}, one query per step, {world} ranks, the store on rank 0's GPU alone "
+                   f"(small-store rule: below {SMALL_STORE_BYTES >> 20} MB nothing is sharded, no exchange) ({label})" if solo else
+                   f"{rows} x {dims} f32 cosine top-{k}, one query per step, row-sharded over {world} GPUs ({label})"),
         "value": steps / elapsed, "unit": "queries/s", "n_gpus": world, "steps": steps, "warmup": warmup,
-        "ms_per_step": elapsed / steps * 1e3, "dtype": "f32", "rows_per_gpu": hi - lo, "last_result_checksum": checksum,
+        "ms_per_step": elapsed / steps * 1e3, "dtype": "f32", "rows_per_gpu": ([rows] + [0] * (world - 1)) if solo else hi - lo,
+        "last_result_checksum": checksum, "exchange": "none (small-store rule)" if solo else ("rccl" if use_rccl else "host"),
         "roofline": rf,
     }
 
@@ -1066,6 +1087,9 @@ def main():
     global TRAFFIC_MODE
     TRAFFIC_MODE = args.traffic if (world == 1 and not in_library) else ("replay" if args.traffic in ("auto", "replay") else "off")
     lo, hi = sharded.shard_bounds(n, world, rank, align=64)
+    solo = (not in_library) and small_store(n, dims, world)   # one rank per GPU, a store too small to shard: rank 0 holds and answers it
+    if solo:
+        lo, hi = (0, n) if rank == 0 else (0, 0)
     t_build = time.perf_counter()
     if in_library:
         same = bool(os.environ.get("WAX_BENCH_SAME_DEVICE"))          # testing only: every shard on GPU 0
@@ -1076,7 +1100,7 @@ def main():
     else:
         eng = HIPVectorEngine(metric=VectorMetric.cosine, dimensions=dims)
         eng.reserve(max(hi - lo, 1))
-        for r0, x in device_rows(torch, lo, hi, dims, dev):
+        for r0, x in (device_rows(torch, lo, hi, dims, dev) if hi > lo else ()):
             eng.addBatchDevice(np.arange(r0, r0 + x.shape[0], dtype=np.uint64), x)
         eng.setRowBase(lo)
     torch.cuda.synchronize()
@@ -1097,7 +1121,7 @@ def main():
         handle_exchange(eng, args, args.gpus)   # --exchange rccl: one ncclAllGather per query on the library's communicator, N ranks or no run
     elif world > 1 and use_rccl and dist.get_world_size() != world:
         raise SystemExit(f"[bench] --exchange rccl: the process group has {dist.get_world_size()} ranks, expected {world}")
-    if world == 1:
+    if world == 1 or solo:
         # two in-order streams: one query's merge / result write / next query upload hide under the neighbouring scan,
         # and (product mode) neighbouring scans overlap each other's ramp and tail
         eng.setTuning("streams", 2)
@@ -1121,7 +1145,8 @@ def main():
             return searcher.collect()
 
     ids, scores = collect(submit(probe))
-    assert int(ids[0]) == probe_row and abs(float(scores[0]) - 1.0) < 1e-5, (ids[:3], scores[:3])
+    if not (solo and rank != 0):
+        assert int(ids[0]) == probe_row and abs(float(scores[0]) - 1.0) < 1e-5, (ids[:3], scores[:3])
 
     def barrier():
         torch.cuda.synchronize()
@@ -1144,7 +1169,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if use_rccl else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert len(last[0]) == min(k, n)
+    assert len(last[0]) == (min(k, n) if not (solo and rank != 0) else 0)
     import hashlib
     checksum = hashlib.sha256(np.asarray(last[0], dtype=np.uint64).tobytes()
                               + np.asarray(last[1], dtype=np.float32).tobytes()).hexdigest()[:16]
@@ -1198,22 +1223,25 @@ def main():
                 "workload": f"{n} x {dims}-dim f32 unit-norm Gaussian corpus (seed {CORPUS_SEED}), cosine top-{k}, "
                             f"one query per step, corpus resident in HBM and row-sharded over {n_gpus} GPU(s)",
                 "workload_short": f"{_human_rows(n)} x {dims} f32 unit-Gaussian corpus in HBM, cosine top-{k}, 1 query/step",
-                "rows": n, "dims": dims, "top_k": k, "rows_per_gpu": (shard_rows if in_library else hi - lo),
+                "rows": n, "dims": dims, "top_k": k, "rows_per_gpu": (shard_rows if in_library else ([n] + [0] * (world - 1)) if solo else hi - lo),
                 # how many ranks the collective library actually joined (torchrun shape: dist world size after the all_reduce
                 # probe; one-process shape: the library's ncclCommCount when its RCCL exchange is on, else 1 = peer copies)
                 "rccl_ranks": rccl_ranks, "shards": n_gpus,
                 "parallelism_short": (f"row-shard x{n_gpus} one-process " + ("rccl" if exchange_mode == 1 else "tickets+host-merge")) if in_library
-                                     else (f"row-shard x{world}" + ((" rccl all_gather" if use_rccl else " gloo all_gather") if world > 1 else "")),
+                                     else (f"x{world} ranks, store on rank 0 (small-store rule)" if solo else
+                                           f"row-shard x{world}" + ((" rccl all_gather" if use_rccl else " gloo all_gather") if world > 1 else "")),
                 "parallelism": (f"row-shard x{args.gpus}, ONE process: the library's multi-GPU engine (wax_hip_engine_create_sharded), "
                                 + ("single-process RCCL all-gather of per-shard top-k + merge on the first device" if exchange_mode == 1 else
                                    "per-shard tickets submitted side by side (one launch per shard, hits straight to pinned memory) + host merge by key")) if in_library else
-                               (f"row-shard x{world}" + ((" + RCCL all-gather of per-shard top-k" if use_rccl else
+                               (f"{world} ranks, the whole store on rank 0's GPU (small-store rule: below {SMALL_STORE_BYTES >> 20} MB nothing is sharded; "
+                                f"no exchange)" if solo else
+                                f"row-shard x{world}" + ((" + RCCL all-gather of per-shard top-k" if use_rccl else
                                                           " + host (gloo) all-gather of per-shard top-k") if world > 1 else "")),
                 "pipeline_depth": args.depth,
                 "timed_region": "kernels timed and chained inside it (--chain-timed-region)" if args.chain_timed_region else
                                 "product mode: scans of neighbouring queries overlap; per-launch times from the calibration pass",
                 "merge": "host" if (world > 1 and (args.host_merge or not use_rccl)) else "device",
-                "exchange": ("in-library" if in_library else (("rccl all_gather" if use_rccl else "host (gloo)") if world > 1 else "none")),
+                "exchange": ("in-library" if in_library else "none (small-store rule)" if solo else (("rccl all_gather" if use_rccl else "host (gloo)") if world > 1 else "none")),
                 "last_result_checksum": checksum,
             },
             "roofline": scan_roofline(bytes_per_launch, kern_ms, launches, elapsed, args.steps, cal, traffic, traffic_source),

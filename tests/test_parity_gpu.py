@@ -904,9 +904,13 @@ def test_bench_contract_and_shard_invariance(wax, tmp_path):
         assert [x["name"] for x in c5] == ["s1m", "s10k", "c5"] and all("error" not in x for x in c5), c5
         for x, ref in ((c5[0], sec[1]), (c5[1], sec[0])):
             assert x["n_gpus"] == run["n_gpus"] and x["value"] > 0 and x["last_result_checksum"] == ref["last_result_checksum"], (x, ref)
+        # 15 MB are never sharded, in either shape (small-store rule): the store sits on the first GPU, which answers alone
+        assert c5[1]["rows_per_gpu"] == [10000] + [0] * (run["n_gpus"] - 1), c5[1]
+        if shape == "ranks":
+            assert c5[1]["exchange"] == "none (small-store rule)" and isinstance(c5[0]["rows_per_gpu"], int)
         if shape == "handle":
             assert c5[0]["rows_per_gpu"] == [333376, 333376, 333248] and c5[0]["ticket_searches"] > 0, c5[0]       # 1M rows: spread
-            assert c5[1]["rows_per_gpu"] == [10000, 0, 0] and c5[1]["single_shard_searches"] > 0, c5[1]             # 15 MB: one device
+            assert c5[1]["single_shard_searches"] > 0, c5[1]
             assert [e_["name"] for e_ in run["_line"]["secondary"]] == ["s1m", "s10k", "c5"]
             assert run["_line"]["secondary"][1]["rows_per_gpu"] == [10000, 0, 0]
             assert run["config"]["rows_per_gpu"] == [100032, 100032, 99936]
