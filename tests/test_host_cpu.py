@@ -479,8 +479,8 @@ def test_bench_reads_fetch_size_per_launch_from_a_counter_pass(tmp_path):
     assert sum(got) / len(got) * 2048 == (7500000 + 17.5) * 2048
     rows = []
     for i in range(5):
-        rows.append(f'{i},{2 * i},1,"void wax::batch_gemm_rega_kernel<384, false, 3, true, false, 0>(wax::GemmArgs, unsigned int)",FETCH_SIZE,{9000 + i}\n')
-        rows.append(f'{i},{2 * i + 1},1,"void wax::batch_gemm_rega_kernel<384, false, 3, false, false, 2>(wax::GemmArgs, unsigned int)",FETCH_SIZE,{375000 + i}\n')
+        rows.append(f'{i},{2 * i},1,"void wax::batch_gemm_rq_kernel<384, 64, 2, 3, true, false, false>(wax::GemmArgs, unsigned int)",FETCH_SIZE,{9000 + i}\n')
+        rows.append(f'{i},{2 * i + 1},1,"void wax::batch_gemm_rq_kernel<384, 64, 2, 3, false, true, true>(wax::GemmArgs, unsigned int)",FETCH_SIZE,{375000 + i}\n')
     (d / "t_counter_collection.csv").write_text(head + "".join(rows))
     assert bench.fetch_size_per_launch(str(tmp_path), True) == [375002.0, 375003.0, 375004.0]
     assert bench.fetch_size_per_launch(str(tmp_path), False) == []     # no scan kernel in a batched pass
