@@ -718,7 +718,11 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
     // proceeds. ("batch_debug" bit 12 switches the gate off.)
     constexpr uint32_t GATE_EVERY = 8u, GATE_WINDOW = 6u;
     const uint32_t ngroups = gridDim.x / blocks_per_group;
-    const bool gate = !SAMPLE && a.progress != nullptr && ngroups > 1u && (blocks_per_group & 7u) == 0u && ngroups * blocks_per_group <= 256u && !(a.debug & 4096u);
+    // (launches of up to GATE_MIN_TILES tiles per workgroup — ~3 ms — do not drift far enough to lose the sharing: 1.25M x 768 reads
+    // 1.01 x the mirror with or without the gate, and the gate's returning atomics cost 1.5 % there)
+    constexpr uint32_t GATE_MIN_TILES = 1024u;
+    const bool gate = !SAMPLE && a.progress != nullptr && ngroups > 1u && (blocks_per_group & 7u) == 0u && ngroups * blocks_per_group <= 256u &&
+                      ntiles > GATE_MIN_TILES * blocks_per_group && !(a.debug & 4096u);
     uint32_t* gate_word = gate ? a.progress + (bidx & 7u) * 32u + (bidx >> 3) : a.progress;   // one word per bidx, one 128-byte line per XCD
     uint32_t gate_added = 0u;                                 // (wave 0) what this workgroup has added to the progress sum
     if (gate && tid == 0) __hip_atomic_fetch_add(gate_word, 1u << 24, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // running
