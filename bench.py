@@ -80,6 +80,9 @@ def parse_args():
     p.add_argument("--traffic", choices=["auto", "live", "replay", "off"], default="auto",
                    help="roofline.traffic of the headline kernel: live = a rocprofv3 --pmc FETCH_SIZE child pass inside this run (N = 1); "
                         "replay = the committed pass in profiles/latest_traffic.json; auto = live where rocprofv3 is on PATH, else replay")
+    p.add_argument("--events", choices=["bound", "bracket"], default="bound",
+                   help="per-launch kernel times: bound = HIP events bound to the dispatch (hipExtLaunchKernel; the kernel's own begin -> end, "
+                        "default, with the bracketed figure beside it), bracket = hipEventRecord in front of and behind the launch only")
     p.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     p.add_argument("--traffic-child-batch", default=None, help=argparse.SUPPRESS)   # "nq:corpus:row_base": the batched form of the child
     p.add_argument("--detail-out", default=None, metavar="PATH",
@@ -325,25 +328,53 @@ def measure_single_query(eng, submit, collect, queries, warmup, steps, depth, ba
         kern_ms = st.scan_kernel_ms_total / launches if launches else float("nan")
         return elapsed, last, kern_ms, launches, {"steps": steps, "ms_per_step": elapsed / steps * 1e3,
                                                   "mode": "the timed region itself (--chain-timed-region: kernels timed and chained inside it)"}
-    # calibration: the same queries again with every scan bracketed by HIP events on its own stream and chained through an
-    # event, so that a launch runs alone and its interval is one kernel (what rocprofv3's per-dispatch duration measures)
+    # calibration: the same queries again with HIP events on every scan launch, on the stream the kernel runs on, scans chained
+    # through an event so that a launch runs alone. Two passes:
+    #   "time_kernels" = 1 (bracketed): hipEventRecord in front of and behind the launch — the interval holds the kernel AND the
+    #       packets around it (the two markers, the chain wait, the dispatch latency: ~10 us whatever the kernel's length);
+    #   "time_kernels" = 2 (kernel-bound, the figure `frac` uses): hipExtLaunchKernel binds the event pair to the dispatch itself —
+    #       the kernel's own begin -> end, i.e. what rocprofv3 --kernel-trace reports for the same dispatch (profiles/).
+    # A kernel-bound mean that is not plausible next to the bracketed one (runtime without the binding) falls back to the bracket.
     n_cal = min(steps, CALIBRATION_STEPS)
-    eng.setTuning("time_kernels", 1)
-    run_pipelined(submit, collect, queries[warmup:warmup + min(4, n_cal)], depth)
-    eng.setTuning("reset_stats", 1)
-    barrier()
-    t1 = time.perf_counter()
-    run_pipelined(submit, collect, queries[warmup:warmup + n_cal], depth)
-    barrier()
-    cal_el = time.perf_counter() - t1
-    st = eng.stats()
-    launches = int(st.scan_kernels_timed)
-    kern_ms = st.scan_kernel_ms_total / launches if launches else float("nan")
+
+    def cal_pass(mode):
+        eng.setTuning("time_kernels", mode)
+        run_pipelined(submit, collect, queries[warmup:warmup + min(4, n_cal)], depth)
+        eng.setTuning("reset_stats", 1)
+        barrier()
+        t1 = time.perf_counter()
+        run_pipelined(submit, collect, queries[warmup:warmup + n_cal], depth)
+        barrier()
+        el = time.perf_counter() - t1
+        st = eng.stats()
+        n_ = int(st.scan_kernels_timed)
+        return (st.scan_kernel_ms_total / n_ if n_ else float("nan")), n_, el
+
+    br_ms, br_n, br_el = cal_pass(1)
+    kern_ms, launches, cal_el, events = br_ms, br_n, br_el, "bracketed"
+    kb_ms = None
+    if EVENT_MODE == "bound":
+        kb_ms, kb_n, kb_el = cal_pass(2)
+        if kb_n and br_n and kernel_bound_plausible(kb_ms, br_ms):
+            kern_ms, launches, cal_el, events = kb_ms, kb_n, kb_el, "kernel-bound"
     eng.setTuning("time_kernels", 0)
     return elapsed, last, kern_ms, launches, {
-        "steps": n_cal, "ms_per_step": cal_el / n_cal * 1e3,
-        "mode": "same run, same engine, the first queries of the timed region again; \"time_kernels\" = 1: HIP events around "
-                "every scan launch on its own stream, scans chained (never two at once)"}
+        "steps": n_cal, "ms_per_step": cal_el / n_cal * 1e3, "events": events,
+        "kernel_avg_ms_bracketed": br_ms, "kernel_avg_ms_kernel_bound": kb_ms,
+        "mode": "same run, same engine, the first queries of the timed region again, scans chained (never two at once), HIP events on "
+                "the scan's own stream: " + ("bound to the scan's dispatch (hipExtLaunchKernel start / stop: the kernel's own begin -> end, "
+                                             "what rocprofv3 reports per dispatch); the bracketed mean (hipEventRecord around the launch: "
+                                             "kernel + marker / chain / dispatch packets) is kernel_avg_ms_bracketed"
+                                             if events == "kernel-bound" else "recorded in front of and behind the launch (\"time_kernels\" = 1)")}
+
+
+EVENT_MODE = "bound"     # --events: "bound" (default) = frac from kernel-bound HIP events, "bracket" = rounds 1-4's hipEventRecord bracket
+
+
+def kernel_bound_plausible(kb_ms, br_ms):
+    """A kernel-bound interval is the bracketed one minus the packets around the kernel: never longer than it (2 % of jitter allowed),
+    and not shorter by more than 40 us + 10 % (the packets cost ~10 us). Anything else is a runtime that did not bind the pair."""
+    return kb_ms == kb_ms and br_ms == br_ms and kb_ms > 0 and kb_ms <= br_ms * 1.02 + 0.002 and kb_ms >= br_ms * 0.9 - 0.04
 
 
 TRAFFIC_CHILD_WARM, TRAFFIC_CHILD_LAUNCHES = 2, 6
@@ -795,7 +826,9 @@ def secondary_batched(torch, dev, rows, dims, nq, k, steps, warmup, label, row_b
     blocking_ms = (time.perf_counter() - tb) / nblk * 1e3
     fb0, rt0, mp0 = eng.getTuning("batch_fallbacks"), eng.getTuning("batch_retries"), eng.getTuning("batch_multi_passes")
     ir0 = eng.getTuning("batch_inline_retries")
-    eng.setTuning("time_kernels", 1)
+    # the filtering GEMMs are timed INSIDE the timed region (and chained, so that an interval is one GEMM): kernel-bound HIP events
+    # ("time_kernels" = 2, see measure_single_query) or the hipEventRecord bracket (--events bracket)
+    eng.setTuning("time_kernels", 2 if EVENT_MODE == "bound" else 1)
     apply_tunes(eng)
     eng.setTuning("reset_stats", 1)
     _bracket(torch)
@@ -806,7 +839,20 @@ def secondary_batched(torch, dev, rows, dims, nq, k, steps, warmup, label, row_b
     st = eng.stats()
     launches = int(st.batch_gemms_timed)
     kern_ms = st.batch_gemm_ms_total / launches if launches else float("nan")
+    events, br_ms = ("kernel-bound" if EVENT_MODE == "bound" else "bracketed"), None
+    if EVENT_MODE == "bound":
+        # the bracketed figure beside it, from a short pass of its own (untimed): hipEventRecord around the same launches
+        eng.setTuning("time_kernels", 1)
+        eng.setTuning("reset_stats", 1)
+        run(max(4, min(steps, 20)))
+        _bracket(torch)
+        st1 = eng.stats()
+        n1 = int(st1.batch_gemms_timed)
+        br_ms = st1.batch_gemm_ms_total / n1 if n1 else float("nan")
+        if not (launches and n1 and kernel_bound_plausible(kern_ms, br_ms)):
+            kern_ms, launches, events = br_ms, n1, "bracketed"
     flops, floor_s, rf = batched_roofline(rows, dims, nq, kern_ms, launches, int(eng.getTuning("batch_rega")))
+    rf["events"], rf["kernel_avg_ms_bracketed"] = events, br_ms
     want_live = True                          # roofline.traffic of the filtering GEMM is measured below (child counter pass)
     res = {
         "config": label,
@@ -978,6 +1024,10 @@ def compact_line(full):
         r = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "pipeline_frac", "kernel_avg_ms", "kernel_launches_timed",
                        "algorithmic_bytes_per_launch", "traffic"))
         r["kernel"] = str(rf.get("kernel", "")).split(" ")[0]
+        cal = rf.get("calibration") or {}
+        if cal.get("events"):
+            r["events"] = cal["events"]                  # "kernel-bound" (hipExtLaunchKernel pair) or "bracketed" (hipEventRecord around the launch)
+            r["kernel_avg_ms_bracketed"] = _r(cal.get("kernel_avg_ms_bracketed"))
         if rf.get("traffic") is not None:
             r["traffic_from"] = "live-pmc" if str(rf.get("traffic_source", "")).startswith("measured in this run") else "replayed-pmc"
         line["roofline"] = r
@@ -1000,6 +1050,9 @@ def compact_line(full):
         xr = x.get("roofline") or {}
         e["frac"] = _r(xr.get("frac"), 4)
         e["kernel_avg_ms"] = _r(xr.get("kernel_avg_ms"), 4)
+        br = (xr.get("calibration") or {}).get("kernel_avg_ms_bracketed") if "calibration" in xr else xr.get("kernel_avg_ms_bracketed")
+        if br is not None:
+            e["bracketed_ms"] = _r(br, 4)                # the same launches under hipEventRecord brackets (kernel + packets around it)
         e["ck"] = x.get("last_result_checksum")          # equal at every N / launch shape for the same workload
         if x.get("n_gpus", 1) != 1:
             e["n_gpus"] = x["n_gpus"]
@@ -1037,9 +1090,52 @@ def emit(full, detail_out=None):
     print(text, flush=True)
 
 
+import threading as _threading
+
+_EMIT_ONCE = {"lock": _threading.Lock(), "done": False}
+
+
+def emit_once(full, detail_out=None):
+    """emit(), at most once per process: the main thread and the secondaries' watchdog may both get here."""
+    with _EMIT_ONCE["lock"]:
+        if _EMIT_ONCE["done"]:
+            return
+        _EMIT_ONCE["done"] = True
+        emit(full, detail_out)
+
+
+SECONDARY_LIMIT_S = float(os.environ.get("WAX_BENCH_SECONDARY_LIMIT_S", "600"))
+
+
+def arm_secondary_watchdog(out, args, rank, limit_s=None):
+    """The headline is measured before the secondaries and printed after them (ONE line): a secondary that never returns — at N > 1 a
+    collective one rank never joins, code that has only ever run on one physical GPU — would lose it. After `limit_s` seconds in the
+    secondaries rank 0 prints the line with what has finished (plus an entry that says so) and every rank leaves (exit code 0, the
+    other ranks a few seconds behind rank 0 so that its line is out first). Cancelled when the secondaries return."""
+    import threading
+    limit_s = SECONDARY_LIMIT_S if limit_s is None else limit_s
+
+    def fire():
+        try:
+            if rank == 0 and out is not None:
+                out.setdefault("secondary", []).append(
+                    {"name": "watchdog", "error": f"secondaries still running after {limit_s:.0f} s: line emitted without the rest"})
+                emit_once(out, args.detail_out)
+                sys.stdout.flush()
+        finally:
+            os._exit(0)
+
+    t = threading.Timer(limit_s + (0.0 if rank == 0 else 5.0), fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
 def main():
     args = parse_args()
     TUNES.extend(args.tune)
+    global EVENT_MODE
+    EVENT_MODE = args.events
     # RCCL / CUDA-tensor IPC on this driver stack needs dmabuf IPC (the image exports it; keep it if launched bare)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
@@ -1258,6 +1354,9 @@ def main():
         gc.collect()
         gc.disable()
         sec = []
+        if out is not None:
+            out["secondary"] = sec
+        watchdog = arm_secondary_watchdog(out, args, rank)
         if world == 1 and not in_library:
             s, w = args.steps, args.warmup
             table = {
@@ -1349,10 +1448,9 @@ def main():
                     sec.append(r)
                 except Exception as ex:  # noqa: BLE001
                     sec.append({"name": "c5", "error": f"{type(ex).__name__}: {ex}"})
-        if out is not None:
-            out["secondary"] = sec
+        watchdog.cancel()
     if rank == 0:
-        emit(out, args.detail_out)
+        emit_once(out, args.detail_out)
     if world > 1:
         if use_rccl:
             dist.barrier(device_ids=[local_rank])

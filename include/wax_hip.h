@@ -322,16 +322,18 @@ int wax_hip_stats(wax_hip_engine* e, wax_hip_stats_t* out);
  * single-query scan
  *   "grid_blocks" (0 = auto), "variant" (scan kernel variant index, -1 = auto), "stream_nt", "force_general" (1 = the distance-buffer +
  *   radix-select path even for small k), "slots" (scratch-slot pool size), "streams" (1..4 in-order streams the slots rotate over),
- *   "time_kernels" (1 = bracket the kernels with HIP events on their own stream: wax_hip_stats), "reset_stats" (any value: zero the counters),
+ *   "time_kernels" (wax_hip_stats' kernel times: 1 = HIP events recorded in front of and behind the scan / filtering-GEMM launch on its own
+ *   stream — the interval holds the kernel and the packets around it; 2 = the event pair bound to the dispatch itself (hipExtLaunchKernel):
+ *   the kernel's own begin -> end, the figure rocprofv3 reports per dispatch), "reset_stats" (any value: zero the counters),
  *   "fuse_merge" (1 (default) = on grids of at most 160 workgroups the scan kernel's last-arriving workgroup does the final merge),
  *   "merge_kway" (1 (default) = top_k <= 64: that workgroup merges the per-workgroup lists by their heads, which lets every default
  *   grid of a store of up to 2 GiB of rows finish in ONE launch; 0 = the round-3 rule),
  *   "query_args" (dims 384 / 768: 1 (default) = a scan that merges in its own kernel takes the query in its kernel arguments; 2 = every
  *   store; 0 = never), "scan_plain_mb" (such scans read stores of at most this many MB with ordinary instead of non-temporal loads, default 32),
  *   "done_flag" (1 (default) = such a scan publishes a completion word in coherent pinned memory behind its hits and collect polls it
- *   instead of an event; never while "time_kernels" = 1),
+ *   instead of an event; never while "time_kernels" != 0),
  *   "scan_chain" (pipelined scans of different streams: 1 = chained through an event so that a per-launch duration is one scan alone;
- *   0 = free to overlap; -1 (default) = chained exactly while "time_kernels" = 1), "share_timing" (1 = a chained scan reuses its
+ *   0 = free to overlap; -1 (default) = chained exactly while "time_kernels" != 0), "share_timing" (1 = a chained scan reuses its
  *   predecessor's end event as its start event),
  *   "filter_device_min" (wax_hip_search_filtered: allow-lists at least this long are resolved by the id -> row table in HBM, default 4096; -1 = never).
  * batched queries (bf16 MFMA GEMM + fused selection + exact re-score; exact answers whatever the setting)

@@ -396,6 +396,61 @@ def test_bench_line_stays_inside_the_drivers_stdout_tail(tmp_path, capsys):
     assert len(out) < 4096 and "secondary_dropped" in j and j["roofline"]["frac"] and j["cpu_baseline"]["cores"] == 16
 
 
+def test_bench_line_carries_the_event_mode_and_the_bracketed_figure():
+    """Round 5: `frac` is priced with kernel-bound HIP events (hipExtLaunchKernel pair = the dispatch's own begin -> end); the line says
+    which events it used and carries the bracketed mean (hipEventRecord around the launch) beside it; the plausibility rule that
+    guards the switch refuses a pair the runtime did not bind."""
+    import json
+    bench = _load_bench()
+    full = _synthetic_full_record(bench, n_secondary=11)
+    full["roofline"] = dict(full["roofline"], calibration={"steps": 60, "events": "kernel-bound", "kernel_avg_ms_bracketed": 2.2112345678,
+                                                           "kernel_avg_ms_kernel_bound": 2.1987654321})
+    full["secondary"][0]["roofline"] = dict(full["secondary"][0]["roofline"], calibration={"events": "kernel-bound", "kernel_avg_ms_bracketed": 0.2959})
+    r1 = {k: v for k, v in full["secondary"][1]["roofline"].items() if k != "calibration"}
+    full["secondary"][1]["roofline"] = dict(r1, events="kernel-bound", kernel_avg_ms_bracketed=0.20412345)
+    line = bench.compact_line(full)
+    assert len(json.dumps(line, separators=(",", ":"))) < bench.LINE_BUDGET
+    assert line["roofline"]["events"] == "kernel-bound" and line["roofline"]["kernel_avg_ms_bracketed"] == 2.21123
+    assert line["secondary"][0]["bracketed_ms"] == 0.2959 and line["secondary"][1]["bracketed_ms"] == 0.2041
+    assert "bracketed_ms" not in line["secondary"][2]
+    ok = bench.kernel_bound_plausible
+    assert ok(2.1744, 2.1874) and ok(0.284, 0.2959) and ok(0.0160, 0.0268) and ok(0.186, 0.194)
+    assert not ok(0.0, 0.2959) and not ok(float("nan"), 0.2959) and not ok(0.31, 0.2959) and not ok(0.1, 0.2959) and not ok(1.9, 2.1874)
+
+
+def test_bench_secondary_watchdog_emits_the_headline_and_leaves(tmp_path):
+    """A secondary that never returns (at N > 1: a collective one rank never joins) must not lose the headline: after the limit rank 0
+    prints the ONE line with what has finished and an entry that says so, and the process exits with code 0; the other ranks only leave."""
+    import json
+    import subprocess
+    import sys
+    import time
+    prog = (
+        "import sys, time, types; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from test_host_cpu import _load_bench, _synthetic_full_record\n"
+        "bench = _load_bench()\n"
+        "rank = int(sys.argv[1])\n"
+        "out = _synthetic_full_record(bench, n_secondary=2) if rank == 0 else None\n"
+        "args = types.SimpleNamespace(detail_out=%r)\n"
+        "bench.arm_secondary_watchdog(out, args, rank, limit_s=0.3)\n"
+        "time.sleep(60)\n"
+        "print('never')\n") % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "d.json"))
+    t0 = time.time()
+    r0 = subprocess.run([sys.executable, "-c", prog, "0"], capture_output=True, text=True, timeout=50)
+    assert r0.returncode == 0 and time.time() - t0 < 40, (r0.returncode, r0.stderr[-400:])
+    lines = [l for l in r0.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and "never" not in r0.stdout
+    j = json.loads(lines[0])
+    assert j["value"] == 460.412 and j["secondary"][-1]["name"] == "watchdog" and "still running" in j["secondary"][-1]["error"]
+    r1 = subprocess.run([sys.executable, "-c", prog, "1"], capture_output=True, text=True, timeout=50)
+    assert r1.returncode == 0 and r1.stdout.strip() == ""
+    # a watchdog that is cancelled does nothing, and emit_once prints once
+    bench = _load_bench()
+    w = bench.arm_secondary_watchdog(None, None, 1, limit_s=0.2)
+    w.cancel()
+    time.sleep(0.4)
+
+
 def _bf16_rne(x):
     """f32 -> bf16 (round to nearest even) -> f32, as f32_to_bf16_rne in common.h does it."""
     u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)

@@ -2241,3 +2241,57 @@ def test_certificate_bound_survives_aligned_rounding_errors(wax):
     assert 3.5e6 < eng.getTuning("batch_max_row_err_e9") < 4.0e6
     eng.close()
 
+
+
+def test_kernel_bound_timing_equals_bracketed_answers_and_is_not_longer(wax):
+    """"time_kernels" = 2 binds the HIP event pair to the kernel's dispatch (hipExtLaunchKernel) instead of recording it in front of
+    and behind the launch ("time_kernels" = 1). Same hits under both (single-query scans that merge in the kernel, the two-launch
+    merge, the general selection, a batch through the filtering GEMM); every timed launch is counted; the kernel-bound mean is the
+    bracketed one minus the packets around the kernel — positive, never longer (bench.kernel_bound_plausible is the rule bench.py
+    applies before it prices the roofline with it)."""
+    import bench
+    dims, n = 384, 200_000
+    corpus = oracle.gaussian_unit_rows(11, n, dims)
+    eng = make_engine(wax, 0, dims, corpus, np.arange(n, dtype=np.uint64) + 3)
+    queries = oracle.gaussian_unit_queries(24, dims, seed=5)
+    ref = {k: [eng.searchArrays(q, k) for q in queries] for k in (10, 100, 500)}
+    eng.setTuning("streams", 2)
+    eng.setTuning("slots", 4)
+    means = {}
+    for mode in (1, 2):
+        eng.setTuning("time_kernels", mode)
+        for k in (10, 100, 500):
+            pend = [eng.submit(q, k) for q in queries[:4]]
+            got = [eng.collect(t, k) for t in pend] + [eng.searchArrays(q, k) for q in queries[4:]]
+            for i in range(len(queries)):
+                assert np.array_equal(got[i][0], ref[k][i][0]) and np.array_equal(got[i][1], ref[k][i][1]), (mode, k, i)
+        eng.setTuning("fuse_merge", 0)
+        c = eng.searchArrays(queries[0], 10)
+        assert np.array_equal(c[0], ref[10][0][0])
+        eng.setTuning("fuse_merge", 1)
+        eng.setTuning("reset_stats", 1)
+        for _ in range(3):
+            for q in queries:
+                eng.searchArrays(q, 10)
+        st = eng.stats()
+        assert int(st.scan_kernels_timed) == 3 * len(queries), (mode, st.scan_kernels_timed)
+        means[mode] = st.scan_kernel_ms_total / st.scan_kernels_timed
+    assert bench.kernel_bound_plausible(means[2], means[1]), means
+    # the filtering GEMM of a batch
+    bq = oracle.gaussian_unit_queries(64, dims, seed=6)
+    eng.setTuning("time_kernels", 0)
+    ids0, sc0, cn0 = eng.searchBatch(bq, 10)
+    gm = {}
+    for mode in (1, 2):
+        eng.setTuning("time_kernels", mode)
+        eng.setTuning("reset_stats", 1)
+        for _ in range(4):
+            ids, sc, cn = eng.searchBatch(bq, 10)
+            assert np.array_equal(ids, ids0) and np.array_equal(sc, sc0) and np.array_equal(cn, cn0), mode
+        st = eng.stats()
+        gm[mode] = (int(st.batch_gemms_timed), st.batch_gemm_ms_total / max(1, int(st.batch_gemms_timed)))
+    assert gm[1][0] == gm[2][0], gm                                  # the same launches are timed under both modes
+    if gm[1][0] > 0:                                                 # (the one-pass pipeline's filtering GEMM is the timed launch)
+        assert bench.kernel_bound_plausible(gm[2][1], gm[1][1]), gm
+    eng.setTuning("time_kernels", 0)
+    eng.close()

@@ -856,7 +856,7 @@ static hipError_t launch_rq(const GemmArgs& a, uint32_t groups, uint32_t per_gro
         hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&batch_gemm_rq_kernel<D, G::TROWS, G::NBUF, G::AHEAD, SAMPLE, SPLIT, NT>), smem, configured);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((batch_gemm_rq_kernel<D, G::TROWS, G::NBUF, G::AHEAD, SAMPLE, SPLIT, NT>), dim3(groups * per_group), dim3(512), smem, st, a, per_group);
+    launch_kernel((batch_gemm_rq_kernel<D, G::TROWS, G::NBUF, G::AHEAD, SAMPLE, SPLIT, NT>), dim3(groups * per_group), dim3(512), smem, st, a, per_group);
     return hipGetLastError();
 }
 
@@ -887,9 +887,9 @@ hipError_t launch_batch_gemm(const GemmArgs& a, int metric, hipStream_t st) {
     const uint32_t ctiles = (a.slab_rows + GN - 1) / GN;
     const dim3 grid(ctiles * a.nqt);
     switch (metric) {
-        case BM_COS: hipLaunchKernelGGL((batch_gemm_kernel<BM_COS>), grid, dim3(256), 0, st, a); break;
-        case BM_DOT: hipLaunchKernelGGL((batch_gemm_kernel<BM_DOT>), grid, dim3(256), 0, st, a); break;
-        case BM_L2: hipLaunchKernelGGL((batch_gemm_kernel<BM_L2>), grid, dim3(256), 0, st, a); break;
+        case BM_COS: launch_kernel((batch_gemm_kernel<BM_COS>), grid, dim3(256), 0, st, a); break;
+        case BM_DOT: launch_kernel((batch_gemm_kernel<BM_DOT>), grid, dim3(256), 0, st, a); break;
+        case BM_L2: launch_kernel((batch_gemm_kernel<BM_L2>), grid, dim3(256), 0, st, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -279,6 +279,7 @@ struct BatchCtx {
     hipStream_t stream = nullptr;        // owned
     hipEvent_t ev_in = nullptr;          // caller-stream -> ctx-stream ordering for device-resident inputs
     hipEvent_t ev_g0 = nullptr, ev_g1 = nullptr;   // "time_kernels": around the filtering GEMM of the last enqueued block
+    hipEvent_t ev_gc = nullptr;                    // "time_kernels" = 2: the chain event behind it (ev_g0 / ev_g1 are bound to the dispatch)
     bool gemm_timed = false;
     uint32_t gemm_rows = 0, gemm_queries = 0;
     float* d_q = nullptr;                // [q_cap][dims] staging for host queries
@@ -821,10 +822,13 @@ int enqueue_scan(wax_hip_engine* e, const float* d_query, float q_norm, int k_ef
     }
     if (used_start) *used_start = ev0;
     if (used_end) *used_end = ev1;
+    // "time_kernels" = 2: the event pair is bound to the scan's dispatch itself (kernels.h: launch_kernel) — its interval is the
+    // kernel's own begin -> end, what rocprofv3 reports for the dispatch; 1: the pair is recorded in front of and behind the launch.
+    const bool bound = ev0 != nullptr && ev1 != nullptr && e->time_kernels.load() == 2;
     if (fused) {
         const int cap = k_eff <= 64 ? 128 : 256;
-        bool record_start = ev0 != nullptr;
-        if (chain_guard.owns_lock() && ev0 && ev1 && used_start && used_end && e->share_timing.load() != 0) {
+        bool record_start = ev0 != nullptr && !bound;
+        if (!bound && chain_guard.owns_lock() && ev0 && ev1 && used_start && used_end && e->share_timing.load() != 0) {
             hipEvent_t& slot_ev = e->tev[e->tev_next % wax_hip_engine::kTimingRing];
             if (!slot_ev && hipEventCreateWithFlags(&slot_ev, hipEventReleaseToDevice) != hipSuccess) slot_ev = nullptr;
             if (slot_ev) {
@@ -843,13 +847,16 @@ int enqueue_scan(wax_hip_engine* e, const float* d_query, float q_norm, int k_ef
         // small grids: the last-arriving workgroup does the final merge itself (one launch per query instead of two)
         bool merged = false;
         if (e->fuse_merge.load() != 0) { a.merge_out = d_hits; a.ids = e->d_ids; a.arrive = partials_ticket(d_partials); a.kpad = kpad; }
-        HIP_TRY(launch_scan(a, e->metric, (int)e->variant.load(), cap, false, (int)e->grid_blocks.load(), stream, &grid, &merged),
-                WAX_HIP_ERR_INTERNAL, "scan kernel launch");
-        if (ev1) HIP_TRY(hipEventRecord(ev1, stream), WAX_HIP_ERR_INTERNAL, "event record");
+        if (bound) launch_timing() = LaunchTiming{ev0, ev1};
+        const hipError_t lerr = launch_scan(a, e->metric, (int)e->variant.load(), cap, false, (int)e->grid_blocks.load(), stream, &grid, &merged);
+        launch_timing() = LaunchTiming{};
+        HIP_TRY(lerr, WAX_HIP_ERR_INTERNAL, "scan kernel launch");
+        if (ev1 && !bound) HIP_TRY(hipEventRecord(ev1, stream), WAX_HIP_ERR_INTERNAL, "event record");
         if (chain_guard.owns_lock()) {
             // the next scan (on the other stream) starts when this one ends: its end-of-kernel timing event doubles
             // as the chain event when kernels are timed — every packet between two scans costs microseconds
-            if (ev1) {
+            // (kernel-bound timing: the packets between two scans are outside the interval, so the chain has its own event)
+            if (ev1 && !bound) {
                 e->chain_event = ev1;
                 e->chain_is_timing = true;
             } else {
@@ -871,10 +878,12 @@ int enqueue_scan(wax_hip_engine* e, const float* d_query, float q_norm, int k_ef
         int rc = ensure_general(e, general_slot);
         if (rc != WAX_HIP_OK) return rc;
         a.dist_out = general_slot->d_dist;
-        if (ev0) HIP_TRY(hipEventRecord(ev0, stream), WAX_HIP_ERR_INTERNAL, "event record");
-        HIP_TRY(launch_scan(a, e->metric, 0, 128, true, (int)e->grid_blocks.load(), stream, &grid), WAX_HIP_ERR_INTERNAL,
-                "distance kernel launch");
-        if (ev1) HIP_TRY(hipEventRecord(ev1, stream), WAX_HIP_ERR_INTERNAL, "event record");
+        if (ev0 && !bound) HIP_TRY(hipEventRecord(ev0, stream), WAX_HIP_ERR_INTERNAL, "event record");
+        if (bound) launch_timing() = LaunchTiming{ev0, ev1};
+        const hipError_t lerr = launch_scan(a, e->metric, 0, 128, true, (int)e->grid_blocks.load(), stream, &grid);
+        launch_timing() = LaunchTiming{};
+        HIP_TRY(lerr, WAX_HIP_ERR_INTERNAL, "distance kernel launch");
+        if (ev1 && !bound) HIP_TRY(hipEventRecord(ev1, stream), WAX_HIP_ERR_INTERNAL, "event record");
         HIP_TRY(launch_select_general(general_slot->d_dist, a.n_rows, a.row_base, k_eff, kpad, e->d_ids,
                                       general_slot->sw, d_hits, stream),
                 WAX_HIP_ERR_INTERNAL, "select kernel launch");
@@ -963,6 +972,7 @@ void free_bctx(BatchCtx* c) {
     if (c->ev_in) (void)hipEventDestroy(c->ev_in);
     if (c->ev_g0) (void)hipEventDestroy(c->ev_g0);
     if (c->ev_g1) (void)hipEventDestroy(c->ev_g1);
+    if (c->ev_gc) (void)hipEventDestroy(c->ev_gc);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -976,6 +986,7 @@ int alloc_bctx(wax_hip_engine* e, BatchCtx** out) {
     if (err == hipSuccess) err = hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&c->ev_g0, hipEventReleaseToDevice);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&c->ev_g1, hipEventReleaseToDevice);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&c->ev_gc, hipEventDisableTiming);
     A(&c->d_qb, (size_t)kBatchMaxQ * D * sizeof(unsigned short));
     A(&c->d_qn2, kBatchMaxQ * sizeof(float));
     A(&c->d_qnorm, kBatchMaxQ * sizeof(float));
@@ -1336,7 +1347,7 @@ int batch_enqueue(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32
             // (the chain wait sits in front of the threshold kernel: the sampling GEMM before it could not get a CU
             // until the previous batch's filtering GEMM left anyway, and one packet less separates threshold and GEMM)
             cg.lock();
-            if (e->gemm_chain_ev && e->gemm_chain_ev != c->ev_g1)
+            if (e->gemm_chain_ev && e->gemm_chain_ev != c->ev_g1 && e->gemm_chain_ev != c->ev_gc)
                 HIP_TRY(hipStreamWaitEvent(st, e->gemm_chain_ev, 0), WAX_HIP_ERR_INTERNAL, "gemm chain wait");
         }
         HIP_TRY(launch_pick_tau(c->d_tile_max, plan->sample_tiles, qn, nq_pad, plan->rank, c->d_tau, e->metric, st), WAX_HIP_ERR_INTERNAL,
@@ -1347,10 +1358,20 @@ int batch_enqueue(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32
             // them, like the single-query scans, so that a timed interval is one GEMM running alone. The small
             // kernels before this point (prep, sampling, thresholds) still overlap the previous batch's GEMM tail
             // and finish kernel.
-            HIP_TRY(hipEventRecord(c->ev_g0, st), WAX_HIP_ERR_INTERNAL, "event record");
-            HIP_TRY(launch_batch_gemm(g, e->metric, st), WAX_HIP_ERR_INTERNAL, "gemm kernel launch");
-            HIP_TRY(hipEventRecord(c->ev_g1, st), WAX_HIP_ERR_INTERNAL, "event record");
-            e->gemm_chain_ev = c->ev_g1;
+            if (e->time_kernels.load() == 2) {
+                // kernel-bound pair (kernels.h: launch_kernel): the GEMM's own begin -> end, as rocprofv3 reports the dispatch
+                launch_timing() = LaunchTiming{c->ev_g0, c->ev_g1};
+                const hipError_t lerr = launch_batch_gemm(g, e->metric, st);
+                launch_timing() = LaunchTiming{};
+                HIP_TRY(lerr, WAX_HIP_ERR_INTERNAL, "gemm kernel launch");
+                HIP_TRY(hipEventRecord(c->ev_gc, st), WAX_HIP_ERR_INTERNAL, "event record");
+                e->gemm_chain_ev = c->ev_gc;
+            } else {
+                HIP_TRY(hipEventRecord(c->ev_g0, st), WAX_HIP_ERR_INTERNAL, "event record");
+                HIP_TRY(launch_batch_gemm(g, e->metric, st), WAX_HIP_ERR_INTERNAL, "gemm kernel launch");
+                HIP_TRY(hipEventRecord(c->ev_g1, st), WAX_HIP_ERR_INTERNAL, "event record");
+                e->gemm_chain_ev = c->ev_g1;
+            }
             c->gemm_timed = true; c->gemm_rows = n; c->gemm_queries = qn;
         } else {
             HIP_TRY(launch_batch_gemm(g, e->metric, st), WAX_HIP_ERR_INTERNAL, "gemm kernel launch");

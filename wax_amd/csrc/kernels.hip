@@ -461,11 +461,11 @@ int scan_grid_for(uint32_t n_rows, uint32_t dims, int variant, int grid_cap) {
 template <int D4, int GROUP, int UNROLL, bool NT, int METRIC>
 static hipError_t launch_metric(const ScanArgs& a, int cap, bool write_dist, int grid, hipStream_t st) {
     if (write_dist) {
-        hipLaunchKernelGGL((scan_kernel<D4, GROUP, METRIC, UNROLL, NT, 128, true>), dim3(grid), dim3(SCAN_THREADS), 0, st, a);
+        launch_kernel((scan_kernel<D4, GROUP, METRIC, UNROLL, NT, 128, true>), dim3(grid), dim3(SCAN_THREADS), 0, st, a);
     } else if (cap <= 128) {
-        hipLaunchKernelGGL((scan_kernel<D4, GROUP, METRIC, UNROLL, NT, 128, false>), dim3(grid), dim3(SCAN_THREADS), 0, st, a);
+        launch_kernel((scan_kernel<D4, GROUP, METRIC, UNROLL, NT, 128, false>), dim3(grid), dim3(SCAN_THREADS), 0, st, a);
     } else {
-        hipLaunchKernelGGL((scan_kernel<D4, GROUP, METRIC, UNROLL, NT, 256, false>), dim3(grid), dim3(SCAN_THREADS), 0, st, a);
+        launch_kernel((scan_kernel<D4, GROUP, METRIC, UNROLL, NT, 256, false>), dim3(grid), dim3(SCAN_THREADS), 0, st, a);
     }
     return hipGetLastError();
 }
@@ -477,8 +477,8 @@ static hipError_t launch_qarg_metric(const ScanArgs& a, int cap, int grid, hipSt
     aq.a = a;
     std::memcpy(aq.q, a.query_host, sizeof(aq.q));
     aq.a.query = nullptr;
-    if (cap <= 128) hipLaunchKernelGGL((scan_kernel_qarg<D4, GROUP, METRIC, UNROLL, NT, 128>), dim3(grid), dim3(SCAN_THREADS), 0, st, aq);
-    else hipLaunchKernelGGL((scan_kernel_qarg<D4, GROUP, METRIC, UNROLL, NT, 256>), dim3(grid), dim3(SCAN_THREADS), 0, st, aq);
+    if (cap <= 128) launch_kernel((scan_kernel_qarg<D4, GROUP, METRIC, UNROLL, NT, 128>), dim3(grid), dim3(SCAN_THREADS), 0, st, aq);
+    else launch_kernel((scan_kernel_qarg<D4, GROUP, METRIC, UNROLL, NT, 256>), dim3(grid), dim3(SCAN_THREADS), 0, st, aq);
     return hipGetLastError();
 }
 template <int D4, int GROUP, int UNROLL, bool NT>
@@ -504,18 +504,18 @@ static hipError_t launch_full(const ScanArgs& a, int metric, int cap, bool write
 // sweep-only variants: cosine, k <= 64, fused path; anything else falls back to variant 0
 template <int D4, int GROUP, int UNROLL, bool NT>
 static hipError_t launch_sweep(const ScanArgs& a, int grid, hipStream_t st) {
-    hipLaunchKernelGGL((scan_kernel<D4, GROUP, M_COS, UNROLL, NT, 128, false>), dim3(grid), dim3(SCAN_THREADS), 0, st, a);
+    launch_kernel((scan_kernel<D4, GROUP, M_COS, UNROLL, NT, 128, false>), dim3(grid), dim3(SCAN_THREADS), 0, st, a);
     return hipGetLastError();
 }
 
 template <int METRIC>
 static hipError_t launch_generic_metric(const ScanArgs& a, int cap, bool write_dist, int grid, hipStream_t st) {
     if (write_dist) {
-        hipLaunchKernelGGL((scan_generic_kernel<METRIC, 128, true>), dim3(grid), dim3(SCAN_THREADS), 0, st, a);
+        launch_kernel((scan_generic_kernel<METRIC, 128, true>), dim3(grid), dim3(SCAN_THREADS), 0, st, a);
     } else if (cap <= 128) {
-        hipLaunchKernelGGL((scan_generic_kernel<METRIC, 128, false>), dim3(grid), dim3(SCAN_THREADS), 0, st, a);
+        launch_kernel((scan_generic_kernel<METRIC, 128, false>), dim3(grid), dim3(SCAN_THREADS), 0, st, a);
     } else {
-        hipLaunchKernelGGL((scan_generic_kernel<METRIC, 256, false>), dim3(grid), dim3(SCAN_THREADS), 0, st, a);
+        launch_kernel((scan_generic_kernel<METRIC, 256, false>), dim3(grid), dim3(SCAN_THREADS), 0, st, a);
     }
     return hipGetLastError();
 }
