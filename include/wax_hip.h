@@ -328,6 +328,9 @@ int wax_hip_stats(wax_hip_engine* e, wax_hip_stats_t* out);
  *   "fuse_merge" (1 (default) = on grids of at most 160 workgroups the scan kernel's last-arriving workgroup does the final merge),
  *   "merge_kway" (1 (default) = top_k <= 64: that workgroup merges the per-workgroup lists by their heads, which lets every default
  *   grid of a store of up to 2 GiB of rows finish in ONE launch; 0 = the round-3 rule),
+ *   "merge_overlap_mb" (default 400: a scan submitted while other single-query tickets of the engine are out — a stream of scans — over a
+ *   store of at least this many MB leaves the merge to a second launch, which overlaps the next scan; 0 = never; a query submitted alone
+ *   always keeps the single launch), "overlap_scans" (read-only: scans that took that form),
  *   "query_args" (dims 384 / 768: 1 (default) = a scan that merges in its own kernel takes the query in its kernel arguments; 2 = every
  *   store; 0 = never), "scan_plain_mb" (such scans read stores of at most this many MB with ordinary instead of non-temporal loads, default 32),
  *   "done_flag" (1 (default) = such a scan publishes a completion word in coherent pinned memory behind its hits and collect polls it

@@ -2295,3 +2295,62 @@ def test_kernel_bound_timing_equals_bracketed_answers_and_is_not_longer(wax):
         assert bench.kernel_bound_plausible(gm[2][1], gm[1][1]), gm
     eng.setTuning("time_kernels", 0)
     eng.close()
+
+
+def test_scans_in_a_stream_of_scans_leave_the_merge_to_a_second_launch(wax):
+    """"merge_overlap_mb" (default 400): a single-query scan submitted while other tickets of the engine are still out runs in a stream
+    of scans, where the separate merge launch overlaps the next scan; stores of at least that size then take the two-launch form
+    (uploaded query, scan, merge kernel, event), a query submitted alone keeps the single launch. Same hits either way, whatever the
+    mix; the shard-device entry point applies the same rule to a ring entry whose predecessor is still running."""
+    import torch
+    dims, n = 384, 120_000
+    corpus = oracle.gaussian_unit_rows(21, n, dims)
+    eng = make_engine(wax, 0, dims, corpus, np.arange(n, dtype=np.uint64) + 9)
+    queries = oracle.gaussian_unit_queries(32, dims, seed=3)
+    assert eng.getTuning("merge_overlap_mb") == 400
+    ref = {k: [eng.searchArrays(q, k) for q in queries] for k in (10, 64, 100)}
+    assert eng.getTuning("overlap_scans") == 0                        # blocking calls: nothing else in flight
+    eng.setTuning("slots", 4)
+    eng.setTuning("streams", 2)
+
+    def pipelined(k):
+        got, pend = [], []
+        for q in queries:
+            if len(pend) == 4:
+                got.append(eng.collect(pend.pop(0), k))
+            pend.append(eng.submit(q, k))
+        got += [eng.collect(t, k) for t in pend]
+        return got
+
+    for k in (10, 64, 100):                                           # a 184 MB store: below the default threshold, one launch each
+        got = pipelined(k)
+        assert all(np.array_equal(g[0], r[0]) and np.array_equal(g[1], r[1]) for g, r in zip(got, ref[k])), k
+    assert eng.getTuning("overlap_scans") == 0
+    eng.setTuning("merge_overlap_mb", 100)
+    m0, f0 = eng.getTuning("merged_scans"), eng.getTuning("done_flag_waits")
+    for k in (10, 64, 100):
+        got = pipelined(k)
+        assert all(np.array_equal(g[0], r[0]) and np.array_equal(g[1], r[1]) for g, r in zip(got, ref[k])), k
+    # the first submit of each run found nothing in flight (one launch, completion word); the other 31 took the two-launch form
+    assert eng.getTuning("overlap_scans") == 3 * 31
+    # (k = 100 is beyond the k-way merge: on this grid it never merges in the kernel)
+    assert eng.getTuning("merged_scans") - m0 == 2 and eng.getTuning("done_flag_waits") - f0 == 2
+    a = eng.searchArrays(queries[5], 10)                              # alone again: the single launch
+    assert np.array_equal(a[0], ref[10][5][0]) and eng.getTuning("overlap_scans") == 3 * 31
+    # the shard-device path: 16 calls enqueued back to back on two streams against the same answers
+    dev = torch.device("cuda", 0)
+    streams = [torch.cuda.Stream(dev) for _ in range(2)]
+    outs = [torch.empty((10, 2), dtype=torch.int64, device=dev) for _ in range(16)]
+    o0 = eng.getTuning("overlap_scans")
+    for i in range(16):
+        eng.searchShardDevice(queries[i], 10, outs[i].data_ptr(), streams[i % 2].cuda_stream)
+    torch.cuda.synchronize()
+    for i in range(16):
+        keys = outs[i].cpu().numpy()
+        assert np.array_equal(keys[:, 1].astype(np.uint64), ref[10][i][0]), i
+    assert eng.getTuning("overlap_scans") > o0                        # (how many depends on how fast the scans drain)
+    eng.setTuning("merge_overlap_mb", 0)
+    o1 = eng.getTuning("overlap_scans")
+    got = pipelined(10)
+    assert all(np.array_equal(g[0], r[0]) for g, r in zip(got, ref[10])) and eng.getTuning("overlap_scans") == o1
+    eng.close()

@@ -411,6 +411,14 @@ struct wax_hip_engine {
     std::atomic<uint64_t> st_flag_waits{0};
     std::atomic<int64_t> query_args{1};      // single-query scans: 1 (default) = stores whose scan grid is small enough for the fused merge (the launch-latency-bound ones) get the query in the kernel arguments (no upload copy); 2 = every store; 0 = always upload
     std::atomic<int64_t> fuse_merge{1};      // 1 = grids of <= SCAN_FUSE_MERGE_GRID workgroups merge in the scan kernel's last-arriving workgroup
+    // A scan submitted while other tickets of this engine are still out (a caller that keeps several queries in flight, or several
+    // callers at once) runs in a stream of scans: there the separate merge launch overlaps the NEXT scan, while the last arriver's
+    // tail (ticket, k-way merge, id gather, ~8 us) is serial inside the kernel. Stores of at least this many MB then take the
+    // two-launch form (upload, scan, merge; 0 = never). A query submitted alone keeps the single launch (12 - 14 us less latency).
+    // Pipelined, depth 4, 384-d (profiles/r05/k_pipelined_merge_forms.txt): 100K rows 24.8 us per query in one launch against 30.1
+    // in two, 200K 45.3 / 45.6, 400K 88.9 / 87.0, 700K 154.0 / 150.1, 1M 224.3 / 214.3, 1.25M 274.3 / 268.7.
+    std::atomic<int64_t> merge_overlap_mb{400};
+    std::atomic<uint64_t> st_overlap_scans{0};
     std::atomic<int64_t> batch_min{1};       // fewer queries than this: always pipelined single-query scans (1..15: cost model below)
     std::atomic<int64_t> batch_mode{1};      // 0 = never use the MFMA path
     std::atomic<int64_t> batch_slab_mb{64};  // cap on slab size, in units of 16 384 rows
@@ -771,7 +779,13 @@ struct Enqueued { int k_eff; };
 // Does a scan of this engine for k_eff results take its query through the kernel arguments ("query_args")? Decided BEFORE the
 // query would be uploaded: the fused path only (the general selection reads the query through its pointer), the default kernel
 // variant, dimensions scan_kernel_qarg exists for.
-bool scan_uses_query_args(wax_hip_engine* e, int k_eff, bool has_general_slot) {
+// Will a scan submitted now run in a stream of scans whose merge is better left to a second launch ("merge_overlap_mb")?
+bool scan_overlaps_merge(wax_hip_engine* e, bool others_in_flight) {
+    const int64_t mb = e->merge_overlap_mb.load();
+    return others_in_flight && mb > 0 && e->count * (uint64_t)e->dims * sizeof(float) >= (uint64_t)mb << 20;
+}
+
+bool scan_uses_query_args(wax_hip_engine* e, int k_eff, bool has_general_slot, bool overlap_merge = false) {
     const int64_t mode = e->query_args.load();
     if (mode == 0 || !scan_query_args_dims(e->dims) || k_eff > FUSED_MAX_K) return false;
     if (e->force_general.load() && has_general_slot) return false;
@@ -781,14 +795,15 @@ bool scan_uses_query_args(wax_hip_engine* e, int k_eff, bool has_general_slot) {
     const int grid = scan_grid_for((uint32_t)e->count, e->dims, 0, (int)e->grid_blocks.load());
     if (grid <= SCAN_FUSE_MERGE_GRID) return true;
     // larger stores: where the scan is the query's only packet (it merges in its own kernel: k <= SCAN_KWAY_MAX_K, <= 2 GiB of rows)
-    return e->fuse_merge.load() != 0 && scan_merges_in_kernel(grid, k_eff, e->merge_kway.load() != 0, (uint32_t)e->count, e->dims);
+    return e->fuse_merge.load() != 0 && !overlap_merge && scan_merges_in_kernel(grid, k_eff, e->merge_kway.load() != 0, (uint32_t)e->count, e->dims);
 }
 
 // d_query == nullptr: the query is `h_query` (host memory, read during this call) and travels in the kernel arguments.
 int enqueue_scan(wax_hip_engine* e, const float* d_query, float q_norm, int k_eff, int kpad, int64_t* d_partials,
                  Slot* general_slot, wax_hip_hit* d_hits, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1,
                  bool chain = false, hipEvent_t* used_start = nullptr, hipEvent_t* used_end = nullptr,
-                 const float* h_query = nullptr, uint64_t* done_flag = nullptr, uint64_t done_value = 0, bool* out_flagged = nullptr) {
+                 const float* h_query = nullptr, uint64_t* done_flag = nullptr, uint64_t done_value = 0, bool* out_flagged = nullptr,
+                 bool overlap_merge = false) {
     ScanArgs a{};
     a.store = e->d_store;
     a.query = d_query;
@@ -846,7 +861,10 @@ int enqueue_scan(wax_hip_engine* e, const float* d_query, float q_norm, int k_ef
         if (record_start) HIP_TRY(hipEventRecord(ev0, stream), WAX_HIP_ERR_INTERNAL, "event record");
         // small grids: the last-arriving workgroup does the final merge itself (one launch per query instead of two)
         bool merged = false;
-        if (e->fuse_merge.load() != 0) { a.merge_out = d_hits; a.ids = e->d_ids; a.arrive = partials_ticket(d_partials); a.kpad = kpad; }
+        // (overlap_merge: a large store in a stream of scans — the merge launch behind this scan overlaps the next one)
+        const bool small_grid = scan_grid_for((uint32_t)e->count, e->dims, 0, (int)e->grid_blocks.load()) <= SCAN_FUSE_MERGE_GRID;
+        if (e->fuse_merge.load() != 0 && (!overlap_merge || small_grid)) { a.merge_out = d_hits; a.ids = e->d_ids; a.arrive = partials_ticket(d_partials); a.kpad = kpad; }
+        else if (overlap_merge) e->st_overlap_scans++;
         if (bound) launch_timing() = LaunchTiming{ev0, ev1};
         const hipError_t lerr = launch_scan(a, e->metric, (int)e->variant.load(), cap, false, (int)e->grid_blocks.load(), stream, &grid, &merged);
         launch_timing() = LaunchTiming{};
@@ -2026,6 +2044,8 @@ static int submit_impl(wax_hip_engine* e, const float* query, uint32_t dims, int
     DeviceGuard g(e->device);
     e->lock.lock_shared(holding(e) > 0);             // withReadLock (:447)
     { const int frc = flush_pending(e); if (frc != WAX_HIP_OK) { e->lock.unlock_shared(); return frc; } }   // staged single-frame appends reach HBM here
+    bool others_in_flight = false;                     // uncollected single-query tickets of this engine, whoever holds them
+    { std::unique_lock<std::mutex> tg(e->slot_mu); others_in_flight = !e->tickets.empty(); }
     Slot* s = nullptr;
     int rc = WAX_HIP_OK;
     do {
@@ -2051,7 +2071,8 @@ static int submit_impl(wax_hip_engine* e, const float* query, uint32_t dims, int
         s->timed = e->time_kernels.load() != 0;
         const float qn = query_norm(query, dims);
         hipError_t err = hipSuccess;
-        const bool qargs = scan_uses_query_args(e, k_eff, true);
+        const bool overlap = scan_overlaps_merge(e, others_in_flight);
+        const bool qargs = scan_uses_query_args(e, k_eff, true, overlap);
         if (!qargs) {
             std::memcpy(s->h_query, query, (size_t)dims * sizeof(float));  // :467-468
             err = hipMemcpyAsync(s->d_query, s->h_query, (size_t)dims * sizeof(float), hipMemcpyHostToDevice, s->stream);
@@ -2070,7 +2091,7 @@ static int submit_impl(wax_hip_engine* e, const float* query, uint32_t dims, int
         bool flagged = false;
         rc = enqueue_scan(e, qargs ? nullptr : s->d_query, qn, k_eff, k_eff, s->d_partials, s, s->h_hits, s->stream,
                           s->timed ? s->ev0 : nullptr, s->timed ? s->ev1 : nullptr, /*chain=*/chain_scans(e), &s->t_start, &s->t_end, query,
-                          want_flag ? s->h_done : nullptr, s->done_seq, &flagged);
+                          want_flag ? s->h_done : nullptr, s->done_seq, &flagged, overlap);
         if (rc != WAX_HIP_OK) break;
         if (flagged) {
             s->flag_wait = true;
@@ -2558,7 +2579,16 @@ static int search_shard_device_impl(wax_hip_engine* e, const float* query, uint3
         }
         const int k_eff = (uint64_t)kpad < e->count ? kpad : (int)e->count;
         const float qn = q_norm >= 0.0f ? q_norm : query_norm(query, dims);
-        const bool qargs = scan_uses_query_args(e, k_eff, false);
+        // the previous call's scan still running (its ring entry in use or not yet drained) = a stream of scans: see "merge_overlap_mb"
+        bool prev_in_flight = false;
+        if (e->merge_overlap_mb.load() > 0 && e->count * (uint64_t)e->dims * sizeof(float) >= (uint64_t)e->merge_overlap_mb.load() << 20) {
+            const uint32_t pr = (r + kShardRing - 1) % kShardRing;
+            std::unique_lock<std::mutex> pg(e->ring_mu[pr], std::try_to_lock);
+            prev_in_flight = !pg.owns_lock() || (e->ring_busy[pr] && hipEventQuery(e->ring_done[pr]) == hipErrorNotReady);
+            (void)hipGetLastError();
+        }
+        const bool overlap = scan_overlaps_merge(e, prev_in_flight);
+        const bool qargs = scan_uses_query_args(e, k_eff, false, overlap);
         if (!qargs) {
             std::memcpy(e->ring_h_query[r], query, (size_t)dims * sizeof(float));
             hipError_t err = hipMemcpyAsync(e->ring_d_query[r], e->ring_h_query[r], (size_t)dims * sizeof(float), hipMemcpyHostToDevice, st);
@@ -2572,7 +2602,8 @@ static int search_shard_device_impl(wax_hip_engine* e, const float* query, uint3
         // each other, while the merge kernel and whatever the caller enqueues next (RCCL all-gather, merge, download)
         // do overlap the following scan.
         rc = enqueue_scan(e, qargs ? nullptr : e->ring_d_query[r], qn, k_eff, kpad, e->ring_d_partials[r], nullptr, d_out_hits, st,
-                          timed ? e->ring_ev0[r] : nullptr, timed ? e->ring_ev1[r] : nullptr, /*chain=*/chain_scans(e), &e->ring_t0[r], &e->ring_t1[r], query);
+                          timed ? e->ring_ev0[r] : nullptr, timed ? e->ring_ev1[r] : nullptr, /*chain=*/chain_scans(e), &e->ring_t0[r], &e->ring_t1[r], query,
+                          nullptr, 0, nullptr, overlap);
         if (rc == WAX_HIP_OK && timed) {
             std::unique_lock<std::mutex> sg(e->st_mu);
             e->ring_ev_pending[r] = true;
@@ -2914,6 +2945,7 @@ int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value) {
     else if (k == "fuse_merge") e->fuse_merge = value != 0;
     else if (k == "done_flag") e->done_flag = value != 0;
     else if (k == "merge_kway") e->merge_kway = value != 0;
+    else if (k == "merge_overlap_mb") e->merge_overlap_mb = value < 0 ? 0 : value;
     else if (k == "scan_plain_mb") e->scan_plain_mb = value;
     else if (k == "query_args") { if (value < 0 || value > 2) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "query_args must be 0, 1 or 2"); e->query_args = value; }
     else if (k == "batch_min") e->batch_min = value;
@@ -2977,6 +3009,8 @@ int64_t wax_hip_get_tuning(wax_hip_engine* e, const char* key) {
     if (k == "query_args") return e->query_args.load();
     if (k == "done_flag") return e->done_flag.load();
     if (k == "merge_kway") return e->merge_kway.load();
+    if (k == "merge_overlap_mb") return e->merge_overlap_mb.load();
+    if (k == "overlap_scans") return (int64_t)e->st_overlap_scans.load();
     if (k == "scan_plain_mb") return e->scan_plain_mb.load();
     if (k == "done_flag_waits") return (int64_t)e->st_flag_waits.load();
     if (k == "query_args_scans") return (int64_t)e->st_query_args.load();
