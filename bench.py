@@ -81,7 +81,7 @@ def parse_args():
                    help="roofline.traffic of the headline kernel: live = a rocprofv3 --pmc FETCH_SIZE child pass inside this run (N = 1); "
                         "replay = the committed pass in profiles/latest_traffic.json; auto = live where rocprofv3 is on PATH, else replay")
     p.add_argument("--events", choices=["bound", "bracket"], default="bound",
-                   help="per-launch kernel times: bound = HIP events bound to the dispatch (hipExtLaunchKernel; the kernel's own begin -> end, "
+                   help="per-launch kernel times: bound = HIP events bound to the dispatch (hipExtLaunchKernel pair: no trailing marker / chain wait in the interval, "
                         "default, with the bracketed figure beside it), bracket = hipEventRecord in front of and behind the launch only")
     p.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     p.add_argument("--traffic-child-batch", default=None, help=argparse.SUPPRESS)   # "nq:corpus:row_base": the batched form of the child
@@ -333,7 +333,9 @@ def measure_single_query(eng, submit, collect, queries, warmup, steps, depth, ba
     #   "time_kernels" = 1 (bracketed): hipEventRecord in front of and behind the launch — the interval holds the kernel AND the
     #       packets around it (the two markers, the chain wait, the dispatch latency: ~10 us whatever the kernel's length);
     #   "time_kernels" = 2 (kernel-bound, the figure `frac` uses): hipExtLaunchKernel binds the event pair to the dispatch itself —
-    #       the kernel's own begin -> end, i.e. what rocprofv3 --kernel-trace reports for the same dispatch (profiles/).
+    #       from the marker the runtime puts in front of the dispatch to the dispatch's completion: no trailing marker, no chain wait.
+    #       Against rocprofv3's own duration of the SAME dispatch (profiles/r05/k_event_modes_vs_rocprofv3_same_launches.txt) it is
+    #       still 4-8 us long (the dispatch latency); the bracket is 6-9 us long on a blocking call, 15-19 us in this chained pass.
     # A kernel-bound mean that is not plausible next to the bracketed one (runtime without the binding) falls back to the bracket.
     n_cal = min(steps, CALIBRATION_STEPS)
 
@@ -362,9 +364,10 @@ def measure_single_query(eng, submit, collect, queries, warmup, steps, depth, ba
         "steps": n_cal, "ms_per_step": cal_el / n_cal * 1e3, "events": events,
         "kernel_avg_ms_bracketed": br_ms, "kernel_avg_ms_kernel_bound": kb_ms,
         "mode": "same run, same engine, the first queries of the timed region again, scans chained (never two at once), HIP events on "
-                "the scan's own stream: " + ("bound to the scan's dispatch (hipExtLaunchKernel start / stop: the kernel's own begin -> end, "
-                                             "what rocprofv3 reports per dispatch); the bracketed mean (hipEventRecord around the launch: "
-                                             "kernel + marker / chain / dispatch packets) is kernel_avg_ms_bracketed"
+                "the scan's own stream: " + ("bound to the scan's dispatch (hipExtLaunchKernel start / stop pair: from the marker the runtime puts in front of "
+                                             "the dispatch to the dispatch's completion; 4-8 us above rocprofv3's duration of the same dispatch, "
+                                             "profiles/r05/k_event_modes_vs_rocprofv3_same_launches.txt); the bracketed mean (hipEventRecord around the "
+                                             "launch: kernel + both markers + the chain wait) is kernel_avg_ms_bracketed"
                                              if events == "kernel-bound" else "recorded in front of and behind the launch (\"time_kernels\" = 1)")}
 
 
@@ -877,6 +880,7 @@ def secondary_batched(torch, dev, rows, dims, nq, k, steps, warmup, label, row_b
         del dq, outs
         torch.cuda.empty_cache()
         _, _, res["roofline"] = batched_roofline(rows, dims, nq, kern_ms, launches, rega, live={"k": k, "corpus": corpus, "row_base": row_base})
+        res["roofline"]["events"], res["roofline"]["kernel_avg_ms_bracketed"] = events, br_ms
     return res
 
 

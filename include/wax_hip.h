@@ -324,7 +324,7 @@ int wax_hip_stats(wax_hip_engine* e, wax_hip_stats_t* out);
  *   radix-select path even for small k), "slots" (scratch-slot pool size), "streams" (1..4 in-order streams the slots rotate over),
  *   "time_kernels" (wax_hip_stats' kernel times: 1 = HIP events recorded in front of and behind the scan / filtering-GEMM launch on its own
  *   stream — the interval holds the kernel and the packets around it; 2 = the event pair bound to the dispatch itself (hipExtLaunchKernel):
- *   the kernel's own begin -> end, the figure rocprofv3 reports per dispatch), "reset_stats" (any value: zero the counters),
+ *   no trailing marker and no chain wait inside the interval; 4-8 us above rocprofv3's duration of the same dispatch), "reset_stats" (any value: zero the counters),
  *   "fuse_merge" (1 (default) = on grids of at most 160 workgroups the scan kernel's last-arriving workgroup does the final merge),
  *   "merge_kway" (1 (default) = top_k <= 64: that workgroup merges the per-workgroup lists by their heads, which lets every default
  *   grid of a store of up to 2 GiB of rows finish in ONE launch; 0 = the round-3 rule),

@@ -397,7 +397,7 @@ def test_bench_line_stays_inside_the_drivers_stdout_tail(tmp_path, capsys):
 
 
 def test_bench_line_carries_the_event_mode_and_the_bracketed_figure():
-    """Round 5: `frac` is priced with kernel-bound HIP events (hipExtLaunchKernel pair = the dispatch's own begin -> end); the line says
+    """Round 5: `frac` is priced with kernel-bound HIP events (hipExtLaunchKernel start / stop pair on the dispatch); the line says
     which events it used and carries the bracketed mean (hipEventRecord around the launch) beside it; the plausibility rule that
     guards the switch refuses a pair the runtime did not bind."""
     import json

@@ -2061,6 +2061,7 @@ def test_query_in_kernel_arguments_equals_uploaded_query(wax):
         queries = oracle.gaussian_unit_queries(12, dims, seed=n)
         queries[3] = corpus[10]
         grid = eng.getTuning("scan_grid")
+        eng.setTuning("merge_overlap_mb", 0)        # (pipelined scans over >= 400 MB would otherwise take the two-launch form: its own test)
         for k in (1, 10, 64, 65, 192, 500):
             small = _merges_in_kernel(grid, k, n, dims)                 # mode 1: where the scan is the query's only packet
             eng.setTuning("query_args", 0)

@@ -837,8 +837,8 @@ int enqueue_scan(wax_hip_engine* e, const float* d_query, float q_norm, int k_ef
     }
     if (used_start) *used_start = ev0;
     if (used_end) *used_end = ev1;
-    // "time_kernels" = 2: the event pair is bound to the scan's dispatch itself (kernels.h: launch_kernel) — its interval is the
-    // kernel's own begin -> end, what rocprofv3 reports for the dispatch; 1: the pair is recorded in front of and behind the launch.
+    // "time_kernels" = 2: the event pair is bound to the scan's dispatch itself (kernels.h: launch_kernel) — no trailing marker and no
+    // chain wait inside the interval; 1: the pair is recorded in front of and behind the launch.
     const bool bound = ev0 != nullptr && ev1 != nullptr && e->time_kernels.load() == 2;
     if (fused) {
         const int cap = k_eff <= 64 ? 128 : 256;
@@ -1377,7 +1377,7 @@ int batch_enqueue(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32
             // kernels before this point (prep, sampling, thresholds) still overlap the previous batch's GEMM tail
             // and finish kernel.
             if (e->time_kernels.load() == 2) {
-                // kernel-bound pair (kernels.h: launch_kernel): the GEMM's own begin -> end, as rocprofv3 reports the dispatch
+                // kernel-bound pair (kernels.h: launch_kernel)
                 launch_timing() = LaunchTiming{c->ev_g0, c->ev_g1};
                 const hipError_t lerr = launch_batch_gemm(g, e->metric, st);
                 launch_timing() = LaunchTiming{};

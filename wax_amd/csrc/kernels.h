@@ -25,11 +25,12 @@ inline hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes, std::atom
 }
 
 // Kernel-bound timing ("time_kernels" = 2). hipEventRecord in front of and behind a launch brackets the kernel AND the packets
-// around it (the record markers, the chain wait, the dispatch latency: ~10-13 us, which is 0.6 % of a 2.2 ms scan but 4 % of a
-// 0.3 ms one). hipExtLaunchKernel binds a start / stop event pair to the DISPATCH ITSELF: hipEventElapsedTime(start, stop) is then
-// the kernel's own begin -> end interval, the figure rocprofv3 --kernel-trace reports for the same dispatch. The caller arms the
-// pair for the next launch of this thread (one shot: the first launch_kernel() consumes it, later launches of the same call —
-// the merge kernel behind a scan — are ordinary).
+// around it (both record markers, the chain wait, the dispatch latency: 15-19 us over rocprofv3's duration of the same dispatch when
+// scans are chained, which is 0.8 % of a 2.2 ms scan but 6 % of a 0.3 ms one). hipExtLaunchKernel binds a start / stop event pair
+// to the DISPATCH: hipEventElapsedTime(start, stop) then runs from the marker the runtime puts in front of the dispatch to the
+// dispatch's own completion — no trailing marker, no chain wait; measured 4-8 us above rocprofv3's per-dispatch duration of the same
+// launch (profiles/r05/k_event_modes_vs_rocprofv3_same_launches.txt). The caller arms the pair for the next launch of this thread
+// (one shot: the first launch_kernel() consumes it, later launches of the same call — the merge kernel behind a scan — are ordinary).
 struct LaunchTiming {
     hipEvent_t start = nullptr, stop = nullptr;
 };
