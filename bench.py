@@ -83,6 +83,7 @@ def parse_args():
     p.add_argument("--events", choices=["bound", "bracket"], default="bound",
                    help="per-launch kernel times: bound = HIP events bound to the dispatch (hipExtLaunchKernel pair: no trailing marker / chain wait in the interval, "
                         "default, with the bracketed figure beside it), bracket = hipEventRecord in front of and behind the launch only")
+    p.add_argument("--batch-depth", type=int, default=0, help="batched secondaries: batches in flight (default 0 = auto: 3 for batches of up to 256 queries, 2 for larger ones)")
     p.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     p.add_argument("--traffic-child-batch", default=None, help=argparse.SUPPRESS)   # "nq:corpus:row_base": the batched form of the child
     p.add_argument("--detail-out", default=None, metavar="PATH",
@@ -371,6 +372,7 @@ def measure_single_query(eng, submit, collect, queries, warmup, steps, depth, ba
                                              if events == "kernel-bound" else "recorded in front of and behind the launch (\"time_kernels\" = 1)")}
 
 
+BATCH_DEPTH = 0          # --batch-depth: batches in flight of the batched secondaries (0 = auto: 3 up to 256 queries per batch, else 2)
 EVENT_MODE = "bound"     # --events: "bound" (default) = frac from kernel-bound HIP events, "bracket" = rounds 1-4's hipEventRecord bracket
 
 
@@ -800,7 +802,11 @@ def secondary_batched(torch, dev, rows, dims, nq, k, steps, warmup, label, row_b
     eng = _load_engine(torch, dev, rows, dims, corpus)
     eng.setRowBase(row_base)
     apply_tunes(eng)
-    depth = 2                                # batches in flight, like the headline's --depth software pipeline
+    # batches in flight, like the headline's --depth software pipeline. Auto: three for batches of up to 256 queries, two for larger
+    # ones — with a third ticket out, the next batch's threshold kernel and the stream gaps around it run under the current filtering
+    # GEMM instead of between two GEMMs (1M x 384 x 256 queries: 0.216 -> 0.210 ms per batch, clustered k = 100 0.323 -> 0.284), while
+    # 1 024-query batches lose 3 % to the extra small kernels in front of their long GEMMs (profiles/r05/k_batch_depth_2_3_4.txt)
+    depth = BATCH_DEPTH if BATCH_DEPTH > 0 else (3 if nq <= 256 else 2)
     dq = batch_queries(torch, dev, nq, dims, corpus)
     outs = [torch.empty((nq, k, 2), dtype=torch.int64, device=dev) for _ in range(depth)]
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -829,9 +835,10 @@ def secondary_batched(torch, dev, rows, dims, nq, k, steps, warmup, label, row_b
     blocking_ms = (time.perf_counter() - tb) / nblk * 1e3
     fb0, rt0, mp0 = eng.getTuning("batch_fallbacks"), eng.getTuning("batch_retries"), eng.getTuning("batch_multi_passes")
     ir0 = eng.getTuning("batch_inline_retries")
-    # the filtering GEMMs are timed INSIDE the timed region (and chained, so that an interval is one GEMM): kernel-bound HIP events
-    # ("time_kernels" = 2, see measure_single_query) or the hipEventRecord bracket (--events bracket)
-    eng.setTuning("time_kernels", 2 if EVENT_MODE == "bound" else 1)
+    # Timed region = the product path, like the headline's: nothing is timed inside it ("time_kernels" = 0 — round 5, second session;
+    # until then the filtering GEMMs were timed and chained INSIDE the region, and the chain wait and the event packets sat between
+    # the threshold kernel and the GEMM of every batch: ~12 us of a 0.22 ms batch, profiles/r05/k_pipelined_batch_timeline.csv).
+    eng.setTuning("time_kernels", 0)
     apply_tunes(eng)
     eng.setTuning("reset_stats", 1)
     _bracket(torch)
@@ -839,21 +846,31 @@ def secondary_batched(torch, dev, rows, dims, nq, k, steps, warmup, label, row_b
     run(steps)
     _bracket(torch)
     el = time.perf_counter() - t0
-    st = eng.stats()
-    launches = int(st.batch_gemms_timed)
-    kern_ms = st.batch_gemm_ms_total / launches if launches else float("nan")
-    events, br_ms = ("kernel-bound" if EVENT_MODE == "bound" else "bracketed"), None
-    if EVENT_MODE == "bound":
-        # the bracketed figure beside it, from a short pass of its own (untimed): hipEventRecord around the same launches
-        eng.setTuning("time_kernels", 1)
+    fb1, rt1, mp1, ir1 = (eng.getTuning("batch_fallbacks"), eng.getTuning("batch_retries"), eng.getTuning("batch_multi_passes"),
+                          eng.getTuning("batch_inline_retries"))
+    last_ck = _hits_checksum(outs[(steps - 1) % depth])
+
+    # calibration passes right behind it (same engine, same batches, still two in flight): the filtering GEMMs timed and chained so
+    # that an interval is one GEMM — kernel-bound HIP events ("time_kernels" = 2, see measure_single_query), then the hipEventRecord
+    # bracket beside it (--events bracket: the bracket only)
+    def cal_pass(mode, n_steps):
+        eng.setTuning("time_kernels", mode)
+        run(2)
         eng.setTuning("reset_stats", 1)
-        run(max(4, min(steps, 20)))
+        run(n_steps)
         _bracket(torch)
-        st1 = eng.stats()
-        n1 = int(st1.batch_gemms_timed)
-        br_ms = st1.batch_gemm_ms_total / n1 if n1 else float("nan")
-        if not (launches and n1 and kernel_bound_plausible(kern_ms, br_ms)):
-            kern_ms, launches, events = br_ms, n1, "bracketed"
+        st_ = eng.stats()
+        n_ = int(st_.batch_gemms_timed)
+        return (st_.batch_gemm_ms_total / n_ if n_ else float("nan")), n_
+
+    n_cal = max(4, min(steps, 40))
+    br_ms, br_n = cal_pass(1, n_cal if EVENT_MODE != "bound" else max(4, min(steps, 20)))
+    kern_ms, launches, events = br_ms, br_n, "bracketed"
+    if EVENT_MODE == "bound":
+        kb_ms, kb_n = cal_pass(2, n_cal)
+        if kb_n and br_n and kernel_bound_plausible(kb_ms, br_ms):
+            kern_ms, launches, events = kb_ms, kb_n, "kernel-bound"
+    eng.setTuning("time_kernels", 0)
     flops, floor_s, rf = batched_roofline(rows, dims, nq, kern_ms, launches, int(eng.getTuning("batch_rega")))
     rf["events"], rf["kernel_avg_ms_bracketed"] = events, br_ms
     want_live = True                          # roofline.traffic of the filtering GEMM is measured below (child counter pass)
@@ -864,13 +881,13 @@ def secondary_batched(torch, dev, rows, dims, nq, k, steps, warmup, label, row_b
         "ms_per_step_blocking_call": blocking_ms,
         "end_to_end_tflops_bf16": flops / (el / steps) / 1e12,
         "end_to_end_frac_of_roof": floor_s / (el / steps),
-        "certificate_fallbacks": int(eng.getTuning("batch_fallbacks") - fb0),
-        "certificate_fallbacks_per_step": (eng.getTuning("batch_fallbacks") - fb0) / (steps + 0.0),
-        "full_retries": int(eng.getTuning("batch_retries") - rt0),
-        "full_retries_on_device": int(eng.getTuning("batch_inline_retries") - ir0),
-        "shared_exact_passes": int(eng.getTuning("batch_multi_passes") - mp0),
+        "certificate_fallbacks": int(fb1 - fb0),
+        "certificate_fallbacks_per_step": (fb1 - fb0) / (steps + 0.0),
+        "full_retries": int(rt1 - rt0),
+        "full_retries_on_device": int(ir1 - ir0),
+        "shared_exact_passes": int(mp1 - mp0),
         "pipeline": "one-pass" if eng.getTuning("onepass_queries") > 0 else "slab",
-        "last_result_checksum": _hits_checksum(outs[(steps - 1) % depth]),
+        "last_result_checksum": last_ck,
         "roofline": rf,
     }
     rega = int(eng.getTuning("batch_rega"))
@@ -955,7 +972,7 @@ def config5_sharded(torch, dist, args, rank, world, in_library, use_rccl, k=10, 
         searcher.submit(dq)
         searcher.collect()                                                                   # mirror (untimed)
     run(warmup)
-    eng.setTuning("time_kernels", 1)
+    eng.setTuning("time_kernels", 0)                 # timed region = the product path (nothing timed or chained inside it)
     eng.setTuning("reset_stats", 1)
     barrier()
     t0 = time.perf_counter()
@@ -966,6 +983,14 @@ def config5_sharded(torch, dist, args, rank, world, in_library, use_rccl, k=10, 
         t = torch.tensor([el], dtype=torch.float64, device=dev if use_rccl else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
+    last_ck = _hits_checksum(last)
+    fallbacks = int(eng.getTuning("batch_fallbacks"))
+    # calibration pass (every rank, the same number of batches): the filtering GEMMs timed and chained, HIP events recorded around them
+    eng.setTuning("time_kernels", 1)
+    eng.setTuning("reset_stats", 1)
+    run(max(4, min(steps, 20)))
+    barrier()
+    eng.setTuning("time_kernels", 0)
     st = eng.stats()
     launches = int(st.batch_gemms_timed)
     kern_ms = st.batch_gemm_ms_total / launches if launches else float("nan")
@@ -982,8 +1007,8 @@ def config5_sharded(torch, dist, args, rank, world, in_library, use_rccl, k=10, 
         "batches_in_flight": depth, "rows_per_gpu": rows_per_gpu,
         "end_to_end_tflops_bf16": 2.0 * nq * rows * dims / (el / steps) / 1e12,
         "end_to_end_frac_of_roof_per_gpu": floor_s / (el / steps),
-        "certificate_fallbacks": int(eng.getTuning("batch_fallbacks")),
-        "last_result_checksum": _hits_checksum(last),
+        "certificate_fallbacks": fallbacks,
+        "last_result_checksum": last_ck,
         "roofline": rf,
     }
     eng.close()
@@ -1138,8 +1163,9 @@ def arm_secondary_watchdog(out, args, rank, limit_s=None):
 def main():
     args = parse_args()
     TUNES.extend(args.tune)
-    global EVENT_MODE
+    global EVENT_MODE, BATCH_DEPTH
     EVENT_MODE = args.events
+    BATCH_DEPTH = max(0, min(4, args.batch_depth))
     # RCCL / CUDA-tensor IPC on this driver stack needs dmabuf IPC (the image exports it; keep it if launched bare)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
@@ -1371,19 +1397,19 @@ def main():
                                                          "the headline's per-GPU shard at 8 GPUs (10M / 8 rows): what one rank of BASELINE config 4 scans per query"),
                 "b1m_q256": lambda: secondary_batched(torch, dev, 1_000_000, 384, 256, k, max(s, 200), max(w, 20),
                                                       "1000000 x 384, 256 queries per step, cosine top-10, bf16 MFMA GEMM + fused top-k, 1 GPU "
-                                                      "(BASELINE config 3), queries and results resident in HBM, 2 batches in flight"),
+                                                      "(BASELINE config 3), queries and results resident in HBM, batches in flight: see batches_in_flight"),
                 "b1m_q1024": lambda: secondary_batched(torch, dev, 1_000_000, 384, 1024, k, max(s // 2, 100), max(w, 20),
                                                        "1000000 x 384, 1024 queries per step, cosine top-10, bf16 MFMA GEMM + fused top-k, 1 GPU "
                                                        "(config 3 at four times the batch: the MFMA-bound shape), queries and results resident in "
-                                                       "HBM, 2 batches in flight"),
+                                                       "HBM, batches in flight: see batches_in_flight"),
                 "c5_shard": lambda: secondary_batched(torch, dev, 1_250_000, 768, 1024, k, max(s // 2, 60), max(w, 10),
                                                       "1250000 x 768 (one GPU's share of 10M x 768 over 8 GPUs), 1024 queries per step, cosine "
                                                       "top-10, bf16 MFMA GEMM + fused top-k (BASELINE config 5, per-GPU part), queries and "
-                                                      "results resident in HBM, 2 batches in flight", row_base=3_750_000),
+                                                      "results resident in HBM, batches in flight: see batches_in_flight", row_base=3_750_000),
                 "c5_full": lambda: secondary_batched(torch, dev, args.c5_rows, 768, 1024, k, max(10, min(s // 8, 25)), 3,
                                                      f"{args.c5_rows} x 768, 1024 queries per step, cosine top-10, bf16 MFMA GEMM + fused top-k, ALL "
                                                      "rows on ONE GPU (BASELINE config 5 at full size: the N = 1 point of its 1/2/4/8-GPU scaling "
-                                                     "curve), queries and results resident in HBM, 2 batches in flight"),
+                                                     "curve), queries and results resident in HBM, batches in flight: see batches_in_flight"),
                 "clustered_k10": lambda: secondary_batched(torch, dev, 1_000_000, 384, 256, 10, max(s // 2, 100), max(w, 10),
                                                            "1000000 x 384 CLUSTERED corpus (20 tight clusters: normalize(centre + 0.3 gaussian), half "
                                                            "of the queries inside a cluster), 256 queries per step, cosine top-10: the batched path "
