@@ -570,7 +570,7 @@ def secondary_single_query(torch, dev, rows, dims, k, steps, warmup, depth, labe
     checksum = hashlib.sha256(np.asarray(last[0], dtype=np.uint64).tobytes() + np.asarray(last[1], dtype=np.float32).tobytes()).hexdigest()[:16]
     nbytes = rows * dims * 4
     grid = eng.getTuning("scan_grid")
-    merged = eng.getTuning("merged_scans")
+    merged, overlapped = eng.getTuning("merged_scans"), eng.getTuning("overlap_scans")
     eng.close()
     traffic, traffic_source = None, None
     if TRAFFIC_MODE in ("auto", "live"):
@@ -588,7 +588,9 @@ def secondary_single_query(torch, dev, rows, dims, k, steps, warmup, depth, labe
         pass
     rf = scan_roofline(nbytes, kern_ms, launches, elapsed, steps, cal, traffic, traffic_source)
     rf["scan_grid"] = grid
-    rf["launches_per_query"] = 1 if merged > 0 else 2     # 1: the scan kernel's last-arriving workgroup did the final merge
+    # 1: the scan kernel's last-arriving workgroup did the final merge; 2: a merge launch behind the scan (stores beyond 2 GiB; and, with
+    # other scans in flight as here, stores from "merge_overlap_mb" up: the merge overlaps the next scan)
+    rf["launches_per_query"] = 1 if merged > overlapped else 2
     return {
         "config": f"{rows} x {dims} f32 cosine top-{k}, one query per step, 1 GPU ({label})",
         "value": steps / elapsed, "unit": "queries/s", "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
@@ -863,7 +865,7 @@ def secondary_batched(torch, dev, rows, dims, nq, k, steps, warmup, label, row_b
         n_ = int(st_.batch_gemms_timed)
         return (st_.batch_gemm_ms_total / n_ if n_ else float("nan")), n_
 
-    n_cal = max(4, min(steps, 40))
+    n_cal = max(4, min(steps, 60))
     br_ms, br_n = cal_pass(1, n_cal if EVENT_MODE != "bound" else max(4, min(steps, 20)))
     kern_ms, launches, events = br_ms, br_n, "bracketed"
     if EVENT_MODE == "bound":
@@ -988,7 +990,7 @@ def config5_sharded(torch, dist, args, rank, world, in_library, use_rccl, k=10, 
     # calibration pass (every rank, the same number of batches): the filtering GEMMs timed and chained, HIP events recorded around them
     eng.setTuning("time_kernels", 1)
     eng.setTuning("reset_stats", 1)
-    run(max(4, min(steps, 20)))
+    run(max(4, min(steps, 60)))
     barrier()
     eng.setTuning("time_kernels", 0)
     st = eng.stats()

@@ -873,8 +873,12 @@ def test_bench_contract_and_shard_invariance(wax, tmp_path):
         if x["name"] != "s10k":                                     # (a 15 MB store lives in the L2s: far fewer bytes than its size)
             assert 0.9 < rr["traffic"] / rr["algorithmic_bytes_per_launch"] < 1.5, (x["name"], rr["traffic"], rr["algorithmic_bytes_per_launch"])
     assert sec[0]["roofline"]["launches_per_query"] == 1            # 10K rows: the scan kernel's last workgroup merges
-    assert sec[1]["roofline"]["launches_per_query"] == 1            # ... and so does the 1M-row store's (top-10: the k-way merge of the list heads)
-    assert all(x["pipeline"] == "one-pass" and x["batches_in_flight"] == 2 and x["ms_per_step_blocking_call"] > 0 for x in sec[2:])
+    assert sec[1]["roofline"]["launches_per_query"] == 2            # the 1M-row store (1.5 GB) in a stream of scans: the merge launch overlaps the next scan ("merge_overlap_mb")
+    # (batches in flight: three for batches of up to 256 queries, two for the 1 024-query ones — bench.secondary_batched)
+    assert all(x["pipeline"] == "one-pass" and x["batches_in_flight"] == (3 if x["queries_per_step"] <= 256 else 2) and x["ms_per_step_blocking_call"] > 0
+               for x in sec[2:])
+    assert all(x["roofline"]["events"] in ("kernel-bound", "bracketed") and x["roofline"]["kernel_avg_ms_bracketed"] > 0 for x in sec[2:])
+    assert one["roofline"]["calibration"]["events"] in ("kernel-bound", "bracketed") and one["_line"]["roofline"]["events"] == one["roofline"]["calibration"]["events"]
     assert all(x["certificate_fallbacks"] == 0 for x in sec[2:6])
     assert sec[6]["corpus"] == "clustered" and "ms_per_step_vs_iid_config3" in sec[6]
     print("\n[bench secondary] " + " | ".join(f"{x['name']}: {x['value']:.0f} q/s, {x['ms_per_step']:.3f} ms/step, frac {x['roofline']['frac']:.3f}" for x in sec))
