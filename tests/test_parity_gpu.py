@@ -2359,3 +2359,30 @@ def test_scans_in_a_stream_of_scans_leave_the_merge_to_a_second_launch(wax):
     got = pipelined(10)
     assert all(np.array_equal(g[0], r[0]) for g, r in zip(got, ref[10])) and eng.getTuning("overlap_scans") == o1
     eng.close()
+
+
+@pytest.mark.parametrize("dims", [128, 256, 384, 512, 768])
+def test_fragment_ordered_queries_equal_row_major_queries(wax, dims):
+    """"batch_qfrag" (default 1): the prep kernel writes the bf16 queries a second time in MFMA A-fragment order and the
+    register-resident GEMM loads its fragments from there (one contiguous 1-KB run per k-step instead of 32 rows x 32 bytes). Same
+    fragments => same approximate similarities => the same thresholds, survivors, certificates and hits as with row-major reads:
+    identical answers AND identical fallback / retry counters, for ragged batch sizes (padding queries) and several query groups."""
+    n = 90_000
+    corpus = oracle.gaussian_unit_rows(100 + dims, n, dims)
+    eng = make_engine(wax, 0, dims, corpus, np.arange(n, dtype=np.uint64) + 2)
+    assert eng.getTuning("batch_qfrag") == 1
+    for nq in (17, 256, 300, 700):
+        queries = oracle.gaussian_unit_queries(nq, dims, seed=nq + dims)
+        res = {}
+        for mode in (1, 0):
+            eng.setTuning("batch_qfrag", mode)
+            f0, r0, o0 = eng.getTuning("batch_fallbacks"), eng.getTuning("batch_retries"), eng.getTuning("onepass_queries")
+            ids, scores, counts = eng.searchBatch(queries, 10)
+            res[mode] = (ids, scores, counts, eng.getTuning("batch_fallbacks") - f0, eng.getTuning("batch_retries") - r0, eng.getTuning("onepass_queries") - o0)
+        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2]), (dims, nq)
+        assert res[0][3:] == res[1][3:], (dims, nq, res[0][3:], res[1][3:])
+        assert res[1][5] > 0, (dims, nq)                             # the one-pass pipeline (the rq kernel) answered
+        for i in (0, nq // 2, nq - 1):
+            s_ids, s_scores = eng.searchArrays(queries[i], 10)
+            assert np.array_equal(res[1][0][i, :res[1][2][i]], s_ids) and np.array_equal(res[1][1][i, :res[1][2][i]], s_scores), (dims, nq, i)
+    eng.close()

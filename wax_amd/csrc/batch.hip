@@ -501,9 +501,15 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
     // A fragments: lane l holds query (l & 31), k = 16*ks + 8*(l >> 5) .. +7
     bf16x8 fa[KS];
     {
-        const u32x4* qp = reinterpret_cast<const u32x4*>(a.qb + (size_t)(q0 + (lane & 31)) * D) + (lane >> 5);
+        if (a.qf != nullptr) {   // fragment order: one contiguous 1-KB run per k-step
+            const u32x4* qp = reinterpret_cast<const u32x4*>(a.qf) + (size_t)(q0 >> 5) * (KS * 64) + lane;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) fa[ks] = __builtin_bit_cast(bf16x8, qp[ks * 2]);
+            for (int ks = 0; ks < KS; ++ks) fa[ks] = __builtin_bit_cast(bf16x8, qp[ks * 64]);
+        } else {
+            const u32x4* qp = reinterpret_cast<const u32x4*>(a.qb + (size_t)(q0 + (lane & 31)) * D) + (lane >> 5);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) fa[ks] = __builtin_bit_cast(bf16x8, qp[ks * 2]);
+        }
         // The fragments are "used" HERE, so hipcc waits for their loads here — before the first DMA request. Left alone it places
         // that wait in front of the first MFMA of the tile loop, where the only count it can prove is vmcnt(0): every wave then
         // drains its whole DMA queue (the tile it requested a moment ago included) at the top of every K loop.
@@ -1283,8 +1289,11 @@ __global__ __launch_bounds__(256) void batch_prep_kernel(PrepArgs a) {
     if (q == 0 && a.progress) for (uint32_t i = lane; i < BATCH_PROGRESS_WORDS; i += WAVE) a.progress[i] = 0u;   // the pace gate's words (one 128-byte line per XCD)
     const uint32_t D = a.dims;
     unsigned short* out = a.qb + (size_t)q * D;
+    // fragment-ordered copy (GemmArgs::qf): element c of query q -> ((q / 32 * D/16 + c / 16) * 64 + (q & 31) + 32 * ((c >> 3) & 1)) * 8 + (c & 7)
+    unsigned short* outf = (a.qf != nullptr && (D & 15u) == 0u) ? a.qf + ((size_t)(q >> 5) * (D >> 4) * 64u + (q & 31u)) * 8u : nullptr;
+    auto frag_at = [](uint32_t c) { return (size_t)(c >> 4) * 512u + (size_t)((c >> 3) & 1u) * 256u + (c & 7u); };
     if (q >= a.nq) {                                     // padding query: admits nothing, matches nothing
-        for (uint32_t c = lane; c < D; c += WAVE) out[c] = 0;
+        for (uint32_t c = lane; c < D; c += WAVE) { out[c] = 0; if (outf) outf[frag_at(c)] = 0; }
         if (lane == 0) {
             a.q_n2[q] = 0.f; a.q_norm[q] = 0.f; a.eps[q] = 0.f; a.tau[q] = -__builtin_inff(); a.overflow[q] = 0u;
             if (a.cand_count) a.cand_count[(size_t)q * CAND_COUNT_STRIDE] = 0u;
@@ -1327,6 +1336,7 @@ __global__ __launch_bounds__(256) void batch_prep_kernel(PrepArgs a) {
         const double d = (double)x - (double)__uint_as_float((unsigned int)b << 16);
         qe2 += d * d;
         out[c] = b;
+        if (outf) outf[frag_at(c)] = b;
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) qe2 += __shfl_xor(qe2, o);

@@ -285,6 +285,7 @@ struct BatchCtx {
     float* d_q = nullptr;                // [q_cap][dims] staging for host queries
     uint64_t q_cap = 0;
     unsigned short* d_qb = nullptr;
+    unsigned short* d_qf = nullptr;                // the same queries in MFMA A-fragment order (GemmArgs::qf)
     float* d_qn2 = nullptr;
     float* d_qnorm = nullptr;
     float* d_eps = nullptr;
@@ -419,6 +420,7 @@ struct wax_hip_engine {
     // in two, 200K 45.3 / 45.6, 400K 88.9 / 87.0, 700K 154.0 / 150.1, 1M 224.3 / 214.3, 1.25M 274.3 / 268.7.
     std::atomic<int64_t> merge_overlap_mb{400};
     std::atomic<uint64_t> st_overlap_scans{0};
+    std::atomic<int64_t> batch_qfrag{1};     // 1 (default) = the prep kernel also writes the bf16 queries in MFMA A-fragment order and the register-resident GEMM loads them from there (coalesced); 0 = row-major reads
     std::atomic<int64_t> batch_min{1};       // fewer queries than this: always pipelined single-query scans (1..15: cost model below)
     std::atomic<int64_t> batch_mode{1};      // 0 = never use the MFMA path
     std::atomic<int64_t> batch_slab_mb{64};  // cap on slab size, in units of 16 384 rows
@@ -981,7 +983,7 @@ int ensure_mirror(wax_hip_engine* e, hipStream_t st) {
 
 void free_bctx(BatchCtx* c) {
     if (!c) return;
-    (void)hipFree(c->d_q); (void)hipFree(c->d_qb); (void)hipFree(c->d_qn2); (void)hipFree(c->d_qnorm); (void)hipFree(c->d_eps);
+    (void)hipFree(c->d_q); (void)hipFree(c->d_qb); (void)hipFree(c->d_qf); (void)hipFree(c->d_qn2); (void)hipFree(c->d_qnorm); (void)hipFree(c->d_eps);
     (void)hipFree(c->d_tau); (void)hipFree(c->d_dense); (void)hipFree(c->d_cand_count); (void)hipFree(c->d_overflow);
     (void)hipFree(c->d_cand); (void)hipFree(c->d_seg_count); (void)hipFree(c->d_exact); (void)hipFree(c->d_sel);
     (void)hipFree(c->d_tile_max); (void)hipFree(c->d_hits);
@@ -1006,6 +1008,7 @@ int alloc_bctx(wax_hip_engine* e, BatchCtx** out) {
     if (err == hipSuccess) err = hipEventCreateWithFlags(&c->ev_g1, hipEventReleaseToDevice);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&c->ev_gc, hipEventDisableTiming);
     A(&c->d_qb, (size_t)kBatchMaxQ * D * sizeof(unsigned short));
+    A(&c->d_qf, (size_t)kBatchMaxQ * D * sizeof(unsigned short));
     A(&c->d_qn2, kBatchMaxQ * sizeof(float));
     A(&c->d_qnorm, kBatchMaxQ * sizeof(float));
     A(&c->d_eps, kBatchMaxQ * sizeof(float));
@@ -1335,6 +1338,8 @@ int batch_enqueue(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32
     PrepArgs pa{};
     pa.queries = d_queries; pa.nq = qn; pa.nq_pad = nq_pad; pa.dims = D; pa.metric = e->metric; pa.max_norm = b.max_norm;
     pa.max_row_err = e->batch_eps_measured.load() != 0 ? b.max_row_err : 0.f;
+    const bool frag_order = e->batch_qfrag.load() != 0 && (D % 16u) == 0;   // "batch_qfrag" (default 1): fragment-ordered query copy for the rq GEMM
+    pa.qf = frag_order ? c->d_qf : nullptr;
     pa.qb = c->d_qb; pa.q_n2 = c->d_qn2; pa.q_norm = c->d_qnorm; pa.eps = c->d_eps; pa.tau = c->d_tau; pa.overflow = c->d_overflow;
     const bool counted = plan != nullptr && !batch_onepass_fast(D, e->metric);   // one-pass on the LDS-tiled kernel: one counted list per query
     pa.cand_count = (plan && !counted) ? nullptr : c->d_cand_count;
@@ -1344,6 +1349,7 @@ int batch_enqueue(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32
     pa.progress = pace_gate ? c->d_overflow + kBatchMaxQ : nullptr;
     HIP_TRY(launch_batch_prep(pa, st), WAX_HIP_ERR_INTERNAL, "batch prep launch");
     GemmArgs g{};
+    g.qf = frag_order ? c->d_qf : nullptr;
     g.qb = c->d_qb; g.cb = b.d_cb; g.q_n2 = c->d_qn2; g.v_n2 = b.d_vn2; g.tau = c->d_tau;
     g.cand = c->d_cand; g.cand_count = c->d_cand_count; g.row_base = (uint32_t)e->row_base;
     g.dims = D; g.n_rows = n; g.nq = qn; g.nqt = nq_pad / 128;
@@ -2946,6 +2952,7 @@ int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value) {
     else if (k == "done_flag") e->done_flag = value != 0;
     else if (k == "merge_kway") e->merge_kway = value != 0;
     else if (k == "merge_overlap_mb") e->merge_overlap_mb = value < 0 ? 0 : value;
+    else if (k == "batch_qfrag") e->batch_qfrag = value != 0;
     else if (k == "scan_plain_mb") e->scan_plain_mb = value;
     else if (k == "query_args") { if (value < 0 || value > 2) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "query_args must be 0, 1 or 2"); e->query_args = value; }
     else if (k == "batch_min") e->batch_min = value;
@@ -3010,6 +3017,7 @@ int64_t wax_hip_get_tuning(wax_hip_engine* e, const char* key) {
     if (k == "done_flag") return e->done_flag.load();
     if (k == "merge_kway") return e->merge_kway.load();
     if (k == "merge_overlap_mb") return e->merge_overlap_mb.load();
+    if (k == "batch_qfrag") return e->batch_qfrag.load();
     if (k == "overlap_scans") return (int64_t)e->st_overlap_scans.load();
     if (k == "scan_plain_mb") return e->scan_plain_mb.load();
     if (k == "done_flag_waits") return (int64_t)e->st_flag_waits.load();

@@ -190,6 +190,11 @@ constexpr uint32_t CAND_COUNT_STRIDE = 32;
 
 struct GemmArgs {
     const unsigned short* qb;   // [nq_pad][dims] bf16 queries (zero padded to a multiple of 128)
+    // The same queries in MFMA A-FRAGMENT order (register-resident GEMM only; may be null = read qb): for a block of 32 queries and
+    // k-step ks, lane l's 16 bytes (query l & 31, elements 16 ks + 8 (l >> 5) .. + 7) sit at ((block * dims/16 + ks) * 64 + l) * 16 —
+    // a wave's fragment load is then ONE contiguous 1-KB run instead of 32 rows x 32 bytes (dims*2 bytes apart), and a workgroup's
+    // prologue (8 waves x dims/16 loads, every workgroup of the launch the same block of queries) stops thrashing the CU's L1.
+    const unsigned short* qf;
     const unsigned short* cb;   // [n_rows][dims] bf16 corpus mirror
     const float* q_n2;          // [nq_pad] ||q||^2 (L2 epilogue)
     const float* v_n2;          // [n_rows] ||v||^2 (L2 epilogue)
@@ -291,6 +296,7 @@ struct PrepArgs {
     const float* queries; uint32_t nq, nq_pad, dims; int metric; float max_norm;
     float max_row_err;          // max over the mirror's rows of ||x - bf16(x)|| (mirror_kernel; x normalised for cosine); 0 = unknown (worst-case bound)
     unsigned short* qb; float* q_n2; float* q_norm; float* eps; float* tau; uint32_t* overflow;
+    unsigned short* qf;         // the bf16 queries once more in MFMA A-fragment order (GemmArgs::qf; dims % 16 == 0); may be null
     uint32_t* cand_count;       // slab pipeline: per-query append counters to zero (stride CAND_COUNT_STRIDE); may be null
     uint32_t* progress;         // one-pass pipeline: [BATCH_PROGRESS_WORDS] pace-gate words of the filtering GEMM to zero; may be null
     float* q_norm_host;         // [nq] the exact norms once more, straight into pinned host memory (fallback queries need them there); may be null
