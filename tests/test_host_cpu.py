@@ -64,6 +64,22 @@ def test_product_never_imports_oracle():
                 assert "wax_oracle" not in text, f
 
 
+def test_every_settable_tuning_key_is_documented_in_the_header():
+    """The boundary is include/wax_hip.h: a key wax_hip_set_tuning accepts (single-device engine or sharded handle) that the header's
+    tunables block does not name is an undocumented switch behind the shipping ABI."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "wax_amd", "csrc", "engine.hip")).read()
+    i = src.index("int wax_hip_set_tuning(")
+    keys = set(re.findall(r'k == "([a-z_0-9]+)"', src[i:src.index("wax_hip_get_tuning(", i)]))
+    sh = open(os.path.join(root, "wax_amd", "csrc", "sharded.inc")).read()
+    i = sh.index("int sh_set_tuning(")
+    keys |= set(re.findall(r'k == "([a-z_0-9]+)"', sh[i:sh.index("sh_get_tuning(", i)]))
+    documented = set(re.findall(r'"([a-z_0-9]+)"', open(os.path.join(root, "include", "wax_hip.h")).read()))
+    assert len(keys) > 30 and {"time_kernels", "merge_overlap_mb", "batch_qfrag", "exchange", "shard_min_mb"} <= keys
+    assert keys <= documented, sorted(keys - documented)
+
+
 def test_create_argument_validation(hip_lib):
     from wax_amd import _abi
     h = ctypes.c_void_p()
