@@ -15,11 +15,12 @@ is the 1.5 KB query in and the k results out (both included in `value`).
 Rank 0 prints ONE JSON line (contract in the task statement):
   `value`        whole-job queries/s of the timed region, run the way the product runs: queries software-pipelined over two
                  streams, scans free to overlap ("scan_chain" auto: no event chain while kernels are not being timed);
-  `roofline`     achieved HBM GB/s of the scan kernel against the 8 TB/s MI355X peak. `frac` is PER LAUNCH: HIP events
-                 recorded around every scan-kernel launch, on the stream the kernel runs on, in a calibration pass of the
-                 SAME run right after the timed region (same engine, same queries, kernels chained so that a launch runs
-                 alone and its event interval is one kernel). `pipeline_frac` prices the timed region itself:
-                 bytes per launch x steps / elapsed;
+  `roofline`     achieved HBM GB/s of the scan kernel against the 8 TB/s MI355X peak. `frac` is PER LAUNCH: HIP events on
+                 every scan-kernel launch, on the stream the kernel runs on, in calibration passes of the SAME run right
+                 after the timed region (same engine, same queries, kernels chained so that a launch runs alone): the event
+                 pair bound to the dispatch (hipExtLaunchKernel; `events: kernel-bound`), with the mean of the hipEventRecord
+                 bracket around the same launches beside it (`kernel_avg_ms_bracketed`). `pipeline_frac` prices the timed
+                 region itself: bytes per launch x steps / elapsed;
   `cpu_baseline` the oracle's CPU scan timed on this host (rank 0, N=1 only; one thread and all threads);
   `secondary`    the other BASELINE configurations, each with the same barrier/synchronise bracket and its own roofline
                  block. N=1: 10K / 1M x 384 single query (configs 1-2), 1M x 384 with 256 and 1024 queries per step
@@ -532,7 +533,7 @@ def scan_roofline(bytes_per_launch, kern_ms, launches, elapsed, steps, cal, traf
         "algorithmic_bytes_per_launch": bytes_per_launch,
         "calibration": cal,
         "note": "frac = rows_per_gpu*dims*4 bytes per launch / mean HIP-event duration of the scan kernel, per launch, from the "
-                "calibration pass of this run (kernels chained: one at a time); pipeline_frac = the same bytes x steps / the "
+                "calibration pass of this run (kernels chained: one at a time; calibration.events says which event pair); pipeline_frac = the same bytes x steps / the "
                 "timed region's elapsed time (rank 0's shard), i.e. what the overlapped product pipeline sustains end to end",
     }
 
