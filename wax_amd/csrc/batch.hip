@@ -464,8 +464,26 @@ __device__ inline void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N
 // SAMPLE = true (one-pass pipeline, threshold estimation): instead of filtering, the workgroup visits `a.sample_tiles` tiles spread
 // evenly over the slab (logical index i -> tile i * ntiles / sample_tiles) and records, per query, the best similarity of each
 // visited tile in a.tile_max[i][query] (pick_tau_kernel turns the j-th best tile maximum into the query's admission threshold).
-template <int D, int TROWS, int NBUF, int AHEAD, bool SAMPLE, bool SPLIT, bool NT = false>
+template <int D, int TROWS, int NBUF, int AHEAD, bool SAMPLE, bool SPLIT, bool NT = false, bool PROF = false>
 __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint32_t blocks_per_group) {
+    // PROF (diagnosis build of the filtering launch, "batch_prof_ptr"): every wave accumulates the shader cycles (s_memtime) it spends in
+    // each phase of the tile loop in SGPRs and leaves them in a.prof[(workgroup * 8 + wave) * RQ_PROF_WORDS ...]; same answers, ~10 % slower.
+    unsigned int ph[RQ_PROF_WORDS];
+#pragma unroll
+    for (int i = 0; i < RQ_PROF_WORDS; ++i) ph[i] = 0u;
+    auto now = [&]() -> unsigned int {
+        if constexpr (PROF) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned int v = (unsigned int)__builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_sched_barrier(0);
+            return v;
+        } else {
+            return 0u;
+        }
+    };
+    unsigned long long rt0 = 0ull;
+    if constexpr (PROF) rt0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned int k_entry = now();
     constexpr int KS = D / 16;                       // MFMA k-steps
     constexpr int RB = TROWS / 32;                   // 32-row blocks per tile = accumulators per wave
     constexpr int NF = KS * RB;                      // B fragments (= MFMAs) per wave and tile; fragment f = (k-step f / RB, block f % RB)
@@ -667,6 +685,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
             for (int g = 0; g < 4; ++g) any |= hit[b][g];
         }
         if (any == 0ull) return;
+        const unsigned int c0t = now();
         uint32_t seg_o = seg_lane0;                   // opaque: the per-query row offsets are computed HERE (cold path), not
         asm volatile("" : "+v"(seg_o));               // hoisted out of the tile loop into VGPRs that do not exist
 #pragma unroll
@@ -692,9 +711,11 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
                     c0 = c0 + n_lo < 0xFFFFu ? c0 + n_lo : 0xFFFFu;   // not clamped to seg_slots: a count above it tells the finish kernel that survivors were dropped
                     c1 = c1 + n_hi < 0xFFFFu ? c1 + n_hi : 0xFFFFu;
                     cq[r] = c0 | (c1 << 16);
+                    if constexpr (PROF) ph[RQP_SURVIVORS] += n_lo + n_hi;
                 }
             }
         }
+        if constexpr (PROF) { ph[RQP_COLD] += now() - c0t; ph[RQP_COLD_N] += 1u; }
     };
 
     uint32_t t = bidx;
@@ -709,6 +730,8 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
         __builtin_amdgcn_s_barrier();                         // also publishes sim_s / sync_s
         asm volatile("" ::: "memory");
     }
+    const unsigned int k_loop0 = now();
+    if constexpr (PROF) ph[RQP_PROLOGUE] = k_loop0 - k_entry;
     const bool late = wave >= 4;
     // Pace gate (advisory). With G > 1 query groups every corpus tile is wanted G times, by the G workgroups that share a `bidx` —
     // they sit on the same XCD (block -> XCD is blockIdx % 8 and G * blocks_per_group = 256), so the second to G-th reader hit in its
@@ -772,26 +795,42 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
         uint32_t pre_idx = cur_idx + PRE;
         pre_idx = pre_idx >= (uint32_t)NBUF ? pre_idx - NBUF : pre_idx;
         const bool issued = tn < ntiles;
+        const unsigned int p0 = now();
         if (late && it > 0) select_tile(t_prev);
+        const unsigned int p1 = now();
         // every wave is through K loop it - 1 (the buffer tile tn goes to is free) and has its pieces of tile `it` in LDS
         if (SPLIT && it > 0) wait_arrivals(8u * it);
+        const unsigned int p2 = now();
         pace(it);
         if (issued) dma_tile(tn, pre_idx * BUF_B);
+        const unsigned int p3 = now();
         mfma_tile(baddr);
+        const unsigned int p4 = now();
         // tile t + 1 must have landed before the others read it (every wave waits for its own pieces, the barrier / the arrival
         // counter joins them); the PRE - 1 younger tiles stay in flight. The wait sits in FRONT of an early wave's selection:
         // vmcnt counts the selection's survivor stores too (they are older than the requests that stay in flight and complete first)
         dma_wait(issued);
+        const unsigned int p5 = now();
         if (SPLIT) arrive();
         if (!late) select_tile(t);
         t_prev = t;
+        const unsigned int p6 = now();
         if (!SPLIT) {
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
+        if constexpr (PROF) {
+            const unsigned int p7 = now();
+            ph[RQP_SELECT] += (p1 - p0) + (p6 - p5);
+            ph[RQP_WAIT_ARRIVALS] += (p2 - p1) + (p7 - p6);
+            ph[RQP_DMA_ISSUE] += p3 - p2;
+            ph[RQP_KLOOP] += p4 - p3;
+            ph[RQP_DMA_WAIT] += p5 - p4;
+        }
         cur_idx = cur_idx + 1 == (uint32_t)NBUF ? 0u : cur_idx + 1;
         t += blocks_per_group;
     }
+    const unsigned int k_loop1 = now();
     if (late && it > 0) select_tile(t_prev);
     if (gate && tid == 0) __hip_atomic_fetch_add(gate_word, 0u - gate_added - (1u << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // leaving: out of the count and the sum
     if (SPLIT && gave_up && lane == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(sync_addr + 4u), "v"(1u) : "memory");
@@ -808,6 +847,25 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
     if (!SAMPLE && tid < 256) {
         const bool poisoned = SPLIT && sync_s[1] != 0u;       // a wave gave up waiting: nothing this workgroup selected can be trusted
         a.seg_count[(size_t)bidx * (a.nqt * 128u) + group * 256u + (uint32_t)tid] = poisoned ? 0x40000000u : cnt_s[tid];
+    }
+    if constexpr (PROF) {
+        if (a.prof != nullptr) {
+            const unsigned int k_exit = now();
+            ph[RQP_LOOP] = k_loop1 - k_loop0;
+            ph[RQP_EPILOGUE] = k_exit - k_loop1;
+            ph[RQP_TILES] = it;
+            const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+            ph[RQP_RT0_LO] = (unsigned int)rt0; ph[RQP_RT0_HI] = (unsigned int)(rt0 >> 32);
+            ph[RQP_RT1_LO] = (unsigned int)rt1; ph[RQP_RT1_HI] = (unsigned int)(rt1 >> 32);
+            unsigned int xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            ph[RQP_XCC] = xcc;
+            if (lane == 0) {
+                unsigned int* dst = a.prof + ((size_t)blockIdx.x * 8u + (unsigned)wave) * RQ_PROF_WORDS;
+#pragma unroll
+                for (int i = 0; i < RQ_PROF_WORDS; ++i) dst[i] = ph[i];
+            }
+        }
     }
 }
 
@@ -852,17 +910,17 @@ bool batch_gemm_segments(const GemmArgs& a, int metric, uint32_t* nseg, uint32_t
     return true;
 }
 
-template <int D, bool SAMPLE, bool SPLIT, bool NT = false>
+template <int D, bool SAMPLE, bool SPLIT, bool NT = false, bool PROF = false>
 static hipError_t launch_rq(const GemmArgs& a, uint32_t groups, uint32_t per_group, hipStream_t st) {
     using G = RqGeom<D>;
     constexpr size_t smem = rq_smem<D>();
     static_assert(smem <= 160 * 1024, "LDS budget of one CU");
     static std::atomic<uint64_t> configured{0};   // per device (ensure_dynamic_lds)
     {
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&batch_gemm_rq_kernel<D, G::TROWS, G::NBUF, G::AHEAD, SAMPLE, SPLIT, NT>), smem, configured);
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&batch_gemm_rq_kernel<D, G::TROWS, G::NBUF, G::AHEAD, SAMPLE, SPLIT, NT, PROF>), smem, configured);
         if (e != hipSuccess) return e;
     }
-    launch_kernel((batch_gemm_rq_kernel<D, G::TROWS, G::NBUF, G::AHEAD, SAMPLE, SPLIT, NT>), dim3(groups * per_group), dim3(512), smem, st, a, per_group);
+    launch_kernel((batch_gemm_rq_kernel<D, G::TROWS, G::NBUF, G::AHEAD, SAMPLE, SPLIT, NT, PROF>), dim3(groups * per_group), dim3(512), smem, st, a, per_group);
     return hipGetLastError();
 }
 
@@ -872,6 +930,13 @@ static hipError_t launch_rq_filter(const GemmArgs& a, hipStream_t st) {
     rq_geometry(a, &groups, &per_group);
     // "batch_rega" 1: a workgroup barrier per tile instead of the split one (A/B, and the variant the fail-safe test compares with)
     if (a.use_rega == 1u) return launch_rq<D, false, false>(a, groups, per_group, st);
+    // "batch_prof_ptr" (diagnosis): the phase-timing build of the same launch, at the two dimensions of BASELINE configs 3 / 5
+    if constexpr (D == 384 || D == 768) {
+        if (a.prof != nullptr) {
+            if (groups == 1) return launch_rq<D, false, true, true, true>(a, groups, per_group, st);
+            return launch_rq<D, false, true, false, true>(a, groups, per_group, st);
+        }
+    }
     // one query group: every tile is requested exactly once, by one workgroup -> non-temporal requests (-1 ... -3 % at Q = 256; with
     // G > 1 groups sharing tiles through their XCD's L2 the same hint costs 3 - 5 %: profiles/r05/e_nontemporal_tile_requests.txt)
     if (groups == 1) return launch_rq<D, false, true, true>(a, groups, per_group, st);

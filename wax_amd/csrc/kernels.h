@@ -228,6 +228,27 @@ struct GemmArgs {
     // XCD) for the advisory pace gate that keeps the groups walking the corpus within a few tiles of each other, so that a tile
     // fetched for one group is still in the XCD's L2 when the others read it.
     uint32_t* progress;
+    // Diagnosis ("batch_prof_ptr"): non-null = device buffer of [grid * 8 waves][RQ_PROF_WORDS] u32 that the PROF instantiation of the
+    // filtering launch fills with per-wave phase cycle counts (indices RQP_*). Never set by the product path.
+    uint32_t* prof;
+};
+// Words per wave of GemmArgs::prof and what they hold (shader cycles unless said otherwise).
+enum : int {
+    RQP_PROLOGUE = 0,       // kernel entry -> first tile hand-over (A fragments, bounds, first DMA requests landed)
+    RQP_SELECT = 1,         // fused selection, hot + cold
+    RQP_COLD = 2,           // ... of which: tiles with at least one survivor in this wave (the cold path)
+    RQP_COLD_N = 3,         // number of such tiles
+    RQP_WAIT_ARRIVALS = 4,  // split barrier: waiting for the other waves (or the workgroup barrier of "batch_rega" 1)
+    RQP_DMA_ISSUE = 5,      // pace gate + LDS-DMA requests of the next tile
+    RQP_KLOOP = 6,          // ds_read_b128 + MFMA
+    RQP_DMA_WAIT = 7,       // counted vmcnt wait for this wave's pieces of the next tile
+    RQP_LOOP = 8,           // the whole tile loop
+    RQP_EPILOGUE = 9,       // after the loop (last selection, counters, final barrier)
+    RQP_TILES = 10,         // tiles this workgroup multiplied
+    RQP_SURVIVORS = 11,     // survivors this wave stored
+    RQP_RT0_LO = 12, RQP_RT0_HI = 13, RQP_RT1_LO = 14, RQP_RT1_HI = 15,   // s_memrealtime (100 MHz) at entry / exit
+    RQP_XCC = 16,           // HW_REG_XCC_ID
+    RQ_PROF_WORDS = 20
 };
 // Geometry the register-resident kernel will use for these arguments (false: the LDS-tiled kernel runs instead,
 // appending through cand_count).
