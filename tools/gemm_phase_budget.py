@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--tune", action="append", default=[], help="key=value tuning applied before the runs")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--opts", type=int, nargs="+", default=[0], help="batch_opt values to run, one line each")
     args = ap.parse_args()
     import torch
     import wax_amd as wax
@@ -60,6 +61,14 @@ def main():
     for _ in range(3):
         run()
     ref = dout.clone()
+    for opt in args.opts:
+        eng.setTuning("batch_opt", opt)
+        budget(args, eng, torch, dev, run, ref, dout, opt)
+
+
+def budget(args, eng, torch, dev, run, ref, dout, opt):
+    for _ in range(2):
+        run()
     # product kernel, timed by the library's dispatch-bound HIP events
     eng.setTuning("time_kernels", 2)
     eng.setTuning("reset_stats", 1)
@@ -93,7 +102,7 @@ def main():
     wall_wave_us = (rt1 - rt0) / 1e3
     total_cyc = (p[:, :, 0] + p[:, :, 8] + p[:, :, 9]).astype(np.float64)
     ghz = float(np.median(total_cyc / np.maximum(wall_wave_us, 1e-9)) / 1e3)
-    out = {"rows": args.rows, "dims": args.dims, "nq": args.nq, "topk": args.topk, "tune": args.tune,
+    out = {"rows": args.rows, "dims": args.dims, "nq": args.nq, "topk": args.topk, "tune": args.tune, "batch_opt": opt,
            "product_kernel_us_hip_events": prod_us, "prof_kernel_us_hip_events": prof_us, "prof_answers_equal_product": same,
            "workgroups": int(p.shape[0]), "kernel_span_us_first_entry_to_last_exit": span_us,
            "shader_clock_ghz_median_wave": ghz,

@@ -464,7 +464,12 @@ __device__ inline void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N
 // SAMPLE = true (one-pass pipeline, threshold estimation): instead of filtering, the workgroup visits `a.sample_tiles` tiles spread
 // evenly over the slab (logical index i -> tile i * ntiles / sample_tiles) and records, per query, the best similarity of each
 // visited tile in a.tile_max[i][query] (pick_tau_kernel turns the j-th best tile maximum into the query's admission threshold).
-template <int D, int TROWS, int NBUF, int AHEAD, bool SAMPLE, bool SPLIT, bool NT = false, bool PROF = false>
+// OPT (round 6, schedule experiments; bit set = new behaviour): 1 = a late wave selects the previous tile AFTER it has waited for the
+// arrivals and requested the next tile (its own K loop no longer starts a whole selection late); 2 = the hot path of the selection runs
+// at s_setprio 2 (above the partner's K loop, which otherwise starves it to ~15 cycles per instruction); 4 = the K loop does not raise
+// its priority; 8 = the next tile's DMA requests are issued from inside the K loop, one every few MFMAs; 16 = the cold path of the
+// selection keeps the raised priority too.
+template <int D, int TROWS, int NBUF, int AHEAD, bool SAMPLE, bool SPLIT, bool NT = false, bool PROF = false, int OPT = 0>
 __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint32_t blocks_per_group) {
     // PROF (diagnosis build of the filtering launch, "batch_prof_ptr"): every wave accumulates the shader cycles (s_memtime) it spends in
     // each phase of the tile loop in SGPRs and leaves them in a.prof[(workgroup * 8 + wave) * RQ_PROF_WORDS ...]; same answers, ~10 % slower.
@@ -563,9 +568,9 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
             doff[i] = (slot - ((slot * DIV_MAGIC) >> DIV_SHIFT)) * 16u;
         }
     }
-    auto dma_tile = [&](uint32_t tile, uint32_t buf_off) {
-#pragma unroll
-        for (int i = 0; i < PPW; ++i) {
+    auto dma_piece = [&](auto I, uint32_t tile, uint32_t buf_off) {
+        constexpr int i = decltype(I)::value;
+        {
             if (i < PPW - 1 || full_wave) {
                 const uint32_t P = (uint32_t)wave + 8u * (uint32_t)i;
                 if constexpr (SAMPLE) {
@@ -600,6 +605,9 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
             }
         }
     };
+    auto dma_tile = [&](uint32_t tile, uint32_t buf_off) {
+        static_for<0, PPW>([&](auto I) { dma_piece(I, tile, buf_off); });
+    };
     // this wave's DMA requests still allowed in flight: PRE - 1 whole tiles, or none
     auto dma_wait = [&](bool keep) {
         if (!keep) wait_vmcnt<0>();
@@ -613,7 +621,9 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
     // K loop. Fragment f + AHEAD is requested before MFMA f; the wait in front of MFMA f leaves at most min(AHEAD, NF - 1 - f)
     // younger reads outstanding. Every step is pinned (sched_barrier) — hipcc otherwise hoists an MFMA over the asm wait it depends
     // on. s_setprio 1 lets the multiplying wave win issue arbitration against its selecting partner.
-    auto mfma_tile = [&](uint32_t baddr) {
+    constexpr bool DMA_IN_K = !SAMPLE && (OPT & 8) != 0;
+    constexpr int DMA_STEP = NF / (PPW + 1);          // OPT 8: piece i goes in front of MFMA DMA_STEP * (i + 1) - 2
+    auto mfma_tile = [&](uint32_t baddr, bool dma_on, uint32_t dma_t, uint32_t dma_off) {
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         u32x4 fb[RING];
         static_for<0, (AHEAD < NF ? AHEAD : NF)>([&](auto F) {
@@ -622,13 +632,17 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
             const uint32_t ba = baddr;
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fbr[f % RING]) : "v"(ba), "n"((f % RB) * 32 * ROW_B + (f / RB) * 32));
         });
-        __builtin_amdgcn_s_setprio(1);
+        if constexpr (!(OPT & 4)) __builtin_amdgcn_s_setprio(1);
         __builtin_amdgcn_sched_barrier(0);
         static_for<0, NF>([&](auto F) {
             constexpr int f = decltype(F)::value;
             constexpr int g = f + AHEAD;
             u32x4(&fbr)[RING] = fb;
             const uint32_t ba = baddr;
+            if constexpr (DMA_IN_K && DMA_STEP >= 2 && (f + 2) % DMA_STEP == 0 && (f + 2) / DMA_STEP >= 1 && (f + 2) / DMA_STEP <= PPW) {
+                if (dma_on) dma_piece(std::integral_constant<int, (f + 2) / DMA_STEP - 1>{}, dma_t, dma_off);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if constexpr (g < NF)
                 asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fbr[g % RING]) : "v"(ba), "n"((g % RB) * 32 * ROW_B + (g / RB) * 32));
             constexpr int younger = (NF - 1 - f) < AHEAD ? (NF - 1 - f) : AHEAD;
@@ -638,7 +652,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
             acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], __builtin_bit_cast(bf16x8, fbr[f % RING]), ks == 0 ? zero16 : acc[rb], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         });
-        __builtin_amdgcn_s_setprio(0);
+        if constexpr (!(OPT & 4)) __builtin_amdgcn_s_setprio(0);
     };
     // Fused selection on one tile. C/D layout of the 32x32 MFMA: column = lane & 31 (corpus row of the block), row =
     // (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (query of the wave). Hot path: 16 RB compares against the bounds (one LDS round trip:
@@ -664,6 +678,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
             }
             return;
         }
+        if constexpr ((OPT & 2) != 0) __builtin_amdgcn_s_setprio(2);
         f32x4 lo[4];
         static_for<0, 4>([&](auto J) {
             constexpr int j = decltype(J)::value;
@@ -684,7 +699,11 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
 #pragma unroll
             for (int g = 0; g < 4; ++g) any |= hit[b][g];
         }
-        if (any == 0ull) return;
+        if constexpr ((OPT & 2) != 0 && (OPT & 16) == 0) __builtin_amdgcn_s_setprio(0);
+        if (any == 0ull) {
+            if constexpr ((OPT & 16) != 0) __builtin_amdgcn_s_setprio(0);
+            return;
+        }
         const unsigned int c0t = now();
         uint32_t seg_o = seg_lane0;                   // opaque: the per-query row offsets are computed HERE (cold path), not
         asm volatile("" : "+v"(seg_o));               // hoisted out of the tile loop into VGPRs that do not exist
@@ -715,6 +734,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
                 }
             }
         }
+        if constexpr ((OPT & 16) != 0) __builtin_amdgcn_s_setprio(0);
         if constexpr (PROF) { ph[RQP_COLD] += now() - c0t; ph[RQP_COLD_N] += 1u; }
     };
 
@@ -795,16 +815,20 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
         uint32_t pre_idx = cur_idx + PRE;
         pre_idx = pre_idx >= (uint32_t)NBUF ? pre_idx - NBUF : pre_idx;
         const bool issued = tn < ntiles;
+        constexpr bool LATE_AFTER = (OPT & 1) != 0;
         const unsigned int p0 = now();
-        if (late && it > 0) select_tile(t_prev);
+        if (!LATE_AFTER && late && it > 0) select_tile(t_prev);
         const unsigned int p1 = now();
         // every wave is through K loop it - 1 (the buffer tile tn goes to is free) and has its pieces of tile `it` in LDS
         if (SPLIT && it > 0) wait_arrivals(8u * it);
         const unsigned int p2 = now();
         pace(it);
-        if (issued) dma_tile(tn, pre_idx * BUF_B);
+        if (!DMA_IN_K && issued) dma_tile(tn, pre_idx * BUF_B);
         const unsigned int p3 = now();
-        mfma_tile(baddr);
+        if (LATE_AFTER && late && it > 0) select_tile(t_prev);
+        const unsigned int p3b = now();
+        if constexpr (PROF && LATE_AFTER) ph[RQP_SELECT] += p3b - p3;
+        mfma_tile(baddr, issued, tn, pre_idx * BUF_B);
         const unsigned int p4 = now();
         // tile t + 1 must have landed before the others read it (every wave waits for its own pieces, the barrier / the arrival
         // counter joins them); the PRE - 1 younger tiles stay in flight. The wait sits in FRONT of an early wave's selection:
@@ -824,7 +848,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
             ph[RQP_SELECT] += (p1 - p0) + (p6 - p5);
             ph[RQP_WAIT_ARRIVALS] += (p2 - p1) + (p7 - p6);
             ph[RQP_DMA_ISSUE] += p3 - p2;
-            ph[RQP_KLOOP] += p4 - p3;
+            ph[RQP_KLOOP] += p4 - p3b;
             ph[RQP_DMA_WAIT] += p5 - p4;
         }
         cur_idx = cur_idx + 1 == (uint32_t)NBUF ? 0u : cur_idx + 1;
@@ -910,17 +934,17 @@ bool batch_gemm_segments(const GemmArgs& a, int metric, uint32_t* nseg, uint32_t
     return true;
 }
 
-template <int D, bool SAMPLE, bool SPLIT, bool NT = false, bool PROF = false>
+template <int D, bool SAMPLE, bool SPLIT, bool NT = false, bool PROF = false, int OPT = 0>
 static hipError_t launch_rq(const GemmArgs& a, uint32_t groups, uint32_t per_group, hipStream_t st) {
     using G = RqGeom<D>;
     constexpr size_t smem = rq_smem<D>();
     static_assert(smem <= 160 * 1024, "LDS budget of one CU");
     static std::atomic<uint64_t> configured{0};   // per device (ensure_dynamic_lds)
     {
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&batch_gemm_rq_kernel<D, G::TROWS, G::NBUF, G::AHEAD, SAMPLE, SPLIT, NT, PROF>), smem, configured);
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&batch_gemm_rq_kernel<D, G::TROWS, G::NBUF, G::AHEAD, SAMPLE, SPLIT, NT, PROF, OPT>), smem, configured);
         if (e != hipSuccess) return e;
     }
-    launch_kernel((batch_gemm_rq_kernel<D, G::TROWS, G::NBUF, G::AHEAD, SAMPLE, SPLIT, NT, PROF>), dim3(groups * per_group), dim3(512), smem, st, a, per_group);
+    launch_kernel((batch_gemm_rq_kernel<D, G::TROWS, G::NBUF, G::AHEAD, SAMPLE, SPLIT, NT, PROF, OPT>), dim3(groups * per_group), dim3(512), smem, st, a, per_group);
     return hipGetLastError();
 }
 
@@ -932,6 +956,26 @@ static hipError_t launch_rq_filter(const GemmArgs& a, hipStream_t st) {
     if (a.use_rega == 1u) return launch_rq<D, false, false>(a, groups, per_group, st);
     // "batch_prof_ptr" (diagnosis): the phase-timing build of the same launch, at the two dimensions of BASELINE configs 3 / 5
     if constexpr (D == 384 || D == 768) {
+        // "batch_opt" (round 6 schedule experiments, see the kernel's OPT): the compiled combinations
+#define WAX_RQ_OPT_CASE(O)                                                                                              \
+        case O:                                                                                                         \
+            if (a.prof != nullptr) {                                                                                    \
+                if (groups == 1) return launch_rq<D, false, true, true, true, O>(a, groups, per_group, st);             \
+                return launch_rq<D, false, true, false, true, O>(a, groups, per_group, st);                             \
+            }                                                                                                           \
+            if (groups == 1) return launch_rq<D, false, true, true, false, O>(a, groups, per_group, st);                \
+            return launch_rq<D, false, true, false, false, O>(a, groups, per_group, st);
+        switch (a.opt) {
+            WAX_RQ_OPT_CASE(1)
+            WAX_RQ_OPT_CASE(2)
+            WAX_RQ_OPT_CASE(3)
+            WAX_RQ_OPT_CASE(7)
+            WAX_RQ_OPT_CASE(11)
+            WAX_RQ_OPT_CASE(19)
+            WAX_RQ_OPT_CASE(27)
+            default: break;
+        }
+#undef WAX_RQ_OPT_CASE
         if (a.prof != nullptr) {
             if (groups == 1) return launch_rq<D, false, true, true, true>(a, groups, per_group, st);
             return launch_rq<D, false, true, false, true>(a, groups, per_group, st);

@@ -426,6 +426,7 @@ struct wax_hip_engine {
     std::atomic<int64_t> batch_slab_mb{64};  // cap on slab size, in units of 16 384 rows
     std::atomic<int64_t> batch_growth{8};    // next slab = growth x rows seen so far
     std::atomic<int64_t> batch_first{2048};  // rows of the dense first slab (<= kBatchFirstSlab)
+    std::atomic<int64_t> batch_opt{0};       // schedule variant of the rq filtering GEMM at D = 384 / 768 (GemmArgs::opt)
     std::atomic<int64_t> batch_prof_ptr{0};  // diagnosis: device address of the phase-timing buffer of the filtering GEMM (GemmArgs::prof); 0 = the product kernel
     std::atomic<int64_t> batch_debug{0};     // test / diagnosis bits, none of which can change an answer: 4096 = no pace gate, 16384 = one wave of workgroup 1 pretends its split-barrier wait timed out, 65536 = the device-side retry re-scores every survivor
     std::atomic<int64_t> batch_rega{5};      // register-resident-queries GEMM where it applies: 5 (default) split tile barrier, 1 workgroup barrier per tile; 0 = the LDS-tiled kernel instead
@@ -1357,6 +1358,7 @@ int batch_enqueue(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32
     g.use_rega = (uint32_t)e->batch_rega.load();  // 0 LDS-tiled kernel, 1 workgroup barrier per tile, 5 split barrier (default)
     g.debug = (uint32_t)e->batch_debug.load();
     g.prof = reinterpret_cast<uint32_t*>((uintptr_t)e->batch_prof_ptr.load());
+    g.opt = (uint32_t)e->batch_opt.load();
     g.seg_count = c->d_seg_count;
     if (plan) {
         // ---- one pass: sample -> threshold -> filter everything -> finish ----
@@ -2962,6 +2964,7 @@ int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value) {
     else if (k == "batch_rega") { if (value != 0 && value != 1 && value != 5) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_rega must be 0, 1 or 5"); e->batch_rega = value; }
     else if (k == "batch_debug") { if (value & ~(int64_t)(4096 | 16384 | 65536)) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_debug: bits 4096, 16384, 65536 only"); e->batch_debug = value; }
     else if (k == "batch_prof_ptr") e->batch_prof_ptr = value;
+    else if (k == "batch_opt") e->batch_opt = value;
     else if (k == "batch_onepass") e->batch_onepass = value;
     else if (k == "batch_onepass_tiles") { if (value < 1024) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_onepass_tiles must be >= 1024"); e->batch_onepass_tiles = value; }
     else if (k == "batch_kp_fused") e->batch_kp_fused = value != 0;
