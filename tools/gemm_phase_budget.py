@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--tune", action="append", default=[], help="key=value tuning applied before the runs")
     ap.add_argument("--out", default=None)
     ap.add_argument("--opts", type=int, nargs="+", default=[0], help="batch_opt values to run, one line each")
+    ap.add_argument("--ab-rounds", type=int, default=0, help="rounds of the interleaved product-kernel A/B over --opts (0 = none)")
     args = ap.parse_args()
     import torch
     import wax_amd as wax
@@ -61,12 +62,27 @@ def main():
     for _ in range(3):
         run()
     ref = dout.clone()
-    for opt in args.opts:
+    # interleaved A/B of the product kernels: the clock drifts by +-10 % within a process, so every variant is timed in every round
+    # and the medians over the rounds are compared
+    times = {o: [] for o in args.opts}
+    if args.ab_rounds:
+        eng.setTuning("time_kernels", 2)
+        for _ in range(args.ab_rounds):
+            for o in dict.fromkeys(args.opts):
+                eng.setTuning("batch_opt", o)
+                run()
+                eng.setTuning("reset_stats", 1)
+                for _ in range(args.reps):
+                    run()
+                stt = eng.stats()
+                times[o].append(stt.batch_gemm_ms_total / max(stt.batch_gemms_timed, 1) * 1e3)
+        eng.setTuning("time_kernels", 0)
+    for opt in dict.fromkeys(args.opts):
         eng.setTuning("batch_opt", opt)
-        budget(args, eng, torch, dev, run, ref, dout, opt)
+        budget(args, eng, torch, dev, run, ref, dout, opt, times[opt])
 
 
-def budget(args, eng, torch, dev, run, ref, dout, opt):
+def budget(args, eng, torch, dev, run, ref, dout, opt, ab_times):
     for _ in range(2):
         run()
     # product kernel, timed by the library's dispatch-bound HIP events
@@ -103,7 +119,8 @@ def budget(args, eng, torch, dev, run, ref, dout, opt):
     total_cyc = (p[:, :, 0] + p[:, :, 8] + p[:, :, 9]).astype(np.float64)
     ghz = float(np.median(total_cyc / np.maximum(wall_wave_us, 1e-9)) / 1e3)
     out = {"rows": args.rows, "dims": args.dims, "nq": args.nq, "topk": args.topk, "tune": args.tune, "batch_opt": opt,
-           "product_kernel_us_hip_events": prod_us, "prof_kernel_us_hip_events": prof_us, "prof_answers_equal_product": same,
+           "product_kernel_us_hip_events": prod_us, "product_kernel_us_ab_median": (float(np.median(ab_times)) if ab_times else None),
+           "product_kernel_us_ab_rounds": [round(x, 1) for x in ab_times], "prof_kernel_us_hip_events": prof_us, "prof_answers_equal_product": same,
            "workgroups": int(p.shape[0]), "kernel_span_us_first_entry_to_last_exit": span_us,
            "shader_clock_ghz_median_wave": ghz,
            "workgroup_start_skew_us": {"p50": float(np.median(wg_start) / 1e3), "max": float(wg_start.max() / 1e3)},

@@ -160,6 +160,23 @@ __device__ inline float group_max32(float v) {
     return v;
 }
 
+template <int CTRL, int ROW_MASK>
+__device__ inline unsigned dpp_or(unsigned v) {
+    // lanes outside ROW_MASK, and lanes whose source is out of range, receive 0
+    const int moved = __builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, true);
+    return v | (unsigned)moved;
+}
+// OR of v over the 64 lanes (wave-uniform result)
+__device__ inline unsigned wave_or32(unsigned v) {
+    v = dpp_or<0x111, 0xF>(v);      // row_shr:1
+    v = dpp_or<0x112, 0xF>(v);      // row_shr:2
+    v = dpp_or<0x114, 0xF>(v);      // row_shr:4
+    v = dpp_or<0x118, 0xF>(v);      // row_shr:8 — lane 15 of every row holds its row
+    v = dpp_or<0x142, 0xA>(v);      // row_bcast15 into rows 1, 3
+    v = dpp_or<0x143, 0xC>(v);      // row_bcast31 into rows 2, 3 — lane 63 holds the wave
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // ---------------------------------------------------------------------------
 // bf16 GEMM tile: 128 queries (M) x 128 corpus rows (N), K chunks of 64, 4 waves each 64x64
 // (2x2 v_mfma_f32_32x32x16_bf16 blocks). Both operands are K-contiguous ("NT" GEMM), so every
@@ -546,6 +563,8 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
         sim_s[wave * 32 + lane] = (1.0f - tq) - 4e-7f * (1.0f + __builtin_fabsf(tq));
     }
     if (SPLIT && tid < 2) sync_s[tid] = 0u;
+    if ((OPT & 256) != 0 && tid < 256) cnt_s[tid] = 0u;       // OPT 256: the survivor counters live here from the start (LDS returning adds)
+    const uint32_t cnt_lane0 = (uint32_t)(size_t)(lds_void*)cnt_s + (uint32_t)(wave * 32 + 4 * (lane >> 5)) * 4u;
     const uint32_t seg_slots = a.seg_area / blocks_per_group;
     const uint32_t seg_lane0 = (q0 + 4u * ((uint32_t)lane >> 5)) * a.cand_cap + a.seg_base + bidx * seg_slots;
 
@@ -688,6 +707,105 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
         });
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        // one survivor test of accumulator (b, r) — the cold path's unit of work, whichever hot test led here
+        auto emit = [&](auto B, auto R, uint32_t seg_o) {
+            constexpr int b = decltype(B)::value, r = decltype(R)::value;
+            const uint32_t row0 = a.slab0 + tile * TROWS + (uint32_t)(b * 32) + (uint32_t)(lane & 31);
+            const bool p = row0 < slab_end && acc[b][r] >= lo[r >> 2][r & 3];
+            const unsigned long long m = __ballot(p);
+            if (m == 0ull) return;
+            const unsigned n_lo = (unsigned)__builtin_popcount((unsigned)m), n_hi = (unsigned)__builtin_popcount((unsigned)(m >> 32));
+            const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            unsigned c0 = cq[r] & 0xFFFFu, c1 = cq[r] >> 16;
+            const unsigned off = lane < 32 ? c0 + below : c1 + (below - n_lo);
+            if (p && off < seg_slots) {
+                const uint32_t e0 = seg_o + (uint32_t)((r & 3) + 8 * (r >> 2)) * a.cand_cap;
+                a.cand[e0 + off] = make_key((1.0f - acc[b][r]) + 0.0f, a.row_base + row0);
+            }
+            c0 = c0 + n_lo < 0xFFFFu ? c0 + n_lo : 0xFFFFu;   // not clamped to seg_slots: a count above it tells the finish kernel that survivors were dropped
+            c1 = c1 + n_hi < 0xFFFFu ? c1 + n_hi : 0xFFFFu;
+            cq[r] = c0 | (c1 << 16);
+            if constexpr (PROF) ph[RQP_SURVIVORS] += n_lo + n_hi;
+        };
+        if constexpr ((OPT & 32) != 0) {
+            // Hot test without a single VALU -> SGPR -> SALU hand-over (each v_cmp + s_or pair of the form below costs ~47 cycles beside the
+            // partner's K loop: profiles/r06): per accumulator a subtraction and a funnel shift that pushes the sign of (acc - bound)
+            // into a per-lane mask (1 = fails; NaN may read as "passes" here, the exact comparison in `emit` decides); one ballot per tile.
+            constexpr int NM = (RB + 1) / 2;
+            unsigned fm[NM];
+#pragma unroll
+            for (int m_ = 0; m_ < NM; ++m_) fm[m_] = 0u;
+#pragma unroll
+            for (int b = 0; b < RB; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    fm[b >> 1] = __builtin_amdgcn_alignbit(fm[b >> 1], __float_as_uint(acc[b][r] - lo[r >> 2][r & 3]), 31u);
+            unsigned pm[NM], anyp = 0u;
+#pragma unroll
+            for (int m_ = 0; m_ < NM; ++m_) {
+                const unsigned valid = (2 * m_ + 1 < RB) ? 0xFFFFFFFFu : 0xFFFFu;   // an odd last block fills 16 bits only
+                pm[m_] = ~fm[m_] & valid;
+                anyp |= pm[m_];
+            }
+            const bool none = __ballot(anyp != 0u) == 0ull;
+            if constexpr ((OPT & 2) != 0 && (OPT & 16) == 0) __builtin_amdgcn_s_setprio(0);
+            if (none) {
+                if constexpr ((OPT & 16) != 0) __builtin_amdgcn_s_setprio(0);
+                return;
+            }
+            const unsigned int c0t = now();
+            uint32_t seg_o = seg_lane0;
+            asm volatile("" : "+v"(seg_o));
+            unsigned wm[NM];
+#pragma unroll
+            for (int m_ = 0; m_ < NM; ++m_) wm[m_] = wave_or32(pm[m_]);
+            if constexpr ((OPT & 256) != 0) {
+                // Lane-parallel cold path: no ballot, no SGPR counter. Per group of four accumulators that holds a survivor anywhere in the
+                // wave (scalar test on the OR-ed masks), every lane with a passing bit picks its accumulator by three selects, takes a slot
+                // from the (workgroup, query) counter in LDS with a returning add, and stores its key — all survivors of the group at once.
+                static_for<0, RB>([&](auto B) {
+                    constexpr int b = decltype(B)::value;
+                    constexpr int nbits = (2 * (b >> 1) + 1 < RB) ? 32 : 16;
+                    static_for<0, 4>([&](auto G) {
+                        constexpr int g = decltype(G)::value;
+                        constexpr int shift = nbits - 1 - ((b & 1) * 16 + 4 * g + 3);   // nibble bit pb <-> r = 4 g + 3 - pb
+                        if (wm[b >> 1] & (0xFu << shift)) {
+                            unsigned nib = (pm[b >> 1] >> shift) & 0xFu;
+                            const uint32_t row0 = a.slab0 + tile * TROWS + (uint32_t)(b * 32) + (uint32_t)(lane & 31);
+                            const bool ok0 = row0 < slab_end;
+                            for (;;) {
+                                if (__ballot(nib != 0u) == 0ull) break;
+                                const unsigned pb = (unsigned)__builtin_ctz(nib | 16u);
+                                const float val = pb == 0u ? acc[b][4 * g + 3] : pb == 1u ? acc[b][4 * g + 2] : pb == 2u ? acc[b][4 * g + 1] : acc[b][4 * g];
+                                const float lov = pb == 0u ? lo[g][3] : pb == 1u ? lo[g][2] : pb == 2u ? lo[g][1] : lo[g][0];
+                                if (nib != 0u && ok0 && val >= lov) {
+                                    const unsigned ql = (3u - pb) + 8u * (unsigned)g;   // + 4 (lane >> 5): folded into the lane bases
+                                    unsigned slot;
+                                    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(slot) : "v"(cnt_lane0 + ql * 4u), "v"(1u) : "memory");
+                                    if (slot < seg_slots) a.cand[seg_o + ql * a.cand_cap + slot] = make_key((1.0f - val) + 0.0f, a.row_base + row0);
+                                }
+                                nib &= nib - 1u;
+                            }
+                        }
+                    });
+                });
+                if constexpr ((OPT & 16) != 0) __builtin_amdgcn_s_setprio(0);
+                if constexpr (PROF) { ph[RQP_COLD] += now() - c0t; ph[RQP_COLD_N] += 1u; }
+                return;
+            }
+            static_for<0, RB>([&](auto B) {
+                constexpr int b = decltype(B)::value;
+                constexpr int nbits = (2 * (b >> 1) + 1 < RB) ? 32 : 16;        // elements in this block's mask
+                static_for<0, 16>([&](auto R) {
+                    constexpr int r = decltype(R)::value;
+                    constexpr int idx = (b & 1) * 16 + r;                       // position in processing order within the mask
+                    if (wm[b >> 1] & (1u << (nbits - 1 - idx))) emit(B, R, seg_o);
+                });
+            });
+            if constexpr ((OPT & 16) != 0) __builtin_amdgcn_s_setprio(0);
+            if constexpr (PROF) { ph[RQP_COLD] += now() - c0t; ph[RQP_COLD_N] += 1u; }
+            return;
+        }
         unsigned long long hit[RB][4];
         unsigned long long any = 0ull;
 #pragma unroll
@@ -707,33 +825,14 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
         const unsigned int c0t = now();
         uint32_t seg_o = seg_lane0;                   // opaque: the per-query row offsets are computed HERE (cold path), not
         asm volatile("" : "+v"(seg_o));               // hoisted out of the tile loop into VGPRs that do not exist
-#pragma unroll
-        for (int b = 0; b < RB; ++b) {
-            const uint32_t row0 = a.slab0 + tile * TROWS + (uint32_t)(b * 32) + (uint32_t)(lane & 31);
-            const bool ok0 = row0 < slab_end;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if (hit[b][g] == 0ull) continue;
-#pragma unroll
-                for (int r = 4 * g; r < 4 * g + 4; ++r) {
-                    const bool p = ok0 && acc[b][r] >= lo[r >> 2][r & 3];
-                    const unsigned long long m = __ballot(p);
-                    if (m == 0ull) continue;
-                    const unsigned n_lo = (unsigned)__builtin_popcount((unsigned)m), n_hi = (unsigned)__builtin_popcount((unsigned)(m >> 32));
-                    const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                    unsigned c0 = cq[r] & 0xFFFFu, c1 = cq[r] >> 16;
-                    const unsigned off = lane < 32 ? c0 + below : c1 + (below - n_lo);
-                    if (p && off < seg_slots) {
-                        const uint32_t e0 = seg_o + (uint32_t)((r & 3) + 8 * (r >> 2)) * a.cand_cap;
-                        a.cand[e0 + off] = make_key((1.0f - acc[b][r]) + 0.0f, a.row_base + row0);
-                    }
-                    c0 = c0 + n_lo < 0xFFFFu ? c0 + n_lo : 0xFFFFu;   // not clamped to seg_slots: a count above it tells the finish kernel that survivors were dropped
-                    c1 = c1 + n_hi < 0xFFFFu ? c1 + n_hi : 0xFFFFu;
-                    cq[r] = c0 | (c1 << 16);
-                    if constexpr (PROF) ph[RQP_SURVIVORS] += n_lo + n_hi;
-                }
-            }
-        }
+        static_for<0, RB>([&](auto B) {
+            constexpr int b = decltype(B)::value;
+            static_for<0, 4>([&](auto G) {
+                constexpr int g = decltype(G)::value;
+                if (hit[b][g] != 0ull)
+                    static_for<4 * g, 4 * g + 4>([&](auto R) { emit(B, R, seg_o); });
+            });
+        });
         if constexpr ((OPT & 16) != 0) __builtin_amdgcn_s_setprio(0);
         if constexpr (PROF) { ph[RQP_COLD] += now() - c0t; ph[RQP_COLD_N] += 1u; }
     };
@@ -795,7 +894,13 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
     // SPLIT: bounded spin on the arrival counter. The counter is touched through inline assembly only (point 1 above).
     bool gave_up = SPLIT && (a.debug & 16384u) != 0 && blockIdx.x == 1 && wave == 3;   // "batch_debug" bit 14: pretend one wave timed out (tests)
     const unsigned sync_addr = (unsigned)(size_t)(lds_u32*)sync_s;
+    unsigned int arr_rtn = 0u;                                // OPT 64 (lane 0): the arrival counter as this wave's last arrive found it
     auto wait_arrivals = [&](unsigned int target) {
+        if constexpr ((OPT & 64) != 0) {
+            // the wave that arrived LAST knows so from its own (returning) add: no poll, no LDS round trip on the critical path
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if ((unsigned int)__builtin_amdgcn_readfirstlane((int)arr_rtn) + 1u >= target) return;
+        }
         bool ok = false;
         for (unsigned int spins = 0; spins < (1u << 22); ++spins) {
             unsigned int v;
@@ -806,7 +911,15 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
         if (!ok) gave_up = true;
     };
     auto arrive = [&]() {
-        if (lane == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\tds_add_u32 %0, %1" ::"v"(sync_addr), "v"(1u) : "memory");
+        if constexpr ((OPT & 64) != 0) {
+            // (no branch around the asm: its result lands asynchronously, so the register must not pass through a phi copy; lane 0 alone
+            // is switched on inside)
+            unsigned long long ex;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tds_add_rtn_u32 %0, %2, %3\n\ts_mov_b64 exec, %1"
+                         : "=v"(arr_rtn), "=&s"(ex) : "v"(sync_addr), "v"(1u) : "memory");
+        } else {
+            if (lane == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\tds_add_u32 %0, %1" ::"v"(sync_addr), "v"(1u) : "memory");
+        }
     };
     uint32_t it = 0, cur_idx = 0, t_prev = 0;
     for (; t < ntiles; ++it) {
@@ -858,7 +971,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
     if (late && it > 0) select_tile(t_prev);
     if (gate && tid == 0) __hip_atomic_fetch_add(gate_word, 0u - gate_added - (1u << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // leaving: out of the count and the sum
     if (SPLIT && gave_up && lane == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(sync_addr + 4u), "v"(1u) : "memory");
-    if (!SAMPLE) {   // the wave's 32 survivor counters, SGPRs -> LDS: lane q takes query q's
+    if (!SAMPLE && (OPT & 256) == 0) {   // the wave's 32 survivor counters, SGPRs -> LDS: lane q takes query q's
         unsigned mine = 0u;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -966,13 +1079,10 @@ static hipError_t launch_rq_filter(const GemmArgs& a, hipStream_t st) {
             if (groups == 1) return launch_rq<D, false, true, true, false, O>(a, groups, per_group, st);                \
             return launch_rq<D, false, true, false, false, O>(a, groups, per_group, st);
         switch (a.opt) {
-            WAX_RQ_OPT_CASE(1)
-            WAX_RQ_OPT_CASE(2)
-            WAX_RQ_OPT_CASE(3)
-            WAX_RQ_OPT_CASE(7)
-            WAX_RQ_OPT_CASE(11)
-            WAX_RQ_OPT_CASE(19)
-            WAX_RQ_OPT_CASE(27)
+            WAX_RQ_OPT_CASE(32)
+            WAX_RQ_OPT_CASE(96)
+            WAX_RQ_OPT_CASE(288)
+            WAX_RQ_OPT_CASE(352)
             default: break;
         }
 #undef WAX_RQ_OPT_CASE

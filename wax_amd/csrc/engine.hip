@@ -1741,6 +1741,7 @@ int wax_hip_engine_create(uint8_t metric, uint32_t dims, int device_id, wax_hip_
     e->device = dev;
     e->metric = metric;
     e->dims = dims;
+    if (const char* v = std::getenv("WAX_HIP_BATCH_OPT")) e->batch_opt = std::atoll(v);   // default of "batch_opt" (A/B runs of the whole test suite)
     if (const char* v = std::getenv("WAX_HIP_BATCH_REGA")) {  // default of the "batch_rega" tunable (A/B runs of the whole test suite)
         const long m = std::strtol(v, nullptr, 10);
         if (m == 0 || m == 1 || m == 5) e->batch_rega = m;
