@@ -313,7 +313,7 @@ def run_pipelined(submit, collect, qs, depth):
     return last
 
 
-def measure_single_query(eng, submit, collect, queries, warmup, steps, depth, barrier, chain_timed_region=False):
+def measure_single_query(eng, submit, collect, queries, warmup, steps, depth, barrier, chain_timed_region=False, floor_ms=0.0):
     """warm-up, then EXACTLY `steps` timed steps bracketed by barrier(); then the per-launch calibration pass.
     Returns (elapsed_s, last_result, kernel_avg_ms, launches_timed, calibration dict)."""
     eng.setTuning("time_kernels", 1 if chain_timed_region else 0)
@@ -359,7 +359,7 @@ def measure_single_query(eng, submit, collect, queries, warmup, steps, depth, ba
     kb_ms = None
     if EVENT_MODE == "bound":
         kb_ms, kb_n, kb_el = cal_pass(2)
-        if kb_n and br_n and kernel_bound_plausible(kb_ms, br_ms):
+        if kb_n and br_n and kernel_bound_plausible(kb_ms, br_ms, floor_ms):
             kern_ms, launches, cal_el, events = kb_ms, kb_n, kb_el, "kernel-bound"
     eng.setTuning("time_kernels", 0)
     return elapsed, last, kern_ms, launches, {
@@ -377,10 +377,13 @@ BATCH_DEPTH = 0          # --batch-depth: batches in flight of the batched secon
 EVENT_MODE = "bound"     # --events: "bound" (default) = frac from kernel-bound HIP events, "bracket" = rounds 1-4's hipEventRecord bracket
 
 
-def kernel_bound_plausible(kb_ms, br_ms):
+def kernel_bound_plausible(kb_ms, br_ms, floor_ms=0.0):
     """A kernel-bound interval is the bracketed one minus the packets around the kernel: never longer than it (2 % of jitter allowed),
-    and not shorter by more than 40 us + 10 % (the packets cost ~10 us). Anything else is a runtime that did not bind the pair."""
-    return kb_ms == kb_ms and br_ms == br_ms and kb_ms > 0 and kb_ms <= br_ms * 1.02 + 0.002 and kb_ms >= br_ms * 0.9 - 0.04
+    not shorter by more than 40 us + 10 % (the packets cost ~10 us), never below a quarter of the bracket (short kernels: 0.9 x - 40 us
+    is negative under 44 us, which used to accept ANY positive interval — advisor, round 5) and never below `floor_ms`, the time the
+    launch's algorithmic bytes take at the peak rate. Anything else is a runtime that did not bind the pair."""
+    return (kb_ms == kb_ms and br_ms == br_ms and kb_ms > 0 and kb_ms <= br_ms * 1.02 + 0.002 and kb_ms >= br_ms * 0.9 - 0.04
+            and kb_ms >= 0.25 * br_ms and kb_ms >= floor_ms)
 
 
 TRAFFIC_CHILD_WARM, TRAFFIC_CHILD_LAUNCHES = 2, 6
@@ -566,7 +569,8 @@ def secondary_single_query(torch, dev, rows, dims, k, steps, warmup, depth, labe
     eng.setTuning("slots", max(depth, 2))
     apply_tunes(eng)
     elapsed, last, kern_ms, launches, cal = measure_single_query(
-        eng, lambda q: eng.submit(q, k), lambda t: eng.collect(t, k), queries, warmup, steps, depth, lambda: _bracket(torch))
+        eng, lambda q: eng.submit(q, k), lambda t: eng.collect(t, k), queries, warmup, steps, depth, lambda: _bracket(torch),
+        floor_ms=rows * dims * 4 / (HBM_PEAK_GBPS * 1e9) * 1e3)
     import hashlib
     checksum = hashlib.sha256(np.asarray(last[0], dtype=np.uint64).tobytes() + np.asarray(last[1], dtype=np.float32).tobytes()).hexdigest()[:16]
     nbytes = rows * dims * 4
@@ -1293,7 +1297,8 @@ def main():
     gc.collect()
     gc.disable()
     elapsed, last, kern_ms, launches, cal = measure_single_query(eng, submit, collect, queries, args.warmup, args.steps, args.depth,
-                                                                 barrier, chain_timed_region=args.chain_timed_region)
+                                                                 barrier, chain_timed_region=args.chain_timed_region,
+                                                                 floor_ms=max(hi - lo, 0) * dims * 4 / (HBM_PEAK_GBPS * 1e9) * 1e3)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if use_rccl else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

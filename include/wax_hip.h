@@ -358,8 +358,7 @@ int wax_hip_stats(wax_hip_engine* e, wax_hip_stats_t* out);
  *   split-barrier wait timed out (its workgroup's queries take the exact path), 65536 = the device-side retry re-scores every
  *   survivor; any other bit is refused), "batch_prof_ptr" (diagnosis: device address of a [256 x 8][20] u32 buffer — the filtering GEMM at
  *   D = 384 / 768 then runs its phase-timing build, which leaves per-wave s_memtime cycle counts there, same answers, ~10 % slower;
- *   0 (default) = the product kernel; tools/gemm_phase_budget.py), "batch_opt" (schedule variant of that GEMM at D = 384 / 768, a
- *   bit mask the kernel documents; same answers; a value without a compiled variant runs the default).
+ *   0 (default) = the product kernel; tools/gemm_phase_budget.py).
  * get-only
  *   "variant_count", "scan_grid", "store_ptr" (device address of the f32 slab), "fused_max_k", "batch_queries", "query_args_scans", "merged_scans", "done_flag_waits",
  *   "batch_inline_retries", "batch_max_row_err_e9", "batch_fallbacks", "onepass_queries", "batch_max_k", "batch_retries",
@@ -372,7 +371,7 @@ int wax_hip_stats(wax_hip_engine* e, wax_hip_stats_t* out);
  *   lacks peer access), "shard_min_mb" (a shard's block holds at least this many MB of rows, default 64: a store below it lives on
  *   the first device only; 0 = spread from the first row; env WAX_HIP_SHARD_MIN_MB sets the default),
  *   get-only "shards", "block_rows", "rebalances", "rccl_collectives", "rccl_ranks" (ncclCommCount of the in-library communicator),
- *   "peer_pairs" / "peer_enabled", "ticket_searches" / "single_shard_searches", "parallel_submits", "parallel_collects". */
+ *   "peer_pairs" / "peer_enabled", "ticket_searches" / "single_shard_searches" / "inline_fanouts" (single-query fan-outs submitted from the caller's thread because the workers were busy with a long job), "parallel_submits", "parallel_collects". */
 int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value);
 int64_t wax_hip_get_tuning(wax_hip_engine* e, const char* key);
 /* Times `iters` back-to-back launches of ONLY the scan kernel for `query`

@@ -432,6 +432,9 @@ def test_bench_line_carries_the_event_mode_and_the_bracketed_figure():
     ok = bench.kernel_bound_plausible
     assert ok(2.1744, 2.1874) and ok(0.284, 0.2959) and ok(0.0160, 0.0268) and ok(0.186, 0.194)
     assert not ok(0.0, 0.2959) and not ok(float("nan"), 0.2959) and not ok(0.31, 0.2959) and not ok(0.1, 0.2959) and not ok(1.9, 2.1874)
+    # short kernels: a near-zero interval from a runtime that did not bind the pair is refused (relative floor), and so is one that
+    # would put the launch above the peak rate (floor = algorithmic bytes / peak)
+    assert not ok(0.0005, 0.0268) and not ok(0.006, 0.0268) and ok(0.0160, 0.0268, floor_ms=0.00192) and not ok(0.0160, 0.0268, floor_ms=0.02)
 
 
 def test_bench_secondary_watchdog_emits_the_headline_and_leaves(tmp_path):

@@ -36,7 +36,8 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--tune", action="append", default=[], help="key=value tuning applied before the runs")
     ap.add_argument("--out", default=None)
-    ap.add_argument("--opts", type=int, nargs="+", default=[0], help="batch_opt values to run, one line each")
+    ap.add_argument("--ab-key", default="batch_rega", help="tuning key the A/B runs over (round 6's kernel variants were switched by a key that no longer exists)")
+    ap.add_argument("--opts", type=int, nargs="+", default=[5], help="values of --ab-key to run, one line each")
     ap.add_argument("--ab-rounds", type=int, default=0, help="rounds of the interleaved product-kernel A/B over --opts (0 = none)")
     args = ap.parse_args()
     import torch
@@ -69,7 +70,7 @@ def main():
         eng.setTuning("time_kernels", 2)
         for _ in range(args.ab_rounds):
             for o in dict.fromkeys(args.opts):
-                eng.setTuning("batch_opt", o)
+                eng.setTuning(args.ab_key, o)
                 run()
                 eng.setTuning("reset_stats", 1)
                 for _ in range(args.reps):
@@ -78,7 +79,7 @@ def main():
                 times[o].append(stt.batch_gemm_ms_total / max(stt.batch_gemms_timed, 1) * 1e3)
         eng.setTuning("time_kernels", 0)
     for opt in dict.fromkeys(args.opts):
-        eng.setTuning("batch_opt", opt)
+        eng.setTuning(args.ab_key, opt)
         budget(args, eng, torch, dev, run, ref, dout, opt, times[opt])
 
 
@@ -118,7 +119,7 @@ def budget(args, eng, torch, dev, run, ref, dout, opt, ab_times):
     wall_wave_us = (rt1 - rt0) / 1e3
     total_cyc = (p[:, :, 0] + p[:, :, 8] + p[:, :, 9]).astype(np.float64)
     ghz = float(np.median(total_cyc / np.maximum(wall_wave_us, 1e-9)) / 1e3)
-    out = {"rows": args.rows, "dims": args.dims, "nq": args.nq, "topk": args.topk, "tune": args.tune, "batch_opt": opt,
+    out = {"rows": args.rows, "dims": args.dims, "nq": args.nq, "topk": args.topk, "tune": args.tune, "ab_key": args.ab_key, "batch_opt": opt,
            "product_kernel_us_hip_events": prod_us, "product_kernel_us_ab_median": (float(np.median(ab_times)) if ab_times else None),
            "product_kernel_us_ab_rounds": [round(x, 1) for x in ab_times], "prof_kernel_us_hip_events": prof_us, "prof_answers_equal_product": same,
            "workgroups": int(p.shape[0]), "kernel_span_us_first_entry_to_last_exit": span_us,

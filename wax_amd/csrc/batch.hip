@@ -481,12 +481,7 @@ __device__ inline void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N
 // SAMPLE = true (one-pass pipeline, threshold estimation): instead of filtering, the workgroup visits `a.sample_tiles` tiles spread
 // evenly over the slab (logical index i -> tile i * ntiles / sample_tiles) and records, per query, the best similarity of each
 // visited tile in a.tile_max[i][query] (pick_tau_kernel turns the j-th best tile maximum into the query's admission threshold).
-// OPT (round 6, schedule experiments; bit set = new behaviour): 1 = a late wave selects the previous tile AFTER it has waited for the
-// arrivals and requested the next tile (its own K loop no longer starts a whole selection late); 2 = the hot path of the selection runs
-// at s_setprio 2 (above the partner's K loop, which otherwise starves it to ~15 cycles per instruction); 4 = the K loop does not raise
-// its priority; 8 = the next tile's DMA requests are issued from inside the K loop, one every few MFMAs; 16 = the cold path of the
-// selection keeps the raised priority too.
-template <int D, int TROWS, int NBUF, int AHEAD, bool SAMPLE, bool SPLIT, bool NT = false, bool PROF = false, int OPT = 0>
+template <int D, int TROWS, int NBUF, int AHEAD, bool SAMPLE, bool SPLIT, bool NT = false, bool PROF = false>
 __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint32_t blocks_per_group) {
     // PROF (diagnosis build of the filtering launch, "batch_prof_ptr"): every wave accumulates the shader cycles (s_memtime) it spends in
     // each phase of the tile loop in SGPRs and leaves them in a.prof[(workgroup * 8 + wave) * RQ_PROF_WORDS ...]; same answers, ~10 % slower.
@@ -563,8 +558,6 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
         sim_s[wave * 32 + lane] = (1.0f - tq) - 4e-7f * (1.0f + __builtin_fabsf(tq));
     }
     if (SPLIT && tid < 2) sync_s[tid] = 0u;
-    if ((OPT & 256) != 0 && tid < 256) cnt_s[tid] = 0u;       // OPT 256: the survivor counters live here from the start (LDS returning adds)
-    const uint32_t cnt_lane0 = (uint32_t)(size_t)(lds_void*)cnt_s + (uint32_t)(wave * 32 + 4 * (lane >> 5)) * 4u;
     const uint32_t seg_slots = a.seg_area / blocks_per_group;
     const uint32_t seg_lane0 = (q0 + 4u * ((uint32_t)lane >> 5)) * a.cand_cap + a.seg_base + bidx * seg_slots;
 
@@ -587,9 +580,9 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
             doff[i] = (slot - ((slot * DIV_MAGIC) >> DIV_SHIFT)) * 16u;
         }
     }
-    auto dma_piece = [&](auto I, uint32_t tile, uint32_t buf_off) {
-        constexpr int i = decltype(I)::value;
-        {
+    auto dma_tile = [&](uint32_t tile, uint32_t buf_off) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
             if (i < PPW - 1 || full_wave) {
                 const uint32_t P = (uint32_t)wave + 8u * (uint32_t)i;
                 if constexpr (SAMPLE) {
@@ -624,9 +617,6 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
             }
         }
     };
-    auto dma_tile = [&](uint32_t tile, uint32_t buf_off) {
-        static_for<0, PPW>([&](auto I) { dma_piece(I, tile, buf_off); });
-    };
     // this wave's DMA requests still allowed in flight: PRE - 1 whole tiles, or none
     auto dma_wait = [&](bool keep) {
         if (!keep) wait_vmcnt<0>();
@@ -640,9 +630,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
     // K loop. Fragment f + AHEAD is requested before MFMA f; the wait in front of MFMA f leaves at most min(AHEAD, NF - 1 - f)
     // younger reads outstanding. Every step is pinned (sched_barrier) — hipcc otherwise hoists an MFMA over the asm wait it depends
     // on. s_setprio 1 lets the multiplying wave win issue arbitration against its selecting partner.
-    constexpr bool DMA_IN_K = !SAMPLE && (OPT & 8) != 0;
-    constexpr int DMA_STEP = NF / (PPW + 1);          // OPT 8: piece i goes in front of MFMA DMA_STEP * (i + 1) - 2
-    auto mfma_tile = [&](uint32_t baddr, bool dma_on, uint32_t dma_t, uint32_t dma_off) {
+    auto mfma_tile = [&](uint32_t baddr) {
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         u32x4 fb[RING];
         static_for<0, (AHEAD < NF ? AHEAD : NF)>([&](auto F) {
@@ -651,17 +639,13 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
             const uint32_t ba = baddr;
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fbr[f % RING]) : "v"(ba), "n"((f % RB) * 32 * ROW_B + (f / RB) * 32));
         });
-        if constexpr (!(OPT & 4)) __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(1);
         __builtin_amdgcn_sched_barrier(0);
         static_for<0, NF>([&](auto F) {
             constexpr int f = decltype(F)::value;
             constexpr int g = f + AHEAD;
             u32x4(&fbr)[RING] = fb;
             const uint32_t ba = baddr;
-            if constexpr (DMA_IN_K && DMA_STEP >= 2 && (f + 2) % DMA_STEP == 0 && (f + 2) / DMA_STEP >= 1 && (f + 2) / DMA_STEP <= PPW) {
-                if (dma_on) dma_piece(std::integral_constant<int, (f + 2) / DMA_STEP - 1>{}, dma_t, dma_off);
-                __builtin_amdgcn_sched_barrier(0);
-            }
             if constexpr (g < NF)
                 asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fbr[g % RING]) : "v"(ba), "n"((g % RB) * 32 * ROW_B + (g / RB) * 32));
             constexpr int younger = (NF - 1 - f) < AHEAD ? (NF - 1 - f) : AHEAD;
@@ -671,7 +655,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
             acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], __builtin_bit_cast(bf16x8, fbr[f % RING]), ks == 0 ? zero16 : acc[rb], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         });
-        if constexpr (!(OPT & 4)) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(0);
     };
     // Fused selection on one tile. C/D layout of the 32x32 MFMA: column = lane & 31 (corpus row of the block), row =
     // (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (query of the wave). Hot path: 16 RB compares against the bounds (one LDS round trip:
@@ -697,7 +681,6 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
             }
             return;
         }
-        if constexpr ((OPT & 2) != 0) __builtin_amdgcn_s_setprio(2);
         f32x4 lo[4];
         static_for<0, 4>([&](auto J) {
             constexpr int j = decltype(J)::value;
@@ -727,113 +710,49 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
             cq[r] = c0 | (c1 << 16);
             if constexpr (PROF) ph[RQP_SURVIVORS] += n_lo + n_hi;
         };
-        if constexpr ((OPT & 32) != 0) {
-            // Hot test without a single VALU -> SGPR -> SALU hand-over (each v_cmp + s_or pair of the form below costs ~47 cycles beside the
-            // partner's K loop: profiles/r06): per accumulator a subtraction and a funnel shift that pushes the sign of (acc - bound)
-            // into a per-lane mask (1 = fails; NaN may read as "passes" here, the exact comparison in `emit` decides); one ballot per tile.
-            constexpr int NM = (RB + 1) / 2;
-            unsigned fm[NM];
+        // Hot test (round 6). Per accumulator a subtraction and a funnel shift that pushes the sign of (acc - bound) into a per-lane
+        // mask (1 = fails; a NaN may read as "passes" here — the exact comparison in `emit` decides), one ballot per tile. Rounds 1-5
+        // compared every accumulator into a wave mask (v_cmp -> SGPR pair -> s_or): 47 cycles per accumulator beside the partner's K
+        // loop, whatever the priorities (the VALU -> SGPR -> SALU hand-over, 32 of them per 64-row tile, plus SGPR spills), ~1 400 of
+        // a tile's ~5 300 cycles on the late waves' critical path (profiles/r06/a_phase_budget_*). This form: ~800.
+        constexpr int NM = (RB + 1) / 2;
+        unsigned fm[NM];
 #pragma unroll
-            for (int m_ = 0; m_ < NM; ++m_) fm[m_] = 0u;
+        for (int m_ = 0; m_ < NM; ++m_) fm[m_] = 0u;
 #pragma unroll
-            for (int b = 0; b < RB; ++b)
+        for (int b = 0; b < RB; ++b)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    fm[b >> 1] = __builtin_amdgcn_alignbit(fm[b >> 1], __float_as_uint(acc[b][r] - lo[r >> 2][r & 3]), 31u);
-            unsigned pm[NM], anyp = 0u;
+            for (int r = 0; r < 16; ++r)
+                fm[b >> 1] = __builtin_amdgcn_alignbit(fm[b >> 1], __float_as_uint(acc[b][r] - lo[r >> 2][r & 3]), 31u);
+        unsigned pm[NM], anyp = 0u;
 #pragma unroll
-            for (int m_ = 0; m_ < NM; ++m_) {
-                const unsigned valid = (2 * m_ + 1 < RB) ? 0xFFFFFFFFu : 0xFFFFu;   // an odd last block fills 16 bits only
-                pm[m_] = ~fm[m_] & valid;
-                anyp |= pm[m_];
-            }
-            const bool none = __ballot(anyp != 0u) == 0ull;
-            if constexpr ((OPT & 2) != 0 && (OPT & 16) == 0) __builtin_amdgcn_s_setprio(0);
-            if (none) {
-                if constexpr ((OPT & 16) != 0) __builtin_amdgcn_s_setprio(0);
-                return;
-            }
-            const unsigned int c0t = now();
-            uint32_t seg_o = seg_lane0;
-            asm volatile("" : "+v"(seg_o));
-            unsigned wm[NM];
-#pragma unroll
-            for (int m_ = 0; m_ < NM; ++m_) wm[m_] = wave_or32(pm[m_]);
-            if constexpr ((OPT & 256) != 0) {
-                // Lane-parallel cold path: no ballot, no SGPR counter. Per group of four accumulators that holds a survivor anywhere in the
-                // wave (scalar test on the OR-ed masks), every lane with a passing bit picks its accumulator by three selects, takes a slot
-                // from the (workgroup, query) counter in LDS with a returning add, and stores its key — all survivors of the group at once.
-                static_for<0, RB>([&](auto B) {
-                    constexpr int b = decltype(B)::value;
-                    constexpr int nbits = (2 * (b >> 1) + 1 < RB) ? 32 : 16;
-                    static_for<0, 4>([&](auto G) {
-                        constexpr int g = decltype(G)::value;
-                        constexpr int shift = nbits - 1 - ((b & 1) * 16 + 4 * g + 3);   // nibble bit pb <-> r = 4 g + 3 - pb
-                        if (wm[b >> 1] & (0xFu << shift)) {
-                            unsigned nib = (pm[b >> 1] >> shift) & 0xFu;
-                            const uint32_t row0 = a.slab0 + tile * TROWS + (uint32_t)(b * 32) + (uint32_t)(lane & 31);
-                            const bool ok0 = row0 < slab_end;
-                            for (;;) {
-                                if (__ballot(nib != 0u) == 0ull) break;
-                                const unsigned pb = (unsigned)__builtin_ctz(nib | 16u);
-                                const float val = pb == 0u ? acc[b][4 * g + 3] : pb == 1u ? acc[b][4 * g + 2] : pb == 2u ? acc[b][4 * g + 1] : acc[b][4 * g];
-                                const float lov = pb == 0u ? lo[g][3] : pb == 1u ? lo[g][2] : pb == 2u ? lo[g][1] : lo[g][0];
-                                if (nib != 0u && ok0 && val >= lov) {
-                                    const unsigned ql = (3u - pb) + 8u * (unsigned)g;   // + 4 (lane >> 5): folded into the lane bases
-                                    unsigned slot;
-                                    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(slot) : "v"(cnt_lane0 + ql * 4u), "v"(1u) : "memory");
-                                    if (slot < seg_slots) a.cand[seg_o + ql * a.cand_cap + slot] = make_key((1.0f - val) + 0.0f, a.row_base + row0);
-                                }
-                                nib &= nib - 1u;
-                            }
-                        }
-                    });
-                });
-                if constexpr ((OPT & 16) != 0) __builtin_amdgcn_s_setprio(0);
-                if constexpr (PROF) { ph[RQP_COLD] += now() - c0t; ph[RQP_COLD_N] += 1u; }
-                return;
-            }
-            static_for<0, RB>([&](auto B) {
-                constexpr int b = decltype(B)::value;
-                constexpr int nbits = (2 * (b >> 1) + 1 < RB) ? 32 : 16;        // elements in this block's mask
-                static_for<0, 16>([&](auto R) {
-                    constexpr int r = decltype(R)::value;
-                    constexpr int idx = (b & 1) * 16 + r;                       // position in processing order within the mask
-                    if (wm[b >> 1] & (1u << (nbits - 1 - idx))) emit(B, R, seg_o);
-                });
-            });
-            if constexpr ((OPT & 16) != 0) __builtin_amdgcn_s_setprio(0);
-            if constexpr (PROF) { ph[RQP_COLD] += now() - c0t; ph[RQP_COLD_N] += 1u; }
-            return;
+        for (int m_ = 0; m_ < NM; ++m_) {
+            const unsigned valid = (2 * m_ + 1 < RB) ? 0xFFFFFFFFu : 0xFFFFu;   // an odd last block fills 16 bits only
+            pm[m_] = ~fm[m_] & valid;
+            anyp |= pm[m_];
         }
-        unsigned long long hit[RB][4];
-        unsigned long long any = 0ull;
-#pragma unroll
-        for (int b = 0; b < RB; ++b) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) hit[b][g] = 0ull;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) hit[b][r >> 2] |= __ballot(acc[b][r] >= lo[r >> 2][r & 3]);   // NaN fails
-#pragma unroll
-            for (int g = 0; g < 4; ++g) any |= hit[b][g];
-        }
-        if constexpr ((OPT & 2) != 0 && (OPT & 16) == 0) __builtin_amdgcn_s_setprio(0);
-        if (any == 0ull) {
-            if constexpr ((OPT & 16) != 0) __builtin_amdgcn_s_setprio(0);
-            return;
-        }
+        if (__ballot(anyp != 0u) == 0ull) return;
+        // Cold path: the masks OR-ed over the wave (DPP) say which accumulators hold a survivor in ANY lane; each of those is tested
+        // exactly and stored as before. A wave's 32 queries are ITS OWN, so the per-(workgroup, query) survivor counters are 16 SGPRs of the
+        // wave (two saturating 16-bit counters each; 0xFFFF is reported as an overflow: the query takes the exact path) and a
+        // survivor's slot is counter + (passing lanes below it in its half-wave): ballot, mbcnt, s_bcnt1 — no atomic of any kind.
+        // (Measured and not kept, profiles/HISTORY.md round 6: every lane storing its own survivor with a returning LDS add as the
+        // counter — one LDS round trip per group of four accumulators, slower from 2 survivors per wave and tile.)
         const unsigned int c0t = now();
         uint32_t seg_o = seg_lane0;                   // opaque: the per-query row offsets are computed HERE (cold path), not
         asm volatile("" : "+v"(seg_o));               // hoisted out of the tile loop into VGPRs that do not exist
+        unsigned wm[NM];
+#pragma unroll
+        for (int m_ = 0; m_ < NM; ++m_) wm[m_] = wave_or32(pm[m_]);
         static_for<0, RB>([&](auto B) {
             constexpr int b = decltype(B)::value;
-            static_for<0, 4>([&](auto G) {
-                constexpr int g = decltype(G)::value;
-                if (hit[b][g] != 0ull)
-                    static_for<4 * g, 4 * g + 4>([&](auto R) { emit(B, R, seg_o); });
+            constexpr int nbits = (2 * (b >> 1) + 1 < RB) ? 32 : 16;        // elements in this block's mask
+            static_for<0, 16>([&](auto R) {
+                constexpr int r = decltype(R)::value;
+                constexpr int idx = (b & 1) * 16 + r;                       // position in processing order within the mask
+                if (wm[b >> 1] & (1u << (nbits - 1 - idx))) emit(B, R, seg_o);
             });
         });
-        if constexpr ((OPT & 16) != 0) __builtin_amdgcn_s_setprio(0);
         if constexpr (PROF) { ph[RQP_COLD] += now() - c0t; ph[RQP_COLD_N] += 1u; }
     };
 
@@ -894,13 +813,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
     // SPLIT: bounded spin on the arrival counter. The counter is touched through inline assembly only (point 1 above).
     bool gave_up = SPLIT && (a.debug & 16384u) != 0 && blockIdx.x == 1 && wave == 3;   // "batch_debug" bit 14: pretend one wave timed out (tests)
     const unsigned sync_addr = (unsigned)(size_t)(lds_u32*)sync_s;
-    unsigned int arr_rtn = 0u;                                // OPT 64 (lane 0): the arrival counter as this wave's last arrive found it
     auto wait_arrivals = [&](unsigned int target) {
-        if constexpr ((OPT & 64) != 0) {
-            // the wave that arrived LAST knows so from its own (returning) add: no poll, no LDS round trip on the critical path
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if ((unsigned int)__builtin_amdgcn_readfirstlane((int)arr_rtn) + 1u >= target) return;
-        }
         bool ok = false;
         for (unsigned int spins = 0; spins < (1u << 22); ++spins) {
             unsigned int v;
@@ -911,15 +824,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
         if (!ok) gave_up = true;
     };
     auto arrive = [&]() {
-        if constexpr ((OPT & 64) != 0) {
-            // (no branch around the asm: its result lands asynchronously, so the register must not pass through a phi copy; lane 0 alone
-            // is switched on inside)
-            unsigned long long ex;
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tds_add_rtn_u32 %0, %2, %3\n\ts_mov_b64 exec, %1"
-                         : "=v"(arr_rtn), "=&s"(ex) : "v"(sync_addr), "v"(1u) : "memory");
-        } else {
-            if (lane == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\tds_add_u32 %0, %1" ::"v"(sync_addr), "v"(1u) : "memory");
-        }
+        if (lane == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\tds_add_u32 %0, %1" ::"v"(sync_addr), "v"(1u) : "memory");
     };
     uint32_t it = 0, cur_idx = 0, t_prev = 0;
     for (; t < ntiles; ++it) {
@@ -928,20 +833,16 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
         uint32_t pre_idx = cur_idx + PRE;
         pre_idx = pre_idx >= (uint32_t)NBUF ? pre_idx - NBUF : pre_idx;
         const bool issued = tn < ntiles;
-        constexpr bool LATE_AFTER = (OPT & 1) != 0;
         const unsigned int p0 = now();
-        if (!LATE_AFTER && late && it > 0) select_tile(t_prev);
+        if (late && it > 0) select_tile(t_prev);
         const unsigned int p1 = now();
         // every wave is through K loop it - 1 (the buffer tile tn goes to is free) and has its pieces of tile `it` in LDS
         if (SPLIT && it > 0) wait_arrivals(8u * it);
         const unsigned int p2 = now();
         pace(it);
-        if (!DMA_IN_K && issued) dma_tile(tn, pre_idx * BUF_B);
+        if (issued) dma_tile(tn, pre_idx * BUF_B);
         const unsigned int p3 = now();
-        if (LATE_AFTER && late && it > 0) select_tile(t_prev);
-        const unsigned int p3b = now();
-        if constexpr (PROF && LATE_AFTER) ph[RQP_SELECT] += p3b - p3;
-        mfma_tile(baddr, issued, tn, pre_idx * BUF_B);
+        mfma_tile(baddr);
         const unsigned int p4 = now();
         // tile t + 1 must have landed before the others read it (every wave waits for its own pieces, the barrier / the arrival
         // counter joins them); the PRE - 1 younger tiles stay in flight. The wait sits in FRONT of an early wave's selection:
@@ -961,7 +862,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
             ph[RQP_SELECT] += (p1 - p0) + (p6 - p5);
             ph[RQP_WAIT_ARRIVALS] += (p2 - p1) + (p7 - p6);
             ph[RQP_DMA_ISSUE] += p3 - p2;
-            ph[RQP_KLOOP] += p4 - p3b;
+            ph[RQP_KLOOP] += p4 - p3;
             ph[RQP_DMA_WAIT] += p5 - p4;
         }
         cur_idx = cur_idx + 1 == (uint32_t)NBUF ? 0u : cur_idx + 1;
@@ -971,7 +872,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
     if (late && it > 0) select_tile(t_prev);
     if (gate && tid == 0) __hip_atomic_fetch_add(gate_word, 0u - gate_added - (1u << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // leaving: out of the count and the sum
     if (SPLIT && gave_up && lane == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(sync_addr + 4u), "v"(1u) : "memory");
-    if (!SAMPLE && (OPT & 256) == 0) {   // the wave's 32 survivor counters, SGPRs -> LDS: lane q takes query q's
+    if (!SAMPLE) {   // the wave's 32 survivor counters, SGPRs -> LDS: lane q takes query q's
         unsigned mine = 0u;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -1047,17 +948,17 @@ bool batch_gemm_segments(const GemmArgs& a, int metric, uint32_t* nseg, uint32_t
     return true;
 }
 
-template <int D, bool SAMPLE, bool SPLIT, bool NT = false, bool PROF = false, int OPT = 0>
+template <int D, bool SAMPLE, bool SPLIT, bool NT = false, bool PROF = false>
 static hipError_t launch_rq(const GemmArgs& a, uint32_t groups, uint32_t per_group, hipStream_t st) {
     using G = RqGeom<D>;
     constexpr size_t smem = rq_smem<D>();
     static_assert(smem <= 160 * 1024, "LDS budget of one CU");
     static std::atomic<uint64_t> configured{0};   // per device (ensure_dynamic_lds)
     {
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&batch_gemm_rq_kernel<D, G::TROWS, G::NBUF, G::AHEAD, SAMPLE, SPLIT, NT, PROF, OPT>), smem, configured);
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&batch_gemm_rq_kernel<D, G::TROWS, G::NBUF, G::AHEAD, SAMPLE, SPLIT, NT, PROF>), smem, configured);
         if (e != hipSuccess) return e;
     }
-    launch_kernel((batch_gemm_rq_kernel<D, G::TROWS, G::NBUF, G::AHEAD, SAMPLE, SPLIT, NT, PROF, OPT>), dim3(groups * per_group), dim3(512), smem, st, a, per_group);
+    launch_kernel((batch_gemm_rq_kernel<D, G::TROWS, G::NBUF, G::AHEAD, SAMPLE, SPLIT, NT, PROF>), dim3(groups * per_group), dim3(512), smem, st, a, per_group);
     return hipGetLastError();
 }
 
@@ -1069,23 +970,6 @@ static hipError_t launch_rq_filter(const GemmArgs& a, hipStream_t st) {
     if (a.use_rega == 1u) return launch_rq<D, false, false>(a, groups, per_group, st);
     // "batch_prof_ptr" (diagnosis): the phase-timing build of the same launch, at the two dimensions of BASELINE configs 3 / 5
     if constexpr (D == 384 || D == 768) {
-        // "batch_opt" (round 6 schedule experiments, see the kernel's OPT): the compiled combinations
-#define WAX_RQ_OPT_CASE(O)                                                                                              \
-        case O:                                                                                                         \
-            if (a.prof != nullptr) {                                                                                    \
-                if (groups == 1) return launch_rq<D, false, true, true, true, O>(a, groups, per_group, st);             \
-                return launch_rq<D, false, true, false, true, O>(a, groups, per_group, st);                             \
-            }                                                                                                           \
-            if (groups == 1) return launch_rq<D, false, true, true, false, O>(a, groups, per_group, st);                \
-            return launch_rq<D, false, true, false, false, O>(a, groups, per_group, st);
-        switch (a.opt) {
-            WAX_RQ_OPT_CASE(32)
-            WAX_RQ_OPT_CASE(96)
-            WAX_RQ_OPT_CASE(288)
-            WAX_RQ_OPT_CASE(352)
-            default: break;
-        }
-#undef WAX_RQ_OPT_CASE
         if (a.prof != nullptr) {
             if (groups == 1) return launch_rq<D, false, true, true, true>(a, groups, per_group, st);
             return launch_rq<D, false, true, false, true>(a, groups, per_group, st);

@@ -426,7 +426,6 @@ struct wax_hip_engine {
     std::atomic<int64_t> batch_slab_mb{64};  // cap on slab size, in units of 16 384 rows
     std::atomic<int64_t> batch_growth{8};    // next slab = growth x rows seen so far
     std::atomic<int64_t> batch_first{2048};  // rows of the dense first slab (<= kBatchFirstSlab)
-    std::atomic<int64_t> batch_opt{0};       // schedule variant of the rq filtering GEMM at D = 384 / 768 (GemmArgs::opt)
     std::atomic<int64_t> batch_prof_ptr{0};  // diagnosis: device address of the phase-timing buffer of the filtering GEMM (GemmArgs::prof); 0 = the product kernel
     std::atomic<int64_t> batch_debug{0};     // test / diagnosis bits, none of which can change an answer: 4096 = no pace gate, 16384 = one wave of workgroup 1 pretends its split-barrier wait timed out, 65536 = the device-side retry re-scores every survivor
     std::atomic<int64_t> batch_rega{5};      // register-resident-queries GEMM where it applies: 5 (default) split tile barrier, 1 workgroup barrier per tile; 0 = the LDS-tiled kernel instead
@@ -807,7 +806,9 @@ int enqueue_scan(wax_hip_engine* e, const float* d_query, float q_norm, int k_ef
                  Slot* general_slot, wax_hip_hit* d_hits, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1,
                  bool chain = false, hipEvent_t* used_start = nullptr, hipEvent_t* used_end = nullptr,
                  const float* h_query = nullptr, uint64_t* done_flag = nullptr, uint64_t done_value = 0, bool* out_flagged = nullptr,
-                 bool overlap_merge = false) {
+                 bool overlap_merge = false, int tk_mode = 0) {
+    // tk_mode: the caller's ONE read of "time_kernels" for this submit (a concurrent set_tuning between two reads could otherwise arm
+    // ev0 / ev1 one way and mark the slot as timed the other: advisor, round 5)
     ScanArgs a{};
     a.store = e->d_store;
     a.query = d_query;
@@ -843,7 +844,7 @@ int enqueue_scan(wax_hip_engine* e, const float* d_query, float q_norm, int k_ef
     if (used_end) *used_end = ev1;
     // "time_kernels" = 2: the event pair is bound to the scan's dispatch itself (kernels.h: launch_kernel) — no trailing marker and no
     // chain wait inside the interval; 1: the pair is recorded in front of and behind the launch.
-    const bool bound = ev0 != nullptr && ev1 != nullptr && e->time_kernels.load() == 2;
+    const bool bound = ev0 != nullptr && ev1 != nullptr && tk_mode == 2;
     if (fused) {
         const int cap = k_eff <= 64 ? 128 : 256;
         bool record_start = ev0 != nullptr && !bound;
@@ -1358,7 +1359,6 @@ int batch_enqueue(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32
     g.use_rega = (uint32_t)e->batch_rega.load();  // 0 LDS-tiled kernel, 1 workgroup barrier per tile, 5 split barrier (default)
     g.debug = (uint32_t)e->batch_debug.load();
     g.prof = reinterpret_cast<uint32_t*>((uintptr_t)e->batch_prof_ptr.load());
-    g.opt = (uint32_t)e->batch_opt.load();
     g.seg_count = c->d_seg_count;
     if (plan) {
         // ---- one pass: sample -> threshold -> filter everything -> finish ----
@@ -1369,7 +1369,8 @@ int batch_enqueue(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32
         gs.tile_max = c->d_tile_max; gs.sample_tiles = plan->sample_tiles;
         g.progress = pa.progress;
         HIP_TRY(launch_batch_gemm_sample(gs, e->metric, st), WAX_HIP_ERR_INTERNAL, "sampling gemm launch");
-        const bool timed = e->time_kernels.load() != 0;
+        const int tk_mode = (int)e->time_kernels.load();   // read once per batch
+        const bool timed = tk_mode != 0;
         std::unique_lock<std::mutex> cg(e->gemm_chain_mu, std::defer_lock);
         if (timed) {
             // (the chain wait sits in front of the threshold kernel: the sampling GEMM before it could not get a CU
@@ -1386,7 +1387,7 @@ int batch_enqueue(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32
             // them, like the single-query scans, so that a timed interval is one GEMM running alone. The small
             // kernels before this point (prep, sampling, thresholds) still overlap the previous batch's GEMM tail
             // and finish kernel.
-            if (e->time_kernels.load() == 2) {
+            if (tk_mode == 2) {
                 // kernel-bound pair (kernels.h: launch_kernel)
                 launch_timing() = LaunchTiming{c->ev_g0, c->ev_g1};
                 const hipError_t lerr = launch_batch_gemm(g, e->metric, st);
@@ -1741,7 +1742,6 @@ int wax_hip_engine_create(uint8_t metric, uint32_t dims, int device_id, wax_hip_
     e->device = dev;
     e->metric = metric;
     e->dims = dims;
-    if (const char* v = std::getenv("WAX_HIP_BATCH_OPT")) e->batch_opt = std::atoll(v);   // default of "batch_opt" (A/B runs of the whole test suite)
     if (const char* v = std::getenv("WAX_HIP_BATCH_REGA")) {  // default of the "batch_rega" tunable (A/B runs of the whole test suite)
         const long m = std::strtol(v, nullptr, 10);
         if (m == 0 || m == 1 || m == 5) e->batch_rega = m;
@@ -2039,9 +2039,9 @@ int wax_hip_remove(wax_hip_engine* e, uint64_t frame_id) {
 static int submit_impl(wax_hip_engine* e, const float* query, uint32_t dims, int32_t top_k, uint64_t* out_ticket,
                        bool try_only);
 
-static bool chain_scans(wax_hip_engine* e) {
+static bool chain_scans(wax_hip_engine* e, int tk_mode) {
     const int64_t sc = e->scan_chain.load();
-    return sc > 0 || (sc < 0 && e->time_kernels.load() != 0);
+    return sc > 0 || (sc < 0 && tk_mode != 0);
 }
 
 int wax_hip_search_submit(wax_hip_engine* e, const float* query, uint32_t dims, int32_t top_k, uint64_t* out_ticket) {
@@ -2079,7 +2079,8 @@ static int submit_impl(wax_hip_engine* e, const float* query, uint32_t dims, int
         rc = acquire_slot(e, &s, try_only, holding(e) > 0);
         if (rc != WAX_HIP_OK) break;
         s->k_eff = k_eff;
-        s->timed = e->time_kernels.load() != 0;
+        const int tk_mode = (int)e->time_kernels.load();   // read once per submit
+        s->timed = tk_mode != 0;
         const float qn = query_norm(query, dims);
         hipError_t err = hipSuccess;
         const bool overlap = scan_overlaps_merge(e, others_in_flight);
@@ -2101,8 +2102,8 @@ static int submit_impl(wax_hip_engine* e, const float* query, uint32_t dims, int
         if (want_flag) s->done_seq += 1;
         bool flagged = false;
         rc = enqueue_scan(e, qargs ? nullptr : s->d_query, qn, k_eff, k_eff, s->d_partials, s, s->h_hits, s->stream,
-                          s->timed ? s->ev0 : nullptr, s->timed ? s->ev1 : nullptr, /*chain=*/chain_scans(e), &s->t_start, &s->t_end, query,
-                          want_flag ? s->h_done : nullptr, s->done_seq, &flagged, overlap);
+                          s->timed ? s->ev0 : nullptr, s->timed ? s->ev1 : nullptr, /*chain=*/chain_scans(e, tk_mode), &s->t_start, &s->t_end, query,
+                          want_flag ? s->h_done : nullptr, s->done_seq, &flagged, overlap, tk_mode);
         if (rc != WAX_HIP_OK) break;
         if (flagged) {
             s->flag_wait = true;
@@ -2608,13 +2609,14 @@ static int search_shard_device_impl(wax_hip_engine* e, const float* query, uint3
             e->st_query_args++;
         }
         harvest_ring_event(e, (int)r);  // the entry's previous use has finished (waited for above)
-        const bool timed = e->time_kernels.load() != 0;
+        const int tk_mode = (int)e->time_kernels.load();   // read once per submit
+        const bool timed = tk_mode != 0;
         // chained (when kernels are timed, or "scan_chain" = 1): scans issued on different caller streams never overlap
         // each other, while the merge kernel and whatever the caller enqueues next (RCCL all-gather, merge, download)
         // do overlap the following scan.
         rc = enqueue_scan(e, qargs ? nullptr : e->ring_d_query[r], qn, k_eff, kpad, e->ring_d_partials[r], nullptr, d_out_hits, st,
-                          timed ? e->ring_ev0[r] : nullptr, timed ? e->ring_ev1[r] : nullptr, /*chain=*/chain_scans(e), &e->ring_t0[r], &e->ring_t1[r], query,
-                          nullptr, 0, nullptr, overlap);
+                          timed ? e->ring_ev0[r] : nullptr, timed ? e->ring_ev1[r] : nullptr, /*chain=*/chain_scans(e, tk_mode), &e->ring_t0[r], &e->ring_t1[r], query,
+                          nullptr, 0, nullptr, overlap, tk_mode);
         if (rc == WAX_HIP_OK && timed) {
             std::unique_lock<std::mutex> sg(e->st_mu);
             e->ring_ev_pending[r] = true;
@@ -2965,7 +2967,6 @@ int wax_hip_set_tuning(wax_hip_engine* e, const char* key, int64_t value) {
     else if (k == "batch_rega") { if (value != 0 && value != 1 && value != 5) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_rega must be 0, 1 or 5"); e->batch_rega = value; }
     else if (k == "batch_debug") { if (value & ~(int64_t)(4096 | 16384 | 65536)) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_debug: bits 4096, 16384, 65536 only"); e->batch_debug = value; }
     else if (k == "batch_prof_ptr") e->batch_prof_ptr = value;
-    else if (k == "batch_opt") e->batch_opt = value;
     else if (k == "batch_onepass") e->batch_onepass = value;
     else if (k == "batch_onepass_tiles") { if (value < 1024) return fail(WAX_HIP_ERR_INVALID_ARGUMENT, "batch_onepass_tiles must be >= 1024"); e->batch_onepass_tiles = value; }
     else if (k == "batch_kp_fused") e->batch_kp_fused = value != 0;

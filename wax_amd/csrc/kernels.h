@@ -231,7 +231,6 @@ struct GemmArgs {
     // Diagnosis ("batch_prof_ptr"): non-null = device buffer of [grid * 8 waves][RQ_PROF_WORDS] u32 that the PROF instantiation of the
     // filtering launch fills with per-wave phase cycle counts (indices RQP_*). Never set by the product path.
     uint32_t* prof;
-    uint32_t opt;               // "batch_opt": schedule variant of the register-resident filtering GEMM (batch_gemm_rq_kernel's OPT; 0 = default)
 };
 // Words per wave of GemmArgs::prof and what they hold (shader cycles unless said otherwise).
 enum : int {
