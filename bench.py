@@ -47,7 +47,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md: ~2.
 CORPUS_SEED = 20260220
 QUERY_SEED = 7
 GRANULE = 65536
-SECONDARY_N1 = ["s10k", "s1m", "s1250k", "b1m_q256", "b1m_q1024", "c5_shard", "c5_full", "clustered_k10", "clustered_k100", "dups17", "detembed"]
+SECONDARY_N1 = ["s10k", "s1m", "s1250k", "s10m_k300", "s1m_k1000", "b1m_q256", "b1m_q1024", "c5_shard", "c5_full", "clustered_k10", "clustered_k100", "dups17", "detembed"]
 DUP_ROWS, DUP_AT, DUP_OF, DUP_QUERIES = 2048, 500_000, 7, 44    # the "dups17" corpus: 2048 copies of row 7; 44 of 256 queries (17 %) aim at it
 
 
@@ -90,9 +90,12 @@ def parse_args():
     p.add_argument("--detail-out", default=None, metavar="PATH",
                    help="where the verbose record goes (default bench_detail.json next to bench.py); stdout carries ONE compact line")
     p.add_argument("--host-merge", action="store_true", help="N>1: merge gathered hits on the host instead of the device")
-    p.add_argument("--exchange", choices=["rccl", "host"], default="rccl",
-                   help="N>1: rccl = all-gather device buffers over RCCL (default); host = download + gloo all-gather "
-                        "(control path; also lets two test ranks share one GPU with WAX_BENCH_SAME_DEVICE=1)")
+    p.add_argument("--exchange", choices=["rccl", "host", "tickets"], default=None,
+                   help="N>1, one rank per GPU (torchrun): rccl = all-gather device buffers over RCCL (default); host = download + gloo "
+                        "all-gather (control path; also lets two test ranks share one GPU with WAX_BENCH_SAME_DEVICE=1). N>1 in ONE process "
+                        "(the library's sharded handle): tickets = per-shard tickets + host merge, the library's default and the faster one "
+                        "(default); rccl = one ncclAllGather per query on the library's communicator. Both are measured as secondaries "
+                        "(h_tickets, h_rccl) in that shape whatever the headline uses")
     return p.parse_args()
 
 
@@ -295,6 +298,18 @@ def cpu_baseline(torch, args, dev, queries):
     }
 
 
+def cpu_baseline_small(torch, dev, rows, dims, topk, queries, seconds=3.0):
+    """`cpu_baseline` for a secondary single-query size (the 10K and 1M points of the north star's N matrix): the same oracle scan over
+    ALL `rows` rows on one thread and on the usable host threads, `seconds` of budget in total. Compact: value, cores, the 1-thread value
+    and what the sample was."""
+    import types
+    a = types.SimpleNamespace(rows=rows, dims=dims, topk=topk, cpu_sample_rows=rows, cpu_baseline_seconds=seconds)
+    full = cpu_baseline(torch, a, dev, queries)
+    v1 = next((v for v in full["variants"] if v["threads"] == 1), None)
+    return {"value": full["value"], "unit": "queries/s", "cores": full["cores"], "kind": "port",
+            "value_1_thread": v1["value"] if v1 else None, "sample": full["sample_short"]}
+
+
 # ---------------------------------------------------------------------------
 # the single-query measurement: product-mode timed region + per-launch calibration pass
 
@@ -373,6 +388,7 @@ def measure_single_query(eng, submit, collect, queries, warmup, steps, depth, ba
                                              if events == "kernel-bound" else "recorded in front of and behind the launch (\"time_kernels\" = 1)")}
 
 
+RCCL_FAILURE = [None]    # why RCCL was abandoned in this run (None = not abandoned)
 BATCH_DEPTH = 0          # --batch-depth: batches in flight of the batched secondaries (0 = auto: 3 up to 256 queries per batch, else 2)
 EVENT_MODE = "bound"     # --events: "bound" (default) = frac from kernel-bound HIP events, "bracket" = rounds 1-4's hipEventRecord bracket
 
@@ -560,9 +576,10 @@ def _load_engine(torch, dev, rows, dims, corpus="gaussian", devices=None, lo=0):
     return eng
 
 
-def secondary_single_query(torch, dev, rows, dims, k, steps, warmup, depth, label="BASELINE config 2"):
+def secondary_single_query(torch, dev, rows, dims, k, steps, warmup, depth, label="BASELINE config 2", cpu_seconds=0.0):
     """BASELINE config 2 (and the 10K-row point of the north star's N matrix): rows x dims f32, one query per step, the
-    headline's code path at another size."""
+    headline's code path at another size. cpu_seconds > 0: the oracle's CPU scan of the same rows beside it (north star: "next to
+    Wax's own CPU scan ... in the same run")."""
     eng = _load_engine(torch, dev, rows, dims)
     queries = unit_queries(warmup + steps, dims)
     eng.setTuning("streams", 2)
@@ -592,15 +609,24 @@ def secondary_single_query(torch, dev, rows, dims, k, steps, warmup, depth, labe
     except (OSError, ValueError, KeyError):
         pass
     rf = scan_roofline(nbytes, kern_ms, launches, elapsed, steps, cal, traffic, traffic_source)
+    if k > 192:
+        rf["note_general_selection"] = ("top_k > 192: the scan writes rows x 4 B of distances (+1/dims traffic) and the radix selection of "
+                                        "DESIGN 4.2 follows it; kernel_avg_ms is the distance kernel, ms_per_step the whole query")
     rf["scan_grid"] = grid
     # 1: the scan kernel's last-arriving workgroup did the final merge; 2: a merge launch behind the scan (stores beyond 2 GiB; and, with
     # other scans in flight as here, stores from "merge_overlap_mb" up: the merge overlaps the next scan)
     rf["launches_per_query"] = 1 if merged > overlapped else 2
-    return {
+    res = {
         "config": f"{rows} x {dims} f32 cosine top-{k}, one query per step, 1 GPU ({label})",
         "value": steps / elapsed, "unit": "queries/s", "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
-        "dtype": "f32", "last_result_checksum": checksum, "roofline": rf,
+        "dtype": "f32", "last_result_checksum": checksum, "roofline": rf, "top_k": k,
     }
+    if cpu_seconds > 0:
+        try:
+            res["cpu_baseline"] = cpu_baseline_small(torch, dev, rows, dims, k, queries, cpu_seconds)
+        except Exception as ex:  # noqa: BLE001 — the baseline beside a secondary must not lose the secondary
+            res["cpu_baseline"] = {"error": f"{type(ex).__name__}: {ex}"}
+    return res
 
 
 def _load_handle(torch, devs, rows, dims):
@@ -624,23 +650,81 @@ def _load_handle(torch, devs, rows, dims):
     return eng
 
 
-def handle_exchange(eng, args, n_devices):
-    """One-process shape: which exchange the handle uses, and the loud check that RCCL really spans the devices."""
-    if args.exchange == "rccl" and not os.environ.get("WAX_BENCH_SAME_DEVICE"):
-        eng.setTuning("exchange", 1)        # one ncclAllGather per query on the library's single-process communicator
-        ranks = int(eng.getTuning("rccl_ranks"))
-        if ranks != n_devices:
-            raise SystemExit(f"[bench] --exchange rccl over {n_devices} devices, but the library's communicator has {ranks} ranks")
-        return 1, ranks
+def handle_preflight(torch, devs):
+    """Untimed first-contact check of the one-process multi-GPU shape (`python bench.py --gpus N`), before anything is measured: peer
+    access pair by pair as the handle found it, a small store FORCED over every device ("shard_min_mb" 0) answering exactly like one
+    engine on device 0, and one engine per non-zero ordinal answering on its own device. Never fatal: what fails is printed and
+    carried in config.preflight, and the run goes on (per-shard tickets need no peer access at all)."""
+    from wax_amd import HIPVectorEngine, VectorMetric
+    info = {"devices": list(devs)}
+    try:
+        rows, dims, k = 32768, 64, 10
+        g = torch.Generator(device="cpu").manual_seed(1234)
+        x = torch.randn((rows, dims), generator=g, dtype=torch.float32)
+        x = (x / x.norm(dim=1, keepdim=True)).numpy()
+        ids = np.arange(rows, dtype=np.uint64)
+        qs = x[[5, 4096, 20000, rows - 1]] * np.float32(1.0)
+        one = HIPVectorEngine(metric=VectorMetric.cosine, dimensions=dims, device=devs[0])
+        one.addBatch(ids, x)
+        ref = [one.searchArrays(q, k) for q in qs]
+        one.close()
+        h = HIPVectorEngine(metric=VectorMetric.cosine, dimensions=dims, devices=list(devs))
+        h.setTuning("shard_min_mb", 0)
+        h.reserve(rows)
+        h.addBatch(ids, x)
+        info["peer_pairs"], info["peer_enabled"] = int(h.getTuning("peer_pairs")), int(h.getTuning("peer_enabled"))
+        info["rows_per_device"] = [int(h.shardInfo(i)[2]) for i in range(len(devs))]
+        got = [h.searchArrays(q, k) for q in qs]
+        info["spread_equals_one_engine"] = all(list(a[0]) == list(b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(got, ref))
+        h.close()
+        per = []
+        for d in sorted(set(devs) - {devs[0]}):
+            e = HIPVectorEngine(metric=VectorMetric.cosine, dimensions=dims, device=d)
+            e.addBatch(ids[:4096], x[:4096])
+            r = e.searchArrays(x[7], k)
+            per.append(bool(int(r[0][0]) == 7 and int(e.device) == d))
+            e.close()
+        info["engine_on_each_nonzero_ordinal"] = all(per) if per else None
+        info["ok"] = bool(info["spread_equals_one_engine"] and (info["engine_on_each_nonzero_ordinal"] in (True, None)))
+    except Exception as ex:  # noqa: BLE001
+        info["ok"] = False
+        info["error"] = f"{type(ex).__name__}: {ex}".replace("\n", " ")[:200]
+    log(f"[bench] preflight (one process, {len(devs)} devices): {json.dumps(info)}")
+    return info
+
+
+def handle_exchange(eng, args, n_devices, want_rccl=None):
+    """One-process shape: which exchange the handle uses. `--exchange rccl` (or want_rccl) asks for one ncclAllGather per query on the
+    library's single-process communicator; if the library cannot load RCCL, or its communicator does not span the N devices, the run
+    DEGRADES to per-shard tickets (the library's default exchange), says so (RCCL_FAILURE -> config.exchange, rccl_ranks = 0) and
+    goes on: the first contact with a multi-GPU node must not end without a line (VERDICT r05 #3; round 5 raised SystemExit here)."""
+    want = (args.exchange == "rccl") if want_rccl is None else want_rccl
+    if want and not os.environ.get("WAX_BENCH_SAME_DEVICE"):
+        try:
+            if os.environ.get("WAX_BENCH_FAKE_RCCL_FAILURE"):
+                raise RuntimeError("WAX_BENCH_FAKE_RCCL_FAILURE")
+            eng.setTuning("exchange", 1)
+            ranks = int(eng.getTuning("rccl_ranks"))
+            if ranks != n_devices:
+                raise RuntimeError(f"the library's communicator has {ranks} ranks for {n_devices} devices")
+            return 1, ranks
+        except Exception as ex:  # noqa: BLE001
+            RCCL_FAILURE[0] = f"{type(ex).__name__}: {ex}".replace("\n", " ")[:160]
+            log(f"[bench] one-process RCCL exchange unavailable ({RCCL_FAILURE[0]}): per-shard tickets + host merge instead")
+            try:
+                eng.setTuning("exchange", 0)
+                eng.setTuning("ticket_path", 1)
+            except Exception:  # noqa: BLE001
+                pass
     return 0, 0
 
 
-def handle_single_query(torch, args, devs, rows, dims, k, steps, warmup, label):
+def handle_single_query(torch, args, devs, rows, dims, k, steps, warmup, label, want_rccl=None):
     """The N-matrix points (N in {10K, 1M} x 384) in the ONE-PROCESS shape (`python bench.py --gpus N`): the same sharded handle
     as the headline at another corpus size. A store below the small-store threshold is not spread (rows_per_gpu shows it)."""
     eng = _load_handle(torch, devs, rows, dims)
     apply_tunes(eng)
-    exchange_mode, rccl_ranks = handle_exchange(eng, args, len(devs))
+    exchange_mode, rccl_ranks = handle_exchange(eng, args, len(devs), want_rccl)
     eng.setTuning("streams", 2)
     eng.setTuning("slots", max(args.depth, 2))
     queries = unit_queries(warmup + steps, dims)
@@ -663,6 +747,57 @@ def handle_single_query(torch, args, devs, rows, dims, k, steps, warmup, label):
         "rccl_ranks": rccl_ranks, "ticket_searches": tickets, "single_shard_searches": single,
         "roofline": rf,
     }
+
+
+def init_distributed(torch, dist, rank, world, dev, use_rccl):
+    """The default process group of the one-rank-per-GPU shape. Returns whether RCCL is the exchange.
+    use_rccl: ONE group with both backends — CPU tensors travel through gloo, CUDA tensors through RCCL (created lazily, at the probe
+    below). If RCCL cannot talk across the node and SAYS so (an exception on any rank, at group creation or at the probe), every rank
+    learns it through gloo and the run goes on with the host exchange, labelled (RCCL_FAILURE -> config.exchange): the first contact
+    with an 8-GPU node then still prints its line. Nothing is torn down (tearing down a half-initialised RCCL group
+    hangs): the dead CUDA backend is simply never used again. A probe that HANGS is ended by the group's timeout, as before."""
+    import datetime
+    if not use_rccl:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        return False
+    ok, why = 1, ""
+    try:
+        dist.init_process_group("cpu:gloo,cuda:nccl", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+    except Exception as ex:  # noqa: BLE001 — no usable NCCL backend at all (every rank sees the same): plain gloo
+        RCCL_FAILURE[0] = f"{type(ex).__name__}: {ex}".replace("\n", " ")[:160]
+        log(f"[bench] rank {rank}: no RCCL backend ({RCCL_FAILURE[0]}): host (gloo) exchange")
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        return False
+    if os.environ.get("WAX_BENCH_FAKE_RCCL_FAILURE"):            # tests: pretend the collective library refused
+        ok, why = 0, "WAX_BENCH_FAKE_RCCL_FAILURE"
+    else:
+        try:
+            probe_t = torch.ones(1, device=dev)
+            dist.all_reduce(probe_t)
+            torch.cuda.synchronize()
+            if int(probe_t.item()) != world:
+                ok, why = 0, f"probe all-reduce returned {int(probe_t.item())}, expected {world}"
+        except Exception as ex:  # noqa: BLE001
+            ok, why = 0, f"{type(ex).__name__}: {ex}"
+    flag = torch.tensor([ok], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)                   # gloo
+    if int(flag.item()) == 0:
+        RCCL_FAILURE[0] = (why or "another rank's probe failed").replace("\n", " ")[:160]
+        log(f"[bench] rank {rank}: RCCL is not usable ({RCCL_FAILURE[0]}): continuing with the host (gloo) exchange")
+        return False
+    return True
+
+
+def dist_barrier(torch, dist, use_rccl, device_index):
+    """Barrier over the default group. RCCL: the device barrier. Host exchange: an all-reduce of a CPU tensor — in a pure gloo group
+    and in the mixed "cpu:gloo,cuda:nccl" group alike it travels through gloo (dist.barrier() on the mixed group would pick the CUDA
+    backend, i.e. the very RCCL that the fall-back exists to avoid)."""
+    if use_rccl:
+        dist.barrier(device_ids=[device_index])
+    else:
+        dist.all_reduce(torch.zeros(1))
 
 
 SMALL_STORE_BYTES = 64 << 20     # = the library's "shard_min_mb" default: a store below it is not spread over GPUs
@@ -690,7 +825,7 @@ def sharded_single_query(torch, dist, args, rank, world, local_rank, use_rccl, r
 
     def barrier():
         torch.cuda.synchronize()
-        dist.barrier(device_ids=[local_rank]) if use_rccl else dist.barrier()
+        dist_barrier(torch, dist, use_rccl, local_rank)
         torch.cuda.synchronize()
 
     if solo:
@@ -722,7 +857,8 @@ def sharded_single_query(torch, dist, args, rank, world, local_rank, use_rccl, r
                    f"{rows} x {dims} f32 cosine top-{k}, one query per step, row-sharded over {world} GPUs ({label})"),
         "value": steps / elapsed, "unit": "queries/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": elapsed / steps * 1e3, "dtype": "f32", "rows_per_gpu": ([rows] + [0] * (world - 1)) if solo else hi - lo,
-        "last_result_checksum": checksum, "exchange": "none (small-store rule)" if solo else ("rccl" if use_rccl else "host"),
+        "last_result_checksum": checksum,
+        "exchange": "none (small-store rule)" if solo else ("rccl" if use_rccl else "host" + (" (rccl failed)" if RCCL_FAILURE[0] else "")),
         "roofline": rf,
     }
 
@@ -948,7 +1084,7 @@ def config5_sharded(torch, dist, args, rank, world, in_library, use_rccl, k=10, 
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier(device_ids=[torch.cuda.current_device()]) if use_rccl else dist.barrier()
+            dist_barrier(torch, dist, use_rccl, torch.cuda.current_device())
         torch.cuda.synchronize()
 
     if in_library:
@@ -1054,11 +1190,18 @@ def compact_line(full):
     c["workload"] = cfg.get("workload_short") or str(cfg.get("workload", ""))[:120]
     c["parallelism"] = cfg.get("parallelism_short") or str(cfg.get("parallelism", ""))[:60]
     c["checksum"] = cfg.get("last_result_checksum")
+    if isinstance(cfg.get("preflight"), dict):       # one-process multi-GPU shape: first-contact check, numbers only
+        pf = cfg["preflight"]
+        c["preflight"] = {k_: pf.get(k_) for k_ in ("ok", "peer_pairs", "peer_enabled") if k_ in pf}
+        if pf.get("error"):
+            c["preflight"]["error"] = str(pf["error"])[:80]
+    if cfg.get("exchange"):
+        c["exchange"] = str(cfg["exchange"])[:80]
     line["config"] = c
     rf = full.get("roofline")
     if rf is not None:
         r = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "pipeline_frac", "kernel_avg_ms", "kernel_launches_timed",
-                       "algorithmic_bytes_per_launch", "traffic"))
+                       "algorithmic_bytes_per_launch", "traffic", "peak_measured", "frac_of_measured"))
         r["kernel"] = str(rf.get("kernel", "")).split(" ")[0]
         cal = rf.get("calibration") or {}
         if cal.get("events"):
@@ -1096,8 +1239,13 @@ def compact_line(full):
                 e["rows_per_gpu"] = x["rows_per_gpu"]
             if x.get("rccl_ranks"):
                 e["rccl_ranks"] = x["rccl_ranks"]
+            if x.get("exchange"):
+                e["exchange"] = str(x["exchange"])[:60]
         if "ms_per_step_blocking_call" in x:
             e["blocking_ms"] = _r(x["ms_per_step_blocking_call"], 4)
+        xc = x.get("cpu_baseline")
+        if isinstance(xc, dict) and "value" in xc:       # the oracle's CPU scan of the same rows, same run: q/s on `cores` threads / on one
+            e["cpu"] = {"qps": _r(xc["value"], 4), "cores": xc.get("cores"), "qps_1t": _r(xc.get("value_1_thread"), 4)}
         sec.append(e)
     if "secondary" in full:
         line["secondary"] = sec
@@ -1190,20 +1338,14 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if args.exchange is None:
+        args.exchange = "tickets" if in_library else "rccl"
+    if args.exchange == "tickets" and not in_library:
+        args.exchange = "host"
     use_rccl = args.exchange == "rccl"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if use_rccl:
-            import datetime
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev,
-                                    timeout=datetime.timedelta(seconds=300))
-            probe_t = torch.ones(1, device=dev)
-            dist.all_reduce(probe_t)  # fail here, loudly and at once, if RCCL cannot talk across the node
-            assert int(probe_t.item()) == world
-            # (A silent fall-back to the gloo host exchange was tried and removed: tearing down a half-initialised
-            # RCCL group hangs instead of failing. `--exchange host` selects the host exchange explicitly.)
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        use_rccl = init_distributed(torch, dist, rank, world, dev, use_rccl)
 
     from wax_amd import HIPVectorEngine, VectorMetric, build, sharded
     build.build()
@@ -1224,9 +1366,11 @@ def main():
     if solo:
         lo, hi = (0, n) if rank == 0 else (0, 0)
     t_build = time.perf_counter()
+    preflight = None
     if in_library:
         same = bool(os.environ.get("WAX_BENCH_SAME_DEVICE"))          # testing only: every shard on GPU 0
         devs = [0 if same else g for g in range(args.gpus)]
+        preflight = handle_preflight(torch, devs)
         eng = _load_handle(torch, devs, n, dims)                       # block layout chosen by the library (ceil(n / N) rows per shard at this size)
         shard_rows = [int(eng.shardInfo(g)[2]) for g in range(args.gpus)]
         lo, hi = 0, max(shard_rows)                                     # rows per launch of ONE shard's scan kernel (roofline)
@@ -1284,10 +1428,7 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
-            if use_rccl:
-                dist.barrier(device_ids=[local_rank])
-            else:
-                dist.barrier()
+            dist_barrier(torch, dist, use_rccl, local_rank)
         torch.cuda.synchronize()
 
     # Python's cyclic collector must not fire inside the timed region: with torch imported a full (generation-2)
@@ -1304,6 +1445,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert len(last[0]) == (min(k, n) if not (solo and rank != 0) else 0)
+    # the node's own streaming-read rate over the same slab ("both denominators"): the library's microbenchmark —
+    # every float4 of the store summed, no selection — timed with HIP events right behind the timed region, on this engine
+    stream_read_gbps = None
+    if not in_library and hi > lo:
+        try:
+            ms_sr = eng.timeStreamRead(10)
+            if ms_sr and ms_sr > 0:
+                stream_read_gbps = (hi - lo) * dims * 4 / (ms_sr * 1e-3) / 1e9
+        except Exception as ex:  # noqa: BLE001
+            log(f"[bench] stream-read microbenchmark unavailable: {type(ex).__name__}: {ex}")
     import hashlib
     checksum = hashlib.sha256(np.asarray(last[0], dtype=np.uint64).tobytes()
                               + np.asarray(last[1], dtype=np.float32).tobytes()).hexdigest()[:16]
@@ -1375,11 +1526,19 @@ def main():
                 "timed_region": "kernels timed and chained inside it (--chain-timed-region)" if args.chain_timed_region else
                                 "product mode: scans of neighbouring queries overlap; per-launch times from the calibration pass",
                 "merge": "host" if (world > 1 and (args.host_merge or not use_rccl)) else "device",
-                "exchange": ("in-library" if in_library else "none (small-store rule)" if solo else (("rccl all_gather" if use_rccl else "host (gloo)") if world > 1 else "none")),
+                "exchange": (("in-library rccl" if exchange_mode == 1 else "in-library tickets" + (f" (rccl failed: {RCCL_FAILURE[0]})" if RCCL_FAILURE[0] else "")) if in_library else "none (small-store rule)" if solo else
+                             (("rccl all_gather" if use_rccl else ("host (gloo)" + (f" (rccl failed: {RCCL_FAILURE[0]})" if RCCL_FAILURE[0] else ""))) if world > 1 else "none")),
                 "last_result_checksum": checksum,
             },
             "roofline": scan_roofline(bytes_per_launch, kern_ms, launches, elapsed, args.steps, cal, traffic, traffic_source),
         }
+        if preflight is not None:
+            out["config"]["preflight"] = preflight
+        if stream_read_gbps and out["roofline"].get("achieved"):
+            out["roofline"]["peak_measured"] = stream_read_gbps          # GB/s: the second denominator, measured in this run on this GPU
+            out["roofline"]["frac_of_measured"] = out["roofline"]["achieved"] / stream_read_gbps
+            out["roofline"]["peak_measured_note"] = ("wax_hip_time_stream_read: 10 passes of a read-only float4 sum over the same slab, HIP events; "
+                                                     "`peak` stays the 8 TB/s spec the contract names")
         if world == 1 and not in_library and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(torch, args, dev, queries)
         elif world == 1:
@@ -1399,8 +1558,16 @@ def main():
             s, w = args.steps, args.warmup
             table = {
                 "s10k": lambda: secondary_single_query(torch, dev, 10_000, 384, k, max(s, 2000), max(w, 100), args.depth,
-                                                       "the 10K-row point of the N matrix: launch-latency-bound, 15 MB per query"),
-                "s1m": lambda: secondary_single_query(torch, dev, 1_000_000, 384, k, max(s, 600), max(w, 50), args.depth),
+                                                       "the 10K-row point of the N matrix: launch-latency-bound, 15 MB per query",
+                                                       cpu_seconds=0.0 if args.no_cpu_baseline else 2.0),
+                "s1m": lambda: secondary_single_query(torch, dev, 1_000_000, 384, k, max(s, 600), max(w, 50), args.depth,
+                                                      cpu_seconds=0.0 if args.no_cpu_baseline else 3.0),
+                # what Wax.search(topK:) asks the engine for: candidateLimit = max(topK, min(3 topK, 1000)) (UnifiedSearch.swift:1195-1200) —
+                # topK 100 -> k = 300, topK >= 334 -> k = 1000: beyond the fused selection (k <= 192), the general path of DESIGN 4.2
+                "s10m_k300": lambda: secondary_single_query(torch, dev, args.rows, 384, 300, max(20, min(s, 60)), 6, args.depth,
+                                                            "the headline store at top-300 = Wax.search(topK: 100): general selection"),
+                "s1m_k1000": lambda: secondary_single_query(torch, dev, 1_000_000, 384, 1000, max(s, 300), max(w, 30), args.depth,
+                                                            "1M rows at top-1000 = Wax.search(topK: 334 ...): general selection"),
                 "s1250k": lambda: secondary_single_query(torch, dev, 1_250_000, 384, k, max(s, 600), max(w, 50), args.depth,
                                                          "the headline's per-GPU shard at 8 GPUs (10M / 8 rows): what one rank of BASELINE config 4 scans per query"),
                 "b1m_q256": lambda: secondary_batched(torch, dev, 1_000_000, 384, 256, k, max(s, 200), max(w, 20),
@@ -1466,6 +1633,21 @@ def main():
             if in_library:
                 same_dev = bool(os.environ.get("WAX_BENCH_SAME_DEVICE"))
                 devs_ = [0 if same_dev else g for g in range(args.gpus)]
+                # the headline store under BOTH exchanges of the handle, whatever the headline itself used: one run = the comparison
+                for name, rccl_ in (("h_tickets", False), ("h_rccl", True)):
+                    if args.secondary != "all" and name not in want:
+                        continue
+                    try:
+                        RCCL_FAILURE[0] = None
+                        r = handle_single_query(torch, args, devs_, n, dims, k, max(20, min(args.steps, 60)), 6,
+                                                "the headline store, exchange = " + ("RCCL all-gather (device gather)" if rccl_ else "per-shard tickets + host merge"),
+                                                want_rccl=rccl_)
+                        r["name"] = name
+                        if rccl_ and RCCL_FAILURE[0]:
+                            r["exchange"] = f"tickets (rccl failed: {RCCL_FAILURE[0]})"
+                        sec.append(r)
+                    except Exception as ex:  # noqa: BLE001
+                        sec.append({"name": name, "error": f"{type(ex).__name__}: {ex}"})
                 for name, rows_, steps_, warm_, label in (
                         ("s1m", 1_000_000, max(args.steps, 600), max(args.warmup, 50), "N matrix: 1M rows; BASELINE config 2's corpus over the node"),
                         ("s10k", 10_000, max(args.steps, 2000), max(args.warmup, 100), "N matrix: 10K rows — a 15 MB store is not spread (small-store rule)")):
@@ -1490,10 +1672,7 @@ def main():
     if rank == 0:
         emit_once(out, args.detail_out)
     if world > 1:
-        if use_rccl:
-            dist.barrier(device_ids=[local_rank])
-        else:
-            dist.barrier()
+        dist_barrier(torch, dist, use_rccl, local_rank)
         dist.destroy_process_group()
 
 

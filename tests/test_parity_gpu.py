@@ -800,13 +800,13 @@ def test_batched_full_size_parity_on_one_gpu(wax, n, dims, nq, n_check):
 # global-row keys, pipelined ShardedSearcher, merge, barriers, max-over-ranks timing) is the code the
 # driver runs with --gpus N over RCCL.
 
-def _run_bench(nproc, extra, tmp_path, one_process=False):
+def _run_bench(nproc, extra, tmp_path, one_process=False, cpu=False):
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    common = ["--rows", "300000", "--steps", "12", "--warmup", "2", "--no-cpu-baseline", "--c5-rows", "300000"] + extra
+    common = ["--rows", "300000", "--steps", "12", "--warmup", "2", "--c5-rows", "300000"] + ([] if cpu else ["--no-cpu-baseline"]) + extra
     env = dict(os.environ)
     env.pop("WAX_HIP_SHARD_MIN_MB", None)          # the bench runs with the library's defaults
     if nproc == 1 or one_process:
@@ -848,6 +848,9 @@ def test_bench_contract_and_shard_invariance(wax, tmp_path):
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     # frac: per launch, from the calibration pass of the same run (12 chained, event-timed scans); pipeline_frac: the timed region
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["kernel_launches_timed"] == 12 and r["calibration"]["steps"] == 12
+    # the second denominator: the node's own streaming-read rate over the same slab, measured in this run
+    assert 1000.0 < r["peak_measured"] < 8000.0 and abs(r["frac_of_measured"] - r["achieved"] / r["peak_measured"]) < 1e-9
+    assert one["_line"]["roofline"]["peak_measured"] > 1000.0 and one["_line"]["roofline"]["frac_of_measured"] > 0
     assert abs(r["pipeline_frac"] - 300000 * 384 * 4 * 12 / (one["ms_per_step"] * 12e-3) / 1e9 / 8000.0) < 1e-6
     assert abs(one["value"] - 12 / (one["ms_per_step"] * 12e-3)) < 1e-6 * one["value"]
     assert "300K x 384" in one["metric"] and one["config"]["parallelism"] == "row-shard x1"
@@ -903,6 +906,14 @@ def test_bench_contract_and_shard_invariance(wax, tmp_path):
     # config 5 at N > 1, both launch shapes: ranks + all-gather, and one process on the sharded handle — same hits as one engine
     for run, shape in ((two, "ranks"), (three, "ranks"), (lib3, "handle")):
         c5 = run["secondary"]
+        if shape == "handle":
+            # the headline store under BOTH exchanges of the handle (round 6; with every shard on one GPU the RCCL one is not taken)
+            assert [x["name"] for x in c5[:2]] == ["h_tickets", "h_rccl"] and all("error" not in x for x in c5[:2]), c5[:2]
+            assert all(x["last_result_checksum"] == run["config"]["last_result_checksum"] and x["n_gpus"] == 3 for x in c5[:2])
+            assert run["config"]["preflight"]["ok"] is True and run["_line"]["config"]["preflight"]["ok"] is True, run["config"]["preflight"]
+            assert run["config"]["preflight"]["spread_equals_one_engine"] is True and sum(run["config"]["preflight"]["rows_per_device"]) == 32768
+            assert run["config"]["exchange"].startswith("in-library tickets")
+            c5 = c5[2:]
         # the rest of the N matrix (1M and 10K rows) on the sharded single-query path, in BOTH launch shapes (round 5: also the
         # one-process shape a driver is most likely to run): same last answer as one engine
         assert [x["name"] for x in c5] == ["s1m", "s10k", "c5"] and all("error" not in x for x in c5), c5
@@ -915,8 +926,8 @@ def test_bench_contract_and_shard_invariance(wax, tmp_path):
         if shape == "handle":
             assert c5[0]["rows_per_gpu"] == [333376, 333376, 333248] and c5[0]["ticket_searches"] > 0, c5[0]       # 1M rows: spread
             assert c5[1]["single_shard_searches"] > 0, c5[1]
-            assert [e_["name"] for e_ in run["_line"]["secondary"]] == ["s1m", "s10k", "c5"]
-            assert run["_line"]["secondary"][1]["rows_per_gpu"] == [10000, 0, 0]
+            assert [e_["name"] for e_ in run["_line"]["secondary"]] == ["h_tickets", "h_rccl", "s1m", "s10k", "c5"]
+            assert run["_line"]["secondary"][3]["rows_per_gpu"] == [10000, 0, 0]
             assert run["config"]["rows_per_gpu"] == [100032, 100032, 99936]
         c5 = c5[2:]
         assert len(c5) == 1 and c5[0]["name"] == "c5" and "error" not in c5[0], c5
@@ -924,6 +935,23 @@ def test_bench_contract_and_shard_invariance(wax, tmp_path):
         assert c5[0]["last_result_checksum"] == c5_one, (shape, run["n_gpus"])
         assert ("sharded handle" in c5[0]["config"]) == (shape == "handle")
         assert c5[0]["roofline"]["kernel_launches_timed"] >= c5[0]["steps"]
+
+
+def test_bench_secondaries_carry_cpu_baselines_and_the_general_selection_sizes(wax, tmp_path):
+    """Round 6: the 10K and 1M points of the N matrix carry the oracle's CPU scan of the same rows from the same
+    run, and the sizes Wax.search(topK: 100 / 334) really asks for (k = 300 / 1000: beyond the fused selection) are bench lines."""
+    run = _run_bench(1, ["--secondary", "s10k,s1m,s10m_k300,s1m_k1000", "--traffic", "off", "--cpu-baseline-seconds", "2"], tmp_path, cpu=True)
+    sec = {x["name"]: x for x in run["secondary"]}
+    assert list(sec) == ["s10k", "s1m", "s10m_k300", "s1m_k1000"] and all("error" not in x for x in sec.values()), sec
+    for name in ("s10k", "s1m"):
+        cb = sec[name]["cpu_baseline"]
+        assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port" and cb["value_1_thread"] > 0 and "rows" in cb["sample"], cb
+        assert sec[name]["value"] > cb["value"]                      # (the GPU path is not slower than the host's threads)
+    assert sec["s10m_k300"]["top_k"] == 300 and sec["s1m_k1000"]["top_k"] == 1000
+    assert "general" in sec["s10m_k300"]["roofline"]["note_general_selection"] and sec["s1m_k1000"]["roofline"]["frac"] > 0
+    line = {x["name"]: x for x in run["_line"]["secondary"]}
+    assert line["s10k"]["cpu"]["qps"] > 0 and line["s1m"]["cpu"]["cores"] >= 1 and "cpu" not in line["s1m_k1000"]
+    assert run["_line"]["cpu_baseline"]["value"] > 0
 
 
 def test_search_batch_hits_and_sharded_batch_single_rank(wax):

@@ -626,10 +626,7 @@ void free_slot(Slot* s) {
     if (!s) return;
     (void)hipFree(s->d_query); (void)hipHostFree(s->h_query); (void)hipFree(s->d_partials);
     (void)hipFree(s->d_hits); (void)hipHostFree(s->h_hits); (void)hipHostFree(s->h_done); (void)hipFree(s->d_dist);
-    if (s->sw_ready) {
-        (void)hipFree(s->sw.hist); (void)hipFree(s->sw.state); (void)hipFree(s->sw.counter);
-        (void)hipFree(s->sw.keys_a); (void)hipFree(s->sw.keys_b);
-    }
+    if (s->sw_ready) free_select_work(&s->sw);
     (void)hipEventDestroy(s->ev0); (void)hipEventDestroy(s->ev1); (void)hipEventDestroy(s->ev_done);
     delete s;
 }
@@ -699,11 +696,7 @@ int ensure_general(wax_hip_engine* e, Slot* s) {
         s->dist_cap = e->capacity;
     }
     if (!s->sw_ready) {
-        HIP_TRY(hipMalloc(&s->sw.hist, 256 * sizeof(uint32_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate select histogram");
-        HIP_TRY(hipMalloc(&s->sw.state, 2 * sizeof(uint64_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate select state");
-        HIP_TRY(hipMalloc(&s->sw.counter, sizeof(uint32_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate select counter");
-        HIP_TRY(hipMalloc(&s->sw.keys_a, (size_t)WAX_HIP_MAX_RESULTS * sizeof(int64_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate select keys");
-        HIP_TRY(hipMalloc(&s->sw.keys_b, (size_t)WAX_HIP_MAX_RESULTS * sizeof(int64_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate select keys");
+        HIP_TRY(alloc_select_work(&s->sw), WAX_HIP_ERR_ALLOC, "Failed to allocate the selection workspace");
         s->sw_ready = true;
     }
     return WAX_HIP_OK;
@@ -1077,7 +1070,7 @@ void free_filter_work(FilterWork* f) {
     if (!f) return;
     (void)hipFree(f->d_rows); (void)hipFree(f->d_ids); (void)hipFree(f->d_dist); (void)hipFree(f->d_allow); (void)hipFree(f->d_bitmap);
     (void)hipFree(f->d_block_sum); (void)hipFree(f->d_total); (void)hipFree(f->d_query); (void)hipFree(f->d_qnorm); (void)hipFree(f->d_hits);
-    (void)hipFree(f->sw.hist); (void)hipFree(f->sw.state); (void)hipFree(f->sw.counter); (void)hipFree(f->sw.keys_a); (void)hipFree(f->sw.keys_b);
+    free_select_work(&f->sw);
     if (f->h_total) (void)hipHostFree(f->h_total);
     if (f->h_hits) (void)hipHostFree(f->h_hits);
     if (f->stream) (void)hipStreamDestroy(f->stream);
@@ -1095,11 +1088,7 @@ static int alloc_filter_work(wax_hip_engine* e, FilterWork** out) {
     HIP_TRY(hipMalloc(&f->d_hits, (size_t)WAX_HIP_MAX_RESULTS * sizeof(wax_hip_hit)), WAX_HIP_ERR_ALLOC, "Failed to allocate filter hits");
     HIP_TRY(hipHostMalloc(&f->h_hits, (size_t)WAX_HIP_MAX_RESULTS * sizeof(wax_hip_hit), hipHostMallocDefault), WAX_HIP_ERR_ALLOC,
             "Failed to allocate filter hits staging");
-    HIP_TRY(hipMalloc(&f->sw.hist, 256 * sizeof(uint32_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate select histogram");
-    HIP_TRY(hipMalloc(&f->sw.state, 2 * sizeof(uint64_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate select state");
-    HIP_TRY(hipMalloc(&f->sw.counter, sizeof(uint32_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate select counter");
-    HIP_TRY(hipMalloc(&f->sw.keys_a, (size_t)WAX_HIP_MAX_RESULTS * sizeof(int64_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate select keys");
-    HIP_TRY(hipMalloc(&f->sw.keys_b, (size_t)WAX_HIP_MAX_RESULTS * sizeof(int64_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate select keys");
+    HIP_TRY(alloc_select_work(&f->sw), WAX_HIP_ERR_ALLOC, "Failed to allocate the selection workspace");
     guard.f = nullptr;
     *out = f;
     return WAX_HIP_OK;

@@ -162,8 +162,8 @@ hipError_t launch_merge_batch_hits(const wax_hip_hit* d_in, uint32_t n_shards, u
 // General (any k <= 10000) selection over a distance buffer: exact k-th key by 8-pass radix
 // select on the 64-bit key, compaction, rank sort, id lookup. Work buffers are caller-owned.
 struct SelectWork {
-    uint32_t* hist;      // [256]
-    uint64_t* state;     // [2]: prefix, remaining-k
+    uint32_t* hist;      // [2048 bins + 1 arrival ticket], zero between launches
+    uint64_t* state;     // [4]: prefix / threshold, rank left, resolved flag
     uint32_t* counter;   // [1]
     int64_t* keys_a;     // [kmax]
     int64_t* keys_b;     // [kmax]
@@ -171,6 +171,8 @@ struct SelectWork {
 hipError_t launch_select_general(const float* d_dist, uint32_t n_rows, uint32_t row_base, int k, int kpad,
                                  const uint64_t* d_ids, const SelectWork& w, wax_hip_hit* d_out,
                                  hipStream_t stream);
+hipError_t alloc_select_work(SelectWork* w);   // on the current device; synchronous (hipMemset of the histogram)
+void free_select_work(SelectWork* w);
 
 // Streaming-read microbenchmark: sums every float4 of [bytes] (16-B multiple), one partial per workgroup.
 hipError_t launch_stream_read(const float* d_src, uint64_t bytes, int nt, int grid, float* d_sink,

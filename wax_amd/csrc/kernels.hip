@@ -768,48 +768,99 @@ __device__ inline uint64_t ukey_of(float d, uint32_t row) {
     return (uint64_t)make_key(d, row) ^ 0x8000000000000000ull;  // unsigned-ordered
 }
 
-__global__ void select_init_kernel(uint32_t* hist, uint64_t* state, uint32_t* counter, uint32_t k) {
-    const int t = (int)threadIdx.x;
-    if (t < 256) hist[t] = 0;
-    if (t == 0) {
-        state[0] = 0;  // prefix (top bytes already decided)
-        state[1] = k;  // how many keys with this prefix precede-or-equal the target
-        *counter = 0;
-    }
-}
-
+// Round 6: 11-bit digits (11 + 11 + 10 over the ordered distance, 11 + 11 + 10 over the row), the pick fused into the histogram
+// pass (its last-arriving workgroup picks, re-arms the histogram and the ticket), no init launch, and passes that have nothing left
+// to decide return at once: after the third pass the distance of the k-th key is known, and when every key with that distance is
+// needed (always, unless equal distances straddle rank k) the threshold is final — the three row passes are three empty launches.
+// Six + three launches behind the distance pass instead of twenty; rounds 1-5 walked 8 x (histogram + pick) over n distances each.
+constexpr int SEL_PASSES = 6;
+constexpr int SEL_BINS = 2048;
+__host__ __device__ constexpr int sel_shift(int pass) { return pass == 0 ? 53 : pass == 1 ? 42 : pass == 2 ? 32 : pass == 3 ? 21 : pass == 4 ? 10 : 0; }
+__host__ __device__ constexpr int sel_bits(int pass) { return (pass == 2 || pass == 5) ? 10 : 11; }
+// state[0] = prefix (the digits decided so far, right-aligned), state[1] = rank still to find among the keys that carry the prefix,
+// state[2] = 1 once state[0] is the final threshold (the exact k-th smallest unsigned key, or the largest key of its tie group when
+// the whole group is needed). hist[SEL_BINS] = arrival ticket of the pass; *counter = slots handed out by the compaction.
 __global__ __launch_bounds__(256) void select_hist_kernel(const float* __restrict__ dist, uint32_t n,
-                                                          uint32_t row_base, int pass,
-                                                          const uint64_t* __restrict__ state,
-                                                          uint32_t* __restrict__ hist) {
-    __shared__ uint32_t h[256];
-    h[threadIdx.x] = 0;
+                                                          uint32_t row_base, int pass, uint32_t k,
+                                                          uint64_t* __restrict__ state,
+                                                          uint32_t* __restrict__ hist, uint32_t* __restrict__ counter) {
+    __shared__ uint32_t h[SEL_BINS];
+    __shared__ uint32_t part[256];
+    __shared__ uint32_t last_s;
+    const bool first = pass == 0;
+    if (!first && state[2] != 0) return;                      // nothing left to decide
+    for (int b = (int)threadIdx.x; b < SEL_BINS; b += 256) h[b] = 0;
     __syncthreads();
-    const uint64_t prefix = state[0];
-    const int shift = 56 - 8 * pass;
+    const uint64_t prefix = first ? 0ull : state[0];
+    const int shift = sel_shift(pass), bits = sel_bits(pass);
+    const uint32_t mask = (1u << bits) - 1u;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const uint64_t u = ukey_of(dist[i], row_base + i);
-        const bool match = (pass == 0) || ((u >> (shift + 8)) == prefix);
-        if (match) atomicAdd(&h[(u >> shift) & 0xff], 1u);
+        const bool match = first || ((u >> (shift + bits)) == prefix);
+        // distances of one store share their leading bits: in the first passes a whole wave lands in ONE bin — one LDS add, not 64
+        const uint32_t bin = match ? (uint32_t)(u >> shift) & mask : 0xFFFFFFFFu;
+        const uint32_t b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)bin);
+        if (__ballot(bin != b0) == 0ull) {
+            if (b0 != 0xFFFFFFFFu) {
+                const unsigned long long act = __ballot(true);
+                if (lane_id() == (int)__builtin_ctzll(act)) atomicAdd(&h[b0], (uint32_t)__builtin_popcountll(act));
+            }
+        } else if (match) {
+            atomicAdd(&h[bin], 1u);
+        }
     }
     __syncthreads();
-    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
-}
-
-__global__ void select_pick_kernel(uint32_t* hist, uint64_t* state) {
-    // single thread: 256 bins
-    if (threadIdx.x != 0) return;
-    uint64_t rem = state[1];
-    uint32_t cum = 0;
-    int bin = 255;
-    for (int b = 0; b < 256; ++b) {
-        const uint32_t c = hist[b];
-        if (cum + c >= rem) { bin = b; break; }
-        cum += c;
+    for (int b = (int)threadIdx.x; b < SEL_BINS; b += 256)
+        if (h[b]) atomicAdd(&hist[b], h[b]);
+    // last arriver picks. The histogram is only ever touched by device-scope atomics (they execute in L2): once a workgroup's adds have
+    // completed — the release fence waits for them — its ticket orders them before the last arriver's atomic loads.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (threadIdx.x == 0) last_s = __hip_atomic_fetch_add(&hist[SEL_BINS], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (last_s == 0u) return;
+    const int nb = 1 << bits, per = SEL_BINS / 256;           // 8 consecutive bins per thread
+    uint32_t mine[SEL_BINS / 256];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int j = 0; j < per; ++j) {
+        const int b = (int)threadIdx.x * per + j;
+        // (a returning atomic: the value comes from wherever device-scope atomics execute, never from a stale line of this XCD's L2;
+        // the exchange also re-arms the bin for the next pass)
+        mine[j] = b < nb ? __hip_atomic_exchange(&hist[b], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        sum += mine[j];
     }
-    state[0] = (state[0] << 8) | (uint64_t)bin;
-    state[1] = rem - cum;
-    for (int b = 0; b < 256; ++b) hist[b] = 0;
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {                                    // exclusive scan of 256 partial sums
+        uint32_t run = 0;
+        for (int t = 0; t < 256; ++t) { const uint32_t v = part[t]; part[t] = run; run += v; }
+    }
+    __syncthreads();
+    const uint64_t rem = first ? (uint64_t)k : state[1];
+    uint32_t cum = part[threadIdx.x];
+    if ((uint64_t)cum < rem && (uint64_t)cum + sum >= rem) {   // exactly one thread: the bin of the k-th key is one of its eight
+        int bin = 0;
+        uint32_t c = 0;
+#pragma unroll
+        for (int j = 0; j < per; ++j) {
+            if ((uint64_t)cum + mine[j] >= rem && c == 0) { bin = (int)threadIdx.x * per + j; c = mine[j]; }
+            if (c == 0) cum += mine[j];
+        }
+        const uint64_t np = (prefix << bits) | (uint64_t)bin;
+        const uint64_t left = rem - cum;                       // rank inside the bin, 1 .. c
+        const bool all_needed = left == (uint64_t)c;           // every key of the bin is among the k smallest: no finer digit matters
+        if (pass == SEL_PASSES - 1 || all_needed) {
+            state[0] = shift == 0 ? np : ((np << shift) | ((1ull << shift) - 1ull));
+            state[2] = 1;
+        } else {
+            state[0] = np;
+            state[2] = 0;
+        }
+        state[1] = left;
+        if (first) *counter = 0;
+    }
+    if (threadIdx.x == 0) (void)__hip_atomic_exchange(&hist[SEL_BINS], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __global__ __launch_bounds__(256) void select_compact_kernel(const float* __restrict__ dist, uint32_t n,
@@ -863,18 +914,30 @@ hipError_t launch_select_general(const float* d_dist, uint32_t n_rows, uint32_t 
     if (k < 1 || (uint32_t)k > n_rows || k > WAX_HIP_MAX_RESULTS || kpad < k) return hipErrorInvalidValue;
     int grid = (int)((n_rows + 255) / 256);
     if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(select_init_kernel, dim3(1), dim3(256), 0, st, w.hist, w.state, w.counter, (uint32_t)k);
-    for (int pass = 0; pass < 8; ++pass) {
-        hipLaunchKernelGGL(select_hist_kernel, dim3(grid), dim3(256), 0, st, d_dist, n_rows, row_base, pass, w.state,
-                           w.hist);
-        hipLaunchKernelGGL(select_pick_kernel, dim3(1), dim3(64), 0, st, w.hist, w.state);
-    }
+    for (int pass = 0; pass < SEL_PASSES; ++pass)
+        hipLaunchKernelGGL(select_hist_kernel, dim3(grid), dim3(256), 0, st, d_dist, n_rows, row_base, pass, (uint32_t)k, w.state,
+                           w.hist, w.counter);
     hipLaunchKernelGGL(select_compact_kernel, dim3(grid), dim3(256), 0, st, d_dist, n_rows, row_base, w.state,
                        w.counter, w.keys_a, (uint32_t)k);
     hipLaunchKernelGGL(rank_sort_kernel, dim3((k + 255) / 256), dim3(256), 0, st, w.keys_a, k, w.keys_b);
     hipLaunchKernelGGL(keys_to_hits_kernel, dim3((kpad + 255) / 256), dim3(256), 0, st, w.keys_b, k, kpad, d_ids,
                        row_base, n_rows, d_out);
     return hipGetLastError();
+}
+
+hipError_t alloc_select_work(SelectWork* w) {
+    hipError_t e = hipMalloc(&w->hist, (SEL_BINS + 1) * sizeof(uint32_t));           // bins + the arrival ticket
+    if (e == hipSuccess) e = hipMemset(w->hist, 0, (SEL_BINS + 1) * sizeof(uint32_t));   // every pass leaves them zero again
+    if (e == hipSuccess) e = hipMalloc(&w->state, 4 * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMemset(w->state, 0, 4 * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMalloc(&w->counter, sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&w->keys_a, (size_t)WAX_HIP_MAX_RESULTS * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMalloc(&w->keys_b, (size_t)WAX_HIP_MAX_RESULTS * sizeof(int64_t));
+    return e;
+}
+void free_select_work(SelectWork* w) {
+    (void)hipFree(w->hist); (void)hipFree(w->state); (void)hipFree(w->counter); (void)hipFree(w->keys_a); (void)hipFree(w->keys_b);
+    *w = SelectWork{};
 }
 
 // ---------------------------------------------------------------------------
