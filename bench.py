@@ -1639,7 +1639,7 @@ def main():
                         continue
                     try:
                         RCCL_FAILURE[0] = None
-                        r = handle_single_query(torch, args, devs_, n, dims, k, max(20, min(args.steps, 60)), 6,
+                        r = handle_single_query(torch, args, devs_, n, dims, k, args.steps, args.warmup,     # (the headline's own steps: same last query, same checksum)
                                                 "the headline store, exchange = " + ("RCCL all-gather (device gather)" if rccl_ else "per-shard tickets + host merge"),
                                                 want_rccl=rccl_)
                         r["name"] = name

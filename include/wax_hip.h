@@ -362,7 +362,9 @@ int wax_hip_stats(wax_hip_engine* e, wax_hip_stats_t* out);
  * get-only
  *   "variant_count", "scan_grid", "store_ptr" (device address of the f32 slab), "fused_max_k", "batch_queries", "query_args_scans", "merged_scans", "done_flag_waits",
  *   "batch_inline_retries", "batch_max_row_err_e9", "batch_fallbacks", "onepass_queries", "batch_max_k", "batch_retries",
- *   "batch_multi_passes", "batch_multi_queries", "batch_multi_group" / "batch_multi_group_big", "filter_device_searches".
+ *   "batch_multi_passes", "batch_multi_queries", "batch_multi_group" / "batch_multi_group_big", "filter_device_searches",
+ *   "mirror_rows_converted" / "mirror_conversions" (bf16 mirror: rows converted / conversions enqueued so far — an append converts its own
+ *   rows only), "idhash_rows_inserted", "batch_max_norm_e6".
  * sharded handles: every key above is forwarded to all shards; plus
  *   "ticket_path" (single queries: 1 (default) = every shard that holds rows answers through its own ticket — one launch per shard,
  *   submitted side by side by the handle's worker threads, hits straight to pinned memory — and the host merges G x k keys;

@@ -63,10 +63,13 @@ __device__ inline unsigned short f32_to_bf16_rne(float x) {
 // Also emits ||v||^2 (L2 epilogue) and the global max ||v|| (certificate bound for dot / L2).
 // One wave per row; used for the corpus mirror and for the query block (rows in
 // [n_rows, n_rows_padded) are zero-filled).
+// row_list != nullptr (round 6: rows overwritten by an upsert): work item i converts row row_list[i] of src into row row_list[i]
+// of dst / norm2 instead of row i.
 __global__ __launch_bounds__(256) void mirror_kernel(const float* __restrict__ src, uint32_t n_rows,
                                                      uint32_t n_rows_padded, uint32_t dims, int normalize,
                                                      unsigned short* __restrict__ dst, float* __restrict__ norm2,
-                                                     unsigned int* __restrict__ max_norm_bits) {
+                                                     unsigned int* __restrict__ max_norm_bits,
+                                                     const uint32_t* __restrict__ row_list) {
     // max_norm_bits[0] = max ||v||; max_norm_bits[1] = max over the rows of ||x - bf16(x)||, x = the (scaled) f32 row that was
     // rounded: the row-side term of the cosine certificate bound, MEASURED instead of the worst case 2^-9 ||x|| (batch_prep_kernel)
     __shared__ unsigned int block_max, block_max_err;
@@ -77,9 +80,10 @@ __global__ __launch_bounds__(256) void mirror_kernel(const float* __restrict__ s
     if (threadIdx.x == 0) { block_max = 0u; block_max_err = 0u; }
     __syncthreads();
     float wave_max = 0.f, wave_max_err = 0.f;  // one global atomic per workgroup: a per-row atomicMax serialises at ~11 ns each
-    for (uint32_t r = gwave; r < n_rows_padded; r += nwaves) {
+    for (uint32_t item = gwave; item < n_rows_padded; item += nwaves) {
+        const uint32_t r = row_list != nullptr ? row_list[item] : item;
         unsigned short* out = dst + (size_t)r * dims;
-        if (r >= n_rows) {
+        if (item >= n_rows) {
             for (uint32_t c = lane; c < dims; c += WAVE) out[c] = 0;
             if (lane == 0) norm2[r] = 0.f;
             continue;
@@ -140,7 +144,17 @@ hipError_t launch_mirror(const float* src, uint32_t n_rows, uint32_t n_rows_padd
     uint64_t blocks = ((uint64_t)n_rows_padded + 3) / 4;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(mirror_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, n_rows, n_rows_padded, dims, normalize,
-                       dst, norm2, max_norm_bits);
+                       dst, norm2, max_norm_bits, (const uint32_t*)nullptr);
+    return hipGetLastError();
+}
+
+hipError_t launch_mirror_rows(const float* src, const uint32_t* d_rows, uint32_t n_listed, uint32_t dims, int normalize,
+                              unsigned short* dst, float* norm2, unsigned int* max_norm_bits, hipStream_t st) {
+    if (n_listed == 0) return hipSuccess;
+    uint64_t blocks = ((uint64_t)n_listed + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(mirror_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, n_listed, n_listed, dims, normalize,
+                       dst, norm2, max_norm_bits, d_rows);
     return hipGetLastError();
 }
 
@@ -1469,11 +1483,14 @@ __global__ __launch_bounds__(256) void batch_prep_kernel(PrepArgs a) {
         // rounding errors are two orders of magnitude below either, which is why no test ever saw it; errors that line up with the
         // query could have defeated it. The measured bound is rigorous AND about what the old constant was.)
         const double qn_d = a.metric == BM_COS ? 1.0 + 1e-6 : (double)c;
-        const double vn_d = a.metric == BM_COS ? 1.0 + 1e-6 : (double)a.max_norm;
+        // the mirror's measured bounds, where its conversions left them (device words: no host round trip between a conversion and this launch)
+        const float max_norm = a.max_bits != nullptr ? __uint_as_float(a.max_bits[0]) : 0.f;
+        const float max_row_err = (a.max_bits != nullptr && a.use_measured) ? __uint_as_float(a.max_bits[1]) : 0.f;
+        const double vn_d = a.metric == BM_COS ? 1.0 + 1e-6 : (double)max_norm;
         const double u = 0.0078125 * (1.0 + 1.0 / 512.0) + (double)D * 5.97e-8 + 1e-6;          // worst case, relative to ||q|| max||v||
         double dot_err = u * qn_d * vn_d * 1.001;
-        if (a.max_row_err > 0.f) {
-            const double measured = sqrt(qe2) * vn_d * (1.0 + 1.0 / 256.0) + qn_d * (double)a.max_row_err * 1.001 +
+        if (max_row_err > 0.f) {
+            const double measured = sqrt(qe2) * vn_d * (1.0 + 1.0 / 256.0) + qn_d * (double)max_row_err * 1.001 +
                                     3.0 * (double)D * 5.97e-8 * qn_d * vn_d;
             if (measured < dot_err) dot_err = measured;
         }
@@ -1481,7 +1498,7 @@ __global__ __launch_bounds__(256) void batch_prep_kernel(PrepArgs a) {
         if (a.metric == BM_COS) eps = (float)(dot_err + 3e-6);
         else if (a.metric == BM_DOT) eps = (float)(dot_err + 1e-6 * (1.0 + qn_d * vn_d));
         else {   // L2: ||q||^2 + ||v||^2 - 2 q.v carries the factor 2 and the norms' own rounding
-            const double ss = (double)c * (double)c + (double)a.max_norm * (double)a.max_norm;
+            const double ss = (double)c * (double)c + (double)max_norm * (double)max_norm;
             eps = (float)(2.0 * dot_err + 4e-6 * (1.0 + ss));
         }
         eps = nextafterf(eps, __builtin_inff());             // the double -> float conversion may have rounded down

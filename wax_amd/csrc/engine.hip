@@ -247,7 +247,12 @@ struct IdHash {
     std::mutex mu;                   // serialises the (re)build only
     uint32_t* d_table = nullptr;
     uint64_t slots = 0;
-    std::atomic<bool> valid{false};
+    std::atomic<bool> valid{false};  // the table holds exactly rows [0, count)
+    // Round 6: appends do not discard the table — rows [rows, count) are inserted by the next long allow-list (an upsert keeps id -> row;
+    // a removal shifts every later row and a deserialize replaces them all: those start over, like the reference's firstIndex(of:) scan
+    // they are O(N) anyway).
+    uint64_t rows = 0;               // rows [0, rows) are in the table (guarded by mu / the exclusive engine lock)
+    bool stale = true;               // the table must be rebuilt from row 0
 };
 
 // Batched (bf16 MFMA) path. The corpus mirror is shared by every batch (read-only during searches, rebuilt lazily by
@@ -259,12 +264,25 @@ struct BatchMirror {
     float* d_vn2 = nullptr;              // [mirror_cap] ||v||^2
     unsigned int* d_maxnorm = nullptr;
     uint64_t mirror_cap = 0;
-    std::atomic<bool> mirror_valid{false};
+    std::atomic<bool> mirror_valid{false};   // fast path: nothing to convert (rows == count, no dirty row, not stale, large enough)
+    // Round 6: a mutation no longer throws the mirror away (rounds 1-5 re-converted the WHOLE store after any add / remove: 30.7 GB read
+    // + 15.4 GB written and a blocking sync at 10M x 768, per mutation, on an ingest-while-serving workload — the reference's add is one
+    // row copy, MetalVectorEngine.swift:330-357). Appends leave rows [rows, count) to convert; an upsert lists its row in `dirty`; a
+    // removal moves the mirror's tail down like the store's (:431-438); only reallocation and deserialize convert everything again.
+    // max ||v|| and max ||x - bf16(x)|| stay on the device (d_maxnorm, read there by the prep kernel) and only ever grow between full
+    // conversions: a bound that is too large by a row that has since been overwritten or removed is still a bound.
+    // Writers hold the exclusive engine lock; ensure_mirror holds `mu` under the shared one.
+    uint64_t rows = 0;                   // rows [0, rows) of the mirror match the store, except `dirty`
+    std::vector<uint32_t> dirty;         // rows < `rows` overwritten since (upserts); more than kMirrorMaxDirty of them = stale
+    bool stale = true;                   // convert everything again
+    uint32_t* d_dirty = nullptr;         // device copy of `dirty` for the listed-rows conversion
+    hipEvent_t ev_ready = nullptr;       // recorded behind the last conversion: other workspaces' streams wait for it
+    bool ev_pending = false;
+    std::atomic<uint64_t> rows_converted{0}, conversions{0};   // statistics ("mirror_rows_converted" / "mirror_conversions")
     std::atomic<int> mirror_wanted{0};   // small batches since the last mutation that a VALID mirror would have made cheaper
-    float max_norm = 0.f;
-    float max_row_err = 0.f;             // max over the rows of ||x - bf16(x)|| (x = the f32 row that was rounded): certificate bound, row side
 };
 
+constexpr size_t kMirrorMaxDirty = 4096; // upserted rows remembered one by one; beyond that the mirror is converted again as a whole
 constexpr uint32_t kBatchMaxQ = 1024;   // queries per GEMM pass
 constexpr uint32_t kBatchSegBase = FUSED_MAX_K;   // slab pipeline: a candidate row = [0, kBatchSegBase) best list, then the survivor area
 constexpr uint32_t kBatchSegArea = 4096;          // survivors per query between two tighten passes (slab pipeline) / of the one pass
@@ -429,7 +447,7 @@ struct wax_hip_engine {
     std::atomic<int64_t> batch_prof_ptr{0};  // diagnosis: device address of the phase-timing buffer of the filtering GEMM (GemmArgs::prof); 0 = the product kernel
     std::atomic<int64_t> batch_debug{0};     // test / diagnosis bits, none of which can change an answer: 4096 = no pace gate, 16384 = one wave of workgroup 1 pretends its split-barrier wait timed out, 65536 = the device-side retry re-scores every survivor
     std::atomic<int64_t> batch_rega{5};      // register-resident-queries GEMM where it applies: 5 (default) split tile barrier, 1 workgroup barrier per tile; 0 = the LDS-tiled kernel instead
-    std::atomic<uint64_t> st_batch_queries{0}, st_batch_fallbacks{0};
+    std::atomic<uint64_t> st_batch_queries{0}, st_batch_fallbacks{0}, st_idhash_rows{0};
     BatchMirror batch;
     std::mutex bctx_mu;
     std::condition_variable bctx_cv;
@@ -943,37 +961,132 @@ void harvest_ring_event(wax_hip_engine* e, int r) {
 // ---------------------------------------------------------------------------
 // Batched path: Q x D^T on the matrix cores (batch.hip). Everything here is called with the shared lock held.
 
-// The bf16 mirror of the store (+ ||v||^2, max ||v||): allocated at the first batched search, rebuilt lazily after
-// any mutation. Concurrent batches serialise on the rebuild only.
+// Rows the next ensure_mirror would convert (a planning figure: read without the mirror's mutex).
+static double mirror_rows_to_convert(wax_hip_engine* e) {
+    const BatchMirror& b = e->batch;
+    if (b.mirror_valid.load(std::memory_order_acquire)) return 0.0;
+    if (b.stale || b.d_cb == nullptr || b.mirror_cap < e->capacity) return (double)e->count;
+    const uint64_t cnt = e->count;
+    return (double)(cnt > b.rows ? cnt - b.rows : 0) + (double)b.dirty.size();
+}
+
+// Mutation hooks of the bf16 mirror and the id -> row table (exclusive engine lock held).
+static void mirror_note_upsert(wax_hip_engine* e, uint64_t row) {
+    BatchMirror& b = e->batch;
+    b.mirror_valid = false;
+    if (b.stale || row >= b.rows) return;                    // not mirrored yet: converted with the appended range
+    if (b.dirty.size() >= kMirrorMaxDirty) { b.stale = true; b.dirty.clear(); return; }
+    b.dirty.push_back((uint32_t)row);
+}
+static void mirror_note_append(wax_hip_engine* e) { e->batch.mirror_valid = false; e->idhash.valid = false; }
+static void mirror_note_replaced(wax_hip_engine* e) {       // deserialize: every row is new
+    e->batch.mirror_valid = false; e->batch.stale = true; e->batch.dirty.clear(); e->batch.rows = 0;
+    e->idhash.valid = false; e->idhash.stale = true; e->idhash.rows = 0;
+}
+// remove(frameId:) moved store rows (idx, count) down by one (MetalVectorEngine.swift:431-438): the mirror's tail follows (half the
+// bytes of the store's own move), and the listed dirty rows move with it. Called BEFORE count is decremented.
+static int mirror_note_remove(wax_hip_engine* e, uint64_t idx) {
+    BatchMirror& b = e->batch;
+    e->idhash.valid = false; e->idhash.stale = true; e->idhash.rows = 0;     // every later row changed its number
+    b.mirror_valid = false;
+    if (b.stale || b.d_cb == nullptr || idx >= b.rows) return WAX_HIP_OK;
+    if (b.ev_pending) { (void)hipEventSynchronize(b.ev_ready); b.ev_pending = false; }
+    const uint64_t after = b.rows - 1 - idx;
+    if (after > 0) {
+        if (!e->d_bounce)
+            HIP_TRY(hipMalloc(&e->d_bounce, kBounceBytes), WAX_HIP_ERR_ALLOC, "Failed to allocate bounce buffer");
+        const uint64_t rb = (uint64_t)e->dims * sizeof(unsigned short);
+        HIP_TRY(device_shift_down(b.d_cb, idx * rb, (idx + 1) * rb, after * rb, e->d_bounce, kBounceBytes, nullptr), WAX_HIP_ERR_INTERNAL, "mirror row shift");
+        HIP_TRY(device_shift_down(b.d_vn2, idx * 4, (idx + 1) * 4, after * 4, e->d_bounce, kBounceBytes, nullptr), WAX_HIP_ERR_INTERNAL, "mirror norm shift");
+        HIP_TRY(hipStreamSynchronize(nullptr), WAX_HIP_ERR_INTERNAL, "mirror shift sync");
+    }
+    b.rows -= 1;
+    size_t w = 0;
+    for (size_t i = 0; i < b.dirty.size(); ++i) {
+        const uint32_t r = b.dirty[i];
+        if (r == idx) continue;
+        b.dirty[w++] = r > idx ? r - 1 : r;
+    }
+    b.dirty.resize(w);
+    return WAX_HIP_OK;
+}
+
+// The bf16 mirror of the store (+ ||v||^2, max ||v||, max rounding error): allocated at the first batched search, then kept in step
+// with the store incrementally — see BatchMirror. Concurrent batches serialise on the conversion's ENQUEUE only: nothing here waits
+// for the device (the converting stream records an event that every other workspace's stream waits for).
 int ensure_mirror(wax_hip_engine* e, hipStream_t st) {
     BatchMirror& b = e->batch;
-    if (b.mirror_valid.load(std::memory_order_acquire) && b.mirror_cap >= e->capacity) return WAX_HIP_OK;
+    if (b.mirror_valid.load(std::memory_order_acquire) && b.mirror_cap >= e->capacity) {
+        // converted, but perhaps still in flight on another workspace's stream
+        std::unique_lock<std::mutex> g(b.mu);
+        if (b.ev_pending) {
+            if (hipEventQuery(b.ev_ready) == hipSuccess) b.ev_pending = false;
+            else HIP_TRY(hipStreamWaitEvent(st, b.ev_ready, 0), WAX_HIP_ERR_INTERNAL, "mirror ready wait");
+        }
+        return WAX_HIP_OK;
+    }
     std::unique_lock<std::mutex> g(b.mu);
     const uint32_t D = e->dims;
-    if (!b.d_maxnorm) HIP_TRY(hipMalloc(&b.d_maxnorm, 2 * sizeof(unsigned int)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch scalars");
+    if (!b.d_maxnorm) {
+        HIP_TRY(hipMalloc(&b.d_maxnorm, 2 * sizeof(unsigned int)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch scalars");
+        HIP_TRY(hipMalloc(&b.d_dirty, kMirrorMaxDirty * sizeof(uint32_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate batch scalars");
+        HIP_TRY(hipEventCreateWithFlags(&b.ev_ready, hipEventDisableTiming), WAX_HIP_ERR_INTERNAL, "event create");
+        b.stale = true;
+    }
+    if (b.ev_pending) HIP_TRY(hipStreamWaitEvent(st, b.ev_ready, 0), WAX_HIP_ERR_INTERNAL, "mirror ready wait");   // order behind the previous conversion
     if (b.mirror_cap < e->capacity) {
-        // no batch can be reading the old mirror: a stale (smaller) mirror is only possible after a mutation, which
-        // took the exclusive lock after every reader had finished
-        (void)hipFree(b.d_cb); (void)hipFree(b.d_vn2);
-        b.d_cb = nullptr; b.d_vn2 = nullptr; b.mirror_cap = 0; b.mirror_valid = false;
+        // The store was reallocated (capacity doubles, MetalVectorEngine.swift:857-871). No batch can be reading the old mirror: a
+        // smaller mirror is only possible after a mutation, which took the exclusive lock after every reader had finished. The
+        // converted rows move over (a device copy of half the store's bytes, not a re-conversion from f32).
+        unsigned short* ncb = nullptr; float* nvn = nullptr;
         // + slack rows: the filtering GEMM requests whole tiles without clamps — its last tile may run up to (tile rows - 1) rows
         // past the store, plus one row for the pad slots and the slack behind the tile image (never used: masked by the selection)
-        HIP_TRY(hipMalloc(&b.d_cb, ((size_t)e->capacity + BATCH_MIRROR_SLACK_ROWS) * D * sizeof(unsigned short)), WAX_HIP_ERR_ALLOC, "Failed to allocate bf16 mirror");
-        HIP_TRY(hipMemsetAsync(b.d_cb + (size_t)e->capacity * D, 0, (size_t)BATCH_MIRROR_SLACK_ROWS * D * sizeof(unsigned short), st), WAX_HIP_ERR_INTERNAL, "mirror slack clear");
-        HIP_TRY(hipMalloc(&b.d_vn2, (size_t)e->capacity * sizeof(float)), WAX_HIP_ERR_ALLOC, "Failed to allocate row norms");
-        b.mirror_cap = e->capacity;
+        HIP_TRY(hipMalloc(&ncb, ((size_t)e->capacity + BATCH_MIRROR_SLACK_ROWS) * D * sizeof(unsigned short)), WAX_HIP_ERR_ALLOC, "Failed to allocate bf16 mirror");
+        if (hipMalloc(&nvn, (size_t)e->capacity * sizeof(float)) != hipSuccess) { (void)hipFree(ncb); return fail(WAX_HIP_ERR_ALLOC, "Failed to allocate row norms"); }
+        hipError_t err = hipMemsetAsync(ncb + (size_t)e->capacity * D, 0, (size_t)BATCH_MIRROR_SLACK_ROWS * D * sizeof(unsigned short), st);
+        if (err == hipSuccess && !b.stale && b.rows > 0 && b.d_cb) {
+            err = hipMemcpyAsync(ncb, b.d_cb, (size_t)b.rows * D * sizeof(unsigned short), hipMemcpyDeviceToDevice, st);
+            if (err == hipSuccess) err = hipMemcpyAsync(nvn, b.d_vn2, (size_t)b.rows * sizeof(float), hipMemcpyDeviceToDevice, st);
+            if (err == hipSuccess) err = hipStreamSynchronize(st);                     // the old buffers are freed next
+        } else {
+            b.stale = true;
+        }
+        if (err != hipSuccess) { (void)hipFree(ncb); (void)hipFree(nvn); return fail(WAX_HIP_ERR_INTERNAL, std::string("mirror move: ") + hipGetErrorString(err)); }
+        (void)hipFree(b.d_cb); (void)hipFree(b.d_vn2);
+        b.d_cb = ncb; b.d_vn2 = nvn; b.mirror_cap = e->capacity;
     }
-    if (!b.mirror_valid.load(std::memory_order_acquire)) {
+    const uint64_t count = e->count;
+    if (b.stale) {
+        b.rows = 0; b.dirty.clear(); b.stale = false;
         HIP_TRY(hipMemsetAsync(b.d_maxnorm, 0, 2 * sizeof(unsigned int), st), WAX_HIP_ERR_INTERNAL, "batch memset");
-        HIP_TRY(launch_mirror(e->d_store, (uint32_t)e->count, (uint32_t)e->count, D, e->metric == WAX_HIP_METRIC_COSINE ? 1 : 0,
-                              b.d_cb, b.d_vn2, b.d_maxnorm, st), WAX_HIP_ERR_INTERNAL, "mirror kernel launch");
-        unsigned int bits[2] = {0u, 0u};
-        HIP_TRY(hipMemcpyAsync(bits, b.d_maxnorm, sizeof(bits), hipMemcpyDeviceToHost, st), WAX_HIP_ERR_INTERNAL, "max norm download");
-        HIP_TRY(hipStreamSynchronize(st), WAX_HIP_ERR_INTERNAL, "mirror sync");
-        std::memcpy(&b.max_norm, &bits[0], sizeof(float));
-        std::memcpy(&b.max_row_err, &bits[1], sizeof(float));
-        b.mirror_valid.store(true, std::memory_order_release);
     }
+    if (b.rows > count) b.rows = count;                       // (cannot happen: removals move `rows` with them)
+    const int normalize = e->metric == WAX_HIP_METRIC_COSINE ? 1 : 0;
+    uint64_t converted = 0;
+    if (b.rows < count) {                                     // appended since: rows [rows, count)
+        const uint64_t n_new = count - b.rows;
+        HIP_TRY(launch_mirror(e->d_store + b.rows * D, (uint32_t)n_new, (uint32_t)n_new, D, normalize, b.d_cb + b.rows * D, b.d_vn2 + b.rows,
+                              b.d_maxnorm, st), WAX_HIP_ERR_INTERNAL, "mirror kernel launch");
+        converted += n_new;
+        b.rows = count;
+    }
+    if (!b.dirty.empty()) {                                   // overwritten since: the listed rows
+        std::sort(b.dirty.begin(), b.dirty.end());
+        b.dirty.erase(std::unique(b.dirty.begin(), b.dirty.end()), b.dirty.end());
+        HIP_TRY(hipMemcpyAsync(b.d_dirty, b.dirty.data(), b.dirty.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st), WAX_HIP_ERR_INTERNAL, "dirty row list upload");
+        HIP_TRY(hipStreamSynchronize(st), WAX_HIP_ERR_INTERNAL, "dirty row list upload");   // (pageable source: the vector is cleared next; a rare path)
+        HIP_TRY(launch_mirror_rows(e->d_store, b.d_dirty, (uint32_t)b.dirty.size(), D, normalize, b.d_cb, b.d_vn2, b.d_maxnorm, st),
+                WAX_HIP_ERR_INTERNAL, "mirror kernel launch");
+        converted += b.dirty.size();
+        b.dirty.clear();
+    }
+    if (converted) {
+        HIP_TRY(hipEventRecord(b.ev_ready, st), WAX_HIP_ERR_INTERNAL, "mirror ready record");
+        b.ev_pending = true;
+        b.rows_converted += converted;
+        b.conversions += 1;
+    }
+    b.mirror_valid.store(true, std::memory_order_release);
     return WAX_HIP_OK;
 }
 
@@ -1132,11 +1245,18 @@ static int ensure_idhash(wax_hip_engine* e, hipStream_t st) {
     if (h.slots < want) {
         (void)hipFree(h.d_table);
         h.d_table = nullptr; h.slots = 0;
+        want *= 2;                                // room for the appends to come: a table that must grow is rebuilt from row 0
         HIP_TRY(hipMalloc(&h.d_table, (size_t)want * sizeof(uint32_t)), WAX_HIP_ERR_ALLOC, "Failed to allocate id table");
         h.slots = want;
+        h.stale = true;
     }
-    HIP_TRY(launch_idhash_build(e->d_ids, (uint32_t)e->count, h.d_table, h.slots, st), WAX_HIP_ERR_INTERNAL, "id table kernel launch");
+    if (h.stale) { h.rows = 0; h.stale = false; }
+    if (h.rows > e->count) { h.rows = 0; }        // (cannot happen: removals start the table over)
+    // rows [h.rows, count): all of them after a removal / deserialize / growth (the table is cleared first), the appended ones otherwise
+    HIP_TRY(launch_idhash_build(e->d_ids, (uint32_t)h.rows, (uint32_t)e->count, h.d_table, h.slots, st), WAX_HIP_ERR_INTERNAL, "id table kernel launch");
     HIP_TRY(hipStreamSynchronize(st), WAX_HIP_ERR_INTERNAL, "id table build failed on device");
+    e->st_idhash_rows += e->count - h.rows;
+    h.rows = e->count;
     h.valid.store(true, std::memory_order_release);
     return WAX_HIP_OK;
 }
@@ -1328,8 +1448,9 @@ int batch_enqueue(wax_hip_engine* e, BatchCtx* c, const float* d_queries, uint32
     const uint32_t n = (uint32_t)e->count;
     const uint32_t nq_pad = (qn + 255u) & ~255u;  // 256: the register-resident-queries GEMM works on groups of 256
     PrepArgs pa{};
-    pa.queries = d_queries; pa.nq = qn; pa.nq_pad = nq_pad; pa.dims = D; pa.metric = e->metric; pa.max_norm = b.max_norm;
-    pa.max_row_err = e->batch_eps_measured.load() != 0 ? b.max_row_err : 0.f;
+    pa.queries = d_queries; pa.nq = qn; pa.nq_pad = nq_pad; pa.dims = D; pa.metric = e->metric;
+    pa.max_bits = b.d_maxnorm;                                   // {max ||v||, max ||x - bf16(x)||} as the mirror's conversions left them, read on the device
+    pa.use_measured = e->batch_eps_measured.load() != 0 ? 1 : 0;
     const bool frag_order = e->batch_qfrag.load() != 0 && (D % 16u) == 0;   // "batch_qfrag" (default 1): fragment-ordered query copy for the rq GEMM
     pa.qf = frag_order ? c->d_qf : nullptr;
     pa.qb = c->d_qb; pa.q_n2 = c->d_qn2; pa.q_norm = c->d_qnorm; pa.eps = c->d_eps; pa.tau = c->d_tau; pa.overflow = c->d_overflow;
@@ -1790,7 +1911,8 @@ void wax_hip_engine_destroy(wax_hip_engine* e) {
     }
     {
         BatchMirror& b = e->batch;
-        (void)hipFree(b.d_cb); (void)hipFree(b.d_vn2); (void)hipFree(b.d_maxnorm);
+        (void)hipFree(b.d_cb); (void)hipFree(b.d_vn2); (void)hipFree(b.d_maxnorm); (void)hipFree(b.d_dirty);
+        if (b.ev_ready) (void)hipEventDestroy(b.ev_ready);
         for (BatchCtx* c : e->bctx_all) free_bctx(c);
         for (FilterWork* f : e->filter_all) free_filter_work(f);
         (void)hipFree(e->idhash.d_table);
@@ -1831,8 +1953,7 @@ int wax_hip_add_batch(wax_hip_engine* e, const uint64_t* frame_ids, const float*
     DeviceGuard g(e->device);
     WriteGuard w(e->lock);
     sync_shard_work(e);
-    e->batch.mirror_valid = false;
-    e->idhash.valid = false;
+    mirror_note_append(e);
     e->batch.mirror_wanted = 0;
     const size_t row_bytes = (size_t)e->dims * sizeof(float);
     if (n == 1) {
@@ -1847,6 +1968,7 @@ int wax_hip_add_batch(wax_hip_engine* e, const uint64_t* frame_ids, const float*
                 HIP_TRY(hipMemcpy(e->d_store + (uint64_t)existing * e->dims, rows, row_bytes, hipMemcpyHostToDevice),
                         WAX_HIP_ERR_INTERNAL, "vector upload");
             }
+            mirror_note_upsert(e, (uint64_t)existing);
             return WAX_HIP_OK;
         }
         int rc1 = reserve_rows(e, e->count + 1);             // :341 (flushes before it reallocates)
@@ -1893,6 +2015,7 @@ int wax_hip_add_batch(wax_hip_engine* e, const uint64_t* frame_ids, const float*
             if ((rc = flush()) != WAX_HIP_OK) return rc;
             HIP_TRY(hipMemcpy(e->d_store + (uint64_t)existing * e->dims, rows + i * e->dims, row_bytes,
                               hipMemcpyHostToDevice), WAX_HIP_ERR_INTERNAL, "vector upload");
+            mirror_note_upsert(e, (uint64_t)existing);
         } else {
             if (run_len == 0) run_start = i;
             e->idmap.put(frame_ids[i], (uint32_t)e->count);
@@ -1918,8 +2041,7 @@ int wax_hip_add_batch_device(wax_hip_engine* e, const uint64_t* frame_ids, const
     DeviceGuard g(e->device);
     WriteGuard w(e->lock);
     sync_shard_work(e);
-    e->batch.mirror_valid = false;
-    e->idhash.valid = false;
+    mirror_note_append(e);
     e->batch.mirror_wanted = 0;
     { const int frc = flush_pending(e); if (frc != WAX_HIP_OK) return frc; }
     for (uint64_t i = 0; i < n; ++i)
@@ -1998,11 +2120,9 @@ int wax_hip_remove(wax_hip_engine* e, uint64_t frame_id) {
     WriteGuard w(e->lock);
     sync_shard_work(e);
     if (e->count == 0) return WAX_HIP_OK;                 // :425
-    e->batch.mirror_valid = false;
-    e->idhash.valid = false;
-    e->batch.mirror_wanted = 0;
     const int64_t idx = e->idmap.find(frame_id);
     if (idx < 0) return WAX_HIP_OK;                       // :426
+    e->batch.mirror_wanted = 0;
     { const int frc = flush_pending(e); if (frc != WAX_HIP_OK) return frc; }   // the shift below works on device rows
     const uint64_t after = e->count - 1 - (uint64_t)idx;  // :431
     if (after > 0) {
@@ -2015,6 +2135,7 @@ int wax_hip_remove(wax_hip_engine* e, uint64_t frame_id) {
                                   kBounceBytes, nullptr), WAX_HIP_ERR_INTERNAL, "frame id shift");
         HIP_TRY(hipStreamSynchronize(nullptr), WAX_HIP_ERR_INTERNAL, "row shift sync");
     }
+    { const int mrc = mirror_note_remove(e, (uint64_t)idx); if (mrc != WAX_HIP_OK) return mrc; }   // the mirror's tail follows the store's
     e->ids.erase(e->ids.begin() + idx);                   // :440
     e->idmap.erase_row(frame_id, (uint32_t)idx);
     e->count -= 1;                                        // :441
@@ -2249,7 +2370,7 @@ static int search_batch_hits_impl(wax_hip_engine* e, const float* queries, uint3
         const double elems = (double)cnt * (double)dims;
         const double t_loop = (double)nq * (elems * 4.0 / 6.9e12 + 25e-6);
         const double t_pass = 135e-6 + elems * 2.0 / 4.7e12;
-        const double t_rebuild = e->batch.mirror_valid.load() ? 0.0 : elems * 6.0 / 5.0e12;
+        const double t_rebuild = mirror_rows_to_convert(e) * (double)dims * 6.0 / 5.0e12;
         use_mfma = t_pass + t_rebuild < t_loop;
         // ... but a steady stream of small batches amortises it: the third one in a row that a valid mirror would have
         // made cheaper pays for the rebuild
@@ -2385,7 +2506,8 @@ bool batch_submit_blocks(wax_hip_engine* e, uint32_t dims, int32_t top_k, uint32
     if ((int64_t)nq < e->batch_min.load() || nq < 16) return true;
     if (!batch_mfma_applicable(e, dims, (int)k64, nq, &plan, &onepass)) return true;
     if (e->pend_rows.load() != 0) return true;               // staged appends are flushed (and the mirror rebuilt) inside submit
-    return !(e->batch.mirror_valid.load(std::memory_order_acquire) && e->batch.mirror_cap >= e->capacity);
+    // an incremental conversion (appended / upserted rows) is a small asynchronous launch; (re)allocation and a whole-store conversion are not
+    return e->batch.mirror_cap < e->capacity || mirror_rows_to_convert(e) > 65536.0;
 }
 
 static int batch_device_impl(wax_hip_engine* e, const float* d_queries, uint32_t nq, uint32_t dims, int32_t top_k,
@@ -2437,7 +2559,7 @@ static int batch_device_impl(wax_hip_engine* e, const float* d_queries, uint32_t
         const double elems = (double)e->count * (double)dims;
         const double t_loop = (double)nq * (elems * 4.0 / 6.9e12 + 25e-6);
         const double t_pass = 135e-6 + elems * 2.0 / 4.7e12;
-        const double t_rebuild = e->batch.mirror_valid.load() ? 0.0 : elems * 6.0 / 5.0e12;
+        const double t_rebuild = mirror_rows_to_convert(e) * (double)dims * 6.0 / 5.0e12;
         use_mfma = t_pass + t_rebuild < t_loop;
         if (!use_mfma && t_pass < t_loop && e->batch.mirror_wanted.fetch_add(1) >= 2) use_mfma = true;
     }
@@ -2888,8 +3010,7 @@ int wax_hip_deserialize(wax_hip_engine* e, const uint8_t* data, size_t len) {
     DeviceGuard g(e->device);
     WriteGuard w(e->lock);  // withWriteLock (:717)
     sync_shard_work(e);
-    e->batch.mirror_valid = false;
-    e->idhash.valid = false;
+    mirror_note_replaced(e);
     e->batch.mirror_wanted = 0;
     e->pend_rows.store(0, std::memory_order_release);   // the store is replaced wholesale: staged appends are dropped with it
     // :790-792 — capacity only grows
@@ -3023,7 +3144,20 @@ int64_t wax_hip_get_tuning(wax_hip_engine* e, const char* key) {
     if (k == "batch_inline_retries") return (int64_t)e->st_batch_inline_retries.load();
     if (k == "retry_hint") return e->retry_hint.load();
     if (k == "batch_eps_measured") return e->batch_eps_measured.load();
-    if (k == "batch_max_row_err_e9") return (int64_t)((double)e->batch.max_row_err * 1e9);
+    if (k == "batch_max_row_err_e9" || k == "batch_max_norm_e6") {   // the mirror's measured bounds (device words; a blocking read)
+        unsigned int bits[2] = {0u, 0u};
+        if (e->batch.d_maxnorm) {
+            DeviceGuard g(e->device);
+            (void)hipDeviceSynchronize();
+            (void)hipMemcpy(bits, e->batch.d_maxnorm, sizeof(bits), hipMemcpyDeviceToHost);
+        }
+        float f[2];
+        std::memcpy(f, bits, sizeof(f));
+        return k == "batch_max_norm_e6" ? (int64_t)((double)f[0] * 1e6) : (int64_t)((double)f[1] * 1e9);
+    }
+    if (k == "mirror_rows_converted") return (int64_t)e->batch.rows_converted.load();   // bf16 mirror: rows converted so far / conversions enqueued
+    if (k == "mirror_conversions") return (int64_t)e->batch.conversions.load();
+    if (k == "idhash_rows_inserted") return (int64_t)e->st_idhash_rows.load();
     if (k == "batch_min") return e->batch_min.load();
     if (k == "batch_mode") return e->batch_mode.load();
     if (k == "batch_rega") return e->batch_rega.load();

@@ -20,9 +20,9 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {  // splitmix64 finaliser
     return x;
 }
 
-__global__ __launch_bounds__(256) void idhash_build_kernel(const uint64_t* __restrict__ ids, uint32_t n, uint32_t* table,
+__global__ __launch_bounds__(256) void idhash_build_kernel(const uint64_t* __restrict__ ids, uint32_t row0, uint32_t n, uint32_t* table,
                                                            uint32_t mask) {
-    const uint32_t row = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t row = row0 + blockIdx.x * 256u + threadIdx.x;     // rows [row0, n): the appended ones, or all of them (row0 = 0)
     if (row >= n) return;
     uint32_t h = (uint32_t)mix64(ids[row]) & mask;
     while (atomicCAS(&table[h], 0u, row + 1u) != 0u) h = (h + 1u) & mask;
@@ -126,10 +126,11 @@ __global__ __launch_bounds__(256) void bitmap_emit_kernel(const uint32_t* __rest
     }
 }
 
-hipError_t launch_idhash_build(const uint64_t* ids, uint32_t n, uint32_t* table, uint64_t slots, hipStream_t st) {
-    hipError_t err = hipMemsetAsync(table, 0, (size_t)slots * sizeof(uint32_t), st);
-    if (err != hipSuccess || n == 0) return err;
-    hipLaunchKernelGGL(idhash_build_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, ids, n, table, (uint32_t)(slots - 1));
+hipError_t launch_idhash_build(const uint64_t* ids, uint32_t row0, uint32_t n, uint32_t* table, uint64_t slots, hipStream_t st) {
+    hipError_t err = hipSuccess;
+    if (row0 == 0) err = hipMemsetAsync(table, 0, (size_t)slots * sizeof(uint32_t), st);   // from scratch; row0 > 0 inserts into the live table
+    if (err != hipSuccess || n <= row0) return err;
+    hipLaunchKernelGGL(idhash_build_kernel, dim3((n - row0 + 255u) / 256u), dim3(256), 0, st, ids, row0, n, table, (uint32_t)(slots - 1));
     return hipGetLastError();
 }
 

@@ -299,6 +299,9 @@ struct FullRetryArgs {
 hipError_t launch_full_retry_select(const FullRetryArgs& a, hipStream_t stream);
 hipError_t launch_mirror(const float* src, uint32_t n_rows, uint32_t n_rows_padded, uint32_t dims, int normalize,
                          unsigned short* dst, float* norm2, unsigned int* max_norm_bits, hipStream_t stream);
+// The same for `n_listed` rows named by d_rows[] (device), each converted in place (round 6: upserted rows).
+hipError_t launch_mirror_rows(const float* src, const uint32_t* d_rows, uint32_t n_listed, uint32_t dims, int normalize,
+                              unsigned short* dst, float* norm2, unsigned int* max_norm_bits, hipStream_t stream);
 hipError_t launch_batch_gemm(const GemmArgs& a, int metric, hipStream_t stream);
 
 // ---- one-pass batched pipeline (large stores; cosine / dot at the register-resident GEMM dims) ----
@@ -316,8 +319,9 @@ bool batch_finish_fused_dims(uint32_t dims);
 // single-query path computes it (f64 accumulation, the host's summation order), certificate eps, and the per-batch
 // state (tau = +inf / -inf for padding, overflow = 0).
 struct PrepArgs {
-    const float* queries; uint32_t nq, nq_pad, dims; int metric; float max_norm;
-    float max_row_err;          // max over the mirror's rows of ||x - bf16(x)|| (mirror_kernel; x normalised for cosine); 0 = unknown (worst-case bound)
+    const float* queries; uint32_t nq, nq_pad, dims; int metric;
+    const unsigned int* max_bits;   // device: {max ||v||, max over the mirror's rows of ||x - bf16(x)||} as f32 bits (mirror_kernel; x normalised for cosine)
+    int use_measured;               // 0 = ignore the measured rounding error (worst-case bound: "batch_eps_measured" = 0)
     unsigned short* qb; float* q_n2; float* q_norm; float* eps; float* tau; uint32_t* overflow;
     unsigned short* qf;         // the bf16 queries once more in MFMA A-fragment order (GemmArgs::qf; dims % 16 == 0); may be null
     uint32_t* cand_count;       // slab pipeline: per-query append counters to zero (stride CAND_COUNT_STRIDE); may be null
@@ -375,7 +379,7 @@ hipError_t launch_finalize_batch(const int64_t* cand, uint32_t cand_cap, const u
 
 
 // ---- filter.hip: allow-list pre-filter on the device (id -> row table in HBM, bitmap, compaction) ----
-hipError_t launch_idhash_build(const uint64_t* ids, uint32_t n, uint32_t* table, uint64_t slots, hipStream_t st);
+hipError_t launch_idhash_build(const uint64_t* ids, uint32_t row0, uint32_t n, uint32_t* table, uint64_t slots, hipStream_t st);   // rows [row0, n); row0 = 0 clears the table first
 uint32_t filter_bitmap_blocks(uint32_t n_rows);
 // probe + per-block popcounts + exclusive scan; *total = number of distinct allowed rows present in the store
 hipError_t launch_allow_probe(const uint64_t* d_allow, uint64_t n_allow, const uint64_t* ids, uint32_t n_rows,

@@ -768,15 +768,15 @@ __device__ inline uint64_t ukey_of(float d, uint32_t row) {
     return (uint64_t)make_key(d, row) ^ 0x8000000000000000ull;  // unsigned-ordered
 }
 
-// Round 6: 11-bit digits (11 + 11 + 10 over the ordered distance, 11 + 11 + 10 over the row), the pick fused into the histogram
-// pass (its last-arriving workgroup picks, re-arms the histogram and the ticket), no init launch, and passes that have nothing left
-// to decide return at once: after the third pass the distance of the k-th key is known, and when every key with that distance is
-// needed (always, unless equal distances straddle rank k) the threshold is final — the three row passes are three empty launches.
-// Six + three launches behind the distance pass instead of twenty; rounds 1-5 walked 8 x (histogram + pick) over n distances each.
-constexpr int SEL_PASSES = 6;
-constexpr int SEL_BINS = 2048;
-__host__ __device__ constexpr int sel_shift(int pass) { return pass == 0 ? 53 : pass == 1 ? 42 : pass == 2 ? 32 : pass == 3 ? 21 : pass == 4 ? 10 : 0; }
-__host__ __device__ constexpr int sel_bits(int pass) { return (pass == 2 || pass == 5) ? 10 : 11; }
+// Round 6: the pick is fused into the histogram pass (its last-arriving workgroup picks and re-arms histogram and ticket), there is no
+// init launch, a wave whose keys all fall into one bin — the rule in the first passes, distances of one store share their leading bits —
+// adds once instead of 64 times, and a pass that has nothing left to decide returns at once: after the fourth pass the distance of the
+// k-th key is known, and when every key with that distance is needed (always, unless equal distances straddle rank k) the threshold is
+// final — the four row passes are four empty launches. 8 + 3 launches behind the distance pass, four of them real passes over the
+// distances, instead of 20 launches and eight passes. (11-bit digits — six passes, three real — were measured and lost: every
+// workgroup flushes up to 2 048 bins with global atomics, 4 M atomics per pass at 10M rows: profiles/r06/e_general_selection_*.)
+constexpr int SEL_PASSES = 8;
+constexpr int SEL_BINS = 256;
 // state[0] = prefix (the digits decided so far, right-aligned), state[1] = rank still to find among the keys that carry the prefix,
 // state[2] = 1 once state[0] is the final threshold (the exact k-th smallest unsigned key, or the largest key of its tie group when
 // the whole group is needed). hist[SEL_BINS] = arrival ticket of the pass; *counter = slots handed out by the compaction.
@@ -785,22 +785,21 @@ __global__ __launch_bounds__(256) void select_hist_kernel(const float* __restric
                                                           uint64_t* __restrict__ state,
                                                           uint32_t* __restrict__ hist, uint32_t* __restrict__ counter) {
     __shared__ uint32_t h[SEL_BINS];
-    __shared__ uint32_t part[256];
+    __shared__ uint32_t part[SEL_BINS];
     __shared__ uint32_t last_s;
     const bool first = pass == 0;
     if (!first && state[2] != 0) return;                      // nothing left to decide
-    for (int b = (int)threadIdx.x; b < SEL_BINS; b += 256) h[b] = 0;
-    __syncthreads();
     const uint64_t prefix = first ? 0ull : state[0];
-    const int shift = sel_shift(pass), bits = sel_bits(pass);
-    const uint32_t mask = (1u << bits) - 1u;
+    const uint64_t rem = first ? (uint64_t)k : state[1];      // (read here, by everyone: the picking thread overwrites it at the end)
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int shift = 56 - 8 * pass;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const uint64_t u = ukey_of(dist[i], row_base + i);
-        const bool match = first || ((u >> (shift + bits)) == prefix);
-        // distances of one store share their leading bits: in the first passes a whole wave lands in ONE bin — one LDS add, not 64
-        const uint32_t bin = match ? (uint32_t)(u >> shift) & mask : 0xFFFFFFFFu;
+        const bool match = first || ((u >> (shift + 8)) == prefix);
+        const uint32_t bin = match ? (uint32_t)(u >> shift) & 0xffu : 0xFFFFFFFFu;
         const uint32_t b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)bin);
-        if (__ballot(bin != b0) == 0ull) {
+        if (__ballot(bin != b0) == 0ull) {                    // the whole wave in one bin (or nobody matches): one LDS add, not 64
             if (b0 != 0xFFFFFFFFu) {
                 const unsigned long long act = __ballot(true);
                 if (lane_id() == (int)__builtin_ctzll(act)) atomicAdd(&h[b0], (uint32_t)__builtin_popcountll(act));
@@ -810,46 +809,33 @@ __global__ __launch_bounds__(256) void select_hist_kernel(const float* __restric
         }
     }
     __syncthreads();
-    for (int b = (int)threadIdx.x; b < SEL_BINS; b += 256)
-        if (h[b]) atomicAdd(&hist[b], h[b]);
-    // last arriver picks. The histogram is only ever touched by device-scope atomics (they execute in L2): once a workgroup's adds have
-    // completed — the release fence waits for them — its ticket orders them before the last arriver's atomic loads.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    // last arriver picks. The histogram is only ever touched by device-scope atomics (they execute where every XCD sees them). The adds
+    // are RETURNING ones and their results are consumed (stored to LDS) before the barrier: a result in a register is the only proof
+    // that the add has been performed — a fire-and-forget add could still be on its way when the last arriver empties the bins. (No
+    // fence: an agent-scope release writes back the XCD's L2, and 2 048 workgroups doing so one after the other cost 200 - 450 us per
+    // pass: profiles/r06/e_general_selection_*.)
+    uint32_t seen = 0;
+    if (h[threadIdx.x]) seen = __hip_atomic_fetch_add(&hist[threadIdx.x], h[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    part[threadIdx.x] = seen;
     __syncthreads();
     if (threadIdx.x == 0) last_s = __hip_atomic_fetch_add(&hist[SEL_BINS], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
     __syncthreads();
     if (last_s == 0u) return;
-    const int nb = 1 << bits, per = SEL_BINS / 256;           // 8 consecutive bins per thread
-    uint32_t mine[SEL_BINS / 256];
-    uint32_t sum = 0;
-#pragma unroll
-    for (int j = 0; j < per; ++j) {
-        const int b = (int)threadIdx.x * per + j;
-        // (a returning atomic: the value comes from wherever device-scope atomics execute, never from a stale line of this XCD's L2;
-        // the exchange also re-arms the bin for the next pass)
-        mine[j] = b < nb ? __hip_atomic_exchange(&hist[b], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        sum += mine[j];
-    }
-    part[threadIdx.x] = sum;
+    // (a returning atomic: the value comes from wherever device-scope atomics execute, never from a stale line of this XCD's L2; the
+    // exchange also re-arms the bin for the next pass)
+    const uint32_t mine = __hip_atomic_exchange(&hist[threadIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    part[threadIdx.x] = mine;
     __syncthreads();
-    if (threadIdx.x == 0) {                                    // exclusive scan of 256 partial sums
+    if (threadIdx.x == 0) {                                    // exclusive scan of the 256 bins
         uint32_t run = 0;
-        for (int t = 0; t < 256; ++t) { const uint32_t v = part[t]; part[t] = run; run += v; }
+        for (int t = 0; t < SEL_BINS; ++t) { const uint32_t v = part[t]; part[t] = run; run += v; }
     }
     __syncthreads();
-    const uint64_t rem = first ? (uint64_t)k : state[1];
-    uint32_t cum = part[threadIdx.x];
-    if ((uint64_t)cum < rem && (uint64_t)cum + sum >= rem) {   // exactly one thread: the bin of the k-th key is one of its eight
-        int bin = 0;
-        uint32_t c = 0;
-#pragma unroll
-        for (int j = 0; j < per; ++j) {
-            if ((uint64_t)cum + mine[j] >= rem && c == 0) { bin = (int)threadIdx.x * per + j; c = mine[j]; }
-            if (c == 0) cum += mine[j];
-        }
-        const uint64_t np = (prefix << bits) | (uint64_t)bin;
-        const uint64_t left = rem - cum;                       // rank inside the bin, 1 .. c
-        const bool all_needed = left == (uint64_t)c;           // every key of the bin is among the k smallest: no finer digit matters
+    const uint32_t cum = part[threadIdx.x];
+    if ((uint64_t)cum < rem && (uint64_t)cum + mine >= rem) {   // exactly one thread: its bin holds the k-th key
+        const uint64_t np = (prefix << 8) | (uint64_t)threadIdx.x;
+        const uint64_t left = rem - cum;                       // rank inside the bin, 1 .. mine
+        const bool all_needed = left == (uint64_t)mine;        // every key of the bin is among the k smallest: no finer digit matters
         if (pass == SEL_PASSES - 1 || all_needed) {
             state[0] = shift == 0 ? np : ((np << shift) | ((1ull << shift) - 1ull));
             state[2] = 1;
@@ -933,6 +919,10 @@ hipError_t alloc_select_work(SelectWork* w) {
     if (e == hipSuccess) e = hipMalloc(&w->counter, sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&w->keys_a, (size_t)WAX_HIP_MAX_RESULTS * sizeof(int64_t));
     if (e == hipSuccess) e = hipMalloc(&w->keys_b, (size_t)WAX_HIP_MAX_RESULTS * sizeof(int64_t));
+    // hipMemset on device memory may return before the fill has run, and the engine's streams are not ordered behind the null stream:
+    // without this wait the first selection of a fresh workspace can meet a histogram that still holds whatever the allocation held
+    // (seen: wrong first answers of a sharded handle's shards, whose workspaces reuse freed memory).
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     return e;
 }
 void free_select_work(SelectWork* w) {
