@@ -794,9 +794,9 @@ __global__ __launch_bounds__(256) void select_hist_kernel(const float* __restric
     h[threadIdx.x] = 0;
     __syncthreads();
     const int shift = 56 - 8 * pass;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const uint64_t u = ukey_of(dist[i], row_base + i);
-        const bool match = first || ((u >> (shift + 8)) == prefix);
+    auto count_one = [&](float d, uint32_t i, bool live) {
+        const uint64_t u = ukey_of(d, row_base + i);
+        const bool match = live && (first || ((u >> (shift + 8)) == prefix));
         const uint32_t bin = match ? (uint32_t)(u >> shift) & 0xffu : 0xFFFFFFFFu;
         const uint32_t b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)bin);
         if (__ballot(bin != b0) == 0ull) {                    // the whole wave in one bin (or nobody matches): one LDS add, not 64
@@ -807,6 +807,37 @@ __global__ __launch_bounds__(256) void select_hist_kernel(const float* __restric
         } else if (match) {
             atomicAdd(&h[bin], 1u);
         }
+    };
+    // four consecutive distances per thread and step (one 16-byte load; the distance array is 16-byte aligned: hipMalloc), two steps in
+    // flight: a thread's chain of dependent global loads was the whole cost of a pass (19 round trips at 10M rows)
+    const uint32_t n4 = n >> 2;
+    const f32x4* __restrict__ dist4 = reinterpret_cast<const f32x4*>(dist);
+    const uint32_t stride = gridDim.x * 256;
+    uint32_t i4 = blockIdx.x * 256 + threadIdx.x;
+    for (; i4 + 3 * stride < n4; i4 += 4 * stride) {          // four loads in flight: at 10M rows a thread's whole share in ~1 round trip
+        f32x4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = dist4[i4 + j * stride];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t j4 = i4 + j * stride;
+            count_one(v[j].x, 4 * j4, true); count_one(v[j].y, 4 * j4 + 1, true); count_one(v[j].z, 4 * j4 + 2, true); count_one(v[j].w, 4 * j4 + 3, true);
+        }
+    }
+    for (; i4 + stride < n4; i4 += 2 * stride) {
+        const f32x4 a = dist4[i4], b = dist4[i4 + stride];
+        count_one(a.x, 4 * i4, true); count_one(a.y, 4 * i4 + 1, true); count_one(a.z, 4 * i4 + 2, true); count_one(a.w, 4 * i4 + 3, true);
+        const uint32_t j4 = i4 + stride;
+        count_one(b.x, 4 * j4, true); count_one(b.y, 4 * j4 + 1, true); count_one(b.z, 4 * j4 + 2, true); count_one(b.w, 4 * j4 + 3, true);
+    }
+    for (; i4 < n4; i4 += stride) {                           // (lanes leave these loops at different trips: the ballots above see the active ones)
+        const f32x4 a = dist4[i4];
+        count_one(a.x, 4 * i4, true); count_one(a.y, 4 * i4 + 1, true); count_one(a.z, 4 * i4 + 2, true); count_one(a.w, 4 * i4 + 3, true);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 64) {                // the last n % 4 distances
+        const uint32_t i = (n4 << 2) + threadIdx.x;
+        const bool live = i < n;
+        count_one(live ? dist[i] : 0.f, i, live);
     }
     __syncthreads();
     // last arriver picks. The histogram is only ever touched by device-scope atomics (they execute where every XCD sees them). The adds
@@ -853,13 +884,30 @@ __global__ __launch_bounds__(256) void select_compact_kernel(const float* __rest
                                                              uint32_t row_base, const uint64_t* __restrict__ state,
                                                              uint32_t* counter, int64_t* __restrict__ out,
                                                              uint32_t kmax) {
-    const uint64_t thr = state[0];  // after 8 passes: the exact k-th smallest unsigned key
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const uint64_t u = ukey_of(dist[i], row_base + i);
+    const uint64_t thr = state[0];  // the exact k-th smallest unsigned key (or the largest key of its tie group when all of it is needed)
+    auto take = [&](float d, uint32_t i) {
+        const uint64_t u = ukey_of(d, row_base + i);
         if (u <= thr) {
             const uint32_t pos = atomicAdd(counter, 1u);
             if (pos < kmax) out[pos] = (int64_t)(u ^ 0x8000000000000000ull);
         }
+    };
+    const uint32_t n4 = n >> 2, stride = gridDim.x * 256;
+    const f32x4* __restrict__ dist4 = reinterpret_cast<const f32x4*>(dist);
+    uint32_t i4 = blockIdx.x * 256 + threadIdx.x;
+    for (; i4 + stride < n4; i4 += 2 * stride) {              // 16-byte loads, two in flight (see select_hist_kernel)
+        const f32x4 a = dist4[i4], b = dist4[i4 + stride];
+        const uint32_t j4 = i4 + stride;
+        take(a.x, 4 * i4); take(a.y, 4 * i4 + 1); take(a.z, 4 * i4 + 2); take(a.w, 4 * i4 + 3);
+        take(b.x, 4 * j4); take(b.y, 4 * j4 + 1); take(b.z, 4 * j4 + 2); take(b.w, 4 * j4 + 3);
+    }
+    for (; i4 < n4; i4 += stride) {
+        const f32x4 a = dist4[i4];
+        take(a.x, 4 * i4); take(a.y, 4 * i4 + 1); take(a.z, 4 * i4 + 2); take(a.w, 4 * i4 + 3);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 4) {
+        const uint32_t i = (n4 << 2) + threadIdx.x;
+        if (i < n) take(dist[i], i);
     }
 }
 
