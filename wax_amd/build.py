@@ -16,7 +16,9 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libwaxhip.so")
 SOURCES = ["kernels.hip", "multiscan.hip", "batch.hip", "filter.hip", "rrf.hip", "engine.hip"]
-HEADERS = ["common.h", "topk.h", "kernels.h", "sharded.inc", os.path.join(ROOT, "include", "wax_hip.h")]
+HEADERS = ["common.h", "topk.h", "kernels.h", "engine_types.inc", "store_internal.inc", "search_internal.inc", "batch_host.inc", "api_store.inc",
+           "api_search.inc", "api_batch.inc", "api_shard.inc", "api_fusion_filter.inc", "codec.inc", "tuning.inc", "sharded.inc",
+           os.path.join(ROOT, "include", "wax_hip.h")]
 ARCH = "gfx950"
 
 
