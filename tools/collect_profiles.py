@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Copy the summaries of a tools/sessions/r0N_final.sh run (gpurun_out/<tag>/) into profiles/<round>/ under stable names and refresh
+"""Copy the summaries of a tools/sessions/final.sh run (gpurun_out/<tag>/) into profiles/<round>/ under stable names and refresh
 profiles/latest_traffic.json (the counters-only FETCH_SIZE passes bench.py replays as `roofline.traffic`).
     python tools/collect_profiles.py gpurun_out/r05_final profiles/r05"""
 import csv
@@ -30,7 +30,8 @@ for a, b in (("sq_768", "z_pmc_sq_counters_768_rq_final_build.json"), ("sq2_768"
              ("sq_384", "z_pmc_sq_counters_384_rq_final_build.json"), ("sq_768_wide", "z_pmc_sq_counters_768_wide_final_build.json"),
              ("sq2_768_wide", "z_pmc_sq2_counters_768_wide_final_build.json")):
     cp(a + ".json", b)
-for a in ("one_process_2_shards.json", "one_process_n1.json", "pytest_gpu.log", "fuzz.txt", "latency_c.jsonl", "smoke.log"):
+for a in ("one_process_2_shards.json", "one_process_n1.json", "pytest_gpu.log", "fuzz.txt", "latency_c.jsonl", "smoke.log", "phase_budget.jsonl", "phase_table.txt",
+          "fanout_ABC.jsonl", "gemm_s10m_k300_kernel_stats.csv", "gemm_s1m_k1000_kernel_stats.csv"):
     cp(a, "z_" + a)
 
 # one rocprofv3 row per GEMM workload

@@ -109,6 +109,16 @@ def budget(args, eng, torch, dev, run, ref, dout, opt, ab_times):
     eng.setTuning("time_kernels", 0)
     used = p[:, 0, 10] > 0
     p = p[used]
+    if p.shape[0] == 0:        # this variant has no phase-timing build ("batch_rega" 1: the workgroup-barrier kernel): times only
+        line = json.dumps({"rows": args.rows, "dims": args.dims, "nq": args.nq, "topk": args.topk, "tune": args.tune, "ab_key": args.ab_key,
+                           "batch_opt": opt, "product_kernel_us_hip_events": prod_us,
+                           "product_kernel_us_ab_median": (float(np.median(ab_times)) if ab_times else None),
+                           "product_kernel_us_ab_rounds": [round(x, 1) for x in ab_times], "prof_answers_equal_product": same, "phases": None})
+        print(line, flush=True)
+        if args.out:
+            with open(args.out, "a") as f:
+                f.write(line + "\n")
+        return
     rt0 = (p[:, :, 12] | (p[:, :, 13] << 32)).astype(np.float64) * 10.0   # ns (100 MHz)
     rt1 = (p[:, :, 14] | (p[:, :, 15] << 32)).astype(np.float64) * 10.0
     k0, k1 = rt0.min(), rt1.max()

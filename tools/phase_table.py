@@ -7,6 +7,10 @@ for path in sys.argv[1:]:
     for l in open(path):
         d = json.loads(l)
         p = d["phases"]
+        if not p:
+            print(d["dims"], d["nq"], "k", d["topk"], d.get("ab_key", ""), d.get("batch_opt", 0), "ab_median_us %s prod_us %.1f (no phase-timing build of this variant)" % (
+                d.get("product_kernel_us_ab_median"), d["product_kernel_us_hip_events"]))
+            continue
         f = lambda n, w: round(p[n][w]["mean_cycles_per_tile"])  # noqa: E731
         ab = d.get("product_kernel_us_ab_median")
         print(d["dims"], d["nq"], "k", d["topk"], "opt", d.get("batch_opt", 0),

@@ -1,11 +1,13 @@
 #!/bin/bash
-# round 5, final measurements: the default bench command (record + under rocprofv3), the headline chained under rocprofv3, one rocprofv3 run
-# per GEMM workload, FETCH_SIZE passes (headline scan, the rq GEMM at 768-d and 384-d), SQ counters of the rq kernel, the one-process
-# shape of bench.py (two shards on one GPU), the N > 1 rehearsal of tools/scale_matrix.sh on one GPU, the full GPU suite, smoke, fuzz,
-# blocking C latency. Counter passes are counters only (--pmc with --kernel-trace).
+# The end-of-round measurement set, one gpurun call (tools/collect_profiles.py copies its summaries into profiles/<round>/):
+# the default bench command (record + under rocprofv3), the headline chained under rocprofv3, one rocprofv3 run per GEMM workload and
+# one for the general selection, FETCH_SIZE passes (headline scan, the rq GEMM at 768-d and 384-d), SQ counters of the rq kernel, the
+# one-process shape of bench.py (two shards on one GPU), the N > 1 rehearsal of tools/scale_matrix.sh on one GPU, the full GPU suite,
+# smoke, fuzz, blocking C latency, the filtering GEMM's phase budget. Counter passes are counters only (--pmc with --kernel-trace).
+#   gpurun --timeout 5400 -- 'WAX_TAG=r06_final bash tools/sessions/final.sh'
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/${WAX_TAG:-r05_final}
+OUT=$R/gpurun_out/${WAX_TAG:-final}
 mkdir -p "$OUT"; cd "$R"; export TMPDIR=/tmp
 stats() {  # stats <name> <cmd...>: rocprofv3 --kernel-trace --stats of a command, keep the kernel_stats csv
   local name=$1; shift
@@ -31,7 +33,7 @@ echo "driver-style rc $? bytes $(wc -c < "$OUT/bench_driver_style.json")" >> "$O
 # 2. rocprofv3 summaries
 stats headline_chained python "$R/bench.py" --gpus 1 --steps 200 --warmup 20 --no-cpu-baseline --no-secondary --chain-timed-region --detail-out "$OUT/headline_chained_detail.json"
 stats default_cmd python "$R/bench.py" --gpus 1 --no-cpu-baseline --detail-out "$OUT/default_cmd_detail.json"
-for w in b1m_q256 b1m_q1024 c5_shard c5_full clustered_k100; do
+for w in b1m_q256 b1m_q1024 c5_shard c5_full clustered_k100 s10m_k300 s1m_k1000; do
   stats gemm_$w python "$R/bench.py" --gpus 1 --steps 40 --warmup 8 --no-cpu-baseline --secondary $w --detail-out "$OUT/gemm_${w}_detail.json"
 done
 # 3. counters
@@ -52,5 +54,6 @@ rm -f "$OUT"/scale_rehearsal.jsonl.detail_*
 # 6. blocking C calls, fan-out
 gcc -O2 -Iinclude tools/latency_c.c -o /tmp/latency_c -Lwax_amd/lib -lwaxhip -Wl,-rpath,$R/wax_amd/lib -lm && for n in 10000 100000 1000000; do timeout 120 /tmp/latency_c $n 384 3000 2>/dev/null | grep '"mode": 1,' >> "$OUT/latency_c.jsonl"; done
 timeout 600 python tools/sharded_handle_bench.py --parts A,B,C > "$OUT/fanout_ABC.jsonl" 2> "$OUT/fanout_ABC.err"
+WAX_TAG=${WAX_TAG:-final} bash tools/sessions/gemm_budget.sh > /dev/null 2>&1
 ls -la "$OUT" > "$OUT/listing.txt"
 tail -4 "$OUT/pytest_gpu.log"; cat "$OUT/bench_n1.json"
