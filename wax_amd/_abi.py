@@ -165,7 +165,7 @@ def lib() -> ctypes.CDLL:
     if _lib is not None:
         return _lib
     _preload_torch_hip_runtime()
-    path = _build.LIB_PATH
+    path = os.environ.get("WAX_HIP_LIB") or _build.LIB_PATH       # (WAX_HIP_LIB: an experiment build of the same ABI, A/B sessions only)
     if not os.path.exists(path):
         raise LibraryMissing(
             f"{path} not found: build it with `python -m wax_amd.build` (hipcc --offload-arch=gfx950). "

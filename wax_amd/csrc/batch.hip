@@ -682,6 +682,11 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
 #pragma unroll
     for (int r = 0; r < 16; ++r) cq[r] = 0u;
     const uint32_t sim_addr = (uint32_t)(size_t)(lds_void*)sim_s + (uint32_t)(wave * 32 + 4 * (lane >> 5)) * 4u;
+    // the lane's sixteen bounds: in registers for the whole launch where they fit (D <= 512; 768-d holds 192 registers of A fragments),
+    // else re-read from LDS per tile — one LDS round trip, ~300 cycles beside eight waves' fragment reads, on the late waves' critical
+    // path (round 6: -2 % cycles per tile, -1 ... -3 % wall at D = 384: profiles/r06/g_*)
+    constexpr bool BOUNDS_REGS = !SAMPLE && D <= 512;
+    f32x4 lo_keep[4];
     auto select_tile = [&](uint32_t tile) {
         if (SAMPLE) {
 #pragma unroll
@@ -696,14 +701,19 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
             return;
         }
         f32x4 lo[4];
-        static_for<0, 4>([&](auto J) {
-            constexpr int j = decltype(J)::value;
-            f32x4(&lor)[4] = lo;
-            const uint32_t sa = sim_addr;
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(lor[j]) : "v"(sa), "n"(j * 32));
-        });
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (BOUNDS_REGS) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) lo[j] = lo_keep[j];
+        } else {
+            static_for<0, 4>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                f32x4(&lor)[4] = lo;
+                const uint32_t sa = sim_addr;
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(lor[j]) : "v"(sa), "n"(j * 32));
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
         // one survivor test of accumulator (b, r) — the cold path's unit of work, whichever hot test led here
         auto emit = [&](auto B, auto R, uint32_t seg_o) {
             constexpr int b = decltype(B)::value, r = decltype(R)::value;
@@ -781,6 +791,15 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
         dma_wait(all);
         __builtin_amdgcn_s_barrier();                         // also publishes sim_s / sync_s
         asm volatile("" ::: "memory");
+    }
+    if constexpr (BOUNDS_REGS) {
+        static_for<0, 4>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            f32x4(&lor)[4] = lo_keep;
+            const uint32_t sa = sim_addr;
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(lor[j]) : "v"(sa), "n"(j * 32));
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     const unsigned int k_loop0 = now();
     if constexpr (PROF) ph[RQP_PROLOGUE] = k_loop0 - k_entry;
@@ -926,6 +945,9 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
 // small kernels (a workgroup of ~100 KB leaves them a third of the CU's LDS; 150 KB does not: measured in round 3 and again in
 // round 5 at D = 384, where two buffers lose nothing), except at D = 768 where a 32-row tile is already 48.5 KB and the third
 // buffer is what lets a request stay in flight across a tile.
+// (Round 6, D = 384: 96-row tiles — 2 x 75 KB — cut 7.6 % of the cycles per row and 4 % of the Q = 1 024 kernel, but a workgroup
+// that fills the CU's LDS keeps the neighbouring batches' small kernels off it: pipelined 256-query batches +2 %, dense
+// neighbourhoods +6 %. 64 rows stay: profiles/r06/g_*.)
 template <int D> struct RqGeom;
 template <> struct RqGeom<128> { static constexpr int TROWS = 128, NBUF = 3, AHEAD = 3; };
 template <> struct RqGeom<256> { static constexpr int TROWS = 64, NBUF = 3, AHEAD = 3; };
