@@ -174,23 +174,6 @@ __device__ inline float group_max32(float v) {
     return v;
 }
 
-template <int CTRL, int ROW_MASK>
-__device__ inline unsigned dpp_or(unsigned v) {
-    // lanes outside ROW_MASK, and lanes whose source is out of range, receive 0
-    const int moved = __builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, true);
-    return v | (unsigned)moved;
-}
-// OR of v over the 64 lanes (wave-uniform result)
-__device__ inline unsigned wave_or32(unsigned v) {
-    v = dpp_or<0x111, 0xF>(v);      // row_shr:1
-    v = dpp_or<0x112, 0xF>(v);      // row_shr:2
-    v = dpp_or<0x114, 0xF>(v);      // row_shr:4
-    v = dpp_or<0x118, 0xF>(v);      // row_shr:8 — lane 15 of every row holds its row
-    v = dpp_or<0x142, 0xA>(v);      // row_bcast15 into rows 1, 3
-    v = dpp_or<0x143, 0xC>(v);      // row_bcast31 into rows 2, 3 — lane 63 holds the wave
-    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-}
-
 // ---------------------------------------------------------------------------
 // bf16 GEMM tile: 128 queries (M) x 128 corpus rows (N), K chunks of 64, 4 waves each 64x64
 // (2x2 v_mfma_f32_32x32x16_bf16 blocks). Both operands are K-contiguous ("NT" GEMM), so every
@@ -462,8 +445,8 @@ __device__ inline void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N
 // a ring of NBUF padded tile images in LDS (row stride 2 D + 16 bytes: conflict-free ds_read_b128), filled by LDS-DMA
 // (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass). All 8 waves read the same B fragments: one ds_read_b128 per MFMA,
 // RB = TROWS / 32 accumulators per wave, KS * RB MFMAs (v_mfma_f32_32x32x16_bf16) per wave and tile. The selection is fused:
-// per tile 16 RB compares against conservative per-query bounds; a survivor takes a slot in THIS workgroup's segment of its
-// query's candidate row (plain 8-byte store, no global atomics); the wave's 32 per-query survivor counters live in SGPRs.
+// per tile 16 RB sign tests against conservative per-query bounds; a survivor takes a slot in THIS workgroup's segment of its
+// query's candidate row (plain 8-byte store, no global atomics); the workgroup's 256 per-query survivor counters live in LDS.
 //
 // What round 5 changed (one kernel instead of four; D = 768 from 0.40 - 0.45 to 0.49 - 0.52 of the dense bf16 peak, same answers):
 //  1. NOTHING in the tile loop is an LDS access the compiler can see, and the A fragments are "used" before the first DMA request.
@@ -572,6 +555,8 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
         sim_s[wave * 32 + lane] = (1.0f - tq) - 4e-7f * (1.0f + __builtin_fabsf(tq));
     }
     if (SPLIT && tid < 2) sync_s[tid] = 0u;
+    if (!SAMPLE && tid < 256) cnt_s[tid] = 0u;                // the (workgroup, query) survivor counters: LDS, returning adds (select_tile's cold path)
+    const uint32_t cnt_lane0 = (uint32_t)(size_t)(lds_void*)cnt_s + (uint32_t)(wave * 32 + 4 * (lane >> 5)) * 4u;
     const uint32_t seg_slots = a.seg_area / blocks_per_group;
     const uint32_t seg_lane0 = (q0 + 4u * ((uint32_t)lane >> 5)) * a.cand_cap + a.seg_base + bidx * seg_slots;
 
@@ -672,15 +657,9 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
         __builtin_amdgcn_s_setprio(0);
     };
     // Fused selection on one tile. C/D layout of the 32x32 MFMA: column = lane & 31 (corpus row of the block), row =
-    // (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (query of the wave). Hot path: 16 RB compares against the bounds (one LDS round trip:
-    // four aligned float4 per lane), OR-ed into wave-level flags per group of four queries; nothing set (the common case) = done.
-    // Cold path: a wave's 32 queries are ITS OWN (no other wave of the workgroup selects for them), so the per-(workgroup, query)
-    // survivor counters are 16 SGPRs of the wave (two saturating 16-bit counters each; 0xFFFF is reported as an overflow: the query
-    // takes the exact path) and a survivor's slot is counter + (passing lanes below it in its half-wave): ballot, mbcnt, s_bcnt1 —
-    // no LDS atomic, no threshold read.
-    unsigned cq[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) cq[r] = 0u;
+    // (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (query of the wave). A wave's 32 queries are ITS OWN: no other wave of the workgroup selects
+    // for them. Hot path: per accumulator a subtraction and a funnel shift into a per-lane pass mask, one ballot per tile; nothing set
+    // (the common case) = done. Cold path: lane-parallel, one returning LDS add per survivor (below).
     const uint32_t sim_addr = (uint32_t)(size_t)(lds_void*)sim_s + (uint32_t)(wave * 32 + 4 * (lane >> 5)) * 4u;
     // the lane's sixteen bounds: in registers for the whole launch where they fit (D <= 512; 768-d holds 192 registers of A fragments),
     // else re-read from LDS per tile — one LDS round trip, ~300 cycles beside eight waves' fragment reads, on the late waves' critical
@@ -714,26 +693,6 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
         }
-        // one survivor test of accumulator (b, r) — the cold path's unit of work, whichever hot test led here
-        auto emit = [&](auto B, auto R, uint32_t seg_o) {
-            constexpr int b = decltype(B)::value, r = decltype(R)::value;
-            const uint32_t row0 = a.slab0 + tile * TROWS + (uint32_t)(b * 32) + (uint32_t)(lane & 31);
-            const bool p = row0 < slab_end && acc[b][r] >= lo[r >> 2][r & 3];
-            const unsigned long long m = __ballot(p);
-            if (m == 0ull) return;
-            const unsigned n_lo = (unsigned)__builtin_popcount((unsigned)m), n_hi = (unsigned)__builtin_popcount((unsigned)(m >> 32));
-            const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-            unsigned c0 = cq[r] & 0xFFFFu, c1 = cq[r] >> 16;
-            const unsigned off = lane < 32 ? c0 + below : c1 + (below - n_lo);
-            if (p && off < seg_slots) {
-                const uint32_t e0 = seg_o + (uint32_t)((r & 3) + 8 * (r >> 2)) * a.cand_cap;
-                a.cand[e0 + off] = make_key((1.0f - acc[b][r]) + 0.0f, a.row_base + row0);
-            }
-            c0 = c0 + n_lo < 0xFFFFu ? c0 + n_lo : 0xFFFFu;   // not clamped to seg_slots: a count above it tells the finish kernel that survivors were dropped
-            c1 = c1 + n_hi < 0xFFFFu ? c1 + n_hi : 0xFFFFu;
-            cq[r] = c0 | (c1 << 16);
-            if constexpr (PROF) ph[RQP_SURVIVORS] += n_lo + n_hi;
-        };
         // Hot test (round 6). Per accumulator a subtraction and a funnel shift that pushes the sign of (acc - bound) into a per-lane
         // mask (1 = fails; a NaN may read as "passes" here — the exact comparison in `emit` decides), one ballot per tile. Rounds 1-5
         // compared every accumulator into a wave mask (v_cmp -> SGPR pair -> s_or): 47 cycles per accumulator beside the partner's K
@@ -756,27 +715,61 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
             anyp |= pm[m_];
         }
         if (__ballot(anyp != 0u) == 0ull) return;
-        // Cold path: the masks OR-ed over the wave (DPP) say which accumulators hold a survivor in ANY lane; each of those is tested
-        // exactly and stored as before. A wave's 32 queries are ITS OWN, so the per-(workgroup, query) survivor counters are 16 SGPRs of the
-        // wave (two saturating 16-bit counters each; 0xFFFF is reported as an overflow: the query takes the exact path) and a
-        // survivor's slot is counter + (passing lanes below it in its half-wave): ballot, mbcnt, s_bcnt1 — no atomic of any kind.
-        // (Measured and not kept, profiles/HISTORY.md round 6: every lane storing its own survivor with a returning LDS add as the
-        // counter — one LDS round trip per group of four accumulators, slower from 2 survivors per wave and tile.)
+        // Cold path (round 6): every lane with a passing bit serves ITS OWN survivor — the accumulator picked by a five-level select
+        // tree on the bit's index (31 v_cndmask; registers cannot be indexed by a lane's value), the exact test (a NaN fails it), a
+        // slot from the (workgroup, query) counter in LDS by a returning add, the 8-byte store — all lanes at once, one LDS round trip
+        // per pass, a second pass only when some lane holds two survivors. ~850 cycles per tile with survivors whatever their number.
+        // Rounds 1-5 walked the accumulators one by one with a wave ballot, mbcnt and 16 packed SGPR counters: ~450 cycles PER survivor
+        // behind ~600 of steering (1 470 per tile at top-10, 1 870 at top-100 where 93 % of the tiles have one), with the VALU -> SGPR
+        // -> SALU hand-overs the hot test also had. A/B of the two builds (profiles/r06/h_*): -10 % cycles per tile and -6 % kernel
+        // time at top-10, -16 % / -8 % at top-100, pipelined clustered corpus at top-100 -5.5 %.
         const unsigned int c0t = now();
         uint32_t seg_o = seg_lane0;                   // opaque: the per-query row offsets are computed HERE (cold path), not
         asm volatile("" : "+v"(seg_o));               // hoisted out of the tile loop into VGPRs that do not exist
-        unsigned wm[NM];
+        uint32_t cnt_o = cnt_lane0;
+        asm volatile("" : "+v"(cnt_o));
 #pragma unroll
-        for (int m_ = 0; m_ < NM; ++m_) wm[m_] = wave_or32(pm[m_]);
-        static_for<0, RB>([&](auto B) {
-            constexpr int b = decltype(B)::value;
-            constexpr int nbits = (2 * (b >> 1) + 1 < RB) ? 32 : 16;        // elements in this block's mask
-            static_for<0, 16>([&](auto R) {
-                constexpr int r = decltype(R)::value;
-                constexpr int idx = (b & 1) * 16 + r;                       // position in processing order within the mask
-                if (wm[b >> 1] & (1u << (nbits - 1 - idx))) emit(B, R, seg_o);
-            });
-        });
+        for (int m_ = 0; m_ < NM; ++m_) {
+            const int nbits = (2 * m_ + 1 < RB) ? 32 : 16;
+            unsigned pmv = pm[m_];
+            while (__ballot(pmv != 0u) != 0ull) {
+                const bool has = pmv != 0u;
+                const unsigned pb = (unsigned)__builtin_ctz(pmv | 0x80000000u);
+                const unsigned idx = (unsigned)(nbits - 1) - (pb < (unsigned)nbits ? pb : 0u);   // element in processing order: (block & 1) * 16 + r
+                float t[32];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) t[i] = (i < nbits) ? acc[(2 * m_ + (i >> 4)) < RB ? 2 * m_ + (i >> 4) : 0][i & 15] : 0.f;
+#pragma unroll
+                for (int bit = 0; bit < 5; ++bit) {
+                    const bool hi = (idx >> bit) & 1u;
+#pragma unroll
+                    for (int i = 0; i < (16 >> bit); ++i) t[i] = hi ? t[2 * i + 1] : t[2 * i];
+                }
+                const float val = t[0];
+                float l16[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) l16[i] = lo[i >> 2][i & 3];
+#pragma unroll
+                for (int bit = 0; bit < 4; ++bit) {
+                    const bool hi = (idx >> bit) & 1u;
+#pragma unroll
+                    for (int i = 0; i < (8 >> bit); ++i) l16[i] = hi ? l16[2 * i + 1] : l16[2 * i];
+                }
+                const float lov = l16[0];
+                const unsigned r = idx & 15u;
+                const uint32_t row0 = a.slab0 + tile * TROWS + (uint32_t)(2 * m_) * 32u + (idx >> 4) * 32u + (uint32_t)(lane & 31);
+                const bool take = has && row0 < slab_end && val >= lov;
+                if constexpr (PROF) ph[RQP_SURVIVORS] += (unsigned)__builtin_popcountll(__ballot(take));
+                if (take) {
+                    const unsigned ql = (r & 3u) + 8u * (r >> 2);   // + 4 (lane >> 5): folded into the lane bases
+                    unsigned slot;       // (inline assembly: no LDS access the compiler can see inside the tile loop; the wait sits inside, the result is valid behind it)
+                    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(slot) : "v"(cnt_o + ql * 4u), "v"(1u) : "memory");
+                    // (the count is not clamped: one above seg_slots tells the finish kernel that survivors were dropped)
+                    if (slot < seg_slots) a.cand[seg_o + ql * a.cand_cap + slot] = make_key((1.0f - val) + 0.0f, a.row_base + row0);
+                }
+                pmv &= pmv - 1u;
+            }
+        }
         if constexpr (PROF) { ph[RQP_COLD] += now() - c0t; ph[RQP_COLD_N] += 1u; }
     };
 
@@ -905,15 +898,6 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
     if (late && it > 0) select_tile(t_prev);
     if (gate && tid == 0) __hip_atomic_fetch_add(gate_word, 0u - gate_added - (1u << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // leaving: out of the count and the sum
     if (SPLIT && gave_up && lane == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(sync_addr + 4u), "v"(1u) : "memory");
-    if (!SAMPLE) {   // the wave's 32 survivor counters, SGPRs -> LDS: lane q takes query q's
-        unsigned mine = 0u;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            mine = lane == (r & 3) + 8 * (r >> 2) ? (cq[r] & 0xFFFFu) : mine;
-            mine = lane == (r & 3) + 8 * (r >> 2) + 4 ? (cq[r] >> 16) : mine;
-        }
-        if (lane < 32) cnt_s[wave * 32 + lane] = mine == 0xFFFFu ? 0x40000000u : mine;   // saturated = unknown = overflowed
-    }
     __syncthreads();
     if (!SAMPLE && tid < 256) {
         const bool poisoned = SPLIT && sync_s[1] != 0u;       // a wave gave up waiting: nothing this workgroup selected can be trusted
