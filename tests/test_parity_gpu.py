@@ -1472,7 +1472,7 @@ def test_filtered_search_long_allow_list_on_device(wax):
 @pytest.mark.parametrize("dims", [384, 128, 768, 256, 512])
 def test_batch_gemm_variants_agree(wax, dims):
     """Every GEMM behind the batched path — the LDS-tiled kernel (batch_rega 0), the register-resident-queries kernel with a
-    workgroup barrier per tile (1) and with the split barrier (5, the default), with and without the pace gate — gives the
+    workgroup barrier per tile (1, the default since round 6) and with the split barrier (5), with and without the pace gate — gives the
     single-query answers bit for bit, over several slab schedules of the slab pipeline and through the one-pass pipeline.
     (Round 5 replaced four register-resident kernels and a dozen build variants by this one; what they measured is in profiles/HISTORY.md.)"""
     n = 150_000
@@ -1942,11 +1942,11 @@ def test_batch_onepass_pipeline_is_exact(wax, metric, dims):
             e_ids, e_scores, _, _ = oracle.search(metric, corpus, ids, queries[i], k)
             x = oracle.search(metric, corpus, ids, queries[i], k + MARGIN)[1]
             assert_parity(b_ids[i, :k], b_scores[i, :k], e_ids, e_scores, x, f"onepass m{metric} d{dims} k{k} q{i}")
-    # a workgroup barrier per tile instead of the split one gives the same answers
+    # the split tile barrier instead of the workgroup barrier (the default) gives the same answers
     ref_ids, ref_scores, _ = eng.searchBatch(queries, 30)
-    eng.setTuning("batch_rega", 1)
-    w_ids, w_scores, _ = eng.searchBatch(queries, 30)
     eng.setTuning("batch_rega", 5)
+    w_ids, w_scores, _ = eng.searchBatch(queries, 30)
+    eng.setTuning("batch_rega", 1)
     assert np.array_equal(ref_ids, w_ids) and np.array_equal(ref_scores, w_scores)
     fb = eng.getTuning("batch_fallbacks")
     print(f"\n[onepass m{metric} d{dims}] fallbacks {fb} of {7 * 301}")

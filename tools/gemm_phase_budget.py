@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--tune", action="append", default=[], help="key=value tuning applied before the runs")
     ap.add_argument("--out", default=None)
     ap.add_argument("--ab-key", default="batch_rega", help="tuning key the A/B runs over (round 6's kernel variants were switched by a key that no longer exists)")
-    ap.add_argument("--opts", type=int, nargs="+", default=[5], help="values of --ab-key to run, one line each")
+    ap.add_argument("--opts", type=int, nargs="+", default=[1], help="values of --ab-key to run, one line each")
     ap.add_argument("--ab-rounds", type=int, default=0, help="rounds of the interleaved product-kernel A/B over --opts (0 = none)")
     args = ap.parse_args()
     import torch
@@ -109,7 +109,7 @@ def budget(args, eng, torch, dev, run, ref, dout, opt, ab_times):
     eng.setTuning("time_kernels", 0)
     used = p[:, 0, 10] > 0
     p = p[used]
-    if p.shape[0] == 0:        # this variant has no phase-timing build ("batch_rega" 1: the workgroup-barrier kernel): times only
+    if p.shape[0] == 0:        # this variant has no phase-timing build: times only
         line = json.dumps({"rows": args.rows, "dims": args.dims, "nq": args.nq, "topk": args.topk, "tune": args.tune, "ab_key": args.ab_key,
                            "batch_opt": opt, "product_kernel_us_hip_events": prod_us,
                            "product_kernel_us_ab_median": (float(np.median(ab_times)) if ab_times else None),

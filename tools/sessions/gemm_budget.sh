@@ -1,13 +1,13 @@
 #!/bin/bash
 # Per-phase cycle budget of the filtering GEMM (s_memtime build, "batch_prof_ptr") at BASELINE configs 3 / 5 and at top-100, with the
-# product kernel's HIP-event time beside it, and the interleaved A/B of the split tile barrier against the workgroup barrier
-# ("batch_rega" 5 / 1). Output: gpurun_out/$WAX_TAG/phase_budget.jsonl + phase_table.txt.
+# product kernel's HIP-event time beside it, and the interleaved A/B of the workgroup barrier (default) against the split tile barrier
+# ("batch_rega" 1 / 5). Output: gpurun_out/$WAX_TAG/phase_budget.jsonl + phase_table.txt.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/${WAX_TAG:-gemm_budget}
 mkdir -p "$OUT"; cd "$R"; export TMPDIR=/tmp
-timeout 900 python tools/gemm_phase_budget.py --rows 1000000 --dims 384 --nq 256 --opts 5 1 --ab-rounds 5 --reps 10 --out "$OUT/phase_budget.jsonl" > /dev/null 2>> "$OUT/phase.err"
-timeout 900 python tools/gemm_phase_budget.py --rows 1000000 --dims 384 --nq 256 --topk 100 --opts 5 --ab-rounds 3 --reps 10 --out "$OUT/phase_budget.jsonl" > /dev/null 2>> "$OUT/phase.err"
-timeout 900 python tools/gemm_phase_budget.py --rows 1000000 --dims 384 --nq 1024 --opts 5 --ab-rounds 3 --reps 6 --out "$OUT/phase_budget.jsonl" > /dev/null 2>> "$OUT/phase.err"
-timeout 900 python tools/gemm_phase_budget.py --rows 1250000 --dims 768 --nq 1024 --opts 5 1 --ab-rounds 4 --reps 6 --out "$OUT/phase_budget.jsonl" > /dev/null 2>> "$OUT/phase.err"
+timeout 900 python tools/gemm_phase_budget.py --rows 1000000 --dims 384 --nq 256 --opts 1 5 --ab-rounds 5 --reps 10 --out "$OUT/phase_budget.jsonl" > /dev/null 2>> "$OUT/phase.err"
+timeout 900 python tools/gemm_phase_budget.py --rows 1000000 --dims 384 --nq 256 --topk 100 --opts 1 --ab-rounds 3 --reps 10 --out "$OUT/phase_budget.jsonl" > /dev/null 2>> "$OUT/phase.err"
+timeout 900 python tools/gemm_phase_budget.py --rows 1000000 --dims 384 --nq 1024 --opts 1 --ab-rounds 3 --reps 6 --out "$OUT/phase_budget.jsonl" > /dev/null 2>> "$OUT/phase.err"
+timeout 900 python tools/gemm_phase_budget.py --rows 1250000 --dims 768 --nq 1024 --opts 1 5 --ab-rounds 4 --reps 6 --out "$OUT/phase_budget.jsonl" > /dev/null 2>> "$OUT/phase.err"
 python tools/phase_table.py "$OUT/phase_budget.jsonl" | tee "$OUT/phase_table.txt"

@@ -986,19 +986,23 @@ template <int D>
 static hipError_t launch_rq_filter(const GemmArgs& a, hipStream_t st) {
     uint32_t groups, per_group;
     rq_geometry(a, &groups, &per_group);
-    // "batch_rega" 1: a workgroup barrier per tile instead of the split one (A/B, and the variant the fail-safe test compares with)
-    if (a.use_rega == 1u) return launch_rq<D, false, false>(a, groups, per_group, st);
+    // "batch_rega" 1 (default since round 6): a workgroup barrier per tile; 5: the split tile barrier (arrive / wait on an LDS counter),
+    // the default of round 5. With the selection at a third of its round-5 cost the early waves reach the hand-over long before the
+    // late ones either way, and the split barrier's polls (an LDS round trip each beside eight waves' fragment reads) cost more than
+    // the overlap buys: -2.2 % (384-d, 256 queries) ... -3.4 % (768-d) with s_barrier, same answers (profiles/r06/j_*).
+    const bool split = a.use_rega == 5u;
+    // one query group: every tile is requested exactly once, by one workgroup -> non-temporal requests (-1 ... -3 % at Q = 256; with
+    // G > 1 groups sharing tiles through their XCD's L2 the same hint costs 3 - 5 %: profiles/r05/e_nontemporal_tile_requests.txt)
+    const bool nt = groups == 1;
     // "batch_prof_ptr" (diagnosis): the phase-timing build of the same launch, at the two dimensions of BASELINE configs 3 / 5
     if constexpr (D == 384 || D == 768) {
         if (a.prof != nullptr) {
-            if (groups == 1) return launch_rq<D, false, true, true, true>(a, groups, per_group, st);
-            return launch_rq<D, false, true, false, true>(a, groups, per_group, st);
+            if (split) return nt ? launch_rq<D, false, true, true, true>(a, groups, per_group, st) : launch_rq<D, false, true, false, true>(a, groups, per_group, st);
+            return nt ? launch_rq<D, false, false, true, true>(a, groups, per_group, st) : launch_rq<D, false, false, false, true>(a, groups, per_group, st);
         }
     }
-    // one query group: every tile is requested exactly once, by one workgroup -> non-temporal requests (-1 ... -3 % at Q = 256; with
-    // G > 1 groups sharing tiles through their XCD's L2 the same hint costs 3 - 5 %: profiles/r05/e_nontemporal_tile_requests.txt)
-    if (groups == 1) return launch_rq<D, false, true, true>(a, groups, per_group, st);
-    return launch_rq<D, false, true>(a, groups, per_group, st);
+    if (split) return nt ? launch_rq<D, false, true, true>(a, groups, per_group, st) : launch_rq<D, false, true>(a, groups, per_group, st);
+    return nt ? launch_rq<D, false, false, true>(a, groups, per_group, st) : launch_rq<D, false, false>(a, groups, per_group, st);
 }
 
 hipError_t launch_batch_gemm(const GemmArgs& a, int metric, hipStream_t st) {
