@@ -8,7 +8,7 @@ cd "$R"; export TMPDIR=/tmp
 for r in $(seq 1 $ROUNDS); do
   for name in "$@"; do
     WAX_HIP_LIB=$R/wax_amd/lib/exp/libwaxhip_$name.so timeout 300 python tools/gemm_phase_budget.py --rows $ROWS --dims $DIMS --nq $NQ --topk $TOPK \
-        --opts 5 --ab-rounds 5 --reps 10 --tune "time_kernels=0" --out "$OUT.tmp" > /dev/null 2>> "$OUT.err"
+        --opts 1 --ab-rounds 5 --reps 10 --tune "time_kernels=0" --out "$OUT.tmp" > /dev/null 2>> "$OUT.err"
     python - "$OUT.tmp" "$OUT" "$name" "$r" <<'PY'
 import json, sys
 src, dst, name, rnd = sys.argv[1:5]

@@ -30,6 +30,7 @@
 #include "kernels.h"
 #include "topk.h"
 
+
 namespace wax {
 
 // Compile-time loop: f(std::integral_constant<int, I>{}) for I in [I0, N) — the index is a constant expression inside
@@ -866,10 +867,16 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
         if (SPLIT && it > 0) wait_arrivals(8u * it);
         const unsigned int p2 = now();
         pace(it);
-        if (issued) dma_tile(tn, pre_idx * BUF_B);
+        // Three tile buffers (D = 128, 256, 768): tile t + 2 goes to the buffer tile t - 1 left at the last hand-over and need not land
+        // before the hand-over after next, so an EARLY wave starts its K loop at once and requests behind it — the matrix pipe no
+        // longer idles through the early waves' requests at the top of every tile (round 6: 768-d x 1 024 queries -5 % kernel time,
+        // profiles/r06/k_*). A late wave requests in front of its K loop as before (its selection sits in front of both).
+        constexpr bool EARLY_AFTER = NBUF >= 3 && !SAMPLE;
+        if (!(EARLY_AFTER && !late) && issued) dma_tile(tn, pre_idx * BUF_B);
         const unsigned int p3 = now();
         mfma_tile(baddr);
         const unsigned int p4 = now();
+        if (EARLY_AFTER && !late && issued) dma_tile(tn, pre_idx * BUF_B);
         // tile t + 1 must have landed before the others read it (every wave waits for its own pieces, the barrier / the arrival
         // counter joins them); the PRE - 1 younger tiles stay in flight. The wait sits in FRONT of an early wave's selection:
         // vmcnt counts the selection's survivor stores too (they are older than the requests that stay in flight and complete first)
@@ -932,6 +939,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
 // (Round 6, D = 384: 96-row tiles — 2 x 75 KB — cut 7.6 % of the cycles per row and 4 % of the Q = 1 024 kernel, but a workgroup
 // that fills the CU's LDS keeps the neighbouring batches' small kernels off it: pipelined 256-query batches +2 %, dense
 // neighbourhoods +6 %. 64 rows stay: profiles/r06/g_*.)
+// (Round 6, D = 384 with three buffers + the early waves requesting behind their K loop: +5 % cycles per tile, pipelined batches +4 ... 7 %.)
 template <int D> struct RqGeom;
 template <> struct RqGeom<128> { static constexpr int TROWS = 128, NBUF = 3, AHEAD = 3; };
 template <> struct RqGeom<256> { static constexpr int TROWS = 64, NBUF = 3, AHEAD = 3; };
