@@ -810,7 +810,9 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
     // apart, and the round-4 form (average over all G, a 1 ms spin bound) made the early ones sleep through every check: the
     // 8-shards-on-one-GPU rehearsal of config 5 took 157 ms instead of 16. Bounded (64 polls, ~70 us) and advisory: a timeout just
     // proceeds. ("batch_debug" bit 12 switches the gate off.)
-    constexpr uint32_t GATE_EVERY = 8u, GATE_WINDOW = 6u;
+    // (round 6: every 4 tiles, window 3 — round 5 had 8 / 6: with three tiles in flight per workgroup, eight workgroup sets per XCD and a
+    // window of six the shared tiles no longer fitted the XCD's 4 MB of L2 once the kernel got faster: 1.06 - 1.29 x the mirror fetched)
+    constexpr uint32_t GATE_EVERY = 4u, GATE_WINDOW = 3u;
     const uint32_t ngroups = gridDim.x / blocks_per_group;
     // (launches of up to GATE_MIN_TILES tiles per workgroup — ~3 ms — do not drift far enough to lose the sharing: 1.25M x 768 reads
     // 1.01 x the mirror with or without the gate, and the gate's returning atomics cost 1.5 % there)
@@ -866,7 +868,7 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
         // every wave is through K loop it - 1 (the buffer tile tn goes to is free) and has its pieces of tile `it` in LDS
         if (SPLIT && it > 0) wait_arrivals(8u * it);
         const unsigned int p2 = now();
-        pace(it);
+        if (SPLIT) pace(it);                                  // (workgroup barrier: the gate sits in front of the barrier, below)
         // Three tile buffers (D = 128, 256, 768): tile t + 2 goes to the buffer tile t - 1 left at the last hand-over and need not land
         // before the hand-over after next, so an EARLY wave starts its K loop at once and requests behind it — the matrix pipe no
         // longer idles through the early waves' requests at the top of every tile (round 6: 768-d x 1 024 queries -5 % kernel time,
@@ -887,6 +889,11 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
         t_prev = t;
         const unsigned int p6 = now();
         if (!SPLIT) {
+            // the pace gate of the NEXT tile, in front of the barrier: while wave 0 sleeps the barrier holds all eight waves, so nobody
+            // requests ahead of the gate (with the gate at the top of the loop the late waves — and, since the early waves request
+            // behind their K loop, everybody — requested a tile before the gate could bite: config 5 whole fetched 1.06 - 1.29 x the
+            // mirror, 1.98 x with the split barrier; profiles/r06/l_*)
+            pace(it + 1);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
