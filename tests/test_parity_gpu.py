@@ -551,6 +551,39 @@ def test_full_size_parity_with_oracle(wax, n, dims, nq):
 # ---------------------------------------------------------------------------
 # batched queries: bf16 MFMA GEMM + select + exact f32 re-score + certificate (BASELINE configs 3 / 5)
 
+@pytest.mark.parametrize("dims,n,nq", [(384, 24 * 256 * 64 + 37, 256), (384, 400_003, 600), (768, 200_011, 700), (128, 24 * 256 * 128 + 5, 200),
+                                       (384, 24 * 256 * 64 - 64, 256)])
+def test_batch_tail_pool_gives_the_fixed_share_answers(wax, dims, n, nq):
+    """The filtering GEMM's workgroups claim the last twelfth of the store's tiles from a pool ("batch_dyn_tail", default 1; stores of
+    at least 24 tiles per workgroup). Which workgroup meets a row must not show: the answers equal those of fixed shares
+    ("batch_dyn_tail" 0) and of the single-query path bit for bit — at the smallest store that has a pool (with a ragged last tile),
+    with 2 - 4 query groups (one pool each), and one tile below the threshold (no pool)."""
+    corpus = oracle.gaussian_unit_rows(77, n, dims)
+    eng = make_engine(wax, 0, dims, corpus)
+    assert eng.getTuning("batch_dyn_tail") == 1
+    queries = oracle.gaussian_unit_queries(nq, dims, seed=5)
+    out = {}
+    for dyn in (1, 0, 1):
+        eng.setTuning("batch_dyn_tail", dyn)
+        before = eng.getTuning("onepass_queries")
+        ids, scores, counts = eng.searchBatch(queries, 10)
+        assert eng.getTuning("onepass_queries") - before == nq
+        if dyn in out:
+            assert np.array_equal(ids, out[dyn][0]) and np.array_equal(scores, out[dyn][1])
+        out[dyn] = (ids, scores, counts)
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+    for i in (0, 1, nq // 2, nq - 1):
+        s_ids, s_scores = eng.searchArrays(queries[i], 10)
+        assert np.array_equal(out[1][0][i], s_ids) and np.array_equal(out[1][1][i], s_scores)
+    # the last rows of the store are pool tiles: a query that IS one of them must find it
+    probe = corpus[[n - 1, n - 40, n - 3000]].copy()
+    ids, scores, counts = eng.searchBatch(np.concatenate([probe, queries[:29]]), 3)
+    assert [int(ids[j, 0]) for j in range(3)] == [n - 1, n - 40, n - 3000]
+    with pytest.raises(Exception):
+        eng.setTuning("batch_dyn_tail", 2)
+    eng.close()
+
+
 def _batch_vs_single(eng, queries, k):
     ids, scores, counts = eng.searchBatch(queries, k)
     for i, q in enumerate(queries):

@@ -31,7 +31,7 @@ t_end = time.time() + args.seconds
 trials = checked = fallbacks = onepass_q = retries = sharded_trials = 0
 while time.time() < t_end:
     dims = int(rng.choice([128, 256, 384, 512, 768, 192]))
-    n = int(rng.integers(20_000, 400_000))
+    n = int(rng.integers(20_000, 400_000)) if rng.random() < 0.8 else int(rng.integers(400_000, 1_200_000))   # (the larger ones: a tail pool at one query group)
     metric = int(rng.choice([0, 0, 1, 2]))
     k = int(rng.choice([1, 5, 10, 30, 64, 100, 200, 300, 460]))
     nq = int(rng.choice([16, 17, 64, 255, 256, 257, 300, 700, 1024, 1500]))

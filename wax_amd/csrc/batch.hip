@@ -855,10 +855,55 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
     auto arrive = [&]() {
         if (lane == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\tds_add_u32 %0, %1" ::"v"(sync_addr), "v"(1u) : "memory");
     };
+    // Tail pool (a.dyn). Fixed shares (tile = bidx + position * blocks_per_group) leave the launch waiting for its slowest workgroups:
+    // the XCDs do not run at one speed (round 6: the odd ones 3 - 4 % behind at 384-d), 15 625 tiles do not divide by 256, and a
+    // workgroup that met more survivors is behind by their cold paths — at 1M x 384 x 256 the mean workgroup idled 7.5 us of 170 at
+    // the end. So only positions < n_static are fixed; the rest of the slab (the last twelfth, at least four tiles per workgroup) is
+    // a pool per query group: wave 0 claims position p's tile with a returning add at the top of iteration p - PRE - 1 (the value is
+    // back by that iteration's DMA wait — it is older than every request the wait lets stay in flight), publishes it in LDS in front
+    // of the tile barrier, and every wave reads it at the top of iteration p - PRE, where it is the tile to request. A claim past the
+    // end of the slab ends the walk (so does every later one: the counter only grows). Two LDS words, alternating: the next claim is
+    // published before the slowest wave need have read this one.
+    constexpr bool DYN_OK = !SAMPLE && !SPLIT;
+    constexpr uint32_t DYN_MIN_TILES = 24u;
+    const uint32_t tiles_min = ntiles / blocks_per_group;
+    const bool dyn = DYN_OK && a.dyn != nullptr && tiles_min >= DYN_MIN_TILES;
+    const uint32_t dyn_keep = tiles_min / 12u > 4u ? tiles_min / 12u : 4u;
+    const uint32_t n_static = dyn ? tiles_min - dyn_keep : 0xffffffffu;
+    const uint32_t dyn_base = n_static * blocks_per_group;       // first tile of the pool (unused without)
+    const uint32_t* dyn_word = a.dyn + group * 32u;
+    const uint32_t dyn_addr = sync_addr + 16u;                    // sync_s[4], sync_s[5]
+    bool dyn_done = false;                                        // wave 0: a claim came back past the end
+    uint32_t t_up[PRE > 1 ? PRE - 1 : 1];                         // the tiles of positions it + 1 .. it + PRE - 1 (requested, not yet current)
+#pragma unroll
+    for (int i = 0; i + 1 < PRE; ++i) t_up[i] = bidx + (uint32_t)(i + 1) * blocks_per_group;
+    uint32_t tn_fixed = bidx + PRE * blocks_per_group;            // position it + PRE's tile while that position is fixed
     uint32_t it = 0, cur_idx = 0, t_prev = 0;
     for (; t < ntiles; ++it) {
         const uint32_t baddr = smem_lds + cur_idx * (uint32_t)BUF_B + lane_boff;
-        const uint32_t tn = t + PRE * blocks_per_group;
+        uint32_t tn = tn_fixed;
+        uint32_t claim_v = 0u;
+        if (DYN_OK && dyn && it + PRE + 1u >= n_static) {        // (uniform; the last twelfth of the walk only)
+            if (it + PRE >= n_static) {
+                unsigned int v;
+                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(dyn_addr + ((it & 1u) << 2)) : "memory");
+                tn = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+            }
+            // the claim for position it + PRE + 1: lane 0 of wave 0 (EXEC narrowed inside the statement — the add's result register
+            // is written long after it, and a branch around it would leave hipcc a copy of the stale value to make)
+            const unsigned int mask = (wave == 0 && !dyn_done) ? 1u : 0u;   // (hipcc hands an "s" input over in a VGPR here: read it inside)
+            unsigned int mask_s;
+            unsigned long long saved;
+            asm volatile("s_mov_b64 %[sv], exec\n\t"
+                         "v_readfirstlane_b32 %[ms], %[m]\n\t"
+                         "s_mov_b32 exec_lo, %[ms]\n\t"
+                         "s_mov_b32 exec_hi, 0\n\t"
+                         "global_atomic_add %[v], %[zero], %[one], %[base] sc0\n\t"
+                         "s_mov_b64 exec, %[sv]"
+                         : [v] "+v"(claim_v), [sv] "=&s"(saved), [ms] "=&s"(mask_s)
+                         : [m] "v"(mask), [zero] "v"(0u), [one] "v"(1u), [base] "s"(dyn_word)
+                         : "memory");
+        }
         uint32_t pre_idx = cur_idx + PRE;
         pre_idx = pre_idx >= (uint32_t)NBUF ? pre_idx - NBUF : pre_idx;
         const bool issued = tn < ntiles;
@@ -888,6 +933,19 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
         if (!late) select_tile(t);
         t_prev = t;
         const unsigned int p6 = now();
+        if (DYN_OK && dyn && it + PRE + 1u >= n_static) {
+            // the claim is back (dma_wait above): publish position it + PRE + 1's tile for the top of the next iteration
+            asm volatile("" : "+v"(claim_v));
+            if (wave == 0) {
+                uint32_t tile_c = 0xffffffffu;
+                if (!dyn_done) {
+                    const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)claim_v);
+                    tile_c = dyn_base + c;
+                    dyn_done = tile_c >= ntiles;
+                }
+                if (lane == 0) asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(dyn_addr + (((it + 1u) & 1u) << 2)), "v"(tile_c) : "memory");
+            }
+        }
         if (!SPLIT) {
             // the pace gate of the NEXT tile, in front of the barrier: while wave 0 sleeps the barrier holds all eight waves, so nobody
             // requests ahead of the gate (with the gate at the top of the loop the late waves — and, since the early waves request
@@ -906,7 +964,15 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
             ph[RQP_DMA_WAIT] += p5 - p4;
         }
         cur_idx = cur_idx + 1 == (uint32_t)NBUF ? 0u : cur_idx + 1;
-        t += blocks_per_group;
+        if constexpr (PRE > 1) {
+            t = t_up[0];
+#pragma unroll
+            for (int i = 0; i + 2 < PRE; ++i) t_up[i] = t_up[i + 1];
+            t_up[PRE - 2] = tn;
+        } else {
+            t = tn;
+        }
+        tn_fixed += blocks_per_group;
     }
     const unsigned int k_loop1 = now();
     if (late && it > 0) select_tile(t_prev);
@@ -1429,6 +1495,7 @@ __global__ __launch_bounds__(256) void batch_prep_kernel(PrepArgs a) {
     const uint32_t q = blockIdx.x * 4 + (uint32_t)wave;
     if (q >= a.nq_pad) return;
     if (q == 0 && a.progress) for (uint32_t i = lane; i < BATCH_PROGRESS_WORDS; i += WAVE) a.progress[i] = 0u;   // the pace gate's words (one 128-byte line per XCD)
+    if (q == 0 && a.dyn) for (uint32_t i = lane; i < BATCH_DYN_WORDS; i += WAVE) a.dyn[i] = 0u;                   // the tail pool's claim counters
     const uint32_t D = a.dims;
     unsigned short* out = a.qb + (size_t)q * D;
     // fragment-ordered copy (GemmArgs::qf): element c of query q -> ((q / 32 * D/16 + c / 16) * 64 + (q & 31) + 32 * ((c >> 3) & 1)) * 8 + (c & 7)

@@ -230,6 +230,11 @@ struct GemmArgs {
     // XCD) for the advisory pace gate that keeps the groups walking the corpus within a few tiles of each other, so that a tile
     // fetched for one group is still in the XCD's L2 when the others read it.
     uint32_t* progress;
+    // rq filtering launch (workgroup-barrier form): non-null = [BATCH_DYN_WORDS] claim counters, zeroed before the launch (one 128-byte line
+    // per query group). Every workgroup walks its fixed share of the slab except the last twelfth; those tiles form a per-group pool the
+    // workgroups claim one at a time (a returning add), so that the launch ends within one tile of every workgroup instead of waiting
+    // for the slowest XCD's fixed share. Null = fixed shares throughout.
+    uint32_t* dyn;
     // Diagnosis ("batch_prof_ptr"): non-null = device buffer of [grid * 8 waves][RQ_PROF_WORDS] u32 that the PROF instantiation of the
     // filtering launch fills with per-wave phase cycle counts (indices RQP_*). Never set by the product path.
     uint32_t* prof;
@@ -326,9 +331,11 @@ struct PrepArgs {
     unsigned short* qf;         // the bf16 queries once more in MFMA A-fragment order (GemmArgs::qf; dims % 16 == 0); may be null
     uint32_t* cand_count;       // slab pipeline: per-query append counters to zero (stride CAND_COUNT_STRIDE); may be null
     uint32_t* progress;         // one-pass pipeline: [BATCH_PROGRESS_WORDS] pace-gate words of the filtering GEMM to zero; may be null
+    uint32_t* dyn;              // one-pass pipeline: [BATCH_DYN_WORDS] tile-claim counters of the filtering GEMM to zero; may be null
     float* q_norm_host;         // [nq] the exact norms once more, straight into pinned host memory (fallback queries need them there); may be null
 };
 constexpr uint32_t BATCH_PROGRESS_WORDS = 256;
+constexpr uint32_t BATCH_DYN_WORDS = 128;          // 4 query groups x one 128-byte line
 hipError_t launch_batch_prep(const PrepArgs& a, hipStream_t stream);
 hipError_t launch_batch_gemm_sample(const GemmArgs& a, int metric, hipStream_t stream);
 // tau[q] = 1 - (the rank-th largest of the sampled tiles' best similarities), rank <= 12; padding queries keep -inf.
