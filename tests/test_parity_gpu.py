@@ -554,10 +554,10 @@ def test_full_size_parity_with_oracle(wax, n, dims, nq):
 @pytest.mark.parametrize("dims,n,nq", [(384, 24 * 256 * 64 + 37, 256), (384, 400_003, 600), (768, 200_011, 700), (128, 24 * 256 * 128 + 5, 200),
                                        (384, 24 * 256 * 64 - 64, 256)])
 def test_batch_tail_pool_gives_the_fixed_share_answers(wax, dims, n, nq):
-    """The filtering GEMM's workgroups claim the last twelfth of the store's tiles from a pool ("batch_dyn_tail", default 1; stores of
-    at least 24 tiles per workgroup). Which workgroup meets a row must not show: the answers equal those of fixed shares
-    ("batch_dyn_tail" 0) and of the single-query path bit for bit — at the smallest store that has a pool (with a ragged last tile),
-    with 2 - 4 query groups (one pool each), and one tile below the threshold (no pool)."""
+    """The filtering GEMM's workgroups claim the last twelfth of the store's tiles from a pool ("batch_dyn_tail", default 1; one query
+    group, stores of at least 24 tiles per workgroup). Which workgroup meets a row must not show: the answers equal those of fixed
+    shares ("batch_dyn_tail" 0) and of the single-query path bit for bit — at the smallest store that has a pool (with a ragged last
+    tile), with 2 - 4 query groups (fixed shares whatever the key says), and one tile below the threshold (no pool)."""
     corpus = oracle.gaussian_unit_rows(77, n, dims)
     eng = make_engine(wax, 0, dims, corpus)
     assert eng.getTuning("batch_dyn_tail") == 1

@@ -30,7 +30,7 @@ for a, b in (("sq_768", "z_pmc_sq_counters_768_rq_final_build.json"), ("sq2_768"
              ("sq_384", "z_pmc_sq_counters_384_rq_final_build.json"), ("sq_768_wide", "z_pmc_sq_counters_768_wide_final_build.json"),
              ("sq2_768_wide", "z_pmc_sq2_counters_768_wide_final_build.json")):
     cp(a + ".json", b)
-for a in ("one_process_2_shards.json", "one_process_n1.json", "pytest_gpu.log", "fuzz.txt", "latency_c.jsonl", "smoke.log", "phase_budget.jsonl", "phase_table.txt",
+for a in ("one_process_2_shards.json", "one_process_n1.json", "pytest_gpu.log", "fuzz.txt", "latency_c.jsonl", "smoke.log", "phase_budget.jsonl", "phase_table.txt", "tail_pool_ab.jsonl",
           "fanout_ABC.jsonl", "gemm_s10m_k300_kernel_stats.csv", "gemm_s1m_k1000_kernel_stats.csv"):
     cp(a, "z_" + a)
 

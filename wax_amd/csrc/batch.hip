@@ -867,7 +867,10 @@ __global__ __launch_bounds__(512, 2) void batch_gemm_rq_kernel(GemmArgs a, uint3
     constexpr bool DYN_OK = !SAMPLE && !SPLIT;
     constexpr uint32_t DYN_MIN_TILES = 24u;
     const uint32_t tiles_min = ntiles / blocks_per_group;
-    const bool dyn = DYN_OK && a.dyn != nullptr && tiles_min >= DYN_MIN_TILES;
+    // One query group only: with G groups a tile is wanted G times, by the G workgroups of one bidx on one XCD, and fixed shares keep
+    // them reading it together (one HBM fetch, G - 1 L2 hits); pool tiles go to whoever is free, on any XCD — measured at 768-d x 1 024:
+    // kernel -2 %, but FETCH_SIZE 1.02 -> 1.18 x the mirror (profiles/r06/n_*). Not worth the re-reads.
+    const bool dyn = DYN_OK && a.dyn != nullptr && tiles_min >= DYN_MIN_TILES && gridDim.x == blocks_per_group;
     const uint32_t dyn_keep = tiles_min / 12u > 4u ? tiles_min / 12u : 4u;
     const uint32_t n_static = dyn ? tiles_min - dyn_keep : 0xffffffffu;
     const uint32_t dyn_base = n_static * blocks_per_group;       // first tile of the pool (unused without)

@@ -230,10 +230,10 @@ struct GemmArgs {
     // XCD) for the advisory pace gate that keeps the groups walking the corpus within a few tiles of each other, so that a tile
     // fetched for one group is still in the XCD's L2 when the others read it.
     uint32_t* progress;
-    // rq filtering launch (workgroup-barrier form): non-null = [BATCH_DYN_WORDS] claim counters, zeroed before the launch (one 128-byte line
-    // per query group). Every workgroup walks its fixed share of the slab except the last twelfth; those tiles form a per-group pool the
-    // workgroups claim one at a time (a returning add), so that the launch ends within one tile of every workgroup instead of waiting
-    // for the slowest XCD's fixed share. Null = fixed shares throughout.
+    // rq filtering launch (workgroup-barrier form, one query group): non-null = [BATCH_DYN_WORDS] claim counters, zeroed before the launch.
+    // Every workgroup walks its fixed share of the slab except the last twelfth; those tiles form a pool the workgroups claim one at a
+    // time (a returning add), so that the launch ends within one tile of every workgroup instead of waiting for the slowest XCD's
+    // fixed share. Null, or more than one query group (pool tiles would lose the groups' shared L2 reads) = fixed shares throughout.
     uint32_t* dyn;
     // Diagnosis ("batch_prof_ptr"): non-null = device buffer of [grid * 8 waves][RQ_PROF_WORDS] u32 that the PROF instantiation of the
     // filtering launch fills with per-wave phase cycle counts (indices RQP_*). Never set by the product path.
