@@ -593,6 +593,7 @@ def secondary_single_query(torch, dev, rows, dims, k, steps, warmup, depth, labe
     nbytes = rows * dims * 4
     grid = eng.getTuning("scan_grid")
     merged, overlapped = eng.getTuning("merged_scans"), eng.getTuning("overlap_scans")
+    short_stats = (int(eng.getTuning("short_selects")), int(eng.getTuning("short_select_failures")))
     eng.close()
     traffic, traffic_source = None, None
     if TRAFFIC_MODE in ("auto", "live"):
@@ -610,8 +611,10 @@ def secondary_single_query(torch, dev, rows, dims, k, steps, warmup, depth, labe
         pass
     rf = scan_roofline(nbytes, kern_ms, launches, elapsed, steps, cal, traffic, traffic_source)
     if k > 192:
-        rf["note_general_selection"] = ("top_k > 192: the scan writes rows x 4 B of distances (+1/dims traffic) and the radix selection of "
-                                        "DESIGN 4.2 follows it; kernel_avg_ms is the distance kernel, ms_per_step the whole query")
+        rf["note_general_selection"] = ("top_k > 192: the fused scan leaves every workgroup's 192 best and one workgroup selects and certifies the "
+                                        "top_k among them (DESIGN 4.2); the distance pass + radix selection behind it return at once unless the "
+                                        "certificate fails; kernel_avg_ms is the scan kernel, ms_per_step the whole query")
+        rf["short_selects"], rf["short_select_failures"] = short_stats
     rf["scan_grid"] = grid
     # 1: the scan kernel's last-arriving workgroup did the final merge; 2: a merge launch behind the scan (stores beyond 2 GiB; and, with
     # other scans in flight as here, stores from "merge_overlap_mb" up: the merge overlaps the next scan)

@@ -338,6 +338,12 @@ int wax_hip_stats(wax_hip_engine* e, wax_hip_stats_t* out);
  *   "scan_chain" (pipelined scans of different streams: 1 = chained through an event so that a per-launch duration is one scan alone;
  *   0 = free to overlap; -1 (default) = chained exactly while "time_kernels" != 0), "share_timing" (1 = a chained scan reuses its
  *   predecessor's end event as its start event),
+ *   "select_short" (1 (default): top_k > 192 = the fused scan leaves every workgroup's 192 best, ONE workgroup selects the top_k among
+ *   them in LDS and certifies that no workgroup dropped one of the answer — otherwise, on the device, the distance pass + radix
+ *   selection behind it answers; 64 < top_k <= 192 on grids that do not merge in the scan kernel = the same workgroup is the final
+ *   merge (nothing can have been dropped: no certificate), the wave-list merge stays behind it, gated; 0 = the long path / the wave-list
+ *   merge at once; "force_general" implies 0 for top_k > 192), "short_selects" / "short_select_failures" (read-only: short selections
+ *   enqueued / that left the answer to the launches behind them),
  *   "filter_device_min" (wax_hip_search_filtered: allow-lists at least this long are resolved by the id -> row table in HBM, default 4096; -1 = never).
  * batched queries (bf16 MFMA GEMM + fused selection + exact re-score; exact answers whatever the setting)
  *   "batch_mode" (0 = never use the MFMA path), "batch_min" (smallest batch that may use it, default 1; below 16 queries a cost model

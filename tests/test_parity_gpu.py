@@ -145,6 +145,110 @@ def test_ragged_row_counts(wax, n):
         check(eng, 0, corpus, None, corpus[n - 1], 1, f"n{n} d{dims} last-row")  # the tail row is reachable
 
 
+@pytest.mark.parametrize("n,dims,metric", [(300_000, 384, 0), (60_000, 128, 2), (150_000, 768, 1), (80_000, 100, 0), (1_100_000, 128, 0)])
+def test_short_selection_equals_the_long_path(wax, n, dims, metric):
+    """top_k > 192 ("select_short", default 1): the fused scan leaves every workgroup's 192 best, one workgroup selects the top_k among
+    them and certifies that nothing was dropped; the distance pass + radix selection behind it only runs when that fails. Same hits,
+    bit for bit, as the long path alone ("select_short" 0) and as the oracle, for every k up to the clamp; no certificate fails on an
+    iid corpus."""
+    corpus = oracle.gaussian_unit_rows(3, n, dims)
+    if metric != 0:
+        corpus = corpus * np.linspace(0.5, 2.0, n, dtype=np.float32)[:, None]
+    eng = make_engine(wax, metric, dims, corpus)
+    assert eng.getTuning("select_short") == 1
+    q = oracle.gaussian_unit_queries(2, dims, seed=9)
+    grid = eng.getTuning("scan_grid")
+    tried = 0
+    for k in (193, 300, 1000, 4096, 4097, 7000, 10000):
+        # (tried while the lists can hold the answer — k <= 64 per list on average —, their first 2k / lists entries fit the LDS buffer,
+        # and the store has at least 256 rows per wanted key)
+        ke = min(k, n)
+        viable = grid * min(192, max(4, -(-2 * ke // grid))) <= 16384 and 3 * ke <= grid * 192 and n >= 256 * ke
+        tried += viable
+        eng.setTuning("select_short", 1)
+        before, fails = eng.getTuning("short_selects"), eng.getTuning("short_select_failures")
+        a = [eng.searchArrays(qi, k) for qi in q]
+        assert eng.getTuning("short_selects") - before == (len(q) if viable else 0), (k, grid)
+        assert eng.getTuning("short_select_failures") == fails, k
+        eng.setTuning("select_short", 0)
+        b = [eng.searchArrays(qi, k) for qi in q]
+        assert eng.getTuning("short_selects") - before == (len(q) if viable else 0)
+        for (ia, sa), (ib, sb) in zip(a, b):
+            assert len(ia) == min(k, n) and np.array_equal(ia, ib) and np.array_equal(sa, sb), k
+    assert tried >= (4 if n >= 1_048_576 else 3 if n >= 256_000 else 1), (grid, tried)
+    eng.setTuning("select_short", 1)
+    check(eng, metric, corpus, None, q[0], 300, "short selection against the oracle")
+    with pytest.raises(Exception):
+        eng.setTuning("select_short", 2)
+    eng.close()
+
+
+@pytest.mark.parametrize("layout", ["iid", "sorted"])
+def test_short_merge_of_the_fused_path_equals_the_wave_list_merge(wax, layout):
+    """64 < top_k <= 192 on a store whose scan does not merge in its own kernel: the per-workgroup lists are merged by the short
+    selection ("select_short" 1) — same hits as the wave-list merge ("select_short" 0), on an iid corpus and on one whose best rows
+    are its first rows (only a few workgroups' lists hold the answer)."""
+    n, dims = 300_000, 384
+    corpus = oracle.gaussian_unit_rows(21, n, dims)
+    q = oracle.gaussian_unit_queries(2, dims, seed=4)
+    if layout == "sorted":
+        order = np.argsort(-(corpus @ q[0]), kind="stable")
+        corpus = np.ascontiguousarray(corpus[order])
+    eng = make_engine(wax, 0, dims, corpus)
+    for k in (64, 65, 100, 150, 192):
+        eng.setTuning("select_short", 1)
+        before, f0 = eng.getTuning("short_selects"), eng.getTuning("short_select_failures")
+        a = [eng.searchArrays(qi, k) for qi in q]
+        assert eng.getTuning("short_selects") - before == (len(q) if k > 64 else 0), k
+        assert eng.getTuning("short_select_failures") == f0
+        eng.setTuning("select_short", 0)
+        b = [eng.searchArrays(qi, k) for qi in q]
+        for (ia, sa), (ib, sb) in zip(a, b):
+            assert len(ia) == k and np.array_equal(ia, ib) and np.array_equal(sa, sb), k
+    eng.setTuning("select_short", 1)
+    check(eng, 0, corpus, None, q[0], 192, f"short merge, {layout}")
+    eng.close()
+
+
+def test_short_selection_certificate_fails_when_one_workgroup_holds_the_answer(wax):
+    """The scan deals 8-row chunks to its waves round-robin; put ~400 near-copies of the query exactly on workgroup 0's chunks. Its list
+    keeps 192 of them, the other 200 best rows of the store are gone from the candidates: the certificate must see that (workgroup 0's
+    last entry is better than the k-th candidate) and the long path must answer — exactly, every time for k = 193 .. 400; a query far
+    from the planted rows certifies."""
+    n, dims = 200_000, 384
+    corpus = oracle.gaussian_unit_rows(11, n, dims)
+    probe = make_engine(wax, 0, dims, corpus[:n])
+    grid = probe.getTuning("scan_grid")
+    probe.close()
+    nwaves = grid * 4
+    target = oracle.gaussian_unit_queries(1, dims, seed=77)[0].astype(np.float32)
+    rows = np.arange(n)
+    mine = ((rows // 8) % nwaves) < 4                  # the rows workgroup 0 reads
+    planted = rows[mine]
+    assert 250 < len(planted) < 2000, (grid, len(planted))
+    rng = np.random.default_rng(5)
+    noise = rng.standard_normal((len(planted), dims)).astype(np.float32) * np.linspace(0.01, 0.2, len(planted), dtype=np.float32)[:, None]
+    near = target[None, :] + noise / np.sqrt(dims)
+    corpus[planted] = near / np.linalg.norm(near, axis=1, keepdims=True)
+    eng = make_engine(wax, 0, dims, corpus)
+    assert eng.getTuning("scan_grid") == grid
+    for k in (193, 250, min(400, len(planted))):
+        f0 = eng.getTuning("short_select_failures")
+        ids, scores = eng.searchArrays(target, k)
+        assert eng.getTuning("short_select_failures") == f0 + 1, k
+        assert set(ids.tolist()) <= set(planted.tolist()) and len(ids) == k
+        eng.setTuning("select_short", 0)
+        ids0, scores0 = eng.searchArrays(target, k)
+        eng.setTuning("select_short", 1)
+        assert np.array_equal(ids, ids0) and np.array_equal(scores, scores0)
+    check(eng, 0, corpus, None, target, 300, "planted rows, long path behind a failed certificate")
+    f0 = eng.getTuning("short_select_failures")
+    far = oracle.gaussian_unit_queries(1, dims, seed=1234)[0]
+    check(eng, 0, corpus, None, far, 300, "a query far from the planted rows")
+    assert eng.getTuning("short_select_failures") == f0
+    eng.close()
+
+
 def test_force_general_path_equals_fused(wax):
     n, dims = 20000, 384
     corpus = oracle.gaussian_unit_rows(0, n, dims)
@@ -1143,6 +1247,9 @@ def test_bench_secondaries_carry_cpu_baselines_and_the_general_selection_sizes(w
         assert sec[name]["value"] > cb["value"]                      # (the GPU path is not slower than the host's threads)
     assert sec["s10m_k300"]["top_k"] == 300 and sec["s1m_k1000"]["top_k"] == 1000
     assert "top_k > 192" in sec["s10m_k300"]["roofline"]["note_general_selection"] and sec["s1m_k1000"]["roofline"]["frac"] > 0
+    for name in ("s10m_k300", "s1m_k1000"):      # every query through the short selection, none left to the long path
+        rf = sec[name]["roofline"]
+        assert rf["short_selects"] >= run["steps"] and rf["short_select_failures"] == 0, rf
     line = {x["name"]: x for x in run["_line"]["secondary"]}
     assert line["s10k"]["cpu"]["qps"] > 0 and line["s1m"]["cpu"]["cores"] >= 1 and "cpu" not in line["s1m_k1000"]
     assert run["_line"]["cpu_baseline"]["value"] > 0

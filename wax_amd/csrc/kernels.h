@@ -56,6 +56,7 @@ struct ScanArgs {
     const float* query;      // [dims] f32 in HBM
     int64_t* partials;       // fused path: [grid][k] per-workgroup sorted keys
     float* dist_out;         // general path: [n_rows] distances (the reference's distances buffer)
+    const uint32_t* gate;    // distance-writing launches only: non-null = return at once while *gate == 0 (the short selection answered; see SelectWork)
     uint32_t n_rows;
     uint32_t row_base;       // global row of local row 0 (shard offset)
     uint32_t dims;
@@ -149,9 +150,11 @@ hipError_t launch_merge_keys_multi(const int64_t* d_in, uint32_t n_lists, int k,
 
 // n_in sorted-or-not keys -> the k smallest, ascending, as hits (frame id looked up in d_ids
 // by local row = key_row - row_base; d_ids may be null => frame_id = global row). kpad >= k
-// slots are written (tail padded). cap as above.
+// slots are written (tail padded). cap as above. gate (may be null = run): the launch returns at once while *gate == 0 (a short
+// selection in front of it answered: launch_select_short).
 hipError_t launch_merge_keys(const int64_t* d_in, uint32_t n_in, int k, int kpad, const uint64_t* d_ids,
-                             uint32_t row_base, uint32_t n_rows, wax_hip_hit* d_out, int cap, hipStream_t stream);
+                             uint32_t row_base, uint32_t n_rows, wax_hip_hit* d_out, int cap, hipStream_t stream,
+                             const uint32_t* gate = nullptr);
 // gathered shard hits (n <= 16384) -> k smallest ascending (k <= 192)
 hipError_t launch_merge_hits(const wax_hip_hit* d_in, uint32_t n, int k, wax_hip_hit* d_out, hipStream_t stream);
 // Batched form: d_in = [n_shards][nq][kin] hits (an all-gather of per-shard batch results), d_out = [nq][out_stride]
@@ -162,15 +165,28 @@ hipError_t launch_merge_batch_hits(const wax_hip_hit* d_in, uint32_t n_shards, u
 // General (any k <= 10000) selection over a distance buffer: exact k-th key by 8-pass radix
 // select on the 64-bit key, compaction, rank sort, id lookup. Work buffers are caller-owned.
 struct SelectWork {
-    uint32_t* hist;      // [2048 bins + 1 arrival ticket], zero between launches
-    uint64_t* state;     // [4]: prefix / threshold, rank left, resolved flag
+    uint32_t* hist;      // [256 bins + 1 arrival ticket], zero between launches
+    uint64_t* state;     // [4]: prefix / threshold, rank left, resolved flag; behind them [4] more whose first 16 bytes are `flags`
     uint32_t* counter;   // [1]
     int64_t* keys_a;     // [kmax]
     int64_t* keys_b;     // [kmax]
+    uint32_t* flags;     // [4] (inside `state`): [0] gate — 1 = the short selection could not certify its answer, the long path runs;
+                         //     [1] short selections that failed, [2] short selections run (both since the workspace was allocated)
 };
+// `gate` (may be null = run): device word; every kernel of the chain returns at once while *gate == 0 (the short selection answered).
 hipError_t launch_select_general(const float* d_dist, uint32_t n_rows, uint32_t row_base, int k, int kpad,
                                  const uint64_t* d_ids, const SelectWork& w, wax_hip_hit* d_out,
-                                 hipStream_t stream);
+                                 hipStream_t stream, const uint32_t* gate = nullptr);
+// Short selection over the fused scan's per-workgroup lists (`lists` x `per_list` keys, each ascending, KEY_PAD-padded: every
+// workgroup's `per_list` best). ONE workgroup sorts the lists' first few entries in LDS to get a tight upper bound of the k-th key,
+// gathers the lists' prefixes below it, sorts those and writes the k best as hits. per_list >= k (the fused path's final merge for
+// 64 < k <= 192): always exact. per_list < k (k > FUSED_MAX_K): exact unless some workgroup dropped one of the answer — certified: a
+// workgroup whose list is full dropped only keys above its last entry, so every full list's last entry must be >= the k-th selected
+// key. d_flags[0] = 0 and hits written, or d_flags[0] = 1 and nothing written (certificate failed, or the prefixes overflowed the LDS
+// buffer): the caller's gated launches behind it answer. d_flags[1] counts failures, d_flags[2] launches.
+bool select_short_viable(int k, int lists, int per_list);
+hipError_t launch_select_short(const int64_t* d_cand, uint32_t lists, uint32_t per_list, int k, int kpad, const uint64_t* d_ids,
+                               uint32_t row_base, uint32_t n_rows, uint32_t* d_flags, wax_hip_hit* d_out, hipStream_t stream);
 hipError_t alloc_select_work(SelectWork* w);   // on the current device; synchronous (hipMemset of the histogram)
 void free_select_work(SelectWork* w);
 

@@ -253,6 +253,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const f32x4* __rest
     constexpr int RPW = WAVE / GROUP;       // rows per wave-wide load
     constexpr int RPC = RPW * UNROLL;       // rows per wave per iteration
     static_assert(D4 % GROUP == 0, "GROUP must divide D4");
+    if (WRITE_DIST && a.gate != nullptr && *a.gate == 0u) return;   // the short selection answered this query
 
     __shared__ int64_t lds[WRITE_DIST ? 1 : SCAN_WAVES * CAP + SCAN_WAVES + FUSED_MAX_K];
 
@@ -326,6 +327,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const f32x4* __rest
 template <int METRIC, int CAP, bool WRITE_DIST>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_generic_kernel(ScanArgs a) {
     __shared__ int64_t lds[WRITE_DIST ? 1 : SCAN_WAVES * CAP + SCAN_WAVES + FUSED_MAX_K];
+    if (WRITE_DIST && a.gate != nullptr && *a.gate == 0u) return;   // the short selection answered this query
     const int lane = lane_id();
     const int wave = (int)(threadIdx.x >> 6);
     const uint32_t n = a.n_rows, D = a.dims;
@@ -590,8 +592,10 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_keys_kernel(const int64_t
                                                                    const uint64_t* __restrict__ ids,
                                                                    uint32_t row_base, uint32_t n_rows,
                                                                    wax_hip_hit* __restrict__ out,
-                                                                   const uint32_t* __restrict__ qlist, uint32_t out_stride) {
+                                                                   const uint32_t* __restrict__ qlist, uint32_t out_stride,
+                                                                   const uint32_t* __restrict__ gate) {
     __shared__ int64_t lds[MERGE_WAVES * CAP + MERGE_WAVES + 2 * FUSED_MAX_K + 1];
+    if (gate != nullptr && *gate == 0u) return;               // the short selection in front of this launch answered
     // one workgroup per query (launch_merge_keys_multi); the single-query launch has one workgroup and out_stride = 0
     in += (size_t)blockIdx.x * n_lists * (uint32_t)k;
     out += (size_t)(qlist ? qlist[blockIdx.x] : blockIdx.x) * out_stride;
@@ -670,15 +674,15 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_keys_kernel(const int64_t
 }
 
 hipError_t launch_merge_keys(const int64_t* d_in, uint32_t n_in, int k, int kpad, const uint64_t* d_ids,
-                             uint32_t row_base, uint32_t n_rows, wax_hip_hit* d_out, int cap, hipStream_t st) {
+                             uint32_t row_base, uint32_t n_rows, wax_hip_hit* d_out, int cap, hipStream_t st, const uint32_t* gate) {
     if (k > FUSED_MAX_K || k < 1 || kpad < k || n_in % (uint32_t)k != 0) return hipErrorInvalidValue;
     const uint32_t n_lists = n_in / (uint32_t)k;
     if (cap <= 128)
         hipLaunchKernelGGL((merge_keys_kernel<128>), dim3(1), dim3(MERGE_THREADS), 0, st, d_in, n_lists, k, kpad, d_ids,
-                           row_base, n_rows, d_out, (const uint32_t*)nullptr, 0u);
+                           row_base, n_rows, d_out, (const uint32_t*)nullptr, 0u, gate);
     else
         hipLaunchKernelGGL((merge_keys_kernel<256>), dim3(1), dim3(MERGE_THREADS), 0, st, d_in, n_lists, k, kpad, d_ids,
-                           row_base, n_rows, d_out, (const uint32_t*)nullptr, 0u);
+                           row_base, n_rows, d_out, (const uint32_t*)nullptr, 0u, gate);
     return hipGetLastError();
 }
 
@@ -688,10 +692,10 @@ hipError_t launch_merge_keys_multi(const int64_t* d_in, uint32_t n_lists, int k,
     if (k > FUSED_MAX_K || k < 1 || out_stride < (uint32_t)k || nq == 0 || n_lists == 0) return hipErrorInvalidValue;
     if (k <= 64)
         hipLaunchKernelGGL((merge_keys_kernel<128>), dim3(nq), dim3(MERGE_THREADS), 0, st, d_in, n_lists, k, (int)out_stride, d_ids,
-                           row_base, n_rows, d_out_base, d_qlist, out_stride);
+                           row_base, n_rows, d_out_base, d_qlist, out_stride, (const uint32_t*)nullptr);
     else
         hipLaunchKernelGGL((merge_keys_kernel<256>), dim3(nq), dim3(MERGE_THREADS), 0, st, d_in, n_lists, k, (int)out_stride, d_ids,
-                           row_base, n_rows, d_out_base, d_qlist, out_stride);
+                           row_base, n_rows, d_out_base, d_qlist, out_stride, (const uint32_t*)nullptr);
     return hipGetLastError();
 }
 
@@ -783,10 +787,12 @@ constexpr int SEL_BINS = 256;
 __global__ __launch_bounds__(256) void select_hist_kernel(const float* __restrict__ dist, uint32_t n,
                                                           uint32_t row_base, int pass, uint32_t k,
                                                           uint64_t* __restrict__ state,
-                                                          uint32_t* __restrict__ hist, uint32_t* __restrict__ counter) {
+                                                          uint32_t* __restrict__ hist, uint32_t* __restrict__ counter,
+                                                          const uint32_t* __restrict__ gate) {
     __shared__ uint32_t h[SEL_BINS];
     __shared__ uint32_t part[SEL_BINS];
     __shared__ uint32_t last_s;
+    if (gate != nullptr && *gate == 0u) return;               // the short selection answered this query
     const bool first = pass == 0;
     if (!first && state[2] != 0) return;                      // nothing left to decide
     const uint64_t prefix = first ? 0ull : state[0];
@@ -883,7 +889,8 @@ __global__ __launch_bounds__(256) void select_hist_kernel(const float* __restric
 __global__ __launch_bounds__(256) void select_compact_kernel(const float* __restrict__ dist, uint32_t n,
                                                              uint32_t row_base, const uint64_t* __restrict__ state,
                                                              uint32_t* counter, int64_t* __restrict__ out,
-                                                             uint32_t kmax) {
+                                                             uint32_t kmax, const uint32_t* __restrict__ gate) {
+    if (gate != nullptr && *gate == 0u) return;
     const uint64_t thr = state[0];  // the exact k-th smallest unsigned key (or the largest key of its tie group when all of it is needed)
     auto take = [&](float d, uint32_t i) {
         const uint64_t u = ukey_of(d, row_base + i);
@@ -912,8 +919,9 @@ __global__ __launch_bounds__(256) void select_compact_kernel(const float* __rest
 }
 
 __global__ __launch_bounds__(256) void rank_sort_kernel(const int64_t* __restrict__ in, int k,
-                                                        int64_t* __restrict__ out) {
+                                                        int64_t* __restrict__ out, const uint32_t* __restrict__ gate) {
     __shared__ int64_t tile[256];
+    if (gate != nullptr && *gate == 0u) return;
     const int i = (int)(blockIdx.x * 256 + threadIdx.x);
     const int64_t mine = (i < k) ? in[i] : KEY_PAD;
     int rank = 0;
@@ -930,9 +938,11 @@ __global__ __launch_bounds__(256) void rank_sort_kernel(const int64_t* __restric
 
 __global__ __launch_bounds__(256) void keys_to_hits_kernel(const int64_t* __restrict__ keys, int k, int kpad,
                                                            const uint64_t* __restrict__ ids, uint32_t row_base,
-                                                           uint32_t n_rows, wax_hip_hit* __restrict__ out) {
+                                                           uint32_t n_rows, wax_hip_hit* __restrict__ out,
+                                                           const uint32_t* __restrict__ gate) {
     const int t = (int)(blockIdx.x * 256 + threadIdx.x);
     if (t >= kpad) return;
+    if (gate != nullptr && *gate == 0u) return;
     wax_hip_hit h;
     h.key = (t < k) ? keys[t] : KEY_PAD;
     h.frame_id = ID_PAD;
@@ -944,26 +954,151 @@ __global__ __launch_bounds__(256) void keys_to_hits_kernel(const int64_t* __rest
 }
 
 hipError_t launch_select_general(const float* d_dist, uint32_t n_rows, uint32_t row_base, int k, int kpad,
-                                 const uint64_t* d_ids, const SelectWork& w, wax_hip_hit* d_out, hipStream_t st) {
+                                 const uint64_t* d_ids, const SelectWork& w, wax_hip_hit* d_out, hipStream_t st, const uint32_t* gate) {
     if (k < 1 || (uint32_t)k > n_rows || k > WAX_HIP_MAX_RESULTS || kpad < k) return hipErrorInvalidValue;
     int grid = (int)((n_rows + 255) / 256);
     if (grid > 2048) grid = 2048;
     for (int pass = 0; pass < SEL_PASSES; ++pass)
         hipLaunchKernelGGL(select_hist_kernel, dim3(grid), dim3(256), 0, st, d_dist, n_rows, row_base, pass, (uint32_t)k, w.state,
-                           w.hist, w.counter);
+                           w.hist, w.counter, gate);
     hipLaunchKernelGGL(select_compact_kernel, dim3(grid), dim3(256), 0, st, d_dist, n_rows, row_base, w.state,
-                       w.counter, w.keys_a, (uint32_t)k);
-    hipLaunchKernelGGL(rank_sort_kernel, dim3((k + 255) / 256), dim3(256), 0, st, w.keys_a, k, w.keys_b);
+                       w.counter, w.keys_a, (uint32_t)k, gate);
+    hipLaunchKernelGGL(rank_sort_kernel, dim3((k + 255) / 256), dim3(256), 0, st, w.keys_a, k, w.keys_b, gate);
     hipLaunchKernelGGL(keys_to_hits_kernel, dim3((kpad + 255) / 256), dim3(256), 0, st, w.keys_b, k, kpad, d_ids,
-                       row_base, n_rows, d_out);
+                       row_base, n_rows, d_out, gate);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Short selection (kernels.h: launch_select_short). One workgroup; the candidate lists are L2-resident (the scan in front of it
+// wrote them) and ascending. Steps:
+//   (1) S = the first p entries of every list (p = about twice the k / lists a list holds of the answer on average), sorted in LDS:
+//       its k-th smallest, U, is an upper bound of the k-th smallest candidate (S is a subset with at least k members) and a tight one —
+//       on a store whose best rows are spread over the workgroups it lies a few per cent of the candidates above the true k-th;
+//       unlike "the largest head" it stays tight when some workgroups hold no good row at all (sorted, clustered corpora);
+//   (2) every list's prefix <= U into LDS, eight independent loads at a time (a thread walking its list one load after the other
+//       would wait for L2 once per key): at least k keys, usually k + a few per cent;
+//   (3) bitonic sort in LDS: the first k are the answer;
+//   (4) certificate (per_list < k only): a full list dropped only keys above its last entry;
+//   (5) hits.
+// More prefix keys than the LDS buffer holds (the k best bunched in a few lists, deeper than p), fewer than k live candidates: the
+// launch fails (*flags = 1, nothing written) and the gated path behind it answers.
+constexpr int SHORT_THREADS = 1024;
+constexpr uint32_t SHORT_CAP = 16384;            // LDS buffer, keys (128 KB)
+__device__ inline void short_sort(int64_t* buf, uint32_t n_pow2, uint32_t tid) {
+    for (uint32_t size = 2; size <= n_pow2; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t i = tid; i < (n_pow2 >> 1); i += SHORT_THREADS) {
+                const uint32_t lo = ((i / stride) * (stride << 1)) + (i % stride), hi = lo + stride;
+                const int64_t a = buf[lo], b = buf[hi];
+                const bool up = (lo & size) == 0u;
+                if ((a > b) == up) { buf[lo] = b; buf[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+}
+__host__ __device__ inline uint32_t short_depth(uint32_t k, uint32_t lists, uint32_t per_list) {
+    uint32_t p = (2u * k + lists - 1) / lists;
+    p = p < 4u ? 4u : p;
+    return p > per_list ? per_list : p;
+}
+__global__ __launch_bounds__(SHORT_THREADS) void select_short_kernel(const int64_t* __restrict__ cand, uint32_t lists, uint32_t per_list,
+                                                                     uint32_t k, uint32_t kpad,
+                                                                     const uint64_t* __restrict__ ids, uint32_t row_base, uint32_t n_rows,
+                                                                     wax_hip_hit* __restrict__ out, uint32_t* __restrict__ flags) {
+    extern __shared__ __attribute__((aligned(16))) int64_t buf[];   // [SHORT_CAP]
+    __shared__ uint32_t s_fill, s_fail;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) { s_fail = 0u; s_fill = 0u; }
+    // (1)
+    const uint32_t p = short_depth(k, lists, per_list), ns = lists * p;   // ns <= SHORT_CAP (launch_select_short)
+    uint32_t sn = 256;
+    while (sn < ns) sn <<= 1;
+    for (uint32_t i = tid; i < sn; i += SHORT_THREADS) buf[i] = i < ns ? cand[(size_t)(i / p) * per_list + (i % p)] : KEY_PAD;
+    __syncthreads();
+    short_sort(buf, sn, tid);
+    const int64_t bound = k <= ns ? buf[k - 1] : KEY_PAD;      // KEY_PAD: fewer than k live entries in S — every live candidate is taken
+    __syncthreads();
+    // (2)
+    for (uint32_t w = tid; w < lists; w += SHORT_THREADS) {
+        const int64_t* __restrict__ lw = cand + (size_t)w * per_list;
+        bool more = true;
+        for (uint32_t base = 0; base < per_list && more; base += 8) {
+            int64_t v[8];
+#pragma unroll
+            for (uint32_t t = 0; t < 8; ++t) v[t] = base + t < per_list ? lw[base + t] : KEY_PAD;
+#pragma unroll
+            for (uint32_t t = 0; t < 8; ++t) {
+                if (more && v[t] != KEY_PAD && v[t] <= bound) {
+                    const uint32_t pos = atomicAdd(&s_fill, 1u);
+                    if (pos < SHORT_CAP) buf[pos] = v[t];
+                } else {
+                    more = false;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t c = s_fill;
+    if ((c < k || c > SHORT_CAP) && tid == 0) s_fail = 1u;
+    uint32_t sort_n = 256;
+    while (sort_n < c && sort_n < SHORT_CAP) sort_n <<= 1;
+    for (uint32_t i = c + tid; i < sort_n; i += SHORT_THREADS) buf[i] = KEY_PAD;
+    __syncthreads();
+    if (s_fail == 0u) {
+        short_sort(buf, sort_n, tid);                          // (3)
+        if (per_list < k) {                                    // (4)
+            const int64_t kth = buf[k - 1];
+            uint32_t bad = 0;
+            for (uint32_t w = tid; w < lists; w += SHORT_THREADS) {
+                const int64_t last = cand[(size_t)w * per_list + per_list - 1];
+                if (last != KEY_PAD && last < kth) bad = 1u;
+            }
+            if (bad) s_fail = 1u;
+        }
+        __syncthreads();
+    }
+    const bool fail = s_fail != 0u;
+    if (!fail) {
+        for (uint32_t t = tid; t < kpad; t += SHORT_THREADS) {
+            wax_hip_hit hit;
+            hit.key = t < k ? buf[t] : KEY_PAD;
+            hit.frame_id = ID_PAD;
+            if (hit.key != KEY_PAD) {
+                const uint32_t local = key_row(hit.key) - row_base;
+                hit.frame_id = (ids != nullptr && local < n_rows) ? ids[local] : (uint64_t)key_row(hit.key);
+            }
+            out[t] = hit;
+        }
+    }
+    if (tid == 0) { flags[0] = fail ? 1u : 0u; flags[1] += fail ? 1u : 0u; flags[2] += 1u; }
+}
+
+// whether the short selection is worth trying: S must fit the LDS buffer, and for k > per_list the lists must be able to hold the
+// answer with room to spare (k <= a third of a list per list on average)
+bool select_short_viable(int k, int lists, int per_list) {
+    if (lists <= 0 || k < 1 || per_list < 1) return false;
+    if ((uint64_t)lists * short_depth((uint32_t)k, (uint32_t)lists, (uint32_t)per_list) > SHORT_CAP) return false;
+    return k <= per_list || (int64_t)k * 3 <= (int64_t)lists * per_list;
+}
+
+hipError_t launch_select_short(const int64_t* d_cand, uint32_t lists, uint32_t per_list, int k, int kpad, const uint64_t* d_ids,
+                               uint32_t row_base, uint32_t n_rows, uint32_t* d_flags, wax_hip_hit* d_out, hipStream_t st) {
+    if (k < 1 || k > WAX_HIP_MAX_RESULTS || kpad < k || d_flags == nullptr || !select_short_viable(k, (int)lists, (int)per_list))
+        return hipErrorInvalidValue;
+    // (dynamic LDS of 128 KB: like the filtering GEMM's tile buffers, no attribute needed on this runtime)
+    hipLaunchKernelGGL(select_short_kernel, dim3(1), dim3(SHORT_THREADS), (size_t)SHORT_CAP * sizeof(int64_t), st, d_cand, lists, per_list,
+                       (uint32_t)k, (uint32_t)kpad, d_ids, row_base, n_rows, d_out, d_flags);
     return hipGetLastError();
 }
 
 hipError_t alloc_select_work(SelectWork* w) {
     hipError_t e = hipMalloc(&w->hist, (SEL_BINS + 1) * sizeof(uint32_t));           // bins + the arrival ticket
     if (e == hipSuccess) e = hipMemset(w->hist, 0, (SEL_BINS + 1) * sizeof(uint32_t));   // every pass leaves them zero again
-    if (e == hipSuccess) e = hipMalloc(&w->state, 4 * sizeof(uint64_t));
-    if (e == hipSuccess) e = hipMemset(w->state, 0, 4 * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMalloc(&w->state, 8 * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMemset(w->state, 0, 8 * sizeof(uint64_t));
+    if (e == hipSuccess) w->flags = reinterpret_cast<uint32_t*>(w->state + 4);
     if (e == hipSuccess) e = hipMalloc(&w->counter, sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&w->keys_a, (size_t)WAX_HIP_MAX_RESULTS * sizeof(int64_t));
     if (e == hipSuccess) e = hipMalloc(&w->keys_b, (size_t)WAX_HIP_MAX_RESULTS * sizeof(int64_t));
