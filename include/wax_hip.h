@@ -342,7 +342,8 @@ int wax_hip_stats(wax_hip_engine* e, wax_hip_stats_t* out);
  *   them in LDS and certifies that no workgroup dropped one of the answer — otherwise, on the device, the distance pass + radix
  *   selection behind it answers; 64 < top_k <= 192 on grids that do not merge in the scan kernel = the same workgroup is the final
  *   merge (nothing can have been dropped: no certificate), the wave-list merge stays behind it, gated; 0 = the long path / the wave-list
- *   merge at once; "force_general" implies 0 for top_k > 192), "short_selects" / "short_select_failures" (read-only: short selections
+ *   merge at once; 2 = like 1 with 192-entry lists whatever top_k (1 keeps 64-entry lists while top_k <= 8 per workgroup); "force_general"
+ *   implies 0 for top_k > 192), "short_selects" / "short_select_failures" (read-only: short selections
  *   enqueued / that left the answer to the launches behind them),
  *   "filter_device_min" (wax_hip_search_filtered: allow-lists at least this long are resolved by the id -> row table in HBM, default 4096; -1 = never).
  * batched queries (bf16 MFMA GEMM + fused selection + exact re-score; exact answers whatever the setting)

@@ -163,7 +163,8 @@ def test_short_selection_equals_the_long_path(wax, n, dims, metric):
         # (tried while the lists can hold the answer — k <= 64 per list on average —, their first 2k / lists entries fit the LDS buffer,
         # and the store has at least 256 rows per wanted key)
         ke = min(k, n)
-        viable = grid * min(192, max(4, -(-2 * ke // grid))) <= 16384 and 3 * ke <= grid * 192 and n >= 256 * ke
+        per_list = 64 if ke <= grid * 8 else 192
+        viable = grid * min(per_list, max(4, -(-2 * ke // grid))) <= 16384 and 3 * ke <= grid * per_list and n >= 256 * ke
         tried += viable
         eng.setTuning("select_short", 1)
         before, fails = eng.getTuning("short_selects"), eng.getTuning("short_select_failures")
@@ -178,8 +179,15 @@ def test_short_selection_equals_the_long_path(wax, n, dims, metric):
     assert tried >= (4 if n >= 1_048_576 else 3 if n >= 256_000 else 1), (grid, tried)
     eng.setTuning("select_short", 1)
     check(eng, metric, corpus, None, q[0], 300, "short selection against the oracle")
-    with pytest.raises(Exception):
+    eng.setTuning("select_short", 2)                       # 192-entry lists whatever k: the same hits again
+    for k in (193, 1000):
+        ia, sa = eng.searchArrays(q[0], k)
+        eng.setTuning("select_short", 1)
+        ib, sb = eng.searchArrays(q[0], k)
         eng.setTuning("select_short", 2)
+        assert np.array_equal(ia, ib) and np.array_equal(sa, sb)
+    with pytest.raises(Exception):
+        eng.setTuning("select_short", 3)
     eng.close()
 
 
