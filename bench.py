@@ -395,10 +395,13 @@ EVENT_MODE = "bound"     # --events: "bound" (default) = frac from kernel-bound 
 
 def kernel_bound_plausible(kb_ms, br_ms, floor_ms=0.0):
     """A kernel-bound interval is the bracketed one minus the packets around the kernel: never longer than it (2 % of jitter allowed),
-    not shorter by more than 40 us + 10 % (the packets cost ~10 us), never below a quarter of the bracket (short kernels: 0.9 x - 40 us
-    is negative under 44 us, which used to accept ANY positive interval — advisor, round 5) and never below `floor_ms`, the time the
-    launch's algorithmic bytes take at the peak rate. Anything else is a runtime that did not bind the pair."""
-    return (kb_ms == kb_ms and br_ms == br_ms and kb_ms > 0 and kb_ms <= br_ms * 1.02 + 0.002 and kb_ms >= br_ms * 0.9 - 0.04
+    not shorter by more than 40 us + 10 % (the packets cost ~10 us) — unless it still is at least `floor_ms`, the time the launch's
+    algorithmic bytes take at the peak rate (an unbound pair reports next to nothing, not a physically possible scan: the k > 192
+    queries' bracket carries 0.5 ms that neither rocprofv3's duration of the same dispatch nor the pipelined rate shows) —, never below a
+    quarter of the bracket (short kernels: 0.9 x - 40 us is negative under 44 us, which used to accept ANY positive interval —
+    advisor, round 5) and never below `floor_ms`. Anything else is a runtime that did not bind the pair."""
+    near_bracket = kb_ms >= br_ms * 0.9 - 0.04 or (floor_ms > 0.0 and kb_ms >= floor_ms)
+    return (kb_ms == kb_ms and br_ms == br_ms and kb_ms > 0 and kb_ms <= br_ms * 1.02 + 0.002 and near_bracket
             and kb_ms >= 0.25 * br_ms and kb_ms >= floor_ms)
 
 

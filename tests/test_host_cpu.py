@@ -435,6 +435,9 @@ def test_bench_line_carries_the_event_mode_and_the_bracketed_figure():
     # short kernels: a near-zero interval from a runtime that did not bind the pair is refused (relative floor), and so is one that
     # would put the launch above the peak rate (floor = algorithmic bytes / peak)
     assert not ok(0.0005, 0.0268) and not ok(0.006, 0.0268) and ok(0.0160, 0.0268, floor_ms=0.00192) and not ok(0.0160, 0.0268, floor_ms=0.02)
+    # a bracket that carries half a millisecond the dispatch does not (the k > 192 queries): the bound interval stands while it is
+    # physically possible (>= the bytes at the peak rate); without a floor the relative rule decides as before
+    assert ok(2.1914, 2.7638, floor_ms=1.92) and not ok(2.1914, 2.7638) and not ok(1.8, 2.7638, floor_ms=1.92) and not ok(0.6, 2.7638, floor_ms=0.5)
 
 
 def test_bench_secondary_watchdog_emits_the_headline_and_leaves(tmp_path):
