@@ -34,6 +34,13 @@ for a in ("one_process_2_shards.json", "one_process_n1.json", "pytest_gpu.log", 
           "fanout_ABC.jsonl", "gemm_s10m_k300_kernel_stats.csv", "gemm_s1m_k1000_kernel_stats.csv"):
     cp(a, "z_" + a)
 
+# the fuzz log: the first trials and the summary line (every trial is one line: 300 KB per run)
+fz = os.path.join(dst, "z_fuzz.txt")
+if os.path.exists(fz):
+    lines = open(fz).read().splitlines()
+    if len(lines) > 60:
+        open(fz, "w").write("\n".join(lines[:40] + [f"... {len(lines) - 41} more trials, one line each ..."] + lines[-1:]) + "\n")
+
 # one rocprofv3 row per GEMM workload
 rows = []
 for w, label in (("b1m_q256", "config 3: 1M x 384, Q = 256"), ("b1m_q1024", "1M x 384, Q = 1024"), ("c5_shard", "config 5 per-GPU part: 1.25M x 768, Q = 1024"),
