@@ -1004,15 +1004,15 @@ __host__ __device__ inline uint32_t short_depth(uint32_t k, uint32_t lists, uint
     return p > per_list ? per_list : p;
 }
 __global__ __launch_bounds__(SHORT_THREADS) void select_short_kernel(const int64_t* __restrict__ cand, uint32_t lists, uint32_t per_list,
-                                                                     uint32_t k, uint32_t kpad,
+                                                                     uint32_t k, uint32_t kpad, uint32_t cap,
                                                                      const uint64_t* __restrict__ ids, uint32_t row_base, uint32_t n_rows,
                                                                      wax_hip_hit* __restrict__ out, uint32_t* __restrict__ flags) {
-    extern __shared__ __attribute__((aligned(16))) int64_t buf[];   // [SHORT_CAP]
+    extern __shared__ __attribute__((aligned(16))) int64_t buf[];   // [cap] (a power of two, >= lists * p, <= SHORT_CAP)
     __shared__ uint32_t s_fill, s_fail;
     const uint32_t tid = threadIdx.x;
     if (tid == 0) { s_fail = 0u; s_fill = 0u; }
     // (1)
-    const uint32_t p = short_depth(k, lists, per_list), ns = lists * p;   // ns <= SHORT_CAP (launch_select_short)
+    const uint32_t p = short_depth(k, lists, per_list), ns = lists * p;   // ns <= cap (launch_select_short)
     uint32_t sn = 256;
     while (sn < ns) sn <<= 1;
     for (uint32_t i = tid; i < sn; i += SHORT_THREADS) buf[i] = i < ns ? cand[(size_t)(i / p) * per_list + (i % p)] : KEY_PAD;
@@ -1032,7 +1032,7 @@ __global__ __launch_bounds__(SHORT_THREADS) void select_short_kernel(const int64
             for (uint32_t t = 0; t < 8; ++t) {
                 if (more && v[t] != KEY_PAD && v[t] <= bound) {
                     const uint32_t pos = atomicAdd(&s_fill, 1u);
-                    if (pos < SHORT_CAP) buf[pos] = v[t];
+                    if (pos < cap) buf[pos] = v[t];
                 } else {
                     more = false;
                 }
@@ -1041,9 +1041,9 @@ __global__ __launch_bounds__(SHORT_THREADS) void select_short_kernel(const int64
     }
     __syncthreads();
     const uint32_t c = s_fill;
-    if ((c < k || c > SHORT_CAP) && tid == 0) s_fail = 1u;
+    if ((c < k || c > cap) && tid == 0) s_fail = 1u;
     uint32_t sort_n = 256;
-    while (sort_n < c && sort_n < SHORT_CAP) sort_n <<= 1;
+    while (sort_n < c && sort_n < cap) sort_n <<= 1;
     for (uint32_t i = c + tid; i < sort_n; i += SHORT_THREADS) buf[i] = KEY_PAD;
     __syncthreads();
     if (s_fail == 0u) {
@@ -1087,9 +1087,15 @@ hipError_t launch_select_short(const int64_t* d_cand, uint32_t lists, uint32_t p
                                uint32_t row_base, uint32_t n_rows, uint32_t* d_flags, wax_hip_hit* d_out, hipStream_t st) {
     if (k < 1 || k > WAX_HIP_MAX_RESULTS || kpad < k || d_flags == nullptr || !select_short_viable(k, (int)lists, (int)per_list))
         return hipErrorInvalidValue;
-    // (dynamic LDS of 128 KB: like the filtering GEMM's tile buffers, no attribute needed on this runtime)
-    hipLaunchKernelGGL(select_short_kernel, dim3(1), dim3(SHORT_THREADS), (size_t)SHORT_CAP * sizeof(int64_t), st, d_cand, lists, per_list,
-                       (uint32_t)k, (uint32_t)kpad, d_ids, row_base, n_rows, d_out, d_flags);
+    // LDS buffer: room for S and for four times the answer (prefixes are the answer plus a few per cent on ordinary stores), a power of
+    // two, at most 128 KB — a small one finds a CU beside the filtering GEMM's workgroups (100 KB at 384-d) when batches are in flight;
+    // prefixes that overflow it leave the answer to the gated launches behind. (Dynamic LDS beyond 64 KB: like the GEMM's tile
+    // buffers, no attribute needed on this runtime.)
+    const uint32_t ns = lists * short_depth((uint32_t)k, lists, per_list);
+    uint32_t cap = 2048;
+    while (cap < SHORT_CAP && (cap < ns || cap < 4u * (uint32_t)k)) cap <<= 1;
+    hipLaunchKernelGGL(select_short_kernel, dim3(1), dim3(SHORT_THREADS), (size_t)cap * sizeof(int64_t), st, d_cand, lists, per_list,
+                       (uint32_t)k, (uint32_t)kpad, cap, d_ids, row_base, n_rows, d_out, d_flags);
     return hipGetLastError();
 }
 
