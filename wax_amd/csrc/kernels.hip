@@ -985,18 +985,35 @@ hipError_t launch_select_general(const float* d_dist, uint32_t n_rows, uint32_t 
 // launch fails (*flags = 1, nothing written) and the gated path behind it answers.
 constexpr int SHORT_THREADS = 1024;
 constexpr uint32_t SHORT_CAP = 16384;            // LDS buffer, keys (128 KB)
+// Bitonic sort of n_pow2 >= 2048 keys in LDS by SHORT_THREADS threads. A wave owns n_pow2 / 16 consecutive keys: every step whose
+// stride stays inside that segment needs no workgroup barrier, only the wave's own LDS order (at 2 048 keys 56 of the 66 steps) —
+// with one compare-exchange per thread and step the barriers were most of the kernel.
 __device__ inline void short_sort(int64_t* buf, uint32_t n_pow2, uint32_t tid) {
+    const uint32_t seg = n_pow2 / (SHORT_THREADS / 64);          // keys per wave, a power of two >= 128
+    const uint32_t wave = tid >> 6, lane = tid & 63u, base = wave * seg;
     for (uint32_t size = 2; size <= n_pow2; size <<= 1) {
         for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-            for (uint32_t i = tid; i < (n_pow2 >> 1); i += SHORT_THREADS) {
-                const uint32_t lo = ((i / stride) * (stride << 1)) + (i % stride), hi = lo + stride;
-                const int64_t a = buf[lo], b = buf[hi];
-                const bool up = (lo & size) == 0u;
-                if ((a > b) == up) { buf[lo] = b; buf[hi] = a; }
+            if (stride < seg) {                                    // inside the wave's own segment
+                for (uint32_t j = lane; j < (seg >> 1); j += 64) {
+                    const uint32_t lo = base + ((j / stride) * (stride << 1)) + (j % stride), hi = lo + stride;
+                    const int64_t a = buf[lo], b = buf[hi];
+                    const bool up = (lo & size) == 0u;
+                    if ((a > b) == up) { buf[lo] = b; buf[hi] = a; }
+                }
+                wave_lds_fence();
+            } else {
+                for (uint32_t i = tid; i < (n_pow2 >> 1); i += SHORT_THREADS) {
+                    const uint32_t lo = ((i / stride) * (stride << 1)) + (i % stride), hi = lo + stride;
+                    const int64_t a = buf[lo], b = buf[hi];
+                    const bool up = (lo & size) == 0u;
+                    if ((a > b) == up) { buf[lo] = b; buf[hi] = a; }
+                }
+                __syncthreads();
             }
-            __syncthreads();
         }
+        if (size >= seg) __syncthreads();                          // the next size starts with a stride that leaves the segments
     }
+    __syncthreads();
 }
 __host__ __device__ inline uint32_t short_depth(uint32_t k, uint32_t lists, uint32_t per_list) {
     uint32_t p = (2u * k + lists - 1) / lists;
@@ -1013,7 +1030,7 @@ __global__ __launch_bounds__(SHORT_THREADS) void select_short_kernel(const int64
     if (tid == 0) { s_fail = 0u; s_fill = 0u; }
     // (1)
     const uint32_t p = short_depth(k, lists, per_list), ns = lists * p;   // ns <= cap (launch_select_short)
-    uint32_t sn = 256;
+    uint32_t sn = 2048;
     while (sn < ns) sn <<= 1;
     for (uint32_t i = tid; i < sn; i += SHORT_THREADS) buf[i] = i < ns ? cand[(size_t)(i / p) * per_list + (i % p)] : KEY_PAD;
     __syncthreads();
@@ -1042,7 +1059,7 @@ __global__ __launch_bounds__(SHORT_THREADS) void select_short_kernel(const int64
     __syncthreads();
     const uint32_t c = s_fill;
     if ((c < k || c > cap) && tid == 0) s_fail = 1u;
-    uint32_t sort_n = 256;
+    uint32_t sort_n = 2048;
     while (sort_n < c && sort_n < cap) sort_n <<= 1;
     for (uint32_t i = c + tid; i < sort_n; i += SHORT_THREADS) buf[i] = KEY_PAD;
     __syncthreads();
