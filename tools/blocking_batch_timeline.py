@@ -21,6 +21,7 @@ def main():
     p.add_argument("--k", type=int, default=10)
     p.add_argument("--calls", type=int, default=200)
     p.add_argument("--tune", action="append", default=[])
+    p.add_argument("--host", action="store_true", help="host-pointer form (searchBatchHits: queries uploaded, hits downloaded by the library)")
     a = p.parse_args()
     import torch
     dev = torch.device("cuda", 0)
@@ -35,12 +36,19 @@ def main():
         eng.searchBatchHitsDevice(dq.data_ptr(), a.nq, a.k, out.data_ptr(), a.k, st)
     torch.cuda.synchronize()
     per = []
+    hq = dq.cpu().numpy() if a.host else None
+    if a.host:
+        for _ in range(5):
+            eng.searchBatchHits(hq, a.k)
     for _ in range(a.calls):
         t0 = time.perf_counter()
-        eng.searchBatchHitsDevice(dq.data_ptr(), a.nq, a.k, out.data_ptr(), a.k, st)
+        if a.host:
+            eng.searchBatchHits(hq, a.k)
+        else:
+            eng.searchBatchHitsDevice(dq.data_ptr(), a.nq, a.k, out.data_ptr(), a.k, st)
         per.append((time.perf_counter() - t0) * 1e6)
     per = np.array(per)
-    print(f"blocking call, {a.rows} x {a.dims}, {a.nq} queries, tunes {a.tune}: mean {per.mean():.1f} us  median {np.median(per):.1f}  p10 {np.percentile(per, 10):.1f}  min {per.min():.1f}", flush=True)
+    print(f"blocking {'host-pointer' if a.host else 'device-resident'} call, {a.rows} x {a.dims}, {a.nq} queries, tunes {a.tune}: mean {per.mean():.1f} us  median {np.median(per):.1f}  p10 {np.percentile(per, 10):.1f}  min {per.min():.1f}", flush=True)
     eng.close()
 
 
