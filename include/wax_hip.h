@@ -366,7 +366,9 @@ int wax_hip_stats(wax_hip_engine* e, wax_hip_stats_t* out);
  *   split-barrier wait timed out (its workgroup's queries take the exact path), 65536 = the device-side retry re-scores every
  *   survivor; any other bit is refused), "batch_prof_ptr" (diagnosis: device address of a [256 x 8][20] u32 buffer — the filtering GEMM at
  *   D = 384 / 768 then runs its phase-timing build, which leaves per-wave s_memtime cycle counts there, same answers, ~10 % slower;
- *   0 (default) = the product kernel; tools/gemm_phase_budget.py).
+ *   0 (default) = the product kernel; tools/gemm_phase_budget.py),
+ *   "batch_in_wait" (device-resident batches: 0 (default) = the library's stream is ordered behind the caller's `stream` by an event
+ *   only while that stream still has work pending — a drained stream costs no marker / barrier packet; 1 = always, as before round 6).
  * get-only
  *   "variant_count", "scan_grid", "store_ptr" (device address of the f32 slab), "fused_max_k", "batch_queries", "query_args_scans", "merged_scans", "done_flag_waits",
  *   "batch_inline_retries", "batch_max_row_err_e9", "batch_fallbacks", "onepass_queries", "batch_max_k", "batch_retries",

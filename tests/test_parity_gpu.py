@@ -2186,6 +2186,42 @@ def test_search_batch_hits_device_resident(wax):
         empty.searchBatchHitsDevice(0, 4, 10, 0, 10)
 
 
+def test_device_resident_batch_waits_for_a_busy_caller_stream_only(wax):
+    """The library's stream is ordered behind the caller's `stream` while that stream still has work pending — here milliseconds
+    of matrix products in front of the copy that produces the queries — and skips the event when the stream has drained
+    ("batch_in_wait" 0, the default; 1 = always record + wait). Both settings, busy and idle stream: the host-pointer call's hits."""
+    import torch
+    dev = torch.device("cuda", 0)
+    dims, n, nq, k = 384, 120_000, 256, 10
+    corpus = oracle.gaussian_unit_rows(77, n, dims)
+    eng = make_engine(wax, 0, dims, corpus, np.arange(n, dtype=np.uint64) + 5)
+    queries = oracle.gaussian_unit_queries(nq, dims, seed=41)
+    ref, _ = eng.searchBatchHits(queries, k)
+    good = torch.from_numpy(np.ascontiguousarray(queries)).to(dev)
+    a = torch.randn((4096, 4096), device=dev)
+    torch.cuda.synchronize()
+    st = torch.cuda.current_stream(dev)
+    assert eng.getTuning("batch_in_wait") == 0
+    for mode in (0, 1, 0):
+        eng.setTuning("batch_in_wait", mode)
+        for busy in (True, False, True):
+            dq = torch.full((nq, dims), float("nan"), device=dev)
+            out = torch.zeros((nq, k, 2), dtype=torch.int64, device=dev)
+            torch.cuda.synchronize()
+            if busy:
+                b = a
+                for _ in range(12):
+                    b = torch.mm(b, a) * 1e-3                      # a few milliseconds on the caller's stream ...
+                dq.copy_(good, non_blocking=True)                # ... in front of the copy that produces the queries
+                assert not st.query()                            # still pending when the library is called
+            else:
+                dq.copy_(good)
+                torch.cuda.synchronize()
+            eng.searchBatchHitsDevice(dq.data_ptr(), nq, k, out.data_ptr(), k, st.cuda_stream)
+            assert np.array_equal(out.cpu().numpy(), ref), (mode, busy)
+    eng.close()
+
+
 def test_concurrent_batched_searches_share_the_mirror(wax):
     """Batched searches are re-entrant like every other read entry point: four threads batch-search at once (pooled
     per-call workspaces, one shared bf16 mirror), interleaved with single-query searches and a writer."""

@@ -5,6 +5,7 @@
 # one-process shape of bench.py (two shards on one GPU), the N > 1 rehearsal of tools/scale_matrix.sh on one GPU, the full GPU suite,
 # smoke, fuzz, blocking C latency, the filtering GEMM's phase budget. Counter passes are counters only (--pmc with --kernel-trace).
 #   gpurun --timeout 5400 -- 'WAX_TAG=r06_final bash tools/sessions/final.sh'
+# WAX_SHORT=1: correctness + the bench records + the rocprofv3 rows of the headline and of configs 3 / 5 only (about 17 minutes).
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/${WAX_TAG:-final}
@@ -32,10 +33,17 @@ timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --detail-out "$OUT/be
 echo "driver-style rc $? bytes $(wc -c < "$OUT/bench_driver_style.json")" >> "$OUT/bench_n1.rc"
 # 2. rocprofv3 summaries
 stats headline_chained python "$R/bench.py" --gpus 1 --steps 200 --warmup 20 --no-cpu-baseline --no-secondary --chain-timed-region --detail-out "$OUT/headline_chained_detail.json"
-stats default_cmd python "$R/bench.py" --gpus 1 --no-cpu-baseline --detail-out "$OUT/default_cmd_detail.json"
-for w in b1m_q256 b1m_q1024 c5_shard c5_full clustered_k100 s10m_k300 s1m_k1000; do
+[ -z "${WAX_SHORT:-}" ] && stats default_cmd python "$R/bench.py" --gpus 1 --no-cpu-baseline --detail-out "$OUT/default_cmd_detail.json"
+WORKLOADS="b1m_q256 b1m_q1024 c5_shard c5_full clustered_k100 s10m_k300 s1m_k1000"
+[ -n "${WAX_SHORT:-}" ] && WORKLOADS="b1m_q256 c5_shard"
+for w in $WORKLOADS; do
   stats gemm_$w python "$R/bench.py" --gpus 1 --steps 40 --warmup 8 --no-cpu-baseline --secondary $w --detail-out "$OUT/gemm_${w}_detail.json"
 done
+if [ -n "${WAX_SHORT:-}" ]; then
+  timeout 200 python tools/fuzz_select.py --seconds 100 --seed 17 > "$OUT/fuzz_select.txt" 2>&1
+  for r in 1 2; do python tools/blocking_batch_timeline.py --calls 400; done 2>/dev/null > "$OUT/blocking_call.txt"
+  ls -la "$OUT" > "$OUT/listing.txt"; tail -4 "$OUT/pytest_gpu.log"; cat "$OUT/bench_n1.json"; exit 0
+fi
 # 3. counters
 pmc fetch_headline FETCH_SIZE python "$R/bench.py" --gpus 1 --steps 20 --warmup 2 --no-cpu-baseline --no-secondary --detail-out "$OUT/fetch_headline_detail.json"
 pmc fetch_768_shard FETCH_SIZE python "$R/tools/batch_bench.py" --dims 768 --rows 1250000 --nq 1024 --reps 2
