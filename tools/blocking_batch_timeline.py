@@ -21,6 +21,7 @@ def main():
     p.add_argument("--k", type=int, default=10)
     p.add_argument("--calls", type=int, default=200)
     p.add_argument("--tune", action="append", default=[])
+    p.add_argument("--pinned", action="store_true", help="with --host: the queries come from pinned host memory")
     p.add_argument("--host", action="store_true", help="host-pointer form (searchBatchHits: queries uploaded, hits downloaded by the library)")
     a = p.parse_args()
     import torch
@@ -37,6 +38,9 @@ def main():
     torch.cuda.synchronize()
     per = []
     hq = dq.cpu().numpy() if a.host else None
+    if a.host and a.pinned:
+        keep = dq.cpu().pin_memory()
+        hq = keep.numpy()
     if a.host:
         for _ in range(5):
             eng.searchBatchHits(hq, a.k)
@@ -48,6 +52,8 @@ def main():
             eng.searchBatchHitsDevice(dq.data_ptr(), a.nq, a.k, out.data_ptr(), a.k, st)
         per.append((time.perf_counter() - t0) * 1e6)
     per = np.array(per)
+    worst = np.argsort(per)[::-1][:5]
+    print("slowest calls (index: us): " + ", ".join(f"{int(i)}: {per[i]:.0f}" for i in worst), flush=True)
     print(f"blocking {'host-pointer' if a.host else 'device-resident'} call, {a.rows} x {a.dims}, {a.nq} queries, tunes {a.tune}: mean {per.mean():.1f} us  median {np.median(per):.1f}  p10 {np.percentile(per, 10):.1f}  min {per.min():.1f}", flush=True)
     eng.close()
 
