@@ -354,7 +354,7 @@ int wax_hip_stats(wax_hip_engine* e, wax_hip_stats_t* out);
  *   "batch_rega" (1 (default) = the register-resident-queries GEMM with a workgroup barrier per tile; 5 = the same with the split
  *   tile barrier (round 5's default); 0 = the LDS-tiled GEMM only), "batch_dyn_tail" (1 (default) = with up to 256 queries per pass the workgroups of the
  *   filtering GEMM claim the last twelfth of the store's tiles from a pool, so the launch ends within one tile of every workgroup; 0 = fixed shares), "batch_onepass" (0 = always the slab pipeline), "batch_onepass_tiles" (smallest store, in
- *   units of 64 rows — 32 at D = 768 —, that the one-pass pipeline takes; default 1024), "batch_survivors" (floor of the expected survivors per query as a
+ *   units of 64 rows — 32 at D = 768 —, that the one-pass pipeline takes; default 64 = 4 096 rows (1024 before round 6), at least 32), "batch_survivors" (floor of the expected survivors per query as a
  *   multiple of k', default 3), "batch_sample_div" (1 / this of the tiles are sampled for the thresholds, default 32),
  *   "batch_retry" (an uncertified query gets ALL of its survivors re-scored before the exact path: 1 (default) = by a device-side
  *   kernel while "retry_hint" > 0 — armed for 16 batches by any such query, settable 0..1024 — and from the host for what is left;

@@ -734,9 +734,15 @@ def test_batch_edge_shapes(wax):
     eng = make_engine(wax, 0, dims, corpus)
     for nq, k in [(16, 10), (17, 1), (130, 30), (1029, 10), (64, 80)]:
         _batch_vs_single(eng, oracle.gaussian_unit_queries(nq, dims, seed=100 + nq), k)
-    # k above the MFMA limit and batches below batch_min fall back to pipelined single-query scans
+    # k above the slab pipeline's limit: the one-pass pipeline takes it since round 6 (30 000 rows >= 64 units of 64 rows) ...
     before = eng.getTuning("batch_queries")
     _batch_vs_single(eng, oracle.gaussian_unit_queries(20, dims), 100)
+    assert eng.getTuning("batch_queries") == before + 20
+    # ... with the old floor (65 536 rows) it falls back to pipelined single-query scans, and so do batches below batch_min
+    eng.setTuning("batch_onepass_tiles", 1024)
+    before = eng.getTuning("batch_queries")
+    _batch_vs_single(eng, oracle.gaussian_unit_queries(20, dims), 100)
+    eng.setTuning("batch_onepass_tiles", 64)
     eng.setTuning("batch_min", 16)
     _batch_vs_single(eng, oracle.gaussian_unit_queries(5, dims), 10)
     assert eng.getTuning("batch_queries") == before
@@ -2186,6 +2192,36 @@ def test_search_batch_hits_device_resident(wax):
         empty.searchBatchHitsDevice(0, 4, 10, 0, 10)
 
 
+@pytest.mark.parametrize("dims,n", [(384, 4_096), (384, 9_000), (384, 33_333), (768, 2_100), (768, 20_000), (128, 60_000)])
+def test_small_stores_take_the_one_pass_pipeline(wax, dims, n):
+    """Since round 6 the one-pass MFMA pipeline (sample -> thresholds -> filtering GEMM -> finish) answers stores from 64 units of 64
+    rows (32 at D = 768) up instead of from 65 536 rows ("batch_onepass_tiles", default 64): top_k 10 / 100 / 300 and a ragged batch
+    equal the single-query answers bit for bit, the one-pass counter says which pipeline ran, and the old floor (slab pipeline, or one
+    scan per query beyond its top_k limit) gives the same hits."""
+    corpus = oracle.gaussian_unit_rows(n % 89, n, dims)
+    eng = make_engine(wax, 0, dims, corpus, np.arange(n, dtype=np.uint64) * 7 + 2)
+    assert eng.getTuning("batch_onepass_tiles") == 64
+    queries = oracle.gaussian_unit_queries(77, dims, seed=n % 31)
+    for k in (10, 100, 300):
+        o0 = eng.getTuning("onepass_queries")
+        hits, counts = eng.searchBatchHits(queries, k)
+        took = eng.getTuning("onepass_queries") - o0       # (a top_k that needs a quarter of a tiny store as candidates is not planned)
+        assert took == len(queries) or (k > 10 and took == 0 and n < 30_000), (dims, n, k, took)
+        for i in (0, 5, 38, 76):
+            s_ids, s_scores = eng.searchArrays(queries[i], k)
+            b_ids, b_scores = wax.HIPVectorEngine.hitsToResults(wax.VectorMetric.cosine, hits[i, :counts[i]])
+            assert np.array_equal(b_ids, s_ids) and np.array_equal(b_scores, s_scores), (dims, n, k, i)
+        eng.setTuning("batch_onepass_tiles", 1024)
+        o0 = eng.getTuning("onepass_queries")
+        old_hits, old_counts = eng.searchBatchHits(queries, k)
+        assert eng.getTuning("onepass_queries") == o0
+        assert np.array_equal(old_hits, hits) and np.array_equal(old_counts, counts), (dims, n, k)
+        eng.setTuning("batch_onepass_tiles", 64)
+    with pytest.raises(wax.WaxError):
+        eng.setTuning("batch_onepass_tiles", 31)
+    eng.close()
+
+
 def test_device_resident_batch_waits_for_a_busy_caller_stream_only(wax):
     """The library's stream is ordered behind the caller's `stream` while that stream still has work pending — here milliseconds
     of matrix products in front of the copy that produces the queries — and skips the event when the stream has drained
@@ -2608,7 +2644,7 @@ def test_certificate_bound_survives_aligned_rounding_errors(wax):
     queries[17] = a
     for onepass in (0, 1):
         eng.setTuning("batch_onepass", onepass)
-        eng.setTuning("batch_onepass_tiles", 1024)
+        eng.setTuning("batch_onepass_tiles", 64 if onepass else 1024)      # (40 000 rows: the one-pass pipeline really runs)
         for k in (1, 5):
             ids, scores, counts = eng.searchBatch(queries, k)
             for i in range(len(queries)):

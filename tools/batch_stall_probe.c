@@ -2,7 +2,7 @@
  * per-call latency, the slowest calls and their indices — does the 37-43 ms call that tools/blocking_batch_timeline.py --host
  * sees at a fixed call index belong to the library (or to HIP under it) or to the Python / torch process around it?
  *   gcc -O2 -Iinclude tools/batch_stall_probe.c -o /tmp/batch_stall_probe -Lwax_amd/lib -lwaxhip -Wl,-rpath,$PWD/wax_amd/lib -lm
- *   /tmp/batch_stall_probe [rows=1000000] [dims=384] [nq=256] [calls=600] */
+ *   /tmp/batch_stall_probe [rows=1000000] [dims=384] [nq=256] [calls=600] [batch_onepass_tiles] [top_k=10] */
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -25,7 +25,7 @@ static float rnd(void) {   /* sum of four uniforms, centred: close enough to a G
 
 int main(int argc, char** argv) {
     const int n = argc > 1 ? atoi(argv[1]) : 1000000, dims = argc > 2 ? atoi(argv[2]) : 384, nq = argc > 3 ? atoi(argv[3]) : 256;
-    const int calls = argc > 4 ? atoi(argv[4]) : 600, k = 10;
+    const int calls = argc > 4 ? atoi(argv[4]) : 600, k = argc > 6 ? atoi(argv[6]) : 10;
     if (!wax_hip_available()) { printf("{\"error\": \"no gfx950 device\"}\n"); return 0; }
     lcg = 99;
     wax_hip_engine* e = NULL;
@@ -43,6 +43,7 @@ int main(int argc, char** argv) {
         }
         if (wax_hip_add_batch(e, ids, rows, (uint64_t)m, (uint32_t)dims)) { printf("{\"error\": \"%s\"}\n", wax_hip_last_error()); return 1; }
     }
+    if (argc > 5 && wax_hip_set_tuning(e, "batch_onepass_tiles", atoi(argv[5]))) { printf("{\"error\": \"%s\"}\n", wax_hip_last_error()); return 1; }
     float* q = malloc((size_t)nq * dims * sizeof(float));
     for (size_t i = 0; i < (size_t)nq * dims; ++i) q[i] = rnd();
     wax_hip_hit* hits = malloc((size_t)nq * k * sizeof(wax_hip_hit));
@@ -67,8 +68,8 @@ int main(int argc, char** argv) {
     }
     double sum = 0.0;
     for (int i = 0; i < calls; ++i) sum += lat[i];
-    printf("{\"tool\": \"batch_stall_probe\", \"rows\": %d, \"dims\": %d, \"nq\": %d, \"calls\": %d, \"mean_us\": %.1f, \"slowest\": [[%d, %.0f], [%d, %.0f], [%d, %.0f], [%d, %.0f]], ",
-           n, dims, nq, calls, sum / calls, w[0], lat[w[0]], w[1], lat[w[1]], w[2], lat[w[2]], w[3], lat[w[3]]);
+    printf("{\"tool\": \"batch_stall_probe\", \"rows\": %d, \"dims\": %d, \"nq\": %d, \"calls\": %d, \"top_k\": %d, \"onepass_tiles\": %d, \"onepass_queries\": %lld, \"mean_us\": %.1f, \"slowest\": [[%d, %.0f], [%d, %.0f], [%d, %.0f], [%d, %.0f]], ",
+           n, dims, nq, calls, k, (int)wax_hip_get_tuning(e, "batch_onepass_tiles"), (long long)wax_hip_get_tuning(e, "onepass_queries"), sum / calls, w[0], lat[w[0]], w[1], lat[w[1]], w[2], lat[w[2]], w[3], lat[w[3]]);
     qsort(lat, (size_t)calls, sizeof(double), cmp);
     printf("\"median_us\": %.1f, \"p99_us\": %.1f, \"mixed_hits\": %u}\n", lat[calls / 2], lat[(int)(calls * 0.99)], counts[0]);
     wax_hip_engine_destroy(e);

@@ -23,6 +23,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=120.0)
 ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--sharded", type=float, default=0.0, help="probability of also checking a sharded handle (shards on GPU 0)")
+ap.add_argument("--rows-min", type=int, default=20_000)
+ap.add_argument("--rows-max", type=int, default=400_000, help="80 %% of the stores have rows-min .. rows-max rows, the others up to 3 x rows-max")
+ap.add_argument("--tune", action="append", default=[], help="KEY=VALUE set on every engine")
 args = ap.parse_args()
 rng = np.random.default_rng(args.seed)
 dev = torch.device("cuda", 0)
@@ -31,7 +34,7 @@ t_end = time.time() + args.seconds
 trials = checked = fallbacks = onepass_q = retries = sharded_trials = 0
 while time.time() < t_end:
     dims = int(rng.choice([128, 256, 384, 512, 768, 192]))
-    n = int(rng.integers(20_000, 400_000)) if rng.random() < 0.8 else int(rng.integers(400_000, 1_200_000))   # (the larger ones: a tail pool at one query group)
+    n = int(rng.integers(args.rows_min, args.rows_max)) if rng.random() < 0.8 else int(rng.integers(args.rows_max, 3 * args.rows_max))   # (the larger ones: a tail pool at one query group)
     metric = int(rng.choice([0, 0, 1, 2]))
     k = int(rng.choice([1, 5, 10, 30, 64, 100, 200, 300, 460]))
     nq = int(rng.choice([16, 17, 64, 255, 256, 257, 300, 700, 1024, 1500]))
@@ -49,6 +52,8 @@ while time.time() < t_end:
         x[n // 2:n // 2 + 500] = x[7]
         x = x * (0.5 + torch.rand((n, 1), generator=g, device=dev))
     eng = wax.HIPVectorEngine(metric=wax.VectorMetric(metric), dimensions=dims)
+    for kv in args.tune:
+        eng.setTuning(kv.split("=", 1)[0], int(kv.split("=", 1)[1]))
     eng.reserve(n)
     eng.addBatchDevice(np.arange(n, dtype=np.uint64) * 3 + 1, x.contiguous())
     row_base = int(rng.integers(0, 1 << 20)) if rng.random() < 0.5 else 0
@@ -73,6 +78,8 @@ while time.time() < t_end:
     if args.sharded > 0 and rng.random() < args.sharded and k <= 1000:
         shards = int(rng.choice([2, 3, 5]))
         many = wax.HIPVectorEngine(metric=wax.VectorMetric(metric), dimensions=dims, devices=[0] * shards)
+        for kv in args.tune:
+            many.setTuning(kv.split("=", 1)[0], int(kv.split("=", 1)[1]))
         many.reserve(n)
         many.addBatchDevice(np.arange(n, dtype=np.uint64) * 3 + 1, x.contiguous())
         h_one, c_one = eng.searchBatchHits(qh, k) if row_base == 0 else (None, None)
