@@ -47,7 +47,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md: ~2.
 CORPUS_SEED = 20260220
 QUERY_SEED = 7
 GRANULE = 65536
-SECONDARY_N1 = ["s10k", "s1m", "s1250k", "s10m_k300", "s1m_k1000", "b1m_q256", "b1m_q1024", "c5_shard", "c5_full", "clustered_k10", "clustered_k100", "dups17", "detembed"]
+SECONDARY_N1 = ["s10k", "s1m", "s1250k", "s10m_k300", "s1m_k1000", "b30k_k100", "b1m_q256", "b1m_q1024", "c5_shard", "c5_full", "clustered_k10", "clustered_k100", "dups17", "detembed"]
 DUP_ROWS, DUP_AT, DUP_OF, DUP_QUERIES = 2048, 500_000, 7, 44    # the "dups17" corpus: 2048 copies of row 7; 44 of 256 queries (17 %) aim at it
 
 
@@ -944,7 +944,7 @@ def batch_queries(torch, dev, nq, dims, corpus, eng_rows=None):
     return q
 
 
-def secondary_batched(torch, dev, rows, dims, nq, k, steps, warmup, label, row_base=0, corpus="gaussian"):
+def secondary_batched(torch, dev, rows, dims, nq, k, steps, warmup, label, row_base=0, corpus="gaussian", live_traffic=True):
     """BASELINE configs 3 / 5: nq queries per step as a bf16 MFMA GEMM + fused top-k + exact f32 re-score. Queries and
     results stay in HBM (wax_hip_search_batch_submit_device / _collect_device): the timed region holds no host<->device
     traffic except nq certificate flags per step."""
@@ -1022,7 +1022,7 @@ def secondary_batched(torch, dev, rows, dims, nq, k, steps, warmup, label, row_b
     eng.setTuning("time_kernels", 0)
     flops, floor_s, rf = batched_roofline(rows, dims, nq, kern_ms, launches, int(eng.getTuning("batch_rega")))
     rf["events"], rf["kernel_avg_ms_bracketed"] = events, br_ms
-    want_live = True                          # roofline.traffic of the filtering GEMM is measured below (child counter pass)
+    want_live = live_traffic                  # roofline.traffic of the filtering GEMM is measured below (child counter pass)
     res = {
         "config": label,
         "value": nq * steps / el, "unit": "queries/s", "steps": steps, "warmup": warmup, "ms_per_step": el / steps * 1e3,
@@ -1576,6 +1576,11 @@ def main():
                                                             "1M rows at top-1000 = Wax.search(topK: 334 ...): general selection"),
                 "s1250k": lambda: secondary_single_query(torch, dev, 1_250_000, 384, k, max(s, 600), max(w, 50), args.depth,
                                                          "the headline's per-GPU shard at 8 GPUs (10M / 8 rows): what one rank of BASELINE config 4 scans per query"),
+                # a store of the size Wax's own harness uses, at the top_k Wax.search(topK: 34 ...) requests: the one-pass pipeline since
+                # round 6 (one scan per query before: 8 ms per batch); latency-bound — see blocking_ms
+                "b30k_k100": lambda: secondary_batched(torch, dev, 30_000, 384, 256, 100, max(s, 200), max(w, 20),
+                                                       "30000 x 384 (a Wax-sized store), 256 queries per step, cosine top-100, one-pass bf16 MFMA pipeline, "
+                                                       "queries and results resident in HBM", live_traffic=False),
                 "b1m_q256": lambda: secondary_batched(torch, dev, 1_000_000, 384, 256, k, max(s, 200), max(w, 20),
                                                       "1000000 x 384, 256 queries per step, cosine top-10, bf16 MFMA GEMM + fused top-k, 1 GPU "
                                                       "(BASELINE config 3), queries and results resident in HBM, batches in flight: see batches_in_flight"),
