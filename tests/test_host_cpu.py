@@ -588,3 +588,20 @@ def test_bench_counter_passes_are_bounded():
         got, note = bench.live_traffic(1000, 384, 10)                   # returns at once, nothing is launched
         assert got is None and "disabled" in note
 
+
+
+def test_every_tuning_key_is_documented_in_the_header():
+    """include/wax_hip.h is the only interface: every key wax_hip_set_tuning / wax_hip_get_tuning accept (tuning.inc, and the sharded
+    handle's own keys in sharded.inc) is named in its comment block — a key a maintainer cannot find does not exist."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = ""
+    for name in ("tuning.inc", "sharded.inc"):
+        with open(os.path.join(root, "wax_amd", "csrc", name)) as f:
+            src += f.read()
+    keys = sorted(set(re.findall(r'k == "([a-z0-9_]+)"', src)))
+    assert len(keys) >= 60
+    with open(os.path.join(root, "include", "wax_hip.h")) as f:
+        header = f.read()
+    missing = [k for k in keys if f'"{k}"' not in header]
+    assert not missing, missing
