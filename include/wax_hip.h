@@ -367,6 +367,9 @@ int wax_hip_stats(wax_hip_engine* e, wax_hip_stats_t* out);
  *   survivor; any other bit is refused), "batch_prof_ptr" (diagnosis: device address of a [256 x 8][20] u32 buffer — the filtering GEMM at
  *   D = 384 / 768 then runs its phase-timing build, which leaves per-wave s_memtime cycle counts there, same answers, ~10 % slower;
  *   0 (default) = the product kernel; tools/gemm_phase_budget.py),
+ *   "batch_host_multi" (host-pointer batches of at least 16 queries that the MFMA pipelines do not take — top_k 81 .. 192 on a store below
+ *   the one-pass floor, "batch_mode" 0 —: 1 (default) = up to 16 queries share one exact pass over the f32 store, bit-identical to the
+ *   single-query kernel; 0 = one scan per query),
  *   "batch_in_wait" (device-resident batches: 0 (default) = the library's stream is ordered behind the caller's `stream` by an event
  *   only while that stream still has work pending — a drained stream costs no marker / barrier packet; 1 = always, as before round 6).
  * get-only

@@ -2222,6 +2222,34 @@ def test_small_stores_take_the_one_pass_pipeline(wax, dims, n):
     eng.close()
 
 
+def test_host_pointer_batches_outside_the_mfma_pipelines_share_exact_passes(wax):
+    """A host-pointer batch of at least 16 queries that no MFMA pipeline takes (top_k 100 on a store below the one-pass floor;
+    "batch_mode" 0) is answered by shared exact passes — 16 queries per pass over the f32 store, the single-query kernel's arithmetic —
+    instead of one scan per query ("batch_host_multi", default 1): the single-query hits bit for bit, the pass counter moves, and
+    the per-query loop ("batch_host_multi" 0) returns the same."""
+    dims, n = 384, 3_000
+    corpus = oracle.gaussian_unit_rows(5, n, dims)
+    eng = make_engine(wax, 0, dims, corpus, np.arange(n, dtype=np.uint64) * 3 + 9)
+    queries = oracle.gaussian_unit_queries(41, dims, seed=19)
+    assert eng.getTuning("batch_host_multi") == 1
+    for mode, k in ((1, 100), (1, 192), (0, 10), (0, 100)):                  # (batch_mode, top_k)
+        eng.setTuning("batch_mode", mode)
+        p0, b0 = eng.getTuning("batch_multi_passes"), eng.getTuning("batch_queries")
+        hits, counts = eng.searchBatchHits(queries, k)
+        assert eng.getTuning("batch_multi_passes") - p0 == 3 and eng.getTuning("batch_queries") == b0, (mode, k)   # 41 queries = 3 passes
+        for i in (0, 15, 16, 40):
+            s_ids, s_scores = eng.searchArrays(queries[i], k)
+            b_ids, b_scores = wax.HIPVectorEngine.hitsToResults(wax.VectorMetric.cosine, hits[i, :counts[i]])
+            assert np.array_equal(b_ids, s_ids) and np.array_equal(b_scores, s_scores), (mode, k, i)
+        eng.setTuning("batch_host_multi", 0)
+        p0 = eng.getTuning("batch_multi_passes")
+        loop_hits, loop_counts = eng.searchBatchHits(queries, k)
+        assert eng.getTuning("batch_multi_passes") == p0
+        assert np.array_equal(loop_hits, hits) and np.array_equal(loop_counts, counts), (mode, k)
+        eng.setTuning("batch_host_multi", 1)
+    eng.close()
+
+
 def test_device_resident_batch_waits_for_a_busy_caller_stream_only(wax):
     """The library's stream is ordered behind the caller's `stream` while that stream still has work pending — here milliseconds
     of matrix products in front of the copy that produces the queries — and skips the event when the stream has drained
